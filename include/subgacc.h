@@ -1,0 +1,172 @@
+/*
+ * subgacc.h -- C ABI of the MI355X-native SubGAcc hot path (libsubgacc_hip.so, gfx950).
+ *
+ * This is the drop-in boundary for the SUREL+ path
+ *     sample (random-walk node sets + landing-probability counts)  ->  SpG  ->  SpJoin.
+ * Every entry point names the reference interface it replaces (paths relative to the reference
+ * tree, Graph-COM/SUREL_Plus).  The reference binds its C half through a CPython module
+ * (`subg_acc`, subg_acc/subg_acc.c:1036-1059) and runs SpJoin in SciPy (train.py:13-111); the host
+ * mirror of both lives in surel_plus_amd/ and is a thin ctypes layer over the functions below.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / numpy / HIP types in any signature.
+ *   - every pointer is a DEVICE pointer (HBM) unless its name ends in `_host`.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and nothing
+ *     synchronises unless the function says so.  No allocation happens inside: scratch comes
+ *     from the caller (`*_workspace_bytes`), so calls are graph-capturable.
+ *   - return value: SUBGACC_OK or a negative subgacc_status; subgacc_last_error() gives the text
+ *     (thread local).
+ *   - node ids are int32 (the reference is int32-only, subg_acc.c:663-676); CSR row offsets may be
+ *     int32 or int64 (`indptr64`), SpG row offsets are always int64.
+ */
+#ifndef SUBGACC_H
+#define SUBGACC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SUBGACC_ABI_VERSION 1
+
+typedef enum subgacc_status {
+    SUBGACC_OK = 0,
+    SUBGACC_ERR_BADARG = -1,    /* TypeError("Input parsing error.") territory, subg_acc.c:658 */
+    SUBGACC_ERR_WORKSPACE = -2, /* caller's scratch too small (the reference's MemoryError paths) */
+    SUBGACC_ERR_KEYWIDTH = -3,  /* m*SHIFT+1 > 64: AssertionError, subg_acc.c:905-915 */
+    SUBGACC_ERR_CAPACITY = -4,  /* unique-row table full: retry with a larger one */
+    SUBGACC_ERR_HIP = -5,       /* a HIP runtime call failed */
+    SUBGACC_ERR_LDS = -6,       /* M*m+1 too large for the per-root LDS tables */
+    SUBGACC_ERR_NODEVICE = -7   /* no gfx950 device visible */
+} subgacc_status;
+
+enum { SUBGACC_RNG_RAND_R = 0, /* glibc rand_r stream, bit-exact with the reference at nthread=1 */
+       SUBGACC_RNG_PHILOX = 1  /* Philox4x32-10 keyed by (seed, root id, walk, step): schedule independent */ };
+enum { SUBGACC_ORDER_WALK_MAJOR = 0, /* set_sampler's first-visit order, subg_acc.c:785-832 */
+       SUBGACC_ORDER_STEP_MAJOR = 1  /* rpe_encoder's first-visit order, subg_acc.c:263-278 */ };
+
+int subgacc_abi_version(void);
+const char *subgacc_last_error(void);
+/* number of visible HIP devices whose arch is gfx950 (0 => every compute call fails loudly) */
+int subgacc_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Sampler: walks + per-root node-set dedup + landing-probability counts.
+ * Replaces the hot loop of set_sampler (subg_acc.c:742-846), random_walk (:144-180),
+ * random_walk_wo (:183-247) and rpe_encoder (:249-314).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct subgacc_walk_cfg {
+    int32_t num_walks;       /* M                                                             */
+    int32_t num_steps;       /* m = hops per walk (gset_sampler's num_steps; CLI --num_steps-1) */
+    int32_t bucket;          /* cap on the set size; <=0 => M*m+1 (subg_acc.c:680)              */
+    int32_t rng_mode;        /* SUBGACC_RNG_*                                                   */
+    uint32_t seed;
+    int32_t first_hop_wo;    /* 1: first hop without replacement (set_sampler, random_walk_wo)  */
+    int32_t order;           /* SUBGACC_ORDER_*                                                 */
+    int32_t cap_root_degree; /* 1: clamp the root degree to 1e6 (NEBMAX, subg_acc.c:750)        */
+    int32_t indptr64;        /* CSR row offsets are int64 (else int32)                          */
+    int32_t emit_walks;      /* 1: also write raw walks int32[n, M*(m+1)] (walk_sampler)        */
+} subgacc_walk_cfg;
+
+/* LP rows are carried as one packed 64-bit key: count of step j in bits [(m-j)*SHIFT, +SHIFT),
+ * SHIFT = 32-clz(M), plus bit m*SHIFT (LEAD) on the root row -- the reference's `bithash`
+ * (subg_acc.c:900-955).  Returns SHIFT, or SUBGACC_ERR_KEYWIDTH. */
+int subgacc_key_shift(int32_t num_walks, int32_t num_steps);
+
+/* RAND_R mode only: per-root position in the sequential rand_r stream.  The reference consumes
+ * calls(r) = (deg>M ? M : 0) + M*(m-1) draws per non-isolated root (first_hop_wo) or M*m
+ * (plain walks), in root order; stream t of `rng_streams` owns libgomp's static chunk t of the n
+ * roots and starts from seed+t (subg_acc.c:157-158,191-192; one stream for set_sampler :731-732).
+ * Writes rng_pos[i] (LCG steps before root i, mod 2^32) and rng_seed[i].
+ * `calls_before` = draws consumed before query[0] (for sharded / chunked callers). */
+size_t subgacc_rng_positions_workspace_bytes(int64_t n);
+int subgacc_rng_positions(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *query, int64_t n,
+                          int32_t rng_streams, uint64_t calls_before, uint32_t *rng_pos, uint32_t *rng_seed,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* Sample n roots.  Outputs per root i, at fixed offsets i*stride (stride = bucket or M*m+1):
+ *   set_ids [n*stride] int32   members in first-visit order (root first)
+ *   set_keys[n*stride] uint64  packed LP row of each member
+ *   nsize   [n]        int32   set size (<= stride)
+ *   walks   [n*M*(m+1)] int32  (emit_walks only, else NULL)
+ *   flags   [4]        int32   [0] |= 1 when RAND_R mode met a dead end (degree-0 non-root: the call
+ *                              count is then data dependent and the stream cannot be reproduced in
+ *                              parallel); [1] += roots whose set overflowed `bucket`.  Caller zeroes.
+ * rng_pos / rng_seed: from subgacc_rng_positions (RAND_R) or NULL (PHILOX). */
+int subgacc_walk_sets(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,
+                      const int32_t *query, int64_t n, const uint32_t *rng_pos, const uint32_t *rng_seed,
+                      int32_t *set_ids, uint64_t *set_keys, int32_t *nsize, int32_t *walks, int32_t *flags,
+                      void *stream);
+
+/* Exclusive scan int32 -> int64, out[n] = total.  (Prefix of nsize, subg_acc.c:848-851.) */
+size_t subgacc_scan_workspace_bytes(int64_t n);
+int subgacc_exclusive_scan_i32(const int32_t *in, int64_t n, int64_t *out, void *workspace, size_t workspace_bytes,
+                               void *stream);
+
+/* Left-compact the strided per-root sets (subg_acc.c:870-871): row i goes to [row_off[i], +nsize[i]). */
+int subgacc_compact_sets(const int32_t *set_ids, const uint64_t *set_keys, const int32_t *nsize,
+                         const int64_t *row_off, int64_t n, int32_t stride, int32_t *out_ids, uint64_t *out_keys,
+                         void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Global first-occurrence dedup of LP rows (subg_acc.c:957-978): key -> index in order of first
+ * appearance over the concatenated sets.  Open-addressing table in HBM, `capacity` a power of two.
+ * ------------------------------------------------------------------------------------------- */
+size_t subgacc_uniq_table_bytes(int64_t capacity);
+int subgacc_uniq_reset(void *table, int64_t capacity, void *stream);
+/* insert keys[0..n) whose global element positions are tag_base+0..n-1 (the position the element will
+ * have in the `keys` array later handed to subgacc_uniq_number); flags[2] |= 1 on a full table */
+int subgacc_uniq_insert(void *table, int64_t capacity, const uint64_t *keys, int64_t n, int64_t tag_base,
+                        int32_t *flags, void *stream);
+/* number the distinct keys by first occurrence and translate every element:
+ *   out_sf[e]   int32  index of keys[e]'s row (remap[1] of the reference)
+ *   out_ukeys[] uint64 the distinct keys in index order (at most max_unique are written)
+ *   out_count   int64  number of distinct keys (device scalar) */
+size_t subgacc_uniq_number_workspace_bytes(int64_t n);
+int subgacc_uniq_number(void *table, int64_t capacity, const uint64_t *keys, int64_t n, int32_t *out_sf,
+                        uint64_t *out_ukeys, int64_t max_unique, int64_t *out_count, void *workspace,
+                        size_t workspace_bytes, void *stream);
+
+/* Unpack keys to LP rows [n, m+1]: col 0 = M on LEAD rows else 0 (subg_acc.c:751,982-1000).
+ * out_i16 / out_i32 / out_f32 may each be NULL; out_f32 is float(count)/float(M) (main.py:174) and,
+ * with zero_row != 0, gets an all-zero row prepended (random_walks.py:81) => [n+1, m+1]. */
+int subgacc_unpack_lp(const uint64_t *keys, int64_t n, int32_t num_walks, int32_t num_steps, int16_t *out_i16,
+                      int32_t *out_i32, float *out_f32, int32_t zero_row, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SpG build (sampler/random_walks.py:79-80: scipy COO->CSR): sort each row's members by node id.
+ *   out_indices[X] int32 sorted ids, out_data[X] int32 = sf+1.  max_len >= max nsize; a longer row is
+ *   left unwritten and flags[3] |= 1 (flags: the int32[4] word array of subgacc_walk_sets).
+ * ------------------------------------------------------------------------------------------- */
+int subgacc_spg_build(const int64_t *row_off, int64_t n, const int32_t *ids, const int32_t *sf, int32_t max_len,
+                      int32_t *out_indices, int32_t *out_data, int32_t *flags, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SpJoin (train.py:13-45 gather, :48-72 hgather, :75-111 bgather/pgather).
+ * A join is a list of S segments (own[j], partner[j]) of SpG row numbers: segment j emits one row
+ * per member w of row own[j] in ascending id order with the pair
+ *     ( value_own(w), value_partner(w) or 0 ).
+ * gather(edge[2,B]):  own = [u..,v..], partner = [v..,u..];  hgather: [u,w,v,w] / [w,u,w,v].
+ * ------------------------------------------------------------------------------------------- */
+/* out_seg[S+1] int64 = exclusive scan of the segment sizes (`indptr` of train.py:20-22) */
+size_t subgacc_sjoin_workspace_bytes(int64_t S);
+int subgacc_sjoin_sizes(const int64_t *spg_indptr, const int64_t *own, int64_t S, int64_t *out_seg, void *workspace,
+                        size_t workspace_bytes, void *stream);
+/* Fill R = out_seg[S] rows.
+ *   spg_data_i32 (payload = SFptr+1) xor spg_data_f64 (PPR payload, train.py:39-43)
+ *   table f32 [table_rows, k] (Z_SF with the zero row) or NULL
+ *   out_xz   f32  [R,2,k] = table[pair] (int payload)  |  [R,2,1] = float(pair) (f64 payload)
+ *   out_idx  i32  [R,2]  the raw index pairs (optional, int payload only)
+ *   out_segid i64 [R]    segment id of every row (`ptr=False`, train.py:25-30) (optional)
+ * max_len >= longest SpG row touched (a longer partner row sets flags[3] |= 1 and its segment is skipped). */
+int subgacc_sjoin_fill(const int64_t *spg_indptr, const int32_t *spg_indices, const int32_t *spg_data_i32,
+                       const double *spg_data_f64, const int64_t *own, const int64_t *partner, int64_t S,
+                       const int64_t *seg, const float *table, int64_t table_rows, int32_t k, float *out_xz,
+                       int32_t *out_idx, int64_t *out_segid, int32_t max_len, int32_t *flags, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUBGACC_H */

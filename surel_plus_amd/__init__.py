@@ -1,0 +1,12 @@
+"""surel_plus_amd -- MI355X-native SubGAcc hot path of SUREL+ (sample -> SpG -> SpJoin).
+
+Host mirror of the reference's interfaces over a C-ABI HIP library (include/subgacc.h):
+    subg_acc.gset_sampler / walk_sampler   <- subg_acc/subg_acc.c (CPython module `subg_acc`)
+    spg.subg_matrix, spg.SpG               <- sampler/random_walks.py:74-82
+    spjoin.gather / pgather / bgather / hgather  <- train.py:13-111
+"""
+from ._lib import SubgAccError, build  # noqa: F401
+from .sampler import DeviceCSR, SampledSets, sample_sets  # noqa: F401
+from .spg import SpG, subg_matrix  # noqa: F401
+from .spjoin import bgather, gather, hgather, pgather, sjoin  # noqa: F401
+from .subg_acc import gset_sampler, walk_sampler  # noqa: F401

@@ -1,0 +1,134 @@
+"""ctypes binding of libsubgacc_hip.so (the C ABI declared in include/subgacc.h).
+
+There is no CPU fallback: if the library is missing, or no gfx950 device is visible when a compute entry
+point is called, this module raises.  Error codes map onto the exceptions the reference raises for the
+same condition (subg_acc/subg_acc.c:658, :688-721, :905-915).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsubgacc_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+OK, ERR_BADARG, ERR_WORKSPACE, ERR_KEYWIDTH, ERR_CAPACITY, ERR_HIP, ERR_LDS, ERR_NODEVICE = 0, -1, -2, -3, -4, -5, -6, -7
+RNG_RAND_R, RNG_PHILOX = 0, 1
+ORDER_WALK_MAJOR, ORDER_STEP_MAJOR = 0, 1
+
+# every symbol include/subgacc.h declares (tests check the built library exports all of them)
+SYMBOLS = (
+    "subgacc_abi_version", "subgacc_last_error", "subgacc_device_count", "subgacc_key_shift",
+    "subgacc_rng_positions_workspace_bytes", "subgacc_rng_positions", "subgacc_walk_sets",
+    "subgacc_scan_workspace_bytes", "subgacc_exclusive_scan_i32", "subgacc_compact_sets",
+    "subgacc_uniq_table_bytes", "subgacc_uniq_reset", "subgacc_uniq_insert",
+    "subgacc_uniq_number_workspace_bytes", "subgacc_uniq_number", "subgacc_unpack_lp", "subgacc_spg_build",
+    "subgacc_sjoin_workspace_bytes", "subgacc_sjoin_sizes", "subgacc_sjoin_fill",
+)
+
+
+class WalkCfg(C.Structure):
+    """struct subgacc_walk_cfg"""
+    _fields_ = [("num_walks", C.c_int32), ("num_steps", C.c_int32), ("bucket", C.c_int32), ("rng_mode", C.c_int32),
+                ("seed", C.c_uint32), ("first_hop_wo", C.c_int32), ("order", C.c_int32),
+                ("cap_root_degree", C.c_int32), ("indptr64", C.c_int32), ("emit_walks", C.c_int32)]
+
+
+class SubgAccError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def build(force=False):
+    """hipcc-compile csrc/*.hip for gfx950 into surel_plus_amd/libsubgacc_hip.so (in-tree)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "subgacc.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", CSRC, "-j4", "all"])
+    return LIB_PATH
+
+
+def lib():
+    """Load the library (after torch, so that both bind the same libamdhip64 runtime instance)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  -- torch's bundled libamdhip64.so.7 must be the one already in the process
+    if not os.path.exists(LIB_PATH):
+        raise SubgAccError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           f"(or `make -C surel_plus_amd/csrc`). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_size_t
+    cfgp = C.POINTER(WalkCfg)
+    sig = {
+        "subgacc_abi_version": (C.c_int, []),
+        "subgacc_last_error": (C.c_char_p, []),
+        "subgacc_device_count": (C.c_int, []),
+        "subgacc_key_shift": (C.c_int, [i32, i32]),
+        "subgacc_rng_positions_workspace_bytes": (sz, [i64]),
+        "subgacc_rng_positions": (C.c_int, [cfgp, vp, vp, i64, i32, u64, vp, vp, vp, sz, vp]),
+        "subgacc_walk_sets": (C.c_int, [cfgp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "subgacc_scan_workspace_bytes": (sz, [i64]),
+        "subgacc_exclusive_scan_i32": (C.c_int, [vp, i64, vp, vp, sz, vp]),
+        "subgacc_compact_sets": (C.c_int, [vp, vp, vp, vp, i64, i32, vp, vp, vp]),
+        "subgacc_uniq_table_bytes": (sz, [i64]),
+        "subgacc_uniq_reset": (C.c_int, [vp, i64, vp]),
+        "subgacc_uniq_insert": (C.c_int, [vp, i64, vp, i64, i64, vp, vp]),
+        "subgacc_uniq_number_workspace_bytes": (sz, [i64]),
+        "subgacc_uniq_number": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, vp, vp, sz, vp]),
+        "subgacc_unpack_lp": (C.c_int, [vp, i64, i32, i32, vp, vp, vp, i32, vp]),
+        "subgacc_spg_build": (C.c_int, [vp, i64, vp, vp, i32, vp, vp, vp, vp]),
+        "subgacc_sjoin_workspace_bytes": (sz, [i64]),
+        "subgacc_sjoin_sizes": (C.c_int, [vp, vp, i64, vp, vp, sz, vp]),
+        "subgacc_sjoin_fill": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, i32, vp, vp]),
+    }
+    assert set(sig) == set(SYMBOLS)
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    if L.subgacc_abi_version() != 1:
+        raise SubgAccError("libsubgacc_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc):
+    """Turn a negative subgacc_status into the exception the reference raises for that condition."""
+    if rc >= 0:
+        return rc
+    msg = lib().subgacc_last_error().decode("utf-8", "replace")
+    if rc == ERR_BADARG:
+        raise TypeError(f"Input parsing error. ({msg})")
+    if rc == ERR_WORKSPACE:
+        raise MemoryError(msg)
+    if rc == ERR_KEYWIDTH:
+        raise AssertionError(msg)
+    if rc == ERR_LDS:
+        raise ValueError(msg)
+    raise SubgAccError(f"subgacc status {rc}: {msg}")
+
+
+def require_device():
+    """Fail loudly unless a gfx950 GPU is usable from this process."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SubgAccError("no HIP device visible: the SubGAcc hot path only runs on MI355X (gfx950); "
+                           "there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device pointer of a torch tensor (None -> NULL)"""
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor expected"
+    return C.c_void_p(t.data_ptr())

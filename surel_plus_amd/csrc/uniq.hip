@@ -1,0 +1,253 @@
+// uniq.hip -- global first-occurrence dedup of packed LP rows (gfx950).
+//
+// Replaces the serial uthash pass of set_sampler (reference subg_acc/subg_acc.c:957-978): every set member's
+// 64-bit LP key is mapped to the index of its first occurrence over the concatenated sets, and the distinct
+// rows are emitted in that order (subg_acc.c:982-1000).  A sequential "have I seen this key" loop becomes:
+//   1. insert: open-addressing table in HBM, key -> min element position (global atomicMin).  The number of
+//      distinct LP rows is tiny next to the number of members (493x..19527x compression in the paper), so
+//      the table is L2-resident and a coherent load in front of the atomic skips almost all of them.
+//   2. number: an element is a "first occurrence" iff the table's min position is its own; an exclusive scan
+//      of those flags in element order IS the reference's numbering.  No sort.
+//   3. translate: every element reads its key's number.
+#include "common.hpp"
+#include "blockscan.hpp"
+
+namespace subgacc {
+
+constexpr uint64_t kEmptyKey = ~0ull;
+constexpr int kUniqItems = 4;  // elements per thread in the numbering passes
+constexpr int kUniqTile = kScanThreads * kUniqItems;
+
+struct UniqTable {
+    unsigned long long *keys;    // [cap]
+    unsigned long long *mintag;  // [cap]
+    int32_t *id;                 // [cap]
+    uint64_t mask;
+};
+
+__host__ __device__ inline UniqTable uniq_view(void *table, int64_t cap) {
+    UniqTable t;
+    t.keys = (unsigned long long *)table;
+    t.mintag = t.keys + cap;
+    t.id = (int32_t *)(t.mintag + cap);
+    t.mask = (uint64_t)cap - 1;
+    return t;
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+
+__global__ void uniq_reset_kernel(UniqTable t, int64_t cap) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) {
+        t.keys[i] = kEmptyKey;
+        t.mintag[i] = ~0ull;
+        t.id[i] = -1;
+    }
+}
+
+__global__ __launch_bounds__(256) void uniq_insert_kernel(UniqTable t, const uint64_t *__restrict__ keys, int64_t n,
+                                                           int64_t tag_base, int32_t *flags) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const unsigned long long key = keys[e];
+    const unsigned long long tag = (unsigned long long)(tag_base + e);
+    uint64_t h = mix64(key) & t.mask;
+    bool found = false;
+    for (uint64_t probes = 0; probes <= t.mask; ++probes) {
+        // agent-scope (L2) load: another CU may have claimed the slot; its L1 copy here could be stale
+        unsigned long long cur = __hip_atomic_load(&t.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == kEmptyKey) cur = atomicCAS(&t.keys[h], kEmptyKey, key);
+        if (cur == kEmptyKey || cur == key) {
+            found = true;
+            break;
+        }
+        h = (h + 1) & t.mask;
+    }
+    if (!found) {
+        atomicOr(&flags[2], 1);
+        return;
+    }
+    // min position; the coherent pre-check removes nearly every atomic once the early positions are in
+    if (__hip_atomic_load(&t.mintag[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > tag) atomicMin(&t.mintag[h], tag);
+}
+
+__device__ __forceinline__ int32_t uniq_find(const UniqTable &t, unsigned long long key) {
+    uint64_t h = mix64(key) & t.mask;
+    while (t.keys[h] != key) h = (h + 1) & t.mask;  // the key was inserted by an earlier launch
+    return (int32_t)h;
+}
+
+// pass A: remember each element's table slot (in out_sf, reused as scratch) and count first occurrences per tile
+__global__ __launch_bounds__(kScanThreads) void uniq_count_kernel(UniqTable t, const uint64_t *__restrict__ keys,
+                                                                   int64_t n, int32_t *__restrict__ slot,
+                                                                   int32_t *__restrict__ tile_count) {
+    const int64_t base = (int64_t)blockIdx.x * kUniqTile;
+    int32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kUniqItems; ++k) {
+        const int64_t e = base + (int64_t)k * kScanThreads + threadIdx.x;
+        if (e < n) {
+            const int32_t h = uniq_find(t, keys[e]);
+            slot[e] = h;
+            cnt += (t.mintag[h] == (unsigned long long)e) ? 1 : 0;
+        }
+    }
+    int32_t tot;
+    block_exclusive_scan<int32_t>(cnt, &tot);
+    if (threadIdx.x == 0) tile_count[blockIdx.x] = tot;
+}
+
+// pass B: number the first occurrences in element order
+__global__ __launch_bounds__(kScanThreads) void uniq_assign_kernel(UniqTable t, const uint64_t *__restrict__ keys,
+                                                                    int64_t n, const int32_t *__restrict__ slot,
+                                                                    const int64_t *__restrict__ tile_off,
+                                                                    uint64_t *__restrict__ out_ukeys,
+                                                                    int64_t max_unique, int64_t *out_count) {
+    const int64_t base = (int64_t)blockIdx.x * kUniqTile;
+    int64_t run = tile_off[blockIdx.x];
+    for (int k = 0; k < kUniqItems; ++k) {
+        const int64_t e = base + (int64_t)k * kScanThreads + threadIdx.x;
+        int32_t h = -1, flag = 0;
+        if (e < n) {
+            h = slot[e];
+            flag = (t.mintag[h] == (unsigned long long)e) ? 1 : 0;
+        }
+        int32_t tot;
+        const int32_t ex = block_exclusive_scan<int32_t>(flag, &tot);
+        if (flag) {
+            const int64_t id = run + ex;
+            t.id[h] = (int32_t)id;
+            if (id < max_unique) out_ukeys[id] = keys[e];
+        }
+        run += tot;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *out_count = run;
+}
+
+// pass C: element -> number of its key
+__global__ __launch_bounds__(256) void uniq_translate_kernel(UniqTable t, int64_t n, int32_t *__restrict__ sf) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n) sf[e] = t.id[sf[e]];
+}
+
+__global__ void set_i64_kernel(int64_t *p, int64_t v) { *p = v; }
+
+template <typename OutI>
+__device__ __forceinline__ void unpack_row(unsigned long long key, int M, int m, int shift, OutI *row) {
+    const unsigned long long fmask = (1ull << shift) - 1ull;
+    row[0] = (OutI)(((key >> (m * shift)) & 1ull) ? M : 0);
+    for (int j = 1; j <= m; ++j) row[j] = (OutI)((key >> ((m - j) * shift)) & fmask);
+}
+
+__global__ __launch_bounds__(256) void unpack_lp_kernel(const uint64_t *__restrict__ keys, int64_t n, int M, int m,
+                                                         int shift, int16_t *o16, int32_t *o32, float *of32,
+                                                         int zero_row) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ncol = m + 1;
+    if (of32 && zero_row && e < ncol) of32[e] = 0.0f;
+    if (e >= n) return;
+    const unsigned long long key = keys[e];
+    if (o16) unpack_row<int16_t>(key, M, m, shift, o16 + e * ncol);
+    if (o32) unpack_row<int32_t>(key, M, m, shift, o32 + e * ncol);
+    if (of32) {
+        float *row = of32 + (e + (zero_row ? 1 : 0)) * ncol;
+        const unsigned long long fmask = (1ull << shift) - 1ull;
+        const float fm = (float)M;
+        row[0] = (((key >> (m * shift)) & 1ull) ? fm : 0.0f) / fm;
+        for (int j = 1; j <= m; ++j) row[j] = (float)((key >> ((m - j) * shift)) & fmask) / fm;
+    }
+}
+
+}  // namespace subgacc
+
+using namespace subgacc;
+
+static bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
+
+extern "C" size_t subgacc_uniq_table_bytes(int64_t capacity) {
+    if (capacity <= 0) return 0;
+    return (size_t)capacity * (8 + 8 + 4);
+}
+
+extern "C" int subgacc_uniq_reset(void *table, int64_t capacity, void *stream) {
+    SG_REQUIRE(table && is_pow2(capacity) && capacity < (1ll << 31), SUBGACC_ERR_BADARG,
+               "uniq_reset: capacity must be a power of two below 2^31");
+    hipLaunchKernelGGL(uniq_reset_kernel, dim3((unsigned)ceil_div(capacity, 256)), dim3(256), 0, (hipStream_t)stream,
+                       uniq_view(table, capacity), capacity);
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}
+
+extern "C" int subgacc_uniq_insert(void *table, int64_t capacity, const uint64_t *keys, int64_t n, int64_t tag_base,
+                                   int32_t *flags, void *stream) {
+    SG_REQUIRE(table && is_pow2(capacity) && capacity < (1ll << 31) && flags && n >= 0 && tag_base >= 0,
+               SUBGACC_ERR_BADARG, "uniq_insert: bad arguments");
+    if (n == 0) return SUBGACC_OK;
+    SG_REQUIRE(keys, SUBGACC_ERR_BADARG, "uniq_insert: null keys");
+    const int64_t blocks = ceil_div(n, 256);
+    SG_REQUIRE(blocks < (1ll << 31), SUBGACC_ERR_BADARG, "uniq_insert: split the call (n too large)");
+    hipLaunchKernelGGL(uniq_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       uniq_view(table, capacity), keys, n, tag_base, flags);
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}
+
+extern "C" size_t subgacc_uniq_number_workspace_bytes(int64_t n) {
+    if (n < 0) n = 0;
+    const int64_t tiles = ceil_div(n > 0 ? n : 1, kUniqTile);
+    return align_up((size_t)tiles * 4, 256) + align_up((size_t)(tiles + 1) * 8, 256) + scan_workspace_bytes(tiles);
+}
+
+extern "C" int subgacc_uniq_number(void *table, int64_t capacity, const uint64_t *keys, int64_t n, int32_t *out_sf,
+                                   uint64_t *out_ukeys, int64_t max_unique, int64_t *out_count, void *workspace,
+                                   size_t workspace_bytes, void *stream) {
+    SG_REQUIRE(table && is_pow2(capacity) && capacity < (1ll << 31) && out_count && n >= 0 && max_unique >= 0,
+               SUBGACC_ERR_BADARG, "uniq_number: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (n == 0) {
+        hipLaunchKernelGGL(set_i64_kernel, dim3(1), dim3(1), 0, s, out_count, (int64_t)0);
+        SG_LAUNCH_CHECK();
+        return SUBGACC_OK;
+    }
+    SG_REQUIRE(keys && out_sf && (out_ukeys || max_unique == 0), SUBGACC_ERR_BADARG, "uniq_number: null argument");
+    SG_REQUIRE(workspace && workspace_bytes >= subgacc_uniq_number_workspace_bytes(n), SUBGACC_ERR_WORKSPACE,
+               "uniq_number: workspace too small");
+    const int64_t tiles = ceil_div(n, kUniqTile);
+    SG_REQUIRE(tiles < (1ll << 31), SUBGACC_ERR_BADARG, "uniq_number: n too large");
+    char *ws = (char *)workspace;
+    int32_t *tile_count = (int32_t *)ws;
+    ws += align_up((size_t)tiles * 4, 256);
+    int64_t *tile_off = (int64_t *)ws;
+    ws += align_up((size_t)(tiles + 1) * 8, 256);
+    UniqTable t = uniq_view(table, capacity);
+    hipLaunchKernelGGL(uniq_count_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, t, keys, n, out_sf, tile_count);
+    SG_LAUNCH_CHECK();
+    int rc = exclusive_scan_i32(tile_count, tiles, tile_off, ws, workspace_bytes - (size_t)(ws - (char *)workspace), s);
+    if (rc != SUBGACC_OK) return rc;
+    hipLaunchKernelGGL(uniq_assign_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, t, keys, n,
+                       (const int32_t *)out_sf, (const int64_t *)tile_off, out_ukeys, max_unique, out_count);
+    SG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(uniq_translate_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, t, n, out_sf);
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}
+
+extern "C" int subgacc_unpack_lp(const uint64_t *keys, int64_t n, int32_t num_walks, int32_t num_steps,
+                                 int16_t *out_i16, int32_t *out_i32, float *out_f32, int32_t zero_row, void *stream) {
+    const int shift = subgacc_key_shift(num_walks, num_steps);
+    if (shift < 0) return shift;
+    SG_REQUIRE(n >= 0 && (keys || n == 0), SUBGACC_ERR_BADARG, "unpack_lp: bad arguments");
+    const int64_t work = n > (num_steps + 1) ? n : (num_steps + 1);  // the zero row is written by the first threads
+    if (n == 0 && !(out_f32 && zero_row)) return SUBGACC_OK;
+    hipLaunchKernelGGL(unpack_lp_kernel, dim3((unsigned)ceil_div(work, 256)), dim3(256), 0, (hipStream_t)stream, keys, n,
+                       num_walks, num_steps, shift, out_i16, out_i32, out_f32, zero_row);
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}

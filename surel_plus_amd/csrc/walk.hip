@@ -1,0 +1,453 @@
+// walk.hip -- random-walk node-set sampling with landing-probability accumulation (gfx950).
+//
+// Replaces the hot loop of set_sampler (reference subg_acc/subg_acc.c:742-846), random_walk (:144-180),
+// random_walk_wo (:183-247) and rpe_encoder (:249-314).  Not a translation: the reference walks one root
+// per OpenMP thread with a malloc'd uthash per root; here ONE 256-lane workgroup owns one root, one lane
+// per walk, and the per-root node set lives in LDS:
+//
+//   keys[T]  int32   open-addressing table of visited node ids (T = pow2 > 1.25*(M*m+1))
+//   minq[T]  uint32  smallest visit sequence number of the key  (ds_min_u32)
+//   pk[T]    uint64  packed landing counts of the key           (ds_add_u64: count of step s lives in
+//                    bits [(m-1-s)*SHIFT, +SHIFT), the reference's `bithash` layout, :936-949)
+//
+// The reference's slot number of a node is its rank in sequential first-visit order.  Parallel lanes
+// cannot produce that order directly, so every visit carries its sequence number q (walk-major
+// q = w*m+s+1, or step-major q = s*M+w+1 for rpe_encoder; the root is q = 0); after the walks a bitmap
+// over q marks the first visits and slot = popcount of the bitmap below minq -- a wave-ballot-style
+// prefix sum instead of a sequential hash iteration.  Integer results are bit-exact with the oracle.
+//
+// RNG: SUBGACC_RNG_RAND_R reproduces glibc rand_r's single sequential stream (the reference at
+// nthread=1): the LCG x -> a*x+c is affine, so a lane jumps straight to the stream position of its
+// (root, walk) in O(log k).  SUBGACC_RNG_PHILOX is Philox4x32-10 keyed by (seed; root id, walk, step).
+#include "common.hpp"
+
+namespace subgacc {
+
+constexpr int kWalkThreads = 256;
+constexpr uint32_t kLcgA = 1103515245u, kLcgC = 12345u;
+constexpr uint32_t kPhiloxKey1 = 0x5355524Cu;  // "SURL"
+constexpr uint32_t kStreamShuffle = 0xFFFFFFFFu;
+constexpr int kNeighCap = 1000000;  // NEBMAX, subg_acc.c:13
+
+// ---------------------------------------------------------------------------------------- RNGs
+__device__ __forceinline__ uint32_t lcg_jump(uint32_t x, uint32_t k) {
+    uint32_t a = kLcgA, c = kLcgC;
+    while (k) {
+        if (k & 1u) x = a * x + c;
+        c *= (a + 1u);
+        a *= a;
+        k >>= 1;
+    }
+    return x;
+}
+__device__ __forceinline__ uint32_t rand_r_next(uint32_t &x) {
+    uint32_t r;
+    x = x * kLcgA + kLcgC;
+    r = (x >> 16) & 2047u;
+    x = x * kLcgA + kLcgC;
+    r = (r << 10) ^ ((x >> 16) & 1023u);
+    x = x * kLcgA + kLcgC;
+    r = (r << 10) ^ ((x >> 16) & 1023u);
+    return r;
+}
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0, c1 = l1, c2 = n2, c3 = l0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+
+// ------------------------------------------------------------------- rand_r stream positions
+template <bool IDX64>
+__device__ __forceinline__ void load_row(const void *indptr, int32_t node, int64_t &beg, int64_t &deg) {
+    if (IDX64) {
+        const int64_t *p = (const int64_t *)indptr + node;
+        beg = p[0];
+        deg = p[1] - beg;
+    } else {
+        const int32_t *p = (const int32_t *)indptr + node;
+        const int32_t b = p[0], e = p[1];
+        beg = b;
+        deg = e - b;
+    }
+}
+
+template <bool IDX64>
+__global__ void rng_calls_kernel(const void *__restrict__ indptr, const int32_t *__restrict__ query, int64_t n,
+                                 int M, int m, int wo, int cap, int32_t *__restrict__ calls) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t beg, deg;
+    load_row<IDX64>(indptr, query[i], beg, deg);
+    if (cap && deg > kNeighCap) deg = kNeighCap;
+    int32_t c = 0;
+    if (deg > 0) c = wo ? ((deg > M ? M : 0) + M * (m - 1)) : M * m;
+    calls[i] = c;
+}
+
+// libgomp static schedule: the first n%T threads own ceil(n/T) iterations
+__global__ void rng_positions_kernel(const int64_t *__restrict__ calls_excl, int64_t n, int32_t streams,
+                                     uint64_t calls_before, uint32_t seed, uint32_t *__restrict__ pos,
+                                     uint32_t *__restrict__ sd) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t q = n / streams, r = n % streams;
+    int64_t t, lo;
+    if (i < r * (q + 1)) {
+        t = i / (q + 1);
+        lo = t * (q + 1);
+    } else {
+        t = r + (q > 0 ? (i - r * (q + 1)) / q : 0);
+        lo = r * (q + 1) + (t - r) * q;
+    }
+    uint64_t c = (uint64_t)(calls_excl[i] - calls_excl[lo]);
+    if (streams == 1) c += calls_before;
+    pos[i] = (uint32_t)(3ull * c);  // three LCG steps per rand_r call; the LCG has period 2^32
+    sd[i] = seed + (uint32_t)t;
+}
+
+// ------------------------------------------------------------------------------ the walk kernel
+struct WalkArgs {
+    const void *indptr;
+    const int32_t *indices;
+    const int32_t *query;
+    int64_t n;
+    const uint32_t *rng_pos, *rng_seed;
+    int32_t *set_ids;
+    uint64_t *set_keys;
+    int32_t *nsize;
+    int32_t *walks;
+    int32_t *flags;
+    int32_t M, m, stride, shift;
+    int32_t T, tshift;   // table size (pow2) and 32-log2(T)
+    int32_t nwords;      // bitmap words over q in [0, M*m]
+    uint32_t seed;
+    int32_t wo, step_major, cap_root;
+};
+
+template <bool IDX64, int RNG>
+__global__ __launch_bounds__(kWalkThreads) void walk_sets_kernel(const WalkArgs a) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    unsigned long long *pk = (unsigned long long *)lds_raw;     // [T]
+    int32_t *keys = (int32_t *)(pk + a.T);                       // [T]
+    uint32_t *minq = (uint32_t *)(keys + a.T);                   // [T]
+    uint32_t *bitmap = minq + a.T;                               // [nwords]
+    uint32_t *prefix = bitmap + a.nwords;                        // [nwords + 1]
+    int32_t *sarr = (int32_t *)(prefix + a.nwords + 1);          // [M] Fisher-Yates draws
+
+    const int64_t i = xcd_item(blockIdx.x, gridDim.x);
+    if (i >= a.n) return;
+    const int tid = threadIdx.x;
+    const int M = a.M, m = a.m, T = a.T;
+    const int32_t root = a.query[i];
+    int64_t rbeg, rdeg64;
+    load_row<IDX64>(a.indptr, root, rbeg, rdeg64);
+    if (a.cap_root && rdeg64 > kNeighCap) rdeg64 = kNeighCap;
+    const int64_t obase = i * (int64_t)a.stride;
+    const unsigned long long lead = 1ull << (m * a.shift);
+
+    if (rdeg64 == 0) {  // isolated root: one member, every count = M (subg_acc.c:753-761); id = the root
+        if (tid == 0) {
+            unsigned long long k = lead;
+            for (int s = 0; s < m; ++s) k |= (unsigned long long)M << (s * a.shift);
+            a.set_ids[obase] = root;
+            a.set_keys[obase] = k;
+            a.nsize[i] = 1;
+        }
+        if (a.walks)
+            for (int x = tid; x < M * (m + 1); x += kWalkThreads) a.walks[i * (int64_t)M * (m + 1) + x] = root;
+        return;
+    }
+
+    for (int h = tid; h < T; h += kWalkThreads) {
+        keys[h] = -1;
+        minq[h] = 0xFFFFFFFFu;
+        pk[h] = 0ull;
+    }
+    for (int x = tid; x < a.nwords; x += kWalkThreads) bitmap[x] = 0u;
+
+    uint32_t rpos = 0, rseed = a.seed;
+    if (RNG == SUBGACC_RNG_RAND_R) {
+        rpos = a.rng_pos[i];
+        rseed = a.rng_seed[i];
+    }
+    const bool shuffled = a.wo && rdeg64 > M;
+    const uint32_t rdeg = (uint32_t)rdeg64;
+    if (shuffled) {  // partial Fisher-Yates draws s_k = draw % (deg-k) + k  (subg_acc.c:769-775), one lane per k
+        for (int k = tid; k < M; k += kWalkThreads) {
+            uint32_t r;
+            if (RNG == SUBGACC_RNG_RAND_R) {
+                uint32_t x = lcg_jump(rseed, rpos + 3u * (uint32_t)k);
+                r = rand_r_next(x);
+            } else {
+                uint32_t o[4];
+                philox4x32_10((uint32_t)root, (uint32_t)k, kStreamShuffle, a.wo ? 0u : 1u, a.seed, kPhiloxKey1, o);
+                r = o[0];
+            }
+            sarr[k] = (int32_t)(r % (rdeg - (uint32_t)k)) + k;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {  // the root is member 0 (q = 0)
+        const uint32_t h = ((uint32_t)root * 2654435761u) >> a.tshift;
+        keys[h] = root;
+        minq[h] = 0u;
+    }
+    __syncthreads();
+
+    const uint32_t tmask = (uint32_t)T - 1u;
+    for (int w = tid; w < M; w += kWalkThreads) {
+        // ---- first hop
+        int32_t cur = root;
+        uint32_t x = 0;         // rand_r state of this walk
+        uint32_t ph[4];         // cached Philox block
+        int ph_blk = -1;
+        if (RNG == SUBGACC_RNG_RAND_R) {
+            const uint32_t per_walk = (uint32_t)(a.wo ? m - 1 : m);
+            x = lcg_jump(rseed, rpos + 3u * ((shuffled ? (uint32_t)M : 0u) + (uint32_t)w * per_walk));
+        }
+        int32_t *wrow = a.walks ? a.walks + (i * (int64_t)M + w) * (m + 1) : nullptr;
+        if (wrow) wrow[0] = root;
+        for (int s = 0; s < m; ++s) {
+            if (s == 0 && a.wo) {
+                uint32_t pick;
+                if (shuffled) {
+                    // value that the sequential swaps leave at position w: follow the chain of earlier
+                    // draws that displaced it (one downward pass over the draws, broadcast LDS reads)
+                    int32_t p = sarr[w];
+                    for (int j = w - 1; j >= 0; --j)
+                        if (sarr[j] == p) p = j;
+                    pick = (uint32_t)p;
+                } else {
+                    pick = (uint32_t)w % rdeg;
+                }
+                cur = a.indices[rbeg + pick];
+            } else {
+                int64_t b, d;
+                load_row<IDX64>(a.indptr, cur, b, d);
+                if (d > 0) {
+                    uint32_t r;
+                    if (RNG == SUBGACC_RNG_RAND_R) {
+                        r = rand_r_next(x);
+                    } else {
+                        const int idx = a.wo ? s - 1 : s;
+                        if ((idx >> 2) != ph_blk) {
+                            ph_blk = idx >> 2;
+                            philox4x32_10((uint32_t)root, (uint32_t)w, (uint32_t)ph_blk, a.wo ? 0u : 1u, a.seed,
+                                          kPhiloxKey1, ph);
+                        }
+                        r = ph[idx & 3];
+                    }
+                    cur = a.indices[b + (int64_t)(r % (uint32_t)d)];
+                } else if (RNG == SUBGACC_RNG_RAND_R) {
+                    atomicOr(&a.flags[0], 1);  // dead end: the sequential stream is no longer reproducible
+                }
+            }
+            if (wrow) wrow[s + 1] = cur;
+            // ---- visit: insert-or-find, first-visit sequence number, landing count
+            uint32_t h = ((uint32_t)cur * 2654435761u) >> a.tshift;
+            while (true) {
+                const int32_t old = atomicCAS(&keys[h], -1, cur);
+                if (old == -1 || old == cur) break;
+                h = (h + 1u) & tmask;
+            }
+            const uint32_t q = a.step_major ? (uint32_t)(s * M + w + 1) : (uint32_t)(w * m + s + 1);
+            atomicMin(&minq[h], q);
+            atomicAdd(&pk[h], 1ull << ((m - 1 - s) * a.shift));
+        }
+    }
+    __syncthreads();
+
+    // ---- rank the members by first visit: bitmap over q, popcount prefix
+    for (int h = tid; h < T; h += kWalkThreads)
+        if (keys[h] != -1) {
+            const uint32_t q = minq[h];
+            atomicOr(&bitmap[q >> 5], 1u << (q & 31u));
+        }
+    __syncthreads();
+    for (int x = tid; x <= a.nwords; x += kWalkThreads) {
+        uint32_t s = 0;
+        for (int j = 0; j < x; ++j) s += __popc(bitmap[j]);
+        prefix[x] = s;
+    }
+    __syncthreads();
+    const int32_t total = (int32_t)prefix[a.nwords];
+    for (int h = tid; h < T; h += kWalkThreads)
+        if (keys[h] != -1) {
+            const uint32_t q = minq[h];
+            const int32_t r = (int32_t)(prefix[q >> 5] + __popc(bitmap[q >> 5] & ((1u << (q & 31u)) - 1u)));
+            if (r < a.stride) {  // members ranked past the bucket are dropped with all their visits (:814-828)
+                a.set_ids[obase + r] = keys[h];
+                a.set_keys[obase + r] = pk[h] | (r == 0 ? lead : 0ull);
+            }
+        }
+    if (tid == 0) {
+        a.nsize[i] = total < a.stride ? total : a.stride;
+        if (total > a.stride) atomicAdd(&a.flags[1], 1);
+    }
+}
+
+// ------------------------------------------------------------------------------- compaction
+// one wave per root: copy its members from the strided staging area to the packed arrays
+__global__ __launch_bounds__(256) void compact_sets_kernel(const int32_t *__restrict__ set_ids,
+                                                            const uint64_t *__restrict__ set_keys,
+                                                            const int32_t *__restrict__ nsize,
+                                                            const int64_t *__restrict__ row_off, int64_t n,
+                                                            int32_t stride, int32_t *__restrict__ out_ids,
+                                                            uint64_t *__restrict__ out_keys) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    if (i >= n) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int ns = nsize[i];
+    const int64_t src = i * (int64_t)stride, dst = row_off[i];
+    for (int r = lane; r < ns; r += kWave) {
+        out_ids[dst + r] = set_ids[src + r];
+        out_keys[dst + r] = set_keys[src + r];
+    }
+}
+
+static int table_size_for(int64_t q) {
+    int64_t want = q + q / 4 + 1;
+    int t = 64;
+    while (t < want) t <<= 1;
+    return t;
+}
+
+static size_t walk_lds_bytes(int T, int nwords, int M) {
+    return (size_t)T * 16 + (size_t)nwords * 4 + (size_t)(nwords + 1) * 4 + (size_t)M * 4 + 16;
+}
+
+}  // namespace subgacc
+
+using namespace subgacc;
+
+extern "C" int subgacc_key_shift(int32_t num_walks, int32_t num_steps) {
+    SG_REQUIRE(num_walks > 0 && num_steps > 0, SUBGACC_ERR_BADARG, "num_walks and num_steps must be positive");
+    const int shift = 32 - __builtin_clz((unsigned)num_walks);
+    SG_REQUIRE((int64_t)num_steps * shift + 1 <= 64, SUBGACC_ERR_KEYWIDTH,
+               "Longer width of type for hasing key needed > INT64.");
+    // an all-ones key would collide with the empty marker of the unique table
+    SG_REQUIRE(!((int64_t)num_steps * shift + 1 == 64 && num_walks == (1 << shift) - 1), SUBGACC_ERR_KEYWIDTH,
+               "key space exhausted: num_steps*SHIFT+1 == 64 with num_walks == 2^SHIFT-1");
+    return shift;
+}
+
+extern "C" size_t subgacc_rng_positions_workspace_bytes(int64_t n) {
+    if (n < 0) n = 0;
+    return align_up((size_t)n * 4, 256) + align_up((size_t)(n + 1) * 8, 256) + scan_workspace_bytes(n);
+}
+
+extern "C" int subgacc_rng_positions(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *query,
+                                     int64_t n, int32_t rng_streams, uint64_t calls_before, uint32_t *rng_pos,
+                                     uint32_t *rng_seed, void *workspace, size_t workspace_bytes, void *stream) {
+    SG_REQUIRE(cfg && indptr && rng_pos && rng_seed && n >= 0, SUBGACC_ERR_BADARG, "rng_positions: null argument");
+    SG_REQUIRE(rng_streams >= 1, SUBGACC_ERR_BADARG, "rng_positions: rng_streams must be >= 1");
+    SG_REQUIRE(rng_streams == 1 || calls_before == 0, SUBGACC_ERR_BADARG,
+               "rng_positions: calls_before only makes sense for a single stream");
+    if (n == 0) return SUBGACC_OK;
+    SG_REQUIRE(query, SUBGACC_ERR_BADARG, "rng_positions: null query");
+    SG_REQUIRE(workspace && workspace_bytes >= subgacc_rng_positions_workspace_bytes(n), SUBGACC_ERR_WORKSPACE,
+               "rng_positions: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    int32_t *calls = (int32_t *)ws;
+    ws += align_up((size_t)n * 4, 256);
+    int64_t *excl = (int64_t *)ws;
+    ws += align_up((size_t)(n + 1) * 8, 256);
+    const unsigned grid = (unsigned)ceil_div(n, 256);
+    if (cfg->indptr64)
+        hipLaunchKernelGGL(rng_calls_kernel<true>, dim3(grid), dim3(256), 0, s, indptr, query, n, cfg->num_walks,
+                           cfg->num_steps, cfg->first_hop_wo, cfg->cap_root_degree, calls);
+    else
+        hipLaunchKernelGGL(rng_calls_kernel<false>, dim3(grid), dim3(256), 0, s, indptr, query, n, cfg->num_walks,
+                           cfg->num_steps, cfg->first_hop_wo, cfg->cap_root_degree, calls);
+    SG_LAUNCH_CHECK();
+    int rc = exclusive_scan_i32(calls, n, excl, ws, workspace_bytes - (size_t)(ws - (char *)workspace), s);
+    if (rc != SUBGACC_OK) return rc;
+    hipLaunchKernelGGL(rng_positions_kernel, dim3(grid), dim3(256), 0, s, (const int64_t *)excl, n, rng_streams,
+                       calls_before, cfg->seed, rng_pos, rng_seed);
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}
+
+extern "C" int subgacc_walk_sets(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices,
+                                 int64_t num_nodes, const int32_t *query, int64_t n, const uint32_t *rng_pos,
+                                 const uint32_t *rng_seed, int32_t *set_ids, uint64_t *set_keys, int32_t *nsize,
+                                 int32_t *walks, int32_t *flags, void *stream) {
+    SG_REQUIRE(cfg && indptr && set_ids && set_keys && nsize && flags, SUBGACC_ERR_BADARG, "walk_sets: null argument");
+    SG_REQUIRE(n >= 0 && num_nodes >= 0, SUBGACC_ERR_BADARG, "walk_sets: negative size");
+    SG_REQUIRE(cfg->rng_mode == SUBGACC_RNG_RAND_R || cfg->rng_mode == SUBGACC_RNG_PHILOX, SUBGACC_ERR_BADARG,
+               "walk_sets: unknown rng_mode %d", cfg->rng_mode);
+    const int shift = subgacc_key_shift(cfg->num_walks, cfg->num_steps);
+    if (shift < 0) return shift;
+    const int M = cfg->num_walks, m = cfg->num_steps;
+    SG_REQUIRE((int64_t)M * m + 1 <= (1 << 20), SUBGACC_ERR_LDS, "walk_sets: M*m+1 = %lld too large", (long long)M * m + 1);
+    const int Q = M * m + 1;
+    const int stride = cfg->bucket > 0 ? cfg->bucket : Q;
+    SG_REQUIRE(!cfg->emit_walks || walks, SUBGACC_ERR_BADARG, "walk_sets: emit_walks without a walks buffer");
+    SG_REQUIRE(cfg->rng_mode != SUBGACC_RNG_RAND_R || (rng_pos && rng_seed) || n == 0, SUBGACC_ERR_BADARG,
+               "walk_sets: RAND_R mode needs rng_pos/rng_seed from subgacc_rng_positions");
+    if (n == 0) return SUBGACC_OK;
+    SG_REQUIRE(query && indices, SUBGACC_ERR_BADARG, "walk_sets: null query/indices");
+
+    WalkArgs a;
+    a.indptr = indptr, a.indices = indices, a.query = query, a.n = n;
+    a.rng_pos = rng_pos, a.rng_seed = rng_seed;
+    a.set_ids = set_ids, a.set_keys = set_keys, a.nsize = nsize;
+    a.walks = cfg->emit_walks ? walks : nullptr;
+    a.flags = flags;
+    a.M = M, a.m = m, a.stride = stride, a.shift = shift;
+    a.T = table_size_for(Q);
+    a.tshift = 32 - (31 - __builtin_clz((unsigned)a.T));
+    a.nwords = (Q + 31) / 32;
+    a.seed = cfg->seed;
+    a.wo = cfg->first_hop_wo ? 1 : 0;
+    a.step_major = cfg->order == SUBGACC_ORDER_STEP_MAJOR ? 1 : 0;
+    a.cap_root = cfg->cap_root_degree ? 1 : 0;
+    const size_t lds = walk_lds_bytes(a.T, a.nwords, M);
+    SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS,
+               "walk_sets: per-root tables need %zu B of LDS (> %d): M*m+1 = %d is too large", lds, kLdsBytes, Q);
+
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t grid = xcd_grid(n);
+    SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "walk_sets: chunk of %lld roots too large, split it", (long long)n);
+#define SG_WALK_LAUNCH(I64, RNGM)                                                                                 \
+    do {                                                                                                          \
+        if (lds > 64 * 1024)                                                                                      \
+            SG_CHECK_HIP(hipFuncSetAttribute((const void *)walk_sets_kernel<I64, RNGM>,                           \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
+        hipLaunchKernelGGL((walk_sets_kernel<I64, RNGM>), dim3((unsigned)grid), dim3(kWalkThreads), lds, s, a);   \
+    } while (0)
+    if (cfg->indptr64) {
+        if (cfg->rng_mode == SUBGACC_RNG_RAND_R) SG_WALK_LAUNCH(true, SUBGACC_RNG_RAND_R);
+        else SG_WALK_LAUNCH(true, SUBGACC_RNG_PHILOX);
+    } else {
+        if (cfg->rng_mode == SUBGACC_RNG_RAND_R) SG_WALK_LAUNCH(false, SUBGACC_RNG_RAND_R);
+        else SG_WALK_LAUNCH(false, SUBGACC_RNG_PHILOX);
+    }
+#undef SG_WALK_LAUNCH
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}
+
+extern "C" int subgacc_compact_sets(const int32_t *set_ids, const uint64_t *set_keys, const int32_t *nsize,
+                                    const int64_t *row_off, int64_t n, int32_t stride, int32_t *out_ids,
+                                    uint64_t *out_keys, void *stream) {
+    SG_REQUIRE(n >= 0 && stride > 0, SUBGACC_ERR_BADARG, "compact_sets: bad sizes");
+    if (n == 0) return SUBGACC_OK;
+    SG_REQUIRE(set_ids && set_keys && nsize && row_off && out_ids && out_keys, SUBGACC_ERR_BADARG,
+               "compact_sets: null argument");
+    const int64_t blocks = ceil_div(n * kWave, 256);
+    SG_REQUIRE(blocks < (1ll << 31), SUBGACC_ERR_BADARG, "compact_sets: too many roots in one call");
+    hipLaunchKernelGGL(compact_sets_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, set_ids,
+                       set_keys, nsize, row_off, n, stride, out_ids, out_keys);
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}

@@ -1,0 +1,77 @@
+"""Synthetic graphs and SpG stores in the shapes BASELINE.json's configs name (there is no network: the
+OGB datasets cannot be downloaded).  Generated on the GPU with torch, seeded, and symmetrised the way the
+reference's loader does (G + G.T, dataloader.py:122-135): undirected, simple, sorted CSR, int32 ids.
+
+  collab-like   N=235,868   avg deg 8.2     (paper Table 7)
+  ppa-like      N=576,289   avg deg 73.7
+  cit2-like     N=2,927,963 avg deg 20.7
+"""
+import torch
+
+from .sampler import DeviceCSR
+
+PRESETS = {
+    "collab": dict(N=235_868, avg_deg=8.2, seed=0),
+    "ppa": dict(N=576_289, avg_deg=73.7, seed=1),
+    "cit2": dict(N=2_927_963, avg_deg=20.7, seed=2),
+}
+
+
+def powerlaw_graph(N, avg_deg, seed=0, exponent=2.5, device="cuda", max_weight_frac=0.002):
+    """Chung-Lu style heavy-tailed undirected graph with ~N*avg_deg/2 distinct edges -> DeviceCSR."""
+    gen = torch.Generator(device=device).manual_seed(int(seed))
+    # expected-degree weights w_i ~ i^(-1/(exponent-1)), capped so the largest hub stays a small fraction of N
+    ranks = torch.arange(1, N + 1, device=device, dtype=torch.float64)
+    w = ranks.pow(-1.0 / (exponent - 1.0))
+    w = torch.minimum(w, w.sum() * max_weight_frac / avg_deg)
+    w = w[torch.randperm(N, device=device, generator=gen)]        # hubs are not the low ids
+    cdf = torch.cumsum(w, 0)
+    cdf = cdf / cdf[-1]
+    E = int(N * avg_deg / 2 * 1.04)                                 # a few draws are lost to loops / duplicates
+    u = torch.searchsorted(cdf, torch.rand(E, device=device, generator=gen, dtype=torch.float64)).clamp_(max=N - 1)
+    v = torch.searchsorted(cdf, torch.rand(E, device=device, generator=gen, dtype=torch.float64)).clamp_(max=N - 1)
+    keep = u != v
+    u, v = u[keep], v[keep]
+    key = torch.cat([u * N + v, v * N + u])                         # symmetrise
+    key = torch.unique(key)                                         # sorted, duplicate edges removed
+    row = torch.div(key, N, rounding_mode="floor")
+    col = (key - row * N).to(torch.int32)
+    counts = torch.bincount(row, minlength=N)
+    nnz = int(key.numel())
+    ptr_dtype = torch.int32 if nnz < 2**31 - 1 else torch.int64
+    indptr = torch.zeros(N + 1, dtype=torch.int64, device=device)
+    indptr[1:] = torch.cumsum(counts, 0)
+    return DeviceCSR(indptr.to(ptr_dtype), col, torch.device(device))
+
+
+def preset_graph(name, device="cuda", scale=1.0):
+    p = PRESETS[name]
+    return powerlaw_graph(max(int(p["N"] * scale), 16), p["avg_deg"], seed=p["seed"], device=device)
+
+
+def query_pairs(csr, B, seed=7, device="cuda"):
+    """B query pairs: half 'positive-like' (drawn from the edges), half uniform random (the 1:k mix of
+    main.py:212-214) -> int64 [2, B]."""
+    gen = torch.Generator(device=device).manual_seed(int(seed))
+    half = B // 2
+    e = torch.randint(0, csr.nnz, (half,), device=device, generator=gen)
+    src = torch.searchsorted(csr.indptr.long(), e, right=True) - 1
+    dst = csr.indices[e].long()
+    rnd = torch.randint(0, csr.num_nodes, (2, B - half), device=device, generator=gen)
+    return torch.cat([torch.stack([src, dst]), rnd], dim=1).contiguous()
+
+
+def ppr_like_spg(N, topk=100, seed=3, device="cuda"):
+    """A float-payload SpG shaped like the citation2 PPR configuration: exactly min(topk, N) sorted distinct
+    ids per row with scores in (0,1] (utils.py:36 maps PPR scores by (x+0.1)/(max+0.1))."""
+    from .spg import SpG
+    gen = torch.Generator(device=device).manual_seed(int(seed))
+    k = min(topk, N)
+    # distinct ids per row: a random start plus strictly increasing random gaps, wrapped and re-sorted
+    gaps = torch.randint(1, max(N // k, 2), (N, k), device=device, generator=gen)
+    start = torch.randint(0, N, (N, 1), device=device, generator=gen)
+    ids = (start + torch.cumsum(gaps, 1) - gaps[:, :1]) % N
+    ids, _ = torch.sort(ids, dim=1)
+    data = (torch.rand((N, k), device=device, generator=gen, dtype=torch.float64) + 0.1) / 1.1
+    indptr = torch.arange(0, (N + 1) * k, k, device=device, dtype=torch.int64)
+    return SpG(indptr, ids.reshape(-1).to(torch.int32), data.reshape(-1), max_len=k, shape=(N, N))

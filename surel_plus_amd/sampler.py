@@ -1,0 +1,205 @@
+"""Device-resident node-set sampler: walks -> per-root dedup + LP counts -> global unique LP rows.
+
+Host side of the kernels in csrc/walk.hip and csrc/uniq.hip.  Everything stays in HBM; the only host
+round trip is one 8-byte read per chunk of roots (the chunk's total set size, needed to size the packed
+output).  Mirrors the stages of set_sampler (reference subg_acc/subg_acc.c:736-1005).
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import WalkCfg, check, lib, ptr, stream_ptr
+
+# strided staging budget per chunk of roots (bytes); stride*12 B per root
+STAGING_BYTES = 6 << 30
+UNIQ_CAPACITY = 1 << 20
+
+
+class DeviceCSR:
+    """Graph CSR resident in HBM: int32 node ids, int32 or int64 row offsets (`indptr64`)."""
+
+    def __init__(self, indptr, indices, device=None):
+        device = device or _lib.require_device()
+        ip = indptr if torch.is_tensor(indptr) else torch.from_numpy(np.ascontiguousarray(indptr))
+        ix = indices if torch.is_tensor(indices) else torch.from_numpy(np.ascontiguousarray(indices))
+        if ip.dtype not in (torch.int32, torch.int64):
+            raise TypeError("Input parsing error. (indptr must be int32 or int64)")
+        if ix.dtype != torch.int32:
+            raise TypeError("Input parsing error. (indices must be int32; the reference casts safely, "
+                            "subg_acc.c:668)")
+        self.indptr = ip.to(device).contiguous()
+        self.indices = ix.to(device).contiguous()
+        self.indptr64 = self.indptr.dtype == torch.int64
+        self.num_nodes = self.indptr.numel() - 1
+        self.device = self.indptr.device
+
+    @property
+    def nnz(self):
+        return self.indices.numel()
+
+
+@dataclass
+class SampledSets:
+    """Output of the sampler, all on device.  remap = (ids, sf) and enc in the reference's terms."""
+    nsize: torch.Tensor      # int32 [n]
+    row_off: torch.Tensor    # int64 [n+1]
+    ids: torch.Tensor        # int32 [X]   members, first-visit order per root
+    keys: torch.Tensor       # int64 [X]   packed LP row (bit pattern of the uint64 key)
+    sf: torch.Tensor         # int32 [X]   index of the member's LP row in `ukeys` (None until dedup)
+    ukeys: torch.Tensor      # int64 [c]   distinct LP rows in first-occurrence order
+    num_walks: int
+    num_steps: int
+    stride: int
+    walks: torch.Tensor = None   # int32 [n, M*(m+1)] when requested
+    n_overflow: int = 0
+    extra: dict = field(default_factory=dict)
+
+    @property
+    def X(self):
+        return self.ids.numel()
+
+    @property
+    def c(self):
+        return self.ukeys.numel()
+
+    def enc_int16(self):
+        """int16 [c, m+1]: the reference's `enc` (subg_acc.c:982-1000)."""
+        out = torch.empty((self.c, self.num_steps + 1), dtype=torch.int16, device=self.ids.device)
+        check(lib().subgacc_unpack_lp(ptr(self.ukeys), self.c, self.num_walks, self.num_steps, ptr(out), None, None, 0,
+                                      stream_ptr()))
+        return out
+
+    def counts_int32(self):
+        """int32 [X, m+1]: per-member landing counts (rpe_encoder's second output, subg_acc.c:281-303)."""
+        out = torch.empty((self.X, self.num_steps + 1), dtype=torch.int32, device=self.ids.device)
+        check(lib().subgacc_unpack_lp(ptr(self.keys), self.X, self.num_walks, self.num_steps, None, ptr(out), None, 0,
+                                      stream_ptr()))
+        return out
+
+    def feature_table(self):
+        """float32 [c+1, m+1] = [0-row ; enc / M]: Z_SF as main.py:174 + random_walks.py:81 build it."""
+        out = torch.empty((self.c + 1, self.num_steps + 1), dtype=torch.float32, device=self.ids.device)
+        check(lib().subgacc_unpack_lp(ptr(self.ukeys), self.c, self.num_walks, self.num_steps, None, None, ptr(out), 1,
+                                      stream_ptr()))
+        return out
+
+
+def make_cfg(csr, num_walks, num_steps, bucket=-1, seed=111413, rng="rand_r", first_hop_wo=True,
+             order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False):
+    rng_mode = {"rand_r": _lib.RNG_RAND_R, "philox": _lib.RNG_PHILOX}[rng]
+    if num_walks <= 0 or num_steps <= 0:
+        raise TypeError("Input parsing error. (num_walks and num_steps must be positive)")
+    return WalkCfg(int(num_walks), int(num_steps), int(bucket), rng_mode, int(seed) & 0xFFFFFFFF,
+                   1 if first_hop_wo else 0, int(order), 1 if cap_root_degree else 0,
+                   1 if csr.indptr64 else 0, 1 if emit_walks else 0)
+
+
+def _as_query(query, device):
+    """`query` is force-cast to int32 like the reference does (NPY_ARRAY_FORCECAST, subg_acc.c:673)."""
+    if torch.is_tensor(query):
+        return query.to(device=device, dtype=torch.int32).contiguous().view(-1)
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(query).astype(np.int32)).ravel()).to(device)
+
+
+def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, rng="rand_r", first_hop_wo=True,
+                order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False, rng_streams=1,
+                calls_before=0, dedup=True, staging_bytes=STAGING_BYTES, uniq_capacity=UNIQ_CAPACITY):
+    """Run the sampler for `query` (roots) on the GPU.  See SampledSets."""
+    L = lib()
+    dev = csr.device
+    q = _as_query(query, dev)
+    n = q.numel()
+    cfg = make_cfg(csr, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order, cap_root_degree, emit_walks)
+    check(L.subgacc_key_shift(cfg.num_walks, cfg.num_steps))   # AssertionError like subg_acc.c:911-915
+    M, m = cfg.num_walks, cfg.num_steps
+    stride = bucket if bucket > 0 else M * m + 1
+    st = stream_ptr()
+    flags = torch.zeros(4, dtype=torch.int32, device=dev)
+
+    rng_pos = rng_seed = None
+    if cfg.rng_mode == _lib.RNG_RAND_R and n > 0:
+        rng_pos = torch.empty(n, dtype=torch.int32, device=dev)
+        rng_seed = torch.empty(n, dtype=torch.int32, device=dev)
+        ws = torch.empty(L.subgacc_rng_positions_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        check(L.subgacc_rng_positions(cfg, ptr(csr.indptr), ptr(q), n, int(rng_streams), int(calls_before), ptr(rng_pos),
+                                      ptr(rng_seed), ptr(ws), ws.numel(), st))
+
+    nsize = torch.empty(n, dtype=torch.int32, device=dev)
+    walks = torch.empty((n, M * (m + 1)), dtype=torch.int32, device=dev) if emit_walks else None
+    chunk = max(1, min(n, int(staging_bytes // (stride * 12)), (1 << 31) - 16)) if n else 0
+    ids_parts, key_parts = [], []
+    if n:
+        st_ids = torch.empty(chunk * stride, dtype=torch.int32, device=dev)
+        st_keys = torch.empty(chunk * stride, dtype=torch.int64, device=dev)
+        scan_ws = torch.empty(L.subgacc_scan_workspace_bytes(chunk), dtype=torch.uint8, device=dev)
+        off_chunk = torch.empty(chunk + 1, dtype=torch.int64, device=dev)
+    for lo in range(0, n, chunk if chunk else 1):
+        cn = min(chunk, n - lo)
+        check(L.subgacc_walk_sets(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn,
+                                  ptr(rng_pos[lo:]) if rng_pos is not None else None,
+                                  ptr(rng_seed[lo:]) if rng_seed is not None else None,
+                                  ptr(st_ids), ptr(st_keys), ptr(nsize[lo:]),
+                                  ptr(walks[lo:]) if walks is not None else None, ptr(flags), st))
+        check(L.subgacc_exclusive_scan_i32(ptr(nsize[lo:]), cn, ptr(off_chunk), ptr(scan_ws), scan_ws.numel(), st))
+        total = int(off_chunk[cn].item())        # the one host round trip of this chunk
+        ids_c = torch.empty(total, dtype=torch.int32, device=dev)
+        keys_c = torch.empty(total, dtype=torch.int64, device=dev)
+        check(L.subgacc_compact_sets(ptr(st_ids), ptr(st_keys), ptr(nsize[lo:]), ptr(off_chunk), cn, stride,
+                                     ptr(ids_c), ptr(keys_c), st))
+        ids_parts.append(ids_c)
+        key_parts.append(keys_c)
+    if len(ids_parts) == 1:
+        ids, keys = ids_parts[0], key_parts[0]
+    elif ids_parts:
+        ids, keys = torch.cat(ids_parts), torch.cat(key_parts)
+    else:
+        ids = torch.empty(0, dtype=torch.int32, device=dev)
+        keys = torch.empty(0, dtype=torch.int64, device=dev)
+    del ids_parts, key_parts
+
+    row_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    ws = torch.empty(L.subgacc_scan_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    check(L.subgacc_exclusive_scan_i32(ptr(nsize), n, ptr(row_off), ptr(ws), ws.numel(), st))
+
+    fl = flags.tolist()
+    if fl[0]:
+        raise _lib.SubgAccError(
+            "rng='rand_r' cannot reproduce the sequential stream on this graph: a walk reached a node without "
+            "out-edges, so the number of draws is data dependent (the reference's graphs are symmetrised, "
+            "dataloader.py:122-135). Use rng='philox'.")
+    sets = SampledSets(nsize, row_off, ids, keys, None, None, M, m, stride, walks, n_overflow=fl[1])
+    if fl[1]:
+        print(f"#SubGAcc: {fl[1]} keys exceed the buffer, try a larger bucket size > {stride}.")
+    if dedup:
+        dedup_lp_rows(sets, uniq_capacity)
+    return sets
+
+
+def dedup_lp_rows(sets, capacity=UNIQ_CAPACITY):
+    """Global first-occurrence dedup of the packed LP rows (subg_acc.c:957-1000) -> sets.sf, sets.ukeys."""
+    L = lib()
+    dev = sets.ids.device
+    st = stream_ptr()
+    X = sets.X
+    sf = torch.empty(X, dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    ws = torch.empty(L.subgacc_uniq_number_workspace_bytes(X), dtype=torch.uint8, device=dev)
+    while True:
+        flags = torch.zeros(4, dtype=torch.int32, device=dev)
+        table = torch.empty(L.subgacc_uniq_table_bytes(capacity), dtype=torch.uint8, device=dev)
+        check(L.subgacc_uniq_reset(ptr(table), capacity, st))
+        check(L.subgacc_uniq_insert(ptr(table), capacity, ptr(sets.keys), X, 0, ptr(flags), st))
+        if int(flags[2].item()):
+            capacity *= 4           # table full: the distinct-row count exceeded the guess, retry larger
+            continue
+        max_unique = min(X, capacity)
+        ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
+        check(L.subgacc_uniq_number(ptr(table), capacity, ptr(sets.keys), X, ptr(sf), ptr(ukeys), max_unique, ptr(count),
+                                    ptr(ws), ws.numel(), st))
+        c = int(count.item())
+        break
+    sets.sf = sf
+    sets.ukeys = ukeys[:c].clone()
+    return sets

@@ -1,0 +1,85 @@
+"""SpG: the sparse node-set store of SUREL+, resident in HBM.
+
+Reference: sampler/random_walks.py:74-82 (`subg_matrix`) builds a scipy csr_matrix whose row u lists the
+sampled set of u (sorted node ids) with data = SFptr+1, plus the LP table `enc` with a zero row in front.
+Here the same CSR lives on the GPU (int64 row offsets, int32 ids, int32 or float64 payload) and is what
+`sjoin` / `gather` consume; it is built by the segmented sort in csrc/spg.hip.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+from .sampler import DeviceCSR, sample_sets
+
+
+class SpG:
+    """Device CSR of node sets.  `data` is int32 (SFptr+1, LP encoder) or float64 (PPR scores)."""
+
+    def __init__(self, indptr, indices, data, max_len=None, shape=None):
+        assert indptr.dtype == torch.int64 and indices.dtype == torch.int32
+        assert data.dtype in (torch.int32, torch.float64)
+        self.indptr, self.indices, self.data = indptr.contiguous(), indices.contiguous(), data.contiguous()
+        self.n_rows = indptr.numel() - 1
+        if max_len is None:
+            max_len = int((self.indptr[1:] - self.indptr[:-1]).max().item()) if self.n_rows else 0
+        self.max_len = int(max_len)
+        self.shape = shape or (self.n_rows, self.n_rows)
+        self.device = indptr.device
+
+    @property
+    def nnz(self):
+        return self.indices.numel()
+
+    @classmethod
+    def from_sets(cls, sets, n_cols=None):
+        """Segmented sort of the sampled sets by node id (random_walks.py:79-80).  Row i = root query[i]."""
+        if sets.sf is None:
+            raise ValueError("SpG.from_sets needs de-duplicated sets (sample_sets(..., dedup=True))")
+        dev = sets.ids.device
+        n = sets.nsize.numel()
+        indices = torch.empty_like(sets.ids)
+        data = torch.empty_like(sets.sf)
+        flags = torch.zeros(4, dtype=torch.int32, device=dev)
+        check(lib().subgacc_spg_build(ptr(sets.row_off), n, ptr(sets.ids), ptr(sets.sf), sets.stride, ptr(indices),
+                                      ptr(data), ptr(flags), stream_ptr()))
+        return cls(sets.row_off, indices, data, max_len=sets.stride, shape=(n, n_cols or n))
+
+    @classmethod
+    def from_scipy(cls, z, device=None):
+        """Upload a scipy CSR (e.g. the PPR matrix of sampler/pprgo.py) as an SpG; float payloads stay float64."""
+        device = device or _lib.require_device()
+        z = z.tocsr()
+        z.sort_indices()
+        data = z.data
+        if np.issubdtype(data.dtype, np.floating):
+            data = data.astype(np.float64)
+        else:
+            data = data.astype(np.int32)
+        return cls(torch.from_numpy(z.indptr.astype(np.int64)).to(device),
+                   torch.from_numpy(z.indices.astype(np.int32)).to(device),
+                   torch.from_numpy(data).to(device), shape=z.shape)
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.csr_matrix((self.data.cpu().numpy(), self.indices.cpu().numpy(), self.indptr.cpu().numpy()),
+                             shape=self.shape)
+
+
+def subg_matrix(G, train_idx, num_walks=200, num_steps=4, seed=111413, rng="rand_r", device=None):
+    """Drop-in for sampler/random_walks.py:74-82: returns (z, enc).
+
+    z   -- SpG on the GPU (row i = sampled set of train_idx[i]); the reference indexes rows by node id and
+           always passes train_idx = arange(N) (main.py:168-178), for which both conventions coincide.
+    enc -- numpy int16 [c+1, num_steps] with the all-zero row 0, exactly what the reference returns, so
+           `torch.from_numpy(xpe).to(device).float() / num_walks` (main.py:174) keeps working.
+    `num_steps` is the CLI value: the walks have num_steps-1 hops (random_walks.py:78).
+    """
+    print(f'Start sampling for #{len(train_idx)} nodes with {num_walks} {num_steps}-step walks')
+    csr = G if isinstance(G, DeviceCSR) else DeviceCSR(G.indptr, G.indices, device)
+    sets = sample_sets(csr, train_idx, num_walks=num_walks, num_steps=num_steps - 1, seed=seed, rng=rng)
+    z = SpG.from_sets(sets, n_cols=csr.num_nodes)
+    enc = sets.enc_int16().cpu().numpy()
+    enc = np.insert(enc, 0, np.zeros((1, num_steps), dtype=enc.dtype), axis=0)
+    z.sets = sets
+    return z, enc

@@ -1,0 +1,144 @@
+"""SpJoin on the GPU: drop-ins for train.py's gather / bgather / pgather / hgather.
+
+Reference: train.py:13-45 (gather), :48-72 (hgather), :75-85 (bgather), :88-111 (pgather).  Same names,
+same argument meaning, same return values (xz float32 [R,2,k], indptr-or-segment-ids int64 on `device`);
+`x` is an SpG (surel_plus_amd.spg.SpG) or a scipy CSR (uploaded once and cached), `encode` the Z_SF table
+as a float32 CUDA tensor or None for a float payload.  The work is done by csrc/sjoin.hip.
+"""
+import weakref
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, stream_ptr
+from .spg import SpG
+
+_scipy_cache = weakref.WeakKeyDictionary()
+
+
+def _as_spg(x):
+    if isinstance(x, SpG):
+        return x
+    try:
+        hit = _scipy_cache.get(x)
+    except TypeError:
+        hit = None
+    if hit is None:
+        hit = SpG.from_scipy(x)
+        try:
+            _scipy_cache[x] = hit
+        except TypeError:
+            pass
+    return hit
+
+
+def _as_rows(edge, device):
+    """[r, B] endpoints as an int64 device tensor (the reference takes torch or numpy integer arrays)."""
+    if torch.is_tensor(edge):
+        return edge.to(device=device, dtype=torch.int64)
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(edge)).astype(np.int64)).to(device)
+
+
+def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False):
+    """Generic segment join (include/subgacc.h: subgacc_sjoin_sizes + subgacc_sjoin_fill).
+
+    own/partner: int64 device tensors of SpG row numbers, one segment each.
+    Returns (xz, ind): xz float32 [R,2,k] (or int32 [R,2] index pairs when return_index), ind = int64 [S+1]
+    segment pointers (ptr_mode) or int64 [R] segment ids.
+    """
+    L = lib()
+    dev = spg.device
+    st = stream_ptr()
+    S = own.numel()
+    own, partner = own.contiguous(), partner.contiguous()
+    seg = torch.empty(S + 1, dtype=torch.int64, device=dev)
+    ws = torch.empty(L.subgacc_sjoin_workspace_bytes(S), dtype=torch.uint8, device=dev)
+    check(L.subgacc_sjoin_sizes(ptr(spg.indptr), ptr(own), S, ptr(seg), ptr(ws), ws.numel(), st))
+    R = int(seg[S].item())                  # the one host round trip: the output size
+    is_f64 = spg.data.dtype == torch.float64
+    flags = torch.zeros(4, dtype=torch.int32, device=dev)
+    segid = None if ptr_mode else torch.empty(R, dtype=torch.int64, device=dev)
+    if is_f64:
+        if encode is not None:
+            raise TypeError("a float-payload SpG is joined without an encode table (train.py:39-43)")
+        xz = torch.empty((R, 2, 1), dtype=torch.float32, device=dev)
+        check(L.subgacc_sjoin_fill(ptr(spg.indptr), ptr(spg.indices), None, ptr(spg.data), ptr(own), ptr(partner), S,
+                                   ptr(seg), None, 0, 1, ptr(xz), None, ptr(segid), spg.max_len, ptr(flags), st))
+        out = xz
+    elif return_index:
+        out = torch.empty((R, 2), dtype=torch.int32, device=dev)
+        check(L.subgacc_sjoin_fill(ptr(spg.indptr), ptr(spg.indices), ptr(spg.data), None, ptr(own), ptr(partner), S,
+                                   ptr(seg), None, 0, 0, None, ptr(out), ptr(segid), spg.max_len, ptr(flags), st))
+    else:
+        if encode is None:
+            raise NotImplementedError("an integer SpG needs the encode table")
+        enc = encode.to(device=dev, dtype=torch.float32).contiguous()
+        k = enc.shape[1]
+        out = torch.empty((R, 2, k), dtype=torch.float32, device=dev)
+        check(L.subgacc_sjoin_fill(ptr(spg.indptr), ptr(spg.indices), ptr(spg.data), None, ptr(own), ptr(partner), S,
+                                   ptr(seg), ptr(enc), enc.shape[0], k, ptr(out), None, ptr(segid), spg.max_len,
+                                   ptr(flags), st))
+    return out, (seg if ptr_mode else segid), flags
+
+
+def _checked(out, ind, flags):
+    f = int(flags[3].item()) if _lib_debug_flags else 0
+    if f & 1:
+        raise _lib.SubgAccError("SpG row longer than SpG.max_len")
+    if f & 2:
+        raise IndexError("SFptr outside the encode table")
+    return out, ind
+
+
+_lib_debug_flags = True
+
+
+def gather(edge, x, device=None, ptr=True, encode=None):
+    """train.py:13-45.  Left blocks (S_u with S_v looked up) then right blocks, per pair in batch order."""
+    spg = _as_spg(x)
+    e = _as_rows(edge, spg.device)
+    own = torch.cat([e[0], e[1]])
+    partner = torch.cat([e[1], e[0]])
+    return _checked(*sjoin(spg, own, partner, encode, ptr_mode=ptr))
+
+
+def hgather(hedge, x, device=None, encode=None):
+    """train.py:48-72.  Blocks [U|w ; W|u ; V|w ; W|v], always segment ids; encode is mandatory."""
+    if encode is None:
+        raise NotImplementedError
+    spg = _as_spg(x)
+    h = _as_rows(hedge, spg.device)
+    u, v, w = h[0], h[1], h[2]
+    own = torch.cat([u, w, v, w])
+    partner = torch.cat([w, u, w, v])
+    xz, ind = _checked(*sjoin(spg, own, partner, encode, ptr_mode=False))
+    assert xz.size(0) == ind.size(0)
+    return xz, ind
+
+
+def bgather(edge, x, out):
+    """train.py:75-85: the per-thread block worker of pgather.  Kept for signature compatibility: fills
+    out[0..3] with (left pairs, right pairs, left sizes, right sizes) as NumPy arrays."""
+    spg = _as_spg(x)
+    e = _as_rows(edge, spg.device)
+    B = e.shape[1]
+    own = torch.cat([e[0], e[1]])
+    partner = torch.cat([e[1], e[0]])
+    if spg.data.dtype == torch.float64:
+        pairs, seg = _checked(*sjoin(spg, own, partner, None, ptr_mode=True))
+        pairs = pairs.view(-1, 2)
+    else:
+        pairs, seg = _checked(*sjoin(spg, own, partner, None, ptr_mode=True, return_index=True))
+    sizes = (seg[1:] - seg[:-1]).cpu().numpy()
+    mid = int(seg[B].item())
+    pairs = pairs.cpu().numpy()
+    out[0], out[1] = pairs[:mid], pairs[mid:]
+    out[2], out[3] = sizes[:B], sizes[B:]
+
+
+def pgather(edge, M, device=None, encode=None, gather_func=None, ptr=True, njobs=4):
+    """train.py:88-111.  The reference splits the batch over `njobs` Python threads; one kernel launch
+    covers the whole batch here, so `gather_func` / `njobs` only keep the call signature.  The result is
+    identical to gather() (as it is in the reference)."""
+    return gather(edge, M, device, ptr=ptr, encode=encode)

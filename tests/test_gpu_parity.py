@@ -1,0 +1,282 @@
+"""GPU (MI355X): the HIP path, called through the C ABI, against the golden vectors of the reference and
+against the oracle on seeded inputs.  Integer / index outputs are compared BIT-EXACT; the only floating
+point is the final table lookup (exact copies) and LP normalisation (float32 division, tolerance 0)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import GOLDEN, golden_files
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sp():
+    import surel_plus_amd
+    from surel_plus_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "libsubgacc_hip.so must be built (no fallback)"
+    assert _lib.lib().subgacc_device_count() >= 1, "no gfx950 device"
+    return surel_plus_amd
+
+
+def _load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def sym_graph(N, E, seed, hubs=0):
+    import scipy.sparse as sps
+    rng = np.random.default_rng(seed)
+    r = rng.integers(0, N, E)
+    c = rng.integers(0, N, E)
+    if hubs:
+        hr = np.repeat(np.arange(hubs), N // 4)
+        hc = rng.integers(0, N, hubs * (N // 4))
+        r, c = np.concatenate([r, hr]), np.concatenate([c, hc])
+    A = sps.csr_matrix((np.ones(len(r)), (r, c)), shape=(N, N))
+    A = sps.csr_matrix(A + A.T)
+    A.setdiag(0)
+    A.eliminate_zeros()
+    A.sort_indices()
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32)
+
+
+# ------------------------------------------------------------------------------------------ scan
+@pytest.mark.parametrize("n", [0, 1, 7, 2047, 2048, 2049, 100000, 2048 * 2048 + 5])
+def test_exclusive_scan(sp, n):
+    from surel_plus_amd._lib import check, lib, ptr, stream_ptr
+    L = lib()
+    x = torch.randint(0, 1000, (n,), dtype=torch.int32, device="cuda")
+    out = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    ws = torch.empty(L.subgacc_scan_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    check(L.subgacc_exclusive_scan_i32(ptr(x), n, ptr(out), ptr(ws), ws.numel(), stream_ptr()))
+    ref = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), torch.cumsum(x.long(), 0)])
+    assert torch.equal(out, ref)
+
+
+# ------------------------------------------------------------------------------- gset_sampler
+@pytest.mark.parametrize("name", golden_files("gset_"))
+def test_gset_sampler_matches_reference_golden(sp, name):
+    g = _load(name)
+    out = sp.gset_sampler(g["indptr"], g["indices"], g["query"], num_walks=int(g["M"]), num_steps=int(g["m"]),
+                          bucket=int(g["bucket"]), seed=int(g["seed"]), debug=1)
+    assert out[0].dtype == np.int32 and out[1].dtype == np.int32 and out[2].dtype == np.int16
+    assert np.array_equal(out[0], g["nsize"])
+    assert np.array_equal(out[1], g["remap"])
+    assert np.array_equal(out[2], g["enc"])
+    assert np.array_equal(out[3], g["raw"])
+
+
+@pytest.mark.parametrize("rng", ["rand_r", "philox"])
+@pytest.mark.parametrize("M,m,N,E,hubs", [(200, 2, 20000, 80000, 4), (200, 3, 6000, 200000, 0), (100, 4, 3000, 9000, 2),
+                                          (7, 5, 500, 1500, 1), (300, 2, 2000, 300000, 0)])
+def test_gset_sampler_matches_oracle(sp, rng, M, m, N, E, hubs):
+    ptr_, idx = sym_graph(N, E, seed=M + m, hubs=hubs)
+    q = np.random.default_rng(3).permutation(N)[: min(N, 4000)]
+    a = sp.gset_sampler(ptr_, idx, q, num_walks=M, num_steps=m, seed=99, debug=1, rng=rng)
+    b = oracle.gset_sampler(ptr_, idx, q, num_walks=M, num_steps=m, seed=99, debug=True, rng=rng)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_gset_multichunk_and_int64_indptr(sp):
+    ptr_, idx = sym_graph(5000, 30000, seed=5, hubs=1)
+    q = np.arange(5000)
+    from surel_plus_amd.sampler import DeviceCSR, sample_sets
+    b = oracle.gset_sampler(ptr_, idx, q, num_walks=50, num_steps=3, seed=4, debug=True)
+    for ip in (ptr_, ptr_.astype(np.int64)):
+        csr = DeviceCSR(ip, idx)
+        s = sample_sets(csr, q, num_walks=50, num_steps=3, seed=4, staging_bytes=151 * 12 * 700)   # 8 chunks
+        assert np.array_equal(s.nsize.cpu().numpy(), b[0])
+        assert np.array_equal(torch.stack([s.ids, s.sf]).cpu().numpy(), b[1])
+        assert np.array_equal(s.enc_int16().cpu().numpy(), b[2])
+        tab = s.feature_table().cpu().numpy()
+        assert np.array_equal(tab, oracle.enc_table(b[2]).astype(np.float32) / np.float32(50))
+
+
+def test_philox_is_schedule_independent(sp):
+    """Sets of a root do not depend on the batch it is sampled in (counter = seed, root id, walk, step)."""
+    ptr_, idx = sym_graph(3000, 20000, seed=8)
+    from surel_plus_amd.sampler import DeviceCSR, sample_sets
+    csr = DeviceCSR(ptr_, idx)
+    full = sample_sets(csr, np.arange(3000), num_walks=64, num_steps=3, seed=1, rng="philox", dedup=False)
+    part = sample_sets(csr, np.arange(1000, 1200), num_walks=64, num_steps=3, seed=1, rng="philox", dedup=False)
+    off = full.row_off.cpu().numpy()
+    assert np.array_equal(full.ids.cpu().numpy()[off[1000]:off[1200]], part.ids.cpu().numpy())
+    assert np.array_equal(full.keys.cpu().numpy()[off[1000]:off[1200]], part.keys.cpu().numpy())
+
+
+def test_rand_r_dead_end_is_reported(sp):
+    """A directed graph with a sink: the sequential rand_r stream is not reproducible in parallel -> loud error."""
+    indptr = np.array([0, 2, 3, 3], np.int32)      # node 2 has no out-edges
+    indices = np.array([1, 2, 2], np.int32)
+    with pytest.raises(sp.SubgAccError, match="philox"):
+        sp.gset_sampler(indptr, indices, np.array([0, 1]), num_walks=4, num_steps=3)
+    out = sp.gset_sampler(indptr, indices, np.array([0, 1, 2]), num_walks=4, num_steps=3, rng="philox")
+    ref = oracle.gset_sampler(indptr, indices, np.array([0, 1, 2]), num_walks=4, num_steps=3, rng="philox")
+    for x, y in zip(out, ref):
+        assert np.array_equal(x, y)
+
+
+def test_reference_invariants_at_scale(sp):
+    """subg_acc/test/test.py:34-45 on a 200k-root run (size-independent properties)."""
+    from surel_plus_amd.graphs import powerlaw_graph
+    from surel_plus_amd.sampler import sample_sets
+    csr = powerlaw_graph(200_000, 8.2, seed=0)
+    M, m = 200, 2
+    s = sample_sets(csr, torch.arange(200_000, device="cuda", dtype=torch.int32), num_walks=M, num_steps=m, rng="philox")
+    assert int(s.nsize.sum()) == s.X
+    assert int(s.sf.max()) == s.c - 1
+    enc = s.enc_int16().long()
+    rows = enc[s.sf.long()]
+    assert int((rows[:, 0] == M).sum()) == 200_000
+    seg = torch.repeat_interleave(torch.arange(200_000, device="cuda"), s.nsize.long())
+    colsum = torch.zeros((200_000, m + 1), dtype=torch.int64, device="cuda").index_add_(0, seg, rows)
+    assert bool((colsum == M).all())
+    assert bool((s.ids[s.row_off[:-1]] == torch.arange(200_000, device="cuda", dtype=torch.int32)).all())
+    # members are unique inside a set
+    key = seg * csr.num_nodes + s.ids.long()
+    assert torch.unique(key).numel() == s.X
+
+
+# ------------------------------------------------------------------------------- walk_sampler
+@pytest.mark.parametrize("name", golden_files("walk_"))
+def test_walk_sampler_matches_reference_golden(sp, name):
+    g = _load(name)
+    walks, obj = sp.walk_sampler(g["indptr"], g["indices"], g["query"], num_walks=int(g["M"]), num_steps=int(g["m"]),
+                                 nthread=int(g["nthread"]), seed=int(g["seed"]), replacement=bool(g["replacement"]))
+    assert walks.dtype == np.int32 and np.array_equal(walks, g["walks"])
+    off = np.concatenate([[0], np.cumsum(g["nsize"])])
+    for i in range(len(g["query"])):
+        assert obj[i, 0].dtype == np.int32 and obj[i, 1].dtype == np.int32
+        assert np.array_equal(obj[i, 0], g["ids"][off[i]:off[i + 1]])
+        assert np.array_equal(obj[i, 1], g["counts"][off[i]:off[i + 1]])
+
+
+# --------------------------------------------------------------------------------------- SpG
+@pytest.mark.parametrize("name", golden_files("spg_"))
+def test_spg_build_matches_scipy_golden(sp, name):
+    g = _load(name)
+    from surel_plus_amd.sampler import SampledSets
+    dev = "cuda"
+    nsize = torch.from_numpy(g["nsize"]).to(dev)
+    row_off = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(nsize.long(), 0)])
+    sets = SampledSets(nsize, row_off, torch.from_numpy(g["remap"][0]).to(dev), None,
+                       torch.from_numpy(g["remap"][1]).to(dev), None, 1, 1, int(g["nsize"].max()))
+    z = sp.SpG.from_sets(sets)
+    assert np.array_equal(z.indptr.cpu().numpy(), g["z_indptr"])
+    assert np.array_equal(z.indices.cpu().numpy(), g["z_indices"])
+    assert np.array_equal(z.data.cpu().numpy(), g["z_data"])
+
+
+def test_subg_matrix_end_to_end(sp):
+    g = _load("gset_collablike_s111413.npz")
+    s = _load("spg_collablike_s111413.npz")
+
+    class G:
+        indptr, indices = g["indptr"], g["indices"]
+    z, enc = sp.subg_matrix(G, g["query"], num_walks=int(g["M"]), num_steps=int(g["m"]) + 1, seed=111413)
+    assert np.array_equal(z.indptr.cpu().numpy(), s["z_indptr"])
+    assert np.array_equal(z.indices.cpu().numpy(), s["z_indices"])
+    assert np.array_equal(z.data.cpu().numpy(), s["z_data"])
+    assert enc.dtype == s["encz"].dtype and np.array_equal(enc, s["encz"])
+
+
+# ------------------------------------------------------------------------------------ SpJoin
+def _spg_from_golden(sp, g):
+    data = g["z_data"]
+    data = torch.from_numpy(data.astype(np.float64) if data.dtype.kind == "f" else data.astype(np.int32))
+    return sp.SpG(torch.from_numpy(g["z_indptr"]).cuda(), torch.from_numpy(g["z_indices"]).cuda(), data.cuda())
+
+
+@pytest.mark.parametrize("name", golden_files("sjoin_"))
+@pytest.mark.parametrize("ptr", [True, False])
+def test_gather_matches_reference_golden(sp, name, ptr):
+    g = _load(name)
+    z = _spg_from_golden(sp, g)
+    enc = torch.from_numpy(g["encode"]).cuda() if g["encode"].size else None
+    for fn in (sp.gather, lambda e, x, d, ptr, encode: sp.pgather(e, x, d, encode, sp.bgather, ptr=ptr)):
+        xz, ind = fn(g["edge"], z, "cuda", ptr=ptr, encode=enc)
+        assert xz.dtype == torch.float32 and ind.dtype == torch.int64 and xz.is_cuda and ind.is_cuda
+        assert np.array_equal(xz.cpu().numpy(), g[f"xz_ptr{int(ptr)}"])
+        assert np.array_equal(ind.cpu().numpy(), g[f"ind_ptr{int(ptr)}"])
+    # torch edges (as train.py passes them) give the same answer
+    xz2, _ = sp.gather(torch.from_numpy(g["edge"]), z, "cuda", ptr=ptr, encode=enc)
+    assert np.array_equal(xz2.cpu().numpy(), g[f"xz_ptr{int(ptr)}"])
+
+
+def test_hgather_matches_reference_golden(sp):
+    g = _load("hjoin_int.npz")
+    z = _spg_from_golden(sp, g)
+    xz, ind = sp.hgather(g["hedge"], z, "cuda", encode=torch.from_numpy(g["encode"]).cuda())
+    assert np.array_equal(xz.cpu().numpy(), g["xz"])
+    assert np.array_equal(ind.cpu().numpy(), g["ind"])
+    with pytest.raises(NotImplementedError):
+        sp.hgather(g["hedge"], z, "cuda", encode=None)
+
+
+def test_bgather_blocks(sp):
+    g = _load("sjoin_int.npz")
+    z = _spg_from_golden(sp, g)
+    out = np.empty(4, dtype=object)
+    sp.bgather(g["edge"], z, out)
+    seg, pairs = oracle.sjoin(g["z_indptr"], g["z_indices"], g["z_data"], *oracle.pair_segments(g["edge"]))
+    B = g["edge"].shape[1]
+    assert np.array_equal(np.vstack([out[0], out[1]]), pairs)
+    assert np.array_equal(np.concatenate([out[2], out[3]]), np.diff(seg))
+    assert len(out[2]) == B
+
+
+@pytest.mark.parametrize("payload", ["int", "float"])
+def test_gather_matches_oracle_large(sp, payload):
+    """SpG from a real sampling run (wide sets), 20k pairs incl. (u,u) pairs and repeated endpoints."""
+    ptr_, idx = sym_graph(8000, 60000, seed=2, hubs=2)
+    nsize, remap, enc = oracle.gset_sampler(ptr_, idx, np.arange(8000), num_walks=100, num_steps=3, seed=1, rng="philox",
+                                            nthreads=8)
+    zi, zx, zd = oracle.spg_build(nsize, remap)
+    rng = np.random.default_rng(0)
+    if payload == "float":
+        zd = rng.random(len(zd)) * 0.9 + 0.1
+        table = None
+    else:
+        table = oracle.enc_table(enc).astype(np.float32) / np.float32(100)
+    edge = rng.integers(0, 8000, (2, 20000))
+    edge[1, :50] = edge[0, :50]
+    z = sp.SpG(torch.from_numpy(zi).cuda(), torch.from_numpy(zx).cuda(), torch.from_numpy(zd).cuda())
+    enc_t = torch.from_numpy(table).cuda() if table is not None else None
+    for ptr in (True, False):
+        xz, ind = sp.gather(edge, z, "cuda", ptr=ptr, encode=enc_t)
+        oxz, oind = oracle.gather(edge, (zi, zx, zd), ptr=ptr, encode=table, nthreads=8)
+        assert np.array_equal(xz.cpu().numpy(), oxz)
+        assert np.array_equal(ind.cpu().numpy(), oind)
+
+
+def test_gather_properties_at_scale(sp):
+    """Size-independent properties of SpJoin on a full sampling run: sizes, symmetry, self-join."""
+    from surel_plus_amd.graphs import powerlaw_graph
+    csr = powerlaw_graph(100_000, 8.2, seed=1)
+    z, enc = sp.subg_matrix(csr, torch.arange(100_000, dtype=torch.int32), num_walks=200, num_steps=3, rng="philox")
+    table = torch.from_numpy(enc.astype(np.float32)).cuda() / 200
+    B = 65536
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    edge = torch.randint(0, 100_000, (2, B), device="cuda", generator=gen)
+    xz, ind = sp.gather(edge, z, "cuda", ptr=True, encode=table)
+    lens = z.indptr[1:] - z.indptr[:-1]
+    assert torch.equal(ind[1:] - ind[:-1], torch.cat([lens[edge[0]], lens[edge[1]]]))
+    assert xz.shape == (int(ind[-1]), 2, 3)
+    # swapping the endpoints swaps the two halves of the output
+    xz_s, ind_s = sp.gather(edge.flip(0), z, "cuda", ptr=True, encode=table)
+    mid = int(ind[B])
+    assert torch.equal(xz_s[: xz.shape[0] - mid], xz[mid:]) and torch.equal(xz_s[xz.shape[0] - mid:], xz[:mid])
+    # joining a node with itself: both slots equal; first slot is the node's own feature row
+    uu = torch.stack([edge[0], edge[0]])
+    xz_u, _ = sp.gather(uu, z, "cuda", ptr=True, encode=table)
+    assert torch.equal(xz_u[:, 0], xz_u[:, 1])
+    # the number of rows with a non-zero second slot is the same on both sides (|S_u & S_v|); root rows have
+    # feature[0] = 1 so a present partner is never the zero row
+    nz = (xz[:, 1, :].abs().sum(-1) > 0)
+    segid = torch.repeat_interleave(torch.arange(2 * B, device="cuda"), ind[1:] - ind[:-1])
+    per_seg = torch.zeros(2 * B, dtype=torch.int64, device="cuda").index_add_(0, segid, nz.long())
+    assert torch.equal(per_seg[:B], per_seg[B:])
