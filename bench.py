@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py -- query-pairs/sec of the SubGAcc hot path (sample + SpJoin) on MI355X.
+
+One "step" = one pass of the whole hot path over one batch of B synthetic query pairs that is already
+resident in HBM:   2B endpoint roots -> walk + per-root dedup + LP counts (walk_sets) -> compaction ->
+global unique LP rows -> SpG (segmented sort) -> Z_SF table -> SpJoin producing xz float32 [R,2,k] + indptr.
+Nothing is cached between steps; every step gets fresh pairs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cit2|collab|ppa] [--pairs B]
+
+N>1 is launched by the driver through torch.distributed.run (one rank per GPU); the graph is replicated, the
+pair batches are sharded (each rank its own), there is no data-path collective ("weak" scaling).
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around the walk_sets kernel on its
+launch stream; `cpu_baseline` times the reference's own OpenMP sampler (oracle/_ref, compiled from the
+reference sources in the build container) plus the oracle's C merge join on a bounded sample of the workload.
+"""
+import argparse
+import contextlib
+import json
+import os
+import sys
+import time
+
+os.environ.setdefault("SUBGACC_QUIET", "1")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # name: (graph preset, num_walks M, CLI num_steps k (walk hops m = k-1), description)
+    "cit2": ("cit2", 200, 4, "cit2-like LP: N=2,927,963 avg-deg 20.7 power-law graph, M=200, --num_steps 4 (m=3 hops)"),
+    "collab": ("collab", 200, 3, "collab-like LP: N=235,868 avg-deg 8.2 power-law graph, M=200, --num_steps 3 (m=2 hops)"),
+    "ppa": ("ppa", 200, 4, "ppa-like LP: N=576,289 avg-deg 73.7 power-law graph, M=200, --num_steps 4 (m=3 hops)"),
+}
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+@contextlib.contextmanager
+def quiet_stdout():
+    """The reference extension printf()s statistics; keep them off the JSON line."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(devnull)
+        os.close(saved)
+
+
+class KernelTimer:
+    """HIP events on the launch stream around one kernel (torch's current stream IS the launch stream: the
+    C ABI receives torch.cuda.current_stream().cuda_stream)."""
+
+    def __init__(self):
+        self.pairs = {}
+        self.enabled = False
+
+    @contextlib.contextmanager
+    def __call__(self, name):
+        if not self.enabled:
+            yield
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        yield
+        b.record()
+        self.pairs.setdefault(name, []).append((a, b))
+
+    def mean_ms(self, name):
+        ev = self.pairs.get(name, [])
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None, len(ev)
+
+
+def hot_path_step(sp, csr, edge, M, k, seed, rng):
+    """sample both endpoints of every pair, build the SpG, join.  Returns (xz, indptr, sets)."""
+    from surel_plus_amd.sampler import sample_sets
+    B = edge.shape[1]
+    roots = edge.reshape(-1).to(torch.int32)
+    sets = sample_sets(csr, roots, num_walks=M, num_steps=k - 1, seed=seed, rng=rng)
+    z = sp.SpG.from_sets(sets, n_cols=csr.num_nodes)
+    table = sets.feature_table()
+    rows = torch.arange(2 * B, device=edge.device, dtype=torch.int64).view(2, B)   # row i = root i of this batch
+    xz, ind = sp.gather(rows, z, edge.device, ptr=True, encode=table)
+    return xz, ind, sets
+
+
+def algorithmic_walk_bytes(csr, roots, sets, M, m):
+    """SURVEY.md 8(d), per root: 4 (query) + 8 (indptr pair) + 4*min(deg,M) (first hop) + 12*M*(m-1) (later
+    steps: 8 B indptr pair + 4 B neighbour) + 8*|S_r| (id + SFptr written) + 4 (nsize); int64 offsets: 8->16, 12->20."""
+    ip = csr.indptr
+    deg = (ip[roots.long() + 1] - ip[roots.long()]).long()
+    w = 16 if csr.indptr64 else 8
+    live = deg > 0
+    per = 4 + w + 4 * torch.clamp(deg, max=M) + (w + 4) * M * (m - 1) * live.long() + 4
+    return int(per.sum().item()) + 8 * sets.X
+
+
+def cpu_baseline(csr, edge_all, M, k, target_s=15.0):
+    """Reference (oracle/_ref: the real subg_acc.gset_sampler with its default OpenMP team) + oracle C merge join,
+    on a bounded number of pairs of the same workload.  Rank 0, N=1 only."""
+    import oracle
+    ref = oracle.ref_module()
+    ptr_h = csr.indptr.cpu().numpy()
+    idx_h = csr.indices.cpu().numpy()
+    cores = os.cpu_count() or 1
+    threads = oracle.num_threads()
+
+    def run(B):
+        e = edge_all[:, :B].cpu().numpy()
+        roots = e.reshape(-1).astype(np.int32)
+        t0 = time.perf_counter()
+        with quiet_stdout():
+            if ref is not None and ptr_h.dtype == np.int32:
+                nsize, remap, enc = ref.gset_sampler(ptr_h, idx_h, roots, num_walks=M, num_steps=k - 1)
+            else:
+                nsize, remap, enc = oracle.gset_sampler(ptr_h, idx_h, roots, num_walks=M, num_steps=k - 1, rng="philox",
+                                                        nthreads=threads)
+        t1 = time.perf_counter()
+        spg = oracle.spg_build(nsize, remap)
+        table = oracle.enc_table(enc).astype(np.float32) / np.float32(M)
+        rows = np.arange(2 * B, dtype=np.int64).reshape(2, B)
+        xz, ind = oracle.gather(rows, spg, ptr=True, encode=table, nthreads=threads)
+        t2 = time.perf_counter()
+        return t2 - t0, t1 - t0
+
+    Bmax = edge_all.shape[1]
+    B0 = min(1024, Bmax)
+    t, _ = run(B0)
+    B = int(min(Bmax, max(B0, B0 * target_s / max(t, 1e-6))))
+    if B > B0:
+        t, ts = run(B)
+    else:
+        t, ts = run(B0)
+        B = B0
+    kind = "reference" if (ref is not None and ptr_h.dtype == np.int32) else "port"
+    return {"value": B / t, "unit": "query-pairs/s", "cores": cores, "kind": kind,
+            "sample": f"{B} pairs of the same workload ({2 * B} roots): sampler = "
+                      + ("the reference's subg_acc.gset_sampler (oracle/_ref, OpenMP default team)" if kind == "reference"
+                         else f"oracle C port, {threads} threads")
+                      + f" {ts:.2f}s of {t:.2f}s; SpG build + SpJoin = oracle C port ({threads} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cit2", choices=sorted(WORKLOADS))
+    ap.add_argument("--pairs", type=int, default=65536, help="query pairs per step per GPU")
+    ap.add_argument("--rng", default="philox", choices=["philox", "rand_r"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; invalidates the number)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    import surel_plus_amd as sp
+    from surel_plus_amd import sampler as sampler_mod
+    from surel_plus_amd.graphs import preset_graph, query_pairs
+
+    preset, M, k, desc = WORKLOADS[args.workload]
+    csr = preset_graph(preset, device=dev, scale=args.scale)
+    B, K, W = args.pairs, args.steps, args.warmup
+    # every step's pairs are resident in HBM before the clock starts; ranks and steps get different pairs
+    edges = [query_pairs(csr, B, seed=1000 * rank + s, device=dev) for s in range(K + W)]
+
+    timer = KernelTimer()
+    sampler_mod.KERNEL_TIMER = timer
+    for s in range(W):
+        hot_path_step(sp, csr, edges[s], M, k, seed=s, rng=args.rng)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    rows_total, algo_bytes = 0, 0
+    last = None
+    for s in range(W, W + K):
+        xz, ind, sets = hot_path_step(sp, csr, edges[s], M, k, seed=s, rng=args.rng)
+        last = (edges[s], sets, xz)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        edge, sets, xz = last
+        walk_ms, launches = timer.mean_ms("walk_sets")
+        join_ms, _ = timer.mean_ms("sjoin_fill")
+        abytes = algorithmic_walk_bytes(csr, edge.reshape(-1), sets, M, k - 1)   # the last step's launch
+        achieved = abytes / (walk_ms * 1e-3) / 1e9 if walk_ms else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            tk = f"{args.workload}:{B}:{M}:{k}"
+            traffic = tj.get(tk, {}).get("walk_sets_hbm_bytes_per_launch")
+        out = {
+            "metric": "query-pairs/sec (sample+SpJoin)", "value": world * B * K / elapsed, "unit": "query-pairs/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+            "config": {"workload": desc, "pairs_per_step_per_gpu": B, "roots_per_step_per_gpu": 2 * B,
+                       "num_walks": M, "num_steps_cli": k, "rng": args.rng, "parallelism": f"query-shard x{world}",
+                       "set_members_last_step": sets.X, "distinct_lp_rows_last_step": sets.c,
+                       "xz_rows_last_step": int(xz.shape[0]), "graph_nnz": csr.nnz,
+                       "sjoin_fill_ms": join_ms},
+            "roofline": {"bound": "hbm", "kernel": "walk_sets_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                         "kernel_ms": walk_ms, "launches_timed": launches, "algorithmic_bytes_per_launch": abytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(csr, edges[W], M, k)
+            except Exception as ex:  # the baseline is a report, never a reason to lose the measurement
+                out["cpu_baseline"] = {"value": None, "unit": "query-pairs/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"failed: {type(ex).__name__}: {ex}"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -39,6 +39,8 @@ class SubgAccError(RuntimeError):
 
 
 _lib = None
+# the reference prints "#SubGAcc: ..." statistics to stdout (subg_acc.c:878,1009); SUBGACC_QUIET=1 silences ours
+VERBOSE = os.environ.get("SUBGACC_QUIET", "0") != "1"
 
 
 def build(force=False):

@@ -16,6 +16,22 @@ from ._lib import WalkCfg, check, lib, ptr, stream_ptr
 STAGING_BYTES = 6 << 30
 UNIQ_CAPACITY = 1 << 20
 
+# bench.py sets this to a callable(name) -> context manager that brackets one kernel launch with HIP events
+# on the launch stream (roofline.achieved is measured live, not taken from a profile)
+KERNEL_TIMER = None
+
+
+class _NoTimer:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def _timed(name):
+    return KERNEL_TIMER(name) if KERNEL_TIMER is not None else _NoTimer()
+
 
 class DeviceCSR:
     """Graph CSR resident in HBM: int32 node ids, int32 or int64 row offsets (`indptr64`)."""
@@ -137,11 +153,12 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
         off_chunk = torch.empty(chunk + 1, dtype=torch.int64, device=dev)
     for lo in range(0, n, chunk if chunk else 1):
         cn = min(chunk, n - lo)
-        check(L.subgacc_walk_sets(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn,
-                                  ptr(rng_pos[lo:]) if rng_pos is not None else None,
-                                  ptr(rng_seed[lo:]) if rng_seed is not None else None,
-                                  ptr(st_ids), ptr(st_keys), ptr(nsize[lo:]),
-                                  ptr(walks[lo:]) if walks is not None else None, ptr(flags), st))
+        with _timed("walk_sets"):
+            check(L.subgacc_walk_sets(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn,
+                                      ptr(rng_pos[lo:]) if rng_pos is not None else None,
+                                      ptr(rng_seed[lo:]) if rng_seed is not None else None,
+                                      ptr(st_ids), ptr(st_keys), ptr(nsize[lo:]),
+                                      ptr(walks[lo:]) if walks is not None else None, ptr(flags), st))
         check(L.subgacc_exclusive_scan_i32(ptr(nsize[lo:]), cn, ptr(off_chunk), ptr(scan_ws), scan_ws.numel(), st))
         total = int(off_chunk[cn].item())        # the one host round trip of this chunk
         ids_c = torch.empty(total, dtype=torch.int32, device=dev)
@@ -170,7 +187,7 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
             "out-edges, so the number of draws is data dependent (the reference's graphs are symmetrised, "
             "dataloader.py:122-135). Use rng='philox'.")
     sets = SampledSets(nsize, row_off, ids, keys, None, None, M, m, stride, walks, n_overflow=fl[1])
-    if fl[1]:
+    if fl[1] and _lib.VERBOSE:
         print(f"#SubGAcc: {fl[1]} keys exceed the buffer, try a larger bucket size > {stride}.")
     if dedup:
         dedup_lp_rows(sets, uniq_capacity)

@@ -75,7 +75,8 @@ def subg_matrix(G, train_idx, num_walks=200, num_steps=4, seed=111413, rng="rand
            `torch.from_numpy(xpe).to(device).float() / num_walks` (main.py:174) keeps working.
     `num_steps` is the CLI value: the walks have num_steps-1 hops (random_walks.py:78).
     """
-    print(f'Start sampling for #{len(train_idx)} nodes with {num_walks} {num_steps}-step walks')
+    if _lib.VERBOSE:
+        print(f'Start sampling for #{len(train_idx)} nodes with {num_walks} {num_steps}-step walks')
     csr = G if isinstance(G, DeviceCSR) else DeviceCSR(G.indptr, G.indices, device)
     sets = sample_sets(csr, train_idx, num_walks=num_walks, num_steps=num_steps - 1, seed=seed, rng=rng)
     z = SpG.from_sets(sets, n_cols=csr.num_nodes)

@@ -12,6 +12,7 @@ import torch
 
 from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
+from .sampler import _timed
 from .spg import SpG
 
 _scipy_cache = weakref.WeakKeyDictionary()
@@ -76,9 +77,10 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False):
         enc = encode.to(device=dev, dtype=torch.float32).contiguous()
         k = enc.shape[1]
         out = torch.empty((R, 2, k), dtype=torch.float32, device=dev)
-        check(L.subgacc_sjoin_fill(ptr(spg.indptr), ptr(spg.indices), ptr(spg.data), None, ptr(own), ptr(partner), S,
-                                   ptr(seg), ptr(enc), enc.shape[0], k, ptr(out), None, ptr(segid), spg.max_len,
-                                   ptr(flags), st))
+        with _timed("sjoin_fill"):
+            check(L.subgacc_sjoin_fill(ptr(spg.indptr), ptr(spg.indices), ptr(spg.data), None, ptr(own), ptr(partner), S,
+                                       ptr(seg), ptr(enc), enc.shape[0], k, ptr(out), None, ptr(segid), spg.max_len,
+                                       ptr(flags), st))
     return out, (seg if ptr_mode else segid), flags
 
 

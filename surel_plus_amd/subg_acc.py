@@ -41,7 +41,8 @@ def gset_sampler(indptr, indices, query, num_walks=100, num_steps=3, bucket=-1, 
     remap = torch.stack([sets.ids, sets.sf]).cpu().numpy()
     enc_dev = sets.enc_int16()
     enc = enc_dev.cpu().numpy()
-    print(f"#SubGAcc: #total {sets.X}; #enc_unique {sets.c}; compression ratio {sets.X / max(sets.c, 1):.2f}")
+    if _lib.VERBOSE:
+        print(f"#SubGAcc: #total {sets.X}; #enc_unique {sets.c}; compression ratio {sets.X / max(sets.c, 1):.2f}")
     if debug > 0:
         raw = enc_dev[sets.sf.long()].cpu().numpy()
         return [nsize, remap, enc, raw]
