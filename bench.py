@@ -16,6 +16,7 @@ reference sources in the build container) plus the oracle's C merge join on a bo
 """
 import argparse
 import contextlib
+import ctypes
 import json
 import os
 import sys
@@ -49,6 +50,7 @@ def quiet_stdout():
         yield
     finally:
         sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)      # the C stdio buffer of the extension's printf
         os.dup2(saved, 1)
         os.close(devnull)
         os.close(saved)
