@@ -39,7 +39,8 @@ struct JoinArgs {
     int32_t *flags;
 };
 
-template <bool F64>
+// KV = 4: k == 4, feature rows move as float4 (16-B aligned: k*4 B rows on a 256-B aligned base); KV = 0: any k.
+template <bool F64, int KV>
 __global__ __launch_bounds__(kJoinThreads) void sjoin_fill_kernel(const JoinArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using Val = typename std::conditional<F64, double, int32_t>::type;
@@ -48,57 +49,91 @@ __global__ __launch_bounds__(kJoinThreads) void sjoin_fill_kernel(const JoinArgs
 
     const int64_t j = xcd_item(blockIdx.x, gridDim.x);
     if (j >= a.S) return;
-    const int tid = threadIdx.x;
+    const int lane = threadIdx.x;
     const int64_t ra = a.own[j], rb = a.partner[j];
     const int64_t ab = a.indptr[ra], na = a.indptr[ra + 1] - ab;
     const int64_t bb = a.indptr[rb], nb64 = a.indptr[rb + 1] - bb;
     if (nb64 > a.max_len) {
-        if (tid == 0) atomicOr(&a.flags[3], 1);
+        if (lane == 0) atomicOr(&a.flags[3], 1);
         return;
     }
     const int nb = (int)nb64;
     const Val *data = (const Val *)a.data;
-    for (int r = tid; r < nb; r += kJoinThreads) {
+    for (int r = lane; r < nb; r += kJoinThreads) {   // partner row -> LDS, coalesced
         pids[r] = a.indices[bb + r];
         pval[r] = data[bb + r];
     }
     __syncthreads();
     const int64_t o = a.seg[j];
     const int k = a.k;
-    for (int64_t t = tid; t < na; t += kJoinThreads) {
-        const int32_t id = a.indices[ab + t];
-        const Val va = data[ab + t];
-        int lo = 0, hi = nb;
-        while (lo < hi) {
+    const int k2 = 2 * k;
+    const uint32_t magic = k2 > 0 ? ((1u << 20) + (uint32_t)k2 - 1u) / (uint32_t)k2 : 0u;   // f / k2 for f < 2^11
+
+    for (int64_t t0 = 0; t0 < na; t0 += kJoinThreads) {   // 64 members of the own row per trip, one per lane
+        const int64_t t = t0 + lane;
+        const bool live = t < na;
+        int32_t id = 0;
+        Val va = 0;
+        if (live) {
+            id = a.indices[ab + t];
+            va = data[ab + t];
+        }
+        int lo = 0, hi = live ? nb : 0;
+        while (lo < hi) {   // sorted-set intersection: lower bound in the partner row (LDS)
             const int mid = (lo + hi) >> 1;
             if (pids[mid] < id) lo = mid + 1;
             else hi = mid;
         }
-        const bool hit = lo < nb && pids[lo] == id;
-        const int64_t row = o + t;
+        const bool hit = live && lo < nb && pids[lo] == id;
+        const int64_t row0 = o + t0;
         if (F64) {
-            // the scipy expression computes (partner value or 0) + 1.0 - 1.0 in double, then casts (train.py:33,39-43)
-            const double second = ((hit ? (double)pval[lo] : 0.0) + 1.0) - 1.0;
-            a.out_xz[2 * row] = (float)va;
-            a.out_xz[2 * row + 1] = (float)second;
+            if (live) {
+                // the scipy expression computes (partner value or 0) + 1.0 - 1.0 in double, then casts (train.py:33,39-43)
+                const double second = ((hit ? (double)pval[lo] : 0.0) + 1.0) - 1.0;
+                float2 v;
+                v.x = (float)va;
+                v.y = (float)second;
+                reinterpret_cast<float2 *>(a.out_xz)[row0 + lane] = v;
+            }
         } else {
             int32_t pa = (int32_t)va, pb = hit ? (int32_t)pval[lo] : 0;
-            if (a.out_idx) {
-                a.out_idx[2 * row] = pa;
-                a.out_idx[2 * row + 1] = pb;
+            if (a.out_idx && live) {
+                int2 v;
+                v.x = pa;
+                v.y = pb;
+                reinterpret_cast<int2 *>(a.out_idx)[row0 + lane] = v;
             }
             if (a.out_xz) {
-                if ((uint64_t)pa >= (uint64_t)a.table_rows || (uint64_t)pb >= (uint64_t)a.table_rows) {
+                if (live && ((uint64_t)pa >= (uint64_t)a.table_rows || (uint64_t)pb >= (uint64_t)a.table_rows)) {
                     atomicOr(&a.flags[3], 2);  // SFptr outside the table: never read out of bounds
                     pa = pb = 0;
                 }
-                float *dst = a.out_xz + row * 2 * k;
-                const float *ta = a.table + (int64_t)pa * k, *tb = a.table + (int64_t)pb * k;
-                for (int c = 0; c < k; ++c) dst[c] = ta[c];
-                for (int c = 0; c < k; ++c) dst[k + c] = tb[c];
+                const int nrows = (int)((na - t0) < kJoinThreads ? (na - t0) : kJoinThreads);
+                // the 64 rows of this trip are one contiguous span of the output: write it with consecutive lanes
+                // on consecutive words, fetching each row's (pa, pb) from its owner lane by a wave shuffle
+                if (KV == 4) {
+                    const float4 *tab4 = reinterpret_cast<const float4 *>(a.table);
+                    float4 *dst4 = reinterpret_cast<float4 *>(a.out_xz) + row0 * 2;
+#pragma unroll
+                    for (int rnd = 0; rnd < 2; ++rnd) {
+                        const int f = rnd * kJoinThreads + lane;   // float4 index inside the span
+                        const int r = f >> 1;
+                        const int spa = __shfl(pa, r, kWave), spb = __shfl(pb, r, kWave);
+                        if (r < nrows) dst4[f] = tab4[(f & 1) ? spb : spa];
+                    }
+                } else {
+                    float *dst = a.out_xz + row0 * k2;
+                    const int total = nrows * k2;
+                    for (int f = lane; f < kJoinThreads * k2; f += kJoinThreads) {
+                        const int r = (int)(((uint32_t)f * magic) >> 20);
+                        const int c = f - r * k2;
+                        const int spa = __shfl(pa, r, kWave), spb = __shfl(pb, r, kWave);
+                        if (f < total) dst[f] = a.table[(int64_t)(c < k ? spa : spb) * k + (c < k ? c : c - k)];
+                    }
+                }
             }
         }
-        if (a.out_segid) a.out_segid[row] = j;
+        if (a.out_segid && live) a.out_segid[row0 + lane] = j;
     }
 }
 
@@ -155,20 +190,21 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, const int32_t *spg_
     a.flags = flags;
     const size_t lds = (size_t)a.max_len * (f64 ? 12 : 8);
     SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "sjoin_fill: rows of %d members do not fit LDS", max_len);
+    SG_REQUIRE(k <= 16, SUBGACC_ERR_BADARG, "sjoin_fill: feature width k = %d > 16 is not supported", k);
     const int64_t grid = xcd_grid(S);
     SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_fill: too many segments in one call");
     hipStream_t s = (hipStream_t)stream;
-    if (f64) {
-        if (lds > 64 * 1024)
-            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_fill_kernel<true>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(sjoin_fill_kernel<true>, dim3((unsigned)grid), dim3(kJoinThreads), lds, s, a);
-    } else {
-        if (lds > 64 * 1024)
-            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_fill_kernel<false>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(sjoin_fill_kernel<false>, dim3((unsigned)grid), dim3(kJoinThreads), lds, s, a);
-    }
+#define SG_JOIN_LAUNCH(F, KVV)                                                                                   \
+    do {                                                                                                          \
+        if (lds > 64 * 1024)                                                                                      \
+            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_fill_kernel<F, KVV>,                             \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
+        hipLaunchKernelGGL((sjoin_fill_kernel<F, KVV>), dim3((unsigned)grid), dim3(kJoinThreads), lds, s, a);     \
+    } while (0)
+    if (f64) SG_JOIN_LAUNCH(true, 0);
+    else if (out_xz && k == 4 && ((uintptr_t)table % 16 == 0) && ((uintptr_t)out_xz % 16 == 0)) SG_JOIN_LAUNCH(false, 4);
+    else SG_JOIN_LAUNCH(false, 0);
+#undef SG_JOIN_LAUNCH
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }

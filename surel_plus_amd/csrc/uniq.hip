@@ -52,35 +52,75 @@ __global__ void uniq_reset_kernel(UniqTable t, int64_t cap) {
     }
 }
 
-__global__ __launch_bounds__(256) void uniq_insert_kernel(UniqTable t, const uint64_t *__restrict__ keys, int64_t n,
-                                                           int64_t tag_base, int32_t *flags) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const unsigned long long key = keys[e];
-    const unsigned long long tag = (unsigned long long)(tag_base + e);
+constexpr int kInsItems = 8;
+constexpr int kInsTile = 256 * kInsItems;
+constexpr int kInsLds = 1024;  // block-local table: a tile of 2048 members holds far fewer distinct LP rows
+constexpr uint64_t kMaxProbes = 128;  // a longer chain means the table is over-full: report it, grow, retry
+
+// one global insert: claim-or-find the key's slot, then lower its min position
+__device__ __forceinline__ void uniq_global_insert(const UniqTable &t, unsigned long long key, unsigned long long tag,
+                                                   int32_t *flags) {
     uint64_t h = mix64(key) & t.mask;
-    bool found = false;
-    for (uint64_t probes = 0; probes <= t.mask; ++probes) {
-        // agent-scope (L2) load: another CU may have claimed the slot; its L1 copy here could be stale
+    for (uint64_t probes = 0; probes <= t.mask && probes < kMaxProbes; ++probes) {
+        // agent-scope (L2) load: another CU may have claimed the slot; this CU's L1 copy could be stale
         unsigned long long cur = __hip_atomic_load(&t.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == kEmptyKey) cur = atomicCAS(&t.keys[h], kEmptyKey, key);
         if (cur == kEmptyKey || cur == key) {
-            found = true;
-            break;
+            // the coherent pre-check removes nearly every atomic once the early positions are in
+            if (__hip_atomic_load(&t.mintag[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > tag)
+                atomicMin(&t.mintag[h], tag);
+            return;
         }
         h = (h + 1) & t.mask;
     }
-    if (!found) {
-        atomicOr(&flags[2], 1);
-        return;
+    atomicOr(&flags[2], 1);  // table (nearly) full
+}
+
+
+// The distinct LP rows are 10^2..10^5 while the members are 10^7..10^9, so almost every member repeats a key
+// its neighbours in the tile already carry.  Each block first folds its tile into an LDS table
+// (key -> min position, ds_cmpst_b64 / ds_min_u64) and only the block-distinct keys go to the HBM table:
+// two orders of magnitude fewer global atomics on the hot keys.
+__global__ __launch_bounds__(256) void uniq_insert_kernel(UniqTable t, const uint64_t *__restrict__ keys, int64_t n,
+                                                           int64_t tag_base, int32_t *flags) {
+    __shared__ unsigned long long lk[kInsLds];
+    __shared__ unsigned long long lt[kInsLds];
+    for (int s = threadIdx.x; s < kInsLds; s += 256) {
+        lk[s] = kEmptyKey;
+        lt[s] = ~0ull;
     }
-    // min position; the coherent pre-check removes nearly every atomic once the early positions are in
-    if (__hip_atomic_load(&t.mintag[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > tag) atomicMin(&t.mintag[h], tag);
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kInsTile;
+#pragma unroll
+    for (int k = 0; k < kInsItems; ++k) {
+        const int64_t e = base + (int64_t)k * 256 + threadIdx.x;
+        if (e >= n) continue;
+        const unsigned long long key = keys[e];
+        const unsigned long long tag = (unsigned long long)(tag_base + e);
+        uint32_t h = (uint32_t)(mix64(key) >> 40) & (kInsLds - 1);
+        bool done = false;
+        for (int p = 0; p < 16; ++p) {
+            unsigned long long cur = lk[h];
+            if (cur == kEmptyKey) cur = atomicCAS(&lk[h], kEmptyKey, key);
+            if (cur == kEmptyKey || cur == key) {
+                if (lt[h] > tag) atomicMin(&lt[h], tag);
+                done = true;
+                break;
+            }
+            h = (h + 1) & (kInsLds - 1);
+        }
+        if (!done) uniq_global_insert(t, key, tag, flags);  // crowded neighbourhood: go straight to HBM
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < kInsLds; s += 256)
+        if (lk[s] != kEmptyKey) uniq_global_insert(t, lk[s], lt[s], flags);
 }
 
 __device__ __forceinline__ int32_t uniq_find(const UniqTable &t, unsigned long long key) {
     uint64_t h = mix64(key) & t.mask;
-    while (t.keys[h] != key) h = (h + 1) & t.mask;  // the key was inserted by an earlier launch
+    // the key was inserted by an earlier launch; the probe count is bounded so that a table that overflowed
+    // (flags[2], the caller retries with a larger one) can never hang the wave
+    for (uint64_t probes = 0; probes < kMaxProbes && t.keys[h] != key; ++probes) h = (h + 1) & t.mask;
     return (int32_t)h;
 }
 
@@ -191,7 +231,7 @@ extern "C" int subgacc_uniq_insert(void *table, int64_t capacity, const uint64_t
                SUBGACC_ERR_BADARG, "uniq_insert: bad arguments");
     if (n == 0) return SUBGACC_OK;
     SG_REQUIRE(keys, SUBGACC_ERR_BADARG, "uniq_insert: null keys");
-    const int64_t blocks = ceil_div(n, 256);
+    const int64_t blocks = ceil_div(n, kInsTile);
     SG_REQUIRE(blocks < (1ll << 31), SUBGACC_ERR_BADARG, "uniq_insert: split the call (n too large)");
     hipLaunchKernelGGL(uniq_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        uniq_view(table, capacity), keys, n, tag_base, flags);

@@ -180,22 +180,28 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     ws = torch.empty(L.subgacc_scan_workspace_bytes(n), dtype=torch.uint8, device=dev)
     check(L.subgacc_exclusive_scan_i32(ptr(nsize), n, ptr(row_off), ptr(ws), ws.numel(), st))
 
-    fl = flags.tolist()
+    sets = SampledSets(nsize, row_off, ids, keys, None, None, M, m, stride, walks)
+    if dedup:
+        dedup_lp_rows(sets, uniq_capacity, walk_flags=flags)      # reads the walk flags in its own host sync
+    else:
+        _check_walk_flags(sets, flags.tolist())
+    return sets
+
+
+def _check_walk_flags(sets, fl):
     if fl[0]:
         raise _lib.SubgAccError(
             "rng='rand_r' cannot reproduce the sequential stream on this graph: a walk reached a node without "
             "out-edges, so the number of draws is data dependent (the reference's graphs are symmetrised, "
             "dataloader.py:122-135). Use rng='philox'.")
-    sets = SampledSets(nsize, row_off, ids, keys, None, None, M, m, stride, walks, n_overflow=fl[1])
+    sets.n_overflow = fl[1]
     if fl[1] and _lib.VERBOSE:
-        print(f"#SubGAcc: {fl[1]} keys exceed the buffer, try a larger bucket size > {stride}.")
-    if dedup:
-        dedup_lp_rows(sets, uniq_capacity)
-    return sets
+        print(f"#SubGAcc: {fl[1]} keys exceed the buffer, try a larger bucket size > {sets.stride}.")
 
 
-def dedup_lp_rows(sets, capacity=UNIQ_CAPACITY):
-    """Global first-occurrence dedup of the packed LP rows (subg_acc.c:957-1000) -> sets.sf, sets.ukeys."""
+def dedup_lp_rows(sets, capacity=UNIQ_CAPACITY, walk_flags=None):
+    """Global first-occurrence dedup of the packed LP rows (subg_acc.c:957-1000) -> sets.sf, sets.ukeys.
+    One host sync: the distinct-row count (needed to size the table) and every status flag come back together."""
     L = lib()
     dev = sets.ids.device
     st = stream_ptr()
@@ -203,19 +209,24 @@ def dedup_lp_rows(sets, capacity=UNIQ_CAPACITY):
     sf = torch.empty(X, dtype=torch.int32, device=dev)
     count = torch.zeros(1, dtype=torch.int64, device=dev)
     ws = torch.empty(L.subgacc_uniq_number_workspace_bytes(X), dtype=torch.uint8, device=dev)
+    if walk_flags is None:
+        walk_flags = torch.zeros(4, dtype=torch.int32, device=dev)
     while True:
         flags = torch.zeros(4, dtype=torch.int32, device=dev)
         table = torch.empty(L.subgacc_uniq_table_bytes(capacity), dtype=torch.uint8, device=dev)
         check(L.subgacc_uniq_reset(ptr(table), capacity, st))
         check(L.subgacc_uniq_insert(ptr(table), capacity, ptr(sets.keys), X, 0, ptr(flags), st))
-        if int(flags[2].item()):
-            capacity *= 4           # table full: the distinct-row count exceeded the guess, retry larger
-            continue
         max_unique = min(X, capacity)
         ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
+        # probe chains are bounded in the kernels, so numbering an over-full table is harmless (and discarded)
         check(L.subgacc_uniq_number(ptr(table), capacity, ptr(sets.keys), X, ptr(sf), ptr(ukeys), max_unique, ptr(count),
                                     ptr(ws), ws.numel(), st))
-        c = int(count.item())
+        status = torch.cat([walk_flags.long(), flags.long(), count]).tolist()
+        _check_walk_flags(sets, status[:4])
+        if status[6]:
+            capacity *= 4           # table (nearly) full: the distinct-row count exceeded the guess, retry larger
+            continue
+        c = status[8]
         break
     sets.sf = sf
     sets.ukeys = ukeys[:c].clone()

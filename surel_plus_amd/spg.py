@@ -16,14 +16,17 @@ from .sampler import DeviceCSR, sample_sets
 class SpG:
     """Device CSR of node sets.  `data` is int32 (SFptr+1, LP encoder) or float64 (PPR scores)."""
 
-    def __init__(self, indptr, indices, data, max_len=None, shape=None):
+    def __init__(self, indptr, indices, data, max_len=None, shape=None, max_data=None):
         assert indptr.dtype == torch.int64 and indices.dtype == torch.int32
         assert data.dtype in (torch.int32, torch.float64)
         self.indptr, self.indices, self.data = indptr.contiguous(), indices.contiguous(), data.contiguous()
         self.n_rows = indptr.numel() - 1
         if max_len is None:
             max_len = int((self.indptr[1:] - self.indptr[:-1]).max().item()) if self.n_rows else 0
-        self.max_len = int(max_len)
+        self.max_len = int(max_len)              # upper bound on the row length (sizes the LDS staging of sjoin)
+        if max_data is None and data.dtype == torch.int32:
+            max_data = int(data.max().item()) if data.numel() else 0
+        self.max_data = max_data                 # largest SFptr+1: the encode table must have more rows than this
         self.shape = shape or (self.n_rows, self.n_rows)
         self.device = indptr.device
 
@@ -43,7 +46,7 @@ class SpG:
         flags = torch.zeros(4, dtype=torch.int32, device=dev)
         check(lib().subgacc_spg_build(ptr(sets.row_off), n, ptr(sets.ids), ptr(sets.sf), sets.stride, ptr(indices),
                                       ptr(data), ptr(flags), stream_ptr()))
-        return cls(sets.row_off, indices, data, max_len=sets.stride, shape=(n, n_cols or n))
+        return cls(sets.row_off, indices, data, max_len=sets.stride, shape=(n, n_cols or n), max_data=sets.c)
 
     @classmethod
     def from_scipy(cls, z, device=None):

@@ -280,3 +280,35 @@ def test_gather_properties_at_scale(sp):
     segid = torch.repeat_interleave(torch.arange(2 * B, device="cuda"), ind[1:] - ind[:-1])
     per_seg = torch.zeros(2 * B, dtype=torch.int64, device="cuda").index_add_(0, segid, nz.long())
     assert torch.equal(per_seg[:B], per_seg[B:])
+
+
+def test_unique_table_grows_on_overflow(sp):
+    """A deliberately tiny unique-row table (64 slots) must be detected as over-full and retried larger."""
+    ptr_, idx = sym_graph(3000, 9000, seed=104, hubs=2)
+    from surel_plus_amd.sampler import DeviceCSR, sample_sets
+    s = sample_sets(DeviceCSR(ptr_, idx), np.arange(3000), num_walks=100, num_steps=4, seed=99, uniq_capacity=64)
+    b = oracle.gset_sampler(ptr_, idx, np.arange(3000), num_walks=100, num_steps=4, seed=99)
+    assert s.c > 64
+    assert np.array_equal(torch.stack([s.ids, s.sf]).cpu().numpy(), b[1])
+    assert np.array_equal(s.enc_int16().cpu().numpy(), b[2])
+
+
+def test_encode_table_too_small_raises(sp):
+    g = _load("sjoin_int.npz")
+    z = _spg_from_golden(sp, g)
+    small = torch.from_numpy(g["encode"][:5]).cuda()
+    with pytest.raises(IndexError):
+        sp.gather(g["edge"], z, "cuda", ptr=True, encode=small)
+
+
+@pytest.mark.parametrize("k", [1, 3, 4, 5, 8])
+def test_gather_feature_widths(sp, k):
+    """every feature width goes through the coalesced store path (k = 4 uses the float4 specialisation)."""
+    g = _load("sjoin_int.npz")
+    z = _spg_from_golden(sp, g)
+    rng = np.random.default_rng(k)
+    table = rng.random((int(g["z_data"].max()) + 1, k)).astype(np.float32)
+    table[0] = 0
+    xz, ind = sp.gather(g["edge"], z, "cuda", ptr=True, encode=torch.from_numpy(table).cuda())
+    oxz, oind = oracle.gather(g["edge"], (g["z_indptr"], g["z_indices"], g["z_data"]), ptr=True, encode=table)
+    assert np.array_equal(xz.cpu().numpy(), oxz) and np.array_equal(ind.cpu().numpy(), oind)
