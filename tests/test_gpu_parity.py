@@ -164,7 +164,9 @@ def test_spg_build_matches_scipy_golden(sp, name):
     nsize = torch.from_numpy(g["nsize"]).to(dev)
     row_off = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(nsize.long(), 0)])
     sets = SampledSets(nsize, row_off, torch.from_numpy(g["remap"][0]).to(dev), None,
-                       torch.from_numpy(g["remap"][1]).to(dev), None, 1, 1, int(g["nsize"].max()))
+                       torch.from_numpy(g["remap"][1]).to(dev),
+                       torch.zeros(int(g["remap"][1].max()) + 1, dtype=torch.int64, device=dev), 1, 1,
+                       int(g["nsize"].max()))
     z = sp.SpG.from_sets(sets)
     assert np.array_equal(z.indptr.cpu().numpy(), g["z_indptr"])
     assert np.array_equal(z.indices.cpu().numpy(), g["z_indices"])
@@ -312,3 +314,17 @@ def test_gather_feature_widths(sp, k):
     xz, ind = sp.gather(g["edge"], z, "cuda", ptr=True, encode=torch.from_numpy(table).cuda())
     oxz, oind = oracle.gather(g["edge"], (g["z_indptr"], g["z_indices"], g["z_data"]), ptr=True, encode=table)
     assert np.array_equal(xz.cpu().numpy(), oxz) and np.array_equal(ind.cpu().numpy(), oind)
+
+
+def test_spg_build_long_rows_use_the_bitonic_fallback(sp):
+    """rows above 1024 members (M*m+1 = 1201 here) leave the rank-sort kernel for the bitonic network."""
+    ptr_, idx = sym_graph(4000, 400000, seed=77)
+    q = np.arange(300)
+    nsize, remap, enc = oracle.gset_sampler(ptr_, idx, q, num_walks=300, num_steps=4, seed=3, rng="philox", nthreads=8)
+    assert nsize.max() > 1024
+    from surel_plus_amd.sampler import DeviceCSR, sample_sets
+    s = sample_sets(DeviceCSR(ptr_, idx), q, num_walks=300, num_steps=4, seed=3, rng="philox")
+    z = sp.SpG.from_sets(s)
+    oi, ox, od = oracle.spg_build(nsize, remap)
+    assert np.array_equal(z.indptr.cpu().numpy(), oi) and np.array_equal(z.indices.cpu().numpy(), ox)
+    assert np.array_equal(z.data.cpu().numpy(), od)
