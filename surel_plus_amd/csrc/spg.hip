@@ -4,52 +4,41 @@
 // is a single-threaded global sort.  Here the sets are already grouped by row (one row per root), so the
 // "conversion" is a segmented sort, one wave64 workgroup per row, rows dealt to XCDs in contiguous ranges.
 //
-// Rows hold at most M*m+1 members (<= 801 in every reference configuration) with DISTINCT ids, so the sort
-// is a rank sort: the row's ids sit in LDS, every lane keeps its own <= 16 members in registers and counts
-// how many ids of the row are smaller (broadcast ds_read_b128, 4 ids per LDS instruction, no bank
-// conflicts, no barriers inside the loop); the count IS the output position.  A bitonic network over the
-// same data costs log^2(P)/2 full read+write passes over LDS and was LDS-bandwidth bound (1.16 ms vs
-// the walk kernel's 1.19 ms on the cit2-like batch).  Rows longer than 1024 fall back to the bitonic path.
+// Rows hold at most M*m+1 members (<= 801 in every reference configuration) with DISTINCT ids that are spread
+// over the node range, so the sort is a one-pass bucket sort in LDS: bucket = the top bits of (id - row min)
+// scaled to the row's id range (monotone in id), histogram with ds_add, wave scan over the buckets, scatter
+// with ds_add cursors, and the few members that share a bucket are ordered by counting smaller ids inside
+// it.  O(n) LDS operations per row instead of the log^2(P)/2 full read+write passes of a bitonic network
+// (which was LDS-bandwidth bound: 1.16 ms vs the walk kernel's 1.19 ms on the cit2-like batch; a register
+// rank sort, O(n^2) compares, was slower still at 1.45 ms).  Rows longer than 4096 use the bitonic fallback.
 #include "common.hpp"
 
 namespace subgacc {
 
 constexpr int kSpgThreads = 64;
-constexpr int kRankMaxLen = 16 * kSpgThreads;
+constexpr int kBucketMaxLen = 4096;
+constexpr int kBucketMax = 1024;
 
-// E = members per lane (compile time so that the own ids / counters stay in registers)
-template <int E>
-__device__ __forceinline__ void rank_sort_row(const int32_t *__restrict__ ids_l, int ns, int ns4, int lane,
-                                              const int32_t *__restrict__ sf_row, unsigned long long *out_l) {
-    int32_t x[E];
-    int32_t cnt[E];
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v) {
 #pragma unroll
-    for (int u = 0; u < E; ++u) {
-        const int e = lane + u * kSpgThreads;
-        x[u] = e < ns ? ids_l[e] : 0x7FFFFFFF;
-        cnt[u] = 0;
-    }
-    for (int j = 0; j < ns4; j += 4) {
-        const int4 kk = *reinterpret_cast<const int4 *>(ids_l + j);   // same address in every lane: broadcast
+    for (int d = kWave / 2; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d, kWave));
+    return v;
+}
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
 #pragma unroll
-        for (int u = 0; u < E; ++u)
-            cnt[u] += (kk.x < x[u]) + (kk.y < x[u]) + (kk.z < x[u]) + (kk.w < x[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < E; ++u) {
-        const int e = lane + u * kSpgThreads;
-        if (e < ns) out_l[cnt[u]] = ((unsigned long long)(uint32_t)x[u] << 32) | (uint32_t)(sf_row[e] + 1);
-    }
+    for (int d = kWave / 2; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, kWave));
+    return v;
 }
 
-__global__ __launch_bounds__(kSpgThreads) void spg_rank_kernel(const int64_t *__restrict__ row_off, int64_t n,
-                                                                const int32_t *__restrict__ ids,
-                                                                const int32_t *__restrict__ sf, int32_t cap,
-                                                                int32_t *__restrict__ out_indices,
-                                                                int32_t *__restrict__ out_data, int32_t *flags) {
+__global__ __launch_bounds__(kSpgThreads) void spg_bucket_kernel(const int64_t *__restrict__ row_off, int64_t n,
+                                                                  const int32_t *__restrict__ ids,
+                                                                  const int32_t *__restrict__ sf, int32_t cap,
+                                                                  int32_t bcap, int32_t *__restrict__ out_indices,
+                                                                  int32_t *__restrict__ out_data, int32_t *flags) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    unsigned long long *out_l = (unsigned long long *)lds_raw;   // [cap]   sorted (id, SFptr+1)
-    int32_t *ids_l = (int32_t *)(out_l + cap);                   // [cap+4] the row's ids, padded with INT_MAX
+    unsigned long long *tmp = (unsigned long long *)lds_raw;   // [cap]    members grouped by bucket
+    int32_t *start = (int32_t *)(tmp + cap);                   // [bcap+1] first slot of every bucket
+    int32_t *cursor = start + bcap + 1;                        // [bcap]   histogram, then scatter cursors
     const int64_t i = xcd_item(blockIdx.x, gridDim.x);
     if (i >= n) return;
     const int64_t beg = row_off[i];
@@ -59,29 +48,68 @@ __global__ __launch_bounds__(kSpgThreads) void spg_rank_kernel(const int64_t *__
         return;
     }
     const int ns = (int)ns64, lane = threadIdx.x;
-    const int ns4 = (ns + 3) & ~3;
-    for (int r = lane; r < ns4; r += kSpgThreads) ids_l[r] = r < ns ? ids[beg + r] : 0x7FFFFFFF;
+    if (ns == 0) return;
+    int logb = 0;
+    while ((1 << logb) < ns && (1 << logb) < bcap) ++logb;
+    const int B = 1 << logb;
+    // id range of the row
+    int32_t mn = 0x7FFFFFFF, mx = 0;
+    for (int r = lane; r < ns; r += kSpgThreads) {
+        const int32_t v = ids[beg + r];
+        mn = min(mn, v);
+        mx = max(mx, v);
+    }
+    mn = wave_min_i32(mn);
+    mx = wave_max_i32(mx);
+    const uint32_t range = (uint32_t)(mx - mn) + 1u;
+    // bucket(id) = ((id - mn) << logb) >> Ls with 2^Ls >= range: monotone in id and < B
+    const int Ls = (range <= 1u) ? 0 : (32 - __builtin_clz(range - 1u));
+    for (int b = lane; b < B; b += kSpgThreads) cursor[b] = 0;
     __syncthreads();
-    const int32_t *sf_row = sf + beg;
-    switch ((ns + kSpgThreads - 1) / kSpgThreads) {
-        case 0: break;
-        case 1: rank_sort_row<1>(ids_l, ns, ns4, lane, sf_row, out_l); break;
-        case 2: rank_sort_row<2>(ids_l, ns, ns4, lane, sf_row, out_l); break;
-        case 3: rank_sort_row<3>(ids_l, ns, ns4, lane, sf_row, out_l); break;
-        case 4: rank_sort_row<4>(ids_l, ns, ns4, lane, sf_row, out_l); break;
-        case 5: rank_sort_row<5>(ids_l, ns, ns4, lane, sf_row, out_l); break;
-        case 6: rank_sort_row<6>(ids_l, ns, ns4, lane, sf_row, out_l); break;
-        case 7: rank_sort_row<7>(ids_l, ns, ns4, lane, sf_row, out_l); break;
-        case 8: rank_sort_row<8>(ids_l, ns, ns4, lane, sf_row, out_l); break;
-        case 9: case 10: rank_sort_row<10>(ids_l, ns, ns4, lane, sf_row, out_l); break;
-        case 11: case 12: case 13: rank_sort_row<13>(ids_l, ns, ns4, lane, sf_row, out_l); break;
-        default: rank_sort_row<16>(ids_l, ns, ns4, lane, sf_row, out_l); break;
+    for (int r = lane; r < ns; r += kSpgThreads) {
+        const uint32_t d = (uint32_t)(ids[beg + r] - mn);
+        atomicAdd(&cursor[(uint32_t)(((uint64_t)d << logb) >> Ls)], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the histogram: B/64 consecutive buckets per lane + one wave scan
+    {
+        const int per = (B + kSpgThreads - 1) / kSpgThreads;
+        const int b0 = lane * per;
+        int32_t s = 0;
+        for (int b = b0; b < b0 + per && b < B; ++b) s += cursor[b];
+        int32_t inc = s;
+#pragma unroll
+        for (int dd = 1; dd < kWave; dd <<= 1) {
+            const int32_t t = __shfl_up(inc, dd, kWave);
+            if (lane >= dd) inc += t;
+        }
+        int32_t run = inc - s;
+        for (int b = b0; b < b0 + per && b < B; ++b) {
+            const int32_t c = cursor[b];
+            start[b] = run;
+            cursor[b] = run;
+            run += c;
+        }
+        if (lane == kSpgThreads - 1) start[B] = inc;
     }
     __syncthreads();
     for (int r = lane; r < ns; r += kSpgThreads) {
-        const unsigned long long v = out_l[r];
-        out_indices[beg + r] = (int32_t)(v >> 32);
-        out_data[beg + r] = (int32_t)(uint32_t)v;
+        const int32_t v = ids[beg + r];
+        const uint32_t d = (uint32_t)(v - mn);
+        const int slot = atomicAdd(&cursor[(uint32_t)(((uint64_t)d << logb) >> Ls)], 1);
+        tmp[slot] = ((unsigned long long)(uint32_t)v << 32) | (uint32_t)(sf[beg + r] + 1);
+    }
+    __syncthreads();
+    // order inside a bucket: position = bucket start + number of smaller ids in the bucket
+    for (int s = lane; s < ns; s += kSpgThreads) {
+        const unsigned long long me = tmp[s];
+        const uint32_t d = (uint32_t)((int32_t)(me >> 32) - mn);
+        const uint32_t b = (uint32_t)(((uint64_t)d << logb) >> Ls);
+        const int lo = start[b], hi = start[b + 1];
+        int rank = 0;
+        for (int t = lo; t < hi; ++t) rank += (tmp[t] < me) ? 1 : 0;
+        out_indices[beg + lo + rank] = (int32_t)(me >> 32);
+        out_data[beg + lo + rank] = (int32_t)(uint32_t)me;
     }
 }
 
@@ -141,11 +169,13 @@ extern "C" int subgacc_spg_build(const int64_t *row_off, int64_t n, const int32_
     SG_REQUIRE(row_off && ids && sf && out_indices && out_data, SUBGACC_ERR_BADARG, "spg_build: null argument");
     const int64_t grid = xcd_grid(n);
     SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "spg_build: too many rows in one call");
-    if (max_len <= kRankMaxLen) {
-        const int cap = ((max_len > 0 ? max_len : 1) + 3) & ~3;
-        const size_t lds_rank = (size_t)cap * 8 + (size_t)(cap + 4) * 4;
-        hipLaunchKernelGGL(spg_rank_kernel, dim3((unsigned)grid), dim3(kSpgThreads), lds_rank, (hipStream_t)stream,
-                           row_off, n, ids, sf, cap, out_indices, out_data, flags);
+    if (max_len <= kBucketMaxLen) {
+        const int cap = max_len > 0 ? max_len : 1;
+        int bcap = 64;
+        while (bcap < cap && bcap < kBucketMax) bcap <<= 1;
+        const size_t lds_b = (size_t)cap * 8 + (size_t)(2 * bcap + 1) * 4;
+        hipLaunchKernelGGL(spg_bucket_kernel, dim3((unsigned)grid), dim3(kSpgThreads), lds_b, (hipStream_t)stream,
+                           row_off, n, ids, sf, cap, bcap, out_indices, out_data, flags);
         SG_LAUNCH_CHECK();
         return SUBGACC_OK;
     }

@@ -317,13 +317,14 @@ def test_gather_feature_widths(sp, k):
 
 
 def test_spg_build_long_rows_use_the_bitonic_fallback(sp):
-    """rows above 1024 members (M*m+1 = 1201 here) leave the rank-sort kernel for the bitonic network."""
+    """a row bound above 4096 members leaves the bucket-sort kernel for the bitonic network."""
     ptr_, idx = sym_graph(4000, 400000, seed=77)
     q = np.arange(300)
     nsize, remap, enc = oracle.gset_sampler(ptr_, idx, q, num_walks=300, num_steps=4, seed=3, rng="philox", nthreads=8)
-    assert nsize.max() > 1024
     from surel_plus_amd.sampler import DeviceCSR, sample_sets
     s = sample_sets(DeviceCSR(ptr_, idx), q, num_walks=300, num_steps=4, seed=3, rng="philox")
+    assert np.array_equal(s.nsize.cpu().numpy(), nsize)
+    s.stride = 5000                                   # claim rows of up to 5000 members -> bitonic path
     z = sp.SpG.from_sets(s)
     oi, ox, od = oracle.spg_build(nsize, remap)
     assert np.array_equal(z.indptr.cpu().numpy(), oi) and np.array_equal(z.indices.cpu().numpy(), ox)
