@@ -230,7 +230,8 @@ def main():
                        "num_walks": M, "num_steps_cli": k, "rng": args.rng, "parallelism": f"query-shard x{world}",
                        "set_members_last_step": sets.X, "distinct_lp_rows_last_step": sets.c,
                        "xz_rows_last_step": int(xz.shape[0]), "graph_nnz": csr.nnz,
-                       "sjoin_fill_ms": join_ms},
+                       "stage_ms": {name: timer.mean_ms(name)[0] for name in
+                                    ("walk_sets", "compact_sets", "uniq_rows", "spg_build", "sjoin_fill")}},
             "roofline": {"bound": "hbm", "kernel": "walk_sets_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel_ms": walk_ms, "launches_timed": launches, "algorithmic_bytes_per_launch": abytes},

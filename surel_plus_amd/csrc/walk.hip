@@ -133,7 +133,7 @@ struct WalkArgs {
 };
 
 template <bool IDX64, int RNG>
-__global__ __launch_bounds__(kWalkThreads) void walk_sets_kernel(const WalkArgs a) {
+__global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) void walk_sets_kernel(const WalkArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     unsigned long long *pk = (unsigned long long *)lds_raw;     // [T]
     int32_t *keys = (int32_t *)(pk + a.T);                       // [T]

@@ -163,8 +163,9 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
         total = int(off_chunk[cn].item())        # the one host round trip of this chunk
         ids_c = torch.empty(total, dtype=torch.int32, device=dev)
         keys_c = torch.empty(total, dtype=torch.int64, device=dev)
-        check(L.subgacc_compact_sets(ptr(st_ids), ptr(st_keys), ptr(nsize[lo:]), ptr(off_chunk), cn, stride,
-                                     ptr(ids_c), ptr(keys_c), st))
+        with _timed("compact_sets"):
+            check(L.subgacc_compact_sets(ptr(st_ids), ptr(st_keys), ptr(nsize[lo:]), ptr(off_chunk), cn, stride,
+                                         ptr(ids_c), ptr(keys_c), st))
         ids_parts.append(ids_c)
         key_parts.append(keys_c)
     if len(ids_parts) == 1:
@@ -214,13 +215,14 @@ def dedup_lp_rows(sets, capacity=UNIQ_CAPACITY, walk_flags=None):
     while True:
         flags = torch.zeros(4, dtype=torch.int32, device=dev)
         table = torch.empty(L.subgacc_uniq_table_bytes(capacity), dtype=torch.uint8, device=dev)
-        check(L.subgacc_uniq_reset(ptr(table), capacity, st))
-        check(L.subgacc_uniq_insert(ptr(table), capacity, ptr(sets.keys), X, 0, ptr(flags), st))
         max_unique = min(X, capacity)
         ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
-        # probe chains are bounded in the kernels, so numbering an over-full table is harmless (and discarded)
-        check(L.subgacc_uniq_number(ptr(table), capacity, ptr(sets.keys), X, ptr(sf), ptr(ukeys), max_unique, ptr(count),
-                                    ptr(ws), ws.numel(), st))
+        with _timed("uniq_rows"):
+            check(L.subgacc_uniq_reset(ptr(table), capacity, st))
+            check(L.subgacc_uniq_insert(ptr(table), capacity, ptr(sets.keys), X, 0, ptr(flags), st))
+            # probe chains are bounded in the kernels, so numbering an over-full table is harmless (and discarded)
+            check(L.subgacc_uniq_number(ptr(table), capacity, ptr(sets.keys), X, ptr(sf), ptr(ukeys), max_unique,
+                                        ptr(count), ptr(ws), ws.numel(), st))
         status = torch.cat([walk_flags.long(), flags.long(), count]).tolist()
         _check_walk_flags(sets, status[:4])
         if status[6]:

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
-from .sampler import DeviceCSR, sample_sets
+from .sampler import DeviceCSR, _timed, sample_sets
 
 
 class SpG:
@@ -44,8 +44,9 @@ class SpG:
         indices = torch.empty_like(sets.ids)
         data = torch.empty_like(sets.sf)
         flags = torch.zeros(4, dtype=torch.int32, device=dev)
-        check(lib().subgacc_spg_build(ptr(sets.row_off), n, ptr(sets.ids), ptr(sets.sf), sets.stride, ptr(indices),
-                                      ptr(data), ptr(flags), stream_ptr()))
+        with _timed("spg_build"):
+            check(lib().subgacc_spg_build(ptr(sets.row_off), n, ptr(sets.ids), ptr(sets.sf), sets.stride, ptr(indices),
+                                          ptr(data), ptr(flags), stream_ptr()))
         return cls(sets.row_off, indices, data, max_len=sets.stride, shape=(n, n_cols or n), max_data=sets.c)
 
     @classmethod
