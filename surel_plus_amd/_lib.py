@@ -85,7 +85,7 @@ def lib():
         "subgacc_spg_build": (C.c_int, [vp, i64, vp, vp, i32, vp, vp, vp, vp]),
         "subgacc_sjoin_workspace_bytes": (sz, [i64]),
         "subgacc_sjoin_sizes": (C.c_int, [vp, vp, i64, vp, vp, sz, vp]),
-        "subgacc_sjoin_fill": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, i32, vp, vp]),
+        "subgacc_sjoin_fill": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, i32, i64, vp, vp]),
     }
     assert set(sig) == set(SYMBOLS)
     for name, (res, args) in sig.items():

@@ -39,7 +39,80 @@ struct JoinArgs {
     int32_t *flags;
 };
 
-// KV = 4: k == 4, feature rows move as float4 (16-B aligned: k*4 B rows on a 256-B aligned base); KV = 0: any k.
+// Emit up to 64 consecutive output rows of one segment (one per lane): look the lane's member up in the
+// partner row (binary search over sorted ids held in LDS) and write the feature pairs of the whole 64-row span
+// with consecutive lanes on consecutive words.  KV = 4: k == 4, rows move as float4; KV = 0: any k <= 16.
+template <bool F64, int KV, typename Val>
+__device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int32_t *own_ids, const Val *own_val,
+                                          int64_t na, const int32_t *pids, const Val *pval, int nb, int64_t t0,
+                                          int64_t o, int64_t segj, int k, int k2, uint32_t magic) {
+    const int64_t t = t0 + lane;
+    const bool live = t < na;
+    int32_t id = 0;
+    Val va = 0;
+    if (live) {
+        id = own_ids[t];
+        va = own_val[t];
+    }
+    int lo = 0, hi = live ? nb : 0;
+    while (lo < hi) {   // sorted-set intersection: lower bound in the partner row
+        const int mid = (lo + hi) >> 1;
+        if (pids[mid] < id) lo = mid + 1;
+        else hi = mid;
+    }
+    const bool hit = live && lo < nb && pids[lo] == id;
+    const int64_t row0 = o + t0;
+    if (F64) {
+        if (live) {
+            // the scipy expression computes (partner value or 0) + 1.0 - 1.0 in double, then casts (train.py:33,39-43)
+            const double second = ((hit ? (double)pval[lo] : 0.0) + 1.0) - 1.0;
+            float2 v;
+            v.x = (float)va;
+            v.y = (float)second;
+            reinterpret_cast<float2 *>(a.out_xz)[row0 + lane] = v;
+        }
+    } else {
+        int32_t pa = (int32_t)va, pb = hit ? (int32_t)pval[lo] : 0;
+        if (a.out_idx && live) {
+            int2 v;
+            v.x = pa;
+            v.y = pb;
+            reinterpret_cast<int2 *>(a.out_idx)[row0 + lane] = v;
+        }
+        if (a.out_xz) {
+            if (live && ((uint64_t)pa >= (uint64_t)a.table_rows || (uint64_t)pb >= (uint64_t)a.table_rows)) {
+                atomicOr(&a.flags[3], 2);  // SFptr outside the table: never read out of bounds
+                pa = pb = 0;
+            }
+            const int nrows = (int)((na - t0) < kWave ? (na - t0) : kWave);
+            // the 64 rows of this trip are one contiguous span of the output: fetch each row's (pa, pb) from its
+            // owner lane by a wave shuffle so that stores are fully coalesced
+            if (KV == 4) {
+                const float4 *tab4 = reinterpret_cast<const float4 *>(a.table);
+                float4 *dst4 = reinterpret_cast<float4 *>(a.out_xz) + row0 * 2;
+#pragma unroll
+                for (int rnd = 0; rnd < 2; ++rnd) {
+                    const int f = rnd * kWave + lane;   // float4 index inside the span
+                    const int r = f >> 1;
+                    const int spa = __shfl(pa, r, kWave), spb = __shfl(pb, r, kWave);
+                    if (r < nrows) dst4[f] = tab4[(f & 1) ? spb : spa];
+                }
+            } else {
+                float *dst = a.out_xz + row0 * k2;
+                const int total = nrows * k2;
+                for (int f = lane; f < kWave * k2; f += kWave) {
+                    const int r = (int)(((uint32_t)f * magic) >> 20);
+                    const int c = f - r * k2;
+                    const int spa = __shfl(pa, r, kWave), spb = __shfl(pb, r, kWave);
+                    if (f < total) dst[f] = a.table[(int64_t)(c < k ? spa : spb) * k + (c < k ? c : c - k)];
+                }
+            }
+        }
+    }
+    if (a.out_segid && live) a.out_segid[row0 + lane] = segj;
+}
+
+// generic: one wave64 workgroup per segment, partner row staged in LDS, own row streamed from HBM
 template <bool F64, int KV>
 __global__ __launch_bounds__(kJoinThreads) void sjoin_fill_kernel(const JoinArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -65,75 +138,67 @@ __global__ __launch_bounds__(kJoinThreads) void sjoin_fill_kernel(const JoinArgs
     }
     __syncthreads();
     const int64_t o = a.seg[j];
-    const int k = a.k;
-    const int k2 = 2 * k;
+    const int k = a.k, k2 = 2 * k;
     const uint32_t magic = k2 > 0 ? ((1u << 20) + (uint32_t)k2 - 1u) / (uint32_t)k2 : 0u;   // f / k2 for f < 2^11
+    for (int64_t t0 = 0; t0 < na; t0 += kWave)
+        emit_rows<F64, KV, Val>(a, lane, a.indices + ab, data + ab, na, pids, pval, nb, t0, o, j, k, k2, magic);
+}
 
-    for (int64_t t0 = 0; t0 < na; t0 += kJoinThreads) {   // 64 members of the own row per trip, one per lane
-        const int64_t t = t0 + lane;
-        const bool live = t < na;
-        int32_t id = 0;
-        Val va = 0;
-        if (live) {
-            id = a.indices[ab + t];
-            va = data[ab + t];
+// paired: the segment list consists of blocks of `pb` segments where block 2t+1 mirrors block 2t (own and
+// partner swapped) -- gather's [u.. | v..] and hgather's [U|w ; W|u ; V|w ; W|v].  One 256-lane workgroup takes
+// the segment (A,B) and its mirror (B,A): both SpG rows are read from HBM once into LDS and both output
+// blocks are produced from there (the generic kernel reads every row twice).
+constexpr int kPairThreads = 256;
+template <bool F64, int KV>
+__global__ __launch_bounds__(kPairThreads) void sjoin_pair_kernel(const JoinArgs a, int64_t pb) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    using Val = typename std::conditional<F64, double, int32_t>::type;
+    Val *valA = (Val *)lds_raw;                       // [max_len]
+    Val *valB = valA + a.max_len;                     // [max_len]
+    int32_t *idsA = (int32_t *)(valB + a.max_len);    // [max_len]
+    int32_t *idsB = idsA + a.max_len;                 // [max_len]
+
+    const int64_t p = xcd_item(blockIdx.x, gridDim.x);
+    if (p >= a.S / 2) return;
+    const int64_t j = (p / pb) * 2 * pb + (p % pb), j2 = j + pb;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    const int64_t ra = a.own[j], rb = a.partner[j];
+    if (a.own[j2] != rb || a.partner[j2] != ra) {   // not a mirrored pair: the caller broke the precondition
+        if (tid == 0) atomicOr(&a.flags[3], 4);
+        return;
+    }
+    const int64_t ab = a.indptr[ra], na64 = a.indptr[ra + 1] - ab;
+    const int64_t bb = a.indptr[rb], nb64 = a.indptr[rb + 1] - bb;
+    if (na64 > a.max_len || nb64 > a.max_len) {
+        if (tid == 0) atomicOr(&a.flags[3], 1);
+        return;
+    }
+    const int na = (int)na64, nb = (int)nb64;
+    const Val *data = (const Val *)a.data;
+    for (int r = tid; r < na; r += kPairThreads) {
+        idsA[r] = a.indices[ab + r];
+        valA[r] = data[ab + r];
+    }
+    if (ra != rb) {
+        for (int r = tid; r < nb; r += kPairThreads) {
+            idsB[r] = a.indices[bb + r];
+            valB[r] = data[bb + r];
         }
-        int lo = 0, hi = live ? nb : 0;
-        while (lo < hi) {   // sorted-set intersection: lower bound in the partner row (LDS)
-            const int mid = (lo + hi) >> 1;
-            if (pids[mid] < id) lo = mid + 1;
-            else hi = mid;
-        }
-        const bool hit = live && lo < nb && pids[lo] == id;
-        const int64_t row0 = o + t0;
-        if (F64) {
-            if (live) {
-                // the scipy expression computes (partner value or 0) + 1.0 - 1.0 in double, then casts (train.py:33,39-43)
-                const double second = ((hit ? (double)pval[lo] : 0.0) + 1.0) - 1.0;
-                float2 v;
-                v.x = (float)va;
-                v.y = (float)second;
-                reinterpret_cast<float2 *>(a.out_xz)[row0 + lane] = v;
-            }
-        } else {
-            int32_t pa = (int32_t)va, pb = hit ? (int32_t)pval[lo] : 0;
-            if (a.out_idx && live) {
-                int2 v;
-                v.x = pa;
-                v.y = pb;
-                reinterpret_cast<int2 *>(a.out_idx)[row0 + lane] = v;
-            }
-            if (a.out_xz) {
-                if (live && ((uint64_t)pa >= (uint64_t)a.table_rows || (uint64_t)pb >= (uint64_t)a.table_rows)) {
-                    atomicOr(&a.flags[3], 2);  // SFptr outside the table: never read out of bounds
-                    pa = pb = 0;
-                }
-                const int nrows = (int)((na - t0) < kJoinThreads ? (na - t0) : kJoinThreads);
-                // the 64 rows of this trip are one contiguous span of the output: write it with consecutive lanes
-                // on consecutive words, fetching each row's (pa, pb) from its owner lane by a wave shuffle
-                if (KV == 4) {
-                    const float4 *tab4 = reinterpret_cast<const float4 *>(a.table);
-                    float4 *dst4 = reinterpret_cast<float4 *>(a.out_xz) + row0 * 2;
-#pragma unroll
-                    for (int rnd = 0; rnd < 2; ++rnd) {
-                        const int f = rnd * kJoinThreads + lane;   // float4 index inside the span
-                        const int r = f >> 1;
-                        const int spa = __shfl(pa, r, kWave), spb = __shfl(pb, r, kWave);
-                        if (r < nrows) dst4[f] = tab4[(f & 1) ? spb : spa];
-                    }
-                } else {
-                    float *dst = a.out_xz + row0 * k2;
-                    const int total = nrows * k2;
-                    for (int f = lane; f < kJoinThreads * k2; f += kJoinThreads) {
-                        const int r = (int)(((uint32_t)f * magic) >> 20);
-                        const int c = f - r * k2;
-                        const int spa = __shfl(pa, r, kWave), spb = __shfl(pb, r, kWave);
-                        if (f < total) dst[f] = a.table[(int64_t)(c < k ? spa : spb) * k + (c < k ? c : c - k)];
-                    }
-                }
-            }
-        }
-        if (a.out_segid && live) a.out_segid[row0 + lane] = j;
+    } else {   // (u,u): the second row is the first
+        idsB = idsA;
+        valB = valA;
+    }
+    __syncthreads();
+    const int64_t oA = a.seg[j], oB = a.seg[j2];
+    const int k = a.k, k2 = 2 * k;
+    const uint32_t magic = k2 > 0 ? ((1u << 20) + (uint32_t)k2 - 1u) / (uint32_t)k2 : 0u;
+    const int chunksA = (na + kWave - 1) / kWave, chunksB = (nb + kWave - 1) / kWave;
+    for (int c = wave; c < chunksA + chunksB; c += kPairThreads / kWave) {   // every wave takes whole 64-row spans
+        if (c < chunksA)
+            emit_rows<F64, KV, Val>(a, lane, idsA, valA, na, idsB, valB, nb, (int64_t)c * kWave, oA, j, k, k2, magic);
+        else
+            emit_rows<F64, KV, Val>(a, lane, idsB, valB, nb, idsA, valA, na, (int64_t)(c - chunksA) * kWave, oB, j2, k, k2,
+                                    magic);
     }
 }
 
@@ -165,7 +230,7 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, const int32_t *spg_
                                   const double *spg_data_f64, const int64_t *own, const int64_t *partner, int64_t S,
                                   const int64_t *seg, const float *table, int64_t table_rows, int32_t k,
                                   float *out_xz, int32_t *out_idx, int64_t *out_segid, int32_t max_len,
-                                  int32_t *flags, void *stream) {
+                                  int64_t pair_block, int32_t *flags, void *stream) {
     SG_REQUIRE(S >= 0 && max_len >= 0 && flags, SUBGACC_ERR_BADARG, "sjoin_fill: bad arguments");
     if (S == 0) return SUBGACC_OK;
     SG_REQUIRE(spg_indptr && spg_indices && own && partner && seg, SUBGACC_ERR_BADARG, "sjoin_fill: null argument");
@@ -188,12 +253,32 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, const int32_t *spg_
     a.out_xz = out_xz, a.out_idx = out_idx, a.out_segid = out_segid;
     a.max_len = max_len > 0 ? max_len : 1;
     a.flags = flags;
-    const size_t lds = (size_t)a.max_len * (f64 ? 12 : 8);
+    SG_REQUIRE(pair_block >= 0 && (pair_block == 0 || S % (2 * pair_block) == 0), SUBGACC_ERR_BADARG,
+               "sjoin_fill: S = %lld is not a multiple of 2*pair_block", (long long)S);
+    const bool paired = pair_block > 0;
+    const size_t lds = (size_t)a.max_len * (f64 ? 12 : 8) * (paired ? 2 : 1);
     SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "sjoin_fill: rows of %d members do not fit LDS", max_len);
     SG_REQUIRE(k <= 16, SUBGACC_ERR_BADARG, "sjoin_fill: feature width k = %d > 16 is not supported", k);
-    const int64_t grid = xcd_grid(S);
+    const int64_t grid = xcd_grid(paired ? S / 2 : S);
     SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_fill: too many segments in one call");
     hipStream_t s = (hipStream_t)stream;
+    const bool vec4 = !f64 && out_xz && k == 4 && ((uintptr_t)table % 16 == 0) && ((uintptr_t)out_xz % 16 == 0);
+#define SG_PAIR_LAUNCH(F, KVV)                                                                                   \
+    do {                                                                                                          \
+        if (lds > 64 * 1024)                                                                                      \
+            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<F, KVV>,                             \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
+        hipLaunchKernelGGL((sjoin_pair_kernel<F, KVV>), dim3((unsigned)grid), dim3(kPairThreads), lds, s, a,      \
+                           pair_block);                                                                           \
+    } while (0)
+    if (paired) {
+        if (f64) SG_PAIR_LAUNCH(true, 0);
+        else if (vec4) SG_PAIR_LAUNCH(false, 4);
+        else SG_PAIR_LAUNCH(false, 0);
+        SG_LAUNCH_CHECK();
+        return SUBGACC_OK;
+    }
+#undef SG_PAIR_LAUNCH
 #define SG_JOIN_LAUNCH(F, KVV)                                                                                   \
     do {                                                                                                          \
         if (lds > 64 * 1024)                                                                                      \
@@ -202,7 +287,7 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, const int32_t *spg_
         hipLaunchKernelGGL((sjoin_fill_kernel<F, KVV>), dim3((unsigned)grid), dim3(kJoinThreads), lds, s, a);     \
     } while (0)
     if (f64) SG_JOIN_LAUNCH(true, 0);
-    else if (out_xz && k == 4 && ((uintptr_t)table % 16 == 0) && ((uintptr_t)out_xz % 16 == 0)) SG_JOIN_LAUNCH(false, 4);
+    else if (vec4) SG_JOIN_LAUNCH(false, 4);
     else SG_JOIN_LAUNCH(false, 0);
 #undef SG_JOIN_LAUNCH
     SG_LAUNCH_CHECK();

@@ -21,6 +21,10 @@
 // (root, walk) in O(log k).  SUBGACC_RNG_PHILOX is Philox4x32-10 keyed by (seed; root id, walk, step).
 #include "common.hpp"
 
+#ifndef SG_EXPERIMENT
+#define SG_EXPERIMENT 0
+#endif
+
 namespace subgacc {
 
 constexpr int kWalkThreads = 256;
@@ -230,6 +234,10 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
                 }
                 cur = a.indices[rbeg + pick];
             } else {
+#if SG_EXPERIMENT == 2   // dedup only: no graph reads after the first hop (timing experiment, results are wrong)
+                cur = (int32_t)(((uint32_t)cur * 2654435761u + (uint32_t)w * 40503u + (uint32_t)s) % 2900000u);
+                goto visit;
+#endif
                 int64_t b, d;
                 load_row<IDX64>(a.indptr, cur, b, d);
                 if (d > 0) {
@@ -250,7 +258,14 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
                     atomicOr(&a.flags[0], 1);  // dead end: the sequential stream is no longer reproducible
                 }
             }
+#if SG_EXPERIMENT == 2
+        visit:
+#endif
             if (wrow) wrow[s + 1] = cur;
+#if SG_EXPERIMENT == 1   // traversal only: no dedup (timing experiment, results are wrong)
+            if (cur == -7) atomicAdd(&pk[0], 1ull);
+            continue;
+#endif
             // ---- visit: insert-or-find, first-visit sequence number, landing count
             uint32_t h = ((uint32_t)cur * 2654435761u) >> a.tshift;
             while (true) {

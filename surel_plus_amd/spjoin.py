@@ -42,10 +42,11 @@ def _as_rows(edge, device):
     return torch.from_numpy(np.ascontiguousarray(np.asarray(edge)).astype(np.int64)).to(device)
 
 
-def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False):
+def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pair_block=0):
     """Generic segment join (include/subgacc.h: subgacc_sjoin_sizes + subgacc_sjoin_fill).
 
-    own/partner: int64 device tensors of SpG row numbers, one segment each.
+    own/partner: int64 device tensors of SpG row numbers, one segment each.  pair_block = P > 0 promises that
+    the list is made of blocks of P segments with block 2t+1 the mirror of block 2t (see include/subgacc.h).
     Returns (xz, ind): xz float32 [R,2,k] (or int32 [R,2] index pairs when return_index), ind = int64 [S+1]
     segment pointers (ptr_mode) or int64 [R] segment ids.
     """
@@ -66,12 +67,12 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False):
             raise TypeError("a float-payload SpG is joined without an encode table (train.py:39-43)")
         xz = torch.empty((R, 2, 1), dtype=torch.float32, device=dev)
         check(L.subgacc_sjoin_fill(ptr(spg.indptr), ptr(spg.indices), None, ptr(spg.data), ptr(own), ptr(partner), S,
-                                   ptr(seg), None, 0, 1, ptr(xz), None, ptr(segid), spg.max_len, ptr(flags), st))
+                                   ptr(seg), None, 0, 1, ptr(xz), None, ptr(segid), spg.max_len, pair_block, ptr(flags), st))
         out = xz
     elif return_index:
         out = torch.empty((R, 2), dtype=torch.int32, device=dev)
         check(L.subgacc_sjoin_fill(ptr(spg.indptr), ptr(spg.indices), ptr(spg.data), None, ptr(own), ptr(partner), S,
-                                   ptr(seg), None, 0, 0, None, ptr(out), ptr(segid), spg.max_len, ptr(flags), st))
+                                   ptr(seg), None, 0, 0, None, ptr(out), ptr(segid), spg.max_len, pair_block, ptr(flags), st))
     else:
         if encode is None:
             raise NotImplementedError("an integer SpG needs the encode table")
@@ -83,7 +84,7 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False):
         with _timed("sjoin_fill"):
             check(L.subgacc_sjoin_fill(ptr(spg.indptr), ptr(spg.indices), ptr(spg.data), None, ptr(own), ptr(partner), S,
                                        ptr(seg), ptr(enc), enc.shape[0], k, ptr(out), None, ptr(segid), spg.max_len,
-                                       ptr(flags), st))
+                                       pair_block, ptr(flags), st))
     return out, (seg if ptr_mode else segid), flags
 
 
@@ -108,7 +109,7 @@ def gather(edge, x, device=None, ptr=True, encode=None):
     e = _as_rows(edge, spg.device)
     own = torch.cat([e[0], e[1]])
     partner = torch.cat([e[1], e[0]])
-    return _checked(*sjoin(spg, own, partner, encode, ptr_mode=ptr))
+    return _checked(*sjoin(spg, own, partner, encode, ptr_mode=ptr, pair_block=e.shape[1]))
 
 
 def hgather(hedge, x, device=None, encode=None):
@@ -120,7 +121,7 @@ def hgather(hedge, x, device=None, encode=None):
     u, v, w = h[0], h[1], h[2]
     own = torch.cat([u, w, v, w])
     partner = torch.cat([w, u, w, v])
-    xz, ind = _checked(*sjoin(spg, own, partner, encode, ptr_mode=False))
+    xz, ind = _checked(*sjoin(spg, own, partner, encode, ptr_mode=False, pair_block=h.shape[1]))
     assert xz.size(0) == ind.size(0)
     return xz, ind
 

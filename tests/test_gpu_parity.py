@@ -329,3 +329,27 @@ def test_spg_build_long_rows_use_the_bitonic_fallback(sp):
     oi, ox, od = oracle.spg_build(nsize, remap)
     assert np.array_equal(z.indptr.cpu().numpy(), oi) and np.array_equal(z.indices.cpu().numpy(), ox)
     assert np.array_equal(z.data.cpu().numpy(), od)
+
+
+def test_paired_and_generic_join_kernels_agree(sp):
+    """gather() uses the pair-fused kernel; the generic one-segment-per-wave kernel must give the same bytes."""
+    from surel_plus_amd.graphs import powerlaw_graph
+    from surel_plus_amd.spjoin import sjoin
+    csr = powerlaw_graph(30_000, 12.0, seed=4)
+    z, enc = sp.subg_matrix(csr, torch.arange(30_000, dtype=torch.int32), num_walks=150, num_steps=4, rng="philox")
+    table = torch.from_numpy(enc.astype(np.float32)).cuda() / 150
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    edge = torch.randint(0, 30_000, (2, 5000), device="cuda", generator=gen)
+    edge[1, :20] = edge[0, :20]
+    own, partner = torch.cat([edge[0], edge[1]]), torch.cat([edge[1], edge[0]])
+    for ptr_mode in (True, False):
+        a = sjoin(z, own, partner, table, ptr_mode=ptr_mode, pair_block=0)
+        b = sjoin(z, own, partner, table, ptr_mode=ptr_mode, pair_block=5000)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert int(a[2][3]) == 0 and int(b[2][3]) == 0
+    ia = sjoin(z, own, partner, None, return_index=True, pair_block=0)
+    ib = sjoin(z, own, partner, None, return_index=True, pair_block=5000)
+    assert torch.equal(ia[0], ib[0])
+    # a list that is not mirrored is refused (flag 4), never silently mis-joined
+    bad = sjoin(z, own, own, table, pair_block=5000)
+    assert int(bad[2][3]) & 4
