@@ -353,3 +353,18 @@ def test_paired_and_generic_join_kernels_agree(sp):
     # a list that is not mirrored is refused (flag 4), never silently mis-joined
     bad = sjoin(z, own, own, table, pair_block=5000)
     assert int(bad[2][3]) & 4
+
+
+@pytest.mark.parametrize("k", [3, 4])
+def test_gather_with_a_table_too_large_for_lds(sp, k):
+    """> 32 KB of Z_SF rows: the join reads the table from HBM/L2 instead of its LDS copy."""
+    g = _load("sjoin_int.npz")
+    rng = np.random.default_rng(5)
+    data = rng.integers(1, 20001, g["z_data"].shape).astype(np.int32)
+    table = rng.random((20001, k)).astype(np.float32)
+    table[0] = 0
+    z = sp.SpG(torch.from_numpy(g["z_indptr"]).cuda(), torch.from_numpy(g["z_indices"]).cuda(),
+               torch.from_numpy(data).cuda())
+    xz, ind = sp.gather(g["edge"], z, "cuda", ptr=True, encode=torch.from_numpy(table).cuda())
+    oxz, oind = oracle.gather(g["edge"], (g["z_indptr"], g["z_indices"], data), ptr=True, encode=table)
+    assert np.array_equal(xz.cpu().numpy(), oxz) and np.array_equal(ind.cpu().numpy(), oind)
