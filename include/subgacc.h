@@ -116,18 +116,23 @@ int subgacc_compact_sets(const int32_t *set_ids, const uint64_t *set_keys, const
  * ------------------------------------------------------------------------------------------- */
 size_t subgacc_uniq_table_bytes(int64_t capacity);
 int subgacc_uniq_reset(void *table, int64_t capacity, void *stream);
-/* insert keys[0..n) whose global element positions are tag_base+0..n-1 (the position the element will
- * have in the `keys` array later handed to subgacc_uniq_number); flags[2] |= 1 on a full table */
+/* insert keys[0..n) whose global element positions are tag_base+0..n-1 (the position the element has in the
+ * concatenated `slot` array later handed to subgacc_uniq_number); out_slot[e] (optional) = table slot of
+ * keys[e]; flags[2] |= 1 when the table is (nearly) full */
 int subgacc_uniq_insert(void *table, int64_t capacity, const uint64_t *keys, int64_t n, int64_t tag_base,
-                        int32_t *flags, void *stream);
-/* number the distinct keys by first occurrence and translate every element:
- *   out_sf[e]   int32  index of keys[e]'s row (remap[1] of the reference)
+                        int32_t *out_slot, int32_t *flags, void *stream);
+/* number the distinct keys by first occurrence (ascending minimum position):
  *   out_ukeys[] uint64 the distinct keys in index order (at most max_unique are written)
- *   out_count   int64  number of distinct keys (device scalar) */
-size_t subgacc_uniq_number_workspace_bytes(int64_t n);
-int subgacc_uniq_number(void *table, int64_t capacity, const uint64_t *keys, int64_t n, int32_t *out_sf,
-                        uint64_t *out_ukeys, int64_t max_unique, int64_t *out_count, void *workspace,
+ *   out_count   int64  number of distinct keys (device scalar)
+ * Tables with at most `small_limit` (<=0: 8192) distinct keys are ranked directly; larger ones are numbered by
+ * a scan over the n elements (`slot` = the out_slot of the inserts, positions == tags). */
+size_t subgacc_uniq_number_workspace_bytes(int64_t capacity, int64_t n);
+int subgacc_uniq_number(void *table, int64_t capacity, const int32_t *slot, int64_t n, uint64_t *out_ukeys,
+                        int64_t max_unique, int64_t *out_count, int64_t small_limit, void *workspace,
                         size_t workspace_bytes, void *stream);
+/* slot_inout[e] <- index of the element's key (+add): remap[1] of the reference with add = 0, the SpG payload
+ * SFptr+1 with add = 1 */
+int subgacc_uniq_translate(void *table, int64_t capacity, int32_t *slot_inout, int64_t n, int32_t add, void *stream);
 
 /* Unpack keys to LP rows [n, m+1]: col 0 = M on LEAD rows else 0 (subg_acc.c:751,982-1000).
  * out_i16 / out_i32 / out_f32 may each be NULL; out_f32 is float(count)/float(M) (main.py:174) and,

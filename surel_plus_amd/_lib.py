@@ -22,7 +22,8 @@ SYMBOLS = (
     "subgacc_rng_positions_workspace_bytes", "subgacc_rng_positions", "subgacc_walk_sets",
     "subgacc_scan_workspace_bytes", "subgacc_exclusive_scan_i32", "subgacc_compact_sets",
     "subgacc_uniq_table_bytes", "subgacc_uniq_reset", "subgacc_uniq_insert",
-    "subgacc_uniq_number_workspace_bytes", "subgacc_uniq_number", "subgacc_unpack_lp", "subgacc_spg_build",
+    "subgacc_uniq_number_workspace_bytes", "subgacc_uniq_number", "subgacc_uniq_translate", "subgacc_unpack_lp",
+    "subgacc_spg_build",
     "subgacc_sjoin_workspace_bytes", "subgacc_sjoin_sizes", "subgacc_sjoin_fill",
 )
 
@@ -78,9 +79,10 @@ def lib():
         "subgacc_compact_sets": (C.c_int, [vp, vp, vp, vp, i64, i32, vp, vp, vp]),
         "subgacc_uniq_table_bytes": (sz, [i64]),
         "subgacc_uniq_reset": (C.c_int, [vp, i64, vp]),
-        "subgacc_uniq_insert": (C.c_int, [vp, i64, vp, i64, i64, vp, vp]),
-        "subgacc_uniq_number_workspace_bytes": (sz, [i64]),
-        "subgacc_uniq_number": (C.c_int, [vp, i64, vp, i64, vp, vp, i64, vp, vp, sz, vp]),
+        "subgacc_uniq_insert": (C.c_int, [vp, i64, vp, i64, i64, vp, vp, vp]),
+        "subgacc_uniq_number_workspace_bytes": (sz, [i64, i64]),
+        "subgacc_uniq_number": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, vp, sz, vp]),
+        "subgacc_uniq_translate": (C.c_int, [vp, i64, vp, i64, i32, vp]),
         "subgacc_unpack_lp": (C.c_int, [vp, i64, i32, i32, vp, vp, vp, i32, vp]),
         "subgacc_spg_build": (C.c_int, [vp, i64, vp, vp, i32, vp, vp, vp, vp]),
         "subgacc_sjoin_workspace_bytes": (sz, [i64]),

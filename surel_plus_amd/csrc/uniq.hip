@@ -57,9 +57,9 @@ constexpr int kInsTile = 256 * kInsItems;
 constexpr int kInsLds = 1024;  // block-local table: a tile of 2048 members holds far fewer distinct LP rows
 constexpr uint64_t kMaxProbes = 128;  // a longer chain means the table is over-full: report it, grow, retry
 
-// one global insert: claim-or-find the key's slot, then lower its min position
-__device__ __forceinline__ void uniq_global_insert(const UniqTable &t, unsigned long long key, unsigned long long tag,
-                                                   int32_t *flags) {
+// one global insert: claim-or-find the key's slot, then lower its min position; returns the slot (or -1)
+__device__ __forceinline__ int32_t uniq_global_insert(const UniqTable &t, unsigned long long key, unsigned long long tag,
+                                                      int32_t *flags) {
     uint64_t h = mix64(key) & t.mask;
     for (uint64_t probes = 0; probes <= t.mask && probes < kMaxProbes; ++probes) {
         // agent-scope (L2) load: another CU may have claimed the slot; this CU's L1 copy could be stale
@@ -69,31 +69,36 @@ __device__ __forceinline__ void uniq_global_insert(const UniqTable &t, unsigned 
             // the coherent pre-check removes nearly every atomic once the early positions are in
             if (__hip_atomic_load(&t.mintag[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > tag)
                 atomicMin(&t.mintag[h], tag);
-            return;
+            return (int32_t)h;
         }
         h = (h + 1) & t.mask;
     }
     atomicOr(&flags[2], 1);  // table (nearly) full
+    return -1;
 }
-
 
 // The distinct LP rows are 10^2..10^5 while the members are 10^7..10^9, so almost every member repeats a key
 // its neighbours in the tile already carry.  Each block first folds its tile into an LDS table
 // (key -> min position, ds_cmpst_b64 / ds_min_u64) and only the block-distinct keys go to the HBM table:
-// two orders of magnitude fewer global atomics on the hot keys.
+// two orders of magnitude fewer global atomics on the hot keys.  out_slot[e] (optional) receives the HBM table
+// slot of every member, so that the later passes never probe again.
 __global__ __launch_bounds__(256) void uniq_insert_kernel(UniqTable t, const uint64_t *__restrict__ keys, int64_t n,
-                                                           int64_t tag_base, int32_t *flags) {
+                                                           int64_t tag_base, int32_t *__restrict__ out_slot,
+                                                           int32_t *flags) {
     __shared__ unsigned long long lk[kInsLds];
     __shared__ unsigned long long lt[kInsLds];
+    __shared__ int32_t ls[kInsLds];
     for (int s = threadIdx.x; s < kInsLds; s += 256) {
         lk[s] = kEmptyKey;
         lt[s] = ~0ull;
     }
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * kInsTile;
+    int32_t mine[kInsItems];   // >= 0: LDS slot of the member; < -1: -(global slot)-2; -1: nothing
 #pragma unroll
     for (int k = 0; k < kInsItems; ++k) {
         const int64_t e = base + (int64_t)k * 256 + threadIdx.x;
+        mine[k] = -1;
         if (e >= n) continue;
         const unsigned long long key = keys[e];
         const unsigned long long tag = (unsigned long long)(tag_base + e);
@@ -104,40 +109,82 @@ __global__ __launch_bounds__(256) void uniq_insert_kernel(UniqTable t, const uin
             if (cur == kEmptyKey) cur = atomicCAS(&lk[h], kEmptyKey, key);
             if (cur == kEmptyKey || cur == key) {
                 if (lt[h] > tag) atomicMin(&lt[h], tag);
+                mine[k] = (int32_t)h;
                 done = true;
                 break;
             }
             h = (h + 1) & (kInsLds - 1);
         }
-        if (!done) uniq_global_insert(t, key, tag, flags);  // crowded neighbourhood: go straight to HBM
+        if (!done) {  // crowded neighbourhood: go straight to HBM
+            const int32_t g = uniq_global_insert(t, key, tag, flags);
+            mine[k] = g >= 0 ? -g - 2 : -1;
+        }
     }
     __syncthreads();
     for (int s = threadIdx.x; s < kInsLds; s += 256)
-        if (lk[s] != kEmptyKey) uniq_global_insert(t, lk[s], lt[s], flags);
+        if (lk[s] != kEmptyKey) ls[s] = uniq_global_insert(t, lk[s], lt[s], flags);
+    if (!out_slot) return;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kInsItems; ++k) {
+        const int64_t e = base + (int64_t)k * 256 + threadIdx.x;
+        if (e >= n) continue;
+        const int32_t m = mine[k];
+        out_slot[e] = m >= 0 ? ls[m] : (m < -1 ? -m - 2 : 0);
+    }
 }
 
-__device__ __forceinline__ int32_t uniq_find(const UniqTable &t, unsigned long long key) {
-    uint64_t h = mix64(key) & t.mask;
-    // the key was inserted by an earlier launch; the probe count is bounded so that a table that overflowed
-    // (flags[2], the caller retries with a larger one) can never hang the wave
-    for (uint64_t probes = 0; probes < kMaxProbes && t.keys[h] != key; ++probes) h = (h + 1) & t.mask;
-    return (int32_t)h;
+// ---- numbering: distinct keys ordered by the position of their first occurrence (= ascending mintag)
+// collect the occupied slots
+__global__ __launch_bounds__(256) void uniq_collect_kernel(UniqTable t, int64_t cap, unsigned long long *list_tag,
+                                                            int32_t *list_slot, unsigned long long *count) {
+    const int64_t h = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= cap || t.keys[h] == kEmptyKey) return;
+    const unsigned long long i = atomicAdd(count, 1ull);
+    list_tag[i] = t.mintag[h];
+    list_slot[i] = (int32_t)h;
 }
 
-// pass A: remember each element's table slot (in out_sf, reused as scratch) and count first occurrences per tile
-__global__ __launch_bounds__(kScanThreads) void uniq_count_kernel(UniqTable t, const uint64_t *__restrict__ keys,
-                                                                   int64_t n, int32_t *__restrict__ slot,
-                                                                   int32_t *__restrict__ tile_count) {
+// few distinct rows (the normal case: hundreds..thousands): rank every entry by counting smaller min positions
+__global__ __launch_bounds__(256) void uniq_rank_small_kernel(UniqTable t, const unsigned long long *__restrict__ list_tag,
+                                                               const int32_t *__restrict__ list_slot,
+                                                               const unsigned long long *__restrict__ count,
+                                                               int64_t small_limit, uint64_t *__restrict__ out_ukeys,
+                                                               int64_t max_unique) {
+    __shared__ unsigned long long tile[256];
+    const int64_t c = (int64_t)*count;
+    if (c > small_limit) return;   // the element-scan path numbers large tables
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if ((int64_t)blockIdx.x * 256 >= c) return;
+    const unsigned long long mytag = i < c ? list_tag[i] : ~0ull;
+    int64_t rank = 0;
+    for (int64_t base = 0; base < c; base += 256) {
+        const int64_t u = base + threadIdx.x;
+        tile[threadIdx.x] = u < c ? list_tag[u] : ~0ull;
+        __syncthreads();
+        const int lim = (int)((c - base) < 256 ? (c - base) : 256);
+        for (int x = 0; x < lim; ++x) rank += tile[x] < mytag ? 1 : 0;
+        __syncthreads();
+    }
+    if (i < c) {
+        const int32_t h = list_slot[i];
+        t.id[h] = (int32_t)rank;
+        if (rank < max_unique) out_ukeys[rank] = t.keys[h];
+    }
+}
+
+// many distinct rows: an element is a first occurrence iff the table's min position is its own; an exclusive
+// scan of those flags in element order is the numbering.  pass A: count the flags per tile
+__global__ __launch_bounds__(kScanThreads) void uniq_count_kernel(UniqTable t, const int32_t *__restrict__ slot,
+                                                                   int64_t n, const unsigned long long *__restrict__ count,
+                                                                   int64_t small_limit, int32_t *__restrict__ tile_count) {
+    if ((int64_t)*count <= small_limit) return;
     const int64_t base = (int64_t)blockIdx.x * kUniqTile;
     int32_t cnt = 0;
 #pragma unroll
     for (int k = 0; k < kUniqItems; ++k) {
         const int64_t e = base + (int64_t)k * kScanThreads + threadIdx.x;
-        if (e < n) {
-            const int32_t h = uniq_find(t, keys[e]);
-            slot[e] = h;
-            cnt += (t.mintag[h] == (unsigned long long)e) ? 1 : 0;
-        }
+        if (e < n) cnt += (t.mintag[slot[e]] == (unsigned long long)e) ? 1 : 0;
     }
     int32_t tot;
     block_exclusive_scan<int32_t>(cnt, &tot);
@@ -145,11 +192,13 @@ __global__ __launch_bounds__(kScanThreads) void uniq_count_kernel(UniqTable t, c
 }
 
 // pass B: number the first occurrences in element order
-__global__ __launch_bounds__(kScanThreads) void uniq_assign_kernel(UniqTable t, const uint64_t *__restrict__ keys,
-                                                                    int64_t n, const int32_t *__restrict__ slot,
+__global__ __launch_bounds__(kScanThreads) void uniq_assign_kernel(UniqTable t, const int32_t *__restrict__ slot,
+                                                                    int64_t n, const unsigned long long *__restrict__ count,
+                                                                    int64_t small_limit,
                                                                     const int64_t *__restrict__ tile_off,
                                                                     uint64_t *__restrict__ out_ukeys,
-                                                                    int64_t max_unique, int64_t *out_count) {
+                                                                    int64_t max_unique) {
+    if ((int64_t)*count <= small_limit) return;
     const int64_t base = (int64_t)blockIdx.x * kUniqTile;
     int64_t run = tile_off[blockIdx.x];
     for (int k = 0; k < kUniqItems; ++k) {
@@ -164,17 +213,17 @@ __global__ __launch_bounds__(kScanThreads) void uniq_assign_kernel(UniqTable t, 
         if (flag) {
             const int64_t id = run + ex;
             t.id[h] = (int32_t)id;
-            if (id < max_unique) out_ukeys[id] = keys[e];
+            if (id < max_unique) out_ukeys[id] = t.keys[h];
         }
         run += tot;
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *out_count = run;
 }
 
-// pass C: element -> number of its key
-__global__ __launch_bounds__(256) void uniq_translate_kernel(UniqTable t, int64_t n, int32_t *__restrict__ sf) {
+// element -> number of its key (+add)
+__global__ __launch_bounds__(256) void uniq_translate_kernel(UniqTable t, int64_t n, int32_t *__restrict__ sf,
+                                                              int32_t add) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < n) sf[e] = t.id[sf[e]];
+    if (e < n) sf[e] = t.id[sf[e]] + add;
 }
 
 __global__ void set_i64_kernel(int64_t *p, int64_t v) { *p = v; }
@@ -226,7 +275,7 @@ extern "C" int subgacc_uniq_reset(void *table, int64_t capacity, void *stream) {
 }
 
 extern "C" int subgacc_uniq_insert(void *table, int64_t capacity, const uint64_t *keys, int64_t n, int64_t tag_base,
-                                   int32_t *flags, void *stream) {
+                                   int32_t *out_slot, int32_t *flags, void *stream) {
     SG_REQUIRE(table && is_pow2(capacity) && capacity < (1ll << 31) && flags && n >= 0 && tag_base >= 0,
                SUBGACC_ERR_BADARG, "uniq_insert: bad arguments");
     if (n == 0) return SUBGACC_OK;
@@ -234,47 +283,77 @@ extern "C" int subgacc_uniq_insert(void *table, int64_t capacity, const uint64_t
     const int64_t blocks = ceil_div(n, kInsTile);
     SG_REQUIRE(blocks < (1ll << 31), SUBGACC_ERR_BADARG, "uniq_insert: split the call (n too large)");
     hipLaunchKernelGGL(uniq_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       uniq_view(table, capacity), keys, n, tag_base, flags);
+                       uniq_view(table, capacity), keys, n, tag_base, out_slot, flags);
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }
 
-extern "C" size_t subgacc_uniq_number_workspace_bytes(int64_t n) {
-    if (n < 0) n = 0;
-    const int64_t tiles = ceil_div(n > 0 ? n : 1, kUniqTile);
-    return align_up((size_t)tiles * 4, 256) + align_up((size_t)(tiles + 1) * 8, 256) + scan_workspace_bytes(tiles);
+static size_t number_list_bytes(int64_t capacity) {
+    return align_up((size_t)capacity * 8, 256) + align_up((size_t)capacity * 4, 256);
 }
 
-extern "C" int subgacc_uniq_number(void *table, int64_t capacity, const uint64_t *keys, int64_t n, int32_t *out_sf,
-                                   uint64_t *out_ukeys, int64_t max_unique, int64_t *out_count, void *workspace,
-                                   size_t workspace_bytes, void *stream) {
+extern "C" size_t subgacc_uniq_number_workspace_bytes(int64_t capacity, int64_t n) {
+    if (n < 0) n = 0;
+    if (capacity < 0) capacity = 0;
+    const int64_t tiles = ceil_div(n > 0 ? n : 1, kUniqTile);
+    return number_list_bytes(capacity) + align_up((size_t)tiles * 4, 256) + align_up((size_t)(tiles + 1) * 8, 256) +
+           scan_workspace_bytes(tiles);
+}
+
+extern "C" int subgacc_uniq_number(void *table, int64_t capacity, const int32_t *slot, int64_t n,
+                                   uint64_t *out_ukeys, int64_t max_unique, int64_t *out_count,
+                                   int64_t small_limit, void *workspace, size_t workspace_bytes, void *stream) {
     SG_REQUIRE(table && is_pow2(capacity) && capacity < (1ll << 31) && out_count && n >= 0 && max_unique >= 0,
                SUBGACC_ERR_BADARG, "uniq_number: bad arguments");
-    hipStream_t s = (hipStream_t)stream;
-    if (n == 0) {
-        hipLaunchKernelGGL(set_i64_kernel, dim3(1), dim3(1), 0, s, out_count, (int64_t)0);
-        SG_LAUNCH_CHECK();
-        return SUBGACC_OK;
-    }
-    SG_REQUIRE(keys && out_sf && (out_ukeys || max_unique == 0), SUBGACC_ERR_BADARG, "uniq_number: null argument");
-    SG_REQUIRE(workspace && workspace_bytes >= subgacc_uniq_number_workspace_bytes(n), SUBGACC_ERR_WORKSPACE,
+    SG_REQUIRE(out_ukeys || max_unique == 0, SUBGACC_ERR_BADARG, "uniq_number: null out_ukeys");
+    SG_REQUIRE(workspace && workspace_bytes >= subgacc_uniq_number_workspace_bytes(capacity, n), SUBGACC_ERR_WORKSPACE,
                "uniq_number: workspace too small");
-    const int64_t tiles = ceil_div(n, kUniqTile);
-    SG_REQUIRE(tiles < (1ll << 31), SUBGACC_ERR_BADARG, "uniq_number: n too large");
-    char *ws = (char *)workspace;
-    int32_t *tile_count = (int32_t *)ws;
-    ws += align_up((size_t)tiles * 4, 256);
-    int64_t *tile_off = (int64_t *)ws;
-    ws += align_up((size_t)(tiles + 1) * 8, 256);
+    if (small_limit <= 0) small_limit = 8192;
+    if (small_limit > capacity) small_limit = capacity;
+    SG_REQUIRE(slot || n == 0, SUBGACC_ERR_BADARG, "uniq_number: null slot array");
+    hipStream_t s = (hipStream_t)stream;
     UniqTable t = uniq_view(table, capacity);
-    hipLaunchKernelGGL(uniq_count_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, t, keys, n, out_sf, tile_count);
+    char *ws = (char *)workspace;
+    unsigned long long *list_tag = (unsigned long long *)ws;
+    ws += align_up((size_t)capacity * 8, 256);
+    int32_t *list_slot = (int32_t *)ws;
+    ws += align_up((size_t)capacity * 4, 256);
+    unsigned long long *count = (unsigned long long *)out_count;
+    hipLaunchKernelGGL(set_i64_kernel, dim3(1), dim3(1), 0, s, out_count, (int64_t)0);
+    hipLaunchKernelGGL(uniq_collect_kernel, dim3((unsigned)ceil_div(capacity, 256)), dim3(256), 0, s, t, capacity, list_tag,
+                       list_slot, count);
     SG_LAUNCH_CHECK();
-    int rc = exclusive_scan_i32(tile_count, tiles, tile_off, ws, workspace_bytes - (size_t)(ws - (char *)workspace), s);
-    if (rc != SUBGACC_OK) return rc;
-    hipLaunchKernelGGL(uniq_assign_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, t, keys, n,
-                       (const int32_t *)out_sf, (const int64_t *)tile_off, out_ukeys, max_unique, out_count);
+    hipLaunchKernelGGL(uniq_rank_small_kernel, dim3((unsigned)ceil_div(small_limit, 256)), dim3(256), 0, s, t,
+                       (const unsigned long long *)list_tag, (const int32_t *)list_slot, (const unsigned long long *)count,
+                       small_limit, out_ukeys, max_unique);
     SG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(uniq_translate_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, t, n, out_sf);
+    if (n > 0) {   // the element-scan path: every kernel returns at once unless count > small_limit
+        const int64_t tiles = ceil_div(n, kUniqTile);
+        SG_REQUIRE(tiles < (1ll << 31), SUBGACC_ERR_BADARG, "uniq_number: n too large");
+        int32_t *tile_count = (int32_t *)ws;
+        ws += align_up((size_t)tiles * 4, 256);
+        int64_t *tile_off = (int64_t *)ws;
+        ws += align_up((size_t)(tiles + 1) * 8, 256);
+        hipLaunchKernelGGL(uniq_count_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, t, slot, n,
+                           (const unsigned long long *)count, small_limit, tile_count);
+        SG_LAUNCH_CHECK();
+        int rc = exclusive_scan_i32(tile_count, tiles, tile_off, ws, workspace_bytes - (size_t)(ws - (char *)workspace), s);
+        if (rc != SUBGACC_OK) return rc;
+        hipLaunchKernelGGL(uniq_assign_kernel, dim3((unsigned)tiles), dim3(kScanThreads), 0, s, t, slot, n,
+                           (const unsigned long long *)count, small_limit, (const int64_t *)tile_off, out_ukeys, max_unique);
+        SG_LAUNCH_CHECK();
+    }
+    return SUBGACC_OK;
+}
+
+extern "C" int subgacc_uniq_translate(void *table, int64_t capacity, int32_t *slot_inout, int64_t n, int32_t add,
+                                      void *stream) {
+    SG_REQUIRE(table && is_pow2(capacity) && capacity < (1ll << 31) && n >= 0, SUBGACC_ERR_BADARG,
+               "uniq_translate: bad arguments");
+    if (n == 0) return SUBGACC_OK;
+    SG_REQUIRE(slot_inout, SUBGACC_ERR_BADARG, "uniq_translate: null slot array");
+    hipLaunchKernelGGL(uniq_translate_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       uniq_view(table, capacity), n, slot_inout, add);
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }

@@ -121,7 +121,8 @@ def _as_query(query, device):
 
 def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, rng="rand_r", first_hop_wo=True,
                 order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False, rng_streams=1,
-                calls_before=0, dedup=True, staging_bytes=STAGING_BYTES, uniq_capacity=UNIQ_CAPACITY):
+                calls_before=0, dedup=True, staging_bytes=STAGING_BYTES, uniq_capacity=UNIQ_CAPACITY,
+                uniq_small_limit=0):
     """Run the sampler for `query` (roots) on the GPU.  See SampledSets."""
     L = lib()
     dev = csr.device
@@ -183,7 +184,7 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
 
     sets = SampledSets(nsize, row_off, ids, keys, None, None, M, m, stride, walks)
     if dedup:
-        dedup_lp_rows(sets, uniq_capacity, walk_flags=flags)      # reads the walk flags in its own host sync
+        dedup_lp_rows(sets, uniq_capacity, walk_flags=flags, small_limit=uniq_small_limit)      # reads the walk flags in its own host sync
     else:
         _check_walk_flags(sets, flags.tolist())
     return sets
@@ -200,7 +201,7 @@ def _check_walk_flags(sets, fl):
         print(f"#SubGAcc: {fl[1]} keys exceed the buffer, try a larger bucket size > {sets.stride}.")
 
 
-def dedup_lp_rows(sets, capacity=UNIQ_CAPACITY, walk_flags=None):
+def dedup_lp_rows(sets, capacity=UNIQ_CAPACITY, walk_flags=None, small_limit=0):
     """Global first-occurrence dedup of the packed LP rows (subg_acc.c:957-1000) -> sets.sf, sets.ukeys.
     One host sync: the distinct-row count (needed to size the table) and every status flag come back together."""
     L = lib()
@@ -209,20 +210,21 @@ def dedup_lp_rows(sets, capacity=UNIQ_CAPACITY, walk_flags=None):
     X = sets.X
     sf = torch.empty(X, dtype=torch.int32, device=dev)
     count = torch.zeros(1, dtype=torch.int64, device=dev)
-    ws = torch.empty(L.subgacc_uniq_number_workspace_bytes(X), dtype=torch.uint8, device=dev)
     if walk_flags is None:
         walk_flags = torch.zeros(4, dtype=torch.int32, device=dev)
     while True:
         flags = torch.zeros(4, dtype=torch.int32, device=dev)
         table = torch.empty(L.subgacc_uniq_table_bytes(capacity), dtype=torch.uint8, device=dev)
+        ws = torch.empty(L.subgacc_uniq_number_workspace_bytes(capacity, X), dtype=torch.uint8, device=dev)
         max_unique = min(X, capacity)
         ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
         with _timed("uniq_rows"):
             check(L.subgacc_uniq_reset(ptr(table), capacity, st))
-            check(L.subgacc_uniq_insert(ptr(table), capacity, ptr(sets.keys), X, 0, ptr(flags), st))
+            check(L.subgacc_uniq_insert(ptr(table), capacity, ptr(sets.keys), X, 0, ptr(sf), ptr(flags), st))
             # probe chains are bounded in the kernels, so numbering an over-full table is harmless (and discarded)
-            check(L.subgacc_uniq_number(ptr(table), capacity, ptr(sets.keys), X, ptr(sf), ptr(ukeys), max_unique,
-                                        ptr(count), ptr(ws), ws.numel(), st))
+            check(L.subgacc_uniq_number(ptr(table), capacity, ptr(sf), X, ptr(ukeys), max_unique, ptr(count),
+                                        small_limit, ptr(ws), ws.numel(), st))
+            check(L.subgacc_uniq_translate(ptr(table), capacity, ptr(sf), X, 0, st))
         status = torch.cat([walk_flags.long(), flags.long(), count]).tolist()
         _check_walk_flags(sets, status[:4])
         if status[6]:

@@ -368,3 +368,17 @@ def test_gather_with_a_table_too_large_for_lds(sp, k):
     xz, ind = sp.gather(g["edge"], z, "cuda", ptr=True, encode=torch.from_numpy(table).cuda())
     oxz, oind = oracle.gather(g["edge"], (g["z_indptr"], g["z_indices"], data), ptr=True, encode=table)
     assert np.array_equal(xz.cpu().numpy(), oxz) and np.array_equal(ind.cpu().numpy(), oind)
+
+
+def test_unique_numbering_large_table_path(sp):
+    """force the element-scan numbering (used when the distinct LP rows exceed `small_limit`) and compare it
+    with the direct ranking and with the oracle."""
+    ptr_, idx = sym_graph(3000, 9000, seed=104, hubs=2)
+    from surel_plus_amd.sampler import DeviceCSR, sample_sets
+    csr = DeviceCSR(ptr_, idx)
+    b = oracle.gset_sampler(ptr_, idx, np.arange(3000), num_walks=100, num_steps=4, seed=7)
+    for limit in (0, 16):       # 0 -> default 8192 (direct ranking); 16 -> scan path since c >> 16
+        s = sample_sets(csr, np.arange(3000), num_walks=100, num_steps=4, seed=7, uniq_small_limit=limit)
+        assert s.c > 16
+        assert np.array_equal(torch.stack([s.ids, s.sf]).cpu().numpy(), b[1])
+        assert np.array_equal(s.enc_int16().cpu().numpy(), b[2])

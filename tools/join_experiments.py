@@ -1,0 +1,40 @@
+"""Dev-only: time SpJoin variants on one cit2-like batch (events on the launch stream)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["SUBGACC_QUIET"] = "1"
+import torch
+import surel_plus_amd as sp
+from surel_plus_amd.graphs import preset_graph, query_pairs
+from surel_plus_amd.sampler import sample_sets
+from surel_plus_amd.spjoin import sjoin
+
+csr = preset_graph(sys.argv[1] if len(sys.argv) > 1 else "cit2")
+B = 65536
+edge = query_pairs(csr, B, seed=1)
+sets = sample_sets(csr, edge.reshape(-1).to(torch.int32), num_walks=200, num_steps=3, rng="philox")
+z = sp.SpG.from_sets(sets)
+table = sets.feature_table()
+rows = torch.arange(2 * B, device="cuda").view(2, B)
+own, partner = torch.cat([rows[0], rows[1]]), torch.cat([rows[1], rows[0]])
+
+
+def timeit(fn, n=10):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+R = z.nnz
+print("rows", R, "k", table.shape[1])
+print("paired xz      ms", timeit(lambda: sjoin(z, own, partner, table, pair_block=B)))
+print("generic xz     ms", timeit(lambda: sjoin(z, own, partner, table, pair_block=0)))
+print("paired index   ms", timeit(lambda: sjoin(z, own, partner, None, return_index=True, pair_block=B)))
+print("paired k=1 tab ms", timeit(lambda: sjoin(z, own, partner, table[:, :1].contiguous(), pair_block=B)))
+print("paired k=8 tab ms", timeit(lambda: sjoin(z, own, partner, torch.cat([table, table], 1).contiguous(), pair_block=B)))
+x = torch.empty(R * 8, device="cuda"); 
+print("memset 1.6GB   ms", timeit(lambda: x.zero_()))
+y = torch.empty(R * 8, device="cuda")
+print("copy 1.6GB     ms", timeit(lambda: y.copy_(x)))
