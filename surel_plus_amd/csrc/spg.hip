@@ -10,13 +10,13 @@
 // with ds_add cursors, and the few members that share a bucket are ordered by counting smaller ids inside
 // it.  O(n) LDS operations per row instead of the log^2(P)/2 full read+write passes of a bitonic network
 // (which was LDS-bandwidth bound: 1.16 ms vs the walk kernel's 1.19 ms on the cit2-like batch; a register
-// rank sort, O(n^2) compares, was slower still at 1.45 ms).  Rows longer than 4096 use the bitonic fallback.
+// rank sort, O(n^2) compares, was slower still at 1.45 ms).  Rows longer than 1024 use the bitonic fallback.
 #include "common.hpp"
 
 namespace subgacc {
 
 constexpr int kSpgThreads = 64;
-constexpr int kBucketMaxLen = 4096;
+constexpr int kBucketMaxLen = 1024;   // 16 members per lane in registers
 constexpr int kBucketMax = 1024;
 
 __device__ __forceinline__ int32_t wave_min_i32(int32_t v) {
@@ -30,49 +30,43 @@ __device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
     return v;
 }
 
-__global__ __launch_bounds__(kSpgThreads) void spg_bucket_kernel(const int64_t *__restrict__ row_off, int64_t n,
-                                                                  const int32_t *__restrict__ ids,
-                                                                  const int32_t *__restrict__ sf, int32_t cap,
-                                                                  int32_t bcap, int32_t *__restrict__ out_indices,
-                                                                  int32_t *__restrict__ out_data, int32_t *flags) {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    unsigned long long *tmp = (unsigned long long *)lds_raw;   // [cap]    members grouped by bucket
-    int32_t *start = (int32_t *)(tmp + cap);                   // [bcap+1] first slot of every bucket
-    int32_t *cursor = start + bcap + 1;                        // [bcap]   histogram, then scatter cursors
-    const int64_t i = xcd_item(blockIdx.x, gridDim.x);
-    if (i >= n) return;
-    const int64_t beg = row_off[i];
-    const int64_t ns64 = row_off[i + 1] - beg;
-    if (ns64 > cap) {  // the caller under-stated max_len: refuse the row, never overrun LDS
-        if (threadIdx.x == 0) atomicOr(&flags[3], 1);
-        return;
-    }
-    const int ns = (int)ns64, lane = threadIdx.x;
-    if (ns == 0) return;
-    int logb = 0;
-    while ((1 << logb) < ns && (1 << logb) < bcap) ++logb;
-    const int B = 1 << logb;
-    // id range of the row
+// E = members per lane, compile time so that the row lives in registers: it is read from HBM exactly once
+template <int E>
+__device__ __forceinline__ void bucket_sort_row(const int32_t *__restrict__ ids, const int32_t *__restrict__ sf,
+                                                int64_t beg, int ns, int lane, int bcap, unsigned long long *tmp,
+                                                int32_t *start, int32_t *cursor, int32_t *__restrict__ out_indices,
+                                                int32_t *__restrict__ out_data) {
+    int32_t x[E], v[E];
     int32_t mn = 0x7FFFFFFF, mx = 0;
-    for (int r = lane; r < ns; r += kSpgThreads) {
-        const int32_t v = ids[beg + r];
-        mn = min(mn, v);
-        mx = max(mx, v);
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+        const int r = lane + u * kSpgThreads;
+        x[u] = 0, v[u] = 0;
+        if (r < ns) {
+            x[u] = ids[beg + r];
+            v[u] = sf[beg + r] + 1;
+            mn = min(mn, x[u]);
+            mx = max(mx, x[u]);
+        }
     }
     mn = wave_min_i32(mn);
     mx = wave_max_i32(mx);
+    int logb = 0;
+    while ((1 << logb) < ns && (1 << logb) < bcap) ++logb;
+    const int B = 1 << logb;
     const uint32_t range = (uint32_t)(mx - mn) + 1u;
     // bucket(id) = ((id - mn) << logb) >> Ls with 2^Ls >= range: monotone in id and < B
     const int Ls = (range <= 1u) ? 0 : (32 - __builtin_clz(range - 1u));
     for (int b = lane; b < B; b += kSpgThreads) cursor[b] = 0;
     __syncthreads();
-    for (int r = lane; r < ns; r += kSpgThreads) {
-        const uint32_t d = (uint32_t)(ids[beg + r] - mn);
-        atomicAdd(&cursor[(uint32_t)(((uint64_t)d << logb) >> Ls)], 1);
+    uint32_t bk[E];
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+        bk[u] = (uint32_t)(((uint64_t)(uint32_t)(x[u] - mn) << logb) >> Ls);
+        if (lane + u * kSpgThreads < ns) atomicAdd(&cursor[bk[u]], 1);
     }
     __syncthreads();
-    // exclusive scan of the histogram: B/64 consecutive buckets per lane + one wave scan
-    {
+    {   // exclusive scan of the histogram: B/64 consecutive buckets per lane + one wave scan
         const int per = (B + kSpgThreads - 1) / kSpgThreads;
         const int b0 = lane * per;
         int32_t s = 0;
@@ -93,24 +87,71 @@ __global__ __launch_bounds__(kSpgThreads) void spg_bucket_kernel(const int64_t *
         if (lane == kSpgThreads - 1) start[B] = inc;
     }
     __syncthreads();
-    for (int r = lane; r < ns; r += kSpgThreads) {
-        const int32_t v = ids[beg + r];
-        const uint32_t d = (uint32_t)(v - mn);
-        const int slot = atomicAdd(&cursor[(uint32_t)(((uint64_t)d << logb) >> Ls)], 1);
-        tmp[slot] = ((unsigned long long)(uint32_t)v << 32) | (uint32_t)(sf[beg + r] + 1);
+#pragma unroll
+    for (int u = 0; u < E; ++u)
+        if (lane + u * kSpgThreads < ns) {
+            const int slot = atomicAdd(&cursor[bk[u]], 1);
+            tmp[slot] = ((unsigned long long)(uint32_t)x[u] << 32) | (uint32_t)v[u];
+        }
+    __syncthreads();
+    // order inside a bucket: final position = bucket start + number of smaller ids in the bucket
+    int32_t pos[E];
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+        pos[u] = -1;
+        if (lane + u * kSpgThreads < ns) {
+            const unsigned long long me = ((unsigned long long)(uint32_t)x[u] << 32) | (uint32_t)v[u];
+            const int lo = start[bk[u]], hi = start[bk[u] + 1];
+            int rank = 0;
+            for (int t = lo; t < hi; ++t) rank += (tmp[t] < me) ? 1 : 0;
+            pos[u] = lo + rank;
+        }
     }
     __syncthreads();
-    // order inside a bucket: position = bucket start + number of smaller ids in the bucket
-    for (int s = lane; s < ns; s += kSpgThreads) {
-        const unsigned long long me = tmp[s];
-        const uint32_t d = (uint32_t)((int32_t)(me >> 32) - mn);
-        const uint32_t b = (uint32_t)(((uint64_t)d << logb) >> Ls);
-        const int lo = start[b], hi = start[b + 1];
-        int rank = 0;
-        for (int t = lo; t < hi; ++t) rank += (tmp[t] < me) ? 1 : 0;
-        out_indices[beg + lo + rank] = (int32_t)(me >> 32);
-        out_data[beg + lo + rank] = (int32_t)(uint32_t)me;
+#pragma unroll
+    for (int u = 0; u < E; ++u)
+        if (pos[u] >= 0) tmp[pos[u]] = ((unsigned long long)(uint32_t)x[u] << 32) | (uint32_t)v[u];
+    __syncthreads();
+    for (int r = lane; r < ns; r += kSpgThreads) {   // coalesced write-back of the sorted row
+        const unsigned long long w = tmp[r];
+        out_indices[beg + r] = (int32_t)(w >> 32);
+        out_data[beg + r] = (int32_t)(uint32_t)w;
     }
+}
+
+__global__ __launch_bounds__(kSpgThreads) void spg_bucket_kernel(const int64_t *__restrict__ row_off, int64_t n,
+                                                                  const int32_t *__restrict__ ids,
+                                                                  const int32_t *__restrict__ sf, int32_t cap,
+                                                                  int32_t bcap, int32_t *__restrict__ out_indices,
+                                                                  int32_t *__restrict__ out_data, int32_t *flags) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    unsigned long long *tmp = (unsigned long long *)lds_raw;   // [cap]    members grouped by bucket, then sorted
+    int32_t *start = (int32_t *)(tmp + cap);                   // [bcap+1] first slot of every bucket
+    int32_t *cursor = start + bcap + 1;                        // [bcap]   histogram, then scatter cursors
+    const int64_t i = xcd_item(blockIdx.x, gridDim.x);
+    if (i >= n) return;
+    const int64_t beg = row_off[i];
+    const int64_t ns64 = row_off[i + 1] - beg;
+    if (ns64 > cap) {  // the caller under-stated max_len: refuse the row, never overrun LDS
+        if (threadIdx.x == 0) atomicOr(&flags[3], 1);
+        return;
+    }
+    const int ns = (int)ns64, lane = threadIdx.x;
+#define SG_ROW(EE) bucket_sort_row<EE>(ids, sf, beg, ns, lane, bcap, tmp, start, cursor, out_indices, out_data)
+    const int e = (ns + kSpgThreads - 1) / kSpgThreads;
+    if (e == 0) return;
+    else if (e <= 1) SG_ROW(1);
+    else if (e <= 2) SG_ROW(2);
+    else if (e <= 3) SG_ROW(3);
+    else if (e <= 4) SG_ROW(4);
+    else if (e <= 5) SG_ROW(5);
+    else if (e <= 6) SG_ROW(6);
+    else if (e <= 7) SG_ROW(7);
+    else if (e <= 8) SG_ROW(8);
+    else if (e <= 10) SG_ROW(10);
+    else if (e <= 13) SG_ROW(13);
+    else SG_ROW(16);
+#undef SG_ROW
 }
 
 __global__ __launch_bounds__(kSpgThreads) void spg_build_kernel(const int64_t *__restrict__ row_off, int64_t n,
@@ -173,6 +214,7 @@ extern "C" int subgacc_spg_build(const int64_t *row_off, int64_t n, const int32_
         const int cap = max_len > 0 ? max_len : 1;
         int bcap = 64;
         while (bcap < cap && bcap < kBucketMax) bcap <<= 1;
+        if (bcap > 512) bcap = 512;   // <= 2 members per bucket on average; halves the LDS footprint
         const size_t lds_b = (size_t)cap * 8 + (size_t)(2 * bcap + 1) * 4;
         hipLaunchKernelGGL(spg_bucket_kernel, dim3((unsigned)grid), dim3(kSpgThreads), lds_b, (hipStream_t)stream,
                            row_off, n, ids, sf, cap, bcap, out_indices, out_data, flags);
