@@ -105,9 +105,13 @@ size_t subgacc_scan_workspace_bytes(int64_t n);
 int subgacc_exclusive_scan_i32(const int32_t *in, int64_t n, int64_t *out, void *workspace, size_t workspace_bytes,
                                void *stream);
 
-/* Left-compact the strided per-root sets (subg_acc.c:870-871): row i goes to [row_off[i], +nsize[i]). */
+/* Left-compact the strided per-root sets (subg_acc.c:870-871): row i goes to [row_off[i], +nsize[i]).
+ * out_keys may be NULL when uniq_table is given.  With uniq_table (see below; `uniq_capacity` slots) the pass
+ * also inserts every member's key with position tag_base + row_off[i] + r (subg_acc.c:957-978) and writes the
+ * table slot of every member to out_slot[] -- this replaces a separate subgacc_uniq_insert over out_keys. */
 int subgacc_compact_sets(const int32_t *set_ids, const uint64_t *set_keys, const int32_t *nsize,
                          const int64_t *row_off, int64_t n, int32_t stride, int32_t *out_ids, uint64_t *out_keys,
+                         void *uniq_table, int64_t uniq_capacity, int64_t tag_base, int32_t *out_slot, int32_t *flags,
                          void *stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -142,11 +146,14 @@ int subgacc_unpack_lp(const uint64_t *keys, int64_t n, int32_t num_walks, int32_
 
 /* ---------------------------------------------------------------------------------------------
  * SpG build (sampler/random_walks.py:79-80: scipy COO->CSR): sort each row's members by node id.
- *   out_indices[X] int32 sorted ids, out_data[X] int32 = sf+1.  max_len >= max nsize; a longer row is
+ *   out_indices[X] int32 sorted ids, out_data[X] int32 = sf+1.  With uniq_table != NULL, sf[] holds table slots
+ *   (out_slot of the inserts) and is translated on the fly, after subgacc_uniq_number.
+ *   max_len >= max nsize; a longer row is
  *   left unwritten and flags[3] |= 1 (flags: the int32[4] word array of subgacc_walk_sets).
  * ------------------------------------------------------------------------------------------- */
-int subgacc_spg_build(const int64_t *row_off, int64_t n, const int32_t *ids, const int32_t *sf, int32_t max_len,
-                      int32_t *out_indices, int32_t *out_data, int32_t *flags, void *stream);
+int subgacc_spg_build(const int64_t *row_off, int64_t n, const int32_t *ids, const int32_t *sf,
+                      const void *uniq_table, int64_t uniq_capacity, int32_t max_len, int32_t *out_indices,
+                      int32_t *out_data, int32_t *flags, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * SpJoin (train.py:13-45 gather, :48-72 hgather, :75-111 bgather/pgather).

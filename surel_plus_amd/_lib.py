@@ -76,7 +76,7 @@ def lib():
         "subgacc_walk_sets": (C.c_int, [cfgp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
         "subgacc_scan_workspace_bytes": (sz, [i64]),
         "subgacc_exclusive_scan_i32": (C.c_int, [vp, i64, vp, vp, sz, vp]),
-        "subgacc_compact_sets": (C.c_int, [vp, vp, vp, vp, i64, i32, vp, vp, vp]),
+        "subgacc_compact_sets": (C.c_int, [vp, vp, vp, vp, i64, i32, vp, vp, vp, i64, i64, vp, vp, vp]),
         "subgacc_uniq_table_bytes": (sz, [i64]),
         "subgacc_uniq_reset": (C.c_int, [vp, i64, vp]),
         "subgacc_uniq_insert": (C.c_int, [vp, i64, vp, i64, i64, vp, vp, vp]),
@@ -84,7 +84,7 @@ def lib():
         "subgacc_uniq_number": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, vp, sz, vp]),
         "subgacc_uniq_translate": (C.c_int, [vp, i64, vp, i64, i32, vp]),
         "subgacc_unpack_lp": (C.c_int, [vp, i64, i32, i32, vp, vp, vp, i32, vp]),
-        "subgacc_spg_build": (C.c_int, [vp, i64, vp, vp, i32, vp, vp, vp, vp]),
+        "subgacc_spg_build": (C.c_int, [vp, i64, vp, vp, vp, i64, i32, vp, vp, vp, vp]),
         "subgacc_sjoin_workspace_bytes": (sz, [i64]),
         "subgacc_sjoin_sizes": (C.c_int, [vp, vp, i64, vp, vp, sz, vp]),
         "subgacc_sjoin_fill": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, i32, i64, vp, vp]),

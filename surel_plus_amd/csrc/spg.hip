@@ -16,6 +16,13 @@
 namespace subgacc {
 
 constexpr int kSpgThreads = 64;
+
+// SFptr of a member: sf[e] itself, or -- when the caller passes the table of distinct LP rows -- the number of the
+// table slot stored in sf[e] (saves the separate translate pass over all members)
+__device__ __forceinline__ int32_t sf_of(const int32_t *__restrict__ sf, const int32_t *__restrict__ slot_id, int64_t e) {
+    const int32_t v = sf[e];
+    return slot_id ? slot_id[v] : v;
+}
 constexpr int kBucketMaxLen = 1024;   // 16 members per lane in registers
 constexpr int kBucketMax = 1024;
 
@@ -33,6 +40,7 @@ __device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
 // E = members per lane, compile time so that the row lives in registers: it is read from HBM exactly once
 template <int E>
 __device__ __forceinline__ void bucket_sort_row(const int32_t *__restrict__ ids, const int32_t *__restrict__ sf,
+                                                const int32_t *__restrict__ slot_id,
                                                 int64_t beg, int ns, int lane, int bcap, unsigned long long *tmp,
                                                 int32_t *start, int32_t *cursor, int32_t *__restrict__ out_indices,
                                                 int32_t *__restrict__ out_data) {
@@ -44,7 +52,7 @@ __device__ __forceinline__ void bucket_sort_row(const int32_t *__restrict__ ids,
         x[u] = 0, v[u] = 0;
         if (r < ns) {
             x[u] = ids[beg + r];
-            v[u] = sf[beg + r] + 1;
+            v[u] = sf_of(sf, slot_id, beg + r) + 1;
             mn = min(mn, x[u]);
             mx = max(mx, x[u]);
         }
@@ -121,7 +129,8 @@ __device__ __forceinline__ void bucket_sort_row(const int32_t *__restrict__ ids,
 
 __global__ __launch_bounds__(kSpgThreads) void spg_bucket_kernel(const int64_t *__restrict__ row_off, int64_t n,
                                                                   const int32_t *__restrict__ ids,
-                                                                  const int32_t *__restrict__ sf, int32_t cap,
+                                                                  const int32_t *__restrict__ sf,
+                                                                  const int32_t *__restrict__ slot_id, int32_t cap,
                                                                   int32_t bcap, int32_t *__restrict__ out_indices,
                                                                   int32_t *__restrict__ out_data, int32_t *flags) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(kSpgThreads) void spg_bucket_kernel(const int64_t *
         return;
     }
     const int ns = (int)ns64, lane = threadIdx.x;
-#define SG_ROW(EE) bucket_sort_row<EE>(ids, sf, beg, ns, lane, bcap, tmp, start, cursor, out_indices, out_data)
+#define SG_ROW(EE) bucket_sort_row<EE>(ids, sf, slot_id, beg, ns, lane, bcap, tmp, start, cursor, out_indices, out_data)
     const int e = (ns + kSpgThreads - 1) / kSpgThreads;
     if (e == 0) return;
     else if (e <= 1) SG_ROW(1);
@@ -156,7 +165,8 @@ __global__ __launch_bounds__(kSpgThreads) void spg_bucket_kernel(const int64_t *
 
 __global__ __launch_bounds__(kSpgThreads) void spg_build_kernel(const int64_t *__restrict__ row_off, int64_t n,
                                                                  const int32_t *__restrict__ ids,
-                                                                 const int32_t *__restrict__ sf, int32_t max_pow2,
+                                                                 const int32_t *__restrict__ sf,
+                                                                 const int32_t *__restrict__ slot_id, int32_t max_pow2,
                                                                  int32_t *__restrict__ out_indices,
                                                                  int32_t *__restrict__ out_data, int32_t *flags) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(kSpgThreads) void spg_build_kernel(const int64_t *_
     while (P < ns) P <<= 1;
     const int tid = threadIdx.x;
     for (int r = tid; r < P; r += kSpgThreads)
-        buf[r] = r < ns ? (((unsigned long long)(uint32_t)ids[beg + r] << 32) | (uint32_t)(sf[beg + r] + 1)) : ~0ull;
+        buf[r] = r < ns ? (((unsigned long long)(uint32_t)ids[beg + r] << 32) | (uint32_t)(sf_of(sf, slot_id, beg + r) + 1)) : ~0ull;
     __syncthreads();
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -203,8 +213,11 @@ __global__ __launch_bounds__(kSpgThreads) void spg_build_kernel(const int64_t *_
 using namespace subgacc;
 
 extern "C" int subgacc_spg_build(const int64_t *row_off, int64_t n, const int32_t *ids, const int32_t *sf,
-                                 int32_t max_len, int32_t *out_indices, int32_t *out_data, int32_t *flags,
-                                 void *stream) {
+                                 const void *uniq_table, int64_t uniq_capacity, int32_t max_len, int32_t *out_indices,
+                                 int32_t *out_data, int32_t *flags, void *stream) {
+    // the id column of the table (layout of uniq_table.hpp: keys u64[cap], mintag u64[cap], id i32[cap])
+    const int32_t *slot_id = uniq_table ? (const int32_t *)((const char *)uniq_table + (size_t)uniq_capacity * 16) : nullptr;
+    SG_REQUIRE(!uniq_table || uniq_capacity > 0, SUBGACC_ERR_BADARG, "spg_build: table without capacity");
     SG_REQUIRE(n >= 0 && max_len >= 0 && flags, SUBGACC_ERR_BADARG, "spg_build: bad arguments");
     if (n == 0) return SUBGACC_OK;
     SG_REQUIRE(row_off && ids && sf && out_indices && out_data, SUBGACC_ERR_BADARG, "spg_build: null argument");
@@ -217,7 +230,7 @@ extern "C" int subgacc_spg_build(const int64_t *row_off, int64_t n, const int32_
         if (bcap > 512) bcap = 512;   // <= 2 members per bucket on average; halves the LDS footprint
         const size_t lds_b = (size_t)cap * 8 + (size_t)(2 * bcap + 1) * 4;
         hipLaunchKernelGGL(spg_bucket_kernel, dim3((unsigned)grid), dim3(kSpgThreads), lds_b, (hipStream_t)stream,
-                           row_off, n, ids, sf, cap, bcap, out_indices, out_data, flags);
+                           row_off, n, ids, sf, slot_id, cap, bcap, out_indices, out_data, flags);
         SG_LAUNCH_CHECK();
         return SUBGACC_OK;
     }
@@ -228,7 +241,7 @@ extern "C" int subgacc_spg_build(const int64_t *row_off, int64_t n, const int32_
     if (lds > 64 * 1024)
         SG_CHECK_HIP(hipFuncSetAttribute((const void *)spg_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(spg_build_kernel, dim3((unsigned)grid), dim3(kSpgThreads), lds, (hipStream_t)stream, row_off, n,
-                       ids, sf, P, out_indices, out_data, flags);
+                       ids, sf, slot_id, P, out_indices, out_data, flags);
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }

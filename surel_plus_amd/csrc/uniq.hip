@@ -11,37 +11,9 @@
 //   3. translate: every element reads its key's number.
 #include "common.hpp"
 #include "blockscan.hpp"
+#include "uniq_table.hpp"
 
 namespace subgacc {
-
-constexpr uint64_t kEmptyKey = ~0ull;
-constexpr int kUniqItems = 4;  // elements per thread in the numbering passes
-constexpr int kUniqTile = kScanThreads * kUniqItems;
-
-struct UniqTable {
-    unsigned long long *keys;    // [cap]
-    unsigned long long *mintag;  // [cap]
-    int32_t *id;                 // [cap]
-    uint64_t mask;
-};
-
-__host__ __device__ inline UniqTable uniq_view(void *table, int64_t cap) {
-    UniqTable t;
-    t.keys = (unsigned long long *)table;
-    t.mintag = t.keys + cap;
-    t.id = (int32_t *)(t.mintag + cap);
-    t.mask = (uint64_t)cap - 1;
-    return t;
-}
-
-__device__ __forceinline__ uint64_t mix64(uint64_t x) {
-    x ^= x >> 33;
-    x *= 0xff51afd7ed558ccdULL;
-    x ^= x >> 33;
-    x *= 0xc4ceb9fe1a85ec53ULL;
-    x ^= x >> 33;
-    return x;
-}
 
 __global__ void uniq_reset_kernel(UniqTable t, int64_t cap) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -50,31 +22,6 @@ __global__ void uniq_reset_kernel(UniqTable t, int64_t cap) {
         t.mintag[i] = ~0ull;
         t.id[i] = -1;
     }
-}
-
-constexpr int kInsItems = 8;
-constexpr int kInsTile = 256 * kInsItems;
-constexpr int kInsLds = 1024;  // block-local table: a tile of 2048 members holds far fewer distinct LP rows
-constexpr uint64_t kMaxProbes = 128;  // a longer chain means the table is over-full: report it, grow, retry
-
-// one global insert: claim-or-find the key's slot, then lower its min position; returns the slot (or -1)
-__device__ __forceinline__ int32_t uniq_global_insert(const UniqTable &t, unsigned long long key, unsigned long long tag,
-                                                      int32_t *flags) {
-    uint64_t h = mix64(key) & t.mask;
-    for (uint64_t probes = 0; probes <= t.mask && probes < kMaxProbes; ++probes) {
-        // agent-scope (L2) load: another CU may have claimed the slot; this CU's L1 copy could be stale
-        unsigned long long cur = __hip_atomic_load(&t.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cur == kEmptyKey) cur = atomicCAS(&t.keys[h], kEmptyKey, key);
-        if (cur == kEmptyKey || cur == key) {
-            // the coherent pre-check removes nearly every atomic once the early positions are in
-            if (__hip_atomic_load(&t.mintag[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > tag)
-                atomicMin(&t.mintag[h], tag);
-            return (int32_t)h;
-        }
-        h = (h + 1) & t.mask;
-    }
-    atomicOr(&flags[2], 1);  // table (nearly) full
-    return -1;
 }
 
 // The distinct LP rows are 10^2..10^5 while the members are 10^7..10^9, so almost every member repeats a key

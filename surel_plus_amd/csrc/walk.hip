@@ -20,6 +20,7 @@
 // nthread=1): the LCG x -> a*x+c is affine, so a lane jumps straight to the stream position of its
 // (root, walk) in O(log k).  SUBGACC_RNG_PHILOX is Philox4x32-10 keyed by (seed; root id, walk, step).
 #include "common.hpp"
+#include "uniq_table.hpp"
 
 #ifndef SG_EXPERIMENT
 #define SG_EXPERIMENT 0
@@ -310,21 +311,81 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
 }
 
 // ------------------------------------------------------------------------------- compaction
-// one wave per root: copy its members from the strided staging area to the packed arrays
-__global__ __launch_bounds__(256) void compact_sets_kernel(const int32_t *__restrict__ set_ids,
-                                                            const uint64_t *__restrict__ set_keys,
-                                                            const int32_t *__restrict__ nsize,
-                                                            const int64_t *__restrict__ row_off, int64_t n,
-                                                            int32_t stride, int32_t *__restrict__ out_ids,
-                                                            uint64_t *__restrict__ out_keys) {
-    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / kWave;
-    if (i >= n) return;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int ns = nsize[i];
-    const int64_t src = i * (int64_t)stride, dst = row_off[i];
+// One wave per root: copy its members from the strided staging area to the packed arrays (subg_acc.c:870-871).
+// INSERT: the same pass also registers every member's LP key in the HBM table of distinct rows
+// (subg_acc.c:957-978) -- the keys of one set are folded in a wave-private LDS table first (a set of ~400
+// members carries a few dozen distinct rows), only those go to HBM, and out_slot[] receives the table slot of
+// every member, so no later pass touches the 8-byte keys again.
+constexpr int kCompactThreads = 256;
+constexpr int kCompactWaves = kCompactThreads / kWave;
+constexpr int kFoldSlots = 256;   // per-wave LDS table
+
+template <bool INSERT>
+__global__ __launch_bounds__(kCompactThreads) void compact_sets_kernel(
+    const int32_t *__restrict__ set_ids, const uint64_t *__restrict__ set_keys, const int32_t *__restrict__ nsize,
+    const int64_t *__restrict__ row_off, int64_t n, int32_t stride, int32_t *__restrict__ out_ids,
+    uint64_t *__restrict__ out_keys, UniqTable t, int64_t tag_base, int32_t *__restrict__ out_slot, int32_t *flags) {
+    __shared__ unsigned long long lk[INSERT ? kCompactWaves * kFoldSlots : 1];
+    __shared__ unsigned long long lt[INSERT ? kCompactWaves * kFoldSlots : 1];
+    __shared__ int32_t ls[INSERT ? kCompactWaves * kFoldSlots : 1];
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    const int64_t i = (int64_t)blockIdx.x * kCompactWaves + wave;
+    const int ns = i < n ? nsize[i] : 0;
+    const int64_t src = i * (int64_t)stride, dst = i < n ? row_off[i] : 0;
+    if (!INSERT) {
+        for (int r = lane; r < ns; r += kWave) {
+            out_ids[dst + r] = set_ids[src + r];
+            out_keys[dst + r] = set_keys[src + r];
+        }
+        return;
+    }
+    unsigned long long *wk = lk + wave * kFoldSlots, *wt = lt + wave * kFoldSlots;
+    int32_t *ws = ls + wave * kFoldSlots;
+    for (int s = lane; s < kFoldSlots; s += kWave) {
+        wk[s] = kEmptyKey;
+        wt[s] = ~0ull;
+    }
+    __syncthreads();
+    for (int r = lane; r < ns; r += kWave) {   // fold the set's keys: key -> min position
+        const unsigned long long key = set_keys[src + r];
+        const unsigned long long tag = (unsigned long long)(tag_base + dst + r);
+        uint32_t h = (uint32_t)(mix64(key) >> 40) & (kFoldSlots - 1);
+        bool done = false;
+        for (int p = 0; p < 16; ++p) {
+            unsigned long long cur = wk[h];
+            if (cur == kEmptyKey) cur = atomicCAS(&wk[h], kEmptyKey, key);
+            if (cur == kEmptyKey || cur == key) {
+                if (wt[h] > tag) atomicMin(&wt[h], tag);
+                done = true;
+                break;
+            }
+            h = (h + 1) & (kFoldSlots - 1);
+        }
+        if (!done) uniq_global_insert(t, key, tag, flags);   // crowded: straight to HBM, found again below
+    }
+    __syncthreads();
+    for (int s = lane; s < kFoldSlots; s += kWave)
+        if (wk[s] != kEmptyKey) ws[s] = uniq_global_insert(t, wk[s], wt[s], flags);
+    __syncthreads();
     for (int r = lane; r < ns; r += kWave) {
+        const unsigned long long key = set_keys[src + r];   // second read: L2 hit
         out_ids[dst + r] = set_ids[src + r];
-        out_keys[dst + r] = set_keys[src + r];
+        if (out_keys) out_keys[dst + r] = key;
+        uint32_t h = (uint32_t)(mix64(key) >> 40) & (kFoldSlots - 1);
+        int32_t slot = -1;
+        for (int p = 0; p < 16; ++p) {
+            if (wk[h] == key) {
+                slot = ws[h];
+                break;
+            }
+            h = (h + 1) & (kFoldSlots - 1);
+        }
+        if (slot < 0) {   // the key went straight to HBM (or the table is over-full: flags[2] is set, caller retries)
+            uint64_t g = mix64(key) & t.mask;
+            for (uint64_t probes = 0; probes < kMaxProbes && t.keys[g] != key; ++probes) g = (g + 1) & t.mask;
+            slot = (int32_t)g;
+        }
+        out_slot[dst + r] = slot;
     }
 }
 
@@ -454,15 +515,26 @@ extern "C" int subgacc_walk_sets(const subgacc_walk_cfg *cfg, const void *indptr
 
 extern "C" int subgacc_compact_sets(const int32_t *set_ids, const uint64_t *set_keys, const int32_t *nsize,
                                     const int64_t *row_off, int64_t n, int32_t stride, int32_t *out_ids,
-                                    uint64_t *out_keys, void *stream) {
+                                    uint64_t *out_keys, void *uniq_table, int64_t uniq_capacity, int64_t tag_base,
+                                    int32_t *out_slot, int32_t *flags, void *stream) {
     SG_REQUIRE(n >= 0 && stride > 0, SUBGACC_ERR_BADARG, "compact_sets: bad sizes");
     if (n == 0) return SUBGACC_OK;
-    SG_REQUIRE(set_ids && set_keys && nsize && row_off && out_ids && out_keys, SUBGACC_ERR_BADARG,
-               "compact_sets: null argument");
-    const int64_t blocks = ceil_div(n * kWave, 256);
+    SG_REQUIRE(set_ids && set_keys && nsize && row_off && out_ids, SUBGACC_ERR_BADARG, "compact_sets: null argument");
+    const bool insert = uniq_table != nullptr;
+    SG_REQUIRE(insert || out_keys, SUBGACC_ERR_BADARG, "compact_sets: nothing to produce (no out_keys, no table)");
+    SG_REQUIRE(!insert || (out_slot && flags && tag_base >= 0 && uniq_capacity > 0 &&
+                           (uniq_capacity & (uniq_capacity - 1)) == 0 && uniq_capacity < (1ll << 31)),
+               SUBGACC_ERR_BADARG, "compact_sets: the fused insert needs out_slot, flags and a power-of-two table");
+    const int64_t blocks = ceil_div(n, kCompactWaves);
     SG_REQUIRE(blocks < (1ll << 31), SUBGACC_ERR_BADARG, "compact_sets: too many roots in one call");
-    hipLaunchKernelGGL(compact_sets_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, set_ids,
-                       set_keys, nsize, row_off, n, stride, out_ids, out_keys);
+    if (insert)
+        hipLaunchKernelGGL(compact_sets_kernel<true>, dim3((unsigned)blocks), dim3(kCompactThreads), 0,
+                           (hipStream_t)stream, set_ids, set_keys, nsize, row_off, n, stride, out_ids, out_keys,
+                           uniq_view(uniq_table, uniq_capacity), tag_base, out_slot, flags);
+    else
+        hipLaunchKernelGGL(compact_sets_kernel<false>, dim3((unsigned)blocks), dim3(kCompactThreads), 0,
+                           (hipStream_t)stream, set_ids, set_keys, nsize, row_off, n, stride, out_ids, out_keys,
+                           UniqTable{nullptr, nullptr, nullptr, 0}, (int64_t)0, (int32_t *)nullptr, (int32_t *)nullptr);
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }

@@ -62,15 +62,17 @@ class SampledSets:
     nsize: torch.Tensor      # int32 [n]
     row_off: torch.Tensor    # int64 [n+1]
     ids: torch.Tensor        # int32 [X]   members, first-visit order per root
-    keys: torch.Tensor       # int64 [X]   packed LP row (bit pattern of the uint64 key)
-    sf: torch.Tensor         # int32 [X]   index of the member's LP row in `ukeys` (None until dedup)
+    keys: torch.Tensor       # int64 [X]   packed LP row (bit pattern of the uint64 key); None when only slots are kept
+    sf: torch.Tensor         # int32 [X]   index of the member's LP row in `ukeys` (None until asked for: get_sf())
     ukeys: torch.Tensor      # int64 [c]   distinct LP rows in first-occurrence order
     num_walks: int
     num_steps: int
     stride: int
     walks: torch.Tensor = None   # int32 [n, M*(m+1)] when requested
     n_overflow: int = 0
-    extra: dict = field(default_factory=dict)
+    slot: torch.Tensor = None    # int32 [X]   slot of the member's key in `table` (fused compaction + insert)
+    table: torch.Tensor = None   # the HBM table of distinct LP rows (uint8 blob, layout of csrc/uniq_table.hpp)
+    capacity: int = 0
 
     @property
     def X(self):
@@ -79,6 +81,16 @@ class SampledSets:
     @property
     def c(self):
         return self.ukeys.numel()
+
+    def get_sf(self):
+        """int32 [X]: remap[1] of the reference.  Materialised on demand from the table slots."""
+        if self.sf is None:
+            if self.slot is None:
+                raise ValueError("the sets were sampled with dedup=False")
+            sf = self.slot.clone()
+            check(lib().subgacc_uniq_translate(ptr(self.table), self.capacity, ptr(sf), self.X, 0, stream_ptr()))
+            self.sf = sf
+        return self.sf
 
     def enc_int16(self):
         """int16 [c, m+1]: the reference's `enc` (subg_acc.c:982-1000)."""
@@ -89,6 +101,8 @@ class SampledSets:
 
     def counts_int32(self):
         """int32 [X, m+1]: per-member landing counts (rpe_encoder's second output, subg_acc.c:281-303)."""
+        if self.keys is None:
+            raise ValueError("the packed keys were not kept (sample_sets(..., keep_keys=True))")
         out = torch.empty((self.X, self.num_steps + 1), dtype=torch.int32, device=self.ids.device)
         check(lib().subgacc_unpack_lp(ptr(self.keys), self.X, self.num_walks, self.num_steps, None, ptr(out), None, 0,
                                       stream_ptr()))
@@ -121,9 +135,13 @@ def _as_query(query, device):
 
 def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, rng="rand_r", first_hop_wo=True,
                 order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False, rng_streams=1,
-                calls_before=0, dedup=True, staging_bytes=STAGING_BYTES, uniq_capacity=UNIQ_CAPACITY,
+                calls_before=0, dedup=True, keep_keys=None, staging_bytes=STAGING_BYTES, uniq_capacity=UNIQ_CAPACITY,
                 uniq_small_limit=0):
-    """Run the sampler for `query` (roots) on the GPU.  See SampledSets."""
+    """Run the sampler for `query` (roots) on the GPU.  See SampledSets.
+
+    dedup=True numbers the distinct LP rows (ukeys, slot/get_sf()); the packed keys are then only kept when
+    keep_keys is set.  Host round trips: one 8-byte read per chunk of roots (its total set size) and one read of
+    the status words + distinct-row count at the end."""
     L = lib()
     dev = csr.device
     q = _as_query(query, dev)
@@ -134,6 +152,8 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     stride = bucket if bucket > 0 else M * m + 1
     st = stream_ptr()
     flags = torch.zeros(4, dtype=torch.int32, device=dev)
+    if keep_keys is None:
+        keep_keys = not dedup
 
     rng_pos = rng_seed = None
     if cfg.rng_mode == _lib.RNG_RAND_R and n > 0:
@@ -143,15 +163,21 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
         check(L.subgacc_rng_positions(cfg, ptr(csr.indptr), ptr(q), n, int(rng_streams), int(calls_before), ptr(rng_pos),
                                       ptr(rng_seed), ptr(ws), ws.numel(), st))
 
+    table = None
+    if dedup:
+        table = torch.empty(L.subgacc_uniq_table_bytes(uniq_capacity), dtype=torch.uint8, device=dev)
+        check(L.subgacc_uniq_reset(ptr(table), uniq_capacity, st))
+
     nsize = torch.empty(n, dtype=torch.int32, device=dev)
     walks = torch.empty((n, M * (m + 1)), dtype=torch.int32, device=dev) if emit_walks else None
     chunk = max(1, min(n, int(staging_bytes // (stride * 12)), (1 << 31) - 16)) if n else 0
-    ids_parts, key_parts = [], []
+    ids_parts, key_parts, slot_parts = [], [], []
     if n:
         st_ids = torch.empty(chunk * stride, dtype=torch.int32, device=dev)
         st_keys = torch.empty(chunk * stride, dtype=torch.int64, device=dev)
         scan_ws = torch.empty(L.subgacc_scan_workspace_bytes(chunk), dtype=torch.uint8, device=dev)
         off_chunk = torch.empty(chunk + 1, dtype=torch.int64, device=dev)
+    X = 0
     for lo in range(0, n, chunk if chunk else 1):
         cn = min(chunk, n - lo)
         with _timed("walk_sets"):
@@ -163,30 +189,59 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
         check(L.subgacc_exclusive_scan_i32(ptr(nsize[lo:]), cn, ptr(off_chunk), ptr(scan_ws), scan_ws.numel(), st))
         total = int(off_chunk[cn].item())        # the one host round trip of this chunk
         ids_c = torch.empty(total, dtype=torch.int32, device=dev)
-        keys_c = torch.empty(total, dtype=torch.int64, device=dev)
+        keys_c = torch.empty(total, dtype=torch.int64, device=dev) if keep_keys else None
+        slot_c = torch.empty(total, dtype=torch.int32, device=dev) if dedup else None
         with _timed("compact_sets"):
             check(L.subgacc_compact_sets(ptr(st_ids), ptr(st_keys), ptr(nsize[lo:]), ptr(off_chunk), cn, stride,
-                                         ptr(ids_c), ptr(keys_c), st))
+                                         ptr(ids_c), ptr(keys_c), ptr(table), uniq_capacity if dedup else 0, X,
+                                         ptr(slot_c), ptr(flags), st))
         ids_parts.append(ids_c)
         key_parts.append(keys_c)
-    if len(ids_parts) == 1:
-        ids, keys = ids_parts[0], key_parts[0]
-    elif ids_parts:
-        ids, keys = torch.cat(ids_parts), torch.cat(key_parts)
-    else:
+        slot_parts.append(slot_c)
+        X += total
+
+    def _cat(parts, dtype):
+        parts = [p_ for p_ in parts if p_ is not None]
+        if not parts:
+            return None
+        return parts[0] if len(parts) == 1 else torch.cat(parts)
+    ids = _cat(ids_parts, torch.int32)
+    if ids is None:
         ids = torch.empty(0, dtype=torch.int32, device=dev)
+    keys = _cat(key_parts, torch.int64)
+    if keys is None and keep_keys:
         keys = torch.empty(0, dtype=torch.int64, device=dev)
-    del ids_parts, key_parts
+    slot = _cat(slot_parts, torch.int32)
+    if slot is None and dedup:
+        slot = torch.empty(0, dtype=torch.int32, device=dev)
+    del ids_parts, key_parts, slot_parts
 
     row_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
     ws = torch.empty(L.subgacc_scan_workspace_bytes(n), dtype=torch.uint8, device=dev)
     check(L.subgacc_exclusive_scan_i32(ptr(nsize), n, ptr(row_off), ptr(ws), ws.numel(), st))
 
     sets = SampledSets(nsize, row_off, ids, keys, None, None, M, m, stride, walks)
-    if dedup:
-        dedup_lp_rows(sets, uniq_capacity, walk_flags=flags, small_limit=uniq_small_limit)      # reads the walk flags in its own host sync
-    else:
+    if not dedup:
         _check_walk_flags(sets, flags.tolist())
+        return sets
+    # number the distinct LP rows by first occurrence (subg_acc.c:957-1000)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    max_unique = min(X, uniq_capacity)
+    ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
+    ws = torch.empty(L.subgacc_uniq_number_workspace_bytes(uniq_capacity, X), dtype=torch.uint8, device=dev)
+    with _timed("uniq_rows"):
+        check(L.subgacc_uniq_number(ptr(table), uniq_capacity, ptr(slot), X, ptr(ukeys), max_unique, ptr(count),
+                                    uniq_small_limit, ptr(ws), ws.numel(), st))
+    status = torch.cat([flags.long(), count]).tolist()
+    _check_walk_flags(sets, status[:4])
+    if status[2]:
+        # the table of distinct rows was (nearly) full -- more distinct LP rows than guessed: walk again with a
+        # larger one (rare: the paper's graphs have 10^2..10^5 distinct rows against 2^20 slots)
+        return sample_sets(csr, q, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order, cap_root_degree,
+                           emit_walks, rng_streams, calls_before, dedup, keep_keys, staging_bytes, uniq_capacity * 4,
+                           uniq_small_limit)
+    sets.slot, sets.table, sets.capacity = slot, table, uniq_capacity
+    sets.ukeys = ukeys[:status[4]].clone()
     return sets
 
 
@@ -202,8 +257,9 @@ def _check_walk_flags(sets, fl):
 
 
 def dedup_lp_rows(sets, capacity=UNIQ_CAPACITY, walk_flags=None, small_limit=0):
-    """Global first-occurrence dedup of the packed LP rows (subg_acc.c:957-1000) -> sets.sf, sets.ukeys.
-    One host sync: the distinct-row count (needed to size the table) and every status flag come back together."""
+    """Global first-occurrence dedup of already packed LP keys (subg_acc.c:957-1000) -> sets.sf, sets.ukeys.
+    The stand-alone form (subgacc_uniq_insert over sets.keys) for sets sampled with dedup=False; sample_sets itself
+    fuses the insert into the compaction pass."""
     L = lib()
     dev = sets.ids.device
     st = stream_ptr()

@@ -66,7 +66,8 @@ def sample_sets_sharded(sampler, query, rank, world, group=None, **kw):
         return sets, sets.ukeys, (lo, hi)
     tables = all_gather_varlen(sets.ukeys, group)
     gkeys, maps = merge_unique_tables(tables)
-    sets.sf = maps[rank].to(sets.sf.dtype)[sets.sf.long()]
+    sf = sets.get_sf() if hasattr(sets, "get_sf") else sets.sf
+    sets.sf = maps[rank].to(sf.dtype)[sf.long()]
     sets.ukeys = gkeys
     return sets, gkeys, (lo, hi)
 

@@ -37,16 +37,21 @@ class SpG:
     @classmethod
     def from_sets(cls, sets, n_cols=None):
         """Segmented sort of the sampled sets by node id (random_walks.py:79-80).  Row i = root query[i]."""
-        if sets.sf is None:
+        if sets.sf is None and sets.slot is None:
             raise ValueError("SpG.from_sets needs de-duplicated sets (sample_sets(..., dedup=True))")
         dev = sets.ids.device
         n = sets.nsize.numel()
         indices = torch.empty_like(sets.ids)
-        data = torch.empty_like(sets.sf)
+        data = torch.empty_like(sets.ids)
         flags = torch.zeros(4, dtype=torch.int32, device=dev)
         with _timed("spg_build"):
-            check(lib().subgacc_spg_build(ptr(sets.row_off), n, ptr(sets.ids), ptr(sets.sf), sets.stride, ptr(indices),
-                                          ptr(data), ptr(flags), stream_ptr()))
+            if sets.sf is not None:
+                check(lib().subgacc_spg_build(ptr(sets.row_off), n, ptr(sets.ids), ptr(sets.sf), None, 0, sets.stride,
+                                              ptr(indices), ptr(data), ptr(flags), stream_ptr()))
+            else:   # table slots are translated to SFptr inside the sort kernel: no pass over `sf` at all
+                check(lib().subgacc_spg_build(ptr(sets.row_off), n, ptr(sets.ids), ptr(sets.slot), ptr(sets.table),
+                                              sets.capacity, sets.stride, ptr(indices), ptr(data), ptr(flags),
+                                              stream_ptr()))
         return cls(sets.row_off, indices, data, max_len=sets.stride, shape=(n, n_cols or n), max_data=sets.c)
 
     @classmethod

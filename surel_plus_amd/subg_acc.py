@@ -38,13 +38,14 @@ def gset_sampler(indptr, indices, query, num_walks=100, num_steps=3, bucket=-1, 
     csr = indptr if isinstance(indptr, DeviceCSR) else _csr_from_host(indptr, indices)
     sets = sample_sets(csr, query, num_walks=num_walks, num_steps=num_steps, bucket=bucket, seed=seed, rng=rng)
     nsize = sets.nsize.cpu().numpy()
-    remap = torch.stack([sets.ids, sets.sf]).cpu().numpy()
+    sf = sets.get_sf()
+    remap = torch.stack([sets.ids, sf]).cpu().numpy()
     enc_dev = sets.enc_int16()
     enc = enc_dev.cpu().numpy()
     if _lib.VERBOSE:
         print(f"#SubGAcc: #total {sets.X}; #enc_unique {sets.c}; compression ratio {sets.X / max(sets.c, 1):.2f}")
     if debug > 0:
-        raw = enc_dev[sets.sf.long()].cpu().numpy()
+        raw = enc_dev[sf.long()].cpu().numpy()
         return [nsize, remap, enc, raw]
     return [nsize, remap, enc]
 

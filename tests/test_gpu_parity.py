@@ -90,7 +90,7 @@ def test_gset_multichunk_and_int64_indptr(sp):
         csr = DeviceCSR(ip, idx)
         s = sample_sets(csr, q, num_walks=50, num_steps=3, seed=4, staging_bytes=151 * 12 * 700)   # 8 chunks
         assert np.array_equal(s.nsize.cpu().numpy(), b[0])
-        assert np.array_equal(torch.stack([s.ids, s.sf]).cpu().numpy(), b[1])
+        assert np.array_equal(torch.stack([s.ids, s.get_sf()]).cpu().numpy(), b[1])
         assert np.array_equal(s.enc_int16().cpu().numpy(), b[2])
         tab = s.feature_table().cpu().numpy()
         assert np.array_equal(tab, oracle.enc_table(b[2]).astype(np.float32) / np.float32(50))
@@ -128,9 +128,9 @@ def test_reference_invariants_at_scale(sp):
     M, m = 200, 2
     s = sample_sets(csr, torch.arange(200_000, device="cuda", dtype=torch.int32), num_walks=M, num_steps=m, rng="philox")
     assert int(s.nsize.sum()) == s.X
-    assert int(s.sf.max()) == s.c - 1
+    assert int(s.get_sf().max()) == s.c - 1
     enc = s.enc_int16().long()
-    rows = enc[s.sf.long()]
+    rows = enc[s.get_sf().long()]
     assert int((rows[:, 0] == M).sum()) == 200_000
     seg = torch.repeat_interleave(torch.arange(200_000, device="cuda"), s.nsize.long())
     colsum = torch.zeros((200_000, m + 1), dtype=torch.int64, device="cuda").index_add_(0, seg, rows)
@@ -291,7 +291,7 @@ def test_unique_table_grows_on_overflow(sp):
     s = sample_sets(DeviceCSR(ptr_, idx), np.arange(3000), num_walks=100, num_steps=4, seed=99, uniq_capacity=64)
     b = oracle.gset_sampler(ptr_, idx, np.arange(3000), num_walks=100, num_steps=4, seed=99)
     assert s.c > 64
-    assert np.array_equal(torch.stack([s.ids, s.sf]).cpu().numpy(), b[1])
+    assert np.array_equal(torch.stack([s.ids, s.get_sf()]).cpu().numpy(), b[1])
     assert np.array_equal(s.enc_int16().cpu().numpy(), b[2])
 
 
@@ -380,5 +380,17 @@ def test_unique_numbering_large_table_path(sp):
     for limit in (0, 16):       # 0 -> default 8192 (direct ranking); 16 -> scan path since c >> 16
         s = sample_sets(csr, np.arange(3000), num_walks=100, num_steps=4, seed=7, uniq_small_limit=limit)
         assert s.c > 16
-        assert np.array_equal(torch.stack([s.ids, s.sf]).cpu().numpy(), b[1])
+        assert np.array_equal(torch.stack([s.ids, s.get_sf()]).cpu().numpy(), b[1])
         assert np.array_equal(s.enc_int16().cpu().numpy(), b[2])
+
+
+def test_standalone_dedup_of_packed_keys_matches_the_fused_path(sp):
+    """subgacc_uniq_insert over already packed keys (dedup_lp_rows) == the insert fused into the compaction."""
+    ptr_, idx = sym_graph(4000, 20000, seed=21, hubs=1)
+    from surel_plus_amd.sampler import DeviceCSR, dedup_lp_rows, sample_sets
+    csr = DeviceCSR(ptr_, idx)
+    fused = sample_sets(csr, np.arange(4000), num_walks=64, num_steps=3, seed=2, rng="philox", keep_keys=True)
+    plain = sample_sets(csr, np.arange(4000), num_walks=64, num_steps=3, seed=2, rng="philox", dedup=False)
+    assert torch.equal(fused.keys, plain.keys) and torch.equal(fused.ids, plain.ids)
+    dedup_lp_rows(plain)
+    assert torch.equal(plain.sf, fused.get_sf()) and torch.equal(plain.ukeys, fused.ukeys)
