@@ -134,7 +134,7 @@ def walk_sampler(ptr, neighs, query, num_walks=100, num_steps=3, nthread=1, seed
     return walks, nsize, ids, counts
 
 
-def spg_build(nsize, remap):
+def spg_build(nsize, remap, nthreads=1):
     """sampler/random_walks.py:79-80 with rows = query positions: (indptr int64, indices int32, data int32)."""
     nsize = np.ascontiguousarray(nsize, np.int32)
     ids = np.ascontiguousarray(remap[0], np.int32)
@@ -144,7 +144,7 @@ def spg_build(nsize, remap):
     indices = np.empty(X, np.int32)
     data = np.empty(X, np.int32)
     rc = lib().orc_spg_build(_p(nsize, C.c_int32), C.c_int64(n), _p(ids, C.c_int32), _p(sf, C.c_int32),
-                             _p(indptr, C.c_int64), _p(indices, C.c_int32), _p(data, C.c_int32))
+                             _p(indptr, C.c_int64), _p(indices, C.c_int32), _p(data, C.c_int32), C.c_int(nthreads))
     assert rc == 0
     return indptr, indices, data
 

@@ -659,30 +659,38 @@ static int idval_cmp(const void *a, const void *b)
 /* rows = query positions; per row the members sorted by node id; data = sf + 1.
  * (scipy's COO->CSR of random_walks.py:79 does exactly this for unique (row, col) pairs.) */
 int orc_spg_build(const int32_t *nsize, int64_t n, const int32_t *ids, const int32_t *sf,
-                  int64_t *out_indptr, int32_t *out_indices, int32_t *out_data)
+                  int64_t *out_indptr, int32_t *out_indices, int32_t *out_data, int nthreads)
 {
-    int64_t off = 0;
     int64_t maxn = 1;
-    for (int64_t i = 0; i < n; ++i)
-        if (nsize[i] > maxn)
-            maxn = nsize[i];
-    idval_t *tmp = (idval_t *)malloc(sizeof(idval_t) * (size_t)maxn);
-    if (!tmp)
-        return -1;
     out_indptr[0] = 0;
     for (int64_t i = 0; i < n; ++i)
     {
-        int ns = nsize[i];
-        for (int r = 0; r < ns; ++r)
-            tmp[r].id = ids[off + r], tmp[r].val = sf[off + r] + 1;
-        qsort(tmp, (size_t)ns, sizeof(idval_t), idval_cmp);
-        for (int r = 0; r < ns; ++r)
-            out_indices[off + r] = tmp[r].id, out_data[off + r] = tmp[r].val;
-        off += ns;
-        out_indptr[i + 1] = off;
+        out_indptr[i + 1] = out_indptr[i] + nsize[i];
+        if (nsize[i] > maxn)
+            maxn = nsize[i];
     }
-    free(tmp);
-    return 0;
+    int rc = 0;
+#pragma omp parallel num_threads(nthreads > 0 ? nthreads : 1)
+    {
+        idval_t *tmp = (idval_t *)malloc(sizeof(idval_t) * (size_t)maxn);
+        if (!tmp)
+            rc = -1;
+#pragma omp for schedule(dynamic, 256)
+        for (int64_t i = 0; i < n; ++i)
+        {
+            if (!tmp)
+                continue;
+            const int64_t off = out_indptr[i];
+            const int ns = nsize[i];
+            for (int r = 0; r < ns; ++r)
+                tmp[r].id = ids[off + r], tmp[r].val = sf[off + r] + 1;
+            qsort(tmp, (size_t)ns, sizeof(idval_t), idval_cmp);
+            for (int r = 0; r < ns; ++r)
+                out_indices[off + r] = tmp[r].id, out_data[off + r] = tmp[r].val;
+        }
+        free(tmp);
+    }
+    return rc;
 }
 
 /* ------------------------------------------------------------------ SpJoin */
