@@ -471,7 +471,7 @@ extern "C" int subgacc_walk_sets(const subgacc_walk_cfg *cfg, const void *indptr
     SG_REQUIRE(cfg->rng_mode != SUBGACC_RNG_RAND_R || (rng_pos && rng_seed) || n == 0, SUBGACC_ERR_BADARG,
                "walk_sets: RAND_R mode needs rng_pos/rng_seed from subgacc_rng_positions");
     if (n == 0) return SUBGACC_OK;
-    SG_REQUIRE(query && indices, SUBGACC_ERR_BADARG, "walk_sets: null query/indices");
+    SG_REQUIRE(query, SUBGACC_ERR_BADARG, "walk_sets: null query");   // `indices` may be NULL for an edgeless graph
 
     WalkArgs a;
     a.indptr = indptr, a.indices = indices, a.query = query, a.n = n;

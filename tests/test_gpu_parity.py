@@ -394,3 +394,73 @@ def test_standalone_dedup_of_packed_keys_matches_the_fused_path(sp):
     assert torch.equal(fused.keys, plain.keys) and torch.equal(fused.ids, plain.ids)
     dedup_lp_rows(plain)
     assert torch.equal(plain.sf, fused.get_sf()) and torch.equal(plain.ukeys, fused.ukeys)
+
+
+# ------------------------------------------------------------------------------------ edge cases
+def test_empty_query_and_empty_join(sp):
+    ptr_, idx = sym_graph(100, 300, seed=1)
+    out = sp.gset_sampler(ptr_, idx, np.zeros(0, np.int64), num_walks=8, num_steps=2)
+    ref = oracle.gset_sampler(ptr_, idx, np.zeros(0, np.int64), num_walks=8, num_steps=2)
+    assert out[0].shape == (0,) and out[1].shape == (2, 0) and out[2].shape == (0, 3)
+    assert all(a.shape == b.shape and a.dtype == b.dtype for a, b in zip(out, ref))
+    g = _load("sjoin_int.npz")
+    z = _spg_from_golden(sp, g)
+    enc = torch.from_numpy(g["encode"]).cuda()
+    for ptr in (True, False):
+        xz, ind = sp.gather(np.zeros((2, 0), np.int64), z, "cuda", ptr=ptr, encode=enc)
+        assert xz.shape == (0, 2, enc.shape[1]) and ind.tolist() == ([0] if ptr else [])
+
+
+@pytest.mark.parametrize("M,m,bucket", [(1, 1, -1), (1, 5, -1), (3, 1, -1), (1000, 2, -1), (64, 3, 1), (64, 3, 2), (255, 7, -1)])
+@pytest.mark.parametrize("rng", ["rand_r", "philox"])
+def test_gset_parameter_corners(sp, M, m, bucket, rng):
+    """one walk, one hop, a 64 KB LDS table (M*m+1 = 2001), buckets that keep only the root, SHIFT*m+1 = 57 bits."""
+    ptr_, idx = sym_graph(600, 3000, seed=M * 7 + m, hubs=1)
+    q = np.concatenate([np.arange(600), [5, 5, 599]])
+    a = sp.gset_sampler(ptr_, idx, q, num_walks=M, num_steps=m, bucket=bucket, seed=3, debug=1, rng=rng)
+    b = oracle.gset_sampler(ptr_, idx, q, num_walks=M, num_steps=m, bucket=bucket, seed=3, debug=True, rng=rng)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_graph_of_isolated_nodes(sp):
+    """every root isolated: sets are {root}, LP rows are [M, M, ..., M] (subg_acc.c:753-761)."""
+    indptr = np.zeros(11, np.int32)
+    indices = np.zeros(0, np.int32)
+    for rng in ("rand_r", "philox"):
+        a = sp.gset_sampler(indptr, indices, np.arange(10), num_walks=9, num_steps=3, debug=1, rng=rng)
+        b = oracle.gset_sampler(indptr, indices, np.arange(10), num_walks=9, num_steps=3, debug=True, rng=rng)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+        assert np.array_equal(a[1][0], np.arange(10)) and a[2].tolist() == [[9, 9, 9, 9]]
+    w, obj = sp.walk_sampler(indptr, indices, np.arange(10), num_walks=4, num_steps=2, replacement=True)
+    assert np.array_equal(w, np.repeat(np.arange(10), 12).reshape(10, 12))
+
+
+def test_key_width_errors_match_the_reference(sp):
+    ptr_, idx = sym_graph(50, 100, seed=1)
+    with pytest.raises(AssertionError, match="hasing key"):      # 9 hops * 8 bits + 1 > 64, subg_acc.c:911-915
+        sp.gset_sampler(ptr_, idx, np.arange(5), num_walks=200, num_steps=9)
+    with pytest.raises(TypeError):                                 # float CSR cannot be safely cast, subg_acc.c:663
+        sp.gset_sampler(ptr_.astype(np.float64), idx, np.arange(5))
+    with pytest.raises(TypeError):
+        sp.gset_sampler(ptr_, idx.astype(np.int64), np.arange(5))
+    # the query is force-cast (subg_acc.c:673): float ids are accepted and truncated
+    a = sp.gset_sampler(ptr_, idx, np.arange(5, dtype=np.float64), num_walks=4, num_steps=2)
+    b = oracle.gset_sampler(ptr_, idx, np.arange(5), num_walks=4, num_steps=2)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("replacement", [False, True])
+def test_walk_sampler_philox_and_many_streams(sp, replacement):
+    ptr_, idx = sym_graph(700, 5000, seed=9, hubs=1)
+    q = np.arange(700)
+    for rng, T in (("philox", 1), ("rand_r", 7), ("rand_r", 700), ("rand_r", 1000)):
+        walks, obj = sp.walk_sampler(ptr_, idx, q, num_walks=33, num_steps=4, nthread=T, seed=5, replacement=replacement,
+                                     rng=rng)
+        ow, on, oi, oc = oracle.walk_sampler(ptr_, idx, q, num_walks=33, num_steps=4, nthread=T, seed=5,
+                                             replacement=replacement, rng=rng)
+        assert np.array_equal(walks, ow)
+        off = np.concatenate([[0], np.cumsum(on)])
+        assert all(np.array_equal(obj[i, 0], oi[off[i]:off[i + 1]]) and np.array_equal(obj[i, 1], oc[off[i]:off[i + 1]])
+                   for i in range(700))
