@@ -35,6 +35,11 @@ WORKLOADS = {
     "cit2": ("cit2", 200, 4, "cit2-like LP: N=2,927,963 avg-deg 20.7 power-law graph, M=200, --num_steps 4 (m=3 hops)"),
     "collab": ("collab", 200, 3, "collab-like LP: N=235,868 avg-deg 8.2 power-law graph, M=200, --num_steps 3 (m=2 hops)"),
     "ppa": ("ppa", 200, 4, "ppa-like LP: N=576,289 avg-deg 73.7 power-law graph, M=200, --num_steps 4 (m=3 hops)"),
+    # configs[4]: twitter-follower scale (41.65 M nodes, ~2.9 B adjacency entries, int64 row offsets, 12 GB CSR
+    # resident in HBM); the reference gives no walk parameters for it -- collab's are used
+    "twitter": ("twitter", 200, 3, "twitter-like LP: N=41,652,230, ~2.9e9 adjacency entries (int64 indptr), M=200, --num_steps 3"),
+    # configs[3]: the PPR sampler itself is out of scope (sampler/pprgo.py); only SpJoin over its float SpG is timed
+    "cit2ppr": (None, 0, 1, "cit2-like PPR encoder: float64 SpG, N=2,927,963 rows x top-100, SpJoin only (train.py:39-43)"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -155,6 +160,60 @@ def cpu_baseline(csr, edge_all, M, k, target_s=15.0):
                       + f", {ts:.2f}s of {t:.2f}s; SpG build + SpJoin = oracle C port ({threads} threads)"}
 
 
+def main_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc):
+    """SpJoin over a resident float-payload SpG (the citation2 PPR configuration): one step = B pairs -> xz [R,2,1]."""
+    from surel_plus_amd.graphs import ppr_like_spg
+    N = max(int(2_927_963 * args.scale), 1000)
+    z = ppr_like_spg(N, 100, seed=3, device=dev)
+    B, K, W = args.pairs, args.steps, args.warmup
+    gens = [torch.Generator(device=dev).manual_seed(1000 * rank + s) for s in range(K + W)]
+    edges = [torch.randint(0, N, (2, B), device=dev, generator=g) for g in gens]
+    timer = KernelTimer()
+    sampler_mod.KERNEL_TIMER = timer
+    import surel_plus_amd.spjoin as sj
+    orig = sj.sjoin
+
+    def timed_sjoin(*a, **kw):           # the float path has no encode table: time the whole fill call
+        with timer("sjoin_fill"):
+            return orig(*a, **kw)
+    for s in range(W):
+        sp.gather(edges[s], z, dev, ptr=True, encode=None)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    sj.sjoin = timed_sjoin
+    t0 = time.perf_counter()
+    for s in range(W, W + K):
+        xz, ind = sp.gather(edges[s], z, dev, ptr=True, encode=None)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    sj.sjoin = orig
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        ms, launches = timer.mean_ms("sjoin_fill")
+        abytes = B * (64 + 200 * 12 + 200 * 8)     # SURVEY 8(d): ids+f64 payload read, f32 [.,2,1] written
+        out = {"metric": "query-pairs/sec (SpJoin, PPR payload)", "value": world * B * K / elapsed, "unit": "query-pairs/s",
+               "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": desc, "pairs_per_step_per_gpu": B, "xz_rows_last_step": int(xz.shape[0])},
+               "roofline": {"bound": "hbm", "kernel": "sjoin_fill (sizes + scan + sjoin_pair_kernel<f64>)", "achieved": abytes / (ms * 1e-3) / 1e9,
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "traffic": None, "kernel_ms": ms, "launches_timed": launches,
+                            "algorithmic_bytes_per_launch": abytes}}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,6 +244,8 @@ def main():
     from surel_plus_amd.graphs import preset_graph, query_pairs
 
     preset, M, k, desc = WORKLOADS[args.workload]
+    if preset is None:
+        return main_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc)
     csr = preset_graph(preset, device=dev, scale=args.scale)
     B, K, W = args.pairs, args.steps, args.warmup
     # every step's pairs are resident in HBM before the clock starts; ranks and steps get different pairs
@@ -242,7 +303,7 @@ def main():
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel_ms": walk_ms, "launches_timed": launches, "algorithmic_bytes_per_launch": abytes},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload != "twitter":   # 12 GB CSR: no host copy
             try:
                 out["cpu_baseline"] = cpu_baseline(csr, edges[W], M, k)
             except Exception as ex:  # the baseline is a report, never a reason to lose the measurement

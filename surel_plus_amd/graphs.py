@@ -44,7 +44,38 @@ def powerlaw_graph(N, avg_deg, seed=0, exponent=2.5, device="cuda", max_weight_f
     return DeviceCSR(indptr.to(ptr_dtype), col, torch.device(device))
 
 
+def directed_powerlaw_graph(N, avg_deg, seed=3, exponent=2.2, device="cuda", chunk=1 << 28, max_weight_frac=0.0005):
+    """Billion-edge stand-in for twitter-follower (41.65 M nodes, ~2.9 B adjacency entries after symmetrisation):
+    every node gets max(1, d_i) out-neighbours drawn from a heavy-tailed popularity distribution, generated in
+    chunks without any global sort (symmetrising 3 B edges would need one).  Not symmetric, not simple, rows
+    unsorted -- none of which the walk kernel needs; there are no dead ends, use rng="philox".
+    Row offsets are int64 whenever nnz >= 2^31."""
+    gen = torch.Generator(device=device).manual_seed(int(seed))
+    ranks = torch.arange(1, N + 1, device=device, dtype=torch.float64)
+    w = ranks.pow(-1.0 / (exponent - 1.0))
+    w = torch.minimum(w, w.sum() * max_weight_frac / avg_deg)
+    w = w[torch.randperm(N, device=device, generator=gen)]
+    deg = torch.clamp((w * (N * avg_deg / w.sum())).round().to(torch.int64), min=1)
+    indptr = torch.zeros(N + 1, dtype=torch.int64, device=device)
+    indptr[1:] = torch.cumsum(deg, 0)
+    nnz = int(indptr[-1].item())
+    cdf = torch.cumsum(w, 0)
+    cdf = (cdf / cdf[-1]).to(torch.float32)
+    del ranks, w, deg
+    indices = torch.empty(nnz, dtype=torch.int32, device=device)
+    for lo in range(0, nnz, chunk):
+        hi = min(lo + chunk, nnz)
+        r = torch.rand(hi - lo, device=device, generator=gen, dtype=torch.float32)
+        indices[lo:hi] = torch.searchsorted(cdf, r).clamp_(max=N - 1).to(torch.int32)
+        del r
+    if nnz < 2**31 - 1:
+        indptr = indptr.to(torch.int32)
+    return DeviceCSR(indptr, indices, torch.device(device))
+
+
 def preset_graph(name, device="cuda", scale=1.0):
+    if name == "twitter":
+        return directed_powerlaw_graph(max(int(41_652_230 * scale), 1000), 70.5, seed=3, device=device)
     p = PRESETS[name]
     return powerlaw_graph(max(int(p["N"] * scale), 16), p["avg_deg"], seed=p["seed"], device=device)
 
