@@ -146,6 +146,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
     uint32_t *bitmap = minq + a.T;                               // [nwords]
     uint32_t *prefix = bitmap + a.nwords;                        // [nwords + 1]
     int32_t *sarr = (int32_t *)(prefix + a.nwords + 1);          // [M] Fisher-Yates draws
+    uint16_t *inv = (uint16_t *)(sarr + a.M);                    // [M*m+1] table slot of the member ranked r
 
     const int64_t i = xcd_item(blockIdx.x, gridDim.x);
     if (i >= a.n) return;
@@ -295,17 +296,22 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
     }
     __syncthreads();
     const int32_t total = (int32_t)prefix[a.nwords];
+    const int32_t ns = total < a.stride ? total : a.stride;
     for (int h = tid; h < T; h += kWalkThreads)
         if (keys[h] != -1) {
             const uint32_t q = minq[h];
             const int32_t r = (int32_t)(prefix[q >> 5] + __popc(bitmap[q >> 5] & ((1u << (q & 31u)) - 1u)));
-            if (r < a.stride) {  // members ranked past the bucket are dropped with all their visits (:814-828)
-                a.set_ids[obase + r] = keys[h];
-                a.set_keys[obase + r] = pk[h] | (r == 0 ? lead : 0ull);
-            }
+            if (r < a.stride) inv[r] = (uint16_t)h;  // members ranked past the bucket are dropped (:814-828)
         }
+    __syncthreads();
+    // members leave in rank order: consecutive lanes write consecutive words of the staging row
+    for (int r = tid; r < ns; r += kWalkThreads) {
+        const int h = inv[r];
+        a.set_ids[obase + r] = keys[h];
+        a.set_keys[obase + r] = pk[h] | (r == 0 ? lead : 0ull);
+    }
     if (tid == 0) {
-        a.nsize[i] = total < a.stride ? total : a.stride;
+        a.nsize[i] = ns;
         if (total > a.stride) atomicAdd(&a.flags[1], 1);
     }
 }
@@ -396,8 +402,8 @@ static int table_size_for(int64_t q) {
     return t;
 }
 
-static size_t walk_lds_bytes(int T, int nwords, int M) {
-    return (size_t)T * 16 + (size_t)nwords * 4 + (size_t)(nwords + 1) * 4 + (size_t)M * 4 + 16;
+static size_t walk_lds_bytes(int T, int nwords, int M, int Q) {
+    return (size_t)T * 16 + (size_t)nwords * 4 + (size_t)(nwords + 1) * 4 + (size_t)M * 4 + (size_t)Q * 2 + 16;
 }
 
 }  // namespace subgacc
@@ -487,7 +493,8 @@ extern "C" int subgacc_walk_sets(const subgacc_walk_cfg *cfg, const void *indptr
     a.wo = cfg->first_hop_wo ? 1 : 0;
     a.step_major = cfg->order == SUBGACC_ORDER_STEP_MAJOR ? 1 : 0;
     a.cap_root = cfg->cap_root_degree ? 1 : 0;
-    const size_t lds = walk_lds_bytes(a.T, a.nwords, M);
+    SG_REQUIRE(a.T <= 65536, SUBGACC_ERR_LDS, "walk_sets: M*m+1 = %d is too large for the per-root LDS tables", Q);
+    const size_t lds = walk_lds_bytes(a.T, a.nwords, M, Q);
     SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS,
                "walk_sets: per-root tables need %zu B of LDS (> %d): M*m+1 = %d is too large", lds, kLdsBytes, Q);
 
