@@ -42,6 +42,7 @@ WORKLOADS = {
     "cit2ppr": (None, 0, 1, "cit2-like PPR encoder: float64 SpG, N=2,927,963 rows x top-100, SpJoin only (train.py:39-43)"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FUSED = os.environ.get("SUBGACC_FUSED", "1") == "1"   # 0: the general pipeline (walk_sets + compact + spg_build)
 
 
 @contextlib.contextmanager
@@ -87,11 +88,9 @@ class KernelTimer:
 
 def hot_path_step(sp, csr, edge, M, k, seed, rng):
     """sample both endpoints of every pair, build the SpG, join.  Returns (xz, indptr, sets)."""
-    from surel_plus_amd.sampler import sample_sets
     B = edge.shape[1]
     roots = edge.reshape(-1).to(torch.int32)
-    sets = sample_sets(csr, roots, num_walks=M, num_steps=k - 1, seed=seed, rng=rng)
-    z = sp.SpG.from_sets(sets, n_cols=csr.num_nodes)
+    z, sets = sp.sample_spg(csr, roots, num_walks=M, num_steps=k - 1, seed=seed, rng=rng, fused=FUSED)
     table = sets.feature_table()
     rows = torch.arange(2 * B, device=edge.device, dtype=torch.int64).view(2, B)   # row i = root i of this batch
     xz, ind = sp.gather(rows, z, edge.device, ptr=True, encode=table)
@@ -106,7 +105,7 @@ def algorithmic_walk_bytes(csr, roots, sets, M, m):
     w = 16 if csr.indptr64 else 8
     live = deg > 0
     per = 4 + w + 4 * torch.clamp(deg, max=M) + (w + 4) * M * (m - 1) * live.long() + 4
-    return int(per.sum().item()) + 8 * sets.X
+    return int(per.sum().item()) + 8 * int(sets.ids.numel())
 
 
 def cpu_baseline(csr, edge_all, M, k, target_s=15.0):

@@ -100,6 +100,22 @@ int subgacc_walk_sets(const subgacc_walk_cfg *cfg, const void *indptr, const int
                       int32_t *set_ids, uint64_t *set_keys, int32_t *nsize, int32_t *walks, int32_t *flags,
                       void *stream);
 
+/* Fused form for the SpG pipeline: sample n roots and leave every set as a FINISHED SpG row at offset i*stride:
+ *   row_ids [n*stride] int32  members sorted by node id (random_walks.py:79-80)
+ *   row_slot[n*stride] int32  slot of the member's LP key in `uniq_table` (translate after subgacc_uniq_number)
+ * The keys are registered in the table with tag (root_base+i)*stride + first-visit rank, which numbers the
+ * distinct rows exactly like the reference's sequential pass (subg_acc.c:957-978); root_base = global index of
+ * query[0] when a job is split into chunks.  Needs M*m+1 <= 1024 (SUBGACC_ERR_LDS otherwise: use
+ * subgacc_walk_sets + subgacc_compact_sets + subgacc_spg_build).  flags as for subgacc_walk_sets, [2] |= 1
+ * when the table is (nearly) full. */
+int subgacc_walk_spg(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,
+                     const int32_t *query, int64_t n, int64_t root_base, const uint32_t *rng_pos,
+                     const uint32_t *rng_seed, void *uniq_table, int64_t uniq_capacity, int32_t *row_ids,
+                     int32_t *row_slot, int32_t *nsize, int32_t *flags, void *stream);
+/* strided -> packed copy of the rows of subgacc_walk_spg: row i goes to [row_off[i], +nsize[i]) */
+int subgacc_compact_rows(const int32_t *row_ids, const int32_t *row_slot, const int32_t *nsize, const int64_t *row_off,
+                         int64_t n, int32_t stride, int32_t *out_indices, int32_t *out_data, void *stream);
+
 /* Exclusive scan int32 -> int64, out[n] = total.  (Prefix of nsize, subg_acc.c:848-851.) */
 size_t subgacc_scan_workspace_bytes(int64_t n);
 int subgacc_exclusive_scan_i32(const int32_t *in, int64_t n, int64_t *out, void *workspace, size_t workspace_bytes,

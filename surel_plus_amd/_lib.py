@@ -19,7 +19,8 @@ ORDER_WALK_MAJOR, ORDER_STEP_MAJOR = 0, 1
 # every symbol include/subgacc.h declares (tests check the built library exports all of them)
 SYMBOLS = (
     "subgacc_abi_version", "subgacc_last_error", "subgacc_device_count", "subgacc_key_shift",
-    "subgacc_rng_positions_workspace_bytes", "subgacc_rng_positions", "subgacc_walk_sets",
+    "subgacc_rng_positions_workspace_bytes", "subgacc_rng_positions", "subgacc_walk_sets", "subgacc_walk_spg",
+    "subgacc_compact_rows",
     "subgacc_scan_workspace_bytes", "subgacc_exclusive_scan_i32", "subgacc_compact_sets",
     "subgacc_uniq_table_bytes", "subgacc_uniq_reset", "subgacc_uniq_insert",
     "subgacc_uniq_number_workspace_bytes", "subgacc_uniq_number", "subgacc_uniq_translate", "subgacc_unpack_lp",
@@ -74,6 +75,8 @@ def lib():
         "subgacc_rng_positions_workspace_bytes": (sz, [i64]),
         "subgacc_rng_positions": (C.c_int, [cfgp, vp, vp, i64, i32, u64, vp, vp, vp, sz, vp]),
         "subgacc_walk_sets": (C.c_int, [cfgp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "subgacc_walk_spg": (C.c_int, [cfgp, vp, vp, i64, vp, i64, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp]),
+        "subgacc_compact_rows": (C.c_int, [vp, vp, vp, vp, i64, i32, vp, vp, vp]),
         "subgacc_scan_workspace_bytes": (sz, [i64]),
         "subgacc_exclusive_scan_i32": (C.c_int, [vp, i64, vp, vp, sz, vp]),
         "subgacc_compact_sets": (C.c_int, [vp, vp, vp, vp, i64, i32, vp, vp, vp, i64, i64, vp, vp, vp]),

@@ -20,6 +20,7 @@
 // nthread=1): the LCG x -> a*x+c is affine, so a lane jumps straight to the stream position of its
 // (root, walk) in O(log k).  SUBGACC_RNG_PHILOX is Philox4x32-10 keyed by (seed; root id, walk, step).
 #include "common.hpp"
+#include "blockscan.hpp"
 #include "uniq_table.hpp"
 
 #ifndef SG_EXPERIMENT
@@ -135,10 +136,17 @@ struct WalkArgs {
     int32_t nwords;      // bitmap words over q in [0, M*m]
     uint32_t seed;
     int32_t wo, step_major, cap_root;
+    // SPG mode (walk_spg_kernel): rows leave sorted by node id with the slot of their LP key in the HBM table
+    int32_t *set_slot;
+    UniqTable table;
+    int64_t root_base;   // global index of query[0]: tags (root_base+i)*stride + rank order the first occurrences
 };
 
-template <bool IDX64, int RNG>
-__global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) void walk_sets_kernel(const WalkArgs a) {
+constexpr int kSpgFold = 128;      // block-local table of the set's distinct LP keys
+constexpr int kSpgPerLane = 4;     // members per lane kept in registers while LDS is re-used => M*m+1 <= 1024
+
+template <bool IDX64, int RNG, bool SPG>
+__global__ __launch_bounds__(kWalkThreads) void walk_sets_kernel(const WalkArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     unsigned long long *pk = (unsigned long long *)lds_raw;     // [T]
     int32_t *keys = (int32_t *)(pk + a.T);                       // [T]
@@ -147,6 +155,11 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
     uint32_t *prefix = bitmap + a.nwords;                        // [nwords + 1]
     int32_t *sarr = (int32_t *)(prefix + a.nwords + 1);          // [M] Fisher-Yates draws
     uint16_t *inv = (uint16_t *)(sarr + a.M);                    // [M*m+1] table slot of the member ranked r
+    // SPG mode only: fold table of distinct LP keys + a reduction scratch, behind inv (8-byte aligned)
+    unsigned long long *fk = (unsigned long long *)(((uintptr_t)(inv + (a.M * a.m + 1)) + 7) & ~(uintptr_t)7);   // [kSpgFold]
+    uint32_t *ft = (uint32_t *)(fk + kSpgFold);                  // [kSpgFold] min rank of the key inside the set
+    int32_t *fs = (int32_t *)(ft + kSpgFold);                    // [kSpgFold] HBM table slot of the key
+    int32_t *red = fs + kSpgFold;                                // [16]
 
     const int64_t i = xcd_item(blockIdx.x, gridDim.x);
     if (i >= a.n) return;
@@ -164,7 +177,8 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
             unsigned long long k = lead;
             for (int s = 0; s < m; ++s) k |= (unsigned long long)M << (s * a.shift);
             a.set_ids[obase] = root;
-            a.set_keys[obase] = k;
+            if (SPG) a.set_slot[obase] = uniq_global_insert(a.table, k, (unsigned long long)((a.root_base + i) * a.stride), a.flags);
+            else a.set_keys[obase] = k;
             a.nsize[i] = 1;
         }
         if (a.walks)
@@ -304,15 +318,143 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
             if (r < a.stride) inv[r] = (uint16_t)h;  // members ranked past the bucket are dropped (:814-828)
         }
     __syncthreads();
-    // members leave in rank order: consecutive lanes write consecutive words of the staging row
-    for (int r = tid; r < ns; r += kWalkThreads) {
-        const int h = inv[r];
-        a.set_ids[obase + r] = keys[h];
-        a.set_keys[obase + r] = pk[h] | (r == 0 ? lead : 0ull);
-    }
     if (tid == 0) {
         a.nsize[i] = ns;
         if (total > a.stride) atomicAdd(&a.flags[1], 1);
+    }
+    if (!SPG) {
+        // members leave in rank order: consecutive lanes write consecutive words of the staging row
+        for (int r = tid; r < ns; r += kWalkThreads) {
+            const int h = inv[r];
+            a.set_ids[obase + r] = keys[h];
+            a.set_keys[obase + r] = pk[h] | (r == 0 ? lead : 0ull);
+        }
+        return;
+    }
+
+    // ================= SPG mode: the set leaves as a finished SpG row =================
+    // (1) fold the set's LP keys (a few dozen distinct rows) and register them in the HBM table of distinct rows
+    //     with tag = (global root index)*stride + first-visit rank, which orders first occurrences exactly like the
+    //     reference's sequential pass (subg_acc.c:957-978); (2) bucket-sort the members by node id in the LDS the
+    //     walk tables occupied (random_walks.py:79-80).  All of it hides under other workgroups' line fetches.
+    for (int s2 = tid; s2 < kSpgFold; s2 += kWalkThreads) {
+        fk[s2] = kEmptyKey;
+        ft[s2] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    const unsigned long long tag0 = (unsigned long long)((a.root_base + i) * (int64_t)a.stride);
+    int32_t idv[kSpgPerLane], slv[kSpgPerLane];
+    unsigned long long kyv[kSpgPerLane];
+#pragma unroll
+    for (int u = 0; u < kSpgPerLane; ++u) {
+        const int r = tid + u * kWalkThreads;
+        idv[u] = 0, slv[u] = -1, kyv[u] = 0ull;
+        if (r < ns) {
+            const int h = inv[r];
+            idv[u] = keys[h];
+            const unsigned long long key = pk[h] | (r == 0 ? lead : 0ull);
+            kyv[u] = key;
+            uint32_t f = (uint32_t)(mix64(key) >> 40) & (kSpgFold - 1);
+            bool done = false;
+            for (int p = 0; p < 16; ++p) {
+                unsigned long long cur = fk[f];
+                if (cur == kEmptyKey) cur = atomicCAS(&fk[f], kEmptyKey, key);
+                if (cur == kEmptyKey || cur == key) {
+                    atomicMin(&ft[f], (uint32_t)r);
+                    slv[u] = -2 - (int32_t)f;   // resolved to the HBM slot after the fold table is flushed
+                    done = true;
+                    break;
+                }
+                f = (f + 1) & (kSpgFold - 1);
+            }
+            if (!done) slv[u] = uniq_global_insert(a.table, key, tag0 + (unsigned long long)r, a.flags);
+        }
+    }
+    __syncthreads();
+    for (int s2 = tid; s2 < kSpgFold; s2 += kWalkThreads)
+        if (fk[s2] != kEmptyKey) fs[s2] = uniq_global_insert(a.table, fk[s2], tag0 + ft[s2], a.flags);
+    // id range of the set
+    int32_t mn = 0x7FFFFFFF, mx = 0;
+#pragma unroll
+    for (int u = 0; u < kSpgPerLane; ++u)
+        if (tid + u * kWalkThreads < ns) {
+            mn = min(mn, idv[u]);
+            mx = max(mx, idv[u]);
+        }
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        mn = min(mn, __shfl_xor(mn, d, kWave));
+        mx = max(mx, __shfl_xor(mx, d, kWave));
+    }
+    if ((tid & (kWave - 1)) == 0) {
+        red[tid / kWave] = mn;
+        red[4 + tid / kWave] = mx;
+    }
+    __syncthreads();   // fold table flushed, reductions visible, every lane holds its members: LDS tables are free
+    mn = min(min(red[0], red[1]), min(red[2], red[3]));
+    mx = max(max(red[4], red[5]), max(red[6], red[7]));
+#pragma unroll
+    for (int u = 0; u < kSpgPerLane; ++u)
+        if (slv[u] <= -2) slv[u] = fs[-2 - slv[u]];
+    unsigned long long *A = pk;                 // [ns] (id << 32 | slot), first grouped by bucket, then sorted
+    int32_t *start = keys;                      // [B+1]
+    int32_t *cursor = keys + (T / 4) + 1;       // [B]      B <= T/4
+    int logb = 0;
+    while ((1 << logb) < ns && (2 << logb) <= T / 4) ++logb;
+    const int B = 1 << logb;
+    const uint32_t range = (uint32_t)(mx - mn) + 1u;
+    const int Ls = (range <= 1u) ? 0 : (32 - __builtin_clz(range - 1u));
+    for (int b = tid; b < B; b += kWalkThreads) cursor[b] = 0;
+    __syncthreads();
+    uint32_t bk[kSpgPerLane];
+#pragma unroll
+    for (int u = 0; u < kSpgPerLane; ++u) {
+        bk[u] = (uint32_t)(((uint64_t)(uint32_t)(idv[u] - mn) << logb) >> Ls);
+        if (tid + u * kWalkThreads < ns) atomicAdd(&cursor[bk[u]], 1);
+    }
+    __syncthreads();
+    {   // exclusive scan over the buckets: `per` consecutive buckets per lane + one block scan
+        const int per = (B + kWalkThreads - 1) / kWalkThreads;
+        const int b0 = tid * per;
+        int32_t sum = 0;
+        for (int b = b0; b < b0 + per && b < B; ++b) sum += cursor[b];
+        int32_t tot;
+        int32_t run = block_exclusive_scan<int32_t>(sum, &tot);
+        for (int b = b0; b < b0 + per && b < B; ++b) {
+            const int32_t c = cursor[b];
+            start[b] = run;
+            cursor[b] = run;
+            run += c;
+        }
+        if (tid == 0) start[B] = tot;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kSpgPerLane; ++u)
+        if (tid + u * kWalkThreads < ns)
+            A[atomicAdd(&cursor[bk[u]], 1)] = ((unsigned long long)(uint32_t)idv[u] << 32) | (uint32_t)slv[u];
+    __syncthreads();
+    int32_t pos[kSpgPerLane];
+#pragma unroll
+    for (int u = 0; u < kSpgPerLane; ++u) {
+        pos[u] = -1;
+        if (tid + u * kWalkThreads < ns) {
+            const unsigned long long me = ((unsigned long long)(uint32_t)idv[u] << 32) | (uint32_t)slv[u];
+            const int lo = start[bk[u]], hi = start[bk[u] + 1];
+            int rank = 0;
+            for (int t2 = lo; t2 < hi; ++t2) rank += (A[t2] < me) ? 1 : 0;
+            pos[u] = lo + rank;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kSpgPerLane; ++u)
+        if (pos[u] >= 0) A[pos[u]] = ((unsigned long long)(uint32_t)idv[u] << 32) | (uint32_t)slv[u];
+    __syncthreads();
+    for (int r = tid; r < ns; r += kWalkThreads) {
+        const unsigned long long w = A[r];
+        a.set_ids[obase + r] = (int32_t)(w >> 32);
+        a.set_slot[obase + r] = (int32_t)(uint32_t)w;
     }
 }
 
@@ -402,8 +544,10 @@ static int table_size_for(int64_t q) {
     return t;
 }
 
-static size_t walk_lds_bytes(int T, int nwords, int M, int Q) {
-    return (size_t)T * 16 + (size_t)nwords * 4 + (size_t)(nwords + 1) * 4 + (size_t)M * 4 + (size_t)Q * 2 + 16;
+static size_t walk_lds_bytes(int T, int nwords, int M, int Q, bool spg) {
+    size_t b = (size_t)T * 16 + (size_t)nwords * 4 + (size_t)(nwords + 1) * 4 + (size_t)M * 4 + (size_t)Q * 2 + 16;
+    if (spg) b += 8 + (size_t)kSpgFold * 16 + 64;
+    return b;
 }
 
 }  // namespace subgacc
@@ -459,25 +603,34 @@ extern "C" int subgacc_rng_positions(const subgacc_walk_cfg *cfg, const void *in
     return SUBGACC_OK;
 }
 
-extern "C" int subgacc_walk_sets(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices,
-                                 int64_t num_nodes, const int32_t *query, int64_t n, const uint32_t *rng_pos,
-                                 const uint32_t *rng_seed, int32_t *set_ids, uint64_t *set_keys, int32_t *nsize,
-                                 int32_t *walks, int32_t *flags, void *stream) {
-    SG_REQUIRE(cfg && indptr && set_ids && set_keys && nsize && flags, SUBGACC_ERR_BADARG, "walk_sets: null argument");
-    SG_REQUIRE(n >= 0 && num_nodes >= 0, SUBGACC_ERR_BADARG, "walk_sets: negative size");
+static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,
+                       const int32_t *query, int64_t n, const uint32_t *rng_pos, const uint32_t *rng_seed,
+                       int32_t *set_ids, uint64_t *set_keys, int32_t *set_slot, void *uniq_table, int64_t uniq_capacity,
+                       int64_t root_base, int32_t *nsize, int32_t *walks, int32_t *flags, void *stream) {
+    const bool spg = set_slot != nullptr;
+    SG_REQUIRE(cfg && indptr && set_ids && (set_keys || spg) && nsize && flags, SUBGACC_ERR_BADARG,
+               "walk: null argument");
+    SG_REQUIRE(n >= 0 && num_nodes >= 0, SUBGACC_ERR_BADARG, "walk: negative size");
     SG_REQUIRE(cfg->rng_mode == SUBGACC_RNG_RAND_R || cfg->rng_mode == SUBGACC_RNG_PHILOX, SUBGACC_ERR_BADARG,
-               "walk_sets: unknown rng_mode %d", cfg->rng_mode);
+               "walk: unknown rng_mode %d", cfg->rng_mode);
     const int shift = subgacc_key_shift(cfg->num_walks, cfg->num_steps);
     if (shift < 0) return shift;
     const int M = cfg->num_walks, m = cfg->num_steps;
-    SG_REQUIRE((int64_t)M * m + 1 <= (1 << 20), SUBGACC_ERR_LDS, "walk_sets: M*m+1 = %lld too large", (long long)M * m + 1);
+    SG_REQUIRE((int64_t)M * m + 1 <= (1 << 20), SUBGACC_ERR_LDS, "walk: M*m+1 = %lld too large", (long long)M * m + 1);
     const int Q = M * m + 1;
     const int stride = cfg->bucket > 0 ? cfg->bucket : Q;
-    SG_REQUIRE(!cfg->emit_walks || walks, SUBGACC_ERR_BADARG, "walk_sets: emit_walks without a walks buffer");
+    SG_REQUIRE(!cfg->emit_walks || walks, SUBGACC_ERR_BADARG, "walk: emit_walks without a walks buffer");
     SG_REQUIRE(cfg->rng_mode != SUBGACC_RNG_RAND_R || (rng_pos && rng_seed) || n == 0, SUBGACC_ERR_BADARG,
-               "walk_sets: RAND_R mode needs rng_pos/rng_seed from subgacc_rng_positions");
+               "walk: RAND_R mode needs rng_pos/rng_seed from subgacc_rng_positions");
+    if (spg) {
+        SG_REQUIRE(Q <= kSpgPerLane * kWalkThreads, SUBGACC_ERR_LDS,
+                   "walk_spg: M*m+1 = %d > %d; use subgacc_walk_sets + subgacc_spg_build", Q, kSpgPerLane * kWalkThreads);
+        SG_REQUIRE(uniq_table && uniq_capacity > 0 && (uniq_capacity & (uniq_capacity - 1)) == 0 &&
+                       uniq_capacity < (1ll << 31) && root_base >= 0,
+                   SUBGACC_ERR_BADARG, "walk_spg: needs a power-of-two table of distinct rows");
+    }
     if (n == 0) return SUBGACC_OK;
-    SG_REQUIRE(query, SUBGACC_ERR_BADARG, "walk_sets: null query");   // `indices` may be NULL for an edgeless graph
+    SG_REQUIRE(query, SUBGACC_ERR_BADARG, "walk: null query");   // `indices` may be NULL for an edgeless graph
 
     WalkArgs a;
     a.indptr = indptr, a.indices = indices, a.query = query, a.n = n;
@@ -493,31 +646,62 @@ extern "C" int subgacc_walk_sets(const subgacc_walk_cfg *cfg, const void *indptr
     a.wo = cfg->first_hop_wo ? 1 : 0;
     a.step_major = cfg->order == SUBGACC_ORDER_STEP_MAJOR ? 1 : 0;
     a.cap_root = cfg->cap_root_degree ? 1 : 0;
-    SG_REQUIRE(a.T <= 65536, SUBGACC_ERR_LDS, "walk_sets: M*m+1 = %d is too large for the per-root LDS tables", Q);
-    const size_t lds = walk_lds_bytes(a.T, a.nwords, M, Q);
+    a.set_slot = set_slot;
+    a.table = spg ? uniq_view(uniq_table, uniq_capacity) : UniqTable{nullptr, nullptr, nullptr, 0};
+    a.root_base = root_base;
+    SG_REQUIRE(a.T <= 65536, SUBGACC_ERR_LDS, "walk: M*m+1 = %d is too large for the per-root LDS tables", Q);
+    const size_t lds = walk_lds_bytes(a.T, a.nwords, M, Q, spg);
     SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS,
-               "walk_sets: per-root tables need %zu B of LDS (> %d): M*m+1 = %d is too large", lds, kLdsBytes, Q);
+               "walk: per-root tables need %zu B of LDS (> %d): M*m+1 = %d is too large", lds, kLdsBytes, Q);
 
     hipStream_t s = (hipStream_t)stream;
     const int64_t grid = xcd_grid(n);
-    SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "walk_sets: chunk of %lld roots too large, split it", (long long)n);
-#define SG_WALK_LAUNCH(I64, RNGM)                                                                                 \
+    SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "walk: chunk of %lld roots too large, split it", (long long)n);
+#define SG_WALK_LAUNCH(I64, RNGM, SPGM)                                                                           \
     do {                                                                                                          \
         if (lds > 64 * 1024)                                                                                      \
-            SG_CHECK_HIP(hipFuncSetAttribute((const void *)walk_sets_kernel<I64, RNGM>,                           \
+            SG_CHECK_HIP(hipFuncSetAttribute((const void *)walk_sets_kernel<I64, RNGM, SPGM>,                     \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
-        hipLaunchKernelGGL((walk_sets_kernel<I64, RNGM>), dim3((unsigned)grid), dim3(kWalkThreads), lds, s, a);   \
+        hipLaunchKernelGGL((walk_sets_kernel<I64, RNGM, SPGM>), dim3((unsigned)grid), dim3(kWalkThreads), lds, s, \
+                           a);                                                                                    \
+    } while (0)
+#define SG_WALK_RNG(I64, SPGM)                                                                                    \
+    do {                                                                                                          \
+        if (cfg->rng_mode == SUBGACC_RNG_RAND_R) SG_WALK_LAUNCH(I64, SUBGACC_RNG_RAND_R, SPGM);                   \
+        else SG_WALK_LAUNCH(I64, SUBGACC_RNG_PHILOX, SPGM);                                                       \
     } while (0)
     if (cfg->indptr64) {
-        if (cfg->rng_mode == SUBGACC_RNG_RAND_R) SG_WALK_LAUNCH(true, SUBGACC_RNG_RAND_R);
-        else SG_WALK_LAUNCH(true, SUBGACC_RNG_PHILOX);
+        if (spg) SG_WALK_RNG(true, true);
+        else SG_WALK_RNG(true, false);
     } else {
-        if (cfg->rng_mode == SUBGACC_RNG_RAND_R) SG_WALK_LAUNCH(false, SUBGACC_RNG_RAND_R);
-        else SG_WALK_LAUNCH(false, SUBGACC_RNG_PHILOX);
+        if (spg) SG_WALK_RNG(false, true);
+        else SG_WALK_RNG(false, false);
     }
+#undef SG_WALK_RNG
 #undef SG_WALK_LAUNCH
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
+}
+
+extern "C" int subgacc_walk_sets(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices,
+                                 int64_t num_nodes, const int32_t *query, int64_t n, const uint32_t *rng_pos,
+                                 const uint32_t *rng_seed, int32_t *set_ids, uint64_t *set_keys, int32_t *nsize,
+                                 int32_t *walks, int32_t *flags, void *stream) {
+    SG_REQUIRE(set_keys, SUBGACC_ERR_BADARG, "walk_sets: null set_keys");
+    return launch_walk(cfg, indptr, indices, num_nodes, query, n, rng_pos, rng_seed, set_ids, set_keys, nullptr, nullptr,
+                       0, 0, nsize, walks, flags, stream);
+}
+
+extern "C" int subgacc_walk_spg(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices,
+                                int64_t num_nodes, const int32_t *query, int64_t n, int64_t root_base,
+                                const uint32_t *rng_pos, const uint32_t *rng_seed, void *uniq_table,
+                                int64_t uniq_capacity, int32_t *row_ids, int32_t *row_slot, int32_t *nsize,
+                                int32_t *flags, void *stream) {
+    SG_REQUIRE(row_slot, SUBGACC_ERR_BADARG, "walk_spg: null row_slot");
+    SG_REQUIRE(cfg && !cfg->emit_walks && cfg->order == SUBGACC_ORDER_WALK_MAJOR, SUBGACC_ERR_BADARG,
+               "walk_spg: set_sampler order only, no raw walks");
+    return launch_walk(cfg, indptr, indices, num_nodes, query, n, rng_pos, rng_seed, row_ids, nullptr, row_slot,
+                       uniq_table, uniq_capacity, root_base, nsize, nullptr, flags, stream);
 }
 
 extern "C" int subgacc_compact_sets(const int32_t *set_ids, const uint64_t *set_keys, const int32_t *nsize,
@@ -542,6 +726,39 @@ extern "C" int subgacc_compact_sets(const int32_t *set_ids, const uint64_t *set_
         hipLaunchKernelGGL(compact_sets_kernel<false>, dim3((unsigned)blocks), dim3(kCompactThreads), 0,
                            (hipStream_t)stream, set_ids, set_keys, nsize, row_off, n, stride, out_ids, out_keys,
                            UniqTable{nullptr, nullptr, nullptr, 0}, (int64_t)0, (int32_t *)nullptr, (int32_t *)nullptr);
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}
+
+// SPG mode: rows are already final (sorted ids + table slot); this is a plain strided -> packed copy
+__global__ __launch_bounds__(kCompactThreads) void compact_rows_kernel(const int32_t *__restrict__ row_ids,
+                                                                        const int32_t *__restrict__ row_slot,
+                                                                        const int32_t *__restrict__ nsize,
+                                                                        const int64_t *__restrict__ row_off, int64_t n,
+                                                                        int32_t stride, int32_t *__restrict__ out_indices,
+                                                                        int32_t *__restrict__ out_data) {
+    const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    const int64_t i = (int64_t)blockIdx.x * kCompactWaves + wave;
+    if (i >= n) return;
+    const int ns = nsize[i];
+    const int64_t src = i * (int64_t)stride, dst = row_off[i];
+    for (int r = lane; r < ns; r += kWave) {
+        out_indices[dst + r] = row_ids[src + r];
+        out_data[dst + r] = row_slot[src + r];
+    }
+}
+
+extern "C" int subgacc_compact_rows(const int32_t *row_ids, const int32_t *row_slot, const int32_t *nsize,
+                                    const int64_t *row_off, int64_t n, int32_t stride, int32_t *out_indices,
+                                    int32_t *out_data, void *stream) {
+    SG_REQUIRE(n >= 0 && stride > 0, SUBGACC_ERR_BADARG, "compact_rows: bad sizes");
+    if (n == 0) return SUBGACC_OK;
+    SG_REQUIRE(row_ids && row_slot && nsize && row_off && out_indices && out_data, SUBGACC_ERR_BADARG,
+               "compact_rows: null argument");
+    const int64_t blocks = ceil_div(n, kCompactWaves);
+    SG_REQUIRE(blocks < (1ll << 31), SUBGACC_ERR_BADARG, "compact_rows: too many rows in one call");
+    hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)blocks), dim3(kCompactThreads), 0, (hipStream_t)stream,
+                       row_ids, row_slot, nsize, row_off, n, stride, out_indices, out_data);
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }

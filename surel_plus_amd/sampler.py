@@ -245,6 +245,93 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     return sets
 
 
+def sample_spg_rows(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, rng="rand_r", calls_before=0,
+                    staging_bytes=STAGING_BYTES, uniq_capacity=UNIQ_CAPACITY, uniq_small_limit=0):
+    """Fused SpG pipeline (subgacc_walk_spg): every set leaves the walk kernel as a finished SpG row.
+
+    Returns (row_off int64[n+1], indices int32[X] sorted per row, data int32[X] = SFptr+1, ukeys int64[c], nsize,
+    n_overflow) or None when the configuration does not fit the fused kernel (M*m+1 > 1024, or more distinct LP
+    rows than the direct ranking handles) -- the caller then uses sample_sets + SpG.from_sets."""
+    L = lib()
+    dev = csr.device
+    q = _as_query(query, dev)
+    n = q.numel()
+    cfg = make_cfg(csr, num_walks, num_steps, bucket, seed, rng, True, _lib.ORDER_WALK_MAJOR, True, False)
+    check(L.subgacc_key_shift(cfg.num_walks, cfg.num_steps))
+    M, m = cfg.num_walks, cfg.num_steps
+    if M * m + 1 > 1024:
+        return None
+    stride = bucket if bucket > 0 else M * m + 1
+    st = stream_ptr()
+    flags = torch.zeros(4, dtype=torch.int32, device=dev)
+    rng_pos = rng_seed = None
+    if cfg.rng_mode == _lib.RNG_RAND_R and n > 0:
+        rng_pos = torch.empty(n, dtype=torch.int32, device=dev)
+        rng_seed = torch.empty(n, dtype=torch.int32, device=dev)
+        ws = torch.empty(L.subgacc_rng_positions_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        check(L.subgacc_rng_positions(cfg, ptr(csr.indptr), ptr(q), n, 1, int(calls_before), ptr(rng_pos), ptr(rng_seed),
+                                      ptr(ws), ws.numel(), st))
+    table = torch.empty(L.subgacc_uniq_table_bytes(uniq_capacity), dtype=torch.uint8, device=dev)
+    check(L.subgacc_uniq_reset(ptr(table), uniq_capacity, st))
+    nsize = torch.empty(n, dtype=torch.int32, device=dev)
+    chunk = max(1, min(n, int(staging_bytes // (stride * 8)), (1 << 31) - 16)) if n else 0
+    idx_parts, dat_parts = [], []
+    if n:
+        st_ids = torch.empty(chunk * stride, dtype=torch.int32, device=dev)
+        st_slot = torch.empty(chunk * stride, dtype=torch.int32, device=dev)
+        scan_ws = torch.empty(L.subgacc_scan_workspace_bytes(chunk), dtype=torch.uint8, device=dev)
+        off_chunk = torch.empty(chunk + 1, dtype=torch.int64, device=dev)
+    X = 0
+    for lo in range(0, n, chunk if chunk else 1):
+        cn = min(chunk, n - lo)
+        with _timed("walk_sets"):
+            check(L.subgacc_walk_spg(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn, lo,
+                                     ptr(rng_pos[lo:]) if rng_pos is not None else None,
+                                     ptr(rng_seed[lo:]) if rng_seed is not None else None,
+                                     ptr(table), uniq_capacity, ptr(st_ids), ptr(st_slot), ptr(nsize[lo:]), ptr(flags), st))
+        check(L.subgacc_exclusive_scan_i32(ptr(nsize[lo:]), cn, ptr(off_chunk), ptr(scan_ws), scan_ws.numel(), st))
+        total = int(off_chunk[cn].item())        # the one host round trip of this chunk
+        idx_c = torch.empty(total, dtype=torch.int32, device=dev)
+        dat_c = torch.empty(total, dtype=torch.int32, device=dev)
+        with _timed("compact_sets"):
+            check(L.subgacc_compact_rows(ptr(st_ids), ptr(st_slot), ptr(nsize[lo:]), ptr(off_chunk), cn, stride,
+                                         ptr(idx_c), ptr(dat_c), st))
+        idx_parts.append(idx_c)
+        dat_parts.append(dat_c)
+        X += total
+    if len(idx_parts) == 1:
+        indices, data = idx_parts[0], dat_parts[0]
+    elif idx_parts:
+        indices, data = torch.cat(idx_parts), torch.cat(dat_parts)
+    else:
+        indices = torch.empty(0, dtype=torch.int32, device=dev)
+        data = torch.empty(0, dtype=torch.int32, device=dev)
+    del idx_parts, dat_parts
+    row_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    ws = torch.empty(L.subgacc_scan_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    check(L.subgacc_exclusive_scan_i32(ptr(nsize), n, ptr(row_off), ptr(ws), ws.numel(), st))
+    # number the distinct LP rows by first occurrence (direct ranking of the table), then slot -> SFptr+1 in place
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    limit = uniq_small_limit if uniq_small_limit > 0 else 16384
+    max_unique = min(max(X, 1), uniq_capacity, limit)
+    ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
+    ws = torch.empty(L.subgacc_uniq_number_workspace_bytes(uniq_capacity, 0), dtype=torch.uint8, device=dev)
+    with _timed("uniq_rows"):
+        check(L.subgacc_uniq_number(ptr(table), uniq_capacity, None, 0, ptr(ukeys), max_unique, ptr(count), limit,
+                                    ptr(ws), ws.numel(), st))
+        check(L.subgacc_uniq_translate(ptr(table), uniq_capacity, ptr(data), X, 1, st))
+    status = torch.cat([flags.long(), count]).tolist()
+    dummy = SampledSets(nsize, row_off, indices, None, None, None, M, m, stride)
+    _check_walk_flags(dummy, status[:4])
+    if status[2]:     # table (nearly) full: walk again with a larger one
+        return sample_spg_rows(csr, q, num_walks, num_steps, bucket, seed, rng, calls_before, staging_bytes,
+                               uniq_capacity * 4, uniq_small_limit)
+    c = status[4]
+    if c > limit:     # too many distinct rows for the direct ranking: the caller takes the general pipeline
+        return None
+    return row_off, indices, data, ukeys[:c].clone(), nsize, dummy.n_overflow
+
+
 def _check_walk_flags(sets, fl):
     if fl[0]:
         raise _lib.SubgAccError(

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
-from .sampler import DeviceCSR, _timed, sample_sets
+from .sampler import DeviceCSR, SampledSets, _timed, sample_sets, sample_spg_rows
 
 
 class SpG:
@@ -75,7 +75,26 @@ class SpG:
                              shape=self.shape)
 
 
-def subg_matrix(G, train_idx, num_walks=200, num_steps=4, seed=111413, rng="rand_r", device=None):
+def sample_spg(csr, query, num_walks=200, num_steps=3, seed=111413, rng="rand_r", bucket=-1, fused=True, **kw):
+    """sample -> SpG on the GPU: (SpG, SampledSets-like summary with ukeys / nsize / feature_table()).
+
+    `num_steps` = walk hops (gset_sampler's meaning).  fused=True runs the one-kernel-per-root pipeline
+    (csrc/walk.hip SPG mode) and falls back to sample_sets + SpG.from_sets when it does not apply."""
+    n_cols = csr.num_nodes
+    if fused:
+        out = sample_spg_rows(csr, query, num_walks=num_walks, num_steps=num_steps, bucket=bucket, seed=seed, rng=rng, **kw)
+        if out is not None:
+            row_off, indices, data, ukeys, nsize, n_overflow = out
+            stride = bucket if bucket > 0 else num_walks * num_steps + 1
+            info = SampledSets(nsize, row_off, indices, None, None, ukeys, int(num_walks), int(num_steps), stride,
+                               n_overflow=n_overflow)
+            z = SpG(row_off, indices, data, max_len=stride, shape=(nsize.numel(), n_cols), max_data=int(ukeys.numel()))
+            return z, info
+    sets = sample_sets(csr, query, num_walks=num_walks, num_steps=num_steps, bucket=bucket, seed=seed, rng=rng, **kw)
+    return SpG.from_sets(sets, n_cols=n_cols), sets
+
+
+def subg_matrix(G, train_idx, num_walks=200, num_steps=4, seed=111413, rng="rand_r", device=None, fused=True):
     """Drop-in for sampler/random_walks.py:74-82: returns (z, enc).
 
     z   -- SpG on the GPU (row i = sampled set of train_idx[i]); the reference indexes rows by node id and
@@ -87,8 +106,7 @@ def subg_matrix(G, train_idx, num_walks=200, num_steps=4, seed=111413, rng="rand
     if _lib.VERBOSE:
         print(f'Start sampling for #{len(train_idx)} nodes with {num_walks} {num_steps}-step walks')
     csr = G if isinstance(G, DeviceCSR) else DeviceCSR(G.indptr, G.indices, device)
-    sets = sample_sets(csr, train_idx, num_walks=num_walks, num_steps=num_steps - 1, seed=seed, rng=rng)
-    z = SpG.from_sets(sets, n_cols=csr.num_nodes)
+    z, sets = sample_spg(csr, train_idx, num_walks=num_walks, num_steps=num_steps - 1, seed=seed, rng=rng, fused=fused)
     enc = sets.enc_int16().cpu().numpy()
     enc = np.insert(enc, 0, np.zeros((1, num_steps), dtype=enc.dtype), axis=0)
     z.sets = sets

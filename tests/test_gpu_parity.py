@@ -464,3 +464,50 @@ def test_walk_sampler_philox_and_many_streams(sp, replacement):
         off = np.concatenate([[0], np.cumsum(on)])
         assert all(np.array_equal(obj[i, 0], oi[off[i]:off[i + 1]]) and np.array_equal(obj[i, 1], oc[off[i]:off[i + 1]])
                    for i in range(700))
+
+
+# ------------------------------------------------------------------------ fused SpG pipeline (walk_spg)
+def _oracle_spg(ptr_, idx, q, M, m, seed, rng, bucket=-1):
+    nsize, remap, enc = oracle.gset_sampler(ptr_, idx, q, num_walks=M, num_steps=m, bucket=bucket, seed=seed, rng=rng,
+                                            nthreads=8 if rng == "philox" else 1)
+    return oracle.spg_build(nsize, remap), enc
+
+
+@pytest.mark.parametrize("rng", ["rand_r", "philox"])
+@pytest.mark.parametrize("M,m,N,E,hubs,bucket", [(200, 2, 20000, 80000, 4, -1), (200, 3, 6000, 200000, 0, -1),
+                                                 (100, 4, 3000, 9000, 2, -1), (7, 5, 500, 1500, 1, -1),
+                                                 (255, 4, 2000, 100000, 1, -1), (64, 3, 3000, 9000, 2, 10), (1, 1, 300, 900, 0, -1)])
+def test_fused_spg_pipeline_matches_oracle(sp, rng, M, m, N, E, hubs, bucket):
+    """one kernel per root: walk + dedup + LP + unique-row registration + sort by id (csrc/walk.hip, SPG mode)."""
+    ptr_, idx = sym_graph(N, E, seed=M + m, hubs=hubs)
+    q = np.concatenate([np.random.default_rng(3).permutation(N)[: min(N, 3000)], [0, 0, 1]])
+    from surel_plus_amd.sampler import DeviceCSR
+    csr = DeviceCSR(ptr_, idx)
+    (oi, ox, od), oenc = _oracle_spg(ptr_, idx, q, M, m, 11, rng, bucket)
+    for fused in (True, False):
+        z, info = sp.sample_spg(csr, q, num_walks=M, num_steps=m, seed=11, rng=rng, bucket=bucket, fused=fused)
+        assert np.array_equal(z.indptr.cpu().numpy(), oi), fused
+        assert np.array_equal(z.indices.cpu().numpy(), ox), fused
+        assert np.array_equal(z.data.cpu().numpy(), od), fused
+        assert np.array_equal(info.enc_int16().cpu().numpy(), oenc), fused
+        assert z.max_data == oenc.shape[0]
+
+
+def test_fused_spg_multichunk_overflow_and_fallbacks(sp):
+    ptr_, idx = sym_graph(4000, 16000, seed=31, hubs=2)
+    ptr_[-1:]  # keep flake quiet
+    q = np.arange(4000)
+    from surel_plus_amd.sampler import DeviceCSR, sample_spg_rows
+    csr = DeviceCSR(ptr_.astype(np.int64), idx)                    # int64 row offsets
+    (oi, ox, od), oenc = _oracle_spg(ptr_, idx, q, 100, 4, 5, "rand_r")
+    # 9 chunks + a 64-slot table that must be regrown
+    z, info = sp.sample_spg(csr, q, num_walks=100, num_steps=4, seed=5, staging_bytes=401 * 8 * 450, uniq_capacity=64)
+    assert np.array_equal(z.indptr.cpu().numpy(), oi) and np.array_equal(z.indices.cpu().numpy(), ox)
+    assert np.array_equal(z.data.cpu().numpy(), od) and np.array_equal(info.enc_int16().cpu().numpy(), oenc)
+    # more distinct rows than the direct ranking is allowed to handle -> None -> general pipeline
+    assert sample_spg_rows(csr, q, num_walks=100, num_steps=4, seed=5, uniq_small_limit=16) is None
+    # M*m+1 > 1024 does not fit the fused kernel
+    assert sample_spg_rows(csr, q[:10], num_walks=300, num_steps=4, seed=5) is None
+    z2, _ = sp.sample_spg(csr, q[:300], num_walks=300, num_steps=4, seed=5, rng="philox")
+    (oi2, ox2, od2), _ = _oracle_spg(ptr_, idx, q[:300], 300, 4, 5, "philox")
+    assert np.array_equal(z2.indices.cpu().numpy(), ox2) and np.array_equal(z2.data.cpu().numpy(), od2)
