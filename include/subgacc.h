@@ -105,7 +105,7 @@ int subgacc_walk_sets(const subgacc_walk_cfg *cfg, const void *indptr, const int
  *   row_slot[n*stride] int32  slot of the member's LP key in `uniq_table` (translate after subgacc_uniq_number)
  * The keys are registered in the table with tag (root_base+i)*stride + first-visit rank, which numbers the
  * distinct rows exactly like the reference's sequential pass (subg_acc.c:957-978); root_base = global index of
- * query[0] when a job is split into chunks.  Needs M*m+1 <= 1024 (SUBGACC_ERR_LDS otherwise: use
+ * query[0] when a job is split into chunks.  Needs M*m+1 <= 818 (SUBGACC_ERR_LDS otherwise: use
  * subgacc_walk_sets + subgacc_compact_sets + subgacc_spg_build).  flags as for subgacc_walk_sets, [2] |= 1
  * when the table is (nearly) full. */
 int subgacc_walk_spg(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,

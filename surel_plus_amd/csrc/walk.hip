@@ -155,8 +155,12 @@ __global__ __launch_bounds__(kWalkThreads) void walk_sets_kernel(const WalkArgs 
     uint32_t *prefix = bitmap + a.nwords;                        // [nwords + 1]
     int32_t *sarr = (int32_t *)(prefix + a.nwords + 1);          // [M] Fisher-Yates draws
     uint16_t *inv = (uint16_t *)(sarr + a.M);                    // [M*m+1] table slot of the member ranked r
-    // SPG mode only: fold table of distinct LP keys + a reduction scratch, behind inv (8-byte aligned)
-    unsigned long long *fk = (unsigned long long *)(((uintptr_t)(inv + (a.M * a.m + 1)) + 7) & ~(uintptr_t)7);   // [kSpgFold]
+    // SPG mode only: fold table of distinct LP keys + a reduction scratch.  Without a truncating bucket the
+    // ranking arrays (bitmap / prefix / inv) are never touched and the fold table takes their place, which keeps
+    // the footprint at 8 workgroups per CU; with a bucket it sits behind inv.
+    const bool fold_aliased = SPG && !(a.stride < a.M * a.m + 1);
+    unsigned long long *fk = fold_aliased ? (unsigned long long *)(((uintptr_t)(sarr + a.M) + 7) & ~(uintptr_t)7)
+                                          : (unsigned long long *)(((uintptr_t)(inv + (a.M * a.m + 1)) + 7) & ~(uintptr_t)7);
     uint32_t *ft = (uint32_t *)(fk + kSpgFold);                  // [kSpgFold] min rank of the key inside the set
     int32_t *fs = (int32_t *)(ft + kSpgFold);                    // [kSpgFold] HBM table slot of the key
     int32_t *red = fs + kSpgFold;                                // [16]
@@ -192,6 +196,13 @@ __global__ __launch_bounds__(kWalkThreads) void walk_sets_kernel(const WalkArgs 
         pk[h] = 0ull;
     }
     for (int x = tid; x < a.nwords; x += kWalkThreads) bitmap[x] = 0u;
+    if (SPG) {
+        for (int s2 = tid; s2 < kSpgFold; s2 += kWalkThreads) {
+            fk[s2] = kEmptyKey;
+            ft[s2] = 0xFFFFFFFFu;
+        }
+        if (tid < 16) red[tid] = tid < 4 ? 0x7FFFFFFF : 0;   // [0..3] min id per wave, [4..7] max id, [8] member count
+    }
 
     uint32_t rpos = 0, rseed = a.seed;
     if (RNG == SUBGACC_RNG_RAND_R) {
@@ -223,6 +234,7 @@ __global__ __launch_bounds__(kWalkThreads) void walk_sets_kernel(const WalkArgs 
     __syncthreads();
 
     const uint32_t tmask = (uint32_t)T - 1u;
+    int32_t vmin = root, vmax = root;   // id range of everything this lane visits (SPG mode: bucket scaling)
     for (int w = tid; w < M; w += kWalkThreads) {
         // ---- first hop
         int32_t cur = root;
@@ -290,39 +302,60 @@ __global__ __launch_bounds__(kWalkThreads) void walk_sets_kernel(const WalkArgs 
                 h = (h + 1u) & tmask;
             }
             const uint32_t q = a.step_major ? (uint32_t)(s * M + w + 1) : (uint32_t)(w * m + s + 1);
+            if (SPG) {
+                vmin = min(vmin, cur);
+                vmax = max(vmax, cur);
+            }
             atomicMin(&minq[h], q);
             atomicAdd(&pk[h], 1ull << ((m - 1 - s) * a.shift));
         }
     }
+    if (SPG) {
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) {
+            vmin = min(vmin, __shfl_xor(vmin, d, kWave));
+            vmax = max(vmax, __shfl_xor(vmax, d, kWave));
+        }
+        if ((tid & (kWave - 1)) == 0) {
+            red[tid / kWave] = vmin;
+            red[4 + tid / kWave] = vmax;
+        }
+    }
     __syncthreads();
 
-    // ---- rank the members by first visit: bitmap over q, popcount prefix
-    for (int h = tid; h < T; h += kWalkThreads)
-        if (keys[h] != -1) {
-            const uint32_t q = minq[h];
-            atomicOr(&bitmap[q >> 5], 1u << (q & 31u));
+    // ---- rank the members by first visit: bitmap over q, popcount prefix.  The SPG mode only needs an ORDER of
+    // first visits for its tags -- the visit sequence number itself is one -- so it ranks only when a bucket can
+    // truncate the set (members ranked >= bucket are dropped, subg_acc.c:814-828)
+    const bool need_rank = !SPG || a.stride < M * m + 1;
+    int32_t total = 0, ns = 0;
+    if (need_rank) {
+        for (int h = tid; h < T; h += kWalkThreads)
+            if (keys[h] != -1) {
+                const uint32_t q = minq[h];
+                atomicOr(&bitmap[q >> 5], 1u << (q & 31u));
+            }
+        __syncthreads();
+        for (int x = tid; x <= a.nwords; x += kWalkThreads) {
+            uint32_t s = 0;
+            for (int j = 0; j < x; ++j) s += __popc(bitmap[j]);
+            prefix[x] = s;
         }
-    __syncthreads();
-    for (int x = tid; x <= a.nwords; x += kWalkThreads) {
-        uint32_t s = 0;
-        for (int j = 0; j < x; ++j) s += __popc(bitmap[j]);
-        prefix[x] = s;
-    }
-    __syncthreads();
-    const int32_t total = (int32_t)prefix[a.nwords];
-    const int32_t ns = total < a.stride ? total : a.stride;
-    for (int h = tid; h < T; h += kWalkThreads)
-        if (keys[h] != -1) {
-            const uint32_t q = minq[h];
-            const int32_t r = (int32_t)(prefix[q >> 5] + __popc(bitmap[q >> 5] & ((1u << (q & 31u)) - 1u)));
-            if (r < a.stride) inv[r] = (uint16_t)h;  // members ranked past the bucket are dropped (:814-828)
-        }
-    __syncthreads();
-    if (tid == 0) {
-        a.nsize[i] = ns;
-        if (total > a.stride) atomicAdd(&a.flags[1], 1);
+        __syncthreads();
+        total = (int32_t)prefix[a.nwords];
+        ns = total < a.stride ? total : a.stride;
+        for (int h = tid; h < T; h += kWalkThreads)
+            if (keys[h] != -1) {
+                const uint32_t q = minq[h];
+                const int32_t r = (int32_t)(prefix[q >> 5] + __popc(bitmap[q >> 5] & ((1u << (q & 31u)) - 1u)));
+                if (r < a.stride) inv[r] = (uint16_t)h;  // members ranked past the bucket are dropped (:814-828)
+            }
+        __syncthreads();
     }
     if (!SPG) {
+        if (tid == 0) {
+            a.nsize[i] = ns;
+            if (total > a.stride) atomicAdd(&a.flags[1], 1);
+        }
         // members leave in rank order: consecutive lanes write consecutive words of the staging row
         for (int r = tid; r < ns; r += kWalkThreads) {
             const int h = inv[r];
@@ -334,128 +367,118 @@ __global__ __launch_bounds__(kWalkThreads) void walk_sets_kernel(const WalkArgs 
 
     // ================= SPG mode: the set leaves as a finished SpG row =================
     // (1) fold the set's LP keys (a few dozen distinct rows) and register them in the HBM table of distinct rows
-    //     with tag = (global root index)*stride + first-visit rank, which orders first occurrences exactly like the
+    //     with tag = (global root index)*stride + first-visit order, which orders first occurrences exactly like the
     //     reference's sequential pass (subg_acc.c:957-978); (2) bucket-sort the members by node id in the LDS the
-    //     walk tables occupied (random_walks.py:79-80).  All of it hides under other workgroups' line fetches.
-    for (int s2 = tid; s2 < kSpgFold; s2 += kWalkThreads) {
-        fk[s2] = kEmptyKey;
-        ft[s2] = 0xFFFFFFFFu;
-    }
-    __syncthreads();
+    //     walk tables occupied (random_walks.py:79-80) and write them to their sorted position.
     const unsigned long long tag0 = (unsigned long long)((a.root_base + i) * (int64_t)a.stride);
     int32_t idv[kSpgPerLane], slv[kSpgPerLane];
-    unsigned long long kyv[kSpgPerLane];
+    bool ok[kSpgPerLane];
+    int mycount = 0;
 #pragma unroll
     for (int u = 0; u < kSpgPerLane; ++u) {
-        const int r = tid + u * kWalkThreads;
-        idv[u] = 0, slv[u] = -1, kyv[u] = 0ull;
-        if (r < ns) {
-            const int h = inv[r];
+        // member u of this lane: by rank (bucket mode) or straight from its table slot
+        const int x = tid + u * kWalkThreads;
+        int h = 0;
+        uint32_t tagoff = 0;
+        if (need_rank) {
+            ok[u] = x < ns;
+            if (ok[u]) h = inv[x];
+            tagoff = (uint32_t)x;
+        } else {
+            ok[u] = x < T && keys[x] != -1;
+            h = x;
+            if (ok[u]) tagoff = minq[x];
+        }
+        idv[u] = 0, slv[u] = -1;
+        if (ok[u]) {
+            ++mycount;
             idv[u] = keys[h];
-            const unsigned long long key = pk[h] | (r == 0 ? lead : 0ull);
-            kyv[u] = key;
+            const unsigned long long key = pk[h] | (tagoff == 0 ? lead : 0ull);   // the root is rank 0 / visit 0
             uint32_t f = (uint32_t)(mix64(key) >> 40) & (kSpgFold - 1);
             bool done = false;
             for (int p = 0; p < 16; ++p) {
                 unsigned long long cur = fk[f];
                 if (cur == kEmptyKey) cur = atomicCAS(&fk[f], kEmptyKey, key);
                 if (cur == kEmptyKey || cur == key) {
-                    atomicMin(&ft[f], (uint32_t)r);
+                    atomicMin(&ft[f], tagoff);
                     slv[u] = -2 - (int32_t)f;   // resolved to the HBM slot after the fold table is flushed
                     done = true;
                     break;
                 }
                 f = (f + 1) & (kSpgFold - 1);
             }
-            if (!done) slv[u] = uniq_global_insert(a.table, key, tag0 + (unsigned long long)r, a.flags);
+            if (!done) slv[u] = uniq_global_insert(a.table, key, tag0 + (unsigned long long)tagoff, a.flags);
         }
     }
-    __syncthreads();
-    for (int s2 = tid; s2 < kSpgFold; s2 += kWalkThreads)
-        if (fk[s2] != kEmptyKey) fs[s2] = uniq_global_insert(a.table, fk[s2], tag0 + ft[s2], a.flags);
-    // id range of the set
-    int32_t mn = 0x7FFFFFFF, mx = 0;
+    if (!need_rank) {
 #pragma unroll
-    for (int u = 0; u < kSpgPerLane; ++u)
-        if (tid + u * kWalkThreads < ns) {
-            mn = min(mn, idv[u]);
-            mx = max(mx, idv[u]);
-        }
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) {
-        mn = min(mn, __shfl_xor(mn, d, kWave));
-        mx = max(mx, __shfl_xor(mx, d, kWave));
+        for (int d = kWave / 2; d > 0; d >>= 1) mycount += __shfl_xor(mycount, d, kWave);
+        if ((tid & (kWave - 1)) == 0) atomicAdd(&red[8], mycount);
     }
-    if ((tid & (kWave - 1)) == 0) {
-        red[tid / kWave] = mn;
-        red[4 + tid / kWave] = mx;
+    __syncthreads();   // every lane holds its members in registers: the walk tables are free to be re-used
+    if (!need_rank) total = ns = red[8];
+    if (tid == 0) {
+        a.nsize[i] = ns;
+        if (total > a.stride) atomicAdd(&a.flags[1], 1);
     }
-    __syncthreads();   // fold table flushed, reductions visible, every lane holds its members: LDS tables are free
-    mn = min(min(red[0], red[1]), min(red[2], red[3]));
-    mx = max(max(red[4], red[5]), max(red[6], red[7]));
-#pragma unroll
-    for (int u = 0; u < kSpgPerLane; ++u)
-        if (slv[u] <= -2) slv[u] = fs[-2 - slv[u]];
-    unsigned long long *A = pk;                 // [ns] (id << 32 | slot), first grouped by bucket, then sorted
+    const int32_t mn = min(min(red[0], red[1]), min(red[2], red[3]));
+    const int32_t mx = max(max(red[4], red[5]), max(red[6], red[7]));
+    unsigned long long *A = pk;                 // [ns] (id << 32 | slot) grouped by bucket
     int32_t *start = keys;                      // [B+1]
-    int32_t *cursor = keys + (T / 4) + 1;       // [B]      B <= T/4
+    int32_t *cursor = keys + (T / 4) + 1;       // [B]      B <= min(T/4, 256)
     int logb = 0;
-    while ((1 << logb) < ns && (2 << logb) <= T / 4) ++logb;
+    while ((1 << logb) < ns && (2 << logb) <= T / 4 && (2 << logb) <= kWalkThreads) ++logb;
     const int B = 1 << logb;
     const uint32_t range = (uint32_t)(mx - mn) + 1u;
     const int Ls = (range <= 1u) ? 0 : (32 - __builtin_clz(range - 1u));
-    for (int b = tid; b < B; b += kWalkThreads) cursor[b] = 0;
+    if (tid < B) cursor[tid] = 0;
+    for (int s2 = tid; s2 < kSpgFold; s2 += kWalkThreads)    // flush the fold table to HBM (latency overlaps the sort)
+        if (fk[s2] != kEmptyKey) fs[s2] = uniq_global_insert(a.table, fk[s2], tag0 + ft[s2], a.flags);
     __syncthreads();
     uint32_t bk[kSpgPerLane];
 #pragma unroll
     for (int u = 0; u < kSpgPerLane; ++u) {
         bk[u] = (uint32_t)(((uint64_t)(uint32_t)(idv[u] - mn) << logb) >> Ls);
-        if (tid + u * kWalkThreads < ns) atomicAdd(&cursor[bk[u]], 1);
+        if (ok[u]) atomicAdd(&cursor[bk[u]], 1);
+        if (slv[u] <= -2) slv[u] = fs[-2 - slv[u]];
     }
     __syncthreads();
-    {   // exclusive scan over the buckets: `per` consecutive buckets per lane + one block scan
-        const int per = (B + kWalkThreads - 1) / kWalkThreads;
+    if (tid < kWave) {   // exclusive scan over the <= 256 buckets by one wave: 4 consecutive buckets per lane
+        const int per = (B + kWave - 1) / kWave;
         const int b0 = tid * per;
         int32_t sum = 0;
         for (int b = b0; b < b0 + per && b < B; ++b) sum += cursor[b];
-        int32_t tot;
-        int32_t run = block_exclusive_scan<int32_t>(sum, &tot);
+        int32_t inc = sum;
+#pragma unroll
+        for (int dd = 1; dd < kWave; dd <<= 1) {
+            const int32_t t2 = __shfl_up(inc, dd, kWave);
+            if (tid >= dd) inc += t2;
+        }
+        int32_t run = inc - sum;
         for (int b = b0; b < b0 + per && b < B; ++b) {
             const int32_t c = cursor[b];
             start[b] = run;
             cursor[b] = run;
             run += c;
         }
-        if (tid == 0) start[B] = tot;
+        if (tid == kWave - 1) start[B] = inc;
     }
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < kSpgPerLane; ++u)
-        if (tid + u * kWalkThreads < ns)
-            A[atomicAdd(&cursor[bk[u]], 1)] = ((unsigned long long)(uint32_t)idv[u] << 32) | (uint32_t)slv[u];
+        if (ok[u]) A[atomicAdd(&cursor[bk[u]], 1)] = ((unsigned long long)(uint32_t)idv[u] << 32) | (uint32_t)slv[u];
     __syncthreads();
-    int32_t pos[kSpgPerLane];
+    // order inside a bucket = number of smaller ids in it; the member goes straight to its final slot of the row
 #pragma unroll
-    for (int u = 0; u < kSpgPerLane; ++u) {
-        pos[u] = -1;
-        if (tid + u * kWalkThreads < ns) {
+    for (int u = 0; u < kSpgPerLane; ++u)
+        if (ok[u]) {
             const unsigned long long me = ((unsigned long long)(uint32_t)idv[u] << 32) | (uint32_t)slv[u];
             const int lo = start[bk[u]], hi = start[bk[u] + 1];
             int rank = 0;
             for (int t2 = lo; t2 < hi; ++t2) rank += (A[t2] < me) ? 1 : 0;
-            pos[u] = lo + rank;
+            a.set_ids[obase + lo + rank] = idv[u];
+            a.set_slot[obase + lo + rank] = slv[u];
         }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < kSpgPerLane; ++u)
-        if (pos[u] >= 0) A[pos[u]] = ((unsigned long long)(uint32_t)idv[u] << 32) | (uint32_t)slv[u];
-    __syncthreads();
-    for (int r = tid; r < ns; r += kWalkThreads) {
-        const unsigned long long w = A[r];
-        a.set_ids[obase + r] = (int32_t)(w >> 32);
-        a.set_slot[obase + r] = (int32_t)(uint32_t)w;
-    }
 }
 
 // ------------------------------------------------------------------------------- compaction
@@ -544,10 +567,12 @@ static int table_size_for(int64_t q) {
     return t;
 }
 
-static size_t walk_lds_bytes(int T, int nwords, int M, int Q, bool spg) {
-    size_t b = (size_t)T * 16 + (size_t)nwords * 4 + (size_t)(nwords + 1) * 4 + (size_t)M * 4 + (size_t)Q * 2 + 16;
-    if (spg) b += 8 + (size_t)kSpgFold * 16 + 64;
-    return b;
+static size_t walk_lds_bytes(int T, int nwords, int M, int Q, bool spg, bool bucket_truncates) {
+    const size_t head = (size_t)T * 16 + (size_t)nwords * 4 + (size_t)(nwords + 1) * 4 + (size_t)M * 4;
+    const size_t fold = 8 + (size_t)kSpgFold * 16 + 64;
+    if (!spg) return head + (size_t)Q * 2 + 16;
+    if (bucket_truncates) return head + (size_t)Q * 2 + fold + 16;
+    return head + (fold > (size_t)Q * 2 ? fold : (size_t)Q * 2) + 16;   // the fold table overlays inv
 }
 
 }  // namespace subgacc
@@ -623,8 +648,9 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
     SG_REQUIRE(cfg->rng_mode != SUBGACC_RNG_RAND_R || (rng_pos && rng_seed) || n == 0, SUBGACC_ERR_BADARG,
                "walk: RAND_R mode needs rng_pos/rng_seed from subgacc_rng_positions");
     if (spg) {
-        SG_REQUIRE(Q <= kSpgPerLane * kWalkThreads, SUBGACC_ERR_LDS,
-                   "walk_spg: M*m+1 = %d > %d; use subgacc_walk_sets + subgacc_spg_build", Q, kSpgPerLane * kWalkThreads);
+        SG_REQUIRE(table_size_for(Q) <= kSpgPerLane * kWalkThreads, SUBGACC_ERR_LDS,
+                   "walk_spg: M*m+1 = %d needs a per-root table above %d slots; use subgacc_walk_sets + subgacc_spg_build",
+                   Q, kSpgPerLane * kWalkThreads);
         SG_REQUIRE(uniq_table && uniq_capacity > 0 && (uniq_capacity & (uniq_capacity - 1)) == 0 &&
                        uniq_capacity < (1ll << 31) && root_base >= 0,
                    SUBGACC_ERR_BADARG, "walk_spg: needs a power-of-two table of distinct rows");
@@ -650,7 +676,7 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
     a.table = spg ? uniq_view(uniq_table, uniq_capacity) : UniqTable{nullptr, nullptr, nullptr, 0};
     a.root_base = root_base;
     SG_REQUIRE(a.T <= 65536, SUBGACC_ERR_LDS, "walk: M*m+1 = %d is too large for the per-root LDS tables", Q);
-    const size_t lds = walk_lds_bytes(a.T, a.nwords, M, Q, spg);
+    const size_t lds = walk_lds_bytes(a.T, a.nwords, M, Q, spg, stride < Q);
     SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS,
                "walk: per-root tables need %zu B of LDS (> %d): M*m+1 = %d is too large", lds, kLdsBytes, Q);
 

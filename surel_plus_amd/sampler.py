@@ -250,7 +250,7 @@ def sample_spg_rows(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=1114
     """Fused SpG pipeline (subgacc_walk_spg): every set leaves the walk kernel as a finished SpG row.
 
     Returns (row_off int64[n+1], indices int32[X] sorted per row, data int32[X] = SFptr+1, ukeys int64[c], nsize,
-    n_overflow) or None when the configuration does not fit the fused kernel (M*m+1 > 1024, or more distinct LP
+    n_overflow) or None when the configuration does not fit the fused kernel (M*m+1 > 818, or more distinct LP
     rows than the direct ranking handles) -- the caller then uses sample_sets + SpG.from_sets."""
     L = lib()
     dev = csr.device
@@ -259,7 +259,7 @@ def sample_spg_rows(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=1114
     cfg = make_cfg(csr, num_walks, num_steps, bucket, seed, rng, True, _lib.ORDER_WALK_MAJOR, True, False)
     check(L.subgacc_key_shift(cfg.num_walks, cfg.num_steps))
     M, m = cfg.num_walks, cfg.num_steps
-    if M * m + 1 > 1024:
+    if M * m + 1 > 818:      # the fused kernel keeps 4 table slots per lane in registers (table <= 1024 slots)
         return None
     stride = bucket if bucket > 0 else M * m + 1
     st = stream_ptr()

@@ -476,7 +476,7 @@ def _oracle_spg(ptr_, idx, q, M, m, seed, rng, bucket=-1):
 @pytest.mark.parametrize("rng", ["rand_r", "philox"])
 @pytest.mark.parametrize("M,m,N,E,hubs,bucket", [(200, 2, 20000, 80000, 4, -1), (200, 3, 6000, 200000, 0, -1),
                                                  (100, 4, 3000, 9000, 2, -1), (7, 5, 500, 1500, 1, -1),
-                                                 (255, 4, 2000, 100000, 1, -1), (64, 3, 3000, 9000, 2, 10), (1, 1, 300, 900, 0, -1)])
+                                                 (200, 4, 2000, 100000, 1, -1), (64, 3, 3000, 9000, 2, 10), (1, 1, 300, 900, 0, -1)])
 def test_fused_spg_pipeline_matches_oracle(sp, rng, M, m, N, E, hubs, bucket):
     """one kernel per root: walk + dedup + LP + unique-row registration + sort by id (csrc/walk.hip, SPG mode)."""
     ptr_, idx = sym_graph(N, E, seed=M + m, hubs=hubs)
