@@ -42,7 +42,8 @@ WORKLOADS = {
     "cit2ppr": (None, 0, 1, "cit2-like PPR encoder: float64 SpG, N=2,927,963 rows x top-100, SpJoin only (train.py:39-43)"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FUSED = os.environ.get("SUBGACC_FUSED", "1") == "1"   # 0: the general pipeline (walk_sets + compact + spg_build)
+FUSED = os.environ.get("SUBGACC_FUSED", "0") == "1"   # 1: the walk kernel also emits finished SpG rows (walk_spg)
+LAZY = os.environ.get("SUBGACC_LAZY", "1") == "1"     # sizes stay on the device: one host round trip per step
 
 
 @contextlib.contextmanager
@@ -90,10 +91,11 @@ def hot_path_step(sp, csr, edge, M, k, seed, rng):
     """sample both endpoints of every pair, build the SpG, join.  Returns (xz, indptr, sets)."""
     B = edge.shape[1]
     roots = edge.reshape(-1).to(torch.int32)
-    z, sets = sp.sample_spg(csr, roots, num_walks=M, num_steps=k - 1, seed=seed, rng=rng, fused=FUSED)
+    z, sets = sp.sample_spg(csr, roots, num_walks=M, num_steps=k - 1, seed=seed, rng=rng, fused=FUSED, lazy=LAZY)
     table = sets.feature_table()
     rows = torch.arange(2 * B, device=edge.device, dtype=torch.int64).view(2, B)   # row i = root i of this batch
     xz, ind = sp.gather(rows, z, edge.device, ptr=True, encode=table)
+    sets.resolve()      # sizes, status flags and the distinct-row count: read once, after everything is queued
     return xz, ind, sets
 
 

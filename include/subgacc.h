@@ -151,14 +151,17 @@ int subgacc_uniq_number(void *table, int64_t capacity, const int32_t *slot, int6
                         int64_t max_unique, int64_t *out_count, int64_t small_limit, void *workspace,
                         size_t workspace_bytes, void *stream);
 /* slot_inout[e] <- index of the element's key (+add): remap[1] of the reference with add = 0, the SpG payload
- * SFptr+1 with add = 1 */
-int subgacc_uniq_translate(void *table, int64_t capacity, int32_t *slot_inout, int64_t n, int32_t add, void *stream);
+ * SFptr+1 with add = 1.  n_dev (optional, device scalar): process min(n, *n_dev) elements -- lets a caller that
+ * has not read the element count back yet launch over its buffer capacity. */
+int subgacc_uniq_translate(void *table, int64_t capacity, int32_t *slot_inout, int64_t n, const int64_t *n_dev,
+                           int32_t add, void *stream);
 
 /* Unpack keys to LP rows [n, m+1]: col 0 = M on LEAD rows else 0 (subg_acc.c:751,982-1000).
  * out_i16 / out_i32 / out_f32 may each be NULL; out_f32 is float(count)/float(M) (main.py:174) and,
- * with zero_row != 0, gets an all-zero row prepended (random_walks.py:81) => [n+1, m+1]. */
-int subgacc_unpack_lp(const uint64_t *keys, int64_t n, int32_t num_walks, int32_t num_steps, int16_t *out_i16,
-                      int32_t *out_i32, float *out_f32, int32_t zero_row, void *stream);
+ * with zero_row != 0, gets an all-zero row prepended (random_walks.py:81) => [n+1, m+1].
+ * n_dev (optional, device scalar): only the first min(n, *n_dev) keys are valid, later rows are zero-filled. */
+int subgacc_unpack_lp(const uint64_t *keys, int64_t n, const int64_t *n_dev, int32_t num_walks, int32_t num_steps,
+                      int16_t *out_i16, int32_t *out_i32, float *out_f32, int32_t zero_row, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * SpG build (sampler/random_walks.py:79-80: scipy COO->CSR): sort each row's members by node id.

@@ -85,8 +85,8 @@ def lib():
         "subgacc_uniq_insert": (C.c_int, [vp, i64, vp, i64, i64, vp, vp, vp]),
         "subgacc_uniq_number_workspace_bytes": (sz, [i64, i64]),
         "subgacc_uniq_number": (C.c_int, [vp, i64, vp, i64, vp, i64, vp, i64, vp, sz, vp]),
-        "subgacc_uniq_translate": (C.c_int, [vp, i64, vp, i64, i32, vp]),
-        "subgacc_unpack_lp": (C.c_int, [vp, i64, i32, i32, vp, vp, vp, i32, vp]),
+        "subgacc_uniq_translate": (C.c_int, [vp, i64, vp, i64, vp, i32, vp]),
+        "subgacc_unpack_lp": (C.c_int, [vp, i64, vp, i32, i32, vp, vp, vp, i32, vp]),
         "subgacc_spg_build": (C.c_int, [vp, i64, vp, vp, vp, i64, i32, vp, vp, vp, vp]),
         "subgacc_sjoin_workspace_bytes": (sz, [i64]),
         "subgacc_sjoin_sizes": (C.c_int, [vp, vp, i64, vp, vp, sz, vp]),

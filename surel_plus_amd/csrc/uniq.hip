@@ -167,9 +167,10 @@ __global__ __launch_bounds__(kScanThreads) void uniq_assign_kernel(UniqTable t, 
 }
 
 // element -> number of its key (+add)
-__global__ __launch_bounds__(256) void uniq_translate_kernel(UniqTable t, int64_t n, int32_t *__restrict__ sf,
-                                                              int32_t add) {
+__global__ __launch_bounds__(256) void uniq_translate_kernel(UniqTable t, int64_t n, const int64_t *__restrict__ n_dev,
+                                                              int32_t *__restrict__ sf, int32_t add) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev && *n_dev < n) n = *n_dev;   // the element count may still live on the device (no host round trip)
     if (e < n) sf[e] = t.id[sf[e]] + add;
 }
 
@@ -182,13 +183,19 @@ __device__ __forceinline__ void unpack_row(unsigned long long key, int M, int m,
     for (int j = 1; j <= m; ++j) row[j] = (OutI)((key >> ((m - j) * shift)) & fmask);
 }
 
-__global__ __launch_bounds__(256) void unpack_lp_kernel(const uint64_t *__restrict__ keys, int64_t n, int M, int m,
-                                                         int shift, int16_t *o16, int32_t *o32, float *of32,
-                                                         int zero_row) {
+__global__ __launch_bounds__(256) void unpack_lp_kernel(const uint64_t *__restrict__ keys, int64_t n,
+                                                         const int64_t *__restrict__ n_dev, int M, int m, int shift,
+                                                         int16_t *o16, int32_t *o32, float *of32, int zero_row) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int ncol = m + 1;
     if (of32 && zero_row && e < ncol) of32[e] = 0.0f;
     if (e >= n) return;
+    if (n_dev && e >= *n_dev) {   // rows past the device-side count: defined (zero), never indexed
+        if (o16) for (int j = 0; j < ncol; ++j) o16[e * ncol + j] = 0;
+        if (o32) for (int j = 0; j < ncol; ++j) o32[e * ncol + j] = 0;
+        if (of32) for (int j = 0; j < ncol; ++j) of32[(e + (zero_row ? 1 : 0)) * ncol + j] = 0.0f;
+        return;
+    }
     const unsigned long long key = keys[e];
     if (o16) unpack_row<int16_t>(key, M, m, shift, o16 + e * ncol);
     if (o32) unpack_row<int32_t>(key, M, m, shift, o32 + e * ncol);
@@ -293,27 +300,28 @@ extern "C" int subgacc_uniq_number(void *table, int64_t capacity, const int32_t 
     return SUBGACC_OK;
 }
 
-extern "C" int subgacc_uniq_translate(void *table, int64_t capacity, int32_t *slot_inout, int64_t n, int32_t add,
-                                      void *stream) {
+extern "C" int subgacc_uniq_translate(void *table, int64_t capacity, int32_t *slot_inout, int64_t n,
+                                      const int64_t *n_dev, int32_t add, void *stream) {
     SG_REQUIRE(table && is_pow2(capacity) && capacity < (1ll << 31) && n >= 0, SUBGACC_ERR_BADARG,
                "uniq_translate: bad arguments");
     if (n == 0) return SUBGACC_OK;
     SG_REQUIRE(slot_inout, SUBGACC_ERR_BADARG, "uniq_translate: null slot array");
     hipLaunchKernelGGL(uniq_translate_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       uniq_view(table, capacity), n, slot_inout, add);
+                       uniq_view(table, capacity), n, n_dev, slot_inout, add);
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }
 
-extern "C" int subgacc_unpack_lp(const uint64_t *keys, int64_t n, int32_t num_walks, int32_t num_steps,
-                                 int16_t *out_i16, int32_t *out_i32, float *out_f32, int32_t zero_row, void *stream) {
+extern "C" int subgacc_unpack_lp(const uint64_t *keys, int64_t n, const int64_t *n_dev, int32_t num_walks,
+                                 int32_t num_steps, int16_t *out_i16, int32_t *out_i32, float *out_f32, int32_t zero_row,
+                                 void *stream) {
     const int shift = subgacc_key_shift(num_walks, num_steps);
     if (shift < 0) return shift;
     SG_REQUIRE(n >= 0 && (keys || n == 0), SUBGACC_ERR_BADARG, "unpack_lp: bad arguments");
     const int64_t work = n > (num_steps + 1) ? n : (num_steps + 1);  // the zero row is written by the first threads
     if (n == 0 && !(out_f32 && zero_row)) return SUBGACC_OK;
     hipLaunchKernelGGL(unpack_lp_kernel, dim3((unsigned)ceil_div(work, 256)), dim3(256), 0, (hipStream_t)stream, keys, n,
-                       num_walks, num_steps, shift, out_i16, out_i32, out_f32, zero_row);
+                       n_dev, num_walks, num_steps, shift, out_i16, out_i32, out_f32, zero_row);
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }

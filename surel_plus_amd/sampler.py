@@ -1,10 +1,15 @@
 """Device-resident node-set sampler: walks -> per-root dedup + LP counts -> global unique LP rows.
 
-Host side of the kernels in csrc/walk.hip and csrc/uniq.hip.  Everything stays in HBM; the only host
-round trip is one 8-byte read per chunk of roots (the chunk's total set size, needed to size the packed
-output).  Mirrors the stages of set_sampler (reference subg_acc/subg_acc.c:736-1005).
+Host side of the kernels in csrc/walk.hip and csrc/uniq.hip.  Everything stays in HBM.  Mirrors the stages of
+set_sampler (reference subg_acc/subg_acc.c:736-1005).
+
+Host round trips.  The eager form reads one 8-byte total per chunk of roots (to size the packed arrays exactly)
+and one status word at the end.  The `lazy` form (single chunk) sizes its arrays by their upper bound
+n*(M*m+1), leaves every count on the device and reads nothing back: sizes, flags and the distinct-row count
+are fetched in one copy when the caller first asks for them (SampledSets.resolve()), so a whole
+sample -> SpG -> SpJoin step queues up asynchronously.
 """
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 
 import numpy as np
 import torch
@@ -15,6 +20,8 @@ from ._lib import WalkCfg, check, lib, ptr, stream_ptr
 # strided staging budget per chunk of roots (bytes); stride*12 B per root
 STAGING_BYTES = 6 << 30
 UNIQ_CAPACITY = 1 << 20
+FUSED_MAX_Q = 818       # subgacc_walk_spg keeps 4 table slots per lane in registers (per-root table <= 1024 slots)
+RANK_LIMIT = 16384      # distinct LP rows that the table-only numbering ranks directly
 
 # bench.py sets this to a callable(name) -> context manager that brackets one kernel launch with HIP events
 # on the launch stream (roofline.achieved is measured live, not taken from a profile)
@@ -58,10 +65,12 @@ class DeviceCSR:
 
 @dataclass
 class SampledSets:
-    """Output of the sampler, all on device.  remap = (ids, sf) and enc in the reference's terms."""
+    """Output of the sampler, all on device.  remap = (ids, sf) and enc in the reference's terms.
+
+    In lazy form `ids` / `slot` / `ukeys` are capacity-sized until resolve() trims them; `X` and `c` resolve."""
     nsize: torch.Tensor      # int32 [n]
     row_off: torch.Tensor    # int64 [n+1]
-    ids: torch.Tensor        # int32 [X]   members, first-visit order per root
+    ids: torch.Tensor        # int32 [X]   members, first-visit order per root (sorted by id in the fused SpG form)
     keys: torch.Tensor       # int64 [X]   packed LP row (bit pattern of the uint64 key); None when only slots are kept
     sf: torch.Tensor         # int32 [X]   index of the member's LP row in `ukeys` (None until asked for: get_sf())
     ukeys: torch.Tensor      # int64 [c]   distinct LP rows in first-occurrence order
@@ -73,30 +82,66 @@ class SampledSets:
     slot: torch.Tensor = None    # int32 [X]   slot of the member's key in `table` (fused compaction + insert)
     table: torch.Tensor = None   # the HBM table of distinct LP rows (uint8 blob, layout of csrc/uniq_table.hpp)
     capacity: int = 0
+    status: torch.Tensor = None  # lazy form: device int64 [flags(4), distinct rows, members], not read back yet
+    data: torch.Tensor = None    # fused SpG form: SFptr+1 per member (capacity-sized while lazy)
+
+    # ------------------------------------------------------------------ lazy bookkeeping
+    @property
+    def pending(self):
+        return self.status is not None
+
+    def resolve(self):
+        """Read sizes and status flags back (one small copy), raise on errors, trim capacity-sized arrays."""
+        if self.status is None:
+            return self
+        st = self.status.tolist()
+        self.status = None
+        check_walk_flags(self, st[:4])
+        if st[2]:
+            raise _lib.SubgAccError("the table of distinct LP rows overflowed: sample again with a larger "
+                                    "uniq_capacity (or lazy=False, which retries by itself)")
+        c, X = st[4], st[5]
+        if c > self.ukeys.numel():
+            raise _lib.SubgAccError(f"{c} distinct LP rows exceed the direct-ranking limit: sample with lazy=False")
+        self.ukeys = self.ukeys[:c]
+        self.ids = self.ids[:X]
+        for name in ("slot", "keys", "data", "sf"):
+            t = getattr(self, name)
+            if t is not None:
+                setattr(self, name, t[:X])
+        return self
 
     @property
     def X(self):
-        return self.ids.numel()
+        return self.resolve().ids.numel()
 
     @property
     def c(self):
-        return self.ukeys.numel()
+        return self.resolve().ukeys.numel()
 
+    def _count_dev(self):
+        """device views of (distinct-row count, member count) while lazy, else (None, None)"""
+        if self.status is None:
+            return None, None
+        return self.status[4:5], self.status[5:6]
+
+    # ------------------------------------------------------------------ views of the result
     def get_sf(self):
         """int32 [X]: remap[1] of the reference.  Materialised on demand from the table slots."""
         if self.sf is None:
             if self.slot is None:
                 raise ValueError("the sets were sampled with dedup=False")
+            self.resolve()
             sf = self.slot.clone()
-            check(lib().subgacc_uniq_translate(ptr(self.table), self.capacity, ptr(sf), self.X, 0, stream_ptr()))
+            check(lib().subgacc_uniq_translate(ptr(self.table), self.capacity, ptr(sf), self.X, None, 0, stream_ptr()))
             self.sf = sf
         return self.sf
 
     def enc_int16(self):
         """int16 [c, m+1]: the reference's `enc` (subg_acc.c:982-1000)."""
         out = torch.empty((self.c, self.num_steps + 1), dtype=torch.int16, device=self.ids.device)
-        check(lib().subgacc_unpack_lp(ptr(self.ukeys), self.c, self.num_walks, self.num_steps, ptr(out), None, None, 0,
-                                      stream_ptr()))
+        check(lib().subgacc_unpack_lp(ptr(self.ukeys), self.c, None, self.num_walks, self.num_steps, ptr(out), None, None,
+                                      0, stream_ptr()))
         return out
 
     def counts_int32(self):
@@ -104,15 +149,18 @@ class SampledSets:
         if self.keys is None:
             raise ValueError("the packed keys were not kept (sample_sets(..., keep_keys=True))")
         out = torch.empty((self.X, self.num_steps + 1), dtype=torch.int32, device=self.ids.device)
-        check(lib().subgacc_unpack_lp(ptr(self.keys), self.X, self.num_walks, self.num_steps, None, ptr(out), None, 0,
-                                      stream_ptr()))
+        check(lib().subgacc_unpack_lp(ptr(self.keys), self.X, None, self.num_walks, self.num_steps, None, ptr(out), None,
+                                      0, stream_ptr()))
         return out
 
     def feature_table(self):
-        """float32 [c+1, m+1] = [0-row ; enc / M]: Z_SF as main.py:174 + random_walks.py:81 build it."""
-        out = torch.empty((self.c + 1, self.num_steps + 1), dtype=torch.float32, device=self.ids.device)
-        check(lib().subgacc_unpack_lp(ptr(self.ukeys), self.c, self.num_walks, self.num_steps, None, None, ptr(out), 1,
-                                      stream_ptr()))
+        """float32 [c+1, m+1] = [0-row ; enc / M]: Z_SF as main.py:174 + random_walks.py:81 build it.
+        While lazy the table has one row per ukeys slot (rows past the real count are zero and never indexed)."""
+        rows = self.ukeys.numel()
+        cdev, _ = self._count_dev()
+        out = torch.empty((rows + 1, self.num_steps + 1), dtype=torch.float32, device=self.ids.device)
+        check(lib().subgacc_unpack_lp(ptr(self.ukeys), rows, ptr(cdev), self.num_walks, self.num_steps, None, None,
+                                      ptr(out), 1, stream_ptr()))
         return out
 
 
@@ -133,206 +181,7 @@ def _as_query(query, device):
     return torch.from_numpy(np.ascontiguousarray(np.asarray(query).astype(np.int32)).ravel()).to(device)
 
 
-def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, rng="rand_r", first_hop_wo=True,
-                order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False, rng_streams=1,
-                calls_before=0, dedup=True, keep_keys=None, staging_bytes=STAGING_BYTES, uniq_capacity=UNIQ_CAPACITY,
-                uniq_small_limit=0):
-    """Run the sampler for `query` (roots) on the GPU.  See SampledSets.
-
-    dedup=True numbers the distinct LP rows (ukeys, slot/get_sf()); the packed keys are then only kept when
-    keep_keys is set.  Host round trips: one 8-byte read per chunk of roots (its total set size) and one read of
-    the status words + distinct-row count at the end."""
-    L = lib()
-    dev = csr.device
-    q = _as_query(query, dev)
-    n = q.numel()
-    cfg = make_cfg(csr, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order, cap_root_degree, emit_walks)
-    check(L.subgacc_key_shift(cfg.num_walks, cfg.num_steps))   # AssertionError like subg_acc.c:911-915
-    M, m = cfg.num_walks, cfg.num_steps
-    stride = bucket if bucket > 0 else M * m + 1
-    st = stream_ptr()
-    flags = torch.zeros(4, dtype=torch.int32, device=dev)
-    if keep_keys is None:
-        keep_keys = not dedup
-
-    rng_pos = rng_seed = None
-    if cfg.rng_mode == _lib.RNG_RAND_R and n > 0:
-        rng_pos = torch.empty(n, dtype=torch.int32, device=dev)
-        rng_seed = torch.empty(n, dtype=torch.int32, device=dev)
-        ws = torch.empty(L.subgacc_rng_positions_workspace_bytes(n), dtype=torch.uint8, device=dev)
-        check(L.subgacc_rng_positions(cfg, ptr(csr.indptr), ptr(q), n, int(rng_streams), int(calls_before), ptr(rng_pos),
-                                      ptr(rng_seed), ptr(ws), ws.numel(), st))
-
-    table = None
-    if dedup:
-        table = torch.empty(L.subgacc_uniq_table_bytes(uniq_capacity), dtype=torch.uint8, device=dev)
-        check(L.subgacc_uniq_reset(ptr(table), uniq_capacity, st))
-
-    nsize = torch.empty(n, dtype=torch.int32, device=dev)
-    walks = torch.empty((n, M * (m + 1)), dtype=torch.int32, device=dev) if emit_walks else None
-    chunk = max(1, min(n, int(staging_bytes // (stride * 12)), (1 << 31) - 16)) if n else 0
-    ids_parts, key_parts, slot_parts = [], [], []
-    if n:
-        st_ids = torch.empty(chunk * stride, dtype=torch.int32, device=dev)
-        st_keys = torch.empty(chunk * stride, dtype=torch.int64, device=dev)
-        scan_ws = torch.empty(L.subgacc_scan_workspace_bytes(chunk), dtype=torch.uint8, device=dev)
-        off_chunk = torch.empty(chunk + 1, dtype=torch.int64, device=dev)
-    X = 0
-    for lo in range(0, n, chunk if chunk else 1):
-        cn = min(chunk, n - lo)
-        with _timed("walk_sets"):
-            check(L.subgacc_walk_sets(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn,
-                                      ptr(rng_pos[lo:]) if rng_pos is not None else None,
-                                      ptr(rng_seed[lo:]) if rng_seed is not None else None,
-                                      ptr(st_ids), ptr(st_keys), ptr(nsize[lo:]),
-                                      ptr(walks[lo:]) if walks is not None else None, ptr(flags), st))
-        check(L.subgacc_exclusive_scan_i32(ptr(nsize[lo:]), cn, ptr(off_chunk), ptr(scan_ws), scan_ws.numel(), st))
-        total = int(off_chunk[cn].item())        # the one host round trip of this chunk
-        ids_c = torch.empty(total, dtype=torch.int32, device=dev)
-        keys_c = torch.empty(total, dtype=torch.int64, device=dev) if keep_keys else None
-        slot_c = torch.empty(total, dtype=torch.int32, device=dev) if dedup else None
-        with _timed("compact_sets"):
-            check(L.subgacc_compact_sets(ptr(st_ids), ptr(st_keys), ptr(nsize[lo:]), ptr(off_chunk), cn, stride,
-                                         ptr(ids_c), ptr(keys_c), ptr(table), uniq_capacity if dedup else 0, X,
-                                         ptr(slot_c), ptr(flags), st))
-        ids_parts.append(ids_c)
-        key_parts.append(keys_c)
-        slot_parts.append(slot_c)
-        X += total
-
-    def _cat(parts, dtype):
-        parts = [p_ for p_ in parts if p_ is not None]
-        if not parts:
-            return None
-        return parts[0] if len(parts) == 1 else torch.cat(parts)
-    ids = _cat(ids_parts, torch.int32)
-    if ids is None:
-        ids = torch.empty(0, dtype=torch.int32, device=dev)
-    keys = _cat(key_parts, torch.int64)
-    if keys is None and keep_keys:
-        keys = torch.empty(0, dtype=torch.int64, device=dev)
-    slot = _cat(slot_parts, torch.int32)
-    if slot is None and dedup:
-        slot = torch.empty(0, dtype=torch.int32, device=dev)
-    del ids_parts, key_parts, slot_parts
-
-    row_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
-    ws = torch.empty(L.subgacc_scan_workspace_bytes(n), dtype=torch.uint8, device=dev)
-    check(L.subgacc_exclusive_scan_i32(ptr(nsize), n, ptr(row_off), ptr(ws), ws.numel(), st))
-
-    sets = SampledSets(nsize, row_off, ids, keys, None, None, M, m, stride, walks)
-    if not dedup:
-        _check_walk_flags(sets, flags.tolist())
-        return sets
-    # number the distinct LP rows by first occurrence (subg_acc.c:957-1000)
-    count = torch.zeros(1, dtype=torch.int64, device=dev)
-    max_unique = min(X, uniq_capacity)
-    ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
-    ws = torch.empty(L.subgacc_uniq_number_workspace_bytes(uniq_capacity, X), dtype=torch.uint8, device=dev)
-    with _timed("uniq_rows"):
-        check(L.subgacc_uniq_number(ptr(table), uniq_capacity, ptr(slot), X, ptr(ukeys), max_unique, ptr(count),
-                                    uniq_small_limit, ptr(ws), ws.numel(), st))
-    status = torch.cat([flags.long(), count]).tolist()
-    _check_walk_flags(sets, status[:4])
-    if status[2]:
-        # the table of distinct rows was (nearly) full -- more distinct LP rows than guessed: walk again with a
-        # larger one (rare: the paper's graphs have 10^2..10^5 distinct rows against 2^20 slots)
-        return sample_sets(csr, q, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order, cap_root_degree,
-                           emit_walks, rng_streams, calls_before, dedup, keep_keys, staging_bytes, uniq_capacity * 4,
-                           uniq_small_limit)
-    sets.slot, sets.table, sets.capacity = slot, table, uniq_capacity
-    sets.ukeys = ukeys[:status[4]].clone()
-    return sets
-
-
-def sample_spg_rows(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, rng="rand_r", calls_before=0,
-                    staging_bytes=STAGING_BYTES, uniq_capacity=UNIQ_CAPACITY, uniq_small_limit=0):
-    """Fused SpG pipeline (subgacc_walk_spg): every set leaves the walk kernel as a finished SpG row.
-
-    Returns (row_off int64[n+1], indices int32[X] sorted per row, data int32[X] = SFptr+1, ukeys int64[c], nsize,
-    n_overflow) or None when the configuration does not fit the fused kernel (M*m+1 > 818, or more distinct LP
-    rows than the direct ranking handles) -- the caller then uses sample_sets + SpG.from_sets."""
-    L = lib()
-    dev = csr.device
-    q = _as_query(query, dev)
-    n = q.numel()
-    cfg = make_cfg(csr, num_walks, num_steps, bucket, seed, rng, True, _lib.ORDER_WALK_MAJOR, True, False)
-    check(L.subgacc_key_shift(cfg.num_walks, cfg.num_steps))
-    M, m = cfg.num_walks, cfg.num_steps
-    if M * m + 1 > 818:      # the fused kernel keeps 4 table slots per lane in registers (table <= 1024 slots)
-        return None
-    stride = bucket if bucket > 0 else M * m + 1
-    st = stream_ptr()
-    flags = torch.zeros(4, dtype=torch.int32, device=dev)
-    rng_pos = rng_seed = None
-    if cfg.rng_mode == _lib.RNG_RAND_R and n > 0:
-        rng_pos = torch.empty(n, dtype=torch.int32, device=dev)
-        rng_seed = torch.empty(n, dtype=torch.int32, device=dev)
-        ws = torch.empty(L.subgacc_rng_positions_workspace_bytes(n), dtype=torch.uint8, device=dev)
-        check(L.subgacc_rng_positions(cfg, ptr(csr.indptr), ptr(q), n, 1, int(calls_before), ptr(rng_pos), ptr(rng_seed),
-                                      ptr(ws), ws.numel(), st))
-    table = torch.empty(L.subgacc_uniq_table_bytes(uniq_capacity), dtype=torch.uint8, device=dev)
-    check(L.subgacc_uniq_reset(ptr(table), uniq_capacity, st))
-    nsize = torch.empty(n, dtype=torch.int32, device=dev)
-    chunk = max(1, min(n, int(staging_bytes // (stride * 8)), (1 << 31) - 16)) if n else 0
-    idx_parts, dat_parts = [], []
-    if n:
-        st_ids = torch.empty(chunk * stride, dtype=torch.int32, device=dev)
-        st_slot = torch.empty(chunk * stride, dtype=torch.int32, device=dev)
-        scan_ws = torch.empty(L.subgacc_scan_workspace_bytes(chunk), dtype=torch.uint8, device=dev)
-        off_chunk = torch.empty(chunk + 1, dtype=torch.int64, device=dev)
-    X = 0
-    for lo in range(0, n, chunk if chunk else 1):
-        cn = min(chunk, n - lo)
-        with _timed("walk_sets"):
-            check(L.subgacc_walk_spg(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn, lo,
-                                     ptr(rng_pos[lo:]) if rng_pos is not None else None,
-                                     ptr(rng_seed[lo:]) if rng_seed is not None else None,
-                                     ptr(table), uniq_capacity, ptr(st_ids), ptr(st_slot), ptr(nsize[lo:]), ptr(flags), st))
-        check(L.subgacc_exclusive_scan_i32(ptr(nsize[lo:]), cn, ptr(off_chunk), ptr(scan_ws), scan_ws.numel(), st))
-        total = int(off_chunk[cn].item())        # the one host round trip of this chunk
-        idx_c = torch.empty(total, dtype=torch.int32, device=dev)
-        dat_c = torch.empty(total, dtype=torch.int32, device=dev)
-        with _timed("compact_sets"):
-            check(L.subgacc_compact_rows(ptr(st_ids), ptr(st_slot), ptr(nsize[lo:]), ptr(off_chunk), cn, stride,
-                                         ptr(idx_c), ptr(dat_c), st))
-        idx_parts.append(idx_c)
-        dat_parts.append(dat_c)
-        X += total
-    if len(idx_parts) == 1:
-        indices, data = idx_parts[0], dat_parts[0]
-    elif idx_parts:
-        indices, data = torch.cat(idx_parts), torch.cat(dat_parts)
-    else:
-        indices = torch.empty(0, dtype=torch.int32, device=dev)
-        data = torch.empty(0, dtype=torch.int32, device=dev)
-    del idx_parts, dat_parts
-    row_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
-    ws = torch.empty(L.subgacc_scan_workspace_bytes(n), dtype=torch.uint8, device=dev)
-    check(L.subgacc_exclusive_scan_i32(ptr(nsize), n, ptr(row_off), ptr(ws), ws.numel(), st))
-    # number the distinct LP rows by first occurrence (direct ranking of the table), then slot -> SFptr+1 in place
-    count = torch.zeros(1, dtype=torch.int64, device=dev)
-    limit = uniq_small_limit if uniq_small_limit > 0 else 16384
-    max_unique = min(max(X, 1), uniq_capacity, limit)
-    ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
-    ws = torch.empty(L.subgacc_uniq_number_workspace_bytes(uniq_capacity, 0), dtype=torch.uint8, device=dev)
-    with _timed("uniq_rows"):
-        check(L.subgacc_uniq_number(ptr(table), uniq_capacity, None, 0, ptr(ukeys), max_unique, ptr(count), limit,
-                                    ptr(ws), ws.numel(), st))
-        check(L.subgacc_uniq_translate(ptr(table), uniq_capacity, ptr(data), X, 1, st))
-    status = torch.cat([flags.long(), count]).tolist()
-    dummy = SampledSets(nsize, row_off, indices, None, None, None, M, m, stride)
-    _check_walk_flags(dummy, status[:4])
-    if status[2]:     # table (nearly) full: walk again with a larger one
-        return sample_spg_rows(csr, q, num_walks, num_steps, bucket, seed, rng, calls_before, staging_bytes,
-                               uniq_capacity * 4, uniq_small_limit)
-    c = status[4]
-    if c > limit:     # too many distinct rows for the direct ranking: the caller takes the general pipeline
-        return None
-    return row_off, indices, data, ukeys[:c].clone(), nsize, dummy.n_overflow
-
-
-def _check_walk_flags(sets, fl):
+def check_walk_flags(sets, fl):
     if fl[0]:
         raise _lib.SubgAccError(
             "rng='rand_r' cannot reproduce the sequential stream on this graph: a walk reached a node without "
@@ -343,7 +192,164 @@ def _check_walk_flags(sets, fl):
         print(f"#SubGAcc: {fl[1]} keys exceed the buffer, try a larger bucket size > {sets.stride}.")
 
 
-def dedup_lp_rows(sets, capacity=UNIQ_CAPACITY, walk_flags=None, small_limit=0):
+def _rng_positions(L, cfg, csr, q, n, rng_streams, calls_before, st):
+    if cfg.rng_mode != _lib.RNG_RAND_R or n == 0:
+        return None, None
+    dev = csr.device
+    rng_pos = torch.empty(n, dtype=torch.int32, device=dev)
+    rng_seed = torch.empty(n, dtype=torch.int32, device=dev)
+    ws = torch.empty(L.subgacc_rng_positions_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    check(L.subgacc_rng_positions(cfg, ptr(csr.indptr), ptr(q), n, int(rng_streams), int(calls_before), ptr(rng_pos),
+                                  ptr(rng_seed), ptr(ws), ws.numel(), st))
+    return rng_pos, rng_seed
+
+
+def _cat(parts, dtype, dev):
+    parts = [p_ for p_ in parts if p_ is not None]
+    if not parts:
+        return torch.empty(0, dtype=dtype, device=dev)
+    return parts[0] if len(parts) == 1 else torch.cat(parts)
+
+
+def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, rng="rand_r", first_hop_wo=True,
+                order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False, rng_streams=1,
+                calls_before=0, dedup=True, keep_keys=None, staging_bytes=STAGING_BYTES, uniq_capacity=UNIQ_CAPACITY,
+                uniq_small_limit=0, fused_rows=False, lazy=False):
+    """Run the sampler for `query` (roots) on the GPU.  See SampledSets.
+
+    dedup=True numbers the distinct LP rows (ukeys, slot / get_sf()); the packed keys are then only kept when
+    keep_keys is set.  fused_rows=True uses subgacc_walk_spg: `ids` come out sorted by node id per root and `data`
+    holds SFptr+1 -- finished SpG rows (needs M*m+1 <= 818 and set_sampler order; returns None when the
+    configuration does not fit, the caller then takes the general pipeline).  lazy=True: see the module docstring."""
+    L = lib()
+    dev = csr.device
+    q = _as_query(query, dev)
+    n = q.numel()
+    cfg = make_cfg(csr, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order, cap_root_degree, emit_walks)
+    check(L.subgacc_key_shift(cfg.num_walks, cfg.num_steps))   # AssertionError like subg_acc.c:911-915
+    M, m = cfg.num_walks, cfg.num_steps
+    stride = bucket if bucket > 0 else M * m + 1
+    if fused_rows and (M * m + 1 > FUSED_MAX_Q or not dedup or emit_walks or not first_hop_wo
+                       or order != _lib.ORDER_WALK_MAJOR):
+        return None
+    st = stream_ptr()
+    flags = torch.zeros(4, dtype=torch.int32, device=dev)
+    if keep_keys is None:
+        keep_keys = not dedup
+    if fused_rows:
+        keep_keys = False
+    limit = uniq_small_limit if uniq_small_limit > 0 else RANK_LIMIT
+    per_member = 8 if fused_rows else 12
+    chunk = max(1, min(n, int(staging_bytes // (stride * per_member)), (1 << 31) - 16)) if n else 0
+    lazy = bool(lazy and dedup and n > 0 and chunk == n)
+
+    rng_pos, rng_seed = _rng_positions(L, cfg, csr, q, n, rng_streams, calls_before, st)
+    table = None
+    if dedup:
+        table = torch.empty(L.subgacc_uniq_table_bytes(uniq_capacity), dtype=torch.uint8, device=dev)
+        check(L.subgacc_uniq_reset(ptr(table), uniq_capacity, st))
+
+    nsize = torch.empty(n, dtype=torch.int32, device=dev)
+    walks = torch.empty((n, M * (m + 1)), dtype=torch.int32, device=dev) if emit_walks else None
+    ids_parts, key_parts, slot_parts = [], [], []
+    off_chunk = None
+    if n:
+        st_ids = torch.empty(chunk * stride, dtype=torch.int32, device=dev)
+        st_aux = torch.empty(chunk * stride, dtype=torch.int32 if fused_rows else torch.int64, device=dev)
+        scan_ws = torch.empty(L.subgacc_scan_workspace_bytes(chunk), dtype=torch.uint8, device=dev)
+        off_chunk = torch.empty(chunk + 1, dtype=torch.int64, device=dev)
+    X = 0
+    for lo in range(0, n, chunk if chunk else 1):
+        cn = min(chunk, n - lo)
+        with _timed("walk_sets"):
+            if fused_rows:
+                check(L.subgacc_walk_spg(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn, lo,
+                                         ptr(rng_pos[lo:]) if rng_pos is not None else None,
+                                         ptr(rng_seed[lo:]) if rng_seed is not None else None,
+                                         ptr(table), uniq_capacity, ptr(st_ids), ptr(st_aux), ptr(nsize[lo:]),
+                                         ptr(flags), st))
+            else:
+                check(L.subgacc_walk_sets(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn,
+                                          ptr(rng_pos[lo:]) if rng_pos is not None else None,
+                                          ptr(rng_seed[lo:]) if rng_seed is not None else None,
+                                          ptr(st_ids), ptr(st_aux), ptr(nsize[lo:]),
+                                          ptr(walks[lo:]) if walks is not None else None, ptr(flags), st))
+        check(L.subgacc_exclusive_scan_i32(ptr(nsize[lo:]), cn, ptr(off_chunk), ptr(scan_ws), scan_ws.numel(), st))
+        # packed arrays: exact size (one 8-byte host read) or, lazily, the upper bound n*stride
+        total = cn * stride if lazy else int(off_chunk[cn].item())
+        ids_c = torch.empty(total, dtype=torch.int32, device=dev)
+        keys_c = torch.empty(total, dtype=torch.int64, device=dev) if keep_keys else None
+        slot_c = torch.empty(total, dtype=torch.int32, device=dev) if dedup else None
+        with _timed("compact_sets"):
+            if fused_rows:
+                check(L.subgacc_compact_rows(ptr(st_ids), ptr(st_aux), ptr(nsize[lo:]), ptr(off_chunk), cn, stride,
+                                             ptr(ids_c), ptr(slot_c), st))
+            else:
+                check(L.subgacc_compact_sets(ptr(st_ids), ptr(st_aux), ptr(nsize[lo:]), ptr(off_chunk), cn, stride,
+                                             ptr(ids_c), ptr(keys_c), ptr(table), uniq_capacity if dedup else 0, X,
+                                             ptr(slot_c), ptr(flags), st))
+        ids_parts.append(ids_c)
+        key_parts.append(keys_c)
+        slot_parts.append(slot_c)
+        X += total
+    ids = _cat(ids_parts, torch.int32, dev)
+    keys = _cat(key_parts, torch.int64, dev) if keep_keys else None
+    slot = _cat(slot_parts, torch.int32, dev) if dedup else None
+    del ids_parts, key_parts, slot_parts
+
+    if lazy:
+        row_off = off_chunk               # a single chunk: its offsets are the global ones
+    else:
+        row_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        ws = torch.empty(L.subgacc_scan_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        check(L.subgacc_exclusive_scan_i32(ptr(nsize), n, ptr(row_off), ptr(ws), ws.numel(), st))
+
+    sets = SampledSets(nsize, row_off, ids, keys, None, None, M, m, stride, walks)
+    if not dedup:
+        check_walk_flags(sets, flags.tolist())
+        return sets
+
+    # number the distinct LP rows by first occurrence (subg_acc.c:957-1000)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    x_dev = row_off[n:n + 1]
+    if fused_rows or lazy:            # table-only direct ranking (tags need not be element positions)
+        max_unique = min(uniq_capacity, limit)
+        ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
+        ws = torch.empty(L.subgacc_uniq_number_workspace_bytes(uniq_capacity, 0), dtype=torch.uint8, device=dev)
+        with _timed("uniq_rows"):
+            check(L.subgacc_uniq_number(ptr(table), uniq_capacity, None, 0, ptr(ukeys), max_unique, ptr(count), limit,
+                                        ptr(ws), ws.numel(), st))
+            if fused_rows:            # slot -> SFptr+1 in place: the rows are finished SpG rows
+                check(L.subgacc_uniq_translate(ptr(table), uniq_capacity, ptr(slot), slot.numel(), ptr(x_dev), 1, st))
+    else:
+        max_unique = min(max(X, 1), uniq_capacity)
+        ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
+        ws = torch.empty(L.subgacc_uniq_number_workspace_bytes(uniq_capacity, X), dtype=torch.uint8, device=dev)
+        with _timed("uniq_rows"):
+            check(L.subgacc_uniq_number(ptr(table), uniq_capacity, ptr(slot), X, ptr(ukeys), max_unique, ptr(count),
+                                        uniq_small_limit, ptr(ws), ws.numel(), st))
+    sets.ukeys, sets.table, sets.capacity = ukeys, table, uniq_capacity
+    if fused_rows:
+        sets.data = slot
+    else:
+        sets.slot = slot
+    sets.status = torch.cat([flags.long(), count, x_dev])
+    if lazy:
+        return sets
+    # eager: read the status now; grow the table and walk again if it overflowed
+    st_host = sets.status.tolist()
+    if fused_rows and not st_host[2] and st_host[4] > max_unique:
+        return None           # more distinct rows than the direct ranking handles: the caller takes the general path
+    if st_host[2]:
+        return sample_sets(csr, q, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order, cap_root_degree,
+                           emit_walks, rng_streams, calls_before, dedup, keep_keys, staging_bytes, uniq_capacity * 4,
+                           uniq_small_limit, fused_rows, lazy)
+    sets.resolve()
+    sets.ukeys = sets.ukeys.clone()
+    return sets
+
+
+def dedup_lp_rows(sets, capacity=UNIQ_CAPACITY, small_limit=0):
     """Global first-occurrence dedup of already packed LP keys (subg_acc.c:957-1000) -> sets.sf, sets.ukeys.
     The stand-alone form (subgacc_uniq_insert over sets.keys) for sets sampled with dedup=False; sample_sets itself
     fuses the insert into the compaction pass."""
@@ -353,27 +359,23 @@ def dedup_lp_rows(sets, capacity=UNIQ_CAPACITY, walk_flags=None, small_limit=0):
     X = sets.X
     sf = torch.empty(X, dtype=torch.int32, device=dev)
     count = torch.zeros(1, dtype=torch.int64, device=dev)
-    if walk_flags is None:
-        walk_flags = torch.zeros(4, dtype=torch.int32, device=dev)
     while True:
         flags = torch.zeros(4, dtype=torch.int32, device=dev)
         table = torch.empty(L.subgacc_uniq_table_bytes(capacity), dtype=torch.uint8, device=dev)
         ws = torch.empty(L.subgacc_uniq_number_workspace_bytes(capacity, X), dtype=torch.uint8, device=dev)
-        max_unique = min(X, capacity)
+        max_unique = min(max(X, 1), capacity)
         ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
-        with _timed("uniq_rows"):
-            check(L.subgacc_uniq_reset(ptr(table), capacity, st))
-            check(L.subgacc_uniq_insert(ptr(table), capacity, ptr(sets.keys), X, 0, ptr(sf), ptr(flags), st))
-            # probe chains are bounded in the kernels, so numbering an over-full table is harmless (and discarded)
-            check(L.subgacc_uniq_number(ptr(table), capacity, ptr(sf), X, ptr(ukeys), max_unique, ptr(count),
-                                        small_limit, ptr(ws), ws.numel(), st))
-            check(L.subgacc_uniq_translate(ptr(table), capacity, ptr(sf), X, 0, st))
-        status = torch.cat([walk_flags.long(), flags.long(), count]).tolist()
-        _check_walk_flags(sets, status[:4])
-        if status[6]:
+        check(L.subgacc_uniq_reset(ptr(table), capacity, st))
+        check(L.subgacc_uniq_insert(ptr(table), capacity, ptr(sets.keys), X, 0, ptr(sf), ptr(flags), st))
+        # probe chains are bounded in the kernels, so numbering an over-full table is harmless (and discarded)
+        check(L.subgacc_uniq_number(ptr(table), capacity, ptr(sf), X, ptr(ukeys), max_unique, ptr(count),
+                                    small_limit, ptr(ws), ws.numel(), st))
+        check(L.subgacc_uniq_translate(ptr(table), capacity, ptr(sf), X, None, 0, st))
+        status = torch.cat([flags.long(), count]).tolist()
+        if status[2]:
             capacity *= 4           # table (nearly) full: the distinct-row count exceeded the guess, retry larger
             continue
-        c = status[8]
+        c = status[4]
         break
     sets.sf = sf
     sets.ukeys = ukeys[:c].clone()

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
-from .sampler import DeviceCSR, SampledSets, _timed, sample_sets, sample_spg_rows
+from .sampler import DeviceCSR, _timed, sample_sets
 
 
 class SpG:
@@ -32,15 +32,20 @@ class SpG:
 
     @property
     def nnz(self):
-        return self.indices.numel()
+        """number of stored members (one 8-byte read of indptr[-1]; the arrays may be capacity-sized)"""
+        return int(self.indptr[-1].item()) if self.n_rows else 0
 
     @classmethod
     def from_sets(cls, sets, n_cols=None):
-        """Segmented sort of the sampled sets by node id (random_walks.py:79-80).  Row i = root query[i]."""
-        if sets.sf is None and sets.slot is None:
-            raise ValueError("SpG.from_sets needs de-duplicated sets (sample_sets(..., dedup=True))")
+        """Segmented sort of the sampled sets by node id (random_walks.py:79-80).  Row i = root query[i].
+        Sets in fused-row form are already finished rows; lazy sets give a capacity-sized SpG (row offsets rule)."""
         dev = sets.ids.device
         n = sets.nsize.numel()
+        max_data = sets.ukeys.numel()          # while lazy: the capacity of the distinct-row table view (an upper bound)
+        if sets.data is not None:
+            return cls(sets.row_off, sets.ids, sets.data, max_len=sets.stride, shape=(n, n_cols or n), max_data=max_data)
+        if sets.sf is None and sets.slot is None:
+            raise ValueError("SpG.from_sets needs de-duplicated sets (sample_sets(..., dedup=True))")
         indices = torch.empty_like(sets.ids)
         data = torch.empty_like(sets.ids)
         flags = torch.zeros(4, dtype=torch.int32, device=dev)
@@ -52,7 +57,7 @@ class SpG:
                 check(lib().subgacc_spg_build(ptr(sets.row_off), n, ptr(sets.ids), ptr(sets.slot), ptr(sets.table),
                                               sets.capacity, sets.stride, ptr(indices), ptr(data), ptr(flags),
                                               stream_ptr()))
-        return cls(sets.row_off, indices, data, max_len=sets.stride, shape=(n, n_cols or n), max_data=sets.c)
+        return cls(sets.row_off, indices, data, max_len=sets.stride, shape=(n, n_cols or n), max_data=max_data)
 
     @classmethod
     def from_scipy(cls, z, device=None):
@@ -71,30 +76,29 @@ class SpG:
 
     def to_scipy(self):
         import scipy.sparse as sp
-        return sp.csr_matrix((self.data.cpu().numpy(), self.indices.cpu().numpy(), self.indptr.cpu().numpy()),
+        nnz = self.nnz
+        return sp.csr_matrix((self.data[:nnz].cpu().numpy(), self.indices[:nnz].cpu().numpy(), self.indptr.cpu().numpy()),
                              shape=self.shape)
 
 
-def sample_spg(csr, query, num_walks=200, num_steps=3, seed=111413, rng="rand_r", bucket=-1, fused=True, **kw):
-    """sample -> SpG on the GPU: (SpG, SampledSets-like summary with ukeys / nsize / feature_table()).
+def sample_spg(csr, query, num_walks=200, num_steps=3, seed=111413, rng="rand_r", bucket=-1, fused=False, lazy=False,
+               **kw):
+    """sample -> SpG on the GPU: (SpG, SampledSets) -- the sets carry ukeys / nsize / feature_table().
 
-    `num_steps` = walk hops (gset_sampler's meaning).  fused=True runs the one-kernel-per-root pipeline
-    (csrc/walk.hip SPG mode) and falls back to sample_sets + SpG.from_sets when it does not apply."""
-    n_cols = csr.num_nodes
+    `num_steps` = walk hops (gset_sampler's meaning).  fused=True lets the walk kernel emit finished SpG rows
+    (csrc/walk.hip SPG mode; falls back to the general pipeline when it does not apply).  lazy=True leaves every
+    size on the device (no host round trip until SampledSets.resolve() / SpG.nnz); arrays are capacity-sized."""
+    sets = None
     if fused:
-        out = sample_spg_rows(csr, query, num_walks=num_walks, num_steps=num_steps, bucket=bucket, seed=seed, rng=rng, **kw)
-        if out is not None:
-            row_off, indices, data, ukeys, nsize, n_overflow = out
-            stride = bucket if bucket > 0 else num_walks * num_steps + 1
-            info = SampledSets(nsize, row_off, indices, None, None, ukeys, int(num_walks), int(num_steps), stride,
-                               n_overflow=n_overflow)
-            z = SpG(row_off, indices, data, max_len=stride, shape=(nsize.numel(), n_cols), max_data=int(ukeys.numel()))
-            return z, info
-    sets = sample_sets(csr, query, num_walks=num_walks, num_steps=num_steps, bucket=bucket, seed=seed, rng=rng, **kw)
-    return SpG.from_sets(sets, n_cols=n_cols), sets
+        sets = sample_sets(csr, query, num_walks=num_walks, num_steps=num_steps, bucket=bucket, seed=seed, rng=rng,
+                           fused_rows=True, lazy=lazy, **kw)
+    if sets is None:
+        sets = sample_sets(csr, query, num_walks=num_walks, num_steps=num_steps, bucket=bucket, seed=seed, rng=rng,
+                           lazy=lazy, **kw)
+    return SpG.from_sets(sets, n_cols=csr.num_nodes), sets
 
 
-def subg_matrix(G, train_idx, num_walks=200, num_steps=4, seed=111413, rng="rand_r", device=None, fused=True):
+def subg_matrix(G, train_idx, num_walks=200, num_steps=4, seed=111413, rng="rand_r", device=None, fused=False):
     """Drop-in for sampler/random_walks.py:74-82: returns (z, enc).
 
     z   -- SpG on the GPU (row i = sampled set of train_idx[i]); the reference indexes rows by node id and

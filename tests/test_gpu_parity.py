@@ -497,17 +497,46 @@ def test_fused_spg_multichunk_overflow_and_fallbacks(sp):
     ptr_, idx = sym_graph(4000, 16000, seed=31, hubs=2)
     ptr_[-1:]  # keep flake quiet
     q = np.arange(4000)
-    from surel_plus_amd.sampler import DeviceCSR, sample_spg_rows
+    from surel_plus_amd.sampler import DeviceCSR, sample_sets
     csr = DeviceCSR(ptr_.astype(np.int64), idx)                    # int64 row offsets
     (oi, ox, od), oenc = _oracle_spg(ptr_, idx, q, 100, 4, 5, "rand_r")
     # 9 chunks + a 64-slot table that must be regrown
-    z, info = sp.sample_spg(csr, q, num_walks=100, num_steps=4, seed=5, staging_bytes=401 * 8 * 450, uniq_capacity=64)
+    z, info = sp.sample_spg(csr, q, num_walks=100, num_steps=4, seed=5, fused=True, staging_bytes=401 * 8 * 450,
+                            uniq_capacity=64)
+    assert info.data is not None                                   # really the fused-row form
     assert np.array_equal(z.indptr.cpu().numpy(), oi) and np.array_equal(z.indices.cpu().numpy(), ox)
     assert np.array_equal(z.data.cpu().numpy(), od) and np.array_equal(info.enc_int16().cpu().numpy(), oenc)
     # more distinct rows than the direct ranking is allowed to handle -> None -> general pipeline
-    assert sample_spg_rows(csr, q, num_walks=100, num_steps=4, seed=5, uniq_small_limit=16) is None
+    assert sample_sets(csr, q, num_walks=100, num_steps=4, seed=5, uniq_small_limit=16, fused_rows=True) is None
     # M*m+1 > 1024 does not fit the fused kernel
-    assert sample_spg_rows(csr, q[:10], num_walks=300, num_steps=4, seed=5) is None
-    z2, _ = sp.sample_spg(csr, q[:300], num_walks=300, num_steps=4, seed=5, rng="philox")
+    assert sample_sets(csr, q[:10], num_walks=300, num_steps=4, seed=5, fused_rows=True) is None
+    z2, _ = sp.sample_spg(csr, q[:300], num_walks=300, num_steps=4, seed=5, rng="philox", fused=True)
     (oi2, ox2, od2), _ = _oracle_spg(ptr_, idx, q[:300], 300, 4, 5, "philox")
     assert np.array_equal(z2.indices.cpu().numpy(), ox2) and np.array_equal(z2.data.cpu().numpy(), od2)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("rng", ["rand_r", "philox"])
+def test_lazy_pipeline_has_no_host_round_trip_and_the_same_result(sp, fused, rng):
+    """lazy=True leaves every size on the device: sample -> SpG -> table -> SpJoin queue up asynchronously and give
+    the same bytes as the eager form / the oracle once resolve() has read the sizes back."""
+    ptr_, idx = sym_graph(6000, 40000, seed=13, hubs=2)
+    q = np.random.default_rng(1).permutation(6000)[:2500]
+    from surel_plus_amd.sampler import DeviceCSR
+    csr = DeviceCSR(ptr_, idx)
+    (oi, ox, od), oenc = _oracle_spg(ptr_, idx, q, 150, 3, 8, rng)
+    z, sets = sp.sample_spg(csr, q, num_walks=150, num_steps=3, seed=8, rng=rng, fused=fused, lazy=True)
+    assert sets.pending and z.indices.numel() == len(q) * 451          # capacity-sized, nothing read back yet
+    table = sets.feature_table()
+    edge = np.random.default_rng(2).integers(0, len(q), (2, 3000))
+    xz, ind = sp.gather(edge, z, "cuda", ptr=True, encode=table)
+    otab = oracle.enc_table(oenc).astype(np.float32) / np.float32(150)
+    oxz, oind = oracle.gather(edge, (oi, ox, od), ptr=True, encode=otab)
+    assert np.array_equal(xz.cpu().numpy(), oxz) and np.array_equal(ind.cpu().numpy(), oind)
+    sets.resolve()
+    assert not sets.pending and sets.c == oenc.shape[0] and sets.X == len(ox)
+    X = sets.X
+    assert np.array_equal(z.indptr.cpu().numpy(), oi)
+    assert np.array_equal(z.indices[:X].cpu().numpy(), ox) and np.array_equal(z.data[:X].cpu().numpy(), od)
+    assert np.array_equal(sets.enc_int16().cpu().numpy(), oenc)
+    assert z.nnz == X and z.to_scipy().nnz == X
