@@ -234,8 +234,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL ("nccl") is the backend; SUBGACC_DIST_BACKEND=gloo + SUBGACC_SHARE_GPU=1 lets a 1-GPU box exercise the
+        # multi-rank control flow (barriers, max-over-ranks) with every rank on cuda:0
+        backend = os.environ.get("SUBGACC_DIST_BACKEND", "nccl")
+        if os.environ.get("SUBGACC_SHARE_GPU", "0") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())

@@ -28,7 +28,22 @@ def _csr_from_host(indptr, indices):
         raise TypeError("Input parsing error. (indices cannot be safely cast to int32)")
     ip = np.ascontiguousarray(ip, dtype=np.int64 if ip.dtype == np.int64 else np.int32)
     ix = np.ascontiguousarray(ix, dtype=np.int32)
+    # The reference reads whatever the CSR says (no bounds checks, a bad graph is a segfault); on the GPU a stray
+    # address can take the device down, so the host arrays are validated before they are uploaded.
+    if ip.ndim != 1 or ip.size < 1 or ix.ndim != 1:
+        raise TypeError("Input parsing error. (indptr / indices must be 1-D, indptr non-empty)")
+    if ip[0] != 0 or ip[-1] > ix.size or (ip.size > 1 and bool((np.diff(ip) < 0).any())):
+        raise IndexError("CSR row offsets are not monotone within [0, len(indices)]")
+    if ix.size and (int(ix.min()) < 0 or int(ix.max()) >= ip.size - 1):
+        raise IndexError("CSR neighbour ids outside [0, num_nodes)")
     return DeviceCSR(ip, ix)
+
+
+def _checked_query(query, num_nodes):
+    q = np.asarray(query)
+    if q.size and (int(q.min()) < 0 or int(q.max()) >= num_nodes):
+        raise IndexError(f"query node ids outside [0, {num_nodes})")
+    return q
 
 
 def gset_sampler(indptr, indices, query, num_walks=100, num_steps=3, bucket=-1, nthread=-1, seed=111413, debug=-1,
@@ -36,6 +51,8 @@ def gset_sampler(indptr, indices, query, num_walks=100, num_steps=3, bucket=-1, 
     """subg_acc.c:649-1034.  Returns [nsize int32[n], remap int32[2,X], enc int16[c,num_steps+1]]
     (+ raw_enc int16[X,num_steps+1] when debug > 0)."""
     csr = indptr if isinstance(indptr, DeviceCSR) else _csr_from_host(indptr, indices)
+    if not torch.is_tensor(query):
+        query = _checked_query(query, csr.num_nodes)
     sets = sample_sets(csr, query, num_walks=num_walks, num_steps=num_steps, bucket=bucket, seed=seed, rng=rng)
     nsize = sets.nsize.cpu().numpy()
     sf = sets.get_sf()
@@ -56,6 +73,8 @@ def walk_sampler(ptr, neighs, query, num_walks=100, num_steps=3, nthread=-1, see
     (ids int32[count], counts int32[count, m+1]).  As in the reference, `replacement=True` selects the
     first hop WITHOUT replacement (subg_acc.c:354-362)."""
     csr = ptr if isinstance(ptr, DeviceCSR) else _csr_from_host(ptr, neighs)
+    if not torch.is_tensor(query):
+        query = _checked_query(query, csr.num_nodes)
     sets = sample_sets(csr, query, num_walks=num_walks, num_steps=num_steps, seed=seed, rng=rng,
                        first_hop_wo=bool(replacement), order=_lib.ORDER_STEP_MAJOR, cap_root_degree=False,
                        emit_walks=True, rng_streams=max(int(nthread), 1), dedup=False)

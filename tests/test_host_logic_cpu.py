@@ -1,0 +1,96 @@
+"""CPU: host-side logic of the mirror layer that needs no GPU -- argument casting rules of the reference's
+C module (subg_acc/subg_acc.c:663-676), synthetic inputs, signatures of the drop-in functions."""
+import inspect
+
+import numpy as np
+import pytest
+import torch
+
+import surel_plus_amd as sp
+from surel_plus_amd import graphs, subg_acc as mirror
+
+
+def test_csr_casting_rules_match_the_reference():
+    ok_ptr, ok_idx = np.array([0, 1, 2], np.int32), np.array([1, 0], np.int32)
+    # PyArray_FROM_OTF(..., NPY_INT, NPY_ARRAY_IN_ARRAY) is a safe cast: floats / int64 indices are rejected
+    with pytest.raises(TypeError, match="Input parsing error"):
+        mirror._csr_from_host(ok_ptr.astype(np.float64), ok_idx)
+    with pytest.raises(TypeError, match="Input parsing error"):
+        mirror._csr_from_host(ok_ptr, ok_idx.astype(np.int64))
+    with pytest.raises(TypeError, match="Input parsing error"):
+        mirror._csr_from_host(ok_ptr, ok_idx.astype(np.uint32))
+    # a malformed graph would be a segfault in the reference and a device fault here: refused on the host
+    with pytest.raises(IndexError):
+        mirror._csr_from_host(np.array([0, 3, 2], np.int32), ok_idx)          # offsets not monotone / past the end
+    with pytest.raises(IndexError):
+        mirror._csr_from_host(ok_ptr, np.array([1, 7], np.int32))             # neighbour id out of range
+    with pytest.raises(IndexError):
+        mirror._checked_query(np.array([0, 5]), 2)
+    # smaller integer types are safe casts; they fail later only because there is no GPU here
+    if not torch.cuda.is_available():
+        with pytest.raises(sp.SubgAccError, match="no HIP device"):
+            mirror._csr_from_host(ok_ptr.astype(np.int16), ok_idx.astype(np.int8))
+
+
+def test_signatures_mirror_the_reference_module():
+    """kwlist of subg_acc.c:655 / :322 and the defaults of :653 / :320."""
+    g = inspect.signature(mirror.gset_sampler).parameters
+    assert list(g)[:9] == ["indptr", "indices", "query", "num_walks", "num_steps", "bucket", "nthread", "seed", "debug"]
+    assert (g["num_walks"].default, g["num_steps"].default, g["bucket"].default, g["nthread"].default,
+            g["seed"].default, g["debug"].default) == (100, 3, -1, -1, 111413, -1)
+    w = inspect.signature(mirror.walk_sampler).parameters
+    assert list(w)[:8] == ["ptr", "neighs", "query", "num_walks", "num_steps", "nthread", "seed", "replacement"]
+    assert (w["num_walks"].default, w["num_steps"].default, w["seed"].default, w["replacement"].default) == \
+        (100, 3, 111413, False)
+    assert mirror.add(3, 4) == 3 * 2 + 4 * 7                    # subg_acc.c:116
+    assert not hasattr(mirror, "run")                            # the system() wrapper is deliberately absent
+    # train.py:13,48,75,88
+    assert list(inspect.signature(sp.gather).parameters) == ["edge", "x", "device", "ptr", "encode"]
+    assert list(inspect.signature(sp.hgather).parameters) == ["hedge", "x", "device", "encode"]
+    assert list(inspect.signature(sp.bgather).parameters) == ["edge", "x", "out"]
+    assert list(inspect.signature(sp.pgather).parameters) == ["edge", "M", "device", "encode", "gather_func", "ptr", "njobs"]
+    # sampler/random_walks.py:74
+    assert list(inspect.signature(sp.subg_matrix).parameters)[:4] == ["G", "train_idx", "num_walks", "num_steps"]
+    import subg_acc as top                                       # the drop-in module name
+    assert top.gset_sampler is mirror.gset_sampler and top.walk_sampler is mirror.walk_sampler
+
+
+def test_synthetic_graph_is_symmetric_simple_and_sorted():
+    g = graphs.powerlaw_graph(20000, 8.2, seed=0, device="cpu")
+    ip, ix = g.indptr.long(), g.indices.long()
+    deg = ip[1:] - ip[:-1]
+    rows = torch.repeat_interleave(torch.arange(g.num_nodes), deg)
+    assert g.indices.dtype == torch.int32 and 6.5 < g.nnz / g.num_nodes < 10
+    assert not bool((rows == ix).any())                                     # no self loops
+    fwd, bwd = rows * g.num_nodes + ix, ix * g.num_nodes + rows
+    assert torch.equal(torch.sort(fwd)[0], torch.sort(bwd)[0])              # G == G.T (dataloader.py:122-135)
+    assert torch.unique(fwd).numel() == fwd.numel()                         # simple
+    assert bool((fwd[1:] > fwd[:-1]).all())                                 # rows sorted by neighbour id
+    again = graphs.powerlaw_graph(20000, 8.2, seed=0, device="cpu")
+    assert torch.equal(again.indices, g.indices)                            # seeded
+    e = graphs.query_pairs(g, 1000, seed=7, device="cpu")
+    assert e.shape == (2, 1000) and e.dtype == torch.int64 and int(e.max()) < g.num_nodes
+    # the first half of the pairs are edges of the graph
+    key = e[0, :500] * g.num_nodes + e[1, :500]
+    assert bool(torch.isin(key, fwd).all())
+
+
+def test_ppr_like_spg_and_directed_graph_shapes():
+    z = graphs.ppr_like_spg(2000, 100, seed=3, device="cpu")
+    assert z.data.dtype == torch.float64 and z.max_len == 100 and z.indices.numel() == 200000
+    rows = z.indices.view(2000, 100)
+    assert bool((rows[:, 1:] > rows[:, :-1]).all()) and float(z.data.min()) > 0 and float(z.data.max()) <= 1
+    d = graphs.directed_powerlaw_graph(50000, 20.0, seed=3, device="cpu", chunk=1 << 20)
+    deg = d.indptr[1:] - d.indptr[:-1]
+    assert int(deg.min()) >= 1 and 15 < d.nnz / d.num_nodes < 25            # no dead ends
+
+
+def test_make_cfg_rejects_bad_parameters():
+    from surel_plus_amd.sampler import make_cfg
+    g = graphs.powerlaw_graph(100, 4.0, device="cpu")
+    with pytest.raises(TypeError):
+        make_cfg(g, 0, 3)
+    with pytest.raises(KeyError):
+        make_cfg(g, 10, 3, rng="mt19937")
+    cfg = make_cfg(g, 200, 3, seed=-1)
+    assert cfg.seed == 0xFFFFFFFF and cfg.indptr64 == 0 and cfg.first_hop_wo == 1
