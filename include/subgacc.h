@@ -202,6 +202,15 @@ int subgacc_sjoin_fill(const int64_t *spg_indptr, const int32_t *spg_indices, co
                        int32_t *out_idx, int64_t *out_segid, int32_t max_len, int64_t pair_block, int32_t *flags,
                        void *stream);
 
+/* Count form of the join (SpJoin fused with the first model stage, model.py:78-83).
+ * out_counts f32 [S, table_rows]: out_counts[j][p] = number of times LP row p (SFptr+1, 0 = partner absent) occurs
+ * in either feature slot of segment j, so that  segment_sum_j(MLP(xz).sum(-2)) == out_counts[j] @ MLP(Z_SF).
+ * The segment list must be mirrored blocks (pair_block as for subgacc_sjoin_fill, > 0).  LDS bound:
+ * 16*max_len + 8*table_rows bytes <= 160 KiB (SUBGACC_ERR_LDS otherwise: use subgacc_sjoin_fill). */
+int subgacc_sjoin_counts(const int64_t *spg_indptr, const int32_t *spg_indices, const int32_t *spg_data_i32,
+                         const int64_t *own, const int64_t *partner, int64_t S, int64_t table_rows, float *out_counts,
+                         int32_t max_len, int64_t pair_block, int32_t *flags, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,7 @@ SYMBOLS = (
     "subgacc_uniq_table_bytes", "subgacc_uniq_reset", "subgacc_uniq_insert",
     "subgacc_uniq_number_workspace_bytes", "subgacc_uniq_number", "subgacc_uniq_translate", "subgacc_unpack_lp",
     "subgacc_spg_build",
-    "subgacc_sjoin_workspace_bytes", "subgacc_sjoin_sizes", "subgacc_sjoin_fill",
+    "subgacc_sjoin_workspace_bytes", "subgacc_sjoin_sizes", "subgacc_sjoin_fill", "subgacc_sjoin_counts",
 )
 
 
@@ -92,6 +92,7 @@ def lib():
         "subgacc_sjoin_sizes": (C.c_int, [vp, vp, i64, vp, vp, sz, vp]),
         "subgacc_sjoin_fill": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, i32, i64, vp, vp]),
     }
+    sig["subgacc_sjoin_counts"] = (C.c_int, [vp, vp, vp, vp, vp, i64, i64, vp, i32, i64, vp, vp])
     assert set(sig) == set(SYMBOLS)
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -202,6 +202,81 @@ __global__ __launch_bounds__(kPairThreads) void sjoin_pair_kernel(const JoinArgs
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Count form of the join ("next" row f.1 of SURVEY.md section 8: SpJoin fused with the first model stage).
+// The reference's Net.forward (model.py:78-83) embeds both feature slots of every output row with the same MLP
+// and, for mean aggregation, sums the rows of a segment: segment_sum_j = sum_p C[j,p] * MLP(Z_SF[p]) with
+// C[j,p] = how often LP row p occurs in either slot of segment j.  This kernel writes C (dense, one row per
+// segment) instead of xz: Z_SF has only c+1 distinct rows, so the [R,2,k] tensor (and the [R,2,H] activations
+// behind it) collapse into one [S, c+1] x [c+1, H] GEMM.  Slot value 0 (partner absent) is counted too: the MLP
+// of the zero row is not zero.  Mirrored segments are produced together, as in sjoin_pair_kernel.
+__global__ __launch_bounds__(kPairThreads) void sjoin_counts_kernel(const JoinArgs a, int64_t pb, float *__restrict__ out_counts) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    int32_t *valA = (int32_t *)lds_raw;               // [max_len]
+    int32_t *valB = valA + a.max_len;                 // [max_len]
+    int32_t *idsA = valB + a.max_len;                 // [max_len]
+    int32_t *idsB = idsA + a.max_len;                 // [max_len]
+    int32_t *histA = idsB + a.max_len;                // [table_rows]
+    int32_t *histB = histA + a.table_rows;            // [table_rows]
+
+    const int64_t p = xcd_item(blockIdx.x, gridDim.x);
+    if (p >= a.S / 2) return;
+    const int64_t j = (p / pb) * 2 * pb + (p % pb), j2 = j + pb;
+    const int tid = threadIdx.x;
+    const int64_t ra = a.own[j], rb = a.partner[j];
+    if (a.own[j2] != rb || a.partner[j2] != ra) {
+        if (tid == 0) atomicOr(&a.flags[3], 4);
+        return;
+    }
+    const int64_t ab = a.indptr[ra], na64 = a.indptr[ra + 1] - ab;
+    const int64_t bb = a.indptr[rb], nb64 = a.indptr[rb + 1] - bb;
+    if (na64 > a.max_len || nb64 > a.max_len) {
+        if (tid == 0) atomicOr(&a.flags[3], 1);
+        return;
+    }
+    const int na = (int)na64, nb = (int)nb64;
+    const int32_t *data = (const int32_t *)a.data;
+    const int rows = (int)a.table_rows;
+    for (int x = tid; x < 2 * rows; x += kPairThreads) histA[x] = 0;   // histA and histB are contiguous
+    for (int r = tid; r < na; r += kPairThreads) {
+        idsA[r] = a.indices[ab + r];
+        valA[r] = data[ab + r];
+    }
+    for (int r = tid; r < nb; r += kPairThreads) {
+        idsB[r] = a.indices[bb + r];
+        valB[r] = data[bb + r];
+    }
+    __syncthreads();
+    for (int t = tid; t < na + nb; t += kPairThreads) {
+        const bool dirB = t >= na;
+        const int r = dirB ? t - na : t;
+        const int32_t *oid = dirB ? idsB : idsA, *oval = dirB ? valB : valA;
+        const int32_t *pid = dirB ? idsA : idsB, *pval = dirB ? valA : valB;
+        const int pn = dirB ? na : nb;
+        int32_t *hist = dirB ? histB : histA;
+        const int32_t id = oid[r];
+        int lo = 0, hi = pn;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (pid[mid] < id) lo = mid + 1;
+            else hi = mid;
+        }
+        int32_t pa = oval[r], pbv = (lo < pn && pid[lo] == id) ? pval[lo] : 0;
+        if ((uint32_t)pa >= (uint32_t)rows || (uint32_t)pbv >= (uint32_t)rows) {
+            atomicOr(&a.flags[3], 2);
+            continue;
+        }
+        atomicAdd(&hist[pa], 1);
+        atomicAdd(&hist[pbv], 1);
+    }
+    __syncthreads();
+    float *outA = out_counts + j * (int64_t)rows, *outB = out_counts + j2 * (int64_t)rows;
+    for (int x = tid; x < rows; x += kPairThreads) {
+        outA[x] = (float)histA[x];
+        outB[x] = (float)histB[x];
+    }
+}
+
 }  // namespace subgacc
 
 using namespace subgacc;
@@ -290,6 +365,38 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, const int32_t *spg_
     else if (vec4) SG_JOIN_LAUNCH(false, 4);
     else SG_JOIN_LAUNCH(false, 0);
 #undef SG_JOIN_LAUNCH
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}
+
+extern "C" int subgacc_sjoin_counts(const int64_t *spg_indptr, const int32_t *spg_indices, const int32_t *spg_data_i32,
+                                    const int64_t *own, const int64_t *partner, int64_t S, int64_t table_rows,
+                                    float *out_counts, int32_t max_len, int64_t pair_block, int32_t *flags,
+                                    void *stream) {
+    SG_REQUIRE(S >= 0 && max_len >= 0 && flags && table_rows > 0, SUBGACC_ERR_BADARG, "sjoin_counts: bad arguments");
+    if (S == 0) return SUBGACC_OK;
+    SG_REQUIRE(spg_indptr && spg_indices && spg_data_i32 && own && partner && out_counts, SUBGACC_ERR_BADARG,
+               "sjoin_counts: null argument");
+    SG_REQUIRE(pair_block > 0 && S % (2 * pair_block) == 0, SUBGACC_ERR_BADARG,
+               "sjoin_counts: the segment list must be mirrored blocks (pair_block > 0, S a multiple of 2*pair_block)");
+    JoinArgs a;
+    a.indptr = spg_indptr, a.indices = spg_indices, a.data = spg_data_i32;
+    a.own = own, a.partner = partner, a.seg = nullptr, a.S = S;
+    a.table = nullptr, a.table_rows = table_rows, a.k = 0;
+    a.out_xz = nullptr, a.out_idx = nullptr, a.out_segid = nullptr;
+    a.max_len = max_len > 0 ? max_len : 1;
+    a.flags = flags;
+    const size_t lds = (size_t)a.max_len * 16 + (size_t)table_rows * 8;
+    SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS,
+               "sjoin_counts: %lld distinct LP rows and rows of %d members need %zu B of LDS; use sjoin_fill",
+               (long long)table_rows, max_len, lds);
+    if (lds > 64 * 1024)
+        SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_counts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds));
+    const int64_t grid = xcd_grid(S / 2);
+    SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_counts: too many segments in one call");
+    hipLaunchKernelGGL(sjoin_counts_kernel, dim3((unsigned)grid), dim3(kPairThreads), lds, (hipStream_t)stream, a,
+                       pair_block, out_counts);
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }

@@ -151,3 +151,30 @@ def pgather(edge, M, device=None, encode=None, gather_func=None, ptr=True, njobs
     covers the whole batch here, so `gather_func` / `njobs` only keep the call signature.  The result is
     identical to gather() (as it is in the reference)."""
     return gather(edge, M, device, ptr=ptr, encode=encode)
+
+
+def gather_counts(edge, x, table_rows, device=None):
+    """Count form of gather() for mean aggregation (reference consumer model.py:78-83).
+
+    Returns (C float32 [2B, table_rows], sizes int64 [2B]) with C[j, p] = occurrences of LP row p (0 = partner
+    absent) in either feature slot of segment j -- left blocks then right blocks, as gather().  For any row-wise
+    embedding f:  segment_sum_j(f(xz).sum(-2)) == C[j] @ f(Z_SF), so `x = f(xz).sum(-2); aggr(x, ptr)` of the
+    reference's Net.forward becomes `(C @ f(Z_SF)) / sizes[:, None]` and the [R,2,k] tensor never exists."""
+    spg = _as_spg(x)
+    if spg.data.dtype != torch.int32:
+        raise TypeError("gather_counts needs an SFptr (integer) SpG")
+    if table_rows <= spg.max_data:
+        raise IndexError(f"index {spg.max_data} is out of bounds for a table with {table_rows} rows")
+    e = _as_rows(edge, spg.device)
+    B = e.shape[1]
+    own = torch.cat([e[0], e[1]]).contiguous()
+    partner = torch.cat([e[1], e[0]]).contiguous()
+    dev = spg.device
+    out = torch.empty((2 * B, int(table_rows)), dtype=torch.float32, device=dev)
+    flags = torch.zeros(4, dtype=torch.int32, device=dev)
+    with _timed("sjoin_counts"):
+        check(lib().subgacc_sjoin_counts(ptr(spg.indptr), ptr(spg.indices), ptr(spg.data), ptr(own), ptr(partner), 2 * B,
+                                         int(table_rows), ptr(out), spg.max_len, B, ptr(flags), stream_ptr()))
+    sizes = spg.indptr[own + 1] - spg.indptr[own]
+    _checked(out, sizes, flags)
+    return out, sizes

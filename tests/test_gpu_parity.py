@@ -540,3 +540,45 @@ def test_lazy_pipeline_has_no_host_round_trip_and_the_same_result(sp, fused, rng
     assert np.array_equal(z.indices[:X].cpu().numpy(), ox) and np.array_equal(z.data[:X].cpu().numpy(), od)
     assert np.array_equal(sets.enc_int16().cpu().numpy(), oenc)
     assert z.nnz == X and z.to_scipy().nnz == X
+
+
+# ----------------------------------------------------------------- count form of the join (next row f.1)
+def _oracle_counts(spg, edge, rows):
+    own, partner = oracle.pair_segments(edge)
+    seg, pairs = oracle.sjoin(spg[0], spg[1], spg[2], own, partner)
+    C = np.zeros((len(own), rows), np.float32)
+    segid = np.repeat(np.arange(len(own)), np.diff(seg))
+    np.add.at(C, (segid, pairs[:, 0]), 1)
+    np.add.at(C, (segid, pairs[:, 1]), 1)
+    return C, np.diff(seg)
+
+
+def test_gather_counts_matches_oracle_and_the_reference_first_stage(sp):
+    """C[j,p] counts are exact; C @ MLP(Z_SF) equals the reference's pe_embedding(xz).sum(-2) summed per segment
+    (model.py:78-83) up to fp32 summation order (tolerance 2e-5 relative, stated here)."""
+    g = _load("sjoin_int_emptyrows.npz")
+    z = _spg_from_golden(sp, g)
+    rows = g["encode"].shape[0]
+    C, sizes = sp.gather_counts(g["edge"], z, rows)
+    oC, osz = _oracle_counts((g["z_indptr"], g["z_indices"], g["z_data"]), g["edge"], rows)
+    assert np.array_equal(C.cpu().numpy(), oC) and np.array_equal(sizes.cpu().numpy(), osz)
+    assert np.array_equal(C.sum(1).cpu().numpy(), 2 * osz)                   # two slots per output row
+    # larger: a real sampling run, plus the model-side identity
+    ptr_, idx = sym_graph(5000, 30000, seed=3, hubs=1)
+    from surel_plus_amd.sampler import DeviceCSR
+    zz, sets = sp.sample_spg(DeviceCSR(ptr_, idx), np.arange(5000), num_walks=100, num_steps=3, seed=1, rng="philox")
+    table = sets.feature_table()
+    edge = np.random.default_rng(0).integers(0, 5000, (2, 4000))
+    C, sizes = sp.gather_counts(edge, zz, table.shape[0])
+    spg_h = (zz.indptr.cpu().numpy(), zz.indices.cpu().numpy(), zz.data.cpu().numpy())
+    oC, osz = _oracle_counts(spg_h, edge, table.shape[0])
+    assert np.array_equal(C.cpu().numpy(), oC) and np.array_equal(sizes.cpu().numpy(), osz)
+    torch.manual_seed(0)
+    mlp = torch.nn.Sequential(torch.nn.Linear(table.shape[1], 32), torch.nn.ReLU(), torch.nn.Linear(32, 32)).cuda()
+    xz, ind = sp.gather(edge, zz, "cuda", ptr=True, encode=table)
+    ref = torch.zeros(2 * 4000, 32, device="cuda").index_add_(
+        0, torch.repeat_interleave(torch.arange(2 * 4000, device="cuda"), ind[1:] - ind[:-1]), mlp(xz).sum(dim=-2))
+    fused = C @ mlp(table)
+    assert torch.allclose(fused, ref, rtol=2e-5, atol=2e-4)
+    with pytest.raises(IndexError):
+        sp.gather_counts(edge, zz, 3)
