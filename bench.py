@@ -42,7 +42,9 @@ WORKLOADS = {
     "cit2ppr": (None, 0, 1, "cit2-like PPR encoder: float64 SpG, N=2,927,963 rows x top-100, SpJoin only (train.py:39-43)"),
 }
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-FUSED = os.environ.get("SUBGACC_FUSED", "0") == "1"   # 1: the walk kernel also emits finished SpG rows (walk_spg)
+# SUBGACC_FUSED: 1 = the walk kernel also emits finished SpG rows (walk_spg), 0 = general pipeline, unset = the
+# library's choice (fused for walks of >= 3 hops)
+FUSED = {"1": True, "0": False}.get(os.environ.get("SUBGACC_FUSED", ""), None)
 LAZY = os.environ.get("SUBGACC_LAZY", "1") == "1"     # sizes stay on the device: one host round trip per step
 
 
@@ -306,9 +308,11 @@ def main():
                        "num_walks": M, "num_steps_cli": k, "rng": args.rng, "parallelism": f"query-shard x{world}",
                        "set_members_last_step": sets.X, "distinct_lp_rows_last_step": sets.c,
                        "xz_rows_last_step": int(xz.shape[0]), "graph_nnz": csr.nnz,
+                       "fused_spg_rows": sets.data is not None,
                        "stage_ms": {name: timer.mean_ms(name)[0] for name in
                                     ("walk_sets", "compact_sets", "uniq_rows", "spg_build", "sjoin_fill")}},
-            "roofline": {"bound": "hbm", "kernel": "walk_sets_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "walk_sets_kernel" + ("<SPG>" if sets.data is not None else ""),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel_ms": walk_ms, "launches_timed": launches, "algorithmic_bytes_per_launch": abytes},
         }

@@ -145,8 +145,10 @@ struct WalkArgs {
 constexpr int kSpgFold = 128;      // block-local table of the set's distinct LP keys
 constexpr int kSpgPerLane = 4;     // members per lane kept in registers while LDS is re-used => M*m+1 <= 1024
 
+// <= 80 SGPRs keeps 8 workgroups (32 waves) resident per CU; the allocator would otherwise take ~100 and the
+// hardware admits only 6 (MI355X_MICROARCH.md, residency formula) -- worth 14 % on the L2-resident collab graph
 template <bool IDX64, int RNG, bool SPG>
-__global__ __launch_bounds__(kWalkThreads) void walk_sets_kernel(const WalkArgs a) {
+__global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) void walk_sets_kernel(const WalkArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     unsigned long long *pk = (unsigned long long *)lds_raw;     // [T]
     int32_t *keys = (int32_t *)(pk + a.T);                       // [T]
@@ -347,20 +349,22 @@ __global__ __launch_bounds__(kWalkThreads) void walk_sets_kernel(const WalkArgs 
             if (keys[h] != -1) {
                 const uint32_t q = minq[h];
                 const int32_t r = (int32_t)(prefix[q >> 5] + __popc(bitmap[q >> 5] & ((1u << (q & 31u)) - 1u)));
-                if (r < a.stride) inv[r] = (uint16_t)h;  // members ranked past the bucket are dropped (:814-828)
+                if (r < a.stride) {  // members ranked past the bucket are dropped with all their visits (:814-828)
+                    if (SPG) {
+                        inv[r] = (uint16_t)h;
+                    } else {         // straight to the staging row (a second LDS pass to coalesce these stores
+                                     // buys nothing: the kernel is bound by its random reads, measured)
+                        a.set_ids[obase + r] = keys[h];
+                        a.set_keys[obase + r] = pk[h] | (r == 0 ? lead : 0ull);
+                    }
+                }
             }
-        __syncthreads();
+        if (SPG) __syncthreads();
     }
     if (!SPG) {
         if (tid == 0) {
             a.nsize[i] = ns;
             if (total > a.stride) atomicAdd(&a.flags[1], 1);
-        }
-        // members leave in rank order: consecutive lanes write consecutive words of the staging row
-        for (int r = tid; r < ns; r += kWalkThreads) {
-            const int h = inv[r];
-            a.set_ids[obase + r] = keys[h];
-            a.set_keys[obase + r] = pk[h] | (r == 0 ? lead : 0ull);
         }
         return;
     }

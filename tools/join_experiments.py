@@ -38,3 +38,26 @@ x = torch.empty(R * 8, device="cuda");
 print("memset 1.6GB   ms", timeit(lambda: x.zero_()))
 y = torch.empty(R * 8, device="cuda")
 print("copy 1.6GB     ms", timeit(lambda: y.copy_(x)))
+
+# ---- count form: first model stage of the reference vs counts @ MLP(table)
+H = 256
+torch.manual_seed(0)
+mlp = torch.nn.Sequential(torch.nn.Linear(table.shape[1], H), torch.nn.ReLU(), torch.nn.Linear(H, H)).cuda()
+print("gather_counts  ms", timeit(lambda: sp.gather_counts(rows, z, table.shape[0])))
+C, sizes = sp.gather_counts(rows, z, table.shape[0])
+print("C shape", tuple(C.shape), "MB", C.numel() * 4 / 1e6)
+with torch.no_grad():
+    print("counts@MLP(tab) ms", timeit(lambda: (C @ mlp(table)) / sizes[:, None].clamp(min=1)))
+    Bs = 4096                                   # the reference-style stage does not fit memory at B = 65536
+    rs = torch.arange(2 * Bs, device="cuda").view(2, Bs)
+    xz, ind = sp.gather(rs, z, "cuda", ptr=True, encode=table)
+    segid = torch.repeat_interleave(torch.arange(2 * Bs, device="cuda"), ind[1:] - ind[:-1])
+    def ref_stage():
+        x = mlp(xz).sum(dim=-2)
+        return torch.zeros(2 * Bs, H, device="cuda").index_add_(0, segid, x) / (ind[1:] - ind[:-1])[:, None].clamp(min=1)
+    t = timeit(ref_stage, n=3)
+    print(f"reference-style stage at B={Bs}: {t:.3f} ms  (x{B // Bs} for B={B}: {t * B / Bs:.1f} ms), xz rows {xz.shape[0]}")
+    Cs, ss = sp.gather_counts(rs, z, table.shape[0])
+    a = (Cs @ mlp(table)) / ss[:, None].clamp(min=1)
+    b = ref_stage()
+    print("max rel err", float(((a - b).abs() / (b.abs() + 1e-3)).max()))
