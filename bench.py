@@ -272,11 +272,12 @@ def main():
     torch.cuda.synchronize()
     timer.enabled = True
     t0 = time.perf_counter()
-    rows_total, algo_bytes = 0, 0
     last = None
+    step_marks = [t0]
     for s in range(W, W + K):
         xz, ind, sets = hot_path_step(sp, csr, edges[s], M, k, seed=s, rng=args.rng)
         last = (edges[s], sets, xz)
+        step_marks.append(time.perf_counter())     # host clock only: a step ends with its one size read-back
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -298,7 +299,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            tk = f"{args.workload}:{B}:{M}:{k}"
+            tk = f"{args.workload}:{B}:{M}:{k}:{'spg' if sets.data is not None else 'sets'}"
             traffic = tj.get(tk, {}).get("walk_sets_hbm_bytes_per_launch")
         out = {
             "metric": "query-pairs/sec (sample+SpJoin)", "value": world * B * K / elapsed, "unit": "query-pairs/s",
@@ -309,6 +310,9 @@ def main():
                        "set_members_last_step": sets.X, "distinct_lp_rows_last_step": sets.c,
                        "xz_rows_last_step": int(xz.shape[0]), "graph_nnz": csr.nnz,
                        "fused_spg_rows": sets.data is not None,
+                       "host_step_ms_min_median_max": [round(1e3 * v, 3) for v in (
+                           lambda d: (min(d), sorted(d)[len(d) // 2], max(d)))(
+                           [b - a for a, b in zip(step_marks, step_marks[1:])])],
                        "stage_ms": {name: timer.mean_ms(name)[0] for name in
                                     ("walk_sets", "compact_sets", "uniq_rows", "spg_build", "sjoin_fill")}},
             "roofline": {"bound": "hbm", "kernel": "walk_sets_kernel" + ("<SPG>" if sets.data is not None else ""),
