@@ -74,6 +74,26 @@ class SpG:
                    torch.from_numpy(z.indices.astype(np.int32)).to(device),
                    torch.from_numpy(data).to(device), shape=z.shape)
 
+    def save(self, path, encode=None):
+        """Persist the store (and optionally its Z_SF table) -- the reference never does; the
+        sampling stage then does not have to be repeated between runs.  Capacity-sized arrays are trimmed."""
+        nnz = self.nnz
+        blob = {"indptr": self.indptr.cpu(), "indices": self.indices[:nnz].cpu(), "data": self.data[:nnz].cpu(),
+                "shape": tuple(self.shape), "max_len": self.max_len, "max_data": self.max_data}
+        if encode is not None:
+            blob["encode"] = torch.as_tensor(encode).cpu()
+        torch.save(blob, path)
+
+    @classmethod
+    def load(cls, path, device=None):
+        """-> (SpG on `device`, encode tensor or None)"""
+        device = device or _lib.require_device()
+        blob = torch.load(path, map_location="cpu")
+        z = cls(blob["indptr"].to(device), blob["indices"].to(device), blob["data"].to(device), max_len=blob["max_len"],
+                shape=tuple(blob["shape"]), max_data=blob["max_data"])
+        enc = blob.get("encode")
+        return z, (enc.to(device) if enc is not None else None)
+
     def to_scipy(self):
         import scipy.sparse as sp
         nnz = self.nnz

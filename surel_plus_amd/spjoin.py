@@ -178,3 +178,18 @@ def gather_counts(edge, x, table_rows, device=None):
     sizes = spg.indptr[own + 1] - spg.indptr[own]
     _checked(out, sizes, flags)
     return out, sizes
+
+
+def mean_stage(edge, x, encode, embed):
+    """The reference's first model stage for mean aggregation, fused:  model.py:78-83
+        x = pe_embedding(xz).sum(dim=-2);  xl, xr = aggr.MeanAggregation()(x, ptr=ptr).view(2, -1, H)
+    as  (C @ embed(encode)) / sizes  with C = gather_counts(edge, x).  `embed` is any row-wise module (the reference's
+    pe_embedding MLP); autograd reaches its parameters through the small [c+1, H] activation -- C is a constant of
+    the batch -- so the stage trains like the original while xz [R,2,k] and the [R,2,H] activations never exist.
+    Returns float32 [2, B, H] (left endpoints, right endpoints); empty segments give zero rows."""
+    table = encode if torch.is_tensor(encode) else torch.as_tensor(encode)
+    spg = _as_spg(x)
+    table = table.to(device=spg.device, dtype=torch.float32)
+    C, sizes = gather_counts(edge, spg, table.shape[0])
+    out = (C @ embed(table)) / sizes.clamp(min=1).to(torch.float32)[:, None]
+    return out.view(2, -1, out.shape[-1])

@@ -582,3 +582,43 @@ def test_gather_counts_matches_oracle_and_the_reference_first_stage(sp):
     assert torch.allclose(fused, ref, rtol=2e-5, atol=2e-4)
     with pytest.raises(IndexError):
         sp.gather_counts(edge, zz, 3)
+
+
+def test_mean_stage_trains_like_the_reference_first_stage(sp):
+    """forward and parameter gradients of the fused stage equal pe_embedding(xz).sum(-2) + mean aggregation
+    (model.py:78-83) up to fp32 summation order (forward rtol 1e-4; gradients 1e-4 of their largest entry, stated here)."""
+    ptr_, idx = sym_graph(3000, 15000, seed=6, hubs=1)
+    from surel_plus_amd.sampler import DeviceCSR
+    z, sets = sp.sample_spg(DeviceCSR(ptr_, idx), np.arange(3000), num_walks=64, num_steps=3, seed=2, rng="philox")
+    table = sets.feature_table()
+    edge = torch.from_numpy(np.random.default_rng(4).integers(0, 3000, (2, 512))).cuda()
+    torch.manual_seed(1)
+    mlp_a = torch.nn.Sequential(torch.nn.Linear(4, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16)).cuda()
+    mlp_b = torch.nn.Sequential(torch.nn.Linear(4, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16)).cuda()
+    mlp_b.load_state_dict(mlp_a.state_dict())
+    w = torch.randn(2, 512, 16, device="cuda")
+    fused = sp.mean_stage(edge, z, table, mlp_a)
+    (fused * w).sum().backward()
+    xz, ind = sp.gather(edge, z, "cuda", ptr=True, encode=table)
+    x = mlp_b(xz).sum(dim=-2)
+    seg = torch.repeat_interleave(torch.arange(1024, device="cuda"), ind[1:] - ind[:-1])
+    ref = (torch.zeros(1024, 16, device="cuda").index_add_(0, seg, x) / (ind[1:] - ind[:-1]).clamp(min=1)[:, None]).view(2, 512, 16)
+    (ref * w).sum().backward()
+    assert torch.allclose(fused, ref, rtol=1e-4, atol=1e-5)
+    for pa, pb in zip(mlp_a.parameters(), mlp_b.parameters()):      # gradients are sums over ~2e5 rows in fp32
+        assert float((pa.grad - pb.grad).abs().max()) <= 1e-4 * float(pb.grad.abs().max()) + 1e-6
+
+
+def test_spg_save_and_load(sp, tmp_path):
+    ptr_, idx = sym_graph(1000, 5000, seed=2)
+    from surel_plus_amd.sampler import DeviceCSR
+    z, sets = sp.sample_spg(DeviceCSR(ptr_, idx), np.arange(1000), num_walks=32, num_steps=3, seed=2, lazy=True)
+    table = sets.feature_table()
+    path = str(tmp_path / "spg.pt")
+    z.save(path, encode=table)
+    z2, enc2 = sp.SpG.load(path)
+    assert z2.nnz == z.nnz and z2.indices.numel() == z.nnz                       # trimmed to the real size
+    edge = np.random.default_rng(0).integers(0, 1000, (2, 200))
+    a = sp.gather(edge, z, "cuda", ptr=True, encode=table)
+    b = sp.gather(edge, z2, "cuda", ptr=True, encode=enc2)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
