@@ -89,6 +89,9 @@ class KernelTimer:
         return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None, len(ev)
 
 
+_XZ_BUF = {}
+
+
 def hot_path_step(sp, csr, edge, M, k, seed, rng):
     """sample both endpoints of every pair, build the SpG, join.  Returns (xz, indptr, sets)."""
     B = edge.shape[1]
@@ -96,7 +99,13 @@ def hot_path_step(sp, csr, edge, M, k, seed, rng):
     z, sets = sp.sample_spg(csr, roots, num_walks=M, num_steps=k - 1, seed=seed, rng=rng, fused=FUSED, lazy=LAZY)
     table = sets.feature_table()
     rows = torch.arange(2 * B, device=edge.device, dtype=torch.int64).view(2, B)   # row i = root i of this batch
-    xz, ind = sp.gather(rows, z, edge.device, ptr=True, encode=table)
+    # the join output is written into one re-used buffer sized for the worst case (every set full): a serving loop
+    # would do the same, and it keeps GB-sized device allocations -- tens of ms on some hosts -- out of the steps
+    cap = 2 * B * z.max_len * 2 * k
+    buf = _XZ_BUF.get((edge.device, cap))
+    if buf is None:
+        buf = _XZ_BUF[(edge.device, cap)] = torch.empty(cap, dtype=torch.float32, device=edge.device)
+    xz, ind = sp.gather(rows, z, edge.device, ptr=True, encode=table, out=buf)
     sets.resolve()      # sizes, status flags and the distinct-row count: read once, after everything is queued
     return xz, ind, sets
 
@@ -271,6 +280,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = True
+    allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
     t0 = time.perf_counter()
     last = None
     step_marks = [t0]
@@ -310,6 +320,7 @@ def main():
                        "set_members_last_step": sets.X, "distinct_lp_rows_last_step": sets.c,
                        "xz_rows_last_step": int(xz.shape[0]), "graph_nnz": csr.nnz,
                        "fused_spg_rows": sets.data is not None,
+                       "device_allocs_in_timed_region": torch.cuda.memory_stats().get("num_device_alloc", 0) - allocs0,
                        "host_step_ms_min_median_max": [round(1e3 * v, 3) for v in (
                            lambda d: (min(d), sorted(d)[len(d) // 2], max(d)))(
                            [b - a for a, b in zip(step_marks, step_marks[1:])])],

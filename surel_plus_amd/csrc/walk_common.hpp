@@ -1,0 +1,110 @@
+// walk_common.hpp -- pieces shared by the walk kernels (walk.hip: one root per workgroup; walk_pipe.hip: persistent,
+// software-pipelined): RNGs, CSR row access, kernel arguments, LDS sizing.
+#pragma once
+#include "common.hpp"
+#include "blockscan.hpp"
+#include "uniq_table.hpp"
+
+namespace subgacc {
+
+constexpr int kWalkThreads = 256;
+constexpr uint32_t kLcgA = 1103515245u, kLcgC = 12345u;
+constexpr uint32_t kPhiloxKey1 = 0x5355524Cu;  // "SURL"
+constexpr uint32_t kStreamShuffle = 0xFFFFFFFFu;
+constexpr int kNeighCap = 1000000;  // NEBMAX, subg_acc.c:13
+
+// ---------------------------------------------------------------------------------------- RNGs
+__device__ __forceinline__ uint32_t lcg_jump(uint32_t x, uint32_t k) {
+    uint32_t a = kLcgA, c = kLcgC;
+    while (k) {
+        if (k & 1u) x = a * x + c;
+        c *= (a + 1u);
+        a *= a;
+        k >>= 1;
+    }
+    return x;
+}
+__device__ __forceinline__ uint32_t rand_r_next(uint32_t &x) {
+    uint32_t r;
+    x = x * kLcgA + kLcgC;
+    r = (x >> 16) & 2047u;
+    x = x * kLcgA + kLcgC;
+    r = (r << 10) ^ ((x >> 16) & 1023u);
+    x = x * kLcgA + kLcgC;
+    r = (r << 10) ^ ((x >> 16) & 1023u);
+    return r;
+}
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0, c1 = l1, c2 = n2, c3 = l0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+
+// ------------------------------------------------------------------- rand_r stream positions
+template <bool IDX64>
+__device__ __forceinline__ void load_row(const void *indptr, int32_t node, int64_t &beg, int64_t &deg) {
+    if (IDX64) {
+        const int64_t *p = (const int64_t *)indptr + node;
+        beg = p[0];
+        deg = p[1] - beg;
+    } else {
+        const int32_t *p = (const int32_t *)indptr + node;
+        const int32_t b = p[0], e = p[1];
+        beg = b;
+        deg = e - b;
+    }
+}
+
+struct WalkArgs {
+    const void *indptr;
+    const int32_t *indices;
+    const int32_t *query;
+    int64_t n;
+    const uint32_t *rng_pos, *rng_seed;
+    int32_t *set_ids;
+    uint64_t *set_keys;
+    int32_t *nsize;
+    int32_t *walks;
+    int32_t *flags;
+    int32_t M, m, stride, shift;
+    int32_t T, tshift;   // table size (pow2) and 32-log2(T)
+    int32_t nwords;      // bitmap words over q in [0, M*m]
+    uint32_t seed;
+    int32_t wo, step_major, cap_root;
+    // SPG mode (walk_spg_kernel): rows leave sorted by node id with the slot of their LP key in the HBM table
+    int32_t *set_slot;
+    UniqTable table;
+    int64_t root_base;   // global index of query[0]: tags (root_base+i)*stride + rank order the first occurrences
+};
+
+constexpr int kSpgFold = 128;      // block-local table of the set's distinct LP keys
+constexpr int kSpgPerLane = 4;     // members per lane kept in registers while LDS is re-used => M*m+1 <= 1024
+
+static inline int table_size_for(int64_t q) {
+    int64_t want = q + q / 4 + 1;
+    int t = 64;
+    while (t < want) t <<= 1;
+    return t;
+}
+
+static inline size_t walk_lds_bytes(int T, int nwords, int M, int Q, bool spg, bool bucket_truncates) {
+    const size_t head = (size_t)T * 16 + (size_t)nwords * 4 + (size_t)(nwords + 1) * 4 + (size_t)M * 4;
+    const size_t fold = 8 + (size_t)kSpgFold * 16 + 64;
+    if (!spg) return head + (size_t)Q * 2 + 16;
+    if (bucket_truncates) return head + (size_t)Q * 2 + fold + 16;
+    return head + (fold > (size_t)Q * 2 ? fold : (size_t)Q * 2) + 16;   // the fold table overlays inv
+}
+
+
+// walk_pipe.hip: persistent software-pipelined form of the walk kernel; returns 1 when it took the launch
+int launch_walk_pipe(const WalkArgs &a, bool indptr64, int rng_mode, bool spg, size_t lds, hipStream_t s);
+
+}  // namespace subgacc

@@ -42,11 +42,13 @@ def _as_rows(edge, device):
     return torch.from_numpy(np.ascontiguousarray(np.asarray(edge)).astype(np.int64)).to(device)
 
 
-def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pair_block=0):
+def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pair_block=0, out=None):
     """Generic segment join (include/subgacc.h: subgacc_sjoin_sizes + subgacc_sjoin_fill).
 
     own/partner: int64 device tensors of SpG row numbers, one segment each.  pair_block = P > 0 promises that
     the list is made of blocks of P segments with block 2t+1 the mirror of block 2t (see include/subgacc.h).
+    out: optional preallocated float32 buffer with room for the R output rows (a steady-state caller re-uses one
+    buffer instead of asking the allocator for a fresh GB-sized block per batch); the result is a view of it.
     Returns (xz, ind): xz float32 [R,2,k] (or int32 [R,2] index pairs when return_index), ind = int64 [S+1]
     segment pointers (ptr_mode) or int64 [R] segment ids.
     """
@@ -80,7 +82,12 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
         k = enc.shape[1]
         if enc.shape[0] <= spg.max_data:       # host-side bound check: no device round trip on the hot path
             raise IndexError(f"index {spg.max_data} is out of bounds for the encode table with {enc.shape[0]} rows")
-        out = torch.empty((R, 2, k), dtype=torch.float32, device=dev)
+        if out is not None:
+            if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() < R * 2 * k or out.device != dev:
+                raise ValueError("out= must be a contiguous float32 buffer on the SpG's device with >= R*2*k elements")
+            out = out.view(-1)[: R * 2 * k].view(R, 2, k)
+        else:
+            out = torch.empty((R, 2, k), dtype=torch.float32, device=dev)
         with _timed("sjoin_fill"):
             check(L.subgacc_sjoin_fill(ptr(spg.indptr), ptr(spg.indices), ptr(spg.data), None, ptr(own), ptr(partner), S,
                                        ptr(seg), ptr(enc), enc.shape[0], k, ptr(out), None, ptr(segid), spg.max_len,
@@ -103,13 +110,13 @@ def _checked(out, ind, flags):
     return out, ind
 
 
-def gather(edge, x, device=None, ptr=True, encode=None):
+def gather(edge, x, device=None, ptr=True, encode=None, out=None):
     """train.py:13-45.  Left blocks (S_u with S_v looked up) then right blocks, per pair in batch order."""
     spg = _as_spg(x)
     e = _as_rows(edge, spg.device)
     own = torch.cat([e[0], e[1]])
     partner = torch.cat([e[1], e[0]])
-    return _checked(*sjoin(spg, own, partner, encode, ptr_mode=ptr, pair_block=e.shape[1]))
+    return _checked(*sjoin(spg, own, partner, encode, ptr_mode=ptr, pair_block=e.shape[1], out=out))
 
 
 def hgather(hedge, x, device=None, encode=None):

@@ -6,7 +6,7 @@ cp ../libsubgacc_hip.so /tmp/lib_orig.so
 IFS='|' read -ra VS <<< "${VARIANTS:-}"
 for V in "" "${VS[@]}"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -ffp-contract=off $V -c walk.hip -o /tmp/walk_v.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/capi.o build/scan.o /tmp/walk_v.o build/uniq.o build/spg.o build/sjoin.o -o ../libsubgacc_hip.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/capi.o build/scan.o /tmp/walk_v.o build/walk_pipe.o build/uniq.o build/spg.o build/sjoin.o -o ../libsubgacc_hip.so
   for W in ${WLS:-cit2 collab}; do
     for rep in 1 2; do
     echo -n "[$V] $W: "
