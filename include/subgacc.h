@@ -112,9 +112,11 @@ int subgacc_walk_spg(const subgacc_walk_cfg *cfg, const void *indptr, const int3
                      const int32_t *query, int64_t n, int64_t root_base, const uint32_t *rng_pos,
                      const uint32_t *rng_seed, void *uniq_table, int64_t uniq_capacity, int32_t *row_ids,
                      int32_t *row_slot, int32_t *nsize, int32_t *flags, void *stream);
-/* strided -> packed copy of the rows of subgacc_walk_spg: row i goes to [row_off[i], +nsize[i]) */
+/* strided -> packed copy of the rows of subgacc_walk_spg: row i goes to [row_off[i], +nsize[i]).  With uniq_table
+ * (already numbered by subgacc_uniq_number) out_data receives SFptr+1 directly; without it the raw table slots. */
 int subgacc_compact_rows(const int32_t *row_ids, const int32_t *row_slot, const int32_t *nsize, const int64_t *row_off,
-                         int64_t n, int32_t stride, int32_t *out_indices, int32_t *out_data, void *stream);
+                         int64_t n, int32_t stride, int32_t *out_indices, int32_t *out_data, const void *uniq_table,
+                         int64_t uniq_capacity, void *stream);
 
 /* Exclusive scan int32 -> int64, out[n] = total.  (Prefix of nsize, subg_acc.c:848-851.) */
 size_t subgacc_scan_workspace_bytes(int64_t n);

@@ -76,7 +76,7 @@ def lib():
         "subgacc_rng_positions": (C.c_int, [cfgp, vp, vp, i64, i32, u64, vp, vp, vp, sz, vp]),
         "subgacc_walk_sets": (C.c_int, [cfgp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
         "subgacc_walk_spg": (C.c_int, [cfgp, vp, vp, i64, vp, i64, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp]),
-        "subgacc_compact_rows": (C.c_int, [vp, vp, vp, vp, i64, i32, vp, vp, vp]),
+        "subgacc_compact_rows": (C.c_int, [vp, vp, vp, vp, i64, i32, vp, vp, vp, i64, vp]),
         "subgacc_scan_workspace_bytes": (sz, [i64]),
         "subgacc_exclusive_scan_i32": (C.c_int, [vp, i64, vp, vp, sz, vp]),
         "subgacc_compact_sets": (C.c_int, [vp, vp, vp, vp, i64, i32, vp, vp, vp, i64, i64, vp, vp, vp]),

@@ -678,7 +678,8 @@ __global__ __launch_bounds__(kCompactThreads) void compact_rows_kernel(const int
                                                                         const int32_t *__restrict__ nsize,
                                                                         const int64_t *__restrict__ row_off, int64_t n,
                                                                         int32_t stride, int32_t *__restrict__ out_indices,
-                                                                        int32_t *__restrict__ out_data) {
+                                                                        int32_t *__restrict__ out_data,
+                                                                        const int32_t *__restrict__ slot_id) {
     const int wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
     const int64_t i = (int64_t)blockIdx.x * kCompactWaves + wave;
     if (i >= n) return;
@@ -686,13 +687,16 @@ __global__ __launch_bounds__(kCompactThreads) void compact_rows_kernel(const int
     const int64_t src = i * (int64_t)stride, dst = row_off[i];
     for (int r = lane; r < ns; r += kWave) {
         out_indices[dst + r] = row_ids[src + r];
-        out_data[dst + r] = row_slot[src + r];
+        const int32_t sl = row_slot[src + r];
+        out_data[dst + r] = slot_id ? slot_id[sl] + 1 : sl;   // numbered table given: SFptr+1 at once, no translate pass
     }
 }
 
 extern "C" int subgacc_compact_rows(const int32_t *row_ids, const int32_t *row_slot, const int32_t *nsize,
                                     const int64_t *row_off, int64_t n, int32_t stride, int32_t *out_indices,
-                                    int32_t *out_data, void *stream) {
+                                    int32_t *out_data, const void *uniq_table, int64_t uniq_capacity, void *stream) {
+    const int32_t *slot_id = uniq_table ? (const int32_t *)((const char *)uniq_table + (size_t)uniq_capacity * 16) : nullptr;
+    SG_REQUIRE(!uniq_table || uniq_capacity > 0, SUBGACC_ERR_BADARG, "compact_rows: table without capacity");
     SG_REQUIRE(n >= 0 && stride > 0, SUBGACC_ERR_BADARG, "compact_rows: bad sizes");
     if (n == 0) return SUBGACC_OK;
     SG_REQUIRE(row_ids && row_slot && nsize && row_off && out_indices && out_data, SUBGACC_ERR_BADARG,
@@ -700,7 +704,7 @@ extern "C" int subgacc_compact_rows(const int32_t *row_ids, const int32_t *row_s
     const int64_t blocks = ceil_div(n, kCompactWaves);
     SG_REQUIRE(blocks < (1ll << 31), SUBGACC_ERR_BADARG, "compact_rows: too many rows in one call");
     hipLaunchKernelGGL(compact_rows_kernel, dim3((unsigned)blocks), dim3(kCompactThreads), 0, (hipStream_t)stream,
-                       row_ids, row_slot, nsize, row_off, n, stride, out_indices, out_data);
+                       row_ids, row_slot, nsize, row_off, n, stride, out_indices, out_data, slot_id);
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }

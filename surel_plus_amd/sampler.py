@@ -275,6 +275,15 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
                                           ptr(st_ids), ptr(st_aux), ptr(nsize[lo:]),
                                           ptr(walks[lo:]) if walks is not None else None, ptr(flags), st))
         check(L.subgacc_exclusive_scan_i32(ptr(nsize[lo:]), cn, ptr(off_chunk), ptr(scan_ws), scan_ws.numel(), st))
+        numbered_early = fused_rows and chunk == n
+        if numbered_early:    # one chunk: the table is complete -> number it now and let the copy emit SFptr+1
+            count = torch.zeros(1, dtype=torch.int64, device=dev)
+            max_unique = min(uniq_capacity, limit)
+            ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
+            nws = torch.empty(L.subgacc_uniq_number_workspace_bytes(uniq_capacity, 0), dtype=torch.uint8, device=dev)
+            with _timed("uniq_rows"):
+                check(L.subgacc_uniq_number(ptr(table), uniq_capacity, None, 0, ptr(ukeys), max_unique, ptr(count), limit,
+                                            ptr(nws), nws.numel(), st))
         # packed arrays: exact size (one 8-byte host read) or, lazily, the upper bound n*stride
         total = cn * stride if lazy else int(off_chunk[cn].item())
         ids_c = torch.empty(total, dtype=torch.int32, device=dev)
@@ -283,7 +292,8 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
         with _timed("compact_sets"):
             if fused_rows:
                 check(L.subgacc_compact_rows(ptr(st_ids), ptr(st_aux), ptr(nsize[lo:]), ptr(off_chunk), cn, stride,
-                                             ptr(ids_c), ptr(slot_c), st))
+                                             ptr(ids_c), ptr(slot_c), ptr(table) if numbered_early else None,
+                                             uniq_capacity if numbered_early else 0, st))
             else:
                 check(L.subgacc_compact_sets(ptr(st_ids), ptr(st_aux), ptr(nsize[lo:]), ptr(off_chunk), cn, stride,
                                              ptr(ids_c), ptr(keys_c), ptr(table), uniq_capacity if dedup else 0, X,
@@ -310,9 +320,11 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
         return sets
 
     # number the distinct LP rows by first occurrence (subg_acc.c:957-1000)
-    count = torch.zeros(1, dtype=torch.int64, device=dev)
     x_dev = row_off[n:n + 1]
-    if fused_rows or lazy:            # table-only direct ranking (tags need not be element positions)
+    if n and fused_rows and chunk == n:
+        pass                          # numbered before the copy, which already wrote SFptr+1
+    elif fused_rows or lazy:          # table-only direct ranking (tags need not be element positions)
+        count = torch.zeros(1, dtype=torch.int64, device=dev)
         max_unique = min(uniq_capacity, limit)
         ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
         ws = torch.empty(L.subgacc_uniq_number_workspace_bytes(uniq_capacity, 0), dtype=torch.uint8, device=dev)
@@ -322,6 +334,7 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
             if fused_rows:            # slot -> SFptr+1 in place: the rows are finished SpG rows
                 check(L.subgacc_uniq_translate(ptr(table), uniq_capacity, ptr(slot), slot.numel(), ptr(x_dev), 1, st))
     else:
+        count = torch.zeros(1, dtype=torch.int64, device=dev)
         max_unique = min(max(X, 1), uniq_capacity)
         ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
         ws = torch.empty(L.subgacc_uniq_number_workspace_bytes(uniq_capacity, X), dtype=torch.uint8, device=dev)
