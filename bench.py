@@ -319,6 +319,10 @@ def main():
                        "num_walks": M, "num_steps_cli": k, "rng": args.rng, "parallelism": f"query-shard x{world}",
                        "set_members_last_step": sets.X, "distinct_lp_rows_last_step": sets.c,
                        "xz_rows_last_step": int(xz.shape[0]), "graph_nnz": csr.nnz,
+                       # S = roots/s of the sampler pipeline (walk .. SpG), J = pairs/s of the join alone
+                       "S_roots_per_s": 2 * B / (1e-3 * sum(v for v in (timer.mean_ms(n_)[0] for n_ in
+                                                 ("walk_sets", "compact_sets", "uniq_rows", "spg_build")) if v)),
+                       "J_pairs_per_s": (B / (1e-3 * join_ms)) if join_ms else None,
                        "fused_spg_rows": sets.data is not None,
                        "device_allocs_in_timed_region": torch.cuda.memory_stats().get("num_device_alloc", 0) - allocs0,
                        "host_step_ms_min_median_max": [round(1e3 * v, 3) for v in (

