@@ -273,8 +273,15 @@ def main():
 
     timer = KernelTimer()
     sampler_mod.KERNEL_TIMER = timer
-    for s in range(W):
-        hot_path_step(sp, csr, edges[s], M, k, seed=s, rng=args.rng)
+    last = None
+    PRIME = 2
+    for s in list(range(PRIME)) + list(range(W)):
+        # Two priming passes (part of set-up, like building the graph), then the W warm-up steps.  The previous step's
+        # results are kept alive exactly like in the timed loop, so torch's caching allocator reaches its steady state
+        # (two generations of buffers) here: a fresh GB-sized hipMalloc inside the timed region costs ~10 ms on some
+        # hosts of the pool (seen as one 11-19 ms step with unchanged kernel times) and is not part of the path.
+        xz, ind, sets = hot_path_step(sp, csr, edges[s % len(edges)], M, k, seed=s, rng=args.rng)
+        last = (edges[s % len(edges)], sets, xz)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -282,7 +289,6 @@ def main():
     timer.enabled = True
     allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
     t0 = time.perf_counter()
-    last = None
     step_marks = [t0]
     for s in range(W, W + K):
         xz, ind, sets = hot_path_step(sp, csr, edges[s], M, k, seed=s, rng=args.rng)
