@@ -190,7 +190,12 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
                 goto visit;
 #endif
                 int64_t b, d;
+#if SG_EXPERIMENT == 6   // upper bound of any row-pointer optimisation: no indptr read at all (results are wrong)
+                b = ((int64_t)(uint32_t)cur * 21) % 62000000;
+                d = 20;
+#else
                 load_row<IDX64>(a.indptr, cur, b, d);
+#endif
                 if (d > 0) {
                     uint32_t r;
                     if (RNG == SUBGACC_RNG_RAND_R) {

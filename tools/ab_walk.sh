@@ -1,6 +1,7 @@
 #!/bin/bash
 # Dev-only A/B of compile-time variants of walk.hip on ONE box: usage  VARIANTS="-DA=1|-DB=1" WLS="cit2 collab" tools/ab_walk.sh
 set -e
+export SUBGACC_WALK_PIPE=${SUBGACC_WALK_PIPE:-0}   # the hooks live in walk_sets_kernel (walk.hip)
 cd $GRAFT_REPO_ROOT/surel_plus_amd/csrc
 cp ../libsubgacc_hip.so /tmp/lib_orig.so
 IFS='|' read -ra VS <<< "${VARIANTS:-}"

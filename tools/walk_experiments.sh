@@ -2,6 +2,7 @@
 # Dev-only: build variants of the walk kernel (traversal only / dedup only) and time them with bench.py.
 # Results of the variants are wrong by construction; only walk_sets stage time matters.
 set -e
+export SUBGACC_WALK_PIPE=${SUBGACC_WALK_PIPE:-0}   # the hooks live in walk_sets_kernel (walk.hip)
 cd $GRAFT_REPO_ROOT/surel_plus_amd/csrc
 cp ../libsubgacc_hip.so /tmp/lib_orig.so
 for E in ${EXPS:-0 1 2}; do
