@@ -1,0 +1,40 @@
+"""Dev-only: the reference's offline stage (main.py:172-178: subg_matrix over all N nodes) -- reference C/OpenMP
+sampler + scipy COO->CSR on the host versus the drop-ins of this repo, same graph, same parameters."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["SUBGACC_QUIET"] = "1"
+import numpy as np, scipy.sparse as sps, torch
+import oracle, surel_plus_amd as sp
+from surel_plus_amd.graphs import preset_graph
+from bench import quiet_stdout
+
+name, M, k = (sys.argv[1] if len(sys.argv) > 1 else "collab"), 200, (3 if len(sys.argv) < 3 else int(sys.argv[2]))
+csr = preset_graph(name)
+N = csr.num_nodes
+ptr_h, idx_h = csr.indptr.cpu().numpy(), csr.indices.cpu().numpy()
+idx = np.arange(N)
+
+class G:
+    indptr, indices = ptr_h, idx_h
+
+def sync_time(fn):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize(); return time.perf_counter() - t0, out
+
+for _ in range(2):
+    t_dev, (z, enc) = sync_time(lambda: sp.subg_matrix(csr, torch.arange(N, dtype=torch.int32, device="cuda"), M, k, rng="philox"))
+t_host_in, (z2, enc2) = sync_time(lambda: sp.subg_matrix(G, idx, M, k))            # numpy CSR in (uploaded), rand_r mode
+t_api, out = sync_time(lambda: sp.gset_sampler(ptr_h, idx_h, idx, num_walks=M, num_steps=k - 1))   # numpy in / numpy out
+print(f"{name}: N={N} nnz={csr.nnz} M={M} --num_steps {k}: set members {z.nnz}, distinct LP rows {enc.shape[0] - 1}")
+print(f"  subg_matrix, graph resident (philox):        {t_dev:8.3f} s  = {N / t_dev / 1e6:7.2f} M roots/s")
+print(f"  subg_matrix, numpy CSR in (rand_r, exact):   {t_host_in:8.3f} s")
+print(f"  gset_sampler drop-in (numpy in, numpy out):  {t_api:8.3f} s")
+ref = oracle.ref_module()
+if ref is not None and ptr_h.dtype == np.int32:
+    for nt in (8, 16, -1):
+        t0 = time.perf_counter()
+        with quiet_stdout():
+            nsize, remap, enc_r = ref.gset_sampler(ptr_h, idx_h, idx, num_walks=M, num_steps=k - 1, nthread=nt)
+        t1 = time.perf_counter()
+        zs = sps.csr_matrix((remap[1] + 1, (np.repeat(idx, nsize), remap[0])), (N, N))
+        t2 = time.perf_counter()
+        print(f"  reference gset_sampler nthread={nt:3d}: {t1 - t0:8.2f} s + scipy csr_matrix {t2 - t1:6.2f} s = {t2 - t0:8.2f} s")
