@@ -213,6 +213,38 @@ int subgacc_sjoin_counts(const int64_t *spg_indptr, const int32_t *spg_indices, 
                          const int64_t *own, const int64_t *partner, int64_t S, int64_t table_rows, float *out_counts,
                          int32_t max_len, int64_t pair_block, int32_t *flags, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Top-K approximate-PPR node sets -- replaces sampler/pprgo.py:9-38 (_calc_ppr_node, the
+ * Andersen-Chung-Lang push with a LIFO work list), :53-63 (calc_ppr_topk_parallel), :85-111 (topk_ppr_matrix
+ * normalisation) and utils.py:35-36 (encoding 'PPR').  The graph is an unweighted CSR without repeated entries
+ * in a row (deg = row length, as np.sum(adj > 0, 1) / adj.sum(1) of pprgo.py:69,92 give for such a graph).
+ * The push order and every float32 rounding follow the reference (numba typing: alpha, epsilon, p, r float32;
+ * (1 - alpha) * res / deg in float64, rounded on the store), so rows are reproducible bit for bit; equal scores
+ * at the top-k cut keep the node that entered p later.
+ *
+ * One wavefront works on one root at a time in a private `slab` of 24 << table_log2 bytes (hash table of p, r
+ * and the work list).  num_waves slabs = num_waves resident wavefronts; reset the slabs once, the kernel hands
+ * them back clean.  A root that touches more than (1 << table_log2) / 2 nodes (bounded by 1/(alpha*epsilon))
+ * gets out_count = -1 and flags[2] |= 1: run those roots again with a larger table.
+ *   out_count [n] int32, out_ids [n*topk] int32 ascending ids of row i at i*topk, out_vals [n*topk] float32
+ *   pushes (optional, device) accumulates the number of pushes.  topk <= 4096.
+ * ------------------------------------------------------------------------------------------- */
+size_t subgacc_ppr_slab_bytes(int32_t table_log2, int32_t num_waves);
+int subgacc_ppr_slab_reset(void *slab, int32_t table_log2, int32_t num_waves, void *stream);
+int subgacc_ppr_topk(const void *indptr, int32_t indptr64, const int32_t *indices, int64_t num_nodes,
+                     const int32_t *roots, int64_t n, float alpha, float epsilon, int32_t topk, void *slab,
+                     int32_t table_log2, int32_t num_waves, int32_t *out_count, int32_t *out_ids, float *out_vals,
+                     int32_t *flags, uint64_t *pushes, void *stream);
+/* Packed rows (row_off[n+1], ids, vals) -> float64 payload.  mode 0 'row': unchanged; 1 'sym':
+ * sqrt(max(deg_root,1e-12)) * v * (1/sqrt(max(deg_col,1e-12))); 2 'col': deg_root * v * (1/max(deg_col,1e-12))
+ * (pprgo.py:88-108, evaluated left to right in float64).  max_nnz >= row_off[n] sizes the launch.  max_bits
+ * (optional, device uint64, zeroed by the caller) receives the bit pattern of the largest output value. */
+int subgacc_ppr_normalize(const void *indptr, int32_t indptr64, const int32_t *roots, int64_t n,
+                          const int64_t *row_off, int64_t max_nnz, const int32_t *ids, const float *vals, int32_t mode,
+                          double *out, uint64_t *max_bits, void *stream);
+/* utils.py:35-36: data = (data + 0.1) / (max + 0.1) over the first *nnz_dev entries; max from max_bits. */
+int subgacc_ppr_encode(double *data, int64_t max_nnz, const int64_t *nnz_dev, const uint64_t *max_bits, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

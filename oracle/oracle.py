@@ -21,8 +21,8 @@ def build(force=False):
     """gcc-compile the C restatement into oracle/_build/liboracle.so (and oracle/_ref when the
     reference tree is present -- build container only)."""
     so = os.path.join(_HERE, "_build", "liboracle.so")
-    src = os.path.join(_HERE, "subgacc_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("subgacc_oracle.c", "ppr_oracle.c")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
     if os.path.exists("/root/reference/subg_acc/subg_acc.c"):
         subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
@@ -252,3 +252,49 @@ def gather_numpy(edge, spg, ptr=True, encode=None):
 
 def num_threads():
     return int(lib().orc_num_threads())
+
+
+# ------------------------------------------------------------------ top-K PPR sets (oracle/ppr_oracle.c; parity UNPINNED)
+def ppr_topk(indptr, indices, roots, alpha, epsilon, topk, table_log2=20):
+    """sampler/pprgo.py:9-38,53-82: rows of the top-`topk` approximate-PPR entries of every root, sorted by node id.
+    Returns (row_off int64[n+1], ids int32[X], vals float32[X], pushes)."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    roots = np.ascontiguousarray(roots, dtype=np.int32)
+    n = len(roots)
+    cnt = np.zeros(n, np.int32)
+    ids = np.zeros(n * topk, np.int32)
+    vals = np.zeros(n * topk, np.float32)
+    pushes = C.c_int64(0)
+    rc = lib().orc_ppr_topk(_p(indptr, C.c_int64), _p(indices, C.c_int32), _p(roots, C.c_int32), C.c_int64(n),
+                            C.c_float(alpha), C.c_float(epsilon), C.c_int32(topk), C.c_int32(table_log2),
+                            _p(cnt, C.c_int32), _p(ids, C.c_int32), _p(vals, C.c_float), C.byref(pushes))
+    if rc:
+        raise MemoryError(f"orc_ppr_topk failed ({rc})")
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(cnt, out=off[1:])
+    keep = (np.arange(topk)[None, :] < cnt[:, None]).ravel()
+    return off, ids[keep], vals[keep], pushes.value
+
+
+_PPR_NORM = {"row": 0, "sym": 1, "col": 2}
+
+
+def topk_ppr_matrix(indptr, indices, alpha, eps, idx, topk, normalization="row", table_log2=20):
+    """sampler/pprgo.py:85-111 on an unweighted CSR graph: (row_off, ids, data float64)."""
+    if normalization not in _PPR_NORM:
+        raise ValueError(f"Unknown PPR normalization: {normalization}")
+    off, ids, vals, _ = ppr_topk(indptr, indices, idx, alpha, eps, topk, table_log2)
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    roots = np.ascontiguousarray(idx, dtype=np.int32)
+    out = np.zeros(len(ids), np.float64)
+    lib().orc_ppr_normalize(_p(indptr, C.c_int64), _p(roots, C.c_int32), C.c_int64(len(roots)), _p(off, C.c_int64),
+                            _p(ids, C.c_int32), _p(vals, C.c_float), C.c_int(_PPR_NORM[normalization]), _p(out, C.c_double))
+    return off, ids, out
+
+
+def ppr_encode(data):
+    """utils.py:35-36 (encoding 'PPR'): (x + 0.1) / (max + 0.1), float64."""
+    data = np.array(data, dtype=np.float64, copy=True)
+    lib().orc_ppr_encode(_p(data, C.c_double), C.c_int64(len(data)))
+    return data

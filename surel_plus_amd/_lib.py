@@ -26,6 +26,7 @@ SYMBOLS = (
     "subgacc_uniq_number_workspace_bytes", "subgacc_uniq_number", "subgacc_uniq_translate", "subgacc_unpack_lp",
     "subgacc_spg_build",
     "subgacc_sjoin_workspace_bytes", "subgacc_sjoin_sizes", "subgacc_sjoin_fill", "subgacc_sjoin_counts",
+    "subgacc_ppr_slab_bytes", "subgacc_ppr_slab_reset", "subgacc_ppr_topk", "subgacc_ppr_normalize", "subgacc_ppr_encode",
 )
 
 
@@ -93,6 +94,12 @@ def lib():
         "subgacc_sjoin_fill": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, i32, i64, vp, vp]),
     }
     sig["subgacc_sjoin_counts"] = (C.c_int, [vp, vp, vp, vp, vp, i64, i64, vp, i32, i64, vp, vp])
+    f32 = C.c_float
+    sig["subgacc_ppr_slab_bytes"] = (sz, [i32, i32])
+    sig["subgacc_ppr_slab_reset"] = (C.c_int, [vp, i32, i32, vp])
+    sig["subgacc_ppr_topk"] = (C.c_int, [vp, i32, vp, i64, vp, i64, f32, f32, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp])
+    sig["subgacc_ppr_normalize"] = (C.c_int, [vp, i32, vp, i64, vp, i64, vp, vp, i32, vp, vp, vp])
+    sig["subgacc_ppr_encode"] = (C.c_int, [vp, i64, vp, vp, vp])
     assert set(sig) == set(SYMBOLS)
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
