@@ -224,10 +224,10 @@ int subgacc_sjoin_counts(const int64_t *spg_indptr, const int32_t *spg_indices, 
  *
  * One wavefront works on one root at a time in a private `slab` of 24 << table_log2 bytes (hash table of p, r
  * and the work list).  num_waves slabs = num_waves resident wavefronts; reset the slabs once, the kernel hands
- * them back clean.  A root that touches more than (1 << table_log2) / 2 nodes (bounded by 1/(alpha*epsilon))
+ * them back clean (table_log2 in [10, 26]).  A root that touches more than (1 << table_log2) / 2 nodes (bounded by 1/(alpha*epsilon))
  * gets out_count = -1 and flags[2] |= 1: run those roots again with a larger table.
  *   out_count [n] int32, out_ids [n*topk] int32 ascending ids of row i at i*topk, out_vals [n*topk] float32
- *   pushes (optional, device) accumulates the number of pushes.  topk <= 4096.
+ *   pushes (optional, device uint64[2]) accumulates the number of pushes and of touched nodes.  topk <= 4096.
  * ------------------------------------------------------------------------------------------- */
 size_t subgacc_ppr_slab_bytes(int32_t table_log2, int32_t num_waves);
 int subgacc_ppr_slab_reset(void *slab, int32_t table_log2, int32_t num_waves, void *stream);

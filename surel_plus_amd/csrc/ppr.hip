@@ -13,15 +13,14 @@
 // State of one root (dicts p, r and list q of the reference) lives in a per-wave slab of HBM sized for the
 // worst case of the approximation (<= 1/(alpha*eps) touched nodes; 288 GB make 8192 x MBs affordable) -- open
 // addressing, cleaned by the list of touched slots, so a slab is cleared once per launch, not once per root.
-// All slab accesses are device-scope atomics (they bypass the per-CU vector L1: lanes of the wave hand values to
-// each other through L2 between instructions).
+// All slab accesses are workgroup-scope atomics: lanes of the wave hand values to each other through the XCD's L2.
 #include "common.hpp"
 
 namespace subgacc {
 
 constexpr int kPprThreads = 64;                 // one wavefront per workgroup, one root per wavefront at a time
-constexpr uint32_t kInQueue = 0x80000000u;      // meta: bit 31 = on the work list; low bits = 1-based order of entry into p
-constexpr uint32_t kOrdMask = 0x7FFFFFFFu;
+constexpr int kPprUnroll = 4;                   // neighbours per lane and trip of the push loop
+constexpr uint32_t kInQueue = 0x80000000u;      // sign bit of the residual word: the node is on the work list
 
 struct PprArgs {
     const void *indptr;
@@ -39,10 +38,14 @@ struct PprArgs {
     unsigned long long *pushes;
 };
 
+// Slab accesses: WORKGROUP-scope atomic loads / stores (no read-modify-writes).  A slab belongs to one single-wave
+// workgroup for the whole launch, so its lines live in that XCD's L2; workgroup scope keeps the accesses there
+// (device scope sends them past the per-XCD L2s to the fabric: 87 % L2 misses, measured).
+constexpr auto kScope = __HIP_MEMORY_SCOPE_WORKGROUP;
 template <typename T>
-__device__ __forceinline__ T ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ T ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, kScope); }
 template <typename T>
-__device__ __forceinline__ void st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, kScope); }
 
 template <bool IDX64>
 __device__ __forceinline__ int64_t row_of(const void *indptr, int32_t node, int64_t &beg) {
@@ -57,6 +60,13 @@ __device__ __forceinline__ int64_t row_of(const void *indptr, int32_t node, int6
     return (int64_t)(e - b);
 }
 
+// One node of the dicts p / r of the reference = one slot of two parallel planes:
+//   kr[slot]  low: node id (0xFFFFFFFF = free); high: residual r (float bits, r >= 0) | kInQueue   -- the hot plane
+//   pm[slot]  low: score p (float bits); high: 1-based order of entry into p, 0 = never popped     -- touched by pops only
+constexpr unsigned long long kFreeSlot = 0x00000000FFFFFFFFull;
+
+__device__ __forceinline__ unsigned long long pack2(uint32_t lo, uint32_t hi) { return ((unsigned long long)hi << 32) | lo; }
+
 template <bool IDX64>
 __global__ __launch_bounds__(kPprThreads) void ppr_push_kernel(const PprArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -67,83 +77,138 @@ __global__ __launch_bounds__(kPprThreads) void ppr_push_kernel(const PprArgs a) 
     const int lane = threadIdx.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const uint32_t mask = (uint32_t)a.cap - 1u;
-    int32_t *keys = a.slab + (size_t)blockIdx.x * 6u * (size_t)a.cap;
-    float *r = (float *)(keys + a.cap);
-    float *p = r + a.cap;
-    uint32_t *meta = (uint32_t *)(p + a.cap);
-    int32_t *stack = (int32_t *)(meta + a.cap);
-    int32_t *touched = stack + a.cap;
+    unsigned long long *kr = (unsigned long long *)(a.slab + (size_t)blockIdx.x * 6u * (size_t)a.cap);   // [cap]
+    unsigned long long *pm = kr + a.cap;                                              // [cap]
+    int32_t *stack = (int32_t *)(pm + a.cap);                                         // [cap]
+    int32_t *touched = stack + a.cap;                                                 // [cap] grows upwards
+    int32_t *plist = touched + (a.cap - 1);      // slots of the popped nodes in order of entry into p; grows DOWNWARDS
+                                                 // from the end of `touched`; np + ntouched <= cap is part of the
+                                                 // overflow test, so the two lists never meet
     const double one_minus_alpha = 1.0 - (double)a.alpha;     // int64 - float32 -> float64 (numba)
-    unsigned long long my_pushes = 0;
+    unsigned long long my_pushes = 0, my_touched = 0;
 
     for (int64_t i = blockIdx.x; i < a.n; i += gridDim.x) {
         const int32_t inode = a.roots[i];
         int32_t ntouched = 1, np = 1, ns = 1;
+        unsigned long long root_pushes = 0;
         bool overflow = false;
         if (lane == 0) {      // p = {inode: 0}; r[inode] = alpha; q = [inode]   (pprgo.py:13-16); the slab is clean
             const int32_t s0 = (int32_t)(((uint32_t)inode * 2654435761u) >> a.hshift);
-            st(&keys[s0], inode);
-            st(&r[s0], a.alpha);
-            st(&meta[s0], 1u | kInQueue);
+            st(&kr[s0], pack2((uint32_t)inode, __float_as_uint(a.alpha) | kInQueue));
+            st(&pm[s0], pack2(0u, 1u));
             st(&touched[0], s0);
+            st(&plist[0], s0);
             st(&stack[0], s0);
         }
         __syncthreads();
         while (ns > 0) {
+            if (np + 1 + ntouched > a.cap) {   // `plist` would run into `touched` (pops of sink nodes add no trip test)
+                overflow = true;
+                break;
+            }
             --ns;
             const int32_t su = ld(&stack[ns]);                 // q.pop()  (:18)
-            const int32_t unode = ld(&keys[su]);
-            const float res = ld(&r[su]);                      // :20
-            const uint32_t mu = ld(&meta[su]);
-            const bool first = (mu & kOrdMask) == 0u;
+            const unsigned long long ekr = ld(&kr[su]);
+            const unsigned long long epm = ld(&pm[su]);
+            const int32_t unode = (int32_t)(uint32_t)ekr;
+            const float res = __uint_as_float((uint32_t)(ekr >> 32) & ~kInQueue);   // :20
+            const uint32_t mu = (uint32_t)(epm >> 32);
+            const bool first = mu == 0u;
             if (first) ++np;
-            __syncthreads();
-            if (lane == 0) {
-                st(&p[su], ld(&p[su]) + res);                  // :21-24
-                st(&r[su], 0.0f);                              // :25
-                st(&meta[su], first ? (uint32_t)np : (mu & kOrdMask));
-                ++my_pushes;
-            }
             int64_t b;
             const int64_t d = row_of<IDX64>(a.indptr, unode, b);
+            if (lane == 0) {   // p[unode] += res (:21-24); r[unode] = 0 (:25); off the work list
+                st(&kr[su], pack2((uint32_t)unode, 0u));
+                st(&pm[su], pack2(__float_as_uint(__uint_as_float((uint32_t)epm) + res), first ? (uint32_t)np : mu));
+                if (first) st(&plist[-(np - 1)], su);
+                ++root_pushes;
+            }
             const float val = d > 0 ? (float)(one_minus_alpha * (double)res / (double)d) : 0.0f;   // :27
             __syncthreads();
-            for (int64_t base = 0; base < d; base += kPprThreads) {
-                const int64_t j = base + lane;
-                const bool act = j < d;
-                bool isnew = false, pass = false;
-                uint32_t h = 0;
-                if (act) {
-                    const int32_t v = a.indices[b + j];
-                    h = ((uint32_t)v * 2654435761u) >> a.hshift;
-                    while (true) {
-                        const int32_t old = atomicCAS(&keys[h], -1, v);
-                        if (old == -1) {
-                            isnew = true;
-                            break;
-                        }
-                        if (old == v) break;
-                        h = (h + 1u) & mask;
-                    }
-                    const float rv = unsafeAtomicAdd(&r[h], val) + val;   // global_atomic_add_f32 at L2, returns the old value                               // :28-31
-                    int64_t bv;
-                    const int64_t dv = row_of<IDX64>(a.indptr, v, bv);
-                    if ((double)rv >= (double)a.alpha_eps * (double)dv)                         // :33-34
-                        pass = (atomicOr(&meta[h], kInQueue) & kInQueue) == 0u;                 // :35 `not in q`
+            // kPprUnroll x 64 neighbours per trip, their loads in flight together.  No read-modify-write atomics: on
+            // this part every global atomic is executed at the memory side of the fabric, not in the XCD's L2 (measured:
+            // TCC_EA0_ATOMIC == TCC_ATOMIC), and that rate bounded the kernel.  The lanes hold DISTINCT nodes (simple
+            // graph), so an entry has one writer per trip; a free slot is claimed by storing the finished entry and
+            // reading it back after the wave's stores have landed -- of several claimants the last store wins, the
+            // others probe on.
+            for (int64_t base = 0; base < d; base += kPprUnroll * kPprThreads) {
+                bool act[kPprUnroll], isnew[kPprUnroll], pass[kPprUnroll], open[kPprUnroll], claim[kPprUnroll];
+                int32_t v[kPprUnroll];
+                int64_t dv[kPprUnroll];
+                uint32_t h[kPprUnroll];
+                unsigned long long e[kPprUnroll];
+#pragma unroll
+                for (int u = 0; u < kPprUnroll; ++u) {
+                    const int64_t j = base + u * kPprThreads + lane;
+                    act[u] = j < d;
+                    v[u] = act[u] ? a.indices[b + j] : 0;
                 }
-                const unsigned long long newm = __ballot(isnew), passm = __ballot(pass);
-                if (isnew) st(&touched[ntouched + __popcll(newm & lt)], (int32_t)h);
-                if (pass) st(&stack[ns + __popcll(passm & lt)], (int32_t)h);                    // :36 q.append
-                ntouched += __popcll(newm);
-                ns += __popcll(passm);
+#pragma unroll
+                for (int u = 0; u < kPprUnroll; ++u) {
+                    int64_t bv;
+                    dv[u] = act[u] ? row_of<IDX64>(a.indptr, v[u], bv) : 0;
+                    h[u] = ((uint32_t)v[u] * 2654435761u) >> a.hshift;
+                    e[u] = act[u] ? ld(&kr[h[u]]) : 0ull;
+                    open[u] = act[u];
+                    isnew[u] = pass[u] = false;
+                }
+                bool any_open = true;
+                while (any_open) {
+                    // (1) settle what the loaded entry allows: found -> update in place; free -> claim; else probe on
+#pragma unroll
+                    for (int u = 0; u < kPprUnroll; ++u) {
+                        claim[u] = false;
+                        if (!open[u]) continue;
+                        const int32_t k = (int32_t)(uint32_t)e[u];
+                        if (k != v[u] && k != -1) continue;
+                        const uint32_t rq = k == v[u] ? (uint32_t)(e[u] >> 32) : 0u;
+                        const float rv = __uint_as_float(rq & ~kInQueue) + val;                      // :28-31
+                        const bool inq = (rq & kInQueue) != 0u;
+                        pass[u] = !inq && (double)rv >= (double)a.alpha_eps * (double)dv[u];     // :33-35
+                        st(&kr[h[u]], pack2((uint32_t)v[u], __float_as_uint(rv) | ((inq || pass[u]) ? kInQueue : 0u)));
+                        if (k == v[u]) open[u] = false;
+                        else claim[u] = true;
+                    }
+                    __syncthreads();
+                    // (2) claimants read back; the others step to the next slot
+                    any_open = false;
+#pragma unroll
+                    for (int u = 0; u < kPprUnroll; ++u) {
+                        if (!open[u]) continue;
+                        if (!claim[u]) h[u] = (h[u] + 1u) & mask;
+                        e[u] = ld(&kr[h[u]]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < kPprUnroll; ++u) {
+                        if (!open[u]) continue;
+                        if (claim[u] && (int32_t)(uint32_t)e[u] == v[u]) {
+                            open[u] = false;
+                            isnew[u] = true;
+                        } else {
+                            pass[u] = false;     // lost the slot (or still probing): e[u] holds what to look at next
+                            any_open = true;
+                        }
+                    }
+                    any_open = __any(any_open);
+                }
+#pragma unroll
+                for (int u = 0; u < kPprUnroll; ++u) {
+                    const unsigned long long newm = __ballot(isnew[u]), passm = __ballot(pass[u]);
+                    if (isnew[u]) st(&touched[ntouched + __popcll(newm & lt)], (int32_t)h[u]);
+                    if (pass[u]) st(&stack[ns + __popcll(passm & lt)], (int32_t)h[u]);          // :36 q.append
+                    ntouched += __popcll(newm);
+                    ns += __popcll(passm);
+                }
                 __syncthreads();
-                if ((int64_t)ntouched * 2 > (int64_t)a.cap) {   // keep the table at most half full (+64 of slack)
+                if (((int64_t)ntouched + kPprUnroll * kPprThreads) * 4 > 3 * (int64_t)a.cap ||
+                    np + 1 + ntouched + kPprUnroll * kPprThreads > a.cap) {   // the next trip / pop could pass 3/4 of the table
                     overflow = true;
                     ns = 0;
                     break;
                 }
             }
         }
+        if (!overflow) my_pushes += root_pushes, my_touched += (unsigned long long)ntouched;   // abandoned attempts do not count
 
         // ---- top-k of p by (value, order of entry) -- np.argsort(val)[-topk:] (:59-61), ties keep the later entry
         int32_t nsel = np < a.topk ? np : a.topk;
@@ -161,12 +226,13 @@ __global__ __launch_bounds__(kPprThreads) void ppr_push_kernel(const PprArgs a) 
                 for (int shift = 56; shift >= 0; shift -= 8) {
                     for (int x = lane; x < 256; x += kPprThreads) hist[x] = 0u;
                     __syncthreads();
-                    for (int x = lane; x < ntouched; x += kPprThreads) {
-                        const int32_t s = ld(&touched[x]);
-                        const uint32_t m = ld(&meta[s]) & kOrdMask;
-                        if (m) {
-                            const unsigned long long key = ((unsigned long long)__float_as_uint(ld(&p[s])) << 32) | m;
-                            if (shift == 56 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+                    for (int x = lane; x < np; x += kPprThreads) {
+                        const int32_t s = ld(&plist[-x]);
+                        const unsigned long long epm = ld(&pm[s]);   // (score bits, order)
+                        const uint32_t m = (uint32_t)(epm >> 32);
+                        if (m) {   // key64 = (score bits << 32) | order of entry
+                            const unsigned long long k64 = (epm << 32) | m;
+                            if (shift == 56 || (k64 >> (shift + 8)) == prefix) atomicAdd(&hist[(k64 >> shift) & 255u], 1u);
                         }
                     }
                     __syncthreads();
@@ -180,8 +246,7 @@ __global__ __launch_bounds__(kPprThreads) void ppr_push_kernel(const PprArgs a) 
                     }
                     const unsigned long long ge = __ballot(suf >= kk);
                     const int L = 63 - __clzll(ge);            // highest lane whose suffix still holds kk keys
-                    uint32_t above = __shfl(suf, L, kPprThreads) - (__shfl(c0, L, kPprThreads) + __shfl(c1, L, kPprThreads) +
-                                                                    __shfl(c2, L, kPprThreads) + __shfl(c3, L, kPprThreads));
+                    uint32_t above = __shfl(suf, L, kPprThreads) - __shfl(c0 + c1 + c2 + c3, L, kPprThreads);
                     int digit = 4 * L;
                     for (int dd = 3; dd >= 0; --dd) {
                         const uint32_t c = hist[4 * L + dd];
@@ -198,23 +263,24 @@ __global__ __launch_bounds__(kPprThreads) void ppr_push_kernel(const PprArgs a) 
                 thr = prefix;
             }
             int32_t base = 0;
-            for (int x0 = 0; x0 < ntouched; x0 += kPprThreads) {
+            for (int x0 = 0; x0 < np; x0 += kPprThreads) {
                 const int x = x0 + lane;
                 bool sel = false;
                 int32_t s = 0;
                 float pv = 0.f;
-                if (x < ntouched) {
-                    s = ld(&touched[x]);
-                    const uint32_t m = ld(&meta[s]) & kOrdMask;
+                if (x < np) {
+                    s = ld(&plist[-x]);
+                    const unsigned long long epm = ld(&pm[s]);
+                    const uint32_t m = (uint32_t)(epm >> 32);
                     if (m) {
-                        pv = ld(&p[s]);
-                        sel = (((unsigned long long)__float_as_uint(pv) << 32) | m) >= thr;
+                        pv = __uint_as_float((uint32_t)epm);
+                        sel = ((epm << 32) | m) >= thr;
                     }
                 }
                 const unsigned long long sm = __ballot(sel);
                 if (sel) {
                     const int32_t pos = base + __popcll(sm & lt);
-                    sel_id[pos] = ld(&keys[s]);
+                    sel_id[pos] = (int32_t)(uint32_t)ld(&kr[s]);
                     sel_val[pos] = pv;
                 }
                 base += __popcll(sm);
@@ -233,14 +299,24 @@ __global__ __launch_bounds__(kPprThreads) void ppr_push_kernel(const PprArgs a) 
         // ---- hand the slab back clean
         for (int x = lane; x < ntouched; x += kPprThreads) {
             const int32_t s = ld(&touched[x]);
-            st(&keys[s], -1);
-            st(&r[s], 0.0f);
-            st(&p[s], 0.0f);
-            st(&meta[s], 0u);
+            st(&kr[s], kFreeSlot);
+            st(&pm[s], 0ull);
         }
         __syncthreads();
     }
-    if (a.pushes && lane == 0 && my_pushes) atomicAdd(a.pushes, my_pushes);
+    if (a.pushes && lane == 0 && my_touched) {
+        atomicAdd(&a.pushes[0], my_pushes);
+        atomicAdd(&a.pushes[1], my_touched);
+    }
+}
+
+__global__ __launch_bounds__(256) void ppr_slab_reset_kernel(unsigned long long *slab, int64_t cap, int64_t waves) {
+    // the two entry planes at the head of every 24*cap-byte slab: kr = free, pm = 0
+    const int64_t total = 2 * cap * waves;
+    for (int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x; x < total; x += (int64_t)gridDim.x * 256) {
+        const int64_t w = x / (2 * cap), e = x - w * 2 * cap;
+        slab[w * 3 * cap + e] = e < cap ? kFreeSlot : 0ull;
+    }
 }
 
 // pprgo.py:88-108 + optional row_of_entry search: one thread per entry, row found by binary search in row_off
@@ -287,16 +363,18 @@ __global__ __launch_bounds__(256) void ppr_encode_kernel(double *data, const int
 using namespace subgacc;
 
 extern "C" size_t subgacc_ppr_slab_bytes(int32_t table_log2, int32_t num_waves) {
-    if (table_log2 < 7 || table_log2 > 26 || num_waves < 1) return 0;
+    if (table_log2 < 10 || table_log2 > 26 || num_waves < 1) return 0;   // half of the table + 256 entries of slack must fit
     return (size_t)num_waves * 6u * sizeof(int32_t) * ((size_t)1 << table_log2);
 }
 
 extern "C" int subgacc_ppr_slab_reset(void *slab, int32_t table_log2, int32_t num_waves, void *stream) {
     SG_REQUIRE(slab && subgacc_ppr_slab_bytes(table_log2, num_waves) > 0, SUBGACC_ERR_BADARG, "ppr_slab_reset: bad arguments");
-    const size_t cap = (size_t)1 << table_log2;
-    // keys = -1, everything else 0; one 2-D memset per plane keeps this a pair of plain fills
-    SG_CHECK_HIP(hipMemsetAsync(slab, 0, subgacc_ppr_slab_bytes(table_log2, num_waves), (hipStream_t)stream));
-    SG_CHECK_HIP(hipMemset2DAsync(slab, 6 * cap * 4, 0xFF, cap * 4, (size_t)num_waves, (hipStream_t)stream));
+    const int64_t cap = (int64_t)1 << table_log2;
+    int64_t blocks = ceil_div(2 * cap * num_waves, 256);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(ppr_slab_reset_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (unsigned long long *)slab, cap,
+                       (int64_t)num_waves);
+    SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }
 
@@ -306,7 +384,7 @@ extern "C" int subgacc_ppr_topk(const void *indptr, int32_t indptr64, const int3
                                 float *out_vals, int32_t *flags, uint64_t *pushes, void *stream) {
     SG_REQUIRE(indptr && out_count && out_ids && out_vals && flags && slab, SUBGACC_ERR_BADARG, "ppr_topk: null argument");
     SG_REQUIRE(n >= 0 && num_nodes >= 0 && topk >= 1 && topk <= 4096, SUBGACC_ERR_BADARG, "ppr_topk: topk must be in [1, 4096]");
-    SG_REQUIRE(subgacc_ppr_slab_bytes(table_log2, num_waves) > 0, SUBGACC_ERR_BADARG, "ppr_topk: table_log2 in [7, 26], num_waves >= 1");
+    SG_REQUIRE(subgacc_ppr_slab_bytes(table_log2, num_waves) > 0, SUBGACC_ERR_BADARG, "ppr_topk: table_log2 in [10, 26], num_waves >= 1");
     SG_REQUIRE(alpha > 0.f && alpha <= 1.f && epsilon > 0.f, SUBGACC_ERR_BADARG, "ppr_topk: alpha in (0,1], epsilon > 0");
     if (n == 0) return SUBGACC_OK;
     SG_REQUIRE(roots, SUBGACC_ERR_BADARG, "ppr_topk: null roots");

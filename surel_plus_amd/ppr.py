@@ -16,7 +16,9 @@ from .spg import SpG
 
 _MODES = {"row": 0, "sym": 1, "col": 2}
 SLAB_BUDGET = 8 << 30        # bytes of HBM given to the per-wavefront tables of one launch
-MAX_WAVES = 8192             # 256 CUs x 32 resident single-wave workgroups
+MAX_WAVES = 4096             # resident single-wave workgroups; the kernel saturates the memory system from ~4096 on
+PILOT_ROOTS = 2048           # roots sampled to size the per-wavefront tables
+LAST_STATS = None            # counters of the last ppr_topk call (dev / profiling)
 
 
 def _as_csr(adj, device):
@@ -35,7 +37,26 @@ def _launch(csr, roots, alpha, eps, topk, table_log2, waves, cnt, ids, vals, fla
     with _timed("ppr_push"):
         check(lib().subgacc_ppr_topk(ptr(csr.indptr), int(csr.indptr64), ptr(csr.indices), csr.num_nodes, ptr(roots), n,
                                      float(alpha), float(eps), int(topk), ptr(slab), table_log2, waves, ptr(cnt), ptr(ids),
-                                     ptr(vals), ptr(flags), ptr(pushes), stream_ptr()))
+                                     ptr(vals), ptr(flags), ptr(pushes) if pushes is not None else None, stream_ptr()))
+
+
+def _pilot_table_log2(csr, roots, alpha, epsilon, topk, log2_max):
+    """smallest table (log2 slots) that holds >= 97 % of a sample of the roots"""
+    n = roots.numel()
+    m = min(n, PILOT_ROOTS)
+    if m == 0:
+        return 10
+    sample = roots[:: max(1, n // m)][:m].contiguous()
+    dev = roots.device
+    cnt = torch.zeros(m, dtype=torch.int32, device=dev)
+    ids = torch.empty(m * topk, dtype=torch.int32, device=dev)
+    vals = torch.empty(m * topk, dtype=torch.float32, device=dev)
+    flags = torch.zeros(4, dtype=torch.int32, device=dev)
+    for log2 in range(10, log2_max):
+        _launch(csr, sample, alpha, epsilon, topk, log2, MAX_WAVES, cnt, ids, vals, flags, None)
+        if int((cnt >= 0).sum()) >= 0.97 * m:
+            return log2
+    return log2_max
 
 
 def ppr_topk(adj, alpha, epsilon, nodes, topk, table_log2=None, device=None):
@@ -52,18 +73,22 @@ def ppr_topk(adj, alpha, epsilon, nodes, topk, table_log2=None, device=None):
     ids = torch.empty(n * topk, dtype=torch.int32, device=device)
     vals = torch.empty(n * topk, dtype=torch.float32, device=device)
     flags = torch.zeros(4, dtype=torch.int32, device=device)
-    pushes = torch.zeros(1, dtype=torch.int64, device=device)
+    pushes = torch.zeros(2, dtype=torch.int64, device=device)      # pushes, touched nodes
     # a push of u moves >= alpha*eps*deg(u) into p and sum(p) <= 1: at most 1/(alpha*eps) nodes are ever touched.
-    # Most roots need far less, so start small (more wavefronts fit the slab budget) and re-run the few that overflow.
-    worst = int(math.ceil(1.0 / (float(alpha) * float(epsilon)))) + 128
-    log2_max = min(26, max(7, int(math.ceil(math.log2(2 * worst)))))
-    log2 = min(log2_max, 14 if table_log2 is None else max(7, int(table_log2)))
+    # Most roots need far less and dense tables are faster (more of them stay in L2), so a pilot over a sample of
+    # the roots picks the smallest table that holds ~all of them; the few roots that overflow are run again, larger.
+    worst = int(math.ceil(1.0 / (float(alpha) * float(epsilon)))) + 512
+    log2_max = min(26, max(10, int(math.ceil(math.log2(2 * worst)))))
+    if table_log2 is None:
+        log2 = _pilot_table_log2(csr, roots, alpha, epsilon, topk, log2_max)
+    else:
+        log2 = min(log2_max, max(10, int(table_log2)))
     todo, dst = roots, None
     while n:
         waves = int(min(MAX_WAVES, max(64, SLAB_BUDGET // (24 << log2))))
         if dst is None:
             _launch(csr, todo, alpha, epsilon, topk, log2, waves, cnt, ids, vals, flags, pushes)
-        else:   # second round: the overflowed roots only, scattered back into their rows
+        else:   # later rounds: the overflowed roots only, scattered back into their rows
             c2 = torch.zeros(todo.numel(), dtype=torch.int32, device=device)
             i2 = torch.empty(todo.numel() * topk, dtype=torch.int32, device=device)
             v2 = torch.empty(todo.numel() * topk, dtype=torch.float32, device=device)
@@ -76,7 +101,7 @@ def ppr_topk(adj, alpha, epsilon, nodes, topk, table_log2=None, device=None):
             break
         if log2 >= log2_max:
             raise MemoryError("ppr_topk: a root touched more nodes than 1/(alpha*eps) allows -- repeated entries in a CSR row?")
-        log2 = min(log2 + 3, log2_max)
+        log2 = min(log2 + 2, log2_max)
         todo, dst = roots[bad].contiguous(), bad
         flags.zero_()
     # strided rows -> packed rows (the copy kernel of the fused walk form; the float32 payload travels as its bits)
@@ -89,7 +114,10 @@ def ppr_topk(adj, alpha, epsilon, nodes, topk, table_log2=None, device=None):
     if X:
         check(lib().subgacc_compact_rows(ptr(ids), ptr(vals.view(torch.int32)), ptr(cnt), ptr(row_off), n, int(topk),
                                          ptr(out_ids), ptr(out_vals.view(torch.int32)), None, 0, stream_ptr()))
-    return row_off, out_ids, out_vals, int(pushes.item())
+    global LAST_STATS
+    st = pushes.tolist()
+    LAST_STATS = {"pushes": st[0], "touched": st[1], "roots": n}
+    return row_off, out_ids, out_vals, st[0]
 
 
 def topk_ppr_matrix(adj_matrix, alpha, eps, idx, topk, normalization="row", device=None, encode=False):

@@ -86,12 +86,12 @@ def test_ppr_int64_offsets_duplicate_and_shuffled_roots(ppr):
 
 
 def test_ppr_small_tables_are_retried(ppr):
-    """table_log2 = 7 holds 64 nodes: nearly every root overflows and is re-run with larger tables."""
+    """table_log2 = 10 holds 512 nodes: most roots overflow and are re-run with larger tables."""
     from surel_plus_amd import DeviceCSR
     indptr, indices = _graph("hubs")
     roots = np.arange(len(indptr) - 1, dtype=np.int32)
     want = orc.ppr_topk(indptr, indices, roots, 0.3, 1e-4, 50, table_log2=18)
-    got = ppr.ppr_topk(DeviceCSR(indptr, indices), 0.3, 1e-4, roots, 50, table_log2=7)
+    got = ppr.ppr_topk(DeviceCSR(indptr, indices), 0.3, 1e-4, roots, 50, table_log2=10)
     _check_rows(got, want)
 
 
