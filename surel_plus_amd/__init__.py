@@ -4,9 +4,11 @@ Host mirror of the reference's interfaces over a C-ABI HIP library (include/subg
     subg_acc.gset_sampler / walk_sampler   <- subg_acc/subg_acc.c (CPython module `subg_acc`)
     spg.subg_matrix, spg.SpG               <- sampler/random_walks.py:74-82
     spjoin.gather / pgather / bgather / hgather  <- train.py:13-111
+    ppr.topk_ppr_matrix, ppr.encoding      <- sampler/pprgo.py:85-111, utils.py:35-36 (float64 SpG for the PPR encoder)
 """
 from ._lib import SubgAccError, build  # noqa: F401
 from .sampler import DeviceCSR, SampledSets, sample_sets  # noqa: F401
 from .spg import SpG, sample_spg, subg_matrix  # noqa: F401
 from .spjoin import bgather, gather, gather_counts, hgather, mean_stage, pgather, sjoin  # noqa: F401
 from .subg_acc import gset_sampler, walk_sampler  # noqa: F401
+from .ppr import topk_ppr_matrix  # noqa: F401
