@@ -45,6 +45,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # SUBGACC_FUSED: 1 = the walk kernel also emits finished SpG rows (walk_spg), 0 = general pipeline, unset = the
 # library's choice (fused for walks of >= 3 hops)
 FUSED = {"1": True, "0": False}.get(os.environ.get("SUBGACC_FUSED", ""), None)
+NSTREAMS = int(os.environ.get("SUBGACC_STREAMS", "1"))   # >1: consecutive steps go to different HIP streams
 LAZY = os.environ.get("SUBGACC_LAZY", "1") == "1"     # sizes stay on the device: one host round trip per step
 
 
@@ -92,21 +93,31 @@ class KernelTimer:
 _XZ_BUF = {}
 
 
-def hot_path_step(sp, csr, edge, M, k, seed, rng):
-    """sample both endpoints of every pair, build the SpG, join.  Returns (xz, indptr, sets)."""
+def hot_path_step(sp, csr, edge, M, k, seed, rng, slot=0):
+    """Queue one pass of the hot path: sample both endpoints of every pair, build the SpG, join.  Nothing here waits
+    for the GPU when LAZY (every size stays on the device); finish_step() reads the sizes / status back.
+    Returns (xz buffer view, indptr, sets)."""
     B = edge.shape[1]
     roots = edge.reshape(-1).to(torch.int32)
     z, sets = sp.sample_spg(csr, roots, num_walks=M, num_steps=k - 1, seed=seed, rng=rng, fused=FUSED, lazy=LAZY)
     table = sets.feature_table()
     rows = torch.arange(2 * B, device=edge.device, dtype=torch.int64).view(2, B)   # row i = root i of this batch
-    # the join output is written into one re-used buffer sized for the worst case (every set full): a serving loop
-    # would do the same, and it keeps GB-sized device allocations -- tens of ms on some hosts -- out of the steps
+    # the join output is written into re-used buffers sized for the worst case (every set full), two of them in
+    # turn so that step s+1 never overwrites what step s handed out: a serving loop would do the same, and it keeps
+    # GB-sized device allocations -- tens of ms on some hosts -- out of the steps
     cap = 2 * B * z.max_len * 2 * k
-    buf = _XZ_BUF.get((edge.device, cap))
+    buf = _XZ_BUF.get((edge.device, cap, slot))
     if buf is None:
-        buf = _XZ_BUF[(edge.device, cap)] = torch.empty(cap, dtype=torch.float32, device=edge.device)
-    xz, ind = sp.gather(rows, z, edge.device, ptr=True, encode=table, out=buf)
-    sets.resolve()      # sizes, status flags and the distinct-row count: read once, after everything is queued
+        buf = _XZ_BUF[(edge.device, cap, slot)] = torch.empty(cap, dtype=torch.float32, device=edge.device)
+    xz, ind = sp.gather(rows, z, edge.device, ptr=True, encode=table, out=buf, lazy=LAZY)
+    return xz, ind, sets
+
+
+def finish_step(xz, ind, sets):
+    """sizes, status flags and the distinct-row count of a queued step: two small reads, errors raised here"""
+    sets.resolve()
+    if LAZY:
+        xz = xz[: int(ind[-1].item())]
     return xz, ind, sets
 
 
@@ -280,7 +291,7 @@ def main():
         # results are kept alive exactly like in the timed loop, so torch's caching allocator reaches its steady state
         # (two generations of buffers) here: a fresh GB-sized hipMalloc inside the timed region costs ~10 ms on some
         # hosts of the pool (seen as one 11-19 ms step with unchanged kernel times) and is not part of the path.
-        xz, ind, sets = hot_path_step(sp, csr, edges[s % len(edges)], M, k, seed=s, rng=args.rng)
+        xz, ind, sets = finish_step(*hot_path_step(sp, csr, edges[s % len(edges)], M, k, seed=s, rng=args.rng, slot=s & 1))
         last = (edges[s % len(edges)], sets, xz)
     torch.cuda.synchronize()
     if dist is not None:
@@ -290,10 +301,21 @@ def main():
     allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
     t0 = time.perf_counter()
     step_marks = [t0]
+    pending = None
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(NSTREAMS - 1)]
     for s in range(W, W + K):
-        xz, ind, sets = hot_path_step(sp, csr, edges[s], M, k, seed=s, rng=args.rng)
-        last = (edges[s], sets, xz)
-        step_marks.append(time.perf_counter())     # host clock only: a step ends with its one size read-back
+        # double-buffered serving loop: step s is queued before the sizes of step s-1 are read back, so the GPU never
+        # waits for the host; every step is complete (kernels done, sizes on the host) before the clock stops
+        with torch.cuda.stream(streams[s % len(streams)]):
+            queued = hot_path_step(sp, csr, edges[s], M, k, seed=s, rng=args.rng, slot=s & 1)
+        if pending is not None:
+            xz, ind, sets = finish_step(*pending[1])
+            last = (pending[0], sets, xz)
+        pending = (edges[s], queued)
+        step_marks.append(time.perf_counter())
+    if pending is not None:
+        xz, ind, sets = finish_step(*pending[1])
+        last = (pending[0], sets, xz)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

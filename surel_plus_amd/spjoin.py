@@ -42,13 +42,15 @@ def _as_rows(edge, device):
     return torch.from_numpy(np.ascontiguousarray(np.asarray(edge)).astype(np.int64)).to(device)
 
 
-def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pair_block=0, out=None):
+def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pair_block=0, out=None, lazy=False):
     """Generic segment join (include/subgacc.h: subgacc_sjoin_sizes + subgacc_sjoin_fill).
 
     own/partner: int64 device tensors of SpG row numbers, one segment each.  pair_block = P > 0 promises that
     the list is made of blocks of P segments with block 2t+1 the mirror of block 2t (see include/subgacc.h).
     out: optional preallocated float32 buffer with room for the R output rows (a steady-state caller re-uses one
     buffer instead of asking the allocator for a fresh GB-sized block per batch); the result is a view of it.
+    lazy=True (needs out=, segment pointers, an integer SpG): no host round trip at all -- the number of rows R stays
+    on the device as ind[-1] and xz is the whole buffer viewed as [capacity, 2, k], of which the first R rows are valid.
     Returns (xz, ind): xz float32 [R,2,k] (or int32 [R,2] index pairs when return_index), ind = int64 [S+1]
     segment pointers (ptr_mode) or int64 [R] segment ids.
     """
@@ -60,8 +62,10 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
     seg = torch.empty(S + 1, dtype=torch.int64, device=dev)
     ws = torch.empty(L.subgacc_sjoin_workspace_bytes(S), dtype=torch.uint8, device=dev)
     check(L.subgacc_sjoin_sizes(ptr(spg.indptr), ptr(own), S, ptr(seg), ptr(ws), ws.numel(), st))
-    R = int(seg[S].item())                  # the one host round trip: the output size
     is_f64 = spg.data.dtype == torch.float64
+    if lazy and (out is None or not ptr_mode or return_index or is_f64 or encode is None):
+        raise ValueError("lazy=True needs out=, ptr=True and an integer SpG with its encode table")
+    R = None if lazy else int(seg[S].item())     # the one host round trip: the output size
     flags = torch.zeros(4, dtype=torch.int32, device=dev)
     segid = None if ptr_mode else torch.empty(R, dtype=torch.int64, device=dev)
     if is_f64:
@@ -82,7 +86,13 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
         k = enc.shape[1]
         if enc.shape[0] <= spg.max_data:       # host-side bound check: no device round trip on the hot path
             raise IndexError(f"index {spg.max_data} is out of bounds for the encode table with {enc.shape[0]} rows")
-        if out is not None:
+        if lazy:      # worst case: every segment as long as the longest SpG row
+            if out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev or \
+                    out.numel() < S * spg.max_len * 2 * k:
+                raise ValueError("lazy out= must hold S * SpG.max_len * 2 * k float32 on the SpG's device")
+            rows = out.numel() // (2 * k)
+            out = out.view(-1)[: rows * 2 * k].view(rows, 2, k)
+        elif out is not None:
             if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() < R * 2 * k or out.device != dev:
                 raise ValueError("out= must be a contiguous float32 buffer on the SpG's device with >= R*2*k elements")
             out = out.view(-1)[: R * 2 * k].view(R, 2, k)
@@ -110,13 +120,14 @@ def _checked(out, ind, flags):
     return out, ind
 
 
-def gather(edge, x, device=None, ptr=True, encode=None, out=None):
-    """train.py:13-45.  Left blocks (S_u with S_v looked up) then right blocks, per pair in batch order."""
+def gather(edge, x, device=None, ptr=True, encode=None, out=None, lazy=False):
+    """train.py:13-45.  Left blocks (S_u with S_v looked up) then right blocks, per pair in batch order.
+    out= / lazy=: see sjoin (a serving loop's forms: caller-owned output buffer, no host round trip)."""
     spg = _as_spg(x)
     e = _as_rows(edge, spg.device)
     own = torch.cat([e[0], e[1]])
     partner = torch.cat([e[1], e[0]])
-    return _checked(*sjoin(spg, own, partner, encode, ptr_mode=ptr, pair_block=e.shape[1], out=out))
+    return _checked(*sjoin(spg, own, partner, encode, ptr_mode=ptr, pair_block=e.shape[1], out=out, lazy=lazy))
 
 
 def hgather(hedge, x, device=None, encode=None):

@@ -622,3 +622,25 @@ def test_spg_save_and_load(sp, tmp_path):
     a = sp.gather(edge, z, "cuda", ptr=True, encode=table)
     b = sp.gather(edge, z2, "cuda", ptr=True, encode=enc2)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_gather_lazy_rows_match_eager(sp):
+    """gather(out=, lazy=True): no host round trip; the first ind[-1] rows of the buffer are the eager result"""
+    indptr, indices = sym_graph(4000, 16000, 21, hubs=2)
+    csr = sp.DeviceCSR(indptr, indices)
+    roots = torch.arange(0, 512, dtype=torch.int32, device="cuda")
+    z, sets = sp.sample_spg(csr, roots, num_walks=50, num_steps=3, rng="philox", lazy=True)
+    table = sets.feature_table()
+    edge = torch.randint(0, 512, (2, 300), device="cuda")
+    k = table.shape[1]
+    buf = torch.full((2 * 300 * z.max_len * 2 * k,), -7.0, dtype=torch.float32, device="cuda")
+    xz_l, ind_l = sp.gather(edge, z, "cuda", ptr=True, encode=table, out=buf, lazy=True)
+    xz_e, ind_e = sp.gather(edge, z, "cuda", ptr=True, encode=table)
+    assert torch.equal(ind_l, ind_e)
+    R = int(ind_l[-1])
+    assert xz_e.shape[0] == R and torch.equal(xz_l[:R], xz_e)
+    assert bool((xz_l[R:] == -7.0).all())          # nothing written past the valid rows
+    with pytest.raises(ValueError):
+        sp.gather(edge, z, "cuda", ptr=True, encode=table, lazy=True)                       # needs out=
+    with pytest.raises(ValueError):
+        sp.gather(edge, z, "cuda", ptr=True, encode=table, out=buf[:100], lazy=True)        # worst case must fit
