@@ -298,3 +298,53 @@ def ppr_encode(data):
     data = np.array(data, dtype=np.float64, copy=True)
     lib().orc_ppr_encode(_p(data, C.c_double), C.c_int64(len(data)))
     return data
+
+
+# ------------------------------------------------------------------ walk_sampler route to the SpG (random_walks.py:35-71)
+def np_sampling(ptr, neighs, bsize, target, num_walks=200, num_steps=4, nthread=1, seed=111413, sampler=None):
+    """sampler/random_walks.py:35-47.  `sampler` = a walk_sampler with the reference's return shape ([walks, obj]);
+    default: this module's C restatement (pinned to the reference's goldens)."""
+    key, freq = [], []
+    target = np.asarray(target)
+    for lo in range(0, len(target), bsize):                     # gen_batch(target, bsize, keep=True), :25-29
+        batch = target[lo:lo + bsize]
+        if sampler is None:
+            _, nsize, ids, counts = walk_sampler(ptr, neighs, batch, num_walks=num_walks, num_steps=num_steps,
+                                                 nthread=nthread, seed=seed, replacement=True)
+            key.append(ids)
+            freq.append(counts)
+        else:
+            _, freqs = sampler(ptr, neighs, batch, num_walks=num_walks, num_steps=num_steps, nthread=nthread, seed=seed,
+                               replacement=True)
+            key.append(np.concatenate(list(freqs[:, 0])))
+            freq.append(np.vstack(list(freqs[:, 1])))
+    return np.concatenate(key), np.vstack(freq)
+
+
+def rw_matrix(indptr, indices, train_idx, num_walks=200, num_steps=4, batch_size=2000, reduced=True, nthread=1,
+              seed=111413, sampler=None):
+    """sampler/random_walks.py:58-71 with np.unique standing in for fastremap.unique (same contract: sorted distinct
+    values + index of the first occurrence).  Returns (scipy csr z with rows = positions in train_idx, freqs)."""
+    import scipy.sparse as sps
+    gsize = len(indptr) - 1
+    neighbors, freqs = np_sampling(indptr, indices, batch_size, train_idx, num_walks=num_walks, num_steps=num_steps - 1,
+                                   nthread=nthread, seed=seed, sampler=sampler)
+    # sizes of the sets, in order (construct_sparse, :50-55, takes the ragged list; np_sampling above returns it flat)
+    sizes = []
+    for lo in range(0, len(train_idx), batch_size):
+        batch = np.asarray(train_idx)[lo:lo + batch_size]
+        sizes.append(walk_sampler(indptr, indices, batch, num_walks=num_walks, num_steps=num_steps - 1, nthread=nthread,
+                                  seed=seed, replacement=True)[1])
+    sizes = np.concatenate(sizes) if sizes else np.zeros(0, np.int32)
+    if reduced:
+        proj = np.array([(num_walks + 1) ** i for i in reversed(range(num_steps))], dtype=np.int64)
+        idy = freqs.astype(np.int64) @ proj
+        val, idx = np.unique(idy, return_index=True)
+        idy = np.searchsorted(val, idy)
+        freqs = freqs[idx]
+    else:
+        idy = np.arange(len(freqs))
+    i = np.repeat(np.arange(len(sizes)), sizes)
+    z = sps.csr_matrix((idy + 1, (i, neighbors)), shape=(gsize, gsize))
+    freqs = np.insert(freqs, 0, np.zeros((1, num_steps), freqs.dtype), axis=0)
+    return z, freqs

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
-from .sampler import DeviceCSR, _timed, sample_sets
+from .sampler import DeviceCSR, SampledSets, _timed, dedup_lp_rows, sample_sets
 
 
 class SpG:
@@ -139,3 +139,74 @@ def subg_matrix(G, train_idx, num_walks=200, num_steps=4, seed=111413, rng="rand
     enc = np.insert(enc, 0, np.zeros((1, num_steps), dtype=enc.dtype), axis=0)
     z.sets = sets
     return z, enc
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The walk_sampler route to the SpG (sampler/random_walks.py:35-71: np_sampling / rw_matrix) -- SUREL's original
+# offline stage, kept by the reference next to subg_matrix.  Same kernels as above in walk_sampler's form: step-major
+# first-visit order, first hop without replacement, one rand_r stream per OpenMP thread and per BATCH (every call of
+# walk_sampler starts again from seed + thread id, so the result depends on batch size and thread count).
+def _walk_batches(csr, target, bsize, num_walks, hops, nthread, seed, rng):
+    dev = csr.device
+    tgt = torch.as_tensor(target).to(device=dev, dtype=torch.int32).contiguous()
+    parts = []
+    for lo in range(0, tgt.numel(), int(bsize)):          # gen_batch(target, bsize, keep=True), random_walks.py:25-29
+        parts.append(sample_sets(csr, tgt[lo:lo + int(bsize)], num_walks=num_walks, num_steps=hops, seed=seed, rng=rng,
+                                 first_hop_wo=True, order=_lib.ORDER_STEP_MAJOR, cap_root_degree=False,
+                                 rng_streams=max(int(nthread), 1), dedup=False))
+    if not parts:
+        z64 = torch.zeros(0, dtype=torch.int64, device=dev)
+        return SampledSets(nsize=torch.zeros(0, dtype=torch.int32, device=dev), row_off=torch.zeros(1, dtype=torch.int64, device=dev),
+                           ids=torch.zeros(0, dtype=torch.int32, device=dev), keys=z64, sf=None, ukeys=z64,
+                           num_walks=num_walks, num_steps=hops, stride=num_walks * hops + 1)
+    nsize = torch.cat([p.nsize for p in parts])
+    row_off = torch.zeros(nsize.numel() + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(nsize, 0, out=row_off[1:])
+    return SampledSets(nsize=nsize, row_off=row_off, ids=torch.cat([p.ids for p in parts]),
+                       keys=torch.cat([p.keys for p in parts]), sf=None, ukeys=None, num_walks=num_walks,
+                       num_steps=hops, stride=parts[0].stride)
+
+
+def np_sampling(ptr, neighs, bsize, target, num_walks=200, num_steps=4, nthread=1, seed=111413, rng="rand_r"):
+    """Drop-in for sampler/random_walks.py:35-47: (node ids int32[X], landing counts int32[X, num_steps+1]) of the
+    sets of `target`, batch by batch.  `num_steps` = walk hops here, as in the reference's call (:61-62).
+    nthread = the OpenMP team size whose streams are reproduced (the reference takes the machine's default)."""
+    csr = ptr if isinstance(ptr, DeviceCSR) else DeviceCSR(ptr, neighs)
+    sets = _walk_batches(csr, target, bsize, num_walks, num_steps, nthread, seed, rng)
+    if sets.ids.numel() == 0:
+        return np.zeros(0, np.int32), np.zeros((0, num_steps + 1), np.int32)
+    return sets.ids.cpu().numpy(), sets.counts_int32().cpu().numpy()
+
+
+def rw_matrix(G, train_idx, num_walks=200, num_steps=4, batch_size=2000, reduced=True, nthread=1, seed=111413,
+              rng="rand_r", device=None):
+    """Drop-in for sampler/random_walks.py:58-71: (z, freqs).
+
+    z     -- SpG, row i = set of train_idx[i] (the reference assumes train_idx = arange, :51), data = LP row number + 1
+    freqs -- numpy int32 [c+1, num_steps] with the all-zero row 0.
+    reduced=True numbers the distinct LP rows in ASCENDING order of their base-(M+1) projection (:64-68:
+    fastremap.unique sorts) -- not in first-occurrence order as subg_matrix does; the packed 64-bit key orders the
+    rows the same way (step 0 = LEAD bit, then steps 1..m, most significant first)."""
+    csr = G if isinstance(G, DeviceCSR) else DeviceCSR(G.indptr, G.indices, device=device)
+    hops = num_steps - 1
+    sets = _walk_batches(csr, train_idx, batch_size, num_walks, hops, nthread, seed, rng)
+    X = sets.ids.numel()
+    dev = csr.device
+    if hops * check(lib().subgacc_key_shift(num_walks, hops)) >= 63:
+        raise AssertionError("rw_matrix: LP key uses bit 63; its signed order would not be the row order")
+    if reduced and X:
+        sets = dedup_lp_rows(sets)
+        ukeys, order = torch.sort(sets.ukeys)                       # c keys: a few hundred to a few thousand
+        rank = torch.empty_like(order)
+        rank[order] = torch.arange(order.numel(), device=dev)
+        sets.sf = rank.to(torch.int32)[sets.sf.long()]
+        sets.ukeys = ukeys
+        rows = SampledSets(nsize=None, row_off=None, ids=torch.empty(ukeys.numel(), dtype=torch.int32, device=dev), keys=ukeys,
+                           sf=None, ukeys=None, num_walks=num_walks, num_steps=hops, stride=sets.stride)
+        freqs = rows.counts_int32().cpu().numpy()
+    else:
+        sets.sf = torch.arange(X, dtype=torch.int32, device=dev)   # every member its own row (:69-70)
+        sets.ukeys = sets.keys
+        freqs = sets.counts_int32().cpu().numpy() if X else np.zeros((0, num_steps), np.int32)
+    z = SpG.from_sets(sets, n_cols=csr.num_nodes)
+    return z, np.insert(freqs, 0, np.zeros((1, num_steps), freqs.dtype), axis=0)

@@ -644,3 +644,28 @@ def test_gather_lazy_rows_match_eager(sp):
         sp.gather(edge, z, "cuda", ptr=True, encode=table, lazy=True)                       # needs out=
     with pytest.raises(ValueError):
         sp.gather(edge, z, "cuda", ptr=True, encode=table, out=buf[:100], lazy=True)        # worst case must fit
+
+
+# ------------------------------------------------------------------------------- rw_matrix / np_sampling (SUREL route)
+@pytest.mark.parametrize("reduced", [True, False])
+@pytest.mark.parametrize("nthread,bsize", [(1, 2000), (4, 300)])
+def test_rw_matrix_matches_restatement(sp, reduced, nthread, bsize):
+    """sampler/random_walks.py:58-71 through walk_sampler; numbering of LP rows = ascending projection order"""
+    indptr, indices = sym_graph(1500, 6000, 31, hubs=2)
+    idx = np.arange(1500)
+    ref = oracle.ref_module()
+    sampler = ref.walk_sampler if ref is not None else None          # the real reference when oracle/_ref exists
+    z_o, f_o = oracle.rw_matrix(indptr, indices, idx, num_walks=40, num_steps=4, batch_size=bsize, reduced=reduced,
+                                nthread=nthread, sampler=sampler)
+    z, f = sp.rw_matrix(sp.DeviceCSR(indptr, indices), idx, num_walks=40, num_steps=4, batch_size=bsize, reduced=reduced,
+                        nthread=nthread)
+    z_o.sort_indices()
+    np.testing.assert_array_equal(f, f_o)
+    assert f.dtype == f_o.dtype
+    np.testing.assert_array_equal(z.indptr.cpu().numpy(), z_o.indptr)
+    np.testing.assert_array_equal(z.indices.cpu().numpy(), z_o.indices)
+    np.testing.assert_array_equal(z.data.cpu().numpy(), z_o.data)
+    k_o, c_o = oracle.np_sampling(indptr, indices, bsize, idx[:700], num_walks=40, num_steps=3, nthread=nthread, sampler=sampler)
+    k, c = sp.np_sampling(indptr, indices, bsize, idx[:700], num_walks=40, num_steps=3, nthread=nthread)
+    np.testing.assert_array_equal(k, k_o)
+    np.testing.assert_array_equal(c, c_o)
