@@ -245,6 +245,23 @@ int subgacc_ppr_normalize(const void *indptr, int32_t indptr64, const int32_t *r
 /* utils.py:35-36: data = (data + 0.1) / (max + 0.1) over the first *nnz_dev entries; max from max_bits. */
 int subgacc_ppr_encode(double *data, int64_t max_nnz, const int64_t *nnz_dev, const uint64_t *max_bits, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * walk_join of the legacy SUREL surface (subg_acc/subg_acc.c:509-647): for every query pair (a, b) of roots and
+ * every position t of their raw walks, the running index of the visited node in a's key list and in b's key list
+ * (find_idx, :78-92; 0 = absent).
+ *   walks   int32 [n, stride]           raw walks, row i belongs to root i (walk_sampler's first output)
+ *   set_*   the n key lists as SpG-form rows: set_off int64[n+1], set_ids int32 ascending per row, set_idx int32 =
+ *           1 + position of the member in the concatenation of the lists as given (:573-584) -- what
+ *           subgacc_spg_build makes of (row_off, ids, sf = 0..X-1)
+ *   qrow    int32 [Q,2] row numbers of the query keys (find_key_item, :617; -1 = not a root: that pair yields -1s)
+ *   out     int32 [2, Q*2*stride], 8-byte aligned: out[s][2*x*stride + 2*t + {0,1}] = index of walks[row_s(x)][t] in
+ *           the list of {key1, key2} of pair x  (:621-629)
+ * max_len >= longest key list (sizes the LDS staging; rows past 5120 members are searched in place).
+ * ------------------------------------------------------------------------------------------- */
+int subgacc_walk_join(const int32_t *walks, int64_t n, int32_t stride, const int64_t *set_off, const int32_t *set_ids,
+                      const int32_t *set_idx, int32_t max_len, const int32_t *qrow, int64_t Q, int32_t *out,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,7 @@ GPU box.  The fixtures it writes are data only: seeded inputs and the outputs th
   G4  sjoin_*.npz   train.gather / train.pgather(bgather) (int + float payload, ptr True/False)  train.py:13-111
   G5  hjoin_*.npz   train.hgather                                      train.py:48-72
   G6  rand_r.npz    glibc rand_r streams (libc.so.6 via ctypes), the RNG the reference calls
+  G7  walkjoin_*.npz subg_acc.walk_join over walk_sampler's output (legacy SUREL join)  subg_acc/subg_acc.c:509-647
 """
 import ctypes
 import os
@@ -175,6 +176,24 @@ def gen_sjoin():
                         xz=xz.numpy(), ind=ind.numpy())
 
 
+def gen_walkjoin():
+    """G7  walkjoin_*.npz  subg_acc.walk_join(return_idx=True) over walk_sampler's own output   subg_acc/subg_acc.c:509-647"""
+    cases = {"small": (300, 900, 3, 120, 10, 3, 50), "wide": (800, 6000, 5, 400, 32, 2, 300), "dup": (200, 700, 9, 60, 6, 4, 40)}
+    for name, (N, E, gs, n, M, m, Q) in cases.items():
+        ptr, idx = sym_graph(N, E, gs)
+        rng = np.random.default_rng(gs)
+        roots = rng.permutation(N)[:n].astype(np.int32)
+        if name == "dup":                       # repeated roots: the query resolves to the LAST row of a root
+            roots = np.concatenate([roots, roots[:20]]).astype(np.int32)
+        walks, obj = ref.walk_sampler(ptr, idx, roots, num_walks=M, num_steps=m, nthread=1, seed=7, replacement=True)
+        q = roots[rng.integers(0, len(roots), (Q, 2))]
+        q[0] = (roots[0], roots[0])             # (u, u)
+        out, xrow = ref.walk_join(walks, list(obj[:, 0]), q, nthread=1, return_idx=True)
+        key_len = np.array([len(obj[i, 0]) for i in range(len(roots))], np.int32)
+        np.savez_compressed(os.path.join(OUT, f"walkjoin_{name}.npz"), walks=walks, key_len=key_len,
+                            key_ids=np.concatenate(list(obj[:, 0])).astype(np.int32), query=q.astype(np.int32), out=out, xrow=xrow)
+
+
 def gen_rand_r():
     libc = ctypes.CDLL("libc.so.6")
     libc.rand_r.restype = ctypes.c_int
@@ -191,5 +210,6 @@ if __name__ == "__main__":
     gen_gset()
     gen_walk()
     gen_sjoin()
+    gen_walkjoin()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"wrote {len(os.listdir(OUT))} fixtures, {tot / 1024:.0f} KiB -> {OUT}")

@@ -348,3 +348,25 @@ def rw_matrix(indptr, indices, train_idx, num_walks=200, num_steps=4, batch_size
     z = sps.csr_matrix((idy + 1, (i, neighbors)), shape=(gsize, gsize))
     freqs = np.insert(freqs, 0, np.zeros((1, num_steps), freqs.dtype), axis=0)
     return z, freqs
+
+
+# ------------------------------------------------------------------ walk_join (subg_acc.c:509-647, legacy SUREL)
+def walk_join(walk, key, query, nthread=-1, return_idx=False):
+    """Returns out int32[2, Q*2*stride] (and xrow int32[Q,2] with return_idx), as the reference does."""
+    walk = np.ascontiguousarray(walk, np.int32)
+    n = walk.shape[0]
+    stride = int(np.prod(walk.shape[1:]))
+    walk = walk.reshape(n, stride)
+    key = [np.asarray(k, np.int32).ravel() for k in key]
+    assert len(key) == n, "Dims do not match between num of walks and keys."
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum([len(k) for k in key], out=off[1:])
+    ids = np.ascontiguousarray(np.concatenate(key) if n else np.zeros(0, np.int32), np.int32)
+    q = np.ascontiguousarray(np.asarray(query).astype(np.int32)).reshape(-1, 2)
+    Q = q.shape[0]
+    out = np.empty((2, Q * 2 * stride), np.int32)
+    xrow = np.empty((Q, 2), np.int32)
+    rc = lib().orc_walk_join(_p(walk, C.c_int32), C.c_int64(n), C.c_int32(stride), _p(off, C.c_int64), _p(ids, C.c_int32),
+                             _p(q, C.c_int32), C.c_int64(Q), _p(out, C.c_int32), _p(xrow, C.c_int32))
+    assert rc == 0
+    return [out, xrow] if return_idx else out

@@ -754,3 +754,93 @@ int orc_num_threads(void)
     return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------ walk_join (legacy SUREL join over raw walks)
+ * subg_acc/subg_acc.c:509-647.  walk int32[n, stride] (column 0 = the root), key lists concatenated in `key_ids`
+ * with offsets key_off[n+1]; member j of the concatenation has index j+1 (:573-584, `idx` runs over all lists).
+ * query int32[Q,2] node ids.  out int32[2, Q*2*stride]; xrow int32[Q,2] = row of each query key (the LAST row
+ * whose root equals it: uthash prepends to its bucket chain, so HASH_FIND meets the latest duplicate first; -1 when
+ * the key is no root -- the reference then reads out of bounds, here the 4 values of that query are left -1).
+ * find_idx(:78-92): index of the node in the key's list, 0 when absent.  The lists hold distinct ids. */
+typedef struct
+{
+    int32_t id, idx;
+} wj_ent;
+static int wj_cmp(const void *a, const void *b)
+{
+    const wj_ent *x = a, *y = b;
+    return x->id < y->id ? -1 : (x->id > y->id);
+}
+static int32_t wj_find(const wj_ent *row, int64_t len, int32_t node)
+{
+    int64_t lo = 0, hi = len;
+    while (lo < hi)
+    {
+        int64_t mid = (lo + hi) >> 1;
+        if (row[mid].id < node)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return (lo < len && row[lo].id == node) ? row[lo].idx : 0;
+}
+int orc_walk_join(const int32_t *walk, int64_t n, int32_t stride, const int64_t *key_off, const int32_t *key_ids,
+                  const int32_t *query, int64_t Q, int32_t *out, int32_t *xrow)
+{
+    const int64_t X = key_off[n];
+    wj_ent *ent = malloc(sizeof(wj_ent) * (size_t)(X > 0 ? X : 1));
+    wj_ent *roots = malloc(sizeof(wj_ent) * (size_t)(n > 0 ? n : 1));
+    if (!ent || !roots)
+        return -1;
+    for (int64_t i = 0; i < n; ++i)
+    {
+        for (int64_t j = key_off[i]; j < key_off[i + 1]; ++j)
+            ent[j].id = key_ids[j], ent[j].idx = (int32_t)(j + 1);
+        qsort(ent + key_off[i], (size_t)(key_off[i + 1] - key_off[i]), sizeof(wj_ent), wj_cmp);
+        roots[i].id = walk[i * (int64_t)stride], roots[i].idx = (int32_t)i;
+    }
+    /* stable by construction: sort by (id, row) and take the last of a run */
+    for (int64_t i = 1; i < n; ++i)
+    { /* insertion sort keeps equal ids in row order; n is a batch (thousands) */
+        wj_ent t = roots[i];
+        int64_t j = i - 1;
+        while (j >= 0 && roots[j].id > t.id)
+            roots[j + 1] = roots[j], --j;
+        roots[j + 1] = t;
+    }
+    const int64_t width = Q * 2 * (int64_t)stride;
+    for (int64_t x = 0; x < Q; ++x)
+    {
+        int32_t row[2];
+        for (int s = 0; s < 2; ++s)
+        {
+            const int32_t key = query[2 * x + s];
+            int64_t lo = 0, hi = n; /* last position with id <= key */
+            while (lo < hi)
+            {
+                int64_t mid = (lo + hi) >> 1;
+                if (roots[mid].id <= key)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            row[s] = (lo > 0 && roots[lo - 1].id == key) ? roots[lo - 1].idx : -1;
+            xrow[2 * x + s] = row[s];
+        }
+        for (int32_t t = 0; t < stride; ++t)
+            for (int s = 0; s < 2; ++s)
+            {
+                int32_t *o = out + s * width + 2 * x * (int64_t)stride + 2 * t;
+                if (row[0] < 0 || row[1] < 0)
+                {
+                    o[0] = o[1] = -1;
+                    continue;
+                }
+                const int32_t node = walk[row[s] * (int64_t)stride + t];
+                o[0] = wj_find(ent + key_off[row[0]], key_off[row[0] + 1] - key_off[row[0]], node);
+                o[1] = wj_find(ent + key_off[row[1]], key_off[row[1] + 1] - key_off[row[1]], node);
+            }
+    }
+    free(ent), free(roots);
+    return 0;
+}

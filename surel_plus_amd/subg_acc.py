@@ -15,7 +15,7 @@ import torch
 from . import _lib
 from .sampler import DeviceCSR, sample_sets
 
-__all__ = ["gset_sampler", "walk_sampler", "add", "sjoin"]
+__all__ = ["gset_sampler", "walk_sampler", "walk_join", "add", "sjoin"]
 
 
 def _csr_from_host(indptr, indices):
@@ -88,6 +88,56 @@ def walk_sampler(ptr, neighs, query, num_walks=100, num_steps=3, nthread=-1, see
         obj[i, 0] = ids[off[i]:off[i + 1]]
         obj[i, 1] = counts[off[i]:off[i + 1]]
     return [walks, obj]
+
+
+def walk_join(walk, key, query, nthread=-1, return_idx=False):
+    """subg_acc.c:509-647 (legacy SUREL join).  walk int32 [n, stride] or [n, M, m+1] -- walk_sampler's first output;
+    key -- n sequences of node ids (walk_sampler's obj[:, 0]); query -- [Q, 2] node ids, each a root of `walk`.
+    Returns out int32 [2, Q*2*stride] (and, with return_idx, int32 [Q, 2] row numbers of the query keys).  For each
+    pair and walk position: (index of the node in key1's list, in key2's list), 1-based over the concatenation of all
+    lists, 0 = absent; out[0] follows key1's walk, out[1] key2's.  A repeated root resolves to its LAST row, as the
+    reference's hash does; a query key that is no root yields -1s (the reference reads out of bounds)."""
+    from ._lib import check, lib, ptr, stream_ptr
+    dev = _lib.require_device()
+    w = walk if torch.is_tensor(walk) else torch.from_numpy(np.ascontiguousarray(np.asarray(walk), dtype=np.int32))
+    if w.dim() < 2:
+        raise TypeError("Input parsing error. (walk must be [n, stride] or [n, M, m+1])")
+    n = w.shape[0]
+    w = w.to(device=dev, dtype=torch.int32).reshape(n, -1).contiguous()
+    stride = w.shape[1]
+    key = list(key)
+    if len(key) != n:
+        raise AssertionError("Dims do not match between num of walks and keys.")
+    lens = np.fromiter((len(k) for k in key), dtype=np.int64, count=n)
+    off = np.zeros(n + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    X = int(off[-1])
+    ids_h = np.concatenate([np.asarray(k).astype(np.int32, copy=False).ravel() for k in key]) if X else np.zeros(0, np.int32)
+    row_off = torch.from_numpy(off).to(dev)
+    ids = torch.from_numpy(np.ascontiguousarray(ids_h, dtype=np.int32)).to(dev)
+    max_len = int(lens.max()) if n else 0
+    st = stream_ptr()
+    # the key lists become SpG-form rows: ids ascending, payload = 1 + position in the concatenation (:573-584)
+    set_ids, set_idx = torch.empty_like(ids), torch.empty_like(ids)
+    flags = torch.zeros(4, dtype=torch.int32, device=dev)
+    if X:
+        pos = torch.arange(X, dtype=torch.int32, device=dev)
+        check(lib().subgacc_spg_build(ptr(row_off), n, ptr(ids), ptr(pos), None, 0, max_len, ptr(set_ids), ptr(set_idx),
+                                      ptr(flags), st))
+    q = torch.as_tensor(np.asarray(query) if not torch.is_tensor(query) else query).to(device=dev, dtype=torch.int32).reshape(-1, 2)
+    Q = q.shape[0]
+    if n:      # find_key_item (:617): row of the root, the last one among equals
+        roots_sorted, order = torch.sort(w[:, 0].contiguous(), stable=True)
+        p = torch.searchsorted(roots_sorted, q.reshape(-1).contiguous(), right=True) - 1
+        hit = (p >= 0) & (roots_sorted[p.clamp(min=0)] == q.reshape(-1))
+        qrow = torch.where(hit, order[p.clamp(min=0)], torch.full_like(p, -1)).to(torch.int32).reshape(Q, 2).contiguous()
+    else:
+        qrow = torch.full((Q, 2), -1, dtype=torch.int32, device=dev)
+    out = torch.empty((2, Q * 2 * stride), dtype=torch.int32, device=dev)
+    check(lib().subgacc_walk_join(ptr(w), n, stride, ptr(row_off), ptr(set_ids), ptr(set_idx), max_len, ptr(qrow), Q,
+                                  ptr(out), st))
+    out = out.cpu().numpy()
+    return [out, qrow.cpu().numpy()] if return_idx else out
 
 
 def add(i, j):

@@ -669,3 +669,38 @@ def test_rw_matrix_matches_restatement(sp, reduced, nthread, bsize):
     k, c = sp.np_sampling(indptr, indices, bsize, idx[:700], num_walks=40, num_steps=3, nthread=nthread)
     np.testing.assert_array_equal(k, k_o)
     np.testing.assert_array_equal(c, c_o)
+
+
+# ------------------------------------------------------------------------------- walk_join (legacy SUREL join)
+def _walkjoin_inputs(g):
+    off = np.concatenate([[0], np.cumsum(g["key_len"])])
+    return g["walks"], [g["key_ids"][off[i]:off[i + 1]] for i in range(len(g["key_len"]))], g["query"]
+
+
+@pytest.mark.parametrize("name", golden_files("walkjoin_"))
+def test_walk_join_matches_reference_golden(sp, name):
+    g = _load(name)
+    walks, key, query = _walkjoin_inputs(g)
+    out, xrow = sp.walk_join(walks, key, query, return_idx=True)
+    np.testing.assert_array_equal(xrow, g["xrow"])
+    np.testing.assert_array_equal(out, g["out"])
+    assert out.dtype == np.int32 and out.shape == g["out"].shape
+    out3 = sp.walk_join(walks.reshape(walks.shape[0], -1, 1), key, query)          # 3-D walks, no index request
+    np.testing.assert_array_equal(out3, g["out"])
+
+
+def test_walk_join_end_to_end_vs_oracle(sp):
+    """walk_sampler -> walk_join on the GPU against the oracle, a batch of 3000 roots and 4096 pairs"""
+    indptr, indices = sym_graph(5000, 25000, 41, hubs=3)
+    rng = np.random.default_rng(3)
+    roots = rng.permutation(5000)[:3000].astype(np.int32)
+    walks, obj = sp.walk_sampler(indptr, indices, roots, num_walks=50, num_steps=3, nthread=2, seed=5, replacement=True)
+    q = roots[rng.integers(0, 3000, (4096, 2))]
+    q[7] = (4999 if 4999 not in roots else roots[0], roots[1])
+    out, xrow = sp.walk_join(walks, list(obj[:, 0]), q, return_idx=True)
+    want, wrow = oracle.walk_join(walks, list(obj[:, 0]), q, return_idx=True)
+    np.testing.assert_array_equal(xrow, wrow)
+    np.testing.assert_array_equal(out, want)
+    with pytest.raises(AssertionError):
+        sp.walk_join(walks, list(obj[:-1, 0]), q)
+    assert sp.walk_join(walks, list(obj[:, 0]), np.zeros((0, 2), np.int32)).shape == (2, 0)

@@ -106,3 +106,15 @@ def test_reference_invariants_hold_for_philox():
                                 rng="philox", nthreads=4, debug=True)
     for a, b in zip((nsize, remap, enc, raw), again):
         assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------------------- walk_join (legacy SUREL join)
+@pytest.mark.parametrize("name", golden_files("walkjoin_"))
+def test_oracle_walk_join_matches_reference(name):
+    g = np.load(os.path.join(GOLDEN, name))
+    off = np.concatenate([[0], np.cumsum(g["key_len"])])
+    key = [g["key_ids"][off[i]:off[i + 1]] for i in range(len(g["key_len"]))]
+    out, xrow = oracle.walk_join(g["walks"], key, g["query"], return_idx=True)
+    np.testing.assert_array_equal(xrow, g["xrow"])
+    np.testing.assert_array_equal(out, g["out"])
+    assert out.dtype == g["out"].dtype and out.shape == g["out"].shape
