@@ -46,7 +46,6 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # SUBGACC_FUSED: 1 = the walk kernel also emits finished SpG rows (walk_spg), 0 = general pipeline, unset = the
 # library's choice (fused for walks of >= 3 hops)
 FUSED = {"1": True, "0": False}.get(os.environ.get("SUBGACC_FUSED", ""), None)
-NSTREAMS = int(os.environ.get("SUBGACC_STREAMS", "1"))   # >1: consecutive steps go to different HIP streams
 LAZY = os.environ.get("SUBGACC_LAZY", "1") == "1"     # sizes stay on the device: one host round trip per step
 
 
@@ -111,6 +110,8 @@ def hot_path_step(sp, csr, edge, M, k, seed, rng, slot=0):
     if buf is None:
         buf = _XZ_BUF[(edge.device, cap, slot)] = torch.empty(cap, dtype=torch.float32, device=edge.device)
     xz, ind = sp.gather(rows, z, edge.device, ptr=True, encode=table, out=buf, lazy=LAZY)
+    if LAZY:    # sizes + status + the join's row count start their way to pinned host memory now, behind this step
+        sets.prefetch(extra=ind[-1:])
     return xz, ind, sets
 
 
@@ -118,7 +119,7 @@ def finish_step(xz, ind, sets):
     """sizes, status flags and the distinct-row count of a queued step: two small reads, errors raised here"""
     sets.resolve()
     if LAZY:
-        xz = xz[: int(ind[-1].item())]
+        xz = xz[: int(sets.extra[0])]
     return xz, ind, sets
 
 
@@ -299,14 +300,31 @@ def main():
     timer = KernelTimer()
     sampler_mod.KERNEL_TIMER = timer
     last = None
-    PRIME = 2
-    for s in list(range(PRIME)) + list(range(W)):
-        # Two priming passes (part of set-up, like building the graph), then the W warm-up steps.  The previous step's
-        # results are kept alive exactly like in the timed loop, so torch's caching allocator reaches its steady state
-        # (two generations of buffers) here: a fresh GB-sized hipMalloc inside the timed region costs ~10 ms on some
-        # hosts of the pool (seen as one 11-19 ms step with unchanged kernel times) and is not part of the path.
-        xz, ind, sets = finish_step(*hot_path_step(sp, csr, edges[s % len(edges)], M, k, seed=s, rng=args.rng, slot=s & 1))
-        last = (edges[s % len(edges)], sets, xz)
+    step_marks = []
+
+    def run_steps(step_ids):
+        """Double-buffered serving loop: step s is queued before the sizes of step s-1 are read back (they travel to
+        pinned host memory behind step s-1's kernels), so the GPU never waits for the host; every step is complete
+        (kernels done, sizes on the host, errors raised) when this returns."""
+        nonlocal last
+        pending = None
+        for s in step_ids:
+            e = edges[s % len(edges)]
+            queued = hot_path_step(sp, csr, e, M, k, seed=s, rng=args.rng, slot=s & 1)
+            if pending is not None:
+                xz, ind, sets = finish_step(*pending[1])
+                last = (pending[0], sets, xz)
+            pending = (e, queued)
+            step_marks.append(time.perf_counter())
+        if pending is not None:
+            xz, ind, sets = finish_step(*pending[1])
+            last = (pending[0], sets, xz)
+
+    # Priming (part of set-up, like building the graph) + the W warm-up steps, in the same loop shape as the timed
+    # region so that torch's caching allocator reaches its steady state (two steps in flight) here: a fresh GB-sized
+    # hipMalloc inside the timed region costs ~10 ms on some hosts of the pool and is not part of the path.
+    PRIME = 3
+    run_steps(list(range(PRIME)) + list(range(W)))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -314,22 +332,8 @@ def main():
     timer.enabled = True
     allocs0 = torch.cuda.memory_stats().get("num_device_alloc", 0)
     t0 = time.perf_counter()
-    step_marks = [t0]
-    pending = None
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(NSTREAMS - 1)]
-    for s in range(W, W + K):
-        # double-buffered serving loop: step s is queued before the sizes of step s-1 are read back, so the GPU never
-        # waits for the host; every step is complete (kernels done, sizes on the host) before the clock stops
-        with torch.cuda.stream(streams[s % len(streams)]):
-            queued = hot_path_step(sp, csr, edges[s], M, k, seed=s, rng=args.rng, slot=s & 1)
-        if pending is not None:
-            xz, ind, sets = finish_step(*pending[1])
-            last = (pending[0], sets, xz)
-        pending = (edges[s], queued)
-        step_marks.append(time.perf_counter())
-    if pending is not None:
-        xz, ind, sets = finish_step(*pending[1])
-        last = (pending[0], sets, xz)
+    step_marks[:] = [t0]
+    run_steps(range(W, W + K))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

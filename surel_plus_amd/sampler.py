@@ -84,17 +84,40 @@ class SampledSets:
     capacity: int = 0
     status: torch.Tensor = None  # lazy form: device int64 [flags(4), distinct rows, members], not read back yet
     data: torch.Tensor = None    # fused SpG form: SFptr+1 per member (capacity-sized while lazy)
+    _pending: tuple = None       # prefetch(): (pinned host copy of status, event, device source)
+    extra: list = None           # values of prefetch(extra=...) once resolved
 
     # ------------------------------------------------------------------ lazy bookkeeping
     @property
     def pending(self):
         return self.status is not None
 
+    def prefetch(self, extra=None):
+        """Queue the read-back of sizes and status flags (plus `extra`, a small int64 device tensor) into pinned host
+        memory, behind everything queued so far.  resolve() then waits for exactly this copy instead of for whatever
+        the stream holds by the time it is called -- a serving loop queues the next batch in between."""
+        if self.status is None or self._pending is not None:
+            return self
+        src = self.status if extra is None else torch.cat([self.status, extra.reshape(-1).to(torch.int64)])
+        host = torch.empty(src.numel(), dtype=torch.int64, pin_memory=True)
+        host.copy_(src, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending = (host, ev, src)          # src stays alive until the copy has run
+        return self
+
     def resolve(self):
         """Read sizes and status flags back (one small copy), raise on errors, trim capacity-sized arrays."""
         if self.status is None:
             return self
-        st = self.status.tolist()
+        if self._pending is not None:
+            host, ev, _ = self._pending
+            ev.synchronize()
+            st = host.tolist()
+            self.extra = st[self.status.numel():]
+            self._pending = None
+        else:
+            st = self.status.tolist()
         self.status = None
         check_walk_flags(self, st[:4])
         if st[2]:
