@@ -193,7 +193,8 @@ int subgacc_sjoin_sizes(const int64_t *spg_indptr, const int64_t *own, int64_t S
  *   out_xz   f32  [R,2,k] = table[pair] (int payload)  |  [R,2,1] = float(pair) (f64 payload)
  *   out_idx  i32  [R,2]  the raw index pairs (optional, int payload only)
  *   out_segid i64 [R]    segment id of every row (`ptr=False`, train.py:25-30) (optional)
- * max_len >= longest SpG row touched (a longer partner row sets flags[3] |= 1 and its segment is skipped).
+ * max_len >= longest SpG row touched (a longer partner row sets flags[3] |= 1 and its segment is skipped); rows that
+ *   do not fit LDS (max_len above ~10k int / ~6.8k float entries) take a kernel that searches them in place.
  * pair_block = 0: segments are independent.  pair_block = P > 0: the list is made of blocks of P segments
  *   and block 2t+1 mirrors block 2t (own/partner swapped) -- gather passes P = B, hgather P = B; the mirrored
  *   segments are then produced together and every SpG row is read once (flags[3] |= 4 if the list is not

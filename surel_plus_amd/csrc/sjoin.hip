@@ -112,8 +112,10 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
     if (a.out_segid && live) a.out_segid[row0 + lane] = segj;
 }
 
-// generic: one wave64 workgroup per segment, partner row staged in LDS, own row streamed from HBM
-template <bool F64, int KV>
+// generic: one wave64 workgroup per segment, partner row staged in LDS, own row streamed from HBM.
+// STAGE = false: rows too long for LDS (an adjacency-like SpG with hub rows) -- the partner row is searched where it
+// lies (L2); slower per look-up, no bound on the row length.
+template <bool F64, int KV, bool STAGE = true>
 __global__ __launch_bounds__(kJoinThreads) void sjoin_fill_kernel(const JoinArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using Val = typename std::conditional<F64, double, int32_t>::type;
@@ -126,17 +128,22 @@ __global__ __launch_bounds__(kJoinThreads) void sjoin_fill_kernel(const JoinArgs
     const int64_t ra = a.own[j], rb = a.partner[j];
     const int64_t ab = a.indptr[ra], na = a.indptr[ra + 1] - ab;
     const int64_t bb = a.indptr[rb], nb64 = a.indptr[rb + 1] - bb;
-    if (nb64 > a.max_len) {
+    if (nb64 > (STAGE ? (int64_t)a.max_len : (int64_t)0x7FFFFFFF)) {
         if (lane == 0) atomicOr(&a.flags[3], 1);
         return;
     }
     const int nb = (int)nb64;
     const Val *data = (const Val *)a.data;
-    for (int r = lane; r < nb; r += kJoinThreads) {   // partner row -> LDS, coalesced
-        pids[r] = a.indices[bb + r];
-        pval[r] = data[bb + r];
+    if (STAGE) {
+        for (int r = lane; r < nb; r += kJoinThreads) {   // partner row -> LDS, coalesced
+            pids[r] = a.indices[bb + r];
+            pval[r] = data[bb + r];
+        }
+        __syncthreads();
+    } else {
+        pids = const_cast<int32_t *>(a.indices + bb);
+        pval = const_cast<Val *>(data + bb);
     }
-    __syncthreads();
     const int64_t o = a.seg[j];
     const int k = a.k, k2 = 2 * k;
     const uint32_t magic = k2 > 0 ? ((1u << 20) + (uint32_t)k2 - 1u) / (uint32_t)k2 : 0u;   // f / k2 for f < 2^11
@@ -330,9 +337,14 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, const int32_t *spg_
     a.flags = flags;
     SG_REQUIRE(pair_block >= 0 && (pair_block == 0 || S % (2 * pair_block) == 0), SUBGACC_ERR_BADARG,
                "sjoin_fill: S = %lld is not a multiple of 2*pair_block", (long long)S);
-    const bool paired = pair_block > 0;
-    const size_t lds = (size_t)a.max_len * (f64 ? 12 : 8) * (paired ? 2 : 1);
-    SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "sjoin_fill: rows of %d members do not fit LDS", max_len);
+    bool paired = pair_block > 0;
+    size_t lds = (size_t)a.max_len * (f64 ? 12 : 8) * (paired ? 2 : 1);
+    if (paired && lds > (size_t)kLdsBytes) {     // two rows do not fit LDS: one might (the mirrored list is a list all the same)
+        paired = false;
+        lds /= 2;
+    }
+    const bool staged = lds <= (size_t)kLdsBytes;   // else: rows longer than LDS, searched in place (sjoin_fill_kernel<.., false>)
+    if (!staged) lds = 0;
     SG_REQUIRE(k <= 16, SUBGACC_ERR_BADARG, "sjoin_fill: feature width k = %d > 16 is not supported", k);
     const int64_t grid = xcd_grid(paired ? S / 2 : S);
     SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_fill: too many segments in one call");
@@ -361,7 +373,11 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, const int32_t *spg_
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
         hipLaunchKernelGGL((sjoin_fill_kernel<F, KVV>), dim3((unsigned)grid), dim3(kJoinThreads), lds, s, a);     \
     } while (0)
-    if (f64) SG_JOIN_LAUNCH(true, 0);
+    if (!staged) {
+        if (f64) hipLaunchKernelGGL((sjoin_fill_kernel<true, 0, false>), dim3((unsigned)grid), dim3(kJoinThreads), 0, s, a);
+        else if (vec4) hipLaunchKernelGGL((sjoin_fill_kernel<false, 4, false>), dim3((unsigned)grid), dim3(kJoinThreads), 0, s, a);
+        else hipLaunchKernelGGL((sjoin_fill_kernel<false, 0, false>), dim3((unsigned)grid), dim3(kJoinThreads), 0, s, a);
+    } else if (f64) SG_JOIN_LAUNCH(true, 0);
     else if (vec4) SG_JOIN_LAUNCH(false, 4);
     else SG_JOIN_LAUNCH(false, 0);
 #undef SG_JOIN_LAUNCH

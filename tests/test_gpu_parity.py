@@ -704,3 +704,31 @@ def test_walk_join_end_to_end_vs_oracle(sp):
     with pytest.raises(AssertionError):
         sp.walk_join(walks, list(obj[:-1, 0]), q)
     assert sp.walk_join(walks, list(obj[:, 0]), np.zeros((0, 2), np.int32)).shape == (2, 0)
+
+
+# ------------------------------------------------------------------------------- SpJoin over rows longer than LDS
+@pytest.mark.parametrize("payload", ["int", "float"])
+def test_gather_rows_longer_than_lds(sp, payload):
+    """an adjacency-like SpG with hub rows of 30k / 12k members (LDS holds ~10k int / ~6.8k float entries of a pair):
+    one row fits -> generic staged kernel; none fits -> rows are searched in place.  Same answers as NumPy."""
+    rng = np.random.default_rng(11)
+    N = 40000
+    lens = rng.integers(0, 40, N)
+    lens[5], lens[17], lens[300] = 30000, 12000, 9000
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    indices = np.concatenate([np.sort(rng.choice(N, int(n_), replace=False)) for n_ in lens]).astype(np.int32)
+    if payload == "int":
+        data, enc = rng.integers(1, 50, indices.size).astype(np.int32), rng.random((50, 3)).astype(np.float32)
+        enc[0] = 0
+    else:
+        data, enc = rng.random(indices.size), None
+    z = sp.SpG(torch.from_numpy(indptr).cuda(), torch.from_numpy(indices).cuda(), torch.from_numpy(data).cuda())
+    edge = rng.integers(0, N, (2, 64))
+    edge[:, 0], edge[:, 1], edge[:, 2], edge[:, 3] = (5, 17), (17, 5), (5, 5), (300, 17)
+    enc_d = torch.from_numpy(enc).cuda() if enc is not None else None
+    for ptr in (True, False):
+        want_xz, want_ind = oracle.gather_numpy(edge, (indptr, indices, data), ptr=ptr, encode=enc)
+        for fn in (sp.gather, lambda e, x, d, ptr, encode: sp.pgather(e, x, d, encode, sp.bgather, ptr=ptr)):
+            xz, ind = fn(edge, z, "cuda", ptr=ptr, encode=enc_d)
+            np.testing.assert_array_equal(ind.cpu().numpy(), want_ind)
+            np.testing.assert_array_equal(xz.cpu().numpy(), want_xz)
