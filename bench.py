@@ -46,6 +46,9 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # SUBGACC_FUSED: 1 = the walk kernel also emits finished SpG rows (walk_spg), 0 = general pipeline, unset = the
 # library's choice (fused for walks of >= 3 hops)
 FUSED = {"1": True, "0": False}.get(os.environ.get("SUBGACC_FUSED", ""), None)
+# join the batch from the walk kernel's strided rows (no packed CSR copy of a batch that is joined once and dropped);
+# unset = wherever the fused-row walk kernel is the faster one (>= 3 hops); SUBGACC_STRIDED=0 builds the CSR SpG per step
+STRIDED = {"1": True, "0": False}.get(os.environ.get("SUBGACC_STRIDED", ""), None)
 LAZY = os.environ.get("SUBGACC_LAZY", "1") == "1"     # sizes stay on the device: one host round trip per step
 
 
@@ -99,7 +102,8 @@ def hot_path_step(sp, csr, edge, M, k, seed, rng, slot=0):
     Returns (xz buffer view, indptr, sets)."""
     B = edge.shape[1]
     roots = edge.reshape(-1).to(torch.int32)
-    z, sets = sp.sample_spg(csr, roots, num_walks=M, num_steps=k - 1, seed=seed, rng=rng, fused=FUSED, lazy=LAZY)
+    strided = (k - 1 >= 3 and FUSED is not False) if STRIDED is None else STRIDED
+    z, sets = sp.sample_spg(csr, roots, num_walks=M, num_steps=k - 1, seed=seed, rng=rng, fused=FUSED, lazy=LAZY, strided=strided)
     table = sets.feature_table()
     rows = torch.arange(2 * B, device=edge.device, dtype=torch.int64).view(2, B)   # row i = root i of this batch
     # the join output is written into re-used buffers sized for the worst case (every set full), two of them in
@@ -131,7 +135,7 @@ def algorithmic_walk_bytes(csr, roots, sets, M, m):
     w = 16 if csr.indptr64 else 8
     live = deg > 0
     per = 4 + w + 4 * torch.clamp(deg, max=M) + (w + 4) * M * (m - 1) * live.long() + 4
-    return int(per.sum().item()) + 8 * int(sets.ids.numel())
+    return int(per.sum().item()) + 8 * int(sets.X)
 
 
 def cpu_baseline(csr, edge_all, M, k, target_s=15.0):
@@ -355,7 +359,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            tk = f"{args.workload}:{B}:{M}:{k}:{'spg' if sets.data is not None else 'sets'}"
+            fused_rows = sets.data is not None or sets.strided
+            tk = f"{args.workload}:{B}:{M}:{k}:{'spg' if fused_rows else 'sets'}"
             traffic = tj.get(tk, {}).get("walk_sets_hbm_bytes_per_launch")
         out = {
             "metric": "query-pairs/sec (sample+SpJoin)", "value": world * B * K / elapsed, "unit": "query-pairs/s",
@@ -369,14 +374,14 @@ def main():
                        "S_roots_per_s": 2 * B / (1e-3 * sum(v for v in (timer.mean_ms(n_)[0] for n_ in
                                                  ("walk_sets", "compact_sets", "uniq_rows", "spg_build")) if v)),
                        "J_pairs_per_s": (B / (1e-3 * join_ms)) if join_ms else None,
-                       "fused_spg_rows": sets.data is not None,
+                       "fused_spg_rows": sets.data is not None or sets.strided, "spg_layout": "strided rows joined in place (no CSR copy of the batch)" if sets.strided else "csr",
                        "device_allocs_in_timed_region": torch.cuda.memory_stats().get("num_device_alloc", 0) - allocs0,
                        "host_step_ms_min_median_max": [round(1e3 * v, 3) for v in (
                            lambda d: (min(d), sorted(d)[len(d) // 2], max(d)))(
                            [b - a for a, b in zip(step_marks, step_marks[1:])])],
                        "stage_ms": {name: timer.mean_ms(name)[0] for name in
                                     ("walk_sets", "compact_sets", "uniq_rows", "spg_build", "sjoin_fill")}},
-            "roofline": {"bound": "hbm", "kernel": "walk_sets_kernel" + ("<SPG>" if sets.data is not None else ""),
+            "roofline": {"bound": "hbm", "kernel": "walk_sets_kernel" + ("<SPG>" if (sets.data is not None or sets.strided) else ""),
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel_ms": walk_ms, "launches_timed": launches, "algorithmic_bytes_per_launch": abytes},

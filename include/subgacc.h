@@ -205,6 +205,17 @@ int subgacc_sjoin_fill(const int64_t *spg_indptr, const int32_t *spg_indices, co
                        int32_t *out_idx, int64_t *out_segid, int32_t max_len, int64_t pair_block, int32_t *flags,
                        void *stream);
 
+/* The same join over STRIDED rows -- the form subgacc_walk_spg leaves its output in: row r = row_ids / row_slot
+ * [r*row_stride, +row_len[r]), sorted by node id, payload = slot in `uniq_table` (numbered by subgacc_uniq_number).
+ * A transient batch is joined straight from there: no packed CSR copy (subgacc_compact_rows) is made, slots become
+ * SFptr+1 on their way into LDS.  Mirrored segment lists only (pair_block > 0); out_idx optional as above. */
+int subgacc_sjoin_sizes_rows(const int32_t *row_len, const int64_t *own, int64_t S, int64_t *out_seg, void *workspace,
+                             size_t workspace_bytes, void *stream);
+int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t row_stride, const int32_t *row_ids, const int32_t *row_slot,
+                            const void *uniq_table, int64_t uniq_capacity, const int64_t *own, const int64_t *partner,
+                            int64_t S, const int64_t *seg, const float *table, int64_t table_rows, int32_t k,
+                            float *out_xz, int32_t *out_idx, int64_t pair_block, int32_t *flags, void *stream);
+
 /* Count form of the join (SpJoin fused with the first model stage, model.py:78-83).
  * out_counts f32 [S, table_rows]: out_counts[j][p] = number of times LP row p (SFptr+1, 0 = partner absent) occurs
  * in either feature slot of segment j, so that  segment_sum_j(MLP(xz).sum(-2)) == out_counts[j] @ MLP(Z_SF).

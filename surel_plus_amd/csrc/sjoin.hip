@@ -14,12 +14,12 @@ namespace subgacc {
 
 constexpr int kJoinThreads = 64;
 
-__global__ void sjoin_len_kernel(const int64_t *__restrict__ indptr, const int64_t *__restrict__ own, int64_t S,
-                                 int64_t *__restrict__ len) {
+__global__ void sjoin_len_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ row_len,
+                                 const int64_t *__restrict__ own, int64_t S, int64_t *__restrict__ len) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < S) {
         const int64_t a = own[j];
-        len[j] = indptr[a + 1] - indptr[a];
+        len[j] = row_len ? (int64_t)row_len[a] : indptr[a + 1] - indptr[a];
     }
 }
 
@@ -37,7 +37,21 @@ struct JoinArgs {
     int64_t *out_segid;
     int32_t max_len;
     int32_t *flags;
+    // strided rows (subgacc_sjoin_*_rows): row r = [r*row_stride, +row_len[r]) of indices / data, data = table slots
+    const int32_t *row_len;
+    int64_t row_stride;
+    const int32_t *slot_id;   // slot -> SFptr (id plane of the numbered table of distinct LP rows)
 };
+
+__device__ __forceinline__ void join_row(const JoinArgs &a, int64_t r, int64_t &beg, int64_t &len) {
+    if (a.row_len) {
+        beg = r * a.row_stride;
+        len = a.row_len[r];
+    } else {
+        beg = a.indptr[r];
+        len = a.indptr[r + 1] - beg;
+    }
+}
 
 // Emit up to 64 consecutive output rows of one segment (one per lane): look the lane's member up in the
 // partner row (binary search over sorted ids held in LDS) and write the feature pairs of the whole 64-row span
@@ -174,22 +188,28 @@ __global__ __launch_bounds__(kPairThreads) void sjoin_pair_kernel(const JoinArgs
         if (tid == 0) atomicOr(&a.flags[3], 4);
         return;
     }
-    const int64_t ab = a.indptr[ra], na64 = a.indptr[ra + 1] - ab;
-    const int64_t bb = a.indptr[rb], nb64 = a.indptr[rb + 1] - bb;
+    int64_t ab, na64, bb, nb64;
+    join_row(a, ra, ab, na64);
+    join_row(a, rb, bb, nb64);
     if (na64 > a.max_len || nb64 > a.max_len) {
         if (tid == 0) atomicOr(&a.flags[3], 1);
         return;
     }
     const int na = (int)na64, nb = (int)nb64;
     const Val *data = (const Val *)a.data;
+    const bool xl = !F64 && a.slot_id != nullptr;    // strided rows carry table slots: SFptr+1 on the way into LDS
     for (int r = tid; r < na; r += kPairThreads) {
         idsA[r] = a.indices[ab + r];
-        valA[r] = data[ab + r];
+        Val v = data[ab + r];
+        if (xl) v = (Val)(a.slot_id[(int32_t)v] + 1);
+        valA[r] = v;
     }
     if (ra != rb) {
         for (int r = tid; r < nb; r += kPairThreads) {
             idsB[r] = a.indices[bb + r];
-            valB[r] = data[bb + r];
+            Val v = data[bb + r];
+            if (xl) v = (Val)(a.slot_id[(int32_t)v] + 1);
+            valB[r] = v;
         }
     } else {   // (u,u): the second row is the first
         idsB = idsA;
@@ -293,19 +313,31 @@ extern "C" size_t subgacc_sjoin_workspace_bytes(int64_t S) {
     return align_up((size_t)S * 8, 256) + scan_workspace_bytes(S);
 }
 
-extern "C" int subgacc_sjoin_sizes(const int64_t *spg_indptr, const int64_t *own, int64_t S, int64_t *out_seg,
-                                   void *workspace, size_t workspace_bytes, void *stream) {
+static int join_sizes(const int64_t *spg_indptr, const int32_t *row_len, const int64_t *own, int64_t S, int64_t *out_seg,
+                      void *workspace, size_t workspace_bytes, void *stream) {
     SG_REQUIRE(S >= 0 && out_seg, SUBGACC_ERR_BADARG, "sjoin_sizes: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (S == 0) return exclusive_scan_i64(nullptr, 0, out_seg, nullptr, 0, s);
-    SG_REQUIRE(spg_indptr && own, SUBGACC_ERR_BADARG, "sjoin_sizes: null argument");
+    SG_REQUIRE((spg_indptr || row_len) && own, SUBGACC_ERR_BADARG, "sjoin_sizes: null argument");
     SG_REQUIRE(workspace && workspace_bytes >= subgacc_sjoin_workspace_bytes(S), SUBGACC_ERR_WORKSPACE,
                "sjoin_sizes: workspace too small");
     int64_t *len = (int64_t *)workspace;
     char *ws = (char *)workspace + align_up((size_t)S * 8, 256);
-    hipLaunchKernelGGL(sjoin_len_kernel, dim3((unsigned)ceil_div(S, 256)), dim3(256), 0, s, spg_indptr, own, S, len);
+    hipLaunchKernelGGL(sjoin_len_kernel, dim3((unsigned)ceil_div(S, 256)), dim3(256), 0, s, spg_indptr, row_len, own, S, len);
     SG_LAUNCH_CHECK();
     return exclusive_scan_i64(len, S, out_seg, ws, workspace_bytes - align_up((size_t)S * 8, 256), s);
+}
+
+extern "C" int subgacc_sjoin_sizes(const int64_t *spg_indptr, const int64_t *own, int64_t S, int64_t *out_seg,
+                                   void *workspace, size_t workspace_bytes, void *stream) {
+    SG_REQUIRE(spg_indptr || S == 0, SUBGACC_ERR_BADARG, "sjoin_sizes: null argument");
+    return join_sizes(spg_indptr, nullptr, own, S, out_seg, workspace, workspace_bytes, stream);
+}
+
+extern "C" int subgacc_sjoin_sizes_rows(const int32_t *row_len, const int64_t *own, int64_t S, int64_t *out_seg,
+                                        void *workspace, size_t workspace_bytes, void *stream) {
+    SG_REQUIRE(row_len || S == 0, SUBGACC_ERR_BADARG, "sjoin_sizes_rows: null argument");
+    return join_sizes(nullptr, row_len, own, S, out_seg, workspace, workspace_bytes, stream);
 }
 
 extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, const int32_t *spg_indices, const int32_t *spg_data_i32,
@@ -335,6 +367,7 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, const int32_t *spg_
     a.out_xz = out_xz, a.out_idx = out_idx, a.out_segid = out_segid;
     a.max_len = max_len > 0 ? max_len : 1;
     a.flags = flags;
+    a.row_len = nullptr, a.row_stride = 0, a.slot_id = nullptr;
     SG_REQUIRE(pair_block >= 0 && (pair_block == 0 || S % (2 * pair_block) == 0), SUBGACC_ERR_BADARG,
                "sjoin_fill: S = %lld is not a multiple of 2*pair_block", (long long)S);
     bool paired = pair_block > 0;
@@ -385,6 +418,49 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, const int32_t *spg_
     return SUBGACC_OK;
 }
 
+extern "C" int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t row_stride, const int32_t *row_ids,
+                                       const int32_t *row_slot, const void *uniq_table, int64_t uniq_capacity,
+                                       const int64_t *own, const int64_t *partner, int64_t S, const int64_t *seg,
+                                       const float *table, int64_t table_rows, int32_t k, float *out_xz,
+                                       int32_t *out_idx, int64_t pair_block, int32_t *flags, void *stream) {
+    SG_REQUIRE(S >= 0 && flags && row_stride > 0 && row_stride < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_fill_rows: bad arguments");
+    if (S == 0) return SUBGACC_OK;
+    SG_REQUIRE(row_len && row_ids && row_slot && uniq_table && uniq_capacity > 0 && own && partner && seg,
+               SUBGACC_ERR_BADARG, "sjoin_fill_rows: null argument");
+    SG_REQUIRE(out_xz || out_idx, SUBGACC_ERR_BADARG, "sjoin_fill_rows: no output requested");
+    SG_REQUIRE(!out_xz || (table && table_rows > 0 && k > 0 && k <= 16), SUBGACC_ERR_BADARG,
+               "sjoin_fill_rows: out_xz needs the feature table, k <= 16");
+    SG_REQUIRE(pair_block > 0 && S % (2 * pair_block) == 0, SUBGACC_ERR_BADARG,
+               "sjoin_fill_rows: the segment list must be mirrored blocks (pair_block > 0, S a multiple of 2*pair_block)");
+    JoinArgs a;
+    a.indptr = nullptr, a.indices = row_ids, a.data = row_slot;
+    a.own = own, a.partner = partner, a.seg = seg, a.S = S;
+    a.table = table, a.table_rows = table_rows, a.k = k;
+    a.out_xz = out_xz, a.out_idx = out_idx, a.out_segid = nullptr;
+    a.max_len = (int32_t)row_stride;
+    a.flags = flags;
+    a.row_len = row_len, a.row_stride = row_stride;
+    a.slot_id = (const int32_t *)((const char *)uniq_table + (size_t)uniq_capacity * 16);   // id plane (uniq_table.hpp)
+    const size_t lds = (size_t)a.max_len * 16;
+    SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "sjoin_fill_rows: rows of %lld members do not fit LDS",
+               (long long)row_stride);
+    const int64_t grid = xcd_grid(S / 2);
+    SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_fill_rows: too many segments in one call");
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec4 = out_xz && k == 4 && ((uintptr_t)table % 16 == 0) && ((uintptr_t)out_xz % 16 == 0);
+    if (vec4) {
+        if (lds > 64 * 1024)
+            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((sjoin_pair_kernel<false, 4>), dim3((unsigned)grid), dim3(kPairThreads), lds, s, a, pair_block);
+    } else {
+        if (lds > 64 * 1024)
+            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((sjoin_pair_kernel<false, 0>), dim3((unsigned)grid), dim3(kPairThreads), lds, s, a, pair_block);
+    }
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}
+
 extern "C" int subgacc_sjoin_counts(const int64_t *spg_indptr, const int32_t *spg_indices, const int32_t *spg_data_i32,
                                     const int64_t *own, const int64_t *partner, int64_t S, int64_t table_rows,
                                     float *out_counts, int32_t max_len, int64_t pair_block, int32_t *flags,
@@ -402,6 +478,7 @@ extern "C" int subgacc_sjoin_counts(const int64_t *spg_indptr, const int32_t *sp
     a.out_xz = nullptr, a.out_idx = nullptr, a.out_segid = nullptr;
     a.max_len = max_len > 0 ? max_len : 1;
     a.flags = flags;
+    a.row_len = nullptr, a.row_stride = 0, a.slot_id = nullptr;
     const size_t lds = (size_t)a.max_len * 16 + (size_t)table_rows * 8;
     SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS,
                "sjoin_counts: %lld distinct LP rows and rows of %d members need %zu B of LDS; use sjoin_fill",

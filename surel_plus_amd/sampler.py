@@ -84,6 +84,8 @@ class SampledSets:
     capacity: int = 0
     status: torch.Tensor = None  # lazy form: device int64 [flags(4), distinct rows, members], not read back yet
     data: torch.Tensor = None    # fused SpG form: SFptr+1 per member (capacity-sized while lazy)
+    strided: bool = False        # ids / slot are the strided staging arrays (row i at i*stride), see sample_sets
+    _members: int = 0
     _pending: tuple = None       # prefetch(): (pinned host copy of status, event, device source)
     extra: list = None           # values of prefetch(extra=...) once resolved
 
@@ -127,6 +129,9 @@ class SampledSets:
         if c > self.ukeys.numel():
             raise _lib.SubgAccError(f"{c} distinct LP rows exceed the direct-ranking limit: sample with lazy=False")
         self.ukeys = self.ukeys[:c]
+        if self.strided:
+            self._members = X
+            return self
         self.ids = self.ids[:X]
         for name in ("slot", "keys", "data", "sf"):
             t = getattr(self, name)
@@ -136,7 +141,8 @@ class SampledSets:
 
     @property
     def X(self):
-        return self.resolve().ids.numel()
+        self.resolve()
+        return self._members if self.strided else self.ids.numel()
 
     @property
     def c(self):
@@ -237,13 +243,16 @@ def _cat(parts, dtype, dev):
 def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, rng="rand_r", first_hop_wo=True,
                 order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False, rng_streams=1,
                 calls_before=0, dedup=True, keep_keys=None, staging_bytes=STAGING_BYTES, uniq_capacity=UNIQ_CAPACITY,
-                uniq_small_limit=0, fused_rows=False, lazy=False):
+                uniq_small_limit=0, fused_rows=False, lazy=False, strided=False):
     """Run the sampler for `query` (roots) on the GPU.  See SampledSets.
 
     dedup=True numbers the distinct LP rows (ukeys, slot / get_sf()); the packed keys are then only kept when
     keep_keys is set.  fused_rows=True uses subgacc_walk_spg: `ids` come out sorted by node id per root and `data`
     holds SFptr+1 -- finished SpG rows (needs M*m+1 <= 818 and set_sampler order; returns None when the
-    configuration does not fit, the caller then takes the general pipeline).  lazy=True: see the module docstring."""
+    configuration does not fit, the caller then takes the general pipeline).  lazy=True: see the module docstring.
+    strided=True (with fused_rows, one chunk): the finished rows stay where the walk kernel left them -- row i at
+    ids / slot [i*stride, +nsize[i]), slot = table slot -- for a join straight from there (spg.StridedSpG); no packed
+    copy, no row offsets."""
     L = lib()
     dev = csr.device
     q = _as_query(query, dev)
@@ -265,6 +274,8 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     per_member = 8 if fused_rows else 12
     chunk = max(1, min(n, int(staging_bytes // (stride * per_member)), (1 << 31) - 16)) if n else 0
     lazy = bool(lazy and dedup and n > 0 and chunk == n)
+    if strided and not (fused_rows and n > 0 and chunk == n):
+        return None
 
     rng_pos, rng_seed = _rng_positions(L, cfg, csr, q, n, rng_streams, calls_before, st)
     table = None
@@ -297,7 +308,8 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
                                           ptr(rng_seed[lo:]) if rng_seed is not None else None,
                                           ptr(st_ids), ptr(st_aux), ptr(nsize[lo:]),
                                           ptr(walks[lo:]) if walks is not None else None, ptr(flags), st))
-        check(L.subgacc_exclusive_scan_i32(ptr(nsize[lo:]), cn, ptr(off_chunk), ptr(scan_ws), scan_ws.numel(), st))
+        if not strided:
+            check(L.subgacc_exclusive_scan_i32(ptr(nsize[lo:]), cn, ptr(off_chunk), ptr(scan_ws), scan_ws.numel(), st))
         numbered_early = fused_rows and chunk == n
         if numbered_early:    # one chunk: the table is complete -> number it now and let the copy emit SFptr+1
             count = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -307,6 +319,13 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
             with _timed("uniq_rows"):
                 check(L.subgacc_uniq_number(ptr(table), uniq_capacity, None, 0, ptr(ukeys), max_unique, ptr(count), limit,
                                             ptr(nws), nws.numel(), st))
+        if strided:           # rows are joined from the staging arrays themselves
+            sets = SampledSets(nsize, None, st_ids, None, None, ukeys, M, m, stride, None)
+            sets.slot, sets.table, sets.capacity, sets.strided = st_aux, table, uniq_capacity, True
+            sets.status = torch.cat([flags.long(), count, nsize.sum(dtype=torch.int64).view(1)])
+            if not lazy:
+                sets.resolve()
+            return sets
         # packed arrays: exact size (one 8-byte host read) or, lazily, the upper bound n*stride
         total = cn * stride if lazy else int(off_chunk[cn].item())
         ids_c = torch.empty(total, dtype=torch.int32, device=dev)

@@ -101,16 +101,60 @@ class SpG:
                              shape=self.shape)
 
 
+class StridedSpG:
+    """The SpG of a transient batch in the layout the fused walk kernel writes: row i = indices / slot
+    [i*stride, +nsize[i]), node ids ascending, payload = slot in the numbered table of distinct LP rows.
+    `gather` / `hgather` join straight from it (subgacc_sjoin_*_rows); to_csr() makes the packed SpG."""
+
+    def __init__(self, sets, n_cols):
+        assert sets.strided
+        self.sets = sets
+        self.indices, self.slot, self.nsize = sets.ids, sets.slot, sets.nsize
+        self.stride = self.max_len = int(sets.stride)
+        self.table, self.capacity = sets.table, sets.capacity
+        self.n_rows = sets.nsize.numel()
+        self.shape = (self.n_rows, n_cols)
+        self.device = sets.ids.device
+
+    @property
+    def max_data(self):
+        """largest SFptr+1 a member can carry: the distinct-row count (its capacity bound while the sets are lazy)"""
+        return self.sets.ukeys.numel()
+
+    @property
+    def nnz(self):
+        return self.sets.X
+
+    def to_csr(self):
+        n, dev = self.n_rows, self.device
+        row_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        ws = torch.empty(max(lib().subgacc_scan_workspace_bytes(n), 8), dtype=torch.uint8, device=dev)
+        check(lib().subgacc_exclusive_scan_i32(ptr(self.nsize), n, ptr(row_off), ptr(ws), ws.numel(), stream_ptr()))
+        X = int(row_off[-1].item()) if n else 0
+        ids = torch.empty(X, dtype=torch.int32, device=dev)
+        data = torch.empty(X, dtype=torch.int32, device=dev)
+        if X:
+            check(lib().subgacc_compact_rows(ptr(self.indices), ptr(self.slot), ptr(self.nsize), ptr(row_off), n, self.stride,
+                                             ptr(ids), ptr(data), ptr(self.table), self.capacity, stream_ptr()))
+        return SpG(row_off, ids, data, max_len=self.stride, shape=self.shape, max_data=self.max_data)
+
+
 def sample_spg(csr, query, num_walks=200, num_steps=3, seed=111413, rng="rand_r", bucket=-1, fused=None, lazy=False,
-               **kw):
+               strided=False, **kw):
     """sample -> SpG on the GPU: (SpG, SampledSets) -- the sets carry ukeys / nsize / feature_table().
 
     `num_steps` = walk hops (gset_sampler's meaning).  fused=True lets the walk kernel emit finished SpG rows
     (csrc/walk.hip SPG mode; falls back to the general pipeline when it does not apply); fused=None picks it for
     walks of >= 3 hops, where the per-root epilogue hides behind the walk's line fetches (measured: +10 % pairs/s
     on the cit2-like graph at 3 hops, -9 % on the collab-like graph at 2 hops).  lazy=True leaves every size on the
-    device (no host round trip until SampledSets.resolve() / SpG.nnz); arrays are capacity-sized."""
+    device (no host round trip until SampledSets.resolve() / SpG.nnz); arrays are capacity-sized.
+    strided=True: for a batch that is sampled, joined and dropped -- returns a StridedSpG (no packed copy of the rows)."""
     sets = None
+    if strided:     # transient batch: rows stay in the walk kernel's own layout (falls through when it does not apply)
+        sets = sample_sets(csr, query, num_walks=num_walks, num_steps=num_steps, bucket=bucket, seed=seed, rng=rng,
+                           fused_rows=True, lazy=lazy, strided=True, **kw)
+        if sets is not None:
+            return StridedSpG(sets, csr.num_nodes), sets
     if fused is None:
         fused = num_steps >= 3
     if fused:

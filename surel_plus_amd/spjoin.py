@@ -14,13 +14,13 @@ import torch
 from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
 from .sampler import _timed
-from .spg import SpG
+from .spg import SpG, StridedSpG
 
 _scipy_cache = weakref.WeakKeyDictionary()
 
 
 def _as_spg(x):
-    if isinstance(x, SpG):
+    if isinstance(x, (SpG, StridedSpG)):
         return x
     try:
         hit = _scipy_cache.get(x)
@@ -61,6 +61,8 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
     own, partner = own.contiguous(), partner.contiguous()
     seg = torch.empty(S + 1, dtype=torch.int64, device=dev)
     ws = torch.empty(L.subgacc_sjoin_workspace_bytes(S), dtype=torch.uint8, device=dev)
+    if isinstance(spg, StridedSpG):
+        return _sjoin_strided(spg, own, partner, seg, ws, encode, ptr_mode, return_index, pair_block, out, lazy)
     check(L.subgacc_sjoin_sizes(ptr(spg.indptr), ptr(own), S, ptr(seg), ptr(ws), ws.numel(), st))
     is_f64 = spg.data.dtype == torch.float64
     if lazy and (out is None or not ptr_mode or return_index or is_f64 or encode is None):
@@ -103,6 +105,47 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
                                        ptr(seg), ptr(enc), enc.shape[0], k, ptr(out), None, ptr(segid), spg.max_len,
                                        pair_block, ptr(flags), st))
     return out, (seg if ptr_mode else segid), flags
+
+
+def _sjoin_strided(spg, own, partner, seg, ws, encode, ptr_mode, return_index, pair_block, out, lazy):
+    """sjoin over a StridedSpG (rows where the fused walk kernel left them): mirrored lists, segment pointers."""
+    L, dev, st, S = lib(), spg.device, stream_ptr(), own.numel()
+    if pair_block <= 0 or not ptr_mode:
+        raise ValueError("a StridedSpG is joined by gather / hgather with segment pointers; use .to_csr() for the other forms")
+    check(L.subgacc_sjoin_sizes_rows(ptr(spg.nsize), ptr(own), S, ptr(seg), ptr(ws), ws.numel(), st))
+    flags = torch.zeros(4, dtype=torch.int32, device=dev)
+    R = None if lazy else int(seg[S].item())
+    if return_index:
+        if lazy:
+            raise ValueError("lazy=True needs the encode table")
+        res = torch.empty((R, 2), dtype=torch.int32, device=dev)
+        check(L.subgacc_sjoin_fill_rows(ptr(spg.nsize), spg.stride, ptr(spg.indices), ptr(spg.slot), ptr(spg.table),
+                                        spg.capacity, ptr(own), ptr(partner), S, ptr(seg), None, 0, 0, None, ptr(res),
+                                        pair_block, ptr(flags), st))
+        return res, seg, flags
+    if encode is None:
+        raise NotImplementedError("an integer SpG needs the encode table")
+    enc = encode.to(device=dev, dtype=torch.float32).contiguous()
+    k = enc.shape[1]
+    if enc.shape[0] <= spg.max_data:
+        raise IndexError(f"index {spg.max_data} is out of bounds for the encode table with {enc.shape[0]} rows")
+    if lazy:
+        if out is None or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev or \
+                out.numel() < S * spg.max_len * 2 * k:
+            raise ValueError("lazy out= must hold S * SpG.max_len * 2 * k float32 on the SpG's device")
+        rows = out.numel() // (2 * k)
+        res = out.view(-1)[: rows * 2 * k].view(rows, 2, k)
+    elif out is not None:
+        if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() < R * 2 * k or out.device != dev:
+            raise ValueError("out= must be a contiguous float32 buffer on the SpG's device with >= R*2*k elements")
+        res = out.view(-1)[: R * 2 * k].view(R, 2, k)
+    else:
+        res = torch.empty((R, 2, k), dtype=torch.float32, device=dev)
+    with _timed("sjoin_fill"):
+        check(L.subgacc_sjoin_fill_rows(ptr(spg.nsize), spg.stride, ptr(spg.indices), ptr(spg.slot), ptr(spg.table),
+                                        spg.capacity, ptr(own), ptr(partner), S, ptr(seg), ptr(enc), enc.shape[0], k,
+                                        ptr(res), None, pair_block, ptr(flags), st))
+    return res, seg, flags
 
 
 # SpG.max_len / SpG.max_data make the kernel's own guards (flags[3]) unreachable; SUBGACC_DEBUG=1 reads them back

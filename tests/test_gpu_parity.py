@@ -732,3 +732,44 @@ def test_gather_rows_longer_than_lds(sp, payload):
             xz, ind = fn(edge, z, "cuda", ptr=ptr, encode=enc_d)
             np.testing.assert_array_equal(ind.cpu().numpy(), want_ind)
             np.testing.assert_array_equal(xz.cpu().numpy(), want_xz)
+
+
+# ------------------------------------------------------------------------------- join straight from strided rows
+@pytest.mark.parametrize("lazy", [False, True])
+@pytest.mark.parametrize("M,m", [(50, 3), (200, 2), (16, 4)])
+def test_strided_spg_join_matches_csr_path(sp, lazy, M, m):
+    """sample_spg(strided=True) + gather / hgather == the packed-SpG path, bit for bit; to_csr() == the packed SpG"""
+    indptr, indices = sym_graph(6000, 30000, 51, hubs=2)
+    csr = sp.DeviceCSR(indptr, indices)
+    rng = np.random.default_rng(1)
+    roots = torch.from_numpy(rng.integers(0, 6000, 700).astype(np.int32)).cuda()       # repeated roots included
+    zs, sets_s = sp.sample_spg(csr, roots, num_walks=M, num_steps=m, rng="philox", lazy=lazy, strided=True)
+    zc, sets_c = sp.sample_spg(csr, roots, num_walks=M, num_steps=m, rng="philox", fused=True)
+    assert isinstance(zs, sp.StridedSpG)
+    table = sets_c.feature_table()
+    assert torch.equal(sets_s.feature_table()[: table.shape[0]], table)
+    z2 = zs.to_csr()
+    assert torch.equal(z2.indptr, zc.indptr) and torch.equal(z2.indices, zc.indices) and torch.equal(z2.data, zc.data)
+    assert sets_s.X == sets_c.X and sets_s.c == sets_c.c and zs.nnz == zc.nnz
+    edge = torch.from_numpy(rng.integers(0, 700, (2, 400))).cuda()
+    edge[:, 0] = 5                                                                        # (u, u)
+    xz_c, ind_c = sp.gather(edge, zc, "cuda", ptr=True, encode=table)
+    xz_s, ind_s = sp.gather(edge, zs, "cuda", ptr=True, encode=sets_s.feature_table())
+    assert torch.equal(ind_s, ind_c) and torch.equal(xz_s, xz_c)
+    buf = torch.empty(2 * 400 * zs.max_len * 2 * table.shape[1], dtype=torch.float32, device="cuda")
+    xz_l, ind_l = sp.gather(edge, zs, "cuda", ptr=True, encode=sets_s.feature_table(), out=buf, lazy=True)
+    assert torch.equal(ind_l, ind_c) and torch.equal(xz_l[: xz_c.shape[0]], xz_c)
+    hedge = torch.from_numpy(rng.integers(0, 700, (3, 100))).cuda()
+    hx_c, hid_c = sp.hgather(hedge, zc, "cuda", encode=table)
+    hx_s, hid_s = sp.hgather(hedge, zs.to_csr(), "cuda", encode=table)
+    assert torch.equal(hx_s, hx_c) and torch.equal(hid_s, hid_c)
+    with pytest.raises(ValueError):
+        sp.gather(edge, zs, "cuda", ptr=False, encode=table)                           # segment ids: packed form only
+
+
+def test_strided_falls_back_when_it_does_not_apply(sp):
+    indptr, indices = sym_graph(2000, 8000, 52)
+    csr = sp.DeviceCSR(indptr, indices)
+    roots = torch.arange(100, dtype=torch.int32, device="cuda")
+    z, sets = sp.sample_spg(csr, roots, num_walks=300, num_steps=4, rng="philox", strided=True)   # M*m+1 = 1201 > 818
+    assert isinstance(z, sp.SpG) and not sets.strided
