@@ -104,7 +104,7 @@ def hot_path_step(sp, csr, edge, M, k, seed, rng, slot=0):
     roots = edge.reshape(-1).to(torch.int32)
     strided = (k - 1 >= 3 and FUSED is not False) if STRIDED is None else STRIDED
     z, sets = sp.sample_spg(csr, roots, num_walks=M, num_steps=k - 1, seed=seed, rng=rng, fused=FUSED, lazy=LAZY, strided=strided)
-    table = sets.feature_table()
+    table = z.slot_table() if sets.strided else sets.feature_table()
     rows = torch.arange(2 * B, device=edge.device, dtype=torch.int64).view(2, B)   # row i = root i of this batch
     # the join output is written into re-used buffers sized for the worst case (every set full), two of them in
     # turn so that step s+1 never overwrites what step s handed out: a serving loop would do the same, and it keeps

@@ -208,7 +208,8 @@ int subgacc_sjoin_fill(const int64_t *spg_indptr, const int32_t *spg_indices, co
 /* The same join over STRIDED rows -- the form subgacc_walk_spg leaves its output in: row r = row_ids / row_slot
  * [r*row_stride, +row_len[r]), sorted by node id, payload = slot in `uniq_table` (numbered by subgacc_uniq_number).
  * A transient batch is joined straight from there: no packed CSR copy (subgacc_compact_rows) is made, slots become
- * SFptr+1 on their way into LDS.  Mirrored segment lists only (pair_block > 0); out_idx optional as above. */
+ * SFptr+1 on their way into LDS.  uniq_table = NULL: `table` is indexed by slot+1 itself (subgacc_unpack_lp over the
+ * table's key plane, zero_row = 1) and no numbering is consulted.  Mirrored segment lists only (pair_block > 0). */
 int subgacc_sjoin_sizes_rows(const int32_t *row_len, const int64_t *own, int64_t S, int64_t *out_seg, void *workspace,
                              size_t workspace_bytes, void *stream);
 int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t row_stride, const int32_t *row_ids, const int32_t *row_slot,

@@ -40,7 +40,8 @@ struct JoinArgs {
     // strided rows (subgacc_sjoin_*_rows): row r = [r*row_stride, +row_len[r]) of indices / data, data = table slots
     const int32_t *row_len;
     int64_t row_stride;
-    const int32_t *slot_id;   // slot -> SFptr (id plane of the numbered table of distinct LP rows)
+    const int32_t *slot_id;   // slot -> SFptr (id plane of the numbered table of distinct LP rows); NULL with
+    int32_t val_add;          // val_add = 1: the feature table is indexed by slot + 1 itself (row 0 = absent)
 };
 
 __device__ __forceinline__ void join_row(const JoinArgs &a, int64_t r, int64_t &beg, int64_t &len) {
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(kPairThreads) void sjoin_pair_kernel(const JoinArgs
         idsA[r] = a.indices[ab + r];
         Val v = data[ab + r];
         if (xl) v = (Val)(a.slot_id[(int32_t)v] + 1);
+        else if (!F64) v = (Val)((int32_t)v + a.val_add);
         valA[r] = v;
     }
     if (ra != rb) {
@@ -209,6 +211,7 @@ __global__ __launch_bounds__(kPairThreads) void sjoin_pair_kernel(const JoinArgs
             idsB[r] = a.indices[bb + r];
             Val v = data[bb + r];
             if (xl) v = (Val)(a.slot_id[(int32_t)v] + 1);
+            else if (!F64) v = (Val)((int32_t)v + a.val_add);
             valB[r] = v;
         }
     } else {   // (u,u): the second row is the first
@@ -367,7 +370,7 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, const int32_t *spg_
     a.out_xz = out_xz, a.out_idx = out_idx, a.out_segid = out_segid;
     a.max_len = max_len > 0 ? max_len : 1;
     a.flags = flags;
-    a.row_len = nullptr, a.row_stride = 0, a.slot_id = nullptr;
+    a.row_len = nullptr, a.row_stride = 0, a.slot_id = nullptr, a.val_add = 0;
     SG_REQUIRE(pair_block >= 0 && (pair_block == 0 || S % (2 * pair_block) == 0), SUBGACC_ERR_BADARG,
                "sjoin_fill: S = %lld is not a multiple of 2*pair_block", (long long)S);
     bool paired = pair_block > 0;
@@ -425,7 +428,7 @@ extern "C" int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t row_strid
                                        int32_t *out_idx, int64_t pair_block, int32_t *flags, void *stream) {
     SG_REQUIRE(S >= 0 && flags && row_stride > 0 && row_stride < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_fill_rows: bad arguments");
     if (S == 0) return SUBGACC_OK;
-    SG_REQUIRE(row_len && row_ids && row_slot && uniq_table && uniq_capacity > 0 && own && partner && seg,
+    SG_REQUIRE(row_len && row_ids && row_slot && (!uniq_table || uniq_capacity > 0) && own && partner && seg,
                SUBGACC_ERR_BADARG, "sjoin_fill_rows: null argument");
     SG_REQUIRE(out_xz || out_idx, SUBGACC_ERR_BADARG, "sjoin_fill_rows: no output requested");
     SG_REQUIRE(!out_xz || (table && table_rows > 0 && k > 0 && k <= 16), SUBGACC_ERR_BADARG,
@@ -440,7 +443,9 @@ extern "C" int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t row_strid
     a.max_len = (int32_t)row_stride;
     a.flags = flags;
     a.row_len = row_len, a.row_stride = row_stride;
-    a.slot_id = (const int32_t *)((const char *)uniq_table + (size_t)uniq_capacity * 16);   // id plane (uniq_table.hpp)
+    // numbered table given: slot -> SFptr+1 through its id plane (uniq_table.hpp); else the table is indexed by slot+1
+    a.slot_id = uniq_table ? (const int32_t *)((const char *)uniq_table + (size_t)uniq_capacity * 16) : nullptr;
+    a.val_add = uniq_table ? 0 : 1;
     const size_t lds = (size_t)a.max_len * 16;
     SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "sjoin_fill_rows: rows of %lld members do not fit LDS",
                (long long)row_stride);
@@ -478,7 +483,7 @@ extern "C" int subgacc_sjoin_counts(const int64_t *spg_indptr, const int32_t *sp
     a.out_xz = nullptr, a.out_idx = nullptr, a.out_segid = nullptr;
     a.max_len = max_len > 0 ? max_len : 1;
     a.flags = flags;
-    a.row_len = nullptr, a.row_stride = 0, a.slot_id = nullptr;
+    a.row_len = nullptr, a.row_stride = 0, a.slot_id = nullptr, a.val_add = 0;
     const size_t lds = (size_t)a.max_len * 16 + (size_t)table_rows * 8;
     SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS,
                "sjoin_counts: %lld distinct LP rows and rows of %d members need %zu B of LDS; use sjoin_fill",

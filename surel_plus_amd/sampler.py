@@ -193,6 +193,18 @@ class SampledSets:
         return out
 
 
+    def feature_table_by_slot(self):
+        """float32 [capacity+1, m+1]: row s+1 = enc/M of the LP row held in slot s of the table of distinct rows, row 0
+        (and the rows of free slots, never indexed) zero -- Z_SF without the numbering, for joins over table slots."""
+        if self.table is None:
+            raise ValueError("no table of distinct LP rows (sample_sets(..., dedup=True))")
+        keys = self.table[: self.capacity * 8].view(torch.int64)
+        out = torch.empty((self.capacity + 1, self.num_steps + 1), dtype=torch.float32, device=self.ids.device)
+        check(lib().subgacc_unpack_lp(ptr(keys), self.capacity, None, self.num_walks, self.num_steps, None, None, ptr(out), 1,
+                                      stream_ptr()))
+        return out
+
+
 def make_cfg(csr, num_walks, num_steps, bucket=-1, seed=111413, rng="rand_r", first_hop_wo=True,
              order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False):
     rng_mode = {"rand_r": _lib.RNG_RAND_R, "philox": _lib.RNG_PHILOX}[rng]

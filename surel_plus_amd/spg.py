@@ -112,9 +112,16 @@ class StridedSpG:
         self.indices, self.slot, self.nsize = sets.ids, sets.slot, sets.nsize
         self.stride = self.max_len = int(sets.stride)
         self.table, self.capacity = sets.table, sets.capacity
+        self._slot_table = None
         self.n_rows = sets.nsize.numel()
         self.shape = (self.n_rows, n_cols)
         self.device = sets.ids.device
+
+    def slot_table(self):
+        """The feature table indexed by table slot (SampledSets.feature_table_by_slot): pass it as `encode` and the
+        join skips the slot -> SFptr indirection altogether."""
+        self._slot_table = self.sets.feature_table_by_slot()
+        return self._slot_table
 
     @property
     def max_data(self):

@@ -125,10 +125,12 @@ def _sjoin_strided(spg, own, partner, seg, ws, encode, ptr_mode, return_index, p
         return res, seg, flags
     if encode is None:
         raise NotImplementedError("an integer SpG needs the encode table")
-    enc = encode.to(device=dev, dtype=torch.float32).contiguous()
+    by_slot = encode is spg._slot_table and encode is not None      # StridedSpG.slot_table(): indexed by slot + 1
+    enc = encode if by_slot else encode.to(device=dev, dtype=torch.float32).contiguous()
     k = enc.shape[1]
-    if enc.shape[0] <= spg.max_data:
+    if not by_slot and enc.shape[0] <= spg.max_data:
         raise IndexError(f"index {spg.max_data} is out of bounds for the encode table with {enc.shape[0]} rows")
+    tab, cap = (None, 0) if by_slot else (spg.table, spg.capacity)
     if lazy:
         if out is None or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev or \
                 out.numel() < S * spg.max_len * 2 * k:
@@ -142,8 +144,8 @@ def _sjoin_strided(spg, own, partner, seg, ws, encode, ptr_mode, return_index, p
     else:
         res = torch.empty((R, 2, k), dtype=torch.float32, device=dev)
     with _timed("sjoin_fill"):
-        check(L.subgacc_sjoin_fill_rows(ptr(spg.nsize), spg.stride, ptr(spg.indices), ptr(spg.slot), ptr(spg.table),
-                                        spg.capacity, ptr(own), ptr(partner), S, ptr(seg), ptr(enc), enc.shape[0], k,
+        check(L.subgacc_sjoin_fill_rows(ptr(spg.nsize), spg.stride, ptr(spg.indices), ptr(spg.slot), ptr(tab), cap,
+                                        ptr(own), ptr(partner), S, ptr(seg), ptr(enc), enc.shape[0], k,
                                         ptr(res), None, pair_block, ptr(flags), st))
     return res, seg, flags
 

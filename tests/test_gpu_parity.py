@@ -759,6 +759,8 @@ def test_strided_spg_join_matches_csr_path(sp, lazy, M, m):
     buf = torch.empty(2 * 400 * zs.max_len * 2 * table.shape[1], dtype=torch.float32, device="cuda")
     xz_l, ind_l = sp.gather(edge, zs, "cuda", ptr=True, encode=sets_s.feature_table(), out=buf, lazy=True)
     assert torch.equal(ind_l, ind_c) and torch.equal(xz_l[: xz_c.shape[0]], xz_c)
+    xz_t, ind_t = sp.gather(edge, zs, "cuda", ptr=True, encode=zs.slot_table())        # table indexed by slot: no numbering used
+    assert torch.equal(ind_t, ind_c) and torch.equal(xz_t, xz_c)
     hedge = torch.from_numpy(rng.integers(0, 700, (3, 100))).cuda()
     hx_c, hid_c = sp.hgather(hedge, zc, "cuda", encode=table)
     hx_s, hid_s = sp.hgather(hedge, zs.to_csr(), "cuda", encode=table)
