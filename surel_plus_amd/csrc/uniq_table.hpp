@@ -45,13 +45,15 @@ __device__ __forceinline__ int32_t uniq_global_insert(const UniqTable &t, unsign
                                                       int32_t *flags) {
     uint64_t h = mix64(key) & t.mask;
     for (uint64_t probes = 0; probes <= t.mask && probes < kMaxProbes; ++probes) {
-        // agent-scope (L2) load: another CU may have claimed the slot; this CU's L1 copy could be stale
-        unsigned long long cur = __hip_atomic_load(&t.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Plain (cacheable) loads first.  A slot's key never changes once set and its tag only decreases, so a stale
+        // copy in this XCD's L2 / this CU's L1 can only make us take the atomic path below once more than needed --
+        // never skip a needed one: stale "empty" -> the CAS returns the real content; stale larger tag -> a redundant
+        // atomicMin.  (Device-scope loads, the first version, leave the XCD for the fabric every time: two serial
+        // ~2 us round trips per distinct LP row in every root's epilogue.)
+        unsigned long long cur = t.keys[h];
         if (cur == kEmptyKey) cur = atomicCAS(&t.keys[h], kEmptyKey, key);
         if (cur == kEmptyKey || cur == key) {
-            // the coherent pre-check removes nearly every atomic once the early positions are in
-            if (__hip_atomic_load(&t.mintag[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > tag)
-                atomicMin(&t.mintag[h], tag);
+            if (t.mintag[h] > tag) atomicMin(&t.mintag[h], tag);
             return (int32_t)h;
         }
         h = (h + 1) & t.mask;
