@@ -215,7 +215,8 @@ int subgacc_sjoin_sizes_rows(const int32_t *row_len, const int64_t *own, int64_t
 int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t row_stride, const int32_t *row_ids, const int32_t *row_slot,
                             const void *uniq_table, int64_t uniq_capacity, const int64_t *own, const int64_t *partner,
                             int64_t S, const int64_t *seg, const float *table, int64_t table_rows, int32_t k,
-                            float *out_xz, int32_t *out_idx, int64_t pair_block, int32_t *flags, void *stream);
+                            float *out_xz, int32_t *out_idx, int64_t *out_segid, int64_t pair_block, int32_t *flags,
+                            void *stream);
 
 /* Count form of the join (SpJoin fused with the first model stage, model.py:78-83).
  * out_counts f32 [S, table_rows]: out_counts[j][p] = number of times LP row p (SFptr+1, 0 = partner absent) occurs

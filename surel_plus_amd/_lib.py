@@ -103,7 +103,7 @@ def lib():
     sig["subgacc_ppr_encode"] = (C.c_int, [vp, i64, vp, vp, vp])
     sig["subgacc_walk_join"] = (C.c_int, [vp, i64, i32, vp, vp, vp, i32, vp, i64, vp, vp])
     sig["subgacc_sjoin_sizes_rows"] = (C.c_int, [vp, vp, i64, vp, vp, sz, vp])
-    sig["subgacc_sjoin_fill_rows"] = (C.c_int, [vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, vp, i64, i32, vp, vp, i64, vp, vp])
+    sig["subgacc_sjoin_fill_rows"] = (C.c_int, [vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, i64, vp, vp])
     assert set(sig) == set(SYMBOLS)
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -425,7 +425,8 @@ extern "C" int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t row_strid
                                        const int32_t *row_slot, const void *uniq_table, int64_t uniq_capacity,
                                        const int64_t *own, const int64_t *partner, int64_t S, const int64_t *seg,
                                        const float *table, int64_t table_rows, int32_t k, float *out_xz,
-                                       int32_t *out_idx, int64_t pair_block, int32_t *flags, void *stream) {
+                                       int32_t *out_idx, int64_t *out_segid, int64_t pair_block, int32_t *flags,
+                                       void *stream) {
     SG_REQUIRE(S >= 0 && flags && row_stride > 0 && row_stride < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_fill_rows: bad arguments");
     if (S == 0) return SUBGACC_OK;
     SG_REQUIRE(row_len && row_ids && row_slot && (!uniq_table || uniq_capacity > 0) && own && partner && seg,
@@ -439,7 +440,7 @@ extern "C" int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t row_strid
     a.indptr = nullptr, a.indices = row_ids, a.data = row_slot;
     a.own = own, a.partner = partner, a.seg = seg, a.S = S;
     a.table = table, a.table_rows = table_rows, a.k = k;
-    a.out_xz = out_xz, a.out_idx = out_idx, a.out_segid = nullptr;
+    a.out_xz = out_xz, a.out_idx = out_idx, a.out_segid = out_segid;
     a.max_len = (int32_t)row_stride;
     a.flags = flags;
     a.row_len = row_len, a.row_stride = row_stride;

@@ -110,19 +110,22 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
 def _sjoin_strided(spg, own, partner, seg, ws, encode, ptr_mode, return_index, pair_block, out, lazy):
     """sjoin over a StridedSpG (rows where the fused walk kernel left them): mirrored lists, segment pointers."""
     L, dev, st, S = lib(), spg.device, stream_ptr(), own.numel()
-    if pair_block <= 0 or not ptr_mode:
-        raise ValueError("a StridedSpG is joined by gather / hgather with segment pointers; use .to_csr() for the other forms")
+    if pair_block <= 0:
+        raise ValueError("a StridedSpG is joined by gather / hgather (mirrored segment lists); use .to_csr() for the other forms")
+    if lazy and not ptr_mode:
+        raise ValueError("lazy=True needs ptr=True")
     check(L.subgacc_sjoin_sizes_rows(ptr(spg.nsize), ptr(own), S, ptr(seg), ptr(ws), ws.numel(), st))
     flags = torch.zeros(4, dtype=torch.int32, device=dev)
     R = None if lazy else int(seg[S].item())
+    segid = None if ptr_mode else torch.empty(R, dtype=torch.int64, device=dev)
     if return_index:
         if lazy:
             raise ValueError("lazy=True needs the encode table")
         res = torch.empty((R, 2), dtype=torch.int32, device=dev)
         check(L.subgacc_sjoin_fill_rows(ptr(spg.nsize), spg.stride, ptr(spg.indices), ptr(spg.slot), ptr(spg.table),
                                         spg.capacity, ptr(own), ptr(partner), S, ptr(seg), None, 0, 0, None, ptr(res),
-                                        pair_block, ptr(flags), st))
-        return res, seg, flags
+                                        ptr(segid), pair_block, ptr(flags), st))
+        return res, (seg if ptr_mode else segid), flags
     if encode is None:
         raise NotImplementedError("an integer SpG needs the encode table")
     by_slot = encode is spg._slot_table and encode is not None      # StridedSpG.slot_table(): indexed by slot + 1
@@ -146,8 +149,8 @@ def _sjoin_strided(spg, own, partner, seg, ws, encode, ptr_mode, return_index, p
     with _timed("sjoin_fill"):
         check(L.subgacc_sjoin_fill_rows(ptr(spg.nsize), spg.stride, ptr(spg.indices), ptr(spg.slot), ptr(tab), cap,
                                         ptr(own), ptr(partner), S, ptr(seg), ptr(enc), enc.shape[0], k,
-                                        ptr(res), None, pair_block, ptr(flags), st))
-    return res, seg, flags
+                                        ptr(res), None, ptr(segid), pair_block, ptr(flags), st))
+    return res, (seg if ptr_mode else segid), flags
 
 
 # SpG.max_len / SpG.max_data make the kernel's own guards (flags[3]) unreachable; SUBGACC_DEBUG=1 reads them back

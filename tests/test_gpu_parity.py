@@ -763,10 +763,17 @@ def test_strided_spg_join_matches_csr_path(sp, lazy, M, m):
     assert torch.equal(ind_t, ind_c) and torch.equal(xz_t, xz_c)
     hedge = torch.from_numpy(rng.integers(0, 700, (3, 100))).cuda()
     hx_c, hid_c = sp.hgather(hedge, zc, "cuda", encode=table)
-    hx_s, hid_s = sp.hgather(hedge, zs.to_csr(), "cuda", encode=table)
-    assert torch.equal(hx_s, hx_c) and torch.equal(hid_s, hid_c)
+    for zz, tb in ((zs.to_csr(), table), (zs, sets_s.feature_table()), (zs, zs.slot_table())):
+        hx_s, hid_s = sp.hgather(hedge, zz, "cuda", encode=tb)
+        assert torch.equal(hx_s, hx_c) and torch.equal(hid_s, hid_c)
+    xz_i, ind_i = sp.gather(edge, zs, "cuda", ptr=False, encode=sets_s.feature_table())     # segment ids
+    xz_ci, ind_ci = sp.gather(edge, zc, "cuda", ptr=False, encode=table)
+    assert torch.equal(xz_i, xz_ci) and torch.equal(ind_i, ind_ci)
+    cnt_c, sz_c = sp.gather_counts(edge, zc, table.shape[0])
+    cnt_s, sz_s = sp.gather_counts(edge, zs.to_csr(), table.shape[0])
+    assert torch.equal(cnt_s, cnt_c) and torch.equal(sz_s, sz_c)
     with pytest.raises(ValueError):
-        sp.gather(edge, zs, "cuda", ptr=False, encode=table)                           # segment ids: packed form only
+        sp.sjoin(zs, edge[0].contiguous(), edge[1].contiguous(), table)                # unpaired lists: packed form only
 
 
 def test_strided_falls_back_when_it_does_not_apply(sp):
