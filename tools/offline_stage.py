@@ -20,16 +20,29 @@ class G:
 def sync_time(fn):
     torch.cuda.synchronize(); t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize(); return time.perf_counter() - t0, out
 
-for _ in range(2):
+z = enc = None
+for _ in range(3):
+    del z, enc          # the previous store goes back to the allocator first: steady state, no fresh GB-sized hipMalloc
     t_dev, (z, enc) = sync_time(lambda: sp.subg_matrix(csr, torch.arange(N, dtype=torch.int32, device="cuda"), M, k, rng="philox"))
 t_host_in, (z2, enc2) = sync_time(lambda: sp.subg_matrix(G, idx, M, k))            # numpy CSR in (uploaded), rand_r mode
 t_api, out = sync_time(lambda: sp.gset_sampler(ptr_h, idx_h, idx, num_walks=M, num_steps=k - 1))   # numpy in / numpy out
+# join throughput from the resident SpG (J of SURVEY 8(d)): 20 batches of 65,536 pairs, output buffer re-used
+from surel_plus_amd.graphs import query_pairs
+tab = torch.from_numpy(enc).to("cuda").float() / M
+edges = [query_pairs(csr, 65536, seed=s, device="cuda") for s in range(22)]
+buf = torch.empty(2 * 65536 * z.max_len * 2 * tab.shape[1], dtype=torch.float32, device="cuda")
+for e in edges[:2]:
+    sp.gather(e, z, "cuda", ptr=True, encode=tab, out=buf, lazy=True)
+t_join, _ = sync_time(lambda: [sp.gather(e, z, "cuda", ptr=True, encode=tab, out=buf, lazy=True) for e in edges[2:]])
+J = 20 * 65536 / t_join
+print(f"  join from the resident SpG: {J / 1e6:.1f} M pairs/s; amortised (sample all N once + 1e8 pairs): "
+      f"{1e8 / (t_dev + 1e8 / J) / 1e6:.1f} M pairs/s")
 print(f"{name}: N={N} nnz={csr.nnz} M={M} --num_steps {k}: set members {z.nnz}, distinct LP rows {enc.shape[0] - 1}")
 print(f"  subg_matrix, graph resident (philox):        {t_dev:8.3f} s  = {N / t_dev / 1e6:7.2f} M roots/s")
 print(f"  subg_matrix, numpy CSR in (rand_r, exact):   {t_host_in:8.3f} s")
 print(f"  gset_sampler drop-in (numpy in, numpy out):  {t_api:8.3f} s")
 ref = oracle.ref_module()
-if ref is not None and ptr_h.dtype == np.int32:
+if ref is not None and ptr_h.dtype == np.int32 and os.environ.get('SKIP_REF', '0') != '1':
     for nt in (8, 16, -1):
         t0 = time.perf_counter()
         with quiet_stdout():
