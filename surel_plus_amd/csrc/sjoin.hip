@@ -9,6 +9,9 @@
 // feature pair straight from the Z_SF table (L2-resident, a few KB..MB) -- the [R,2] index array of the
 // reference never exists in memory unless asked for.
 #include "common.hpp"
+#ifndef SJ_EXPERIMENT
+#define SJ_EXPERIMENT 0   // dev-only timing variants, see tools/ab_sjoin.sh
+#endif
 
 namespace subgacc {
 
@@ -70,6 +73,9 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
         va = own_val[t];
     }
     int lo = 0, hi = live ? nb : 0;
+#if SJ_EXPERIMENT == 1   // timing experiment: no search (results are wrong)
+    hi = 0;
+#endif
     while (lo < hi) {   // sorted-set intersection: lower bound in the partner row
         const int mid = (lo + hi) >> 1;
         if (pids[mid] < id) lo = mid + 1;
@@ -110,7 +116,13 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
                     const int f = rnd * kWave + lane;   // float4 index inside the span
                     const int r = f >> 1;
                     const int spa = __shfl(pa, r, kWave), spb = __shfl(pb, r, kWave);
+#if SJ_EXPERIMENT == 2   // timing experiment: no output stores (results are wrong)
+                    if (r < nrows && spa == -12345) dst4[f] = tab4[(f & 1) ? spb : spa];
+#elif SJ_EXPERIMENT == 3 // timing experiment: stores without the feature-table read
+                    if (r < nrows) dst4[f] = make_float4((float)spa, (float)spb, 0.f, 0.f);
+#else
                     if (r < nrows) dst4[f] = tab4[(f & 1) ? spb : spa];
+#endif
                 }
             } else {
                 float *dst = a.out_xz + row0 * k2;
