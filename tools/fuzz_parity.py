@@ -1,0 +1,89 @@
+"""Dev-only: randomized parity sweep, HIP path vs oracle, bit-exact (usage: fuzz_parity.py [cases] [seed]).
+Every case draws a graph shape (incl. hubs, isolated nodes, directed), M, m, bucket, RNG mode, query (repeats, arbitrary
+order) and checks gset_sampler, the fused / general / strided SpG paths, walk_sampler and gather against the oracle."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["SUBGACC_QUIET"] = "1"
+import numpy as np, scipy.sparse as sps, torch
+import oracle
+import surel_plus_amd as sp
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+only = int(sys.argv[3]) if len(sys.argv) > 3 else None          # re-run one case verbosely
+bad = skipped = 0
+t0 = time.time()
+for c in range(cases):
+    if only is not None and c != only:
+        continue
+    rng0 = np.random.default_rng([seed0, c])                     # every case has its own stream: reproducible alone
+    fails = []
+    N = int(rng0.choice([50, 300, 2000, 9000]))
+    E = int(N * rng0.choice([0.5, 2, 8, 40]))
+    hubs = int(rng0.choice([0, 0, 1, 3]))
+    iso = int(rng0.choice([0, 0, 5]))
+    r, cc = rng0.integers(0, N, E), rng0.integers(0, N, E)
+    if hubs:
+        r = np.concatenate([r, np.repeat(np.arange(hubs), N // 3)])
+        cc = np.concatenate([cc, rng0.integers(0, N, hubs * (N // 3))])
+    A = sps.csr_matrix((np.ones(len(r)), (r, cc)), shape=(N + iso, N + iso))
+    A = sps.csr_matrix(A + A.T)
+    A.setdiag(0); A.eliminate_zeros(); A.sort_indices()
+    ptr_, idx = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+    M = int(rng0.choice([1, 3, 16, 64, 200, 256, 300]))
+    m = int(rng0.choice([1, 2, 3, 4, 5]))
+    if (32 - (M.bit_length() and (32 - M.bit_length()))) and m * M.bit_length() + 1 > 63:
+        m = 2
+    bucket = int(rng0.choice([-1, -1, -1, 5, 40]))
+    rng = str(rng0.choice(["rand_r", "philox"]))
+    nq = int(rng0.choice([1, 17, 400, 1500]))
+    q = rng0.integers(0, N + iso, nq)
+    seed = int(rng0.integers(0, 2**31))
+    tag = f"case {c}: N={N}+{iso} nnz={len(idx)} hubs={hubs} M={M} m={m} bucket={bucket} rng={rng} nq={nq} seed={seed}"
+    try:
+        a = sp.gset_sampler(ptr_, idx, q, num_walks=M, num_steps=m, bucket=bucket, seed=seed, debug=1, rng=rng)
+        b = oracle.gset_sampler(ptr_, idx, q, num_walks=M, num_steps=m, bucket=bucket, seed=seed, debug=True, rng=rng)
+        ok = True
+        for nm, x, y in zip(("nsize", "remap", "enc", "raw"), a, b):
+            if not np.array_equal(x, y):
+                fails.append(f"gset.{nm}")
+        (oi, ox, od) = oracle.spg_build(b[0], b[1])
+        csr = sp.DeviceCSR(ptr_, idx)
+        for kw in ({"fused": True}, {"fused": False}, {"strided": True}, {"fused": True, "lazy": True}):
+            z, sets = sp.sample_spg(csr, q, num_walks=M, num_steps=m, seed=seed, rng=rng, bucket=bucket, **kw)
+            if kw.get("lazy") and b[2].shape[0] > 16384:
+                continue        # lazy numbering ranks at most RANK_LIMIT distinct rows directly; resolve() says so
+            if isinstance(z, sp.StridedSpG):
+                z = z.to_csr()
+            X = z.nnz
+            if not (np.array_equal(z.indptr.cpu().numpy(), oi) and np.array_equal(z.indices[:X].cpu().numpy(), ox)
+                    and np.array_equal(z.data[:X].cpu().numpy(), od) and np.array_equal(sets.enc_int16().cpu().numpy(), b[2])):
+                fails.append(f"spg{kw}")
+        edge = rng0.integers(0, nq, (2, 64))
+        enc = np.insert(b[2], 0, 0, axis=0).astype(np.float32) / M
+        wxz, wind = oracle.gather_numpy(edge, (oi, ox, od), ptr=True, encode=enc)
+        zs, ss = sp.sample_spg(csr, q, num_walks=M, num_steps=m, seed=seed, rng=rng, bucket=bucket, strided=True)
+        tab = zs.slot_table() if isinstance(zs, sp.StridedSpG) else ss.feature_table()
+        xz, ind = sp.gather(edge, zs, "cuda", ptr=True, encode=tab)
+        if not (np.array_equal(ind.cpu().numpy(), wind) and np.array_equal(xz.cpu().numpy(), wxz)):
+            fails.append("gather")
+        T = int(rng0.choice([1, 3]))
+        rep = bool(rng0.integers(0, 2))
+        w1, o1 = sp.walk_sampler(ptr_, idx, q, num_walks=M, num_steps=m, nthread=T, seed=seed, replacement=rep, rng=rng)
+        w2, n2, i2, c2 = oracle.walk_sampler(ptr_, idx, q, num_walks=M, num_steps=m, nthread=T, seed=seed, replacement=rep, rng=rng)
+        if not np.array_equal(w1, w2):
+            fails.append("walks")
+        if not (np.array_equal(np.concatenate(list(o1[:, 0])), i2) and np.array_equal(np.vstack(list(o1[:, 1])), c2)):
+            fails.append("walk_sets")
+    except (RuntimeError, ValueError, AssertionError) as e:       # rand_r on a graph with dead ends is refused by design
+        if "dead end" in str(e) or "Philox" in str(e) or "philox" in str(e) or "hasing key" in str(e) or "key" in str(e).lower():
+            skipped += 1
+            continue
+        print("EXC", tag, repr(e)); bad += 1
+        continue
+    if fails:
+        print("MISMATCH", tag, fails); bad += 1
+    elif only is not None:
+        print("ok", tag)
+print(f"{cases} cases, {bad} bad, {skipped} refused by design, {time.time() - t0:.1f} s")
+sys.exit(1 if bad else 0)
