@@ -12,6 +12,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 only = int(sys.argv[3]) if len(sys.argv) > 3 else None          # re-run one case verbosely
 bad = skipped = 0
+cov = {"directed": 0, "int64": 0, "ppr": 0, "strided_join": 0, "members": 0}
 t0 = time.time()
 for c in range(cases):
     if only is not None and c != only:
@@ -27,19 +28,22 @@ for c in range(cases):
         r = np.concatenate([r, np.repeat(np.arange(hubs), N // 3)])
         cc = np.concatenate([cc, rng0.integers(0, N, hubs * (N // 3))])
     A = sps.csr_matrix((np.ones(len(r)), (r, cc)), shape=(N + iso, N + iso))
-    A = sps.csr_matrix(A + A.T)
-    A.setdiag(0); A.eliminate_zeros(); A.sort_indices()
-    ptr_, idx = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+    directed = bool(rng0.integers(0, 4) == 0)          # dead ends: Philox mode only (rand_r refuses them by design)
+    if not directed:
+        A = sps.csr_matrix(A + A.T)
+    A.sum_duplicates(); A.setdiag(0); A.eliminate_zeros(); A.sort_indices()
+    wide = bool(rng0.integers(0, 4) == 0)              # int64 row offsets (the twitter-scale form)
+    ptr_, idx = A.indptr.astype(np.int64 if wide else np.int32), A.indices.astype(np.int32)
     M = int(rng0.choice([1, 3, 16, 64, 200, 256, 300]))
     m = int(rng0.choice([1, 2, 3, 4, 5]))
     if (32 - (M.bit_length() and (32 - M.bit_length()))) and m * M.bit_length() + 1 > 63:
         m = 2
     bucket = int(rng0.choice([-1, -1, -1, 5, 40]))
-    rng = str(rng0.choice(["rand_r", "philox"]))
+    rng = "philox" if directed else str(rng0.choice(["rand_r", "philox"]))
     nq = int(rng0.choice([1, 17, 400, 1500]))
     q = rng0.integers(0, N + iso, nq)
     seed = int(rng0.integers(0, 2**31))
-    tag = f"case {c}: N={N}+{iso} nnz={len(idx)} hubs={hubs} M={M} m={m} bucket={bucket} rng={rng} nq={nq} seed={seed}"
+    tag = f"case {c}: N={N}+{iso} nnz={len(idx)} hubs={hubs} directed={directed} int64={wide} M={M} m={m} bucket={bucket} rng={rng} nq={nq} seed={seed}"
     try:
         a = sp.gset_sampler(ptr_, idx, q, num_walks=M, num_steps=m, bucket=bucket, seed=seed, debug=1, rng=rng)
         b = oracle.gset_sampler(ptr_, idx, q, num_walks=M, num_steps=m, bucket=bucket, seed=seed, debug=True, rng=rng)
@@ -48,6 +52,7 @@ for c in range(cases):
             if not np.array_equal(x, y):
                 fails.append(f"gset.{nm}")
         (oi, ox, od) = oracle.spg_build(b[0], b[1])
+        cov["directed"] += directed; cov["int64"] += wide; cov["members"] += len(ox)
         csr = sp.DeviceCSR(ptr_, idx)
         for kw in ({"fused": True}, {"fused": False}, {"strided": True}, {"fused": True, "lazy": True}):
             z, sets = sp.sample_spg(csr, q, num_walks=M, num_steps=m, seed=seed, rng=rng, bucket=bucket, **kw)
@@ -64,6 +69,7 @@ for c in range(cases):
         wxz, wind = oracle.gather_numpy(edge, (oi, ox, od), ptr=True, encode=enc)
         zs, ss = sp.sample_spg(csr, q, num_walks=M, num_steps=m, seed=seed, rng=rng, bucket=bucket, strided=True)
         tab = zs.slot_table() if isinstance(zs, sp.StridedSpG) else ss.feature_table()
+        cov["strided_join"] += isinstance(zs, sp.StridedSpG)
         xz, ind = sp.gather(edge, zs, "cuda", ptr=True, encode=tab)
         if not (np.array_equal(ind.cpu().numpy(), wind) and np.array_equal(xz.cpu().numpy(), wxz)):
             fails.append("gather")
@@ -75,6 +81,16 @@ for c in range(cases):
             fails.append("walks")
         if not (np.array_equal(np.concatenate(list(o1[:, 0])), i2) and np.array_equal(np.vstack(list(o1[:, 1])), c2)):
             fails.append("walk_sets")
+        if N <= 2000:          # top-K PPR sets: scores compared as bit patterns
+            from surel_plus_amd import ppr
+            alpha = float(rng0.choice([0.1, 0.15, 0.5, 0.7])); eps = float(rng0.choice([1e-3, 1e-4])); topk = int(rng0.choice([1, 8, 100]))
+            roots = q[:200].astype(np.int32)
+            cov["ppr"] += 1
+            want = oracle.ppr_topk(ptr_, idx, roots, alpha, eps, topk, table_log2=16)
+            got = ppr.ppr_topk(csr, alpha, eps, roots, topk, table_log2=int(rng0.choice([10, 14])))
+            if not (np.array_equal(got[0].cpu().numpy(), want[0]) and np.array_equal(got[1].cpu().numpy(), want[1])
+                    and np.array_equal(got[2].cpu().numpy().view(np.int32), want[2].view(np.int32)) and got[3] == want[3]):
+                fails.append(f"ppr(alpha={alpha},eps={eps},topk={topk})")
     except (RuntimeError, ValueError, AssertionError) as e:       # rand_r on a graph with dead ends is refused by design
         if "dead end" in str(e) or "Philox" in str(e) or "philox" in str(e) or "hasing key" in str(e) or "key" in str(e).lower():
             skipped += 1
@@ -85,5 +101,5 @@ for c in range(cases):
         print("MISMATCH", tag, fails); bad += 1
     elif only is not None:
         print("ok", tag)
-print(f"{cases} cases, {bad} bad, {skipped} refused by design, {time.time() - t0:.1f} s")
+print(f"{cases} cases, {bad} bad, {skipped} refused by design, {time.time() - t0:.1f} s; coverage {cov}")
 sys.exit(1 if bad else 0)
