@@ -260,6 +260,25 @@ int subgacc_ppr_normalize(const void *indptr, int32_t indptr64, const int32_t *r
 int subgacc_ppr_encode(double *data, int64_t max_nnz, const int64_t *nnz_dev, const uint64_t *max_bits, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * DEG and SPD structural encoders over a PPR node-set store (utils.py:22-34, `encoding(x, adj, 'DEG' | 'SPD')`):
+ * per row the union of the PPR row x_i (x_off / x_ids / x_val, ids ascending) and the adjacency row N(i), with
+ *   mode 1 DEG  value(i,j) = log(|x_j u N(j)| + 1)  (log_table[d] = log(d+1), made by the caller with the libm the
+ *               reference uses); out_agg(i,j) = x_ij + 1/deg(i)  (`x += normalize(adj, 'l1')`, the `agg` return)
+ *   mode 2 SPD  value(i,j) = 1[j in N(i)] + 0.5[j in x_i and N(i) n N(j) != {}] + 0.3[j in x_i], diagonal = 2.3
+ *               (x1 + x0.multiply(x1**2 * 0.5) + x0 * 0.3; setdiag(2.3)); the adjacency is taken as symmetric.
+ * Rows = nodes (n = number of nodes), adjacency rows ascending without repeats.  Two calls: subgacc_encode_sizes
+ * gives row_len[n] (for DEG these are also the d of the value rule); scan them into out_off[n+1]; then
+ * subgacc_encode_fill writes the merged rows (ids ascending) -- kmax >= longest x row (<= 8192).
+ * flags[3] |= 8: a row length outside log_table.
+ * ------------------------------------------------------------------------------------------- */
+int subgacc_encode_sizes(const int64_t *x_off, const int32_t *x_ids, int64_t n, const void *indptr, int32_t indptr64,
+                         const int32_t *indices, int32_t mode, int32_t *row_len, int32_t *flags, void *stream);
+int subgacc_encode_fill(const int64_t *x_off, const int32_t *x_ids, const double *x_val, int64_t n, int32_t kmax,
+                        const void *indptr, int32_t indptr64, const int32_t *indices, int32_t mode,
+                        const int32_t *deg_row_len, const double *log_table, int64_t log_len, const int64_t *out_off,
+                        int32_t *out_ids, double *out_val, double *out_agg, int32_t *flags, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * walk_join of the legacy SUREL surface (subg_acc/subg_acc.c:509-647): for every query pair (a, b) of roots and
  * every position t of their raw walks, the running index of the visited node in a's key list and in b's key list
  * (find_idx, :78-92; 0 = absent).

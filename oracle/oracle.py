@@ -370,3 +370,36 @@ def walk_join(walk, key, query, nthread=-1, return_idx=False):
                              _p(q, C.c_int32), C.c_int64(Q), _p(out, C.c_int32), _p(xrow, C.c_int32))
     assert rc == 0
     return [out, xrow] if return_idx else out
+
+
+# ------------------------------------------------------------------ DEG / SPD encoders (utils.py:22-34) with SciPy
+def encoding_scipy(x, adj, encoding):
+    """The reference's few lines of sparse algebra, executed by SciPy itself (utils.py cannot be imported here: its
+    module header pulls in torch_geometric).  x, adj: scipy CSR.  Returns (x', agg) with canonical (sorted) rows."""
+    import scipy.sparse as sps
+    from sklearn.preprocessing import normalize
+    x = sps.csr_matrix(x, copy=True)
+    agg = None
+    if encoding == "DEG":                                            # utils.py:24-30
+        x += normalize(adj, norm="l1", axis=1)
+        x_deg = x.getnnz(axis=1)
+        x_deg = np.log(x_deg + 1)
+        agg = x.copy()
+        x.data = (x > 0).multiply(x_deg).data
+    elif encoding == "SPD":                                          # utils.py:31-36
+        x0 = x > 0
+        x1 = adj > 0
+        x2 = x1 ** 2
+        x = x1 + x0.multiply(x2 * 0.5) + x0 * 0.3
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            x.setdiag(2.3)
+    else:
+        raise NotImplementedError
+    x = sps.csr_matrix(x)
+    x.sort_indices()
+    if agg is not None:
+        agg = sps.csr_matrix(agg)
+        agg.sort_indices()
+    return x, agg

@@ -140,13 +140,50 @@ def topk_ppr_matrix(adj_matrix, alpha, eps, idx, topk, normalization="row", devi
     return SpG(row_off, ids, data, max_len=int(topk), shape=(n, csr.num_nodes))
 
 
-def encoding(x, adj=None, encoding="PPR"):
-    """utils.py:22-38 for the 'PPR' encoder: (x, None) with x.data = (x.data + 0.1) / (x.data.max() + 0.1), in place."""
-    if encoding != "PPR":
-        raise NotImplementedError(encoding)
-    X = x.nnz
-    if X:
-        mx = x.data[:X].max().view(1).view(torch.int64)     # bit pattern of a non-negative double
-        nnz = torch.tensor([X], dtype=torch.int64, device=x.device)
-        check(lib().subgacc_ppr_encode(ptr(x.data), X, ptr(nnz), ptr(mx), stream_ptr()))
-    return x, None
+def encoding(x, adj=None, encoding="PPR", device=None):
+    """Drop-in for utils.py:22-38: (x', agg).
+
+    'PPR'  x.data = (x.data + 0.1) / (x.data.max() + 0.1), in place; agg None.
+    'DEG'  pattern x u adj, value(i,j) = log(nnz(row j of x u adj) + 1); agg = x + l1-normalised adj (an SpG, where the
+           reference returns the scipy matrix).
+    'SPD'  pattern adj u x u diagonal, value = 1[adj] + 0.5[x and a 2-path] + 0.3[x], diagonal 2.3; agg None.
+    x: SpG with one row per node (float64 payload, e.g. topk_ppr_matrix over all nodes); adj: the unweighted,
+    symmetric adjacency (scipy CSR or DeviceCSR)."""
+    if encoding == "PPR":
+        X = x.nnz
+        if X:
+            mx = x.data[:X].max().view(1).view(torch.int64)     # bit pattern of a non-negative double
+            nnz = torch.tensor([X], dtype=torch.int64, device=x.device)
+            check(lib().subgacc_ppr_encode(ptr(x.data), X, ptr(nnz), ptr(mx), stream_ptr()))
+        return x, None
+    if encoding not in ("DEG", "SPD"):
+        raise NotImplementedError
+    import numpy as np
+    dev = x.device
+    csr = _as_csr(adj, dev)
+    n = x.n_rows
+    if n != csr.num_nodes or x.data.dtype != torch.float64:
+        raise ValueError("encoding: x must hold one float64 row per node of adj")
+    mode = 1 if encoding == "DEG" else 2
+    st = stream_ptr()
+    flags = torch.zeros(4, dtype=torch.int32, device=dev)
+    row_len = torch.empty(n, dtype=torch.int32, device=dev)
+    check(lib().subgacc_encode_sizes(ptr(x.indptr), ptr(x.indices), n, ptr(csr.indptr), int(csr.indptr64), ptr(csr.indices),
+                                     mode, ptr(row_len), ptr(flags), st))
+    out_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    ws = torch.empty(max(lib().subgacc_scan_workspace_bytes(n), 8), dtype=torch.uint8, device=dev)
+    check(lib().subgacc_exclusive_scan_i32(ptr(row_len), n, ptr(out_off), ptr(ws), ws.numel(), st))
+    total = int(out_off[-1].item()) if n else 0
+    max_len = int(row_len.max().item()) if n else 0
+    ids = torch.empty(total, dtype=torch.int32, device=dev)
+    val = torch.empty(total, dtype=torch.float64, device=dev)
+    agg = torch.empty(total, dtype=torch.float64, device=dev) if mode == 1 else None
+    # np.log on the host: the same libm the reference's NumPy calls, so the values match it bit for bit
+    logt = torch.from_numpy(np.log(np.arange(max_len + 1, dtype=np.int64) + 1)).to(dev) if mode == 1 else None
+    check(lib().subgacc_encode_fill(ptr(x.indptr), ptr(x.indices), ptr(x.data), n, int(x.max_len), ptr(csr.indptr),
+                                    int(csr.indptr64), ptr(csr.indices), mode, ptr(row_len) if mode == 1 else None,
+                                    ptr(logt), max_len + 1 if mode == 1 else 0, ptr(out_off), ptr(ids), ptr(val), ptr(agg),
+                                    ptr(flags), st))
+    shape = (n, csr.num_nodes)
+    z = SpG(out_off, ids, val, max_len=max_len, shape=shape)
+    return z, (SpG(out_off, ids, agg, max_len=max_len, shape=shape) if mode == 1 else None)

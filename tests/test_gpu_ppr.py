@@ -157,3 +157,34 @@ def test_ppr_spg_feeds_gather(ppr):
                                         ptr=True, encode=None)
     np.testing.assert_array_equal(ip.cpu().numpy(), want_ip)
     np.testing.assert_array_equal(xz.cpu().numpy(), want_xz)
+
+
+@pytest.mark.parametrize("enc", ["DEG", "SPD"])
+@pytest.mark.parametrize("kind", ["sparse", "hubs", "dense", "star"])
+def test_deg_spd_encoders_match_scipy(ppr, enc, kind):
+    """utils.py:22-34 executed by SciPy (oracle.encoding_scipy) vs the union kernels: pattern and float64 values, bit for bit"""
+    from surel_plus_amd import DeviceCSR
+    indptr, indices = _graph(kind)
+    N = len(indptr) - 1
+    adj = sps.csr_matrix((np.ones(len(indices)), indices, indptr), shape=(N, N))
+    csr = DeviceCSR(indptr, indices)
+    x = ppr.topk_ppr_matrix(csr, 0.5, 1e-4, np.arange(N), 30, normalization="sym")
+    want, wagg = orc.encoding_scipy(x.to_scipy(), adj, enc)
+    z, agg = ppr.encoding(x, csr, enc)
+    got = z.to_scipy()
+    np.testing.assert_array_equal(got.indptr, want.indptr)
+    np.testing.assert_array_equal(got.indices, want.indices)
+    np.testing.assert_array_equal(got.data.view(np.int64), want.data.astype(np.float64).view(np.int64))
+    if enc == "DEG":
+        ga = agg.to_scipy()
+        np.testing.assert_array_equal(ga.indices, wagg.indices)
+        np.testing.assert_array_equal(ga.data.view(np.int64), wagg.data.view(np.int64))
+    else:
+        assert agg is None and wagg is None
+    # and the result feeds SpJoin's float mode, hub rows included (rows longer than LDS are searched in place)
+    import surel_plus_amd as sp
+    edge = np.random.default_rng(0).integers(0, N, (2, 200))
+    xz, ip = sp.gather(torch.from_numpy(edge).cuda(), z, "cuda", ptr=True, encode=None)
+    wxz, wip = orc.gather_numpy(edge, (want.indptr.astype(np.int64), want.indices, want.data.astype(np.float64)), ptr=True, encode=None)
+    np.testing.assert_array_equal(ip.cpu().numpy(), wip)
+    np.testing.assert_array_equal(xz.cpu().numpy(), wxz)
