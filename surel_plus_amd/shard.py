@@ -36,8 +36,8 @@ def merge_unique_tables(tables):
 
 
 def all_gather_varlen(t, group=None):
-    """all_gather of 1-D int64 tensors of different lengths (pad to the max length, one collective each for
-    the sizes and the payload)."""
+    """all_gather of 1-D tensors (any dtype, the same on every rank) of different lengths: pad to the max length, one
+    collective each for the sizes and the payload."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
@@ -76,3 +76,14 @@ def shard_pairs(edge, rank, world):
     """Contiguous share of the query pairs [2, B] of this rank (SpG replicated, no collective)."""
     lo, hi = shard_range(edge.shape[1], rank, world)
     return edge[:, lo:hi], (lo, hi)
+
+
+def replicate_rows(nsize, ids, data, group=None):
+    """The one-off exchange that makes a row-sharded SpG resident on every GPU: every rank holds the rows
+    of its contiguous root range (nsize [n_r], ids / data [X_r], rank order = row order); returns the full
+    (row_off int64 [n+1], ids, data) on every rank.  Three all-gathers (RCCL ring over xGMI on GPUs; sized by the
+    store, e.g. 8 B per member), not part of the steady state."""
+    ns = torch.cat(all_gather_varlen(nsize, group))
+    row_off = torch.zeros(ns.numel() + 1, dtype=torch.int64, device=ns.device)
+    torch.cumsum(ns, 0, out=row_off[1:])
+    return row_off, torch.cat(all_gather_varlen(ids, group)), torch.cat(all_gather_varlen(data, group))

@@ -47,6 +47,33 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _spg_worker(rank, world, port, out_dir):
+    """sharded offline stage: sample the rank's roots, number LP rows globally, sort the rank's rows, replicate"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = np.load(os.path.join(GOLDEN, "gset_mixeddeg_s1.npz"))
+    M, m = int(g["M"]), int(g["m"])
+    sets, gkeys, _ = shard.sample_sets_sharded(oracle_sampler(g, M, m, 9), g["query"], rank, world)
+    _, ids, data = oracle.spg_build(sets.nsize.numpy(), np.stack([sets.ids.numpy(), sets.sf.numpy().astype(np.int32)]))
+    row_off, ids, data = shard.replicate_rows(sets.nsize, torch.from_numpy(ids), torch.from_numpy(data))
+    np.savez(os.path.join(out_dir, f"spg{rank}.npz"), row_off=row_off.numpy(), ids=ids.numpy(), data=data.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_spg_is_replicated_identically(tmp_path):
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    mp.spawn(_spg_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    g = np.load(os.path.join(GOLDEN, "gset_mixeddeg_s1.npz"))
+    M, m = int(g["M"]), int(g["m"])
+    nsize, remap, enc = oracle.gset_sampler(g["indptr"], g["indices"], g["query"], num_walks=M, num_steps=m, seed=9, rng="philox")
+    indptr, ids, data = oracle.spg_build(nsize, remap)
+    for r in range(world):
+        p = np.load(os.path.join(str(tmp_path), f"spg{r}.npz"))
+        assert np.array_equal(p["row_off"], indptr) and np.array_equal(p["ids"], ids) and np.array_equal(p["data"], data)
+
+
 def test_shard_range_covers_everything():
     for n in (0, 1, 7, 8, 1000):
         for w in (1, 2, 3, 8):
