@@ -12,7 +12,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 only = int(sys.argv[3]) if len(sys.argv) > 3 else None          # re-run one case verbosely
 bad = skipped = 0
-cov = {"directed": 0, "int64": 0, "ppr": 0, "strided_join": 0, "members": 0}
+cov = {"directed": 0, "int64": 0, "ppr": 0, "strided_join": 0, "multichunk": 0, "members": 0}
 t0 = time.time()
 for c in range(cases):
     if only is not None and c != only:
@@ -54,7 +54,9 @@ for c in range(cases):
         (oi, ox, od) = oracle.spg_build(b[0], b[1])
         cov["directed"] += directed; cov["int64"] += wide; cov["members"] += len(ox)
         csr = sp.DeviceCSR(ptr_, idx)
-        for kw in ({"fused": True}, {"fused": False}, {"strided": True}, {"fused": True, "lazy": True}):
+        small = {"staging_bytes": 1 << 18} if rng0.integers(0, 5) == 0 else {}     # several chunks of roots per call
+        cov["multichunk"] += bool(small)
+        for kw in ({"fused": True, **small}, {"fused": False, **small}, {"strided": True}, {"fused": True, "lazy": True}):
             z, sets = sp.sample_spg(csr, q, num_walks=M, num_steps=m, seed=seed, rng=rng, bucket=bucket, **kw)
             if kw.get("lazy") and b[2].shape[0] > 16384:
                 continue        # lazy numbering ranks at most RANK_LIMIT distinct rows directly; resolve() says so
