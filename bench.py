@@ -351,6 +351,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # for the record, outside the clock: the same steps with a packed CSR SpG built for every batch (rank 0, 1 GPU)
+    csr_ms = None
+    if rank == 0 and world == 1 and last is not None and last[1].strided:
+        global STRIDED
+        keep_last, keep_strided, STRIDED = last, STRIDED, False
+        run_steps(range(3))                                   # allocator steady state for this variant
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(range(W, W + K))
+        torch.cuda.synchronize()
+        csr_ms = (time.perf_counter() - t1) / max(K, 1) * 1e3
+        last, STRIDED = keep_last, keep_strided
+
     if rank == 0:
         edge, sets, xz = last
         walk_ms, launches = timer.mean_ms("walk_sets")
@@ -377,6 +390,7 @@ def main():
                                                  ("walk_sets", "compact_sets", "uniq_rows", "spg_build")) if v)),
                        "J_pairs_per_s": (B / (1e-3 * join_ms)) if join_ms else None,
                        "fused_spg_rows": sets.data is not None or sets.strided, "spg_layout": "strided rows joined in place (no CSR copy of the batch)" if sets.strided else "csr",
+                       "ms_per_step_with_a_packed_csr_spg_per_batch": csr_ms,
                        "device_allocs_in_timed_region": torch.cuda.memory_stats().get("num_device_alloc", 0) - allocs0,
                        "host_step_ms_min_median_max": [round(1e3 * v, 3) for v in (
                            lambda d: (min(d), sorted(d)[len(d) // 2], max(d)))(
