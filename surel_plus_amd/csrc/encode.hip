@@ -253,6 +253,10 @@ extern "C" int subgacc_encode_fill(const int64_t *x_off, const int32_t *x_ids, c
     a.log_table = log_table, a.log_len = log_len;
     a.out_off = out_off, a.out_ids = out_ids, a.out_val = out_val, a.out_agg = out_agg;
     const size_t lds = (size_t)a.kmax * 4 + ((size_t)a.kmax + 1) * 4 + (size_t)a.kmax * 2 + 16;
+    if (lds > 64 * 1024) {
+        SG_CHECK_HIP(hipFuncSetAttribute((const void *)enc_fill_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        SG_CHECK_HIP(hipFuncSetAttribute((const void *)enc_fill_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     if (indptr64) hipLaunchKernelGGL(enc_fill_kernel<true>, dim3((unsigned)n), dim3(kEncThreads), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(enc_fill_kernel<false>, dim3((unsigned)n), dim3(kEncThreads), lds, (hipStream_t)stream, a);
     SG_LAUNCH_CHECK();
