@@ -212,6 +212,11 @@ __global__ __launch_bounds__(kPairThreads) void sjoin_pair_kernel(const JoinArgs
     const Val *data = (const Val *)a.data;
     const bool xl = !F64 && a.slot_id != nullptr;    // strided rows carry table slots: SFptr+1 on the way into LDS
     for (int r = tid; r < na; r += kPairThreads) {
+#if SJ_EXPERIMENT == 4   // timing experiment: no row loads from HBM (results are wrong)
+        idsA[r] = (int32_t)(ra & 1023) + 3 * r;
+        valA[r] = (Val)(r & 127);
+        continue;
+#endif
         idsA[r] = a.indices[ab + r];
         Val v = data[ab + r];
         if (xl) v = (Val)(a.slot_id[(int32_t)v] + 1);
@@ -220,6 +225,11 @@ __global__ __launch_bounds__(kPairThreads) void sjoin_pair_kernel(const JoinArgs
     }
     if (ra != rb) {
         for (int r = tid; r < nb; r += kPairThreads) {
+#if SJ_EXPERIMENT == 4
+            idsB[r] = (int32_t)(rb & 1023) + 2 * r;
+            valB[r] = (Val)(r & 127);
+            continue;
+#endif
             idsB[r] = a.indices[bb + r];
             Val v = data[bb + r];
             if (xl) v = (Val)(a.slot_id[(int32_t)v] + 1);
