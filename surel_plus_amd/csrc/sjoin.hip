@@ -47,6 +47,29 @@ struct JoinArgs {
     int32_t val_add;          // val_add = 1: the feature table is indexed by slot + 1 itself (row 0 = absent)
 };
 
+// The join's outputs are written once and read by a later kernel, its SpG rows are read once per pair: non-temporal
+// (streaming) accesses keep them from displacing each other in L2 -- measured -12 % on the cit2 batch (0.57 -> 0.50 ms).
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void stream_store(float4 *p, const float4 &t) {
+    v4f v;
+    v.x = t.x, v.y = t.y, v.z = t.z, v.w = t.w;
+    __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(p));
+}
+__device__ __forceinline__ void stream_store(float2 *p, const float2 &t) {
+    v2f v;
+    v.x = t.x, v.y = t.y;
+    __builtin_nontemporal_store(v, reinterpret_cast<v2f *>(p));
+}
+__device__ __forceinline__ void stream_store(int2 *p, const int2 &t) {
+    v2i v;
+    v.x = t.x, v.y = t.y;
+    __builtin_nontemporal_store(v, reinterpret_cast<v2i *>(p));
+}
+template <typename T>
+__device__ __forceinline__ T stream_load(const T *p) { return __builtin_nontemporal_load(p); }
+
 __device__ __forceinline__ void join_row(const JoinArgs &a, int64_t r, int64_t &beg, int64_t &len) {
     if (a.row_len) {
         beg = r * a.row_stride;
@@ -90,7 +113,7 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
             float2 v;
             v.x = (float)va;
             v.y = (float)second;
-            reinterpret_cast<float2 *>(a.out_xz)[row0 + lane] = v;
+            stream_store(reinterpret_cast<float2 *>(a.out_xz) + row0 + lane, v);
         }
     } else {
         int32_t pa = (int32_t)va, pb = hit ? (int32_t)pval[lo] : 0;
@@ -98,7 +121,7 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
             int2 v;
             v.x = pa;
             v.y = pb;
-            reinterpret_cast<int2 *>(a.out_idx)[row0 + lane] = v;
+            stream_store(reinterpret_cast<int2 *>(a.out_idx) + row0 + lane, v);
         }
         if (a.out_xz) {
             if (live && ((uint64_t)pa >= (uint64_t)a.table_rows || (uint64_t)pb >= (uint64_t)a.table_rows)) {
@@ -120,8 +143,10 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
                     if (r < nrows && spa == -12345) dst4[f] = tab4[(f & 1) ? spb : spa];
 #elif SJ_EXPERIMENT == 3 // timing experiment: stores without the feature-table read
                     if (r < nrows) dst4[f] = make_float4((float)spa, (float)spb, 0.f, 0.f);
-#else
+#elif SJ_EXPERIMENT == 8 // plain (cached) stores, as before round 1's last change
                     if (r < nrows) dst4[f] = tab4[(f & 1) ? spb : spa];
+#else
+                    if (r < nrows) stream_store(dst4 + f, tab4[(f & 1) ? spb : spa]);
 #endif
                 }
             } else {
@@ -131,12 +156,12 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
                     const int r = (int)(((uint32_t)f * magic) >> 20);
                     const int c = f - r * k2;
                     const int spa = __shfl(pa, r, kWave), spb = __shfl(pb, r, kWave);
-                    if (f < total) dst[f] = a.table[(int64_t)(c < k ? spa : spb) * k + (c < k ? c : c - k)];
+                    if (f < total) __builtin_nontemporal_store(a.table[(int64_t)(c < k ? spa : spb) * k + (c < k ? c : c - k)], dst + f);
                 }
             }
         }
     }
-    if (a.out_segid && live) a.out_segid[row0 + lane] = segj;
+    if (a.out_segid && live) __builtin_nontemporal_store(segj, a.out_segid + row0 + lane);
 }
 
 // generic: one wave64 workgroup per segment, partner row staged in LDS, own row streamed from HBM.
@@ -217,8 +242,8 @@ __global__ __launch_bounds__(kPairThreads) void sjoin_pair_kernel(const JoinArgs
         valA[r] = (Val)(r & 127);
         continue;
 #endif
-        idsA[r] = a.indices[ab + r];
-        Val v = data[ab + r];
+        idsA[r] = stream_load(&a.indices[ab + r]);
+        Val v = stream_load(&data[ab + r]);
         if (xl) v = (Val)(a.slot_id[(int32_t)v] + 1);
         else if (!F64) v = (Val)((int32_t)v + a.val_add);
         valA[r] = v;
@@ -230,8 +255,8 @@ __global__ __launch_bounds__(kPairThreads) void sjoin_pair_kernel(const JoinArgs
             valB[r] = (Val)(r & 127);
             continue;
 #endif
-            idsB[r] = a.indices[bb + r];
-            Val v = data[bb + r];
+            idsB[r] = stream_load(&a.indices[bb + r]);
+            Val v = stream_load(&data[bb + r]);
             if (xl) v = (Val)(a.slot_id[(int32_t)v] + 1);
             else if (!F64) v = (Val)((int32_t)v + a.val_add);
             valB[r] = v;
