@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
                 } else {
                     pick = (uint32_t)w % rdeg;
                 }
-                cur = a.indices[rbeg + pick];
+                cur = SG_NEIGH_LOAD(&a.indices[rbeg + pick]);
             } else {
 #if SG_EXPERIMENT == 2   // dedup only: no graph reads after the first hop (timing experiment, results are wrong)
                 cur = (int32_t)(((uint32_t)cur * 2654435761u + (uint32_t)w * 40503u + (uint32_t)s) % 2900000u);
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
                         }
                         r = ph[idx & 3];
                     }
-                    cur = a.indices[b + (int64_t)(r % (uint32_t)d)];
+                    cur = SG_NEIGH_LOAD(&a.indices[b + (int64_t)(r % (uint32_t)d)]);
                 } else if (RNG == SUBGACC_RNG_RAND_R) {
                     atomicOr(&a.flags[0], 1);  // dead end: the sequential stream is no longer reproducible
                 }

@@ -48,6 +48,17 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
 }
 
+// neighbour reads of the walk: SG_NT_NEIGH=1 marks them non-temporal (a random 4-byte read of `indices` pulls a line
+// that is rarely used again; streaming it keeps the row-pointer lines in L2) -- see tools/ab_walk.sh
+#ifndef SG_NT_NEIGH
+#define SG_NT_NEIGH 0
+#endif
+#if SG_NT_NEIGH
+#define SG_NEIGH_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define SG_NEIGH_LOAD(p) (*(p))
+#endif
+
 // ------------------------------------------------------------------- rand_r stream positions
 template <bool IDX64>
 __device__ __forceinline__ void load_row(const void *indptr, int32_t node, int64_t &beg, int64_t &deg) {

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
             }
             if (RNG == SUBGACC_RNG_RAND_R)
                 xB = lcg_jump(rseedB, rposB + 3u * ((shufB ? (uint32_t)M : 0u) + (uint32_t)tid * (uint32_t)(MH - 1)));
-            pendN = a.indices[rbegB + pick];
+            pendN = SG_NEIGH_LOAD(&a.indices[rbegB + pick]);
         } else if constexpr (J % 2 == 1) {
             constexpr int hop = (J - 1) / 2;          // 0-based hop whose node just arrived
             visB[hop] = pendN;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
                         philox4x32_10((uint32_t)rootB, (uint32_t)tid, (uint32_t)(idx >> 2), 0u, a.seed, kPhiloxKey1, phB);
                     r = phB[idx & 3];
                 }
-                pendN = a.indices[pendB + (int64_t)(r % (uint32_t)pendD)];
+                pendN = SG_NEIGH_LOAD(&a.indices[pendB + (int64_t)(r % (uint32_t)pendD)]);
             } else {
                 pendN = visB[hop - 1];                // dead end: stay (the rand_r stream is then not reproducible)
                 if (RNG == SUBGACC_RNG_RAND_R) atomicOr(&a.flags[0], 1);

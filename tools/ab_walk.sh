@@ -1,17 +1,21 @@
 #!/bin/bash
-# Dev-only A/B of compile-time variants of walk.hip on ONE box: usage  VARIANTS="-DA=1|-DB=1" WLS="cit2 collab" tools/ab_walk.sh
+# Dev-only A/B of compile-time variants of walk.hip / walk_pipe.hip on ONE box:
+#   VARIANTS="-DSG_NT_NEIGH=1|-DSG_EXPERIMENT=1" WLS="cit2 collab" tools/ab_walk.sh
+# (SUBGACC_WALK_PIPE=0 keeps the hooks of walk_sets_kernel in play for the set_sampler form.)
 set -e
-export SUBGACC_WALK_PIPE=${SUBGACC_WALK_PIPE:-0}   # the hooks live in walk_sets_kernel (walk.hip)
 cd $GRAFT_REPO_ROOT/surel_plus_amd/csrc
 cp ../libsubgacc_hip.so /tmp/lib_orig.so
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -ffp-contract=off"
+OBJS=$(ls build/*.o | grep -v -x -F -e build/walk.o -e build/walk_pipe.o)
 IFS='|' read -ra VS <<< "${VARIANTS:-}"
 for V in "" "${VS[@]}"; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -ffp-contract=off $V -c walk.hip -o /tmp/walk_v.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/capi.o build/scan.o /tmp/walk_v.o build/walk_pipe.o build/uniq.o build/spg.o build/sjoin.o -o ../libsubgacc_hip.so
+  /opt/rocm/bin/hipcc $FLAGS $V -c walk.hip -o /tmp/walk_v.o
+  /opt/rocm/bin/hipcc $FLAGS $V -c walk_pipe.hip -o /tmp/walk_pipe_v.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/walk_v.o /tmp/walk_pipe_v.o -o ../libsubgacc_hip.so
   for W in ${WLS:-cit2 collab}; do
     for rep in 1 2; do
     echo -n "[$V] $W: "
-    python $GRAFT_REPO_ROOT/bench.py --workload $W --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['config']['stage_ms']['walk_sets'],4), round(d['ms_per_step'],3))"
+    python $GRAFT_REPO_ROOT/bench.py --workload $W --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('walk', round(d['config']['stage_ms']['walk_sets'],4), 'step', round(d['ms_per_step'],3))"
     done
   done
 done
