@@ -7,7 +7,7 @@ cd $GRAFT_REPO_ROOT/surel_plus_amd/csrc
 cp ../libsubgacc_hip.so /tmp/lib_orig.so
 for E in ${EXPS:-0 1 2}; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -ffp-contract=off -DSG_EXPERIMENT=$E -c walk.hip -o /tmp/walk_e$E.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/capi.o build/scan.o /tmp/walk_e$E.o build/walk_pipe.o build/uniq.o build/spg.o build/sjoin.o -o ../libsubgacc_hip.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls build/*.o | grep -v -x -F -e build/walk.o) /tmp/walk_e$E.o -o ../libsubgacc_hip.so
   for W in ${WLS:-collab cit2}; do
     echo -n "EXPERIMENT=$E $W: "
     python $GRAFT_REPO_ROOT/bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['config']['stage_ms']['walk_sets'])"
