@@ -68,9 +68,24 @@ __global__ void rng_positions_kernel(const int64_t *__restrict__ calls_excl, int
 // ------------------------------------------------------------------------------ the walk kernel
 // <= 80 SGPRs keeps 8 workgroups (32 waves) resident per CU; the allocator would otherwise take ~100 and the
 // hardware admits only 6 (MI355X_MICROARCH.md, residency formula) -- worth 14 % on the L2-resident collab graph
+#if SG_EXPERIMENT == 7   // per-phase cycle shares (tools/walk_phases.py): lane 0 adds the cycles since the last stamp to flags[8 + 2k]
+#define SG_STAMP(k)                                                                             \
+    do {                                                                                        \
+        if (threadIdx.x == 0) {                                                                 \
+            const unsigned long long now__ = __builtin_readcyclecounter();                      \
+            atomicAdd((unsigned long long *)(a.flags + 8) + (k), now__ - t_prev__);             \
+            t_prev__ = now__;                                                                   \
+        }                                                                                       \
+    } while (0)
+#else
+#define SG_STAMP(k)
+#endif
 template <bool IDX64, int RNG, bool SPG>
 __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) void walk_sets_kernel(const WalkArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
+#if SG_EXPERIMENT == 7
+    unsigned long long t_prev__ = __builtin_readcyclecounter();
+#endif
     unsigned long long *pk = (unsigned long long *)lds_raw;     // [T]
     int32_t *keys = (int32_t *)(pk + a.T);                       // [T]
     uint32_t *minq = (uint32_t *)(keys + a.T);                   // [T]
@@ -149,12 +164,14 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
         }
     }
     __syncthreads();
+    SG_STAMP(0);
     if (tid == 0) {  // the root is member 0 (q = 0)
         const uint32_t h = ((uint32_t)root * 2654435761u) >> a.tshift;
         keys[h] = root;
         minq[h] = 0u;
     }
     __syncthreads();
+    SG_STAMP(1);
 
     const uint32_t tmask = (uint32_t)T - 1u;
     int32_t vmin = root, vmax = root;   // id range of everything this lane visits (SPG mode: bucket scaling)
@@ -250,6 +267,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
         }
     }
     __syncthreads();
+    SG_STAMP(2);
 
     // ---- rank the members by first visit: bitmap over q, popcount prefix.  The SPG mode only needs an ORDER of
     // first visits for its tags -- the visit sequence number itself is one -- so it ranks only when a bucket can
@@ -346,6 +364,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
         if ((tid & (kWave - 1)) == 0) atomicAdd(&red[8], mycount);
     }
     __syncthreads();   // every lane holds its members in registers: the walk tables are free to be re-used
+    SG_STAMP(3);
     if (!need_rank) total = ns = red[8];
     if (tid == 0) {
         a.nsize[i] = ns;
@@ -365,6 +384,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
     for (int s2 = tid; s2 < kSpgFold; s2 += kWalkThreads)    // flush the fold table to HBM (latency overlaps the sort)
         if (fk[s2] != kEmptyKey) fs[s2] = uniq_global_insert(a.table, fk[s2], tag0 + ft[s2], a.flags);
     __syncthreads();
+    SG_STAMP(4);
     uint32_t bk[kSpgPerLane];
 #pragma unroll
     for (int u = 0; u < kSpgPerLane; ++u) {
@@ -373,6 +393,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
         if (slv[u] <= -2) slv[u] = fs[-2 - slv[u]];
     }
     __syncthreads();
+    SG_STAMP(5);
     if (tid < kWave) {   // exclusive scan over the <= 256 buckets by one wave: 4 consecutive buckets per lane
         const int per = (B + kWave - 1) / kWave;
         const int b0 = tid * per;
@@ -394,11 +415,17 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
         if (tid == kWave - 1) start[B] = inc;
     }
     __syncthreads();
+    SG_STAMP(6);
 #pragma unroll
     for (int u = 0; u < kSpgPerLane; ++u)
         if (ok[u]) A[atomicAdd(&cursor[bk[u]], 1)] = ((unsigned long long)(uint32_t)idv[u] << 32) | (uint32_t)slv[u];
     __syncthreads();
-    // order inside a bucket = number of smaller ids in it; the member goes straight to its final slot of the row
+    SG_STAMP(7);
+    // order inside a bucket = number of smaller ids in it -> final position in the row.  The sorted row is assembled
+    // in LDS (ids over the dead minq table, slots behind A) and leaves with consecutive lanes on consecutive words.
+    int32_t *fin_id = (int32_t *)minq;                 // [ns] <= T
+    int32_t *fin_sl = (int32_t *)(pk + a.stride + 1);   // [ns]: A occupies pk[0..ns), ns <= stride; (T - stride - 1) * 8 >= 4 * stride
+    const bool staged = (int64_t)(T - a.stride - 1) * 8 >= (int64_t)4 * a.stride;
 #pragma unroll
     for (int u = 0; u < kSpgPerLane; ++u)
         if (ok[u]) {
@@ -406,9 +433,22 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
             const int lo = start[bk[u]], hi = start[bk[u] + 1];
             int rank = 0;
             for (int t2 = lo; t2 < hi; ++t2) rank += (A[t2] < me) ? 1 : 0;
-            a.set_ids[obase + lo + rank] = idv[u];
-            a.set_slot[obase + lo + rank] = slv[u];
+            if (staged) {
+                fin_id[lo + rank] = idv[u];
+                fin_sl[lo + rank] = slv[u];
+            } else {
+                a.set_ids[obase + lo + rank] = idv[u];
+                a.set_slot[obase + lo + rank] = slv[u];
+            }
         }
+    if (staged) {
+        __syncthreads();
+        for (int x = tid; x < ns; x += kWalkThreads) {
+            a.set_ids[obase + x] = fin_id[x];
+            a.set_slot[obase + x] = fin_sl[x];
+        }
+    }
+    SG_STAMP(8);
 }
 
 // ------------------------------------------------------------------------------- compaction

@@ -8,10 +8,11 @@ from surel_plus_amd._lib import check, lib, ptr, stream_ptr
 from surel_plus_amd.graphs import preset_graph, query_pairs
 from surel_plus_amd.sampler import make_cfg
 L = lib()
-csr = preset_graph("cit2")
+csr = preset_graph(sys.argv[1] if len(sys.argv) > 1 else "cit2")
+M, m = 200, int(sys.argv[2]) if len(sys.argv) > 2 else 3
 B = 65536
 roots = query_pairs(csr, B, seed=1).reshape(-1).to(torch.int32)
-n = roots.numel(); M, m = 200, 3; stride = M * m + 1
+n = roots.numel(); stride = M * m + 1
 cfg = make_cfg(csr, M, m, rng="philox")
 flags = torch.zeros(64, dtype=torch.int32, device="cuda")
 table = torch.empty(L.subgacc_uniq_table_bytes(1 << 20), dtype=torch.uint8, device="cuda")
@@ -24,7 +25,7 @@ for it in range(2):
                              1 << 20, ptr(ids), ptr(slot), ptr(nsize), ptr(flags), stream_ptr()))
 torch.cuda.synchronize()
 c = flags[8:8 + 18].view(torch.int64).tolist()
-names = ["init tables", "fisher-yates / root insert", "WALK (3 hops) + visits", "member load + fold (LDS)", "flush fold to HBM + zero buckets",
+names = ["init tables + fisher-yates draws", "root insert", "WALK + visits", "member load + fold (LDS)", "flush fold to HBM + zero buckets",
          "histogram", "bucket scan (wave 0)", "scatter", "in-bucket rank + global write"]
 tot = sum(c)
 for nm, v in zip(names, c):
