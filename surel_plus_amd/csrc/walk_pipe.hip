@@ -34,6 +34,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
     uint32_t *bitmap = minq + a.T;                               // [nwords]
     uint32_t *prefix = bitmap + a.nwords;                        // [nwords + 1]
     int32_t *sarr = (int32_t *)(prefix + a.nwords + 1);          // [M] Fisher-Yates draws of the NEXT root
+    uint16_t *inv = (uint16_t *)(sarr + a.M);                    // [M*m+1] table slot of the member ranked r
 
     const int tid = threadIdx.x;
     const int M = a.M, T = a.T;
@@ -221,18 +222,29 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
         SG_BSTEP(3);
         const int32_t total = (int32_t)prefix[a.nwords];
         const int32_t ns = total < a.stride ? total : a.stride;
+        // rank -> table slot first (LDS), then the row leaves with consecutive lanes on consecutive words: scattered
+        // 4/8-byte stores cost the memory pipeline as much as the walk's random reads do
         for (int h = tid; h < T; h += kWalkThreads)
             if (keys[h] != -1) {
                 const uint32_t q = minq[h];
                 const int32_t r = (int32_t)(prefix[q >> 5] + __popc(bitmap[q >> 5] & ((1u << (q & 31u)) - 1u)));
-                if (r < a.stride) {               // members ranked past the bucket are dropped (:814-828)
-                    a.set_ids[obase + r] = keys[h];
-                    a.set_keys[obase + r] = pk[h] | (r == 0 ? lead : 0ull);
+                if (r < a.stride) {
+                    inv[r] = (uint16_t)h;
+                } else {                          // members ranked past the bucket are dropped (:814-828)
+                    keys[h] = -1;
+                    minq[h] = 0xFFFFFFFFu;
+                    pk[h] = 0ull;
                 }
-                keys[h] = -1;                     // hand the slot back clean
-                minq[h] = 0xFFFFFFFFu;
-                pk[h] = 0ull;
             }
+        __syncthreads();                          // b3': inv complete
+        for (int x = tid; x < ns; x += kWalkThreads) {
+            const int h = inv[x];
+            a.set_ids[obase + x] = keys[h];
+            a.set_keys[obase + x] = pk[h] | (x == 0 ? lead : 0ull);
+            keys[h] = -1;                         // hand the slot back clean
+            minq[h] = 0xFFFFFFFFu;
+            pk[h] = 0ull;
+        }
         __syncthreads();                          // b4: tables clean again, bitmap no longer read
         for (int x = tid; x < a.nwords; x += kWalkThreads) bitmap[x] = 0u;
         if (tid == 0) {
