@@ -47,7 +47,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # library's choice (fused for walks of >= 3 hops)
 FUSED = {"1": True, "0": False}.get(os.environ.get("SUBGACC_FUSED", ""), None)
 # join the batch from the walk kernel's strided rows (no packed CSR copy of a batch that is joined once and dropped);
-# unset = wherever the fused-row walk kernel is the faster one (>= 3 hops); SUBGACC_STRIDED=0 builds the CSR SpG per step
+# unset = wherever the fused-row walk kernel is the faster one (spg.prefers_fused); SUBGACC_STRIDED=0 builds the CSR SpG per step
 STRIDED = {"1": True, "0": False}.get(os.environ.get("SUBGACC_STRIDED", ""), None)
 UNIQ_CAPACITY = 1 << int(os.environ.get("SUBGACC_UNIQ_LOG2", "17"))   # slots of the table of distinct LP rows (a batch holds ~10^3)
 LAZY = os.environ.get("SUBGACC_LAZY", "1") == "1"     # sizes stay on the device: one host round trip per step
@@ -103,7 +103,8 @@ def hot_path_step(sp, csr, edge, M, k, seed, rng, slot=0):
     Returns (xz buffer view, indptr, sets)."""
     B = edge.shape[1]
     roots = edge.reshape(-1).to(torch.int32)
-    strided = (k - 1 >= 3 and FUSED is not False) if STRIDED is None else STRIDED
+    from surel_plus_amd.spg import prefers_fused
+    strided = (prefers_fused(csr, k - 1) and FUSED is not False) if STRIDED is None else STRIDED
     z, sets = sp.sample_spg(csr, roots, num_walks=M, num_steps=k - 1, seed=seed, rng=rng, fused=FUSED, lazy=LAZY, strided=strided,
                             uniq_capacity=UNIQ_CAPACITY)
     table = z.slot_table() if sets.strided else sets.feature_table()

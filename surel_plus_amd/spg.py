@@ -146,14 +146,23 @@ class StridedSpG:
         return SpG(row_off, ids, data, max_len=self.stride, shape=self.shape, max_data=self.max_data)
 
 
+FUSED_MIN_GRAPH_BYTES = 64 << 20     # adjacency beyond this no longer lives in the 8 x 4 MiB L2s
+
+
+def prefers_fused(csr, hops):
+    """Is the fused-row walk kernel (and the strided join on top of it) the faster way through this graph?"""
+    return hops >= 3 or csr.nnz * 4 > FUSED_MIN_GRAPH_BYTES
+
+
 def sample_spg(csr, query, num_walks=200, num_steps=3, seed=111413, rng="rand_r", bucket=-1, fused=None, lazy=False,
                strided=False, **kw):
     """sample -> SpG on the GPU: (SpG, SampledSets) -- the sets carry ukeys / nsize / feature_table().
 
     `num_steps` = walk hops (gset_sampler's meaning).  fused=True lets the walk kernel emit finished SpG rows
-    (csrc/walk.hip SPG mode; falls back to the general pipeline when it does not apply); fused=None picks it for
-    walks of >= 3 hops, where the per-root epilogue hides behind the walk's line fetches (measured: +10 % pairs/s
-    on the cit2-like graph at 3 hops, -9 % on the collab-like graph at 2 hops).  lazy=True leaves every size on the
+    (csrc/walk.hip SPG mode; falls back to the general pipeline when it does not apply); fused=None asks
+    prefers_fused(): walks of >= 3 hops, or any walk over a graph far beyond the caches -- there the per-root epilogue
+    hides behind the walk's line fetches (measured: cit2-like, 3 hops +10 % pairs/s; twitter-like, 2 hops +5 %;
+    collab-like, 2 hops, an 8 MB graph that lives in L2: -5 %).  lazy=True leaves every size on the
     device (no host round trip until SampledSets.resolve() / SpG.nnz); arrays are capacity-sized.
     strided=True: for a batch that is sampled, joined and dropped -- returns a StridedSpG (no packed copy of the rows)."""
     sets = None
@@ -163,7 +172,7 @@ def sample_spg(csr, query, num_walks=200, num_steps=3, seed=111413, rng="rand_r"
         if sets is not None:
             return StridedSpG(sets, csr.num_nodes), sets
     if fused is None:
-        fused = num_steps >= 3
+        fused = prefers_fused(csr, num_steps)
     if fused:
         sets = sample_sets(csr, query, num_walks=num_walks, num_steps=num_steps, bucket=bucket, seed=seed, rng=rng,
                            fused_rows=True, lazy=lazy, **kw)
