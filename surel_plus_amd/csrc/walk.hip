@@ -382,7 +382,11 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
     const int Ls = (range <= 1u) ? 0 : (32 - __builtin_clz(range - 1u));
     if (tid < B) cursor[tid] = 0;
     for (int s2 = tid; s2 < kSpgFold; s2 += kWalkThreads)    // flush the fold table to HBM (latency overlaps the sort)
+#if SG_EXPERIMENT == 8   // timing experiment: no registration in the HBM table (results are wrong)
+        if (fk[s2] != kEmptyKey) fs[s2] = s2;
+#else
         if (fk[s2] != kEmptyKey) fs[s2] = uniq_global_insert(a.table, fk[s2], tag0 + ft[s2], a.flags);
+#endif
     __syncthreads();
     SG_STAMP(4);
     uint32_t bk[kSpgPerLane];
