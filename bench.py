@@ -102,21 +102,18 @@ def hot_path_step(sp, csr, edge, M, k, seed, rng, slot=0):
     for the GPU when LAZY (every size stays on the device); finish_step() reads the sizes / status back.
     Returns (xz buffer view, indptr, sets)."""
     B = edge.shape[1]
-    roots = edge.reshape(-1).to(torch.int32)
     from surel_plus_amd.spg import prefers_fused
     strided = (prefers_fused(csr, k - 1) and FUSED is not False) if STRIDED is None else STRIDED
-    z, sets = sp.sample_spg(csr, roots, num_walks=M, num_steps=k - 1, seed=seed, rng=rng, fused=FUSED, lazy=LAZY, strided=strided,
-                            uniq_capacity=UNIQ_CAPACITY)
-    table = z.slot_table() if sets.strided else sets.feature_table()
-    rows = torch.arange(2 * B, device=edge.device, dtype=torch.int64).view(2, B)   # row i = root i of this batch
     # the join output is written into re-used buffers sized for the worst case (every set full), two of them in
     # turn so that step s+1 never overwrites what step s handed out: a serving loop would do the same, and it keeps
     # GB-sized device allocations -- tens of ms on some hosts -- out of the steps
-    cap = 2 * B * z.max_len * 2 * k
+    cap = 2 * B * (M * (k - 1) + 1) * 2 * k
     buf = _XZ_BUF.get((edge.device, cap, slot))
     if buf is None:
         buf = _XZ_BUF[(edge.device, cap, slot)] = torch.empty(cap, dtype=torch.float32, device=edge.device)
-    xz, ind = sp.gather(rows, z, edge.device, ptr=True, encode=table, out=buf, lazy=LAZY)
+    # the library's on-demand entry point: sample both endpoints of every pair -> SpG rows -> join
+    xz, ind, sets = sp.sample_and_gather(csr, edge, num_walks=M, num_steps=k - 1, seed=seed, rng=rng, out=buf if LAZY else None,
+                                         lazy=LAZY, strided=strided, fused=FUSED, uniq_capacity=UNIQ_CAPACITY)
     if LAZY:    # sizes + status + the join's row count start their way to pinned host memory now, behind this step
         sets.prefetch(extra=ind[-1:])
     return xz, ind, sets
@@ -331,6 +328,9 @@ def main():
     # region so that torch's caching allocator reaches its steady state (two steps in flight) here: a fresh GB-sized
     # hipMalloc inside the timed region costs ~10 ms on some hosts of the pool and is not part of the path.
     PRIME = 3
+    for slot in (0, 1):       # the two output buffers first, so that everything allocated per step settles around them
+        cap = 2 * B * (M * (k - 1) + 1) * 2 * k
+        _XZ_BUF[(dev, cap, slot)] = torch.empty(cap, dtype=torch.float32, device=dev)
     run_steps(list(range(PRIME)) + list(range(W)))
     torch.cuda.synchronize()
     if dist is not None:
@@ -347,6 +347,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    allocs_timed = torch.cuda.memory_stats().get("num_device_alloc", 0) - allocs0
+    host_steps = [b - a for a, b in zip(step_marks, step_marks[1:])]
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -392,10 +394,10 @@ def main():
                        "J_pairs_per_s": (B / (1e-3 * join_ms)) if join_ms else None,
                        "fused_spg_rows": sets.data is not None or sets.strided, "spg_layout": "strided rows joined in place (no CSR copy of the batch)" if sets.strided else "csr",
                        "ms_per_step_with_a_packed_csr_spg_per_batch": csr_ms,
-                       "device_allocs_in_timed_region": torch.cuda.memory_stats().get("num_device_alloc", 0) - allocs0,
-                       "host_step_ms_min_median_max": [round(1e3 * v, 3) for v in (
-                           lambda d: (min(d), sorted(d)[len(d) // 2], max(d)))(
-                           [b - a for a, b in zip(step_marks, step_marks[1:])])],
+                       "device_allocs_in_timed_region": allocs_timed,
+                       "host_step_ms_min_median_max": [round(1e3 * v, 3) for v in
+                                                       (min(host_steps), sorted(host_steps)[len(host_steps) // 2], max(host_steps))]
+                       if host_steps else None,
                        "stage_ms": {name: timer.mean_ms(name)[0] for name in
                                     ("walk_sets", "compact_sets", "uniq_rows", "spg_build", "sjoin_fill")}},
             "roofline": {"bound": "hbm", "kernel": "walk_sets_kernel" + ("<SPG>" if (sets.data is not None or sets.strided) else ""),

@@ -219,6 +219,36 @@ def pgather(edge, M, device=None, encode=None, gather_func=None, ptr=True, njobs
     return gather(edge, M, device, ptr=ptr, encode=encode)
 
 
+def sample_and_gather(csr, edge, num_walks=200, num_steps=3, seed=111413, rng="philox", dedup_roots=False, out=None,
+                      lazy=False, strided=None, **kw):
+    """The on-demand form of the path in one call: sample the endpoints of `edge` [2, B] (node ids), build their SpG
+    rows, join -> (xz, indptr, sets), the same (xz, indptr) as `gather(edge, subg_matrix(G, arange(N)))` would give for sets
+    drawn with the same RNG (Philox keys every walk by (seed, root id, walk, step), so a root's set does not depend on
+    where or how often it appears).  `num_steps` = walk hops.
+
+    dedup_roots=True samples every distinct endpoint once (needs rng="philox"): evaluation batches repeat a source
+    against a thousand candidates (utils.py:92-95), so half of the endpoints of such a batch are duplicates.
+    strided=None picks the joined-in-place form where the fused walk kernel is the faster one (spg.prefers_fused)."""
+    from .spg import prefers_fused, sample_spg
+    e = _as_rows(edge, csr.device)
+    B = e.shape[1]
+    if dedup_roots:
+        if rng != "philox":
+            raise ValueError("dedup_roots=True needs rng='philox' (rand_r sets depend on the position in the stream)")
+        roots, inv = torch.unique(e.reshape(-1), return_inverse=True)
+        rows = inv.view(2, B)
+    else:
+        roots = e.reshape(-1)
+        rows = torch.arange(2 * B, device=e.device, dtype=torch.int64).view(2, B)
+    if strided is None:
+        strided = prefers_fused(csr, num_steps)
+    z, sets = sample_spg(csr, roots.to(torch.int32), num_walks=num_walks, num_steps=num_steps, seed=seed, rng=rng, lazy=lazy,
+                         strided=strided, **kw)
+    table = z.slot_table() if sets.strided else sets.feature_table()
+    xz, ind = gather(rows, z, e.device, ptr=True, encode=table, out=out, lazy=lazy)
+    return xz, ind, sets
+
+
 def gather_counts(edge, x, table_rows, device=None):
     """Count form of gather() for mean aggregation (reference consumer model.py:78-83).
 

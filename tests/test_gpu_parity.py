@@ -782,3 +782,26 @@ def test_strided_falls_back_when_it_does_not_apply(sp):
     roots = torch.arange(100, dtype=torch.int32, device="cuda")
     z, sets = sp.sample_spg(csr, roots, num_walks=300, num_steps=4, rng="philox", strided=True)   # M*m+1 = 1201 > 818
     assert isinstance(z, sp.SpG) and not sets.strided
+
+
+@pytest.mark.parametrize("hops", [2, 3])
+def test_sample_and_gather_on_demand_and_root_dedup(sp, hops):
+    """one call = sample both endpoints + join; an evaluation-style batch (each source against many candidates,
+    utils.py:92-95) gives the same (xz, indptr) whether every endpoint is sampled or every DISTINCT endpoint once"""
+    indptr, indices = sym_graph(8000, 40000, 61, hubs=2)
+    csr = sp.DeviceCSR(indptr, indices)
+    rng = np.random.default_rng(2)
+    src = np.repeat(rng.integers(0, 8000, 16), 101)
+    dst = rng.integers(0, 8000, src.size)
+    edge = torch.from_numpy(np.stack([src, dst])).cuda()
+    xz_a, ind_a, sets_a = sp.sample_and_gather(csr, edge, num_walks=64, num_steps=hops, seed=5)
+    xz_b, ind_b, sets_b = sp.sample_and_gather(csr, edge, num_walks=64, num_steps=hops, seed=5, dedup_roots=True)
+    assert sets_b.nsize.numel() < sets_a.nsize.numel() // 2 + 20            # sources collapse to 16 roots
+    assert torch.equal(ind_a, ind_b) and torch.equal(xz_a, xz_b)
+    # against the offline route: SpG of all nodes, then gather by node id
+    z, setsz = sp.sample_spg(csr, torch.arange(8000, dtype=torch.int32, device="cuda"), num_walks=64, num_steps=hops, seed=5,
+                             rng="philox")
+    xz_c, ind_c = sp.gather(edge, z, "cuda", ptr=True, encode=setsz.feature_table())
+    assert torch.equal(ind_a, ind_c) and torch.equal(xz_a, xz_c)
+    with pytest.raises(ValueError):
+        sp.sample_and_gather(csr, edge, num_walks=8, num_steps=2, rng="rand_r", dedup_roots=True)
