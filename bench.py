@@ -271,6 +271,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        # `python bench.py --gpus N` without a launcher: this process has not touched the GPU yet, so it may start the
+        # N ranks itself (one process per GPU through torch.distributed.run, as the driver does) and hand their exit
+        # code on.  A launcher that set WORLD_SIZE to something else than --gpus is a usage error.
+        if "WORLD_SIZE" in os.environ:
+            sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; launch with "
+                     f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                     f"--master-port 29511 bench.py --gpus {args.gpus} ...`")
+        import subprocess
+        port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 400))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -635,7 +635,10 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
     a.table = spg ? uniq_view(uniq_table, uniq_capacity) : UniqTable{nullptr, nullptr, nullptr, 0};
     a.root_base = root_base;
     SG_REQUIRE(a.T <= 65536, SUBGACC_ERR_LDS, "walk: M*m+1 = %d is too large for the per-root LDS tables", Q);
-    const size_t lds = walk_lds_bytes(a.T, a.nwords, M, Q, spg, stride < Q);
+    // SUBGACC_LDS_PAD (dev-only): extra dynamic LDS per workgroup, i.e. fewer resident workgroups per CU -- the
+    // occupancy response of the kernel (tools/README.md)
+    static const size_t lds_pad = getenv("SUBGACC_LDS_PAD") ? (size_t)atol(getenv("SUBGACC_LDS_PAD")) : 0;
+    const size_t lds = walk_lds_bytes(a.T, a.nwords, M, Q, spg, stride < Q) + lds_pad;
     SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS,
                "walk: per-root tables need %zu B of LDS (> %d): M*m+1 = %d is too large", lds, kLdsBytes, Q);
 

@@ -144,7 +144,12 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
         if (shufB) draws_to_lds();
     }
     __syncthreads();
-    SG_BSTEP(0); SG_BSTEP(1); SG_BSTEP(2); SG_BSTEP(3); SG_BSTEP(4); SG_BSTEP(5);
+    SG_BSTEP(0);
+    // BSTEP(0) follows the Fisher-Yates chain through sarr[0..tid) -- reads that cross waves -- and the first loop
+    // iteration overwrites sarr with the NEXT root's draws: every wave must be through its chain before that
+    // (in the loop the barriers b1..b5 stand between the two)
+    __syncthreads();
+    SG_BSTEP(1); SG_BSTEP(2); SG_BSTEP(3); SG_BSTEP(4); SG_BSTEP(5);
     SG_BSTEP(6); SG_BSTEP(7); SG_BSTEP(8); SG_BSTEP(9); SG_BSTEP(10); SG_BSTEP(11);
 
     while (hasB) {

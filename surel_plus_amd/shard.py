@@ -37,9 +37,12 @@ def merge_unique_tables(tables):
 
 def all_gather_varlen(t, group=None):
     """all_gather of 1-D tensors (any dtype, the same on every rank) of different lengths: pad to the max length, one
-    collective each for the sizes and the payload."""
+    collective each for the sizes and the payload.  gloo has no all_gather for device tensors: they are staged
+    through the host there (the 1-GPU test set-up: several ranks share cuda:0 over gloo); RCCL gathers in HBM."""
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        return [p.to(t.device) for p in all_gather_varlen(t.cpu(), group)]
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
@@ -52,16 +55,54 @@ def all_gather_varlen(t, group=None):
     return [b[:s] for b, s in zip(bufs, sizes)]
 
 
+def rand_r_calls(indptr, roots, num_walks, num_steps, first_hop_wo=True, cap_root_degree=True):
+    """Number of rand_r draws the reference's sequential loop makes for `roots` (subg_acc.c:763-776: M shuffle draws when
+    deg > M; :790-808: one draw per later step of every walk; nothing for an isolated root) -- the stream position
+    at which the NEXT root starts.  This is what a rank needs to know about the roots in front of its range
+    (`calls_before` of subgacc_rng_positions); same arithmetic as rng_calls_kernel (csrc/walk.hip).  Works on
+    host or device tensors (a gather of the roots' degrees and a sum)."""
+    M, m = int(num_walks), int(num_steps)
+    r = torch.as_tensor(roots).long().reshape(-1)
+    if r.numel() == 0:
+        return 0
+    ip = indptr if torch.is_tensor(indptr) else torch.as_tensor(indptr)
+    deg = (ip[r + 1] - ip[r]).long()
+    if cap_root_degree:
+        deg = deg.clamp(max=1000000)                      # NEBMAX, subg_acc.c:13
+    if first_hop_wo:
+        calls = (deg > M).long() * M + M * (m - 1)
+    else:
+        calls = torch.full_like(deg, M * m)
+    return int((calls * (deg > 0).long()).sum().item())
+
+
+def hip_sampler(csr, **cfg):
+    """The product sampler (sampler.sample_sets over a DeviceCSR) in the form sample_sets_sharded drives:
+    sampler(query, lo, hi) samples roots [lo, hi) of `query` exactly as a single process sampling all of `query`
+    would have -- Philox streams are keyed by root id; the sequential rand_r stream is entered at the position the
+    roots in front of `lo` leave it at (rand_r_calls)."""
+    from . import sampler as S
+
+    def run(query, lo, hi, **kw):
+        q = S._as_query(query, csr.device)
+        args = dict(cfg, **kw)
+        if args.get("rng", "rand_r") == "rand_r" and lo > 0:
+            args["calls_before"] = rand_r_calls(csr.indptr, q[:lo], args.get("num_walks", 100), args.get("num_steps", 3),
+                                                args.get("first_hop_wo", True), args.get("cap_root_degree", True))
+        return S.sample_sets(csr, q[lo:hi], **args)
+    return run
+
+
 def sample_sets_sharded(sampler, query, rank, world, group=None, **kw):
     """Sample the contiguous share of `query` owned by this rank and give its LP rows GLOBAL numbers.
 
-    sampler(query_slice, lo=..., **kw) -> object with .sf (int32/int64 [X_local]) and .ukeys (int64 [c_local])
-    (surel_plus_amd.sampler.sample_sets bound to a DeviceCSR on GPUs; an oracle-backed stand-in in the CPU tests).
-    Returns (sets, global_ukeys, (lo, hi)); sets.sf is relabelled to index global_ukeys, sets.ukeys replaced.
-    With rng="philox" the sets do not depend on the sharding; with rng="rand_r" the caller passes
-    calls_before for its range (subgacc_rng_positions)."""
+    sampler(query, lo, hi, **kw) -> object with .sf / get_sf() (int32/int64 [X_local]) and .ukeys (int64 [c_local]):
+    hip_sampler(csr, ...) on GPUs; an oracle-backed stand-in in the CPU tests.
+    Returns (sets, global_ukeys, (lo, hi)); sets.sf is relabelled to index global_ukeys, sets.ukeys replaced."""
     lo, hi = shard_range(len(query), rank, world)
-    sets = sampler(query[lo:hi], lo=lo, **kw)
+    sets = sampler(query, lo, hi, **kw)
+    if hasattr(sets, "resolve"):
+        sets.resolve()
     if world == 1:
         return sets, sets.ukeys, (lo, hi)
     tables = all_gather_varlen(sets.ukeys, group)
@@ -70,6 +111,50 @@ def sample_sets_sharded(sampler, query, rank, world, group=None, **kw):
     sets.sf = maps[rank].to(sf.dtype)[sf.long()]
     sets.ukeys = gkeys
     return sets, gkeys, (lo, hi)
+
+
+def sample_spg_sharded(csr, roots, rank, world, group=None, num_walks=200, num_steps=3, seed=111413, rng="rand_r",
+                       bucket=-1, fused=None, replicate=True):
+    """The offline stage (subg_matrix, sampler/random_walks.py:74-82) split over `world` GPUs: every rank samples the
+    contiguous range of `roots` it owns with the product kernels (csr replicated), the per-rank tables of distinct LP
+    rows are all-gathered and merged in rank order -- the numbering a single process gives (subg_acc.c:957-978) --
+    and, with replicate=True, the finished rows are all-gathered so that every GPU holds the whole SpG (what the
+    join shards its pairs over).  Returns (SpG, global ukeys int64 [c], (lo, hi)); with replicate=False the SpG holds
+    rows [lo, hi) only.  `num_steps` = walk hops.  Bit-identical to the single-process sample_spg() in both RNG modes."""
+    from . import sampler as S
+    from .spg import SpG, sample_spg
+    q = S._as_query(roots, csr.device)
+    lo, hi = shard_range(q.numel(), rank, world)
+    kw = {}
+    if rng == "rand_r" and lo > 0:
+        kw["calls_before"] = rand_r_calls(csr.indptr, q[:lo], num_walks, num_steps)
+    z, sets = sample_spg(csr, q[lo:hi], num_walks=num_walks, num_steps=num_steps, seed=seed, rng=rng, bucket=bucket,
+                         fused=fused, **kw)
+    sets.resolve()
+    nnz = z.nnz
+    ids, data = z.indices[:nnz], z.data[:nnz]
+    gkeys = sets.ukeys
+    if world > 1:
+        gkeys, maps = merge_unique_tables(all_gather_varlen(sets.ukeys, group))
+        if nnz:
+            data = (maps[rank].to(torch.int32) + 1)[(data - 1).long()]      # SFptr+1 of the global numbering
+    n_cols = csr.num_nodes
+    if world > 1 and replicate:
+        row_off, ids, data = replicate_rows(sets.nsize, ids, data, group)
+        return SpG(row_off, ids, data, max_len=sets.stride, shape=(q.numel(), n_cols), max_data=gkeys.numel()), gkeys, (lo, hi)
+    return SpG(z.indptr, ids.contiguous(), data.contiguous(), max_len=sets.stride, shape=(hi - lo, n_cols),
+               max_data=gkeys.numel()), gkeys, (lo, hi)
+
+
+def lp_table(gkeys, num_walks, num_steps):
+    """Z_SF of a numbering held as packed keys: float32 [c+1, num_steps+1] = [0-row ; enc / M] (main.py:174 +
+    random_walks.py:81), on the device of `gkeys`."""
+    from ._lib import check, lib, ptr, stream_ptr
+    c = gkeys.numel()
+    out = torch.empty((c + 1, num_steps + 1), dtype=torch.float32, device=gkeys.device)
+    check(lib().subgacc_unpack_lp(ptr(gkeys.contiguous()), c, None, int(num_walks), int(num_steps), None, None, ptr(out), 1,
+                                  stream_ptr()))
+    return out
 
 
 def shard_pairs(edge, rank, world):

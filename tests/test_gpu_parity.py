@@ -81,6 +81,27 @@ def test_gset_sampler_matches_oracle(sp, rng, M, m, N, E, hubs):
         assert np.array_equal(x, y)
 
 
+@pytest.mark.parametrize("rng", ["rand_r", "philox"])
+def test_pipelined_walk_with_every_root_shuffled(sp, rng):
+    """Every degree > M = 200 and more roots than resident workgroups (2048): each workgroup of the persistent walk
+    kernel pipelines several roots whose first hop is the partial Fisher-Yates of subg_acc.c:763-776 -- the draws of
+    root k+1 land in the LDS array root k's lanes are still chasing unless a barrier separates them."""
+    ptr_, idx = sym_graph(6000, 900000, seed=21)
+    assert int(np.diff(ptr_).min()) > 200
+    q = np.random.default_rng(5).permutation(6000)
+    a = sp.gset_sampler(ptr_, idx, q, num_walks=200, num_steps=2, seed=31, debug=1, rng=rng)
+    b = oracle.gset_sampler(ptr_, idx, q, num_walks=200, num_steps=2, seed=31, debug=True, rng=rng)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    from surel_plus_amd.spg import sample_spg
+    csr = sp.DeviceCSR(ptr_, idx)
+    for fused in (False, True):          # the fused-row kernel on the same all-shuffled batch
+        z, sets = sample_spg(csr, q, num_walks=200, num_steps=2, seed=31, rng=rng, fused=fused)
+        oi, od, ov = oracle.spg_build(b[0], b[1])
+        assert np.array_equal(z.indptr.cpu().numpy(), oi) and np.array_equal(z.indices[: z.nnz].cpu().numpy(), od)
+        assert np.array_equal(z.data[: z.nnz].cpu().numpy(), ov)
+
+
 def test_gset_multichunk_and_int64_indptr(sp):
     ptr_, idx = sym_graph(5000, 30000, seed=5, hubs=1)
     q = np.arange(5000)

@@ -26,7 +26,8 @@ def pack_keys(rows, M):
 
 
 def oracle_sampler(g, M, m, seed):
-    def run(q, lo=0):
+    def run(query, lo, hi):
+        q = query[lo:hi]
         nsize, remap, enc = oracle.gset_sampler(g["indptr"], g["indices"], q, num_walks=M, num_steps=m, seed=seed,
                                                 rng="philox")
         return types.SimpleNamespace(nsize=torch.from_numpy(nsize), ids=torch.from_numpy(remap[0]),
@@ -112,3 +113,43 @@ def test_shard_pairs():
     e = torch.arange(20).view(2, 10)
     a, (lo, hi) = shard.shard_pairs(e, 1, 3)
     assert (lo, hi) == (4, 7) and torch.equal(a, e[:, 4:7])
+
+
+def _mixed_graph(seed=5, N=400, M=8):
+    """symmetric graph with isolated nodes, rows shorter and longer than M"""
+    rng = np.random.default_rng(seed)
+    src = rng.integers(10, N, 3000)
+    dst = (rng.integers(10, N, 3000) ** 2 // N).clip(10, N - 1)        # skewed: some long rows
+    keep = src != dst
+    e = np.unique(np.stack([np.r_[src[keep], dst[keep]], np.r_[dst[keep], src[keep]]]), axis=1)
+    indptr = np.zeros(N + 1, np.int64)
+    np.add.at(indptr, e[0] + 1, 1)
+    return np.cumsum(indptr).astype(np.int32), e[1].astype(np.int32)     # np.unique sorted by (row, col)
+
+
+def test_rand_r_calls_is_the_stream_position_of_the_next_root():
+    """shard.rand_r_calls(prefix) must be exactly what decides where the roots behind the prefix enter the sequential
+    rand_r stream (subg_acc.c:771,807): two different prefixes with the same count leave the suffix's sets unchanged,
+    a prefix with a different count does not -- checked with the oracle's sequential stream."""
+    M, m = 8, 3
+    indptr, indices = _mixed_graph(M=M)
+    deg = np.diff(indptr)
+    big, small, iso = np.flatnonzero(deg > M), np.flatnonzero((deg > 0) & (deg <= M)), np.flatnonzero(deg == 0)
+    assert len(big) >= 8 and len(small) >= 8 and len(iso) >= 4
+    suffix = np.r_[big[:3], small[:3], iso[:1], big[5:7]].astype(np.int32)
+    pa = np.r_[big[:4], small[:4], iso[:2]].astype(np.int32)
+    pb = np.r_[iso[2:4], small[4:8], big[4:8]].astype(np.int32)          # same class counts, other nodes, other order
+    pc = np.r_[big[:5], small[:3], iso[:2]].astype(np.int32)             # one more shuffled root: M more draws
+    ca, cb, cc = (shard.rand_r_calls(torch.from_numpy(indptr), p, M, m) for p in (pa, pb, pc))
+    assert ca == cb == 4 * (M + M * (m - 1)) + 4 * M * (m - 1) and cc == ca + M
+
+    def suffix_sets(prefix):
+        nsize, remap, enc, raw = oracle.gset_sampler(indptr, indices, np.r_[prefix, suffix], num_walks=M, num_steps=m,
+                                                     seed=3, rng="rand_r", debug=True)
+        off = int(nsize[: len(prefix)].sum())
+        return nsize[len(prefix):], remap[0][off:], raw[off:]
+    a, b, c = suffix_sets(pa), suffix_sets(pb), suffix_sets(pc)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert not all(np.array_equal(x, y) for x, y in zip(a, c))
+    assert shard.rand_r_calls(indptr, np.zeros(0, np.int32), M, m) == 0
+    assert shard.rand_r_calls(torch.from_numpy(indptr), pa, M, m, first_hop_wo=False) == 8 * M * m
