@@ -31,17 +31,37 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 WORKLOADS = {
-    # name: (graph preset, num_walks M, CLI num_steps k (walk hops m = k-1), description)
-    "cit2": ("cit2", 200, 4, "cit2-like LP: N=2,927,963 avg-deg 20.7 power-law graph, M=200, --num_steps 4 (m=3 hops)"),
-    "collab": ("collab", 200, 3, "collab-like LP: N=235,868 avg-deg 8.2 power-law graph, M=200, --num_steps 3 (m=2 hops)"),
-    "ppa": ("ppa", 200, 4, "ppa-like LP: N=576,289 avg-deg 73.7 power-law graph, M=200, --num_steps 4 (m=3 hops)"),
+    # name: (graph preset, num_walks M, CLI num_steps k (walk hops m = k-1), description, fraction of positive pairs)
+    "cit2": ("cit2", 200, 4, "cit2-like LP: N=2,927,963 avg-deg 20.7 power-law graph, M=200, --num_steps 4 (m=3 hops)", 0.5),
+    "collab": ("collab", 200, 3, "collab-like LP: N=235,868 avg-deg 8.2 power-law graph, M=200, --num_steps 3 (m=2 hops)", 0.5),
+    # configs[2]: --k 20 negatives per positive (README.md:86) -> 1 pair in 21 is an edge of the graph, 20 are uniform pairs
+    "ppa": ("ppa", 200, 4, "ppa-like LP: N=576,289 avg-deg 73.7 power-law graph, M=200, --num_steps 4 (m=3 hops), "
+                           "1:20 positive:negative pairs (k=20)", 1.0 / 21.0),
     # configs[4]: twitter-follower scale (41.65 M nodes, ~2.9 B adjacency entries, int64 row offsets, 12 GB CSR
     # resident in HBM); the reference gives no walk parameters for it -- collab's are used
-    "twitter": ("twitter", 200, 3, "twitter-like LP: N=41,652,230, ~2.9e9 adjacency entries (int64 indptr), M=200, --num_steps 3"),
-    # configs[3]: the PPR sampler itself is out of scope (sampler/pprgo.py); only SpJoin over its float SpG is timed
+    "twitter": ("twitter", 200, 3, "twitter-like LP: N=41,652,230, ~2.9e9 adjacency entries (int64 indptr), M=200, --num_steps 3", 0.5),
+    # configs[3]: SpJoin over the float SpG of the PPR encoder (the store is built by the GPU PPR sampler in set-up)
     "cit2ppr": (None, 0, 1, "cit2-like PPR encoder: float64 SpG = topk_ppr_matrix(alpha=0.1, eps=1e-4, top-100, 'sym') + encoding 'PPR' "
-                            "over all N=2,927,963 nodes (built on the GPU in set-up), SpJoin only (train.py:39-43)"),
+                            "over all N=2,927,963 nodes (built on the GPU in set-up), SpJoin only (train.py:39-43)", 0.5),
 }
+# Measured on this part (tools/line_probe.hip, profiles/r02_line_probe_pmc.csv): an L2 miss moves one whole 128-byte line
+# whatever the access width, and the chip sustains ~55 G random lines/s from tables up to 1 GiB (Infinity Cache or
+# HBM alike), ~48-50 G lines/s from 4-12 GiB.  This -- not bytes of useful data -- is what bounds a random walk.
+LINE_BYTES = 128
+
+
+def random_line_roof(table_bytes):
+    return 55e9 if table_bytes <= (1 << 30) else 49e9
+
+
+def kernel_source_sha():
+    """identifies the kernels a PMC traffic figure belongs to (the GPU box has no .git): sha256 over csrc + the header"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "surel_plus_amd", "csrc", "*.h*")) + [os.path.join(ROOT, "include", "subgacc.h")]):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # SUBGACC_FUSED: 1 = the walk kernel also emits finished SpG rows (walk_spg), 0 = general pipeline, unset = the
 # library's choice (fused for walks of >= 3 hops)
@@ -189,7 +209,7 @@ def cpu_baseline(csr, edge_all, M, k, target_s=15.0):
                       + f", {ts:.2f}s of {t:.2f}s; SpG build + SpJoin = oracle C port ({threads} threads)"}
 
 
-def main_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc):
+def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W):
     """SpJoin over a resident float-payload SpG (the citation2 PPR configuration): one step = B pairs -> xz [R,2,1]."""
     from surel_plus_amd.graphs import ppr_like_spg, preset_graph
     if os.environ.get("SUBGACC_PPR_SYNTH", "0") == "1":      # stand-in payload: exactly 100 random ids per row
@@ -205,7 +225,6 @@ def main_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc):
         torch.cuda.synchronize()
         prep_s = time.perf_counter() - t_prep
         del csr
-    B, K, W = args.pairs, args.steps, args.warmup
     gens = [torch.Generator(device=dev).manual_seed(1000 * rank + s) for s in range(K + W)]
     edges = [torch.randint(0, N, (2, B), device=dev, generator=g) for g in gens]
     timer = KernelTimer()
@@ -233,87 +252,37 @@ def main_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     sj.sjoin = orig
+    sampler_mod.KERNEL_TIMER = None
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    if rank == 0:
-        ms, launches = timer.mean_ms("sjoin_fill")
-        rows_out = int(xz.shape[0])                # 64 + (|S_u|+|S_v|) * (12 read: id + f64 payload, 8 written: f32 [.,2,1])
-        abytes = B * 64 + rows_out * (12 + 8)
-        out = {"metric": "query-pairs/sec (SpJoin, PPR payload)", "value": world * B * K / elapsed, "unit": "query-pairs/s",
-               "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": desc, "pairs_per_step_per_gpu": B, "xz_rows_last_step": int(xz.shape[0]),
-                          "spg_members": z.nnz, "offline_ppr_stage_s": prep_s},
-               "roofline": {"bound": "hbm", "kernel": "sjoin_fill (sizes + scan + sjoin_pair_kernel<f64>)", "achieved": abytes / (ms * 1e-3) / 1e9,
-                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "traffic": None, "kernel_ms": ms, "launches_timed": launches,
-                            "algorithmic_bytes_per_launch": abytes}}
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    ms, launches = timer.mean_ms("sjoin_fill")
+    rows_out = int(xz.shape[0])                # 64 + (|S_u|+|S_v|) * (12 read: id + f64 payload, 8 written: f32 [.,2,1])
+    abytes = B * 64 + rows_out * (12 + 8)
+    return {"metric": "query-pairs/sec (SpJoin, PPR payload)", "value": world * B * K / elapsed, "unit": "query-pairs/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc, "pairs_per_step_per_gpu": B, "xz_rows_last_step": int(xz.shape[0]),
+                       "spg_members": z.nnz, "offline_ppr_stage_s": prep_s},
+            "roofline": {"bound": "hbm", "kernel": "sjoin_fill (sizes + scan + sjoin_pair_kernel<f64>)", "achieved": abytes / (ms * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": None, "kernel_ms": ms, "launches_timed": launches,
+                         "algorithmic_bytes_per_launch": abytes}}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cit2", choices=sorted(WORKLOADS))
-    ap.add_argument("--pairs", type=int, default=65536, help="query pairs per step per GPU")
-    ap.add_argument("--rng", default="philox", choices=["philox", "rand_r"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; invalidates the number)")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        # `python bench.py --gpus N` without a launcher: this process has not touched the GPU yet, so it may start the
-        # N ranks itself (one process per GPU through torch.distributed.run, as the driver does) and hand their exit
-        # code on.  A launcher that set WORLD_SIZE to something else than --gpus is a usage error.
-        if "WORLD_SIZE" in os.environ:
-            sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; launch with "
-                     f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
-                     f"--master-port 29511 bench.py --gpus {args.gpus} ...`")
-        import subprocess
-        port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 400))
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
-        sys.exit(subprocess.call(cmd))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL ("nccl") is the backend; SUBGACC_DIST_BACKEND=gloo + SUBGACC_SHARE_GPU=1 lets a 1-GPU box exercise the
-        # multi-rank control flow (barriers, max-over-ranks) with every rank on cuda:0
-        backend = os.environ.get("SUBGACC_DIST_BACKEND", "nccl")
-        if os.environ.get("SUBGACC_SHARE_GPU", "0") == "1":
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", torch.cuda.current_device())
-
-    import surel_plus_amd as sp
-    from surel_plus_amd import sampler as sampler_mod
+def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, with_cpu_baseline, csr_variant=True):
+    """sample + SpJoin over one LP workload: W warm-up steps, K timed steps bracketed by barrier + synchronize, max over
+    ranks.  Returns the JSON object (rank 0) or None."""
+    global STRIDED
     from surel_plus_amd.graphs import preset_graph, query_pairs
-
-    preset, M, k, desc = WORKLOADS[args.workload]
-    if preset is None:
-        return main_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc)
+    preset, M, k, desc, pos_frac = WORKLOADS[name]
     csr = preset_graph(preset, device=dev, scale=args.scale)
-    B, K, W = args.pairs, args.steps, args.warmup
     # every step's pairs are resident in HBM before the clock starts; ranks and steps get different pairs
-    edges = [query_pairs(csr, B, seed=1000 * rank + s, device=dev) for s in range(K + W)]
-
+    edges = [query_pairs(csr, B, seed=1000 * rank + s, device=dev, pos_frac=pos_frac) for s in range(K + W)]
+    _XZ_BUF.clear()
     timer = KernelTimer()
     sampler_mod.KERNEL_TIMER = timer
     last = None
@@ -327,7 +296,7 @@ def main():
         pending = None
         for s in step_ids:
             e = edges[s % len(edges)]
-            queued = hot_path_step(sp, csr, e, M, k, seed=s, rng=args.rng, slot=s & 1)
+            queued = hot_path_step(sp, csr, e, M, k, seed=s, rng=rng, slot=s & 1)
             if pending is not None:
                 xz, ind, sets = finish_step(*pending[1])
                 last = (pending[0], sets, xz)
@@ -369,8 +338,7 @@ def main():
 
     # for the record, outside the clock: the same steps with a packed CSR SpG built for every batch (rank 0, 1 GPU)
     csr_ms = None
-    if rank == 0 and world == 1 and last is not None and last[1].strided:
-        global STRIDED
+    if csr_variant and rank == 0 and world == 1 and last is not None and last[1].strided:
         keep_last, keep_strided, STRIDED = last, STRIDED, False
         run_steps(range(3))                                   # allocator steady state for this variant
         torch.cuda.synchronize()
@@ -379,51 +347,162 @@ def main():
         torch.cuda.synchronize()
         csr_ms = (time.perf_counter() - t1) / max(K, 1) * 1e3
         last, STRIDED = keep_last, keep_strided
+    sampler_mod.KERNEL_TIMER = None
+    if rank != 0:
+        return None
 
-    if rank == 0:
-        edge, sets, xz = last
-        walk_ms, launches = timer.mean_ms("walk_sets")
-        join_ms, _ = timer.mean_ms("sjoin_fill")
-        abytes = algorithmic_walk_bytes(csr, edge.reshape(-1), sets, M, k - 1)   # the last step's launch
-        achieved = abytes / (walk_ms * 1e-3) / 1e9 if walk_ms else None
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            fused_rows = sets.data is not None or sets.strided
-            tk = f"{args.workload}:{B}:{M}:{k}:{'spg' if fused_rows else 'sets'}"
-            traffic = tj.get(tk, {}).get("walk_sets_hbm_bytes_per_launch")
-        out = {
-            "metric": "query-pairs/sec (sample+SpJoin)", "value": world * B * K / elapsed, "unit": "query-pairs/s",
-            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": desc, "pairs_per_step_per_gpu": B, "roots_per_step_per_gpu": 2 * B,
-                       "num_walks": M, "num_steps_cli": k, "rng": args.rng, "parallelism": f"query-shard x{world}",
-                       "set_members_last_step": sets.X, "distinct_lp_rows_last_step": sets.c,
-                       "xz_rows_last_step": int(xz.shape[0]), "graph_nnz": csr.nnz,
-                       # S = roots/s of the sampler pipeline (walk .. SpG), J = pairs/s of the join alone
-                       "S_roots_per_s": 2 * B / (1e-3 * sum(v for v in (timer.mean_ms(n_)[0] for n_ in
-                                                 ("walk_sets", "compact_sets", "uniq_rows", "spg_build")) if v)),
-                       "J_pairs_per_s": (B / (1e-3 * join_ms)) if join_ms else None,
-                       "fused_spg_rows": sets.data is not None or sets.strided, "spg_layout": "strided rows joined in place (no CSR copy of the batch)" if sets.strided else "csr",
-                       "ms_per_step_with_a_packed_csr_spg_per_batch": csr_ms,
-                       "device_allocs_in_timed_region": allocs_timed,
-                       "host_step_ms_min_median_max": [round(1e3 * v, 3) for v in
-                                                       (min(host_steps), sorted(host_steps)[len(host_steps) // 2], max(host_steps))]
-                       if host_steps else None,
-                       "stage_ms": {name: timer.mean_ms(name)[0] for name in
-                                    ("walk_sets", "compact_sets", "uniq_rows", "spg_build", "sjoin_fill")}},
-            "roofline": {"bound": "hbm", "kernel": "walk_sets_kernel" + ("<SPG>" if (sets.data is not None or sets.strided) else ""),
-                         "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel_ms": walk_ms, "launches_timed": launches, "algorithmic_bytes_per_launch": abytes},
-        }
-        if world == 1 and not args.no_cpu_baseline and args.workload != "twitter":   # 12 GB CSR: no host copy
+    edge, sets, xz = last
+    walk_ms, launches = timer.mean_ms("walk_sets")
+    join_ms, _ = timer.mean_ms("sjoin_fill")
+    abytes = algorithmic_walk_bytes(csr, edge.reshape(-1), sets, M, k - 1)   # the last step's launch
+    achieved = abytes / (walk_ms * 1e-3) / 1e9 if walk_ms else None
+    fused_rows = sets.data is not None or sets.strided
+    recs = csr.hop_records()
+    # HBM-side traffic / missed lines of the walk kernel: PMC passes (tools/pmc_traffic.py) of exactly these kernels
+    # (matched by a hash of the kernel sources) and this configuration -- or null
+    traffic = lines = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath)).get(f"{name}:{B}:{M}:{k}:{'spg' if fused_rows else 'sets'}:{rng}", {})
+        if tj.get("kernel_source_sha") == kernel_source_sha():
+            traffic, lines = tj.get("walk_sets_hbm_bytes_per_launch"), tj.get("walk_sets_l2_miss_lines_per_launch")
+    roof = random_line_roof((8 if recs else 4) * csr.nnz)
+    out = {
+        "metric": "query-pairs/sec (sample+SpJoin)", "value": world * B * K / elapsed, "unit": "query-pairs/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "config": {"workload": desc, "pairs_per_step_per_gpu": B, "roots_per_step_per_gpu": 2 * B,
+                   "num_walks": M, "num_steps_cli": k, "rng": rng, "parallelism": f"query-shard x{world}",
+                   "set_members_last_step": sets.X, "distinct_lp_rows_last_step": sets.c,
+                   "xz_rows_last_step": int(xz.shape[0]), "graph_nnz": csr.nnz,
+                   "graph_walked_through": "packed hop records (8 B per adjacency entry)" if recs else "plain CSR",
+                   # S = roots/s of the sampler pipeline (walk .. SpG), J = pairs/s of the join alone
+                   "S_roots_per_s": 2 * B / (1e-3 * sum(v for v in (timer.mean_ms(n_)[0] for n_ in
+                                             ("walk_sets", "compact_sets", "uniq_rows", "spg_build")) if v)),
+                   "J_pairs_per_s": (B / (1e-3 * join_ms)) if join_ms else None,
+                   "fused_spg_rows": fused_rows, "spg_layout": "strided rows joined in place (no CSR copy of the batch)" if sets.strided else "csr",
+                   "ms_per_step_with_a_packed_csr_spg_per_batch": csr_ms,
+                   "device_allocs_in_timed_region": allocs_timed,
+                   "host_step_ms_min_median_max": [round(1e3 * v, 3) for v in
+                                                   (min(host_steps), sorted(host_steps)[len(host_steps) // 2], max(host_steps))]
+                   if host_steps else None,
+                   "stage_ms": {n_: timer.mean_ms(n_)[0] for n_ in
+                                ("walk_sets", "compact_sets", "uniq_rows", "spg_build", "sjoin_fill")}},
+        "roofline": {"bound": "hbm", "kernel": "walk_sets_kernel" + ("<SPG>" if fused_rows else ""),
+                     "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+                     "kernel_ms": walk_ms, "launches_timed": launches, "algorithmic_bytes_per_launch": abytes,
+                     # the roof this kernel actually sits under: random 128-byte lines per second
+                     "random_line_roof": {"lines_per_s": roof, "line_bytes": LINE_BYTES,
+                                          "source": "profiles/r02_line_probe_pmc.csv (tools/line_probe.hip)",
+                                          "l2_miss_lines_per_launch": lines,
+                                          "achieved_lines_per_s": (lines / (walk_ms * 1e-3)) if (lines and walk_ms) else None,
+                                          "frac": (lines / (walk_ms * 1e-3) / roof) if (lines and walk_ms) else None}},
+    }
+    if with_cpu_baseline and name != "twitter":   # 12 GB CSR: no host copy
+        try:
+            out["cpu_baseline"] = cpu_baseline(csr, edges[W], M, k)
+        except Exception as ex:  # the baseline is a report, never a reason to lose the measurement
+            out["cpu_baseline"] = {"value": None, "unit": "query-pairs/s", "cores": os.cpu_count(), "kind": "port",
+                                   "sample": f"failed: {type(ex).__name__}: {ex}"}
+    return out
+
+
+def summary(o):
+    """what an `other_workloads` entry keeps of a full line"""
+    keep = {k_: o[k_] for k_ in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype")}
+    keep["config"] = {k_: o["config"].get(k_) for k_ in ("workload", "pairs_per_step_per_gpu", "rng", "set_members_last_step",
+                                                         "distinct_lp_rows_last_step", "xz_rows_last_step", "graph_nnz",
+                                                         "graph_walked_through", "spg_layout", "stage_ms", "spg_members",
+                                                         "offline_ppr_stage_s") if k_ in o["config"]}
+    keep["roofline"] = o["roofline"]
+    if "cpu_baseline" in o:
+        keep["cpu_baseline"] = o["cpu_baseline"]
+    return keep
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cit2", choices=sorted(WORKLOADS))
+    ap.add_argument("--pairs", type=int, default=65536, help="query pairs per step per GPU")
+    ap.add_argument("--rng", default="philox", choices=["philox", "rand_r"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="skip the short passes over BASELINE.json's other configs")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; invalidates the number)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        # `python bench.py --gpus N` without a launcher: this process has not touched the GPU yet, so it may start the
+        # N ranks itself (one process per GPU through torch.distributed.run, as the driver does) and hand their exit
+        # code on.  A launcher that set WORLD_SIZE to something else than --gpus is a usage error.
+        if "WORLD_SIZE" in os.environ:
+            sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; launch with "
+                     f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 "
+                     f"--master-port 29511 bench.py --gpus {args.gpus} ...`")
+        import subprocess
+        port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 400))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # RCCL ("nccl") is the backend; SUBGACC_DIST_BACKEND=gloo + SUBGACC_SHARE_GPU=1 lets a 1-GPU box exercise the
+        # multi-rank control flow (barriers, max-over-ranks) with every rank on cuda:0
+        backend = os.environ.get("SUBGACC_DIST_BACKEND", "nccl")
+        if os.environ.get("SUBGACC_SHARE_GPU", "0") == "1":
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    import surel_plus_amd as sp
+    from surel_plus_amd import sampler as sampler_mod
+
+    B, K, W = args.pairs, args.steps, args.warmup
+    t_start = time.perf_counter()
+    if WORKLOADS[args.workload][0] is None:
+        out = bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, WORKLOADS[args.workload][3], B, K, W)
+    else:
+        out = bench_lp(args, args.workload, args.rng, B, K, W, sp, sampler_mod, dev, rank, world, dist,
+                       with_cpu_baseline=(world == 1 and not args.no_cpu_baseline))
+    # BASELINE.json's other single-GPU configurations (and the reference-bit-exact rand_r stream on the headline one),
+    # as short passes after the timed region: same code path, >= 5 timed steps each, their own roofline blocks
+    # (configs[0], the reference's CPU-runnable collab case, rides on the collab entry as its cpu_baseline).
+    if rank == 0 and world == 1 and not args.no_others and args.workload == "cit2" and args.rng == "philox" and args.scale == 1.0:
+        others = {}
+        budget_s = float(os.environ.get("SUBGACC_OTHERS_BUDGET_S", "900"))
+        for key, (wl, rng_o) in {"cit2 (rng=rand_r: the reference's own stream, bit-exact mode)": ("cit2", "rand_r"),
+                                 "collab": ("collab", "philox"), "ppa": ("ppa", "philox"),
+                                 "cit2ppr": ("cit2ppr", "philox"), "twitter": ("twitter", "philox")}.items():
+            if time.perf_counter() - t_start > budget_s:
+                others[key] = {"skipped": f"time budget of {budget_s:.0f} s for the whole run reached"}
+                continue
             try:
-                out["cpu_baseline"] = cpu_baseline(csr, edges[W], M, k)
-            except Exception as ex:  # the baseline is a report, never a reason to lose the measurement
-                out["cpu_baseline"] = {"value": None, "unit": "query-pairs/s", "cores": os.cpu_count(), "kind": "port",
-                                       "sample": f"failed: {type(ex).__name__}: {ex}"}
+                torch.cuda.empty_cache()
+                Ko, Wo = max(5, min(K, 10)), 2
+                if WORKLOADS[wl][0] is None:
+                    o = bench_ppr(args, sp, sampler_mod, dev, 0, 1, None, WORKLOADS[wl][3], B, Ko, Wo)
+                else:
+                    o = bench_lp(args, wl, rng_o, B, Ko, Wo, sp, sampler_mod, dev, 0, 1, None,
+                                 with_cpu_baseline=(wl == "collab" and not args.no_cpu_baseline), csr_variant=False)
+                others[key] = summary(o)
+            except Exception as ex:   # an extra must never cost the headline line
+                others[key] = {"failed": f"{type(ex).__name__}: {ex}"}
+        out["config"]["other_workloads"] = others
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SUBGACC_ABI_VERSION 1
+#define SUBGACC_ABI_VERSION 2
 
 typedef enum subgacc_status {
     SUBGACC_OK = 0,
@@ -68,7 +68,24 @@ typedef struct subgacc_walk_cfg {
     int32_t cap_root_degree; /* 1: clamp the root degree to 1e6 (NEBMAX, subg_acc.c:750)        */
     int32_t indptr64;        /* CSR row offsets are int64 (else int32)                          */
     int32_t emit_walks;      /* 1: also write raw walks int32[n, M*(m+1)] (walk_sampler)        */
+    /* optional packed hop records (subgacc_hop_records_build; NULL = walk the plain CSR).  Same sets, bit for bit:
+     * a hop then costs ONE dependent read (neighbour id, its row begin and its degree arrive together) instead of
+     * the reference's two (indices[...] then indptr[neighbour], subg_acc.c:803-808). */
+    const uint64_t *hop_records;
+    int32_t rec_id_bits;     /* field widths of a record, from the top: [id | row begin | degree]        */
+    int32_t rec_beg_bits;
 } subgacc_walk_cfg;
+
+/* Packed hop records of a CSR graph: rec[e] = (v = indices[e], indptr[v], deg(v)) in one 64-bit word, for every
+ * adjacency entry e -- an auxiliary, read-only view of the replicated graph (8 B per entry) built once per graph.
+ * Widths: id_bits = bits of num_nodes-1, beg_bits = bits of nnz, the degree takes the rest; a degree that does not
+ * fit is stored as all-ones and looked up in indptr by the walk (hubs: their row pointers are L2-hot anyway).
+ * subgacc_hop_records_layout returns the degree width (>= 12 or the graph is not worth packing: returns 0, e.g.
+ * the twitter-like graph with 26 + 32 bits).  subgacc_hop_records_build accepts wider id / offset fields than the
+ * layout's (id_bits <= 32, id_bits + beg_bits <= 60). */
+int subgacc_hop_records_layout(int64_t num_nodes, int64_t nnz, int32_t *id_bits, int32_t *beg_bits);
+int subgacc_hop_records_build(const void *indptr, int32_t indptr64, const int32_t *indices, int64_t num_nodes, int64_t nnz,
+                              int32_t id_bits, int32_t beg_bits, uint64_t *out_records, void *stream);
 
 /* LP rows are carried as one packed 64-bit key: count of step j in bits [(m-j)*SHIFT, +SHIFT),
  * SHIFT = 32-clz(M), plus bit m*SHIFT (LEAD) on the root row -- the reference's `bithash`
@@ -82,7 +99,7 @@ int subgacc_key_shift(int32_t num_walks, int32_t num_steps);
  * Writes rng_pos[i] (LCG steps before root i, mod 2^32) and rng_seed[i].
  * `calls_before` = draws consumed before query[0] (for sharded / chunked callers). */
 size_t subgacc_rng_positions_workspace_bytes(int64_t n);
-int subgacc_rng_positions(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *query, int64_t n,
+int subgacc_rng_positions(const subgacc_walk_cfg *cfg, const void *indptr, int64_t num_nodes, const int32_t *query, int64_t n,
                           int32_t rng_streams, uint64_t calls_before, uint32_t *rng_pos, uint32_t *rng_seed,
                           void *workspace, size_t workspace_bytes, void *stream);
 
@@ -93,7 +110,10 @@ int subgacc_rng_positions(const subgacc_walk_cfg *cfg, const void *indptr, const
  *   walks   [n*M*(m+1)] int32  (emit_walks only, else NULL)
  *   flags   [4]        int32   [0] |= 1 when RAND_R mode met a dead end (degree-0 non-root: the call
  *                              count is then data dependent and the stream cannot be reproduced in
- *                              parallel); [1] += roots whose set overflowed `bucket`.  Caller zeroes.
+ *                              parallel); [1] += roots whose set overflowed `bucket`; [3] |= 16 when a root
+ *                              lies outside [0, num_nodes): it is never looked up (the reference reads out of
+ *                              bounds there), its set is empty and the host mirror raises IndexError.
+ *                              Caller zeroes.
  * rng_pos / rng_seed: from subgacc_rng_positions (RAND_R) or NULL (PHILOX). */
 int subgacc_walk_sets(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,
                       const int32_t *query, int64_t n, const uint32_t *rng_pos, const uint32_t *rng_seed,
@@ -183,10 +203,13 @@ int subgacc_spg_build(const int64_t *row_off, int64_t n, const int32_t *ids, con
  *     ( value_own(w), value_partner(w) or 0 ).
  * gather(edge[2,B]):  own = [u..,v..], partner = [v..,u..];  hgather: [u,w,v,w] / [w,u,w,v].
  * ------------------------------------------------------------------------------------------- */
-/* out_seg[S+1] int64 = exclusive scan of the segment sizes (`indptr` of train.py:20-22) */
+/* out_seg[S+1] int64 = exclusive scan of the segment sizes (`indptr` of train.py:20-22).
+ * n_rows = rows of the store.  A row number outside [0, n_rows) in own / partner (partner may be NULL: not checked
+ * then) -- an IndexError of `x[edge[0]]` in the reference, train.py:15 -- is never dereferenced by any join entry
+ * point: the row reads as empty and flags[3] |= 16 (flags: int32[4], caller zeroes; may be NULL). */
 size_t subgacc_sjoin_workspace_bytes(int64_t S);
-int subgacc_sjoin_sizes(const int64_t *spg_indptr, const int64_t *own, int64_t S, int64_t *out_seg, void *workspace,
-                        size_t workspace_bytes, void *stream);
+int subgacc_sjoin_sizes(const int64_t *spg_indptr, int64_t n_rows, const int64_t *own, const int64_t *partner, int64_t S,
+                        int64_t *out_seg, int32_t *flags, void *workspace, size_t workspace_bytes, void *stream);
 /* Fill R = out_seg[S] rows.
  *   spg_data_i32 (payload = SFptr+1) xor spg_data_f64 (PPR payload, train.py:39-43)
  *   table f32 [table_rows, k] (Z_SF with the zero row) or NULL
@@ -199,7 +222,7 @@ int subgacc_sjoin_sizes(const int64_t *spg_indptr, const int64_t *own, int64_t S
  *   and block 2t+1 mirrors block 2t (own/partner swapped) -- gather passes P = B, hgather P = B; the mirrored
  *   segments are then produced together and every SpG row is read once (flags[3] |= 4 if the list is not
  *   mirrored like that). */
-int subgacc_sjoin_fill(const int64_t *spg_indptr, const int32_t *spg_indices, const int32_t *spg_data_i32,
+int subgacc_sjoin_fill(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices, const int32_t *spg_data_i32,
                        const double *spg_data_f64, const int64_t *own, const int64_t *partner, int64_t S,
                        const int64_t *seg, const float *table, int64_t table_rows, int32_t k, float *out_xz,
                        int32_t *out_idx, int64_t *out_segid, int32_t max_len, int64_t pair_block, int32_t *flags,
@@ -210,9 +233,9 @@ int subgacc_sjoin_fill(const int64_t *spg_indptr, const int32_t *spg_indices, co
  * A transient batch is joined straight from there: no packed CSR copy (subgacc_compact_rows) is made, slots become
  * SFptr+1 on their way into LDS.  uniq_table = NULL: `table` is indexed by slot+1 itself (subgacc_unpack_lp over the
  * table's key plane, zero_row = 1) and no numbering is consulted.  Mirrored segment lists only (pair_block > 0). */
-int subgacc_sjoin_sizes_rows(const int32_t *row_len, const int64_t *own, int64_t S, int64_t *out_seg, void *workspace,
-                             size_t workspace_bytes, void *stream);
-int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t row_stride, const int32_t *row_ids, const int32_t *row_slot,
+int subgacc_sjoin_sizes_rows(const int32_t *row_len, int64_t n_rows, const int64_t *own, const int64_t *partner, int64_t S,
+                             int64_t *out_seg, int32_t *flags, void *workspace, size_t workspace_bytes, void *stream);
+int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids, const int32_t *row_slot,
                             const void *uniq_table, int64_t uniq_capacity, const int64_t *own, const int64_t *partner,
                             int64_t S, const int64_t *seg, const float *table, int64_t table_rows, int32_t k,
                             float *out_xz, int32_t *out_idx, int64_t *out_segid, int64_t pair_block, int32_t *flags,
@@ -223,7 +246,7 @@ int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t row_stride, const in
  * in either feature slot of segment j, so that  segment_sum_j(MLP(xz).sum(-2)) == out_counts[j] @ MLP(Z_SF).
  * The segment list must be mirrored blocks (pair_block as for subgacc_sjoin_fill, > 0).  LDS bound:
  * 16*max_len + 8*table_rows bytes <= 160 KiB (SUBGACC_ERR_LDS otherwise: use subgacc_sjoin_fill). */
-int subgacc_sjoin_counts(const int64_t *spg_indptr, const int32_t *spg_indices, const int32_t *spg_data_i32,
+int subgacc_sjoin_counts(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices, const int32_t *spg_data_i32,
                          const int64_t *own, const int64_t *partner, int64_t S, int64_t table_rows, float *out_counts,
                          int32_t max_len, int64_t pair_block, int32_t *flags, void *stream);
 

@@ -45,9 +45,15 @@ def ref_module():
     hits = glob.glob(os.path.join(_HERE, "_ref", "subg_acc*.so"))
     if not hits:
         return None
+    import sys
+    prev = sys.modules.get("subg_acc")          # the drop-in mirror at the repo root has the same module name:
     spec = importlib.util.spec_from_file_location("subg_acc", hits[0])
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
+    if prev is not None:                        # a single-phase extension registers itself in sys.modules -- the
+        sys.modules["subg_acc"] = prev          # checker must never shadow (or be mistaken for) the product module
+    else:
+        sys.modules.pop("subg_acc", None)
     return mod
 
 

@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsubgacc_hip.so")
+# SUBGACC_LIB (dev-only): load an experiment build from elsewhere (tools/ab_*.sh) -- the shipped library is never overwritten
+LIB_PATH = os.environ.get("SUBGACC_LIB") or os.path.join(_HERE, "libsubgacc_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 OK, ERR_BADARG, ERR_WORKSPACE, ERR_KEYWIDTH, ERR_CAPACITY, ERR_HIP, ERR_LDS, ERR_NODEVICE = 0, -1, -2, -3, -4, -5, -6, -7
@@ -29,6 +30,7 @@ SYMBOLS = (
     "subgacc_ppr_slab_bytes", "subgacc_ppr_slab_reset", "subgacc_ppr_topk", "subgacc_ppr_normalize", "subgacc_ppr_encode",
     "subgacc_walk_join", "subgacc_sjoin_sizes_rows", "subgacc_sjoin_fill_rows",
     "subgacc_encode_sizes", "subgacc_encode_fill",
+    "subgacc_hop_records_layout", "subgacc_hop_records_build",
 )
 
 
@@ -36,7 +38,8 @@ class WalkCfg(C.Structure):
     """struct subgacc_walk_cfg"""
     _fields_ = [("num_walks", C.c_int32), ("num_steps", C.c_int32), ("bucket", C.c_int32), ("rng_mode", C.c_int32),
                 ("seed", C.c_uint32), ("first_hop_wo", C.c_int32), ("order", C.c_int32),
-                ("cap_root_degree", C.c_int32), ("indptr64", C.c_int32), ("emit_walks", C.c_int32)]
+                ("cap_root_degree", C.c_int32), ("indptr64", C.c_int32), ("emit_walks", C.c_int32),
+                ("hop_records", C.c_void_p), ("rec_id_bits", C.c_int32), ("rec_beg_bits", C.c_int32)]
 
 
 class SubgAccError(RuntimeError):
@@ -76,7 +79,7 @@ def lib():
         "subgacc_device_count": (C.c_int, []),
         "subgacc_key_shift": (C.c_int, [i32, i32]),
         "subgacc_rng_positions_workspace_bytes": (sz, [i64]),
-        "subgacc_rng_positions": (C.c_int, [cfgp, vp, vp, i64, i32, u64, vp, vp, vp, sz, vp]),
+        "subgacc_rng_positions": (C.c_int, [cfgp, vp, i64, vp, i64, i32, u64, vp, vp, vp, sz, vp]),
         "subgacc_walk_sets": (C.c_int, [cfgp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
         "subgacc_walk_spg": (C.c_int, [cfgp, vp, vp, i64, vp, i64, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp]),
         "subgacc_compact_rows": (C.c_int, [vp, vp, vp, vp, i64, i32, vp, vp, vp, i64, vp]),
@@ -92,10 +95,10 @@ def lib():
         "subgacc_unpack_lp": (C.c_int, [vp, i64, vp, i32, i32, vp, vp, vp, i32, vp]),
         "subgacc_spg_build": (C.c_int, [vp, i64, vp, vp, vp, i64, i32, vp, vp, vp, vp]),
         "subgacc_sjoin_workspace_bytes": (sz, [i64]),
-        "subgacc_sjoin_sizes": (C.c_int, [vp, vp, i64, vp, vp, sz, vp]),
-        "subgacc_sjoin_fill": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, i32, i64, vp, vp]),
+        "subgacc_sjoin_sizes": (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, sz, vp]),
+        "subgacc_sjoin_fill": (C.c_int, [vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, i32, i64, vp, vp]),
     }
-    sig["subgacc_sjoin_counts"] = (C.c_int, [vp, vp, vp, vp, vp, i64, i64, vp, i32, i64, vp, vp])
+    sig["subgacc_sjoin_counts"] = (C.c_int, [vp, i64, vp, vp, vp, vp, i64, i64, vp, i32, i64, vp, vp])
     f32 = C.c_float
     sig["subgacc_ppr_slab_bytes"] = (sz, [i32, i32])
     sig["subgacc_ppr_slab_reset"] = (C.c_int, [vp, i32, i32, vp])
@@ -103,16 +106,18 @@ def lib():
     sig["subgacc_ppr_normalize"] = (C.c_int, [vp, i32, vp, i64, vp, i64, vp, vp, i32, vp, vp, vp])
     sig["subgacc_ppr_encode"] = (C.c_int, [vp, i64, vp, vp, vp])
     sig["subgacc_walk_join"] = (C.c_int, [vp, i64, i32, vp, vp, vp, i32, vp, i64, vp, vp])
-    sig["subgacc_sjoin_sizes_rows"] = (C.c_int, [vp, vp, i64, vp, vp, sz, vp])
-    sig["subgacc_sjoin_fill_rows"] = (C.c_int, [vp, i64, vp, vp, vp, i64, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, i64, vp, vp])
+    sig["subgacc_sjoin_sizes_rows"] = (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, sz, vp])
+    sig["subgacc_sjoin_fill_rows"] = (C.c_int, [vp, i64, i64, vp, vp, vp, i64, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, i64, vp, vp])
     sig["subgacc_encode_sizes"] = (C.c_int, [vp, vp, i64, vp, i32, vp, i32, vp, vp, vp])
     sig["subgacc_encode_fill"] = (C.c_int, [vp, vp, vp, i64, i32, vp, i32, vp, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp])
+    sig["subgacc_hop_records_layout"] = (C.c_int, [i64, i64, C.POINTER(i32), C.POINTER(i32)])
+    sig["subgacc_hop_records_build"] = (C.c_int, [vp, i32, vp, i64, i64, i32, i32, vp, vp])
     assert set(sig) == set(SYMBOLS)
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    if L.subgacc_abi_version() != 1:
+    if L.subgacc_abi_version() != 2:
         raise SubgAccError("libsubgacc_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -17,12 +17,17 @@ namespace subgacc {
 
 constexpr int kJoinThreads = 64;
 
-__global__ void sjoin_len_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ row_len,
-                                 const int64_t *__restrict__ own, int64_t S, int64_t *__restrict__ len) {
+// A row number outside [0, n_rows) -- the reference's `x[edge[0]]` raises IndexError for it (train.py:15) -- is never
+// dereferenced: the row counts as empty and flags[3] |= 16 tells the host (which raises).
+__global__ void sjoin_len_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ row_len, int64_t n_rows,
+                                 const int64_t *__restrict__ own, const int64_t *__restrict__ partner, int64_t S,
+                                 int64_t *__restrict__ len, int32_t *__restrict__ flags) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j < S) {
         const int64_t a = own[j];
-        len[j] = row_len ? (int64_t)row_len[a] : indptr[a + 1] - indptr[a];
+        const bool bad = (uint64_t)a >= (uint64_t)n_rows;
+        if ((bad || (partner && (uint64_t)partner[j] >= (uint64_t)n_rows)) && flags) atomicOr(&flags[3], 16);
+        len[j] = bad ? 0 : (row_len ? (int64_t)row_len[a] : indptr[a + 1] - indptr[a]);
     }
 }
 
@@ -32,6 +37,7 @@ struct JoinArgs {
     const void *data;  // int32 (SFptr+1) or double (PPR score)
     const int64_t *own, *partner, *seg;
     int64_t S;
+    int64_t n_rows;   // rows of the store: own / partner values outside [0, n_rows) read as empty rows, flags[3] |= 16
     const float *table;
     int64_t table_rows;
     int32_t k;
@@ -71,6 +77,10 @@ template <typename T>
 __device__ __forceinline__ T stream_load(const T *p) { return __builtin_nontemporal_load(p); }
 
 __device__ __forceinline__ void join_row(const JoinArgs &a, int64_t r, int64_t &beg, int64_t &len) {
+    if ((uint64_t)r >= (uint64_t)a.n_rows) {   // never dereferenced (sjoin_len_kernel gave it length 0 and raised the flag)
+        beg = 0, len = 0;
+        return;
+    }
     if (a.row_len) {
         beg = r * a.row_stride;
         len = a.row_len[r];
@@ -178,8 +188,9 @@ __global__ __launch_bounds__(kJoinThreads) void sjoin_fill_kernel(const JoinArgs
     if (j >= a.S) return;
     const int lane = threadIdx.x;
     const int64_t ra = a.own[j], rb = a.partner[j];
-    const int64_t ab = a.indptr[ra], na = a.indptr[ra + 1] - ab;
-    const int64_t bb = a.indptr[rb], nb64 = a.indptr[rb + 1] - bb;
+    int64_t ab, na, bb, nb64;
+    join_row(a, ra, ab, na);
+    join_row(a, rb, bb, nb64);
     if (nb64 > (STAGE ? (int64_t)a.max_len : (int64_t)0x7FFFFFFF)) {
         if (lane == 0) atomicOr(&a.flags[3], 1);
         return;
@@ -305,8 +316,9 @@ __global__ __launch_bounds__(kPairThreads) void sjoin_counts_kernel(const JoinAr
         if (tid == 0) atomicOr(&a.flags[3], 4);
         return;
     }
-    const int64_t ab = a.indptr[ra], na64 = a.indptr[ra + 1] - ab;
-    const int64_t bb = a.indptr[rb], nb64 = a.indptr[rb + 1] - bb;
+    int64_t ab, na64, bb, nb64;
+    join_row(a, ra, ab, na64);
+    join_row(a, rb, bb, nb64);
     if (na64 > a.max_len || nb64 > a.max_len) {
         if (tid == 0) atomicOr(&a.flags[3], 1);
         return;
@@ -363,9 +375,10 @@ extern "C" size_t subgacc_sjoin_workspace_bytes(int64_t S) {
     return align_up((size_t)S * 8, 256) + scan_workspace_bytes(S);
 }
 
-static int join_sizes(const int64_t *spg_indptr, const int32_t *row_len, const int64_t *own, int64_t S, int64_t *out_seg,
-                      void *workspace, size_t workspace_bytes, void *stream) {
-    SG_REQUIRE(S >= 0 && out_seg, SUBGACC_ERR_BADARG, "sjoin_sizes: bad arguments");
+static int join_sizes(const int64_t *spg_indptr, const int32_t *row_len, int64_t n_rows, const int64_t *own,
+                      const int64_t *partner, int64_t S, int64_t *out_seg, int32_t *flags, void *workspace,
+                      size_t workspace_bytes, void *stream) {
+    SG_REQUIRE(S >= 0 && out_seg && n_rows >= 0, SUBGACC_ERR_BADARG, "sjoin_sizes: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     if (S == 0) return exclusive_scan_i64(nullptr, 0, out_seg, nullptr, 0, s);
     SG_REQUIRE((spg_indptr || row_len) && own, SUBGACC_ERR_BADARG, "sjoin_sizes: null argument");
@@ -373,29 +386,32 @@ static int join_sizes(const int64_t *spg_indptr, const int32_t *row_len, const i
                "sjoin_sizes: workspace too small");
     int64_t *len = (int64_t *)workspace;
     char *ws = (char *)workspace + align_up((size_t)S * 8, 256);
-    hipLaunchKernelGGL(sjoin_len_kernel, dim3((unsigned)ceil_div(S, 256)), dim3(256), 0, s, spg_indptr, row_len, own, S, len);
+    hipLaunchKernelGGL(sjoin_len_kernel, dim3((unsigned)ceil_div(S, 256)), dim3(256), 0, s, spg_indptr, row_len, n_rows, own,
+                       partner, S, len, flags);
     SG_LAUNCH_CHECK();
     return exclusive_scan_i64(len, S, out_seg, ws, workspace_bytes - align_up((size_t)S * 8, 256), s);
 }
 
-extern "C" int subgacc_sjoin_sizes(const int64_t *spg_indptr, const int64_t *own, int64_t S, int64_t *out_seg,
-                                   void *workspace, size_t workspace_bytes, void *stream) {
+extern "C" int subgacc_sjoin_sizes(const int64_t *spg_indptr, int64_t n_rows, const int64_t *own, const int64_t *partner,
+                                   int64_t S, int64_t *out_seg, int32_t *flags, void *workspace, size_t workspace_bytes,
+                                   void *stream) {
     SG_REQUIRE(spg_indptr || S == 0, SUBGACC_ERR_BADARG, "sjoin_sizes: null argument");
-    return join_sizes(spg_indptr, nullptr, own, S, out_seg, workspace, workspace_bytes, stream);
+    return join_sizes(spg_indptr, nullptr, n_rows, own, partner, S, out_seg, flags, workspace, workspace_bytes, stream);
 }
 
-extern "C" int subgacc_sjoin_sizes_rows(const int32_t *row_len, const int64_t *own, int64_t S, int64_t *out_seg,
-                                        void *workspace, size_t workspace_bytes, void *stream) {
+extern "C" int subgacc_sjoin_sizes_rows(const int32_t *row_len, int64_t n_rows, const int64_t *own, const int64_t *partner,
+                                        int64_t S, int64_t *out_seg, int32_t *flags, void *workspace,
+                                        size_t workspace_bytes, void *stream) {
     SG_REQUIRE(row_len || S == 0, SUBGACC_ERR_BADARG, "sjoin_sizes_rows: null argument");
-    return join_sizes(nullptr, row_len, own, S, out_seg, workspace, workspace_bytes, stream);
+    return join_sizes(nullptr, row_len, n_rows, own, partner, S, out_seg, flags, workspace, workspace_bytes, stream);
 }
 
-extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, const int32_t *spg_indices, const int32_t *spg_data_i32,
-                                  const double *spg_data_f64, const int64_t *own, const int64_t *partner, int64_t S,
+extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,
+                                  const int32_t *spg_data_i32, const double *spg_data_f64, const int64_t *own, const int64_t *partner, int64_t S,
                                   const int64_t *seg, const float *table, int64_t table_rows, int32_t k,
                                   float *out_xz, int32_t *out_idx, int64_t *out_segid, int32_t max_len,
                                   int64_t pair_block, int32_t *flags, void *stream) {
-    SG_REQUIRE(S >= 0 && max_len >= 0 && flags, SUBGACC_ERR_BADARG, "sjoin_fill: bad arguments");
+    SG_REQUIRE(S >= 0 && max_len >= 0 && flags && n_rows >= 0, SUBGACC_ERR_BADARG, "sjoin_fill: bad arguments");
     if (S == 0) return SUBGACC_OK;
     SG_REQUIRE(spg_indptr && spg_indices && own && partner && seg, SUBGACC_ERR_BADARG, "sjoin_fill: null argument");
     SG_REQUIRE((spg_data_i32 != nullptr) != (spg_data_f64 != nullptr), SUBGACC_ERR_BADARG,
@@ -412,7 +428,7 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, const int32_t *spg_
     JoinArgs a;
     a.indptr = spg_indptr, a.indices = spg_indices;
     a.data = f64 ? (const void *)spg_data_f64 : (const void *)spg_data_i32;
-    a.own = own, a.partner = partner, a.seg = seg, a.S = S;
+    a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
     a.table = table, a.table_rows = table_rows, a.k = k;
     a.out_xz = out_xz, a.out_idx = out_idx, a.out_segid = out_segid;
     a.max_len = max_len > 0 ? max_len : 1;
@@ -468,13 +484,14 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, const int32_t *spg_
     return SUBGACC_OK;
 }
 
-extern "C" int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t row_stride, const int32_t *row_ids,
+extern "C" int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
                                        const int32_t *row_slot, const void *uniq_table, int64_t uniq_capacity,
                                        const int64_t *own, const int64_t *partner, int64_t S, const int64_t *seg,
                                        const float *table, int64_t table_rows, int32_t k, float *out_xz,
                                        int32_t *out_idx, int64_t *out_segid, int64_t pair_block, int32_t *flags,
                                        void *stream) {
-    SG_REQUIRE(S >= 0 && flags && row_stride > 0 && row_stride < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_fill_rows: bad arguments");
+    SG_REQUIRE(S >= 0 && flags && n_rows >= 0 && row_stride > 0 && row_stride < (1ll << 31), SUBGACC_ERR_BADARG,
+               "sjoin_fill_rows: bad arguments");
     if (S == 0) return SUBGACC_OK;
     SG_REQUIRE(row_len && row_ids && row_slot && (!uniq_table || uniq_capacity > 0) && own && partner && seg,
                SUBGACC_ERR_BADARG, "sjoin_fill_rows: null argument");
@@ -485,7 +502,7 @@ extern "C" int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t row_strid
                "sjoin_fill_rows: the segment list must be mirrored blocks (pair_block > 0, S a multiple of 2*pair_block)");
     JoinArgs a;
     a.indptr = nullptr, a.indices = row_ids, a.data = row_slot;
-    a.own = own, a.partner = partner, a.seg = seg, a.S = S;
+    a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
     a.table = table, a.table_rows = table_rows, a.k = k;
     a.out_xz = out_xz, a.out_idx = out_idx, a.out_segid = out_segid;
     a.max_len = (int32_t)row_stride;
@@ -514,11 +531,12 @@ extern "C" int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t row_strid
     return SUBGACC_OK;
 }
 
-extern "C" int subgacc_sjoin_counts(const int64_t *spg_indptr, const int32_t *spg_indices, const int32_t *spg_data_i32,
-                                    const int64_t *own, const int64_t *partner, int64_t S, int64_t table_rows,
+extern "C" int subgacc_sjoin_counts(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,
+                                    const int32_t *spg_data_i32, const int64_t *own, const int64_t *partner, int64_t S, int64_t table_rows,
                                     float *out_counts, int32_t max_len, int64_t pair_block, int32_t *flags,
                                     void *stream) {
-    SG_REQUIRE(S >= 0 && max_len >= 0 && flags && table_rows > 0, SUBGACC_ERR_BADARG, "sjoin_counts: bad arguments");
+    SG_REQUIRE(S >= 0 && max_len >= 0 && flags && table_rows > 0 && n_rows >= 0, SUBGACC_ERR_BADARG,
+               "sjoin_counts: bad arguments");
     if (S == 0) return SUBGACC_OK;
     SG_REQUIRE(spg_indptr && spg_indices && spg_data_i32 && own && partner && out_counts, SUBGACC_ERR_BADARG,
                "sjoin_counts: null argument");
@@ -526,7 +544,7 @@ extern "C" int subgacc_sjoin_counts(const int64_t *spg_indptr, const int32_t *sp
                "sjoin_counts: the segment list must be mirrored blocks (pair_block > 0, S a multiple of 2*pair_block)");
     JoinArgs a;
     a.indptr = spg_indptr, a.indices = spg_indices, a.data = spg_data_i32;
-    a.own = own, a.partner = partner, a.seg = nullptr, a.S = S;
+    a.own = own, a.partner = partner, a.seg = nullptr, a.S = S, a.n_rows = n_rows;
     a.table = nullptr, a.table_rows = table_rows, a.k = 0;
     a.out_xz = nullptr, a.out_idx = nullptr, a.out_segid = nullptr;
     a.max_len = max_len > 0 ? max_len : 1;

@@ -33,11 +33,11 @@ namespace subgacc {
 
 template <bool IDX64>
 __global__ void rng_calls_kernel(const void *__restrict__ indptr, const int32_t *__restrict__ query, int64_t n,
-                                 int M, int m, int wo, int cap, int32_t *__restrict__ calls) {
+                                 int64_t num_nodes, int M, int m, int wo, int cap, int32_t *__restrict__ calls) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int64_t beg, deg;
-    load_row<IDX64>(indptr, query[i], beg, deg);
+    int64_t beg, deg = 0;
+    if ((uint64_t)(int64_t)query[i] < (uint64_t)num_nodes) load_row<IDX64>(indptr, query[i], beg, deg);   // else: the walk kernel flags it
     if (cap && deg > kNeighCap) deg = kNeighCap;
     int32_t c = 0;
     if (deg > 0) c = wo ? ((deg > M ? M : 0) + M * (m - 1)) : M * m;
@@ -71,7 +71,7 @@ __global__ void rng_positions_kernel(const int64_t *__restrict__ calls_excl, int
 #if SG_EXPERIMENT == 7   // per-phase cycle shares (tools/walk_phases.py): lane 0 adds the cycles since the last stamp to flags[8 + 2k]
 #define SG_STAMP(k)                                                                             \
     do {                                                                                        \
-        if (threadIdx.x == 0) {                                                                 \
+        if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) {   /* 1 workgroup in 64: the atomics stay uncontended */ \
             const unsigned long long now__ = __builtin_readcyclecounter();                      \
             atomicAdd((unsigned long long *)(a.flags + 8) + (k), now__ - t_prev__);             \
             t_prev__ = now__;                                                                   \
@@ -80,7 +80,9 @@ __global__ void rng_positions_kernel(const int64_t *__restrict__ calls_excl, int
 #else
 #define SG_STAMP(k)
 #endif
-template <bool IDX64, int RNG, bool SPG>
+// REC: the graph is walked through its packed hop records (one dependent read per hop: the neighbour arrives with its
+// row begin and degree) instead of indices[] + indptr[] (two); same picks, same sets.
+template <bool IDX64, int RNG, bool SPG, bool REC>
 __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) void walk_sets_kernel(const WalkArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
 #if SG_EXPERIMENT == 7
@@ -108,8 +110,16 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
     const int tid = threadIdx.x;
     const int M = a.M, m = a.m, T = a.T;
     const int32_t root = a.query[i];
+    if ((uint64_t)(int64_t)root >= (uint64_t)a.num_nodes) {   // the reference would read out of bounds here (no checks)
+        if (tid == 0) {
+            atomicOr(&a.flags[3], 16);
+            a.nsize[i] = 0;
+        }
+        return;
+    }
     int64_t rbeg, rdeg64;
     load_row<IDX64>(a.indptr, root, rbeg, rdeg64);
+    const int64_t rdeg_full = rdeg64;   // NEBMAX caps the root's first hop only (subg_acc.c:750)
     if (a.cap_root && rdeg64 > kNeighCap) rdeg64 = kNeighCap;
     const int64_t obase = i * (int64_t)a.stride;
     const unsigned long long lead = 1ull << (m * a.shift);
@@ -187,6 +197,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
         }
         int32_t *wrow = a.walks ? a.walks + (i * (int64_t)M + w) * (m + 1) : nullptr;
         if (wrow) wrow[0] = root;
+        int64_t cb = rbeg, cd = rdeg_full;   // REC: row (begin, degree) of the node the walk stands on
         for (int s = 0; s < m; ++s) {
             if (s == 0 && a.wo) {
                 uint32_t pick;
@@ -200,7 +211,13 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
                 } else {
                     pick = (uint32_t)w % rdeg;
                 }
-                cur = SG_NEIGH_LOAD(&a.indices[rbeg + pick]);
+                if (REC) {
+                    bool esc;
+                    rec_unpack(a.recs[rbeg + pick], a.rec, cur, cb, cd, esc);
+                    if (esc && m > 1) load_row<IDX64>(a.indptr, cur, cb, cd);
+                } else {
+                    cur = SG_NEIGH_LOAD(&a.indices[rbeg + pick]);
+                }
             } else {
 #if SG_EXPERIMENT == 2   // dedup only: no graph reads after the first hop (timing experiment, results are wrong)
                 cur = (int32_t)(((uint32_t)cur * 2654435761u + (uint32_t)w * 40503u + (uint32_t)s) % 2900000u);
@@ -211,7 +228,8 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
                 b = ((int64_t)(uint32_t)cur * 21) % 62000000;
                 d = 20;
 #else
-                load_row<IDX64>(a.indptr, cur, b, d);
+                if (REC) b = cb, d = cd;
+                else load_row<IDX64>(a.indptr, cur, b, d);
 #endif
                 if (d > 0) {
                     uint32_t r;
@@ -226,7 +244,13 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
                         }
                         r = ph[idx & 3];
                     }
-                    cur = SG_NEIGH_LOAD(&a.indices[b + (int64_t)(r % (uint32_t)d)]);
+                    if (REC) {
+                        bool esc;
+                        rec_unpack(a.recs[b + (int64_t)(r % (uint32_t)d)], a.rec, cur, cb, cd, esc);
+                        if (esc && s + 1 < m) load_row<IDX64>(a.indptr, cur, cb, cd);
+                    } else {
+                        cur = SG_NEIGH_LOAD(&a.indices[b + (int64_t)(r % (uint32_t)d)]);
+                    }
                 } else if (RNG == SUBGACC_RNG_RAND_R) {
                     atomicOr(&a.flags[0], 1);  // dead end: the sequential stream is no longer reproducible
                 }
@@ -554,10 +578,11 @@ extern "C" size_t subgacc_rng_positions_workspace_bytes(int64_t n) {
     return align_up((size_t)n * 4, 256) + align_up((size_t)(n + 1) * 8, 256) + scan_workspace_bytes(n);
 }
 
-extern "C" int subgacc_rng_positions(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *query,
-                                     int64_t n, int32_t rng_streams, uint64_t calls_before, uint32_t *rng_pos,
+extern "C" int subgacc_rng_positions(const subgacc_walk_cfg *cfg, const void *indptr, int64_t num_nodes,
+                                     const int32_t *query, int64_t n, int32_t rng_streams, uint64_t calls_before, uint32_t *rng_pos,
                                      uint32_t *rng_seed, void *workspace, size_t workspace_bytes, void *stream) {
-    SG_REQUIRE(cfg && indptr && rng_pos && rng_seed && n >= 0, SUBGACC_ERR_BADARG, "rng_positions: null argument");
+    SG_REQUIRE(cfg && indptr && rng_pos && rng_seed && n >= 0 && num_nodes >= 0, SUBGACC_ERR_BADARG,
+               "rng_positions: null argument");
     SG_REQUIRE(rng_streams >= 1, SUBGACC_ERR_BADARG, "rng_positions: rng_streams must be >= 1");
     SG_REQUIRE(rng_streams == 1 || calls_before == 0, SUBGACC_ERR_BADARG,
                "rng_positions: calls_before only makes sense for a single stream");
@@ -573,10 +598,10 @@ extern "C" int subgacc_rng_positions(const subgacc_walk_cfg *cfg, const void *in
     ws += align_up((size_t)(n + 1) * 8, 256);
     const unsigned grid = (unsigned)ceil_div(n, 256);
     if (cfg->indptr64)
-        hipLaunchKernelGGL(rng_calls_kernel<true>, dim3(grid), dim3(256), 0, s, indptr, query, n, cfg->num_walks,
+        hipLaunchKernelGGL(rng_calls_kernel<true>, dim3(grid), dim3(256), 0, s, indptr, query, n, num_nodes, cfg->num_walks,
                            cfg->num_steps, cfg->first_hop_wo, cfg->cap_root_degree, calls);
     else
-        hipLaunchKernelGGL(rng_calls_kernel<false>, dim3(grid), dim3(256), 0, s, indptr, query, n, cfg->num_walks,
+        hipLaunchKernelGGL(rng_calls_kernel<false>, dim3(grid), dim3(256), 0, s, indptr, query, n, num_nodes, cfg->num_walks,
                            cfg->num_steps, cfg->first_hop_wo, cfg->cap_root_degree, calls);
     SG_LAUNCH_CHECK();
     int rc = exclusive_scan_i32(calls, n, excl, ws, workspace_bytes - (size_t)(ws - (char *)workspace), s);
@@ -618,7 +643,7 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
     SG_REQUIRE(query, SUBGACC_ERR_BADARG, "walk: null query");   // `indices` may be NULL for an edgeless graph
 
     WalkArgs a;
-    a.indptr = indptr, a.indices = indices, a.query = query, a.n = n;
+    a.indptr = indptr, a.indices = indices, a.query = query, a.n = n, a.num_nodes = num_nodes;
     a.rng_pos = rng_pos, a.rng_seed = rng_seed;
     a.set_ids = set_ids, a.set_keys = set_keys, a.nsize = nsize;
     a.walks = cfg->emit_walks ? walks : nullptr;
@@ -634,6 +659,15 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
     a.set_slot = set_slot;
     a.table = spg ? uniq_view(uniq_table, uniq_capacity) : UniqTable{nullptr, nullptr, nullptr, 0};
     a.root_base = root_base;
+    a.recs = nullptr, a.rec = RecFmt{0, 0};
+    if (cfg->hop_records && !cfg->indptr64) {
+        SG_REQUIRE(cfg->rec_id_bits > 0 && cfg->rec_beg_bits > 0 && cfg->rec_id_bits <= 32 &&
+                       cfg->rec_id_bits + cfg->rec_beg_bits <= 60,
+                   SUBGACC_ERR_BADARG, "walk: hop_records given with field widths %d / %d (subgacc_hop_records_layout)",
+                   cfg->rec_id_bits, cfg->rec_beg_bits);
+        a.recs = (const unsigned long long *)cfg->hop_records;
+        a.rec = RecFmt{cfg->rec_id_bits, cfg->rec_beg_bits};
+    }
     SG_REQUIRE(a.T <= 65536, SUBGACC_ERR_LDS, "walk: M*m+1 = %d is too large for the per-root LDS tables", Q);
     // SUBGACC_LDS_PAD (dev-only): extra dynamic LDS per workgroup, i.e. fewer resident workgroups per CU -- the
     // occupancy response of the kernel (tools/README.md)
@@ -651,28 +685,82 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
     }
     const int64_t grid = xcd_grid(n);
     SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "walk: chunk of %lld roots too large, split it", (long long)n);
-#define SG_WALK_LAUNCH(I64, RNGM, SPGM)                                                                           \
+#define SG_WALK_LAUNCH(I64, RNGM, SPGM, RECM)                                                                     \
     do {                                                                                                          \
         if (lds > 64 * 1024)                                                                                      \
-            SG_CHECK_HIP(hipFuncSetAttribute((const void *)walk_sets_kernel<I64, RNGM, SPGM>,                     \
+            SG_CHECK_HIP(hipFuncSetAttribute((const void *)walk_sets_kernel<I64, RNGM, SPGM, RECM>,               \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
-        hipLaunchKernelGGL((walk_sets_kernel<I64, RNGM, SPGM>), dim3((unsigned)grid), dim3(kWalkThreads), lds, s, \
-                           a);                                                                                    \
+        hipLaunchKernelGGL((walk_sets_kernel<I64, RNGM, SPGM, RECM>), dim3((unsigned)grid), dim3(kWalkThreads),   \
+                           lds, s, a);                                                                            \
     } while (0)
-#define SG_WALK_RNG(I64, SPGM)                                                                                    \
+#define SG_WALK_RNG(I64, SPGM, RECM)                                                                              \
     do {                                                                                                          \
-        if (cfg->rng_mode == SUBGACC_RNG_RAND_R) SG_WALK_LAUNCH(I64, SUBGACC_RNG_RAND_R, SPGM);                   \
-        else SG_WALK_LAUNCH(I64, SUBGACC_RNG_PHILOX, SPGM);                                                       \
+        if (cfg->rng_mode == SUBGACC_RNG_RAND_R) SG_WALK_LAUNCH(I64, SUBGACC_RNG_RAND_R, SPGM, RECM);             \
+        else SG_WALK_LAUNCH(I64, SUBGACC_RNG_PHILOX, SPGM, RECM);                                                 \
     } while (0)
-    if (cfg->indptr64) {
-        if (spg) SG_WALK_RNG(true, true);
-        else SG_WALK_RNG(true, false);
+    if (cfg->indptr64) {          // graphs with 64-bit row offsets are not packed (subgacc_hop_records_layout)
+        if (spg) SG_WALK_RNG(true, true, false);
+        else SG_WALK_RNG(true, false, false);
+    } else if (a.recs) {
+        if (spg) SG_WALK_RNG(false, true, true);
+        else SG_WALK_RNG(false, false, true);
     } else {
-        if (spg) SG_WALK_RNG(false, true);
-        else SG_WALK_RNG(false, false);
+        if (spg) SG_WALK_RNG(false, true, false);
+        else SG_WALK_RNG(false, false, false);
     }
 #undef SG_WALK_RNG
 #undef SG_WALK_LAUNCH
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}
+
+// ------------------------------------------------------------------------------ packed hop records
+namespace subgacc {
+template <bool IDX64>
+__global__ void hop_records_kernel(const void *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t nnz,
+                                   int64_t num_nodes, RecFmt f, unsigned long long *__restrict__ out) {
+    const int deg_bits = 64 - f.id_bits - f.beg_bits;
+    const unsigned long long dmask = (1ull << deg_bits) - 1ull;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t v = indices[e];
+        int64_t beg = 0, deg = 0;
+        if ((uint64_t)(int64_t)v < (uint64_t)num_nodes) load_row<IDX64>(indptr, v, beg, deg);
+        const unsigned long long d = (unsigned long long)deg >= dmask ? dmask : (unsigned long long)deg;
+        out[e] = ((unsigned long long)(uint32_t)v << (64 - f.id_bits)) | ((unsigned long long)beg << deg_bits) | d;
+    }
+}
+}  // namespace subgacc
+
+extern "C" int subgacc_hop_records_layout(int64_t num_nodes, int64_t nnz, int32_t *id_bits, int32_t *beg_bits) {
+    SG_REQUIRE(num_nodes >= 0 && nnz >= 0 && id_bits && beg_bits, SUBGACC_ERR_BADARG, "hop_records_layout: bad arguments");
+    int ib = 1, bb = 1;
+    while (ib < 32 && (1ll << ib) < num_nodes) ++ib;
+    while (bb < 62 && (1ll << bb) <= nnz) ++bb;
+    *id_bits = ib, *beg_bits = bb;
+    const int db = 64 - ib - bb;
+    return db >= 12 ? db : 0;
+}
+
+extern "C" int subgacc_hop_records_build(const void *indptr, int32_t indptr64, const int32_t *indices, int64_t num_nodes,
+                                         int64_t nnz, int32_t id_bits, int32_t beg_bits, uint64_t *out_records,
+                                         void *stream) {
+    SG_REQUIRE(num_nodes >= 0 && nnz >= 0, SUBGACC_ERR_BADARG, "hop_records_build: negative size");
+    int32_t ib, bb;
+    subgacc_hop_records_layout(num_nodes, nnz, &ib, &bb);
+    // wider id / offset fields than the minimal layout are fine (a narrower degree field only means more look-ups)
+    SG_REQUIRE(id_bits >= ib && id_bits <= 32 && beg_bits >= bb && id_bits + beg_bits <= 60, SUBGACC_ERR_BADARG,
+               "hop_records_build: widths %d / %d cannot hold this graph (needs >= %d / %d, at least 4 bits left)", id_bits,
+               beg_bits, ib, bb);
+    if (nnz == 0) return SUBGACC_OK;
+    SG_REQUIRE(indptr && indices && out_records, SUBGACC_ERR_BADARG, "hop_records_build: null argument");
+    const RecFmt f{id_bits, beg_bits};
+    const unsigned grid = (unsigned)(ceil_div(nnz, 256) < 65536 ? ceil_div(nnz, 256) : 65536);
+    if (indptr64)
+        hipLaunchKernelGGL(hop_records_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, indptr, indices, nnz,
+                           num_nodes, f, (unsigned long long *)out_records);
+    else
+        hipLaunchKernelGGL(hop_records_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, indptr, indices, nnz,
+                           num_nodes, f, (unsigned long long *)out_records);
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }

@@ -80,11 +80,12 @@ def preset_graph(name, device="cuda", scale=1.0):
     return powerlaw_graph(max(int(p["N"] * scale), 16), p["avg_deg"], seed=p["seed"], device=device)
 
 
-def query_pairs(csr, B, seed=7, device="cuda"):
-    """B query pairs: half 'positive-like' (drawn from the edges), half uniform random (the 1:k mix of
-    main.py:212-214) -> int64 [2, B]."""
+def query_pairs(csr, B, seed=7, device="cuda", pos_frac=0.5):
+    """B query pairs -> int64 [2, B]: a fraction `pos_frac` 'positive-like' (drawn from the edges), the rest uniform
+    random pairs -- the training mix of main.py:212-214 / dataloader.py:77-79 (positives + k uniform negatives per
+    positive, shuffled into batches): pos_frac = 1/(k+1), e.g. 1/21 for ogbl-ppa's --k 20; SURVEY 8(d) uses 1/2."""
     gen = torch.Generator(device=device).manual_seed(int(seed))
-    half = B // 2
+    half = int(round(B * pos_frac))
     e = torch.randint(0, csr.nnz, (half,), device=device, generator=gen)
     src = torch.searchsorted(csr.indptr.long(), e, right=True) - 1
     dst = csr.indices[e].long()

@@ -43,7 +43,11 @@ def _timed(name):
 class DeviceCSR:
     """Graph CSR resident in HBM: int32 node ids, int32 or int64 row offsets (`indptr64`)."""
 
-    def __init__(self, indptr, indices, device=None):
+    def __init__(self, indptr, indices, device=None, validate=True):
+        """validate=True checks the CSR once, on the device, after the upload (row offsets monotone within
+        [0, len(indices)], neighbour ids within [0, N)): the reference reads whatever the arrays say (a bad graph is a
+        segfault there); on a GPU a stray address can take the device down, so nothing reaches a kernel unchecked.
+        A few reductions over arrays that are resident anyway (3 ms for the 12 GB twitter-like graph)."""
         device = device or _lib.require_device()
         ip = indptr if torch.is_tensor(indptr) else torch.from_numpy(np.ascontiguousarray(indptr))
         ix = indices if torch.is_tensor(indices) else torch.from_numpy(np.ascontiguousarray(indices))
@@ -57,10 +61,46 @@ class DeviceCSR:
         self.indptr64 = self.indptr.dtype == torch.int64
         self.num_nodes = self.indptr.numel() - 1
         self.device = self.indptr.device
+        self._recs = False           # hop records: not built yet
+        if self.indptr.dim() != 1 or self.indices.dim() != 1 or self.num_nodes < 0:
+            raise TypeError("Input parsing error. (indptr / indices must be 1-D, indptr non-empty)")
+        if validate:
+            self._validate()
+
+    def _validate(self):
+        ip, ix, N = self.indptr, self.indices, self.num_nodes
+        z = torch.zeros((), dtype=torch.bool, device=self.device)
+        bad = torch.stack([ip[0] != 0, ip[-1] > ix.numel(), (ip[1:] < ip[:-1]).any() if N else z,
+                           (ix.min() < 0) if ix.numel() else z, (ix.max() >= N) if ix.numel() else z]).tolist()
+        if bad[0] or bad[1] or bad[2]:
+            raise IndexError("CSR row offsets are not monotone within [0, len(indices)]")
+        if bad[3] or bad[4]:
+            raise IndexError("CSR neighbour ids outside [0, num_nodes)")
 
     @property
     def nnz(self):
         return self.indices.numel()
+
+    def hop_records(self):
+        """Packed hop records of this graph (include/subgacc.h: subgacc_hop_records_build), built on first use and kept
+        with the graph: 8 B per adjacency entry, (neighbour, its row begin, its degree) in one word, so that a walk
+        step is ONE dependent read.  Returns (int64 tensor [nnz], id_bits, beg_bits) or None when the graph does not
+        pack (64-bit row offsets / fewer than 12 bits left for the degree) or SUBGACC_HOP_RECORDS=0."""
+        if self._recs is False:
+            import ctypes as C
+            import os
+            self._recs = None
+            ib, bb = C.c_int32(0), C.c_int32(0)
+            if os.environ.get("SUBGACC_HOP_RECORDS", "1") != "0" and not self.indptr64 and self.nnz > 0 and self.indices.is_cuda \
+                    and lib().subgacc_hop_records_layout(self.num_nodes, self.nnz, C.byref(ib), C.byref(bb)) > 0:
+                forced = int(os.environ.get("SUBGACC_REC_DEG_BITS", "0"))     # tests: a narrow degree field (escapes)
+                if forced:
+                    bb = C.c_int32(64 - ib.value - forced)
+                recs = torch.empty(self.nnz, dtype=torch.int64, device=self.device)
+                check(lib().subgacc_hop_records_build(ptr(self.indptr), 0, ptr(self.indices), self.num_nodes, self.nnz,
+                                                      ib.value, bb.value, ptr(recs), stream_ptr()))
+                self._recs = (recs, ib.value, bb.value)
+        return self._recs
 
 
 @dataclass
@@ -206,13 +246,15 @@ class SampledSets:
 
 
 def make_cfg(csr, num_walks, num_steps, bucket=-1, seed=111413, rng="rand_r", first_hop_wo=True,
-             order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False):
+             order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False, hop_records=True):
     rng_mode = {"rand_r": _lib.RNG_RAND_R, "philox": _lib.RNG_PHILOX}[rng]
     if num_walks <= 0 or num_steps <= 0:
         raise TypeError("Input parsing error. (num_walks and num_steps must be positive)")
+    recs = csr.hop_records() if (hop_records and csr.indices.is_cuda) else None
     return WalkCfg(int(num_walks), int(num_steps), int(bucket), rng_mode, int(seed) & 0xFFFFFFFF,
                    1 if first_hop_wo else 0, int(order), 1 if cap_root_degree else 0,
-                   1 if csr.indptr64 else 0, 1 if emit_walks else 0)
+                   1 if csr.indptr64 else 0, 1 if emit_walks else 0,
+                   recs[0].data_ptr() if recs else None, recs[1] if recs else 0, recs[2] if recs else 0)
 
 
 def _as_query(query, device):
@@ -223,6 +265,9 @@ def _as_query(query, device):
 
 
 def check_walk_flags(sets, fl):
+    if fl[3] & 16:
+        raise IndexError("query node ids outside [0, num_nodes) (such a root is never looked up on the device; the "
+                         "reference reads out of bounds for it)")
     if fl[0]:
         raise _lib.SubgAccError(
             "rng='rand_r' cannot reproduce the sequential stream on this graph: a walk reached a node without "
@@ -240,7 +285,7 @@ def _rng_positions(L, cfg, csr, q, n, rng_streams, calls_before, st):
     rng_pos = torch.empty(n, dtype=torch.int32, device=dev)
     rng_seed = torch.empty(n, dtype=torch.int32, device=dev)
     ws = torch.empty(L.subgacc_rng_positions_workspace_bytes(n), dtype=torch.uint8, device=dev)
-    check(L.subgacc_rng_positions(cfg, ptr(csr.indptr), ptr(q), n, int(rng_streams), int(calls_before), ptr(rng_pos),
+    check(L.subgacc_rng_positions(cfg, ptr(csr.indptr), csr.num_nodes, ptr(q), n, int(rng_streams), int(calls_before), ptr(rng_pos),
                                   ptr(rng_seed), ptr(ws), ws.numel(), st))
     return rng_pos, rng_seed
 
@@ -255,7 +300,7 @@ def _cat(parts, dtype, dev):
 def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, rng="rand_r", first_hop_wo=True,
                 order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False, rng_streams=1,
                 calls_before=0, dedup=True, keep_keys=None, staging_bytes=STAGING_BYTES, uniq_capacity=UNIQ_CAPACITY,
-                uniq_small_limit=0, fused_rows=False, lazy=False, strided=False):
+                uniq_small_limit=0, fused_rows=False, lazy=False, strided=False, hop_records=True):
     """Run the sampler for `query` (roots) on the GPU.  See SampledSets.
 
     dedup=True numbers the distinct LP rows (ukeys, slot / get_sf()); the packed keys are then only kept when
@@ -269,7 +314,8 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     dev = csr.device
     q = _as_query(query, dev)
     n = q.numel()
-    cfg = make_cfg(csr, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order, cap_root_degree, emit_walks)
+    cfg = make_cfg(csr, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order, cap_root_degree, emit_walks,
+                   hop_records)
     check(L.subgacc_key_shift(cfg.num_walks, cfg.num_steps))   # AssertionError like subg_acc.c:911-915
     M, m = cfg.num_walks, cfg.num_steps
     stride = bucket if bucket > 0 else M * m + 1
@@ -335,7 +381,15 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
             sets = SampledSets(nsize, None, st_ids, None, None, ukeys, M, m, stride, None)
             sets.slot, sets.table, sets.capacity, sets.strided = st_aux, table, uniq_capacity, True
             sets.status = torch.cat([flags.long(), count, nsize.sum(dtype=torch.int64).view(1)])
-            if not lazy:
+            if not lazy:      # eager: same recovery as the packed forms below
+                st_host = sets.status.tolist()
+                if st_host[2]:                    # the table of distinct LP rows overflowed: walk again with a larger one
+                    return sample_sets(csr, q, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order,
+                                       cap_root_degree, emit_walks, rng_streams, calls_before, dedup, keep_keys,
+                                       staging_bytes, uniq_capacity * 4, uniq_small_limit, fused_rows, lazy, strided,
+                                       hop_records)
+                if st_host[4] > max_unique:       # more distinct rows than the direct ranking numbers: the caller
+                    return None                   # (sample_spg) falls through to the packed forms
                 sets.resolve()
             return sets
         # packed arrays: exact size (one 8-byte host read) or, lazily, the upper bound n*stride
@@ -410,7 +464,7 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     if st_host[2]:
         return sample_sets(csr, q, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order, cap_root_degree,
                            emit_walks, rng_streams, calls_before, dedup, keep_keys, staging_bytes, uniq_capacity * 4,
-                           uniq_small_limit, fused_rows, lazy)
+                           uniq_small_limit, fused_rows, lazy, strided, hop_records)
     sets.resolve()
     sets.ukeys = sets.ukeys.clone()
     return sets

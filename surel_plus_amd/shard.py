@@ -66,7 +66,10 @@ def rand_r_calls(indptr, roots, num_walks, num_steps, first_hop_wo=True, cap_roo
     if r.numel() == 0:
         return 0
     ip = indptr if torch.is_tensor(indptr) else torch.as_tensor(indptr)
-    deg = (ip[r + 1] - ip[r]).long()
+    r = r.to(ip.device)
+    ok = (r >= 0) & (r < ip.numel() - 1)             # a root out of range draws nothing (and the walk kernel flags it)
+    r = r.clamp(0, max(ip.numel() - 2, 0))
+    deg = (ip[r + 1] - ip[r]).long() * ok.long()
     if cap_root_degree:
         deg = deg.clamp(max=1000000)                      # NEBMAX, subg_acc.c:13
     if first_hop_wo:

@@ -163,7 +163,10 @@ def sample_spg(csr, query, num_walks=200, num_steps=3, seed=111413, rng="rand_r"
     prefers_fused(): walks of >= 3 hops, or any walk over a graph far beyond the caches -- there the per-root epilogue
     hides behind the walk's line fetches (measured: cit2-like, 3 hops +10 % pairs/s; twitter-like, 2 hops +5 %;
     collab-like, 2 hops, an 8 MB graph that lives in L2: -5 %).  lazy=True leaves every size on the
-    device (no host round trip until SampledSets.resolve() / SpG.nnz); arrays are capacity-sized.
+    device (no host round trip until SampledSets.resolve() / SpG.nnz); arrays are capacity-sized.  A lazy batch cannot
+    recover by itself from a table of distinct LP rows that is too small (`uniq_capacity`, or more than
+    sampler.RANK_LIMIT distinct rows): resolve() raises SubgAccError then and the batch is sampled again with
+    lazy=False, which regrows the table / takes the packed path on its own (a serving loop: catch, re-run that batch).
     strided=True: for a batch that is sampled, joined and dropped -- returns a StridedSpG (no packed copy of the rows)."""
     sets = None
     if strided:     # transient batch: rows stay in the walk kernel's own layout (falls through when it does not apply)

@@ -63,23 +63,24 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
     ws = torch.empty(L.subgacc_sjoin_workspace_bytes(S), dtype=torch.uint8, device=dev)
     if isinstance(spg, StridedSpG):
         return _sjoin_strided(spg, own, partner, seg, ws, encode, ptr_mode, return_index, pair_block, out, lazy)
-    check(L.subgacc_sjoin_sizes(ptr(spg.indptr), ptr(own), S, ptr(seg), ptr(ws), ws.numel(), st))
+    flags = torch.zeros(4, dtype=torch.int32, device=dev)
+    check(L.subgacc_sjoin_sizes(ptr(spg.indptr), spg.n_rows, ptr(own), ptr(partner), S, ptr(seg), ptr(flags), ptr(ws),
+                                ws.numel(), st))
     is_f64 = spg.data.dtype == torch.float64
     if lazy and (out is None or not ptr_mode or return_index or is_f64 or encode is None):
         raise ValueError("lazy=True needs out=, ptr=True and an integer SpG with its encode table")
-    R = None if lazy else int(seg[S].item())     # the one host round trip: the output size
-    flags = torch.zeros(4, dtype=torch.int32, device=dev)
+    R = None if lazy else _size_and_row_check(seg, S, flags, spg.n_rows)     # the one host round trip
     segid = None if ptr_mode else torch.empty(R, dtype=torch.int64, device=dev)
     if is_f64:
         if encode is not None:
             raise TypeError("a float-payload SpG is joined without an encode table (train.py:39-43)")
         xz = torch.empty((R, 2, 1), dtype=torch.float32, device=dev)
-        check(L.subgacc_sjoin_fill(ptr(spg.indptr), ptr(spg.indices), None, ptr(spg.data), ptr(own), ptr(partner), S,
+        check(L.subgacc_sjoin_fill(ptr(spg.indptr), spg.n_rows, ptr(spg.indices), None, ptr(spg.data), ptr(own), ptr(partner), S,
                                    ptr(seg), None, 0, 1, ptr(xz), None, ptr(segid), spg.max_len, pair_block, ptr(flags), st))
         out = xz
     elif return_index:
         out = torch.empty((R, 2), dtype=torch.int32, device=dev)
-        check(L.subgacc_sjoin_fill(ptr(spg.indptr), ptr(spg.indices), ptr(spg.data), None, ptr(own), ptr(partner), S,
+        check(L.subgacc_sjoin_fill(ptr(spg.indptr), spg.n_rows, ptr(spg.indices), ptr(spg.data), None, ptr(own), ptr(partner), S,
                                    ptr(seg), None, 0, 0, None, ptr(out), ptr(segid), spg.max_len, pair_block, ptr(flags), st))
     else:
         if encode is None:
@@ -101,7 +102,7 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
         else:
             out = torch.empty((R, 2, k), dtype=torch.float32, device=dev)
         with _timed("sjoin_fill"):
-            check(L.subgacc_sjoin_fill(ptr(spg.indptr), ptr(spg.indices), ptr(spg.data), None, ptr(own), ptr(partner), S,
+            check(L.subgacc_sjoin_fill(ptr(spg.indptr), spg.n_rows, ptr(spg.indices), ptr(spg.data), None, ptr(own), ptr(partner), S,
                                        ptr(seg), ptr(enc), enc.shape[0], k, ptr(out), None, ptr(segid), spg.max_len,
                                        pair_block, ptr(flags), st))
     return out, (seg if ptr_mode else segid), flags
@@ -114,15 +115,16 @@ def _sjoin_strided(spg, own, partner, seg, ws, encode, ptr_mode, return_index, p
         raise ValueError("a StridedSpG is joined by gather / hgather (mirrored segment lists); use .to_csr() for the other forms")
     if lazy and not ptr_mode:
         raise ValueError("lazy=True needs ptr=True")
-    check(L.subgacc_sjoin_sizes_rows(ptr(spg.nsize), ptr(own), S, ptr(seg), ptr(ws), ws.numel(), st))
     flags = torch.zeros(4, dtype=torch.int32, device=dev)
-    R = None if lazy else int(seg[S].item())
+    check(L.subgacc_sjoin_sizes_rows(ptr(spg.nsize), spg.n_rows, ptr(own), ptr(partner), S, ptr(seg), ptr(flags), ptr(ws),
+                                     ws.numel(), st))
+    R = None if lazy else _size_and_row_check(seg, S, flags, spg.n_rows)
     segid = None if ptr_mode else torch.empty(R, dtype=torch.int64, device=dev)
     if return_index:
         if lazy:
             raise ValueError("lazy=True needs the encode table")
         res = torch.empty((R, 2), dtype=torch.int32, device=dev)
-        check(L.subgacc_sjoin_fill_rows(ptr(spg.nsize), spg.stride, ptr(spg.indices), ptr(spg.slot), ptr(spg.table),
+        check(L.subgacc_sjoin_fill_rows(ptr(spg.nsize), spg.n_rows, spg.stride, ptr(spg.indices), ptr(spg.slot), ptr(spg.table),
                                         spg.capacity, ptr(own), ptr(partner), S, ptr(seg), None, 0, 0, None, ptr(res),
                                         ptr(segid), pair_block, ptr(flags), st))
         return res, (seg if ptr_mode else segid), flags
@@ -147,20 +149,33 @@ def _sjoin_strided(spg, own, partner, seg, ws, encode, ptr_mode, return_index, p
     else:
         res = torch.empty((R, 2, k), dtype=torch.float32, device=dev)
     with _timed("sjoin_fill"):
-        check(L.subgacc_sjoin_fill_rows(ptr(spg.nsize), spg.stride, ptr(spg.indices), ptr(spg.slot), ptr(tab), cap,
+        check(L.subgacc_sjoin_fill_rows(ptr(spg.nsize), spg.n_rows, spg.stride, ptr(spg.indices), ptr(spg.slot), ptr(tab), cap,
                                         ptr(own), ptr(partner), S, ptr(seg), ptr(enc), enc.shape[0], k,
                                         ptr(res), None, ptr(segid), pair_block, ptr(flags), st))
     return res, (seg if ptr_mode else segid), flags
 
 
-# SpG.max_len / SpG.max_data make the kernel's own guards (flags[3]) unreachable; SUBGACC_DEBUG=1 reads them back
-# after every join anyway (one extra host sync per call).
+def _size_and_row_check(seg, S, flags, n_rows):
+    """The join's one host read: the output size R = seg[S] and, in the same copy, the status word of the size pass --
+    a row number outside the store is an IndexError here as it is in the reference (scipy's x[edge[0]], train.py:15);
+    the kernels never dereference such a row (it reads as empty), so nothing out of bounds has happened by now."""
+    R, status = torch.cat([seg[S:S + 1], flags[3:4].long()]).tolist()
+    if status & 16:
+        raise IndexError(f"row index out of range for an SpG with {n_rows} rows")
+    return int(R)
+
+
+# SpG.max_len / SpG.max_data make the kernel's other guards (flags[3] & 1, & 2) unreachable; SUBGACC_DEBUG=1 reads them
+# back after every join anyway (one extra host sync per call).  Row numbers out of range: raised by the eager forms
+# above; a lazy join (no host read at all) returns empty segments for them and leaves flags[3] & 16 set.
 _DEBUG_FLAGS = os.environ.get("SUBGACC_DEBUG", "0") == "1"
 
 
 def _checked(out, ind, flags):
     if _DEBUG_FLAGS:
         f = int(flags[3].item())
+        if f & 16:
+            raise IndexError("row index out of range for the SpG")
         if f & 1:
             raise _lib.SubgAccError("SpG row longer than SpG.max_len")
         if f & 2:
@@ -263,13 +278,15 @@ def gather_counts(edge, x, table_rows, device=None):
         raise IndexError(f"index {spg.max_data} is out of bounds for a table with {table_rows} rows")
     e = _as_rows(edge, spg.device)
     B = e.shape[1]
+    if B and bool(((e < 0) | (e >= spg.n_rows)).any()):          # this form has no size pass to carry the check
+        raise IndexError(f"row index out of range for an SpG with {spg.n_rows} rows")
     own = torch.cat([e[0], e[1]]).contiguous()
     partner = torch.cat([e[1], e[0]]).contiguous()
     dev = spg.device
     out = torch.empty((2 * B, int(table_rows)), dtype=torch.float32, device=dev)
     flags = torch.zeros(4, dtype=torch.int32, device=dev)
     with _timed("sjoin_counts"):
-        check(lib().subgacc_sjoin_counts(ptr(spg.indptr), ptr(spg.indices), ptr(spg.data), ptr(own), ptr(partner), 2 * B,
+        check(lib().subgacc_sjoin_counts(ptr(spg.indptr), spg.n_rows, ptr(spg.indices), ptr(spg.data), ptr(own), ptr(partner), 2 * B,
                                          int(table_rows), ptr(out), spg.max_len, B, ptr(flags), stream_ptr()))
     sizes = spg.indptr[own + 1] - spg.indptr[own]
     _checked(out, sizes, flags)

@@ -89,12 +89,12 @@ int main(int argc, char **argv) {
     int64_t *own = dev(sizeof own_h, own_h), *partner = dev(sizeof partner_h, partner_h), *seg = dev(5 * 8, NULL);
     size_t jwb = p_subgacc_sjoin_workspace_bytes(4);
     void *jws = dev(jwb, NULL);
-    CHECK(p_subgacc_sjoin_sizes(row_off, own, 4, seg, jws, jwb, NULL) == 0);
+    CHECK(p_subgacc_sjoin_sizes(row_off, n, own, partner, 4, seg, flags, jws, jwb, NULL) == 0);
     int64_t seg_h[5];
     HIP(hipMemcpy(seg_h, seg, sizeof seg_h, hipMemcpyDeviceToHost));
     const int64_t R = seg_h[4];
     float *xz = dev(R * 2 * (m + 1) * 4, NULL);
-    CHECK(p_subgacc_sjoin_fill(row_off, z_idx, z_dat, NULL, own, partner, 4, seg, tab, c + 1, m + 1, xz, NULL, NULL, STRIDE, 2,
+    CHECK(p_subgacc_sjoin_fill(row_off, n, z_idx, z_dat, NULL, own, partner, 4, seg, tab, c + 1, m + 1, xz, NULL, NULL, STRIDE, 2,
                                flags, NULL) == 0);
     HIP(hipDeviceSynchronize());
 

@@ -826,3 +826,123 @@ def test_sample_and_gather_on_demand_and_root_dedup(sp, hops):
     assert torch.equal(ind_a, ind_c) and torch.equal(xz_a, xz_c)
     with pytest.raises(ValueError):
         sp.sample_and_gather(csr, edge, num_walks=8, num_steps=2, rng="rand_r", dedup_roots=True)
+
+
+def test_out_of_range_rows_and_roots_raise_instead_of_reading_out_of_bounds(sp):
+    """The reference indexes with whatever it is given (scipy raises IndexError for a bad row, train.py:15; the C sampler
+    reads out of bounds for a bad root).  Here a bad row / root is never dereferenced on the device and the
+    host mirror raises IndexError -- for host AND device inputs."""
+    from surel_plus_amd.sampler import sample_sets
+    from surel_plus_amd.spg import sample_spg
+    ptr_, idx = sym_graph(500, 2500, seed=2)
+    csr = sp.DeviceCSR(ptr_, idx)
+    z, sets = sample_spg(csr, np.arange(500), num_walks=16, num_steps=2, seed=1, rng="philox")
+    table = sets.feature_table()
+    good = torch.tensor([[1, 2, 3], [4, 5, 6]], device="cuda")
+    ref_xz, ref_ind = sp.gather(good, z, None, ptr=True, encode=table)
+    for bad_val in (500, -1, 1 << 40):
+        bad = good.clone()
+        bad[1, 1] = bad_val
+        with pytest.raises(IndexError):
+            sp.gather(bad, z, None, ptr=True, encode=table)
+        with pytest.raises(IndexError):
+            sp.gather(bad.cpu().numpy(), z, None, ptr=False, encode=table)
+        with pytest.raises(IndexError):
+            sp.hgather(torch.cat([bad, good[:1]]), z, None, encode=table)
+        with pytest.raises(IndexError):
+            sp.gather_counts(bad, z, table.shape[0])
+        with pytest.raises(IndexError):
+            sp.bgather(bad, z, [None] * 4)
+    # strided rows of a transient batch
+    zs, ssets = sample_spg(csr, np.arange(100), num_walks=16, num_steps=3, seed=1, rng="philox", strided=True)
+    assert ssets.strided
+    with pytest.raises(IndexError):
+        sp.gather(torch.tensor([[1, 100], [2, 3]], device="cuda"), zs, None, ptr=True, encode=zs.slot_table())
+    # the device is fine afterwards and the good batch still gives the same answer
+    xz, ind = sp.gather(good, z, None, ptr=True, encode=table)
+    assert torch.equal(xz, ref_xz) and torch.equal(ind, ref_ind)
+    # roots: device tensors are not pre-checked on the host; the kernels flag them
+    for q in (torch.tensor([3, 500, 7], device="cuda"), torch.tensor([3, -2, 7], device="cuda", dtype=torch.int32)):
+        for kw in ({}, {"rng": "philox"}, {"rng": "philox", "fused_rows": True}):
+            with pytest.raises(IndexError):
+                sample_sets(csr, q, num_walks=16, num_steps=3, seed=1, **kw)
+        lazy = sample_sets(csr, q, num_walks=16, num_steps=3, seed=1, rng="philox", fused_rows=True, lazy=True)
+        with pytest.raises(IndexError):
+            lazy.resolve()
+    with pytest.raises(IndexError):
+        sp.gset_sampler(ptr_, idx, np.array([1, 500]), num_walks=8, num_steps=2)
+    with pytest.raises(IndexError):
+        sp.sample_and_gather(csr, torch.tensor([[1, 2], [3, 777]], device="cuda"), num_walks=16, num_steps=3)
+    # a malformed CSR handed over as device tensors is refused before any kernel sees it
+    ip, ix = torch.from_numpy(ptr_).cuda(), torch.from_numpy(idx).cuda()
+    ix_bad = ix.clone()
+    ix_bad[5] = 500
+    with pytest.raises(IndexError):
+        sp.DeviceCSR(ip, ix_bad)
+    ip_bad = ip.clone()
+    ip_bad[10] = ip_bad[9] - 1
+    with pytest.raises(IndexError):
+        sp.DeviceCSR(ip_bad, ix)
+    a = sp.gset_sampler(ptr_, idx, np.arange(50), num_walks=8, num_steps=2)
+    b = oracle.gset_sampler(ptr_, idx, np.arange(50), num_walks=8, num_steps=2)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_strided_eager_recovers_from_a_small_table_of_distinct_rows(sp):
+    """The eager strided form regrows an overflowing table of distinct LP rows like the packed forms do (and the retry
+    keeps the strided layout); more distinct rows than the direct ranking numbers -> None, sample_spg falls through."""
+    from surel_plus_amd.sampler import sample_sets
+    from surel_plus_amd.spg import StridedSpG, sample_spg
+    ptr_, idx = sym_graph(4000, 40000, seed=12, hubs=2)
+    csr = sp.DeviceCSR(ptr_, idx)
+    q = np.arange(4000)
+    ref = sample_sets(csr, q, num_walks=64, num_steps=3, seed=5, rng="philox", fused_rows=True)
+    assert ref.c > 64
+    s = sample_sets(csr, q, num_walks=64, num_steps=3, seed=5, rng="philox", fused_rows=True, strided=True, uniq_capacity=64)
+    assert s is not None and s.strided and s.capacity > 64 and s.c == ref.c
+    assert torch.equal(s.ukeys, ref.ukeys) and torch.equal(s.nsize, ref.nsize)
+    assert sample_sets(csr, q, num_walks=64, num_steps=3, seed=5, rng="philox", fused_rows=True, strided=True,
+                       uniq_small_limit=32) is None
+    z, sets = sample_spg(csr, q, num_walks=64, num_steps=3, seed=5, rng="philox", strided=True, uniq_small_limit=32)
+    assert not isinstance(z, StridedSpG) and sets.c == ref.c
+
+
+@pytest.mark.parametrize("rng", ["rand_r", "philox"])
+@pytest.mark.parametrize("deg_bits", [0, 4])
+def test_hop_records_give_the_same_sets_as_the_plain_csr(sp, rng, deg_bits, monkeypatch):
+    """The packed hop records (one dependent read per hop) are a view of the same graph: sets, LP rows, raw walks and
+    SpG rows are bit-identical with and without them -- also when the degree field is so narrow (4 bits, forced)
+    that most nodes escape to the row-pointer look-up, and on the step-major / with-replacement walk_sampler forms."""
+    from surel_plus_amd.sampler import DeviceCSR, sample_sets
+    from surel_plus_amd.spg import sample_spg
+    if deg_bits:
+        monkeypatch.setenv("SUBGACC_REC_DEG_BITS", str(deg_bits))
+    ptr_, idx = sym_graph(3000, 30000, seed=17, hubs=3)
+    csr = DeviceCSR(ptr_, idx)
+    recs = csr.hop_records()
+    assert recs is not None and 64 - recs[1] - recs[2] == (deg_bits or 64 - recs[1] - recs[2])
+    deg = np.diff(ptr_)
+    if deg_bits:
+        assert (deg >= 15).sum() > 100 and (deg < 15).sum() > 100        # both escaped and inline degrees occur
+    q = np.random.default_rng(1).permutation(3000)[:2500]
+    o = oracle.gset_sampler(ptr_, idx, q, num_walks=40, num_steps=3, seed=8, debug=True, rng=rng)
+    for hr in (True, False):
+        s = sample_sets(csr, q, num_walks=40, num_steps=3, seed=8, rng=rng, hop_records=hr)
+        assert np.array_equal(s.nsize.cpu().numpy(), o[0])
+        assert np.array_equal(torch.stack([s.ids, s.get_sf()]).cpu().numpy(), o[1])
+        assert np.array_equal(s.enc_int16().cpu().numpy(), o[2])
+        z, fs = sample_spg(csr, q, num_walks=40, num_steps=3, seed=8, rng=rng, fused=True, hop_records=hr)
+        oi, od, ov = oracle.spg_build(o[0], o[1])
+        assert np.array_equal(z.indptr.cpu().numpy(), oi) and np.array_equal(z.indices[: z.nnz].cpu().numpy(), od)
+        assert np.array_equal(z.data[: z.nnz].cpu().numpy(), ov)
+        # walk_sampler's forms: raw walks, step-major order, first hop with replacement (replacement=False)
+        for wo in (True, False):
+            w = sample_sets(csr, q[:700], num_walks=12, num_steps=4, seed=3, rng=rng, first_hop_wo=wo, order=1,
+                            cap_root_degree=False, emit_walks=True, rng_streams=3 if rng == "rand_r" else 1, dedup=False,
+                            hop_records=hr)
+            ow, on, oids, oc = oracle.walk_sampler(ptr_, idx, q[:700], num_walks=12, num_steps=4, nthread=3 if rng == "rand_r" else 1,
+                                                   seed=3, replacement=wo, rng=rng)
+            assert np.array_equal(w.walks.cpu().numpy(), ow) and np.array_equal(w.nsize.cpu().numpy(), on)
+            assert np.array_equal(w.ids.cpu().numpy(), oids) and np.array_equal(w.counts_int32().cpu().numpy(), oc)
+    # a graph the layout declines (64-bit row offsets) simply walks the plain CSR
+    assert DeviceCSR(ptr_.astype(np.int64), idx).hop_records() is None

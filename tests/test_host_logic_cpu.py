@@ -19,11 +19,18 @@ def test_csr_casting_rules_match_the_reference():
         mirror._csr_from_host(ok_ptr, ok_idx.astype(np.int64))
     with pytest.raises(TypeError, match="Input parsing error"):
         mirror._csr_from_host(ok_ptr, ok_idx.astype(np.uint32))
-    # a malformed graph would be a segfault in the reference and a device fault here: refused on the host
+    # a malformed graph would be a segfault in the reference and a device fault here: DeviceCSR refuses it where the
+    # arrays live (a few reductions on the device after the upload; the same torch code runs on host tensors here)
     with pytest.raises(IndexError):
-        mirror._csr_from_host(np.array([0, 3, 2], np.int32), ok_idx)          # offsets not monotone / past the end
+        sp.DeviceCSR(np.array([0, 3, 2], np.int32), ok_idx, device="cpu")     # offsets not monotone / past the end
     with pytest.raises(IndexError):
-        mirror._csr_from_host(ok_ptr, np.array([1, 7], np.int32))             # neighbour id out of range
+        sp.DeviceCSR(np.array([1, 1, 2], np.int32), ok_idx, device="cpu")     # does not start at 0
+    with pytest.raises(IndexError):
+        sp.DeviceCSR(ok_ptr, np.array([1, 7], np.int32), device="cpu")        # neighbour id out of range
+    with pytest.raises(IndexError):
+        sp.DeviceCSR(ok_ptr, np.array([1, -1], np.int32), device="cpu")
+    assert sp.DeviceCSR(ok_ptr, ok_idx, device="cpu").num_nodes == 2
+    assert sp.DeviceCSR(np.array([0], np.int64), np.zeros(0, np.int32), device="cpu").num_nodes == 0
     with pytest.raises(IndexError):
         mirror._checked_query(np.array([0, 5]), 2)
     # smaller integer types are safe casts; they fail later only because there is no GPU here

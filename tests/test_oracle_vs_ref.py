@@ -8,6 +8,8 @@ fixtures: random graphs (isolated nodes, star hubs, K2 components), random M / m
 
 Skips cleanly where oracle/_ref does not exist (the GPU box may or may not carry it; nothing here needs a GPU).
 Every case has its own seeded stream: a failing case number reproduces alone."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -86,6 +88,7 @@ def test_gset_sampler_random_sweep(block, capfd):
         assert np.array_equal(o[1], remap), what
         assert np.array_equal(o[2], enc), what
         assert np.array_equal(o[3], raw), what
+    ctypes.CDLL(None).fflush(None)
     capfd.readouterr()        # the reference printf()s statistics
 
 
@@ -120,4 +123,5 @@ def test_walk_sampler_and_walk_join_random_sweep(block, capfd):
         out, xrow = ref.walk_join(uw, ukeys, pairs, nthread=1, return_idx=True)
         oout, oxrow = oracle.walk_join(uw, ukeys, pairs, return_idx=True)
         assert np.array_equal(oout, out) and np.array_equal(oxrow, xrow), what
+    ctypes.CDLL(None).fflush(None)
     capfd.readouterr()

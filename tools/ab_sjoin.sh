@@ -2,12 +2,13 @@
 # Dev-only A/B of compile-time variants of sjoin.hip on ONE box: usage  VARIANTS="-DSJ_EXPERIMENT=1|-DSJ_EXPERIMENT=2" tools/ab_sjoin.sh
 set -e
 cd $GRAFT_REPO_ROOT/surel_plus_amd/csrc
-cp ../libsubgacc_hip.so /tmp/lib_orig.so
+# variants are linked into /tmp and selected with SUBGACC_LIB: the shipped library is never touched
+export SUBGACC_LIB=/tmp/libsubgacc_variant.so
 IFS='|' read -ra VS <<< "${VARIANTS:-}"
 OBJS=$(ls build/*.o | grep -v sjoin.o)
 for V in "" "${VS[@]}"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -ffp-contract=off $V -c sjoin.hip -o /tmp/sjoin_v.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/sjoin_v.o -o ../libsubgacc_hip.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/sjoin_v.o -o $SUBGACC_LIB
   for W in ${WLS:-cit2}; do
     for rep in 1 2; do
     echo -n "[$V] $W: "
@@ -15,4 +16,3 @@ for V in "" "${VS[@]}"; do
     done
   done
 done
-cp /tmp/lib_orig.so ../libsubgacc_hip.so

@@ -4,14 +4,15 @@
 # (SUBGACC_WALK_PIPE=0 keeps the hooks of walk_sets_kernel in play for the set_sampler form.)
 set -e
 cd $GRAFT_REPO_ROOT/surel_plus_amd/csrc
-cp ../libsubgacc_hip.so /tmp/lib_orig.so
+# variants are linked into /tmp and selected with SUBGACC_LIB: the shipped library is never touched
+export SUBGACC_LIB=/tmp/libsubgacc_variant.so
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -ffp-contract=off"
 OBJS=$(ls build/*.o | grep -v -x -F -e build/walk.o -e build/walk_pipe.o)
 IFS='|' read -ra VS <<< "${VARIANTS:-}"
 for V in "" "${VS[@]}"; do
   /opt/rocm/bin/hipcc $FLAGS $V -c walk.hip -o /tmp/walk_v.o
   /opt/rocm/bin/hipcc $FLAGS $V -c walk_pipe.hip -o /tmp/walk_pipe_v.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/walk_v.o /tmp/walk_pipe_v.o -o ../libsubgacc_hip.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/walk_v.o /tmp/walk_pipe_v.o -o $SUBGACC_LIB
   for W in ${WLS:-cit2 collab}; do
     for rep in 1 2; do
     echo -n "[$V] $W: "
@@ -19,4 +20,3 @@ for V in "" "${VS[@]}"; do
     done
   done
 done
-cp /tmp/lib_orig.so ../libsubgacc_hip.so

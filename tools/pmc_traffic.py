@@ -1,0 +1,59 @@
+"""Dev-only: per-kernel means of the PMC passes of tools/pmc_collect.sh (with the gfx950 byte correction: FETCH_SIZE
+tallies a 128-byte line request at 64 bytes -- MI355X_MICROARCH.md, HBM section; confirmed for random 4-byte reads by
+tools/line_probe.hip: one request per missed 128-byte line) and the matching entry of profiles/traffic.json.
+
+    python tools/pmc_traffic.py OUTDIR TAG [bench args that were used]"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+out, tag, bargs = sys.argv[1], sys.argv[2], sys.argv[3:]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(out, "*", "*", "*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "subgacc" in k or "compact_rows" in k:
+            acc[k.split("(")[0].replace("void subgacc::", "").replace("subgacc::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+print("kernel,launches,FETCH_SIZE,WRITE_SIZE,TCC_REQ_sum,TCC_HIT_sum,TCC_MISS_sum,hbm_bytes_per_launch=(2*FETCH_SIZE+WRITE_SIZE)*1024")
+rows = []
+for k, c in acc.items():
+    m = {n: sum(v) / len(v) for n, v in c.items()}
+    if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+        rows.append((-(2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]), k, len(c["FETCH_SIZE"]), m))
+walk = None
+for _, k, n, m in sorted(rows)[:10]:
+    hbm = (2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024
+    print(f"\"{k}\",{n},{m['FETCH_SIZE']:.0f},{m['WRITE_SIZE']:.0f},{m.get('TCC_REQ_sum', 0):.0f},{m.get('TCC_HIT_sum', 0):.0f},{m.get('TCC_MISS_sum', 0):.0f},{hbm:.0f}")
+    if walk is None and (k.startswith("walk_sets_kernel") or k.startswith("walk_pipe_kernel") or k.startswith("walk_wave_kernel")):
+        walk = (k, hbm, m.get("TCC_MISS_sum", 0), m.get("TCC_REQ_sum", 0), n)
+# the bench line of one of the passes tells the configuration (workload, B, M, k, layout, rng)
+line = None
+for f in glob.glob(os.path.join(out, "*.json")):
+    for ln in open(f):
+        if ln.startswith('{"metric"'):
+            line = json.loads(ln)
+if walk and line:
+    import bench
+    cfg = line["config"]
+    name = "cit2"
+    for i, a in enumerate(bargs):
+        if a == "--workload":
+            name = bargs[i + 1]
+    key = f"{name}:{cfg['pairs_per_step_per_gpu']}:{cfg['num_walks']}:{cfg['num_steps_cli']}:{'spg' if cfg['fused_spg_rows'] else 'sets'}:{cfg['rng']}"
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    tj = {k: v for k, v in tj.items() if isinstance(v, dict) and "kernel_source_sha" in v}     # entries without a hash are stale
+    tj[key] = {"walk_sets_hbm_bytes_per_launch": walk[1], "walk_sets_l2_miss_lines_per_launch": walk[2],
+               "walk_sets_l2_requests_per_launch": walk[3], "kernel": walk[0], "launches_averaged": walk[4],
+               "kernel_source_sha": bench.kernel_source_sha(), "source": f"profiles/{tag}_pmc_per_launch.csv",
+               "how": "tools/pmc_collect.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum "
+                      "in separate passes over `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-others`; mean over the "
+                      "walk kernel's dispatches; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (KB units; gfx950 tallies a 128-B line "
+                      "request at 64 B: MI355X_MICROARCH.md HBM section, and tools/line_probe.hip for random 4-B reads)"}
+    json.dump(tj, open(tpath, "w"), indent=1)
+    print(f"# profiles/traffic.json[{key}] <- {walk[1]:.0f} B, {walk[2]:.0f} missed lines per launch (kernel sources {tj[key]['kernel_source_sha']})")

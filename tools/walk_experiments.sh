@@ -4,13 +4,13 @@
 set -e
 export SUBGACC_WALK_PIPE=${SUBGACC_WALK_PIPE:-0}   # the hooks live in walk_sets_kernel (walk.hip)
 cd $GRAFT_REPO_ROOT/surel_plus_amd/csrc
-cp ../libsubgacc_hip.so /tmp/lib_orig.so
+# variants are linked into /tmp and selected with SUBGACC_LIB: the shipped library is never touched
+export SUBGACC_LIB=/tmp/libsubgacc_variant.so
 for E in ${EXPS:-0 1 2}; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -ffp-contract=off -DSG_EXPERIMENT=$E -c walk.hip -o /tmp/walk_e$E.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls build/*.o | grep -v -x -F -e build/walk.o) /tmp/walk_e$E.o -o ../libsubgacc_hip.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls build/*.o | grep -v -x -F -e build/walk.o) /tmp/walk_e$E.o -o $SUBGACC_LIB
   for W in ${WLS:-collab cit2}; do
     echo -n "EXPERIMENT=$E $W: "
     python $GRAFT_REPO_ROOT/bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['config']['stage_ms']['walk_sets'])"
   done
 done
-cp /tmp/lib_orig.so ../libsubgacc_hip.so

@@ -19,12 +19,17 @@ table = torch.empty(L.subgacc_uniq_table_bytes(1 << 20), dtype=torch.uint8, devi
 check(L.subgacc_uniq_reset(ptr(table), 1 << 20, stream_ptr()))
 ids = torch.empty(n * stride, dtype=torch.int32, device="cuda"); slot = torch.empty_like(ids)
 nsize = torch.empty(n, dtype=torch.int32, device="cuda")
-for it in range(2):
+for it in range(3):
     flags.zero_()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
     check(L.subgacc_walk_spg(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(roots), n, 0, None, None, ptr(table),
                              1 << 20, ptr(ids), ptr(slot), ptr(nsize), ptr(flags), stream_ptr()))
+    b.record()
 torch.cuda.synchronize()
+print(f"kernel {a.elapsed_time(b):.3f} ms (stamps on 1 workgroup in 64), LDS pad {os.environ.get('SUBGACC_LDS_PAD', '0')}")
 c = flags[8:8 + 18].view(torch.int64).tolist()
+n = (n + 63) // 64          # sampled workgroups
 names = ["init tables + fisher-yates draws", "root insert", "WALK + visits", "member load + fold (LDS)", "flush fold to HBM + zero buckets",
          "histogram", "bucket scan (wave 0)", "scatter", "in-bucket rank + global write"]
 tot = sum(c)
