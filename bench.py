@@ -273,7 +273,8 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W):
                          "algorithmic_bytes_per_launch": abytes}}
 
 
-def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, with_cpu_baseline, csr_variant=True):
+def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, with_cpu_baseline, csr_variant=True,
+             small_batches=False):
     """sample + SpJoin over one LP workload: W warm-up steps, K timed steps bracketed by barrier + synchronize, max over
     ranks.  Returns the JSON object (rank 0) or None."""
     global STRIDED
@@ -357,7 +358,6 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
     abytes = algorithmic_walk_bytes(csr, edge.reshape(-1), sets, M, k - 1)   # the last step's launch
     achieved = abytes / (walk_ms * 1e-3) / 1e9 if walk_ms else None
     fused_rows = sets.data is not None or sets.strided
-    recs = csr.hop_records()
     # HBM-side traffic / missed lines of the walk kernel: PMC passes (tools/pmc_traffic.py) of exactly these kernels
     # (matched by a hash of the kernel sources) and this configuration -- or null
     traffic = lines = None
@@ -366,7 +366,7 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
         tj = json.load(open(tpath)).get(f"{name}:{B}:{M}:{k}:{'spg' if fused_rows else 'sets'}:{rng}", {})
         if tj.get("kernel_source_sha") == kernel_source_sha():
             traffic, lines = tj.get("walk_sets_hbm_bytes_per_launch"), tj.get("walk_sets_l2_miss_lines_per_launch")
-    roof = random_line_roof((8 if recs else 4) * csr.nnz)
+    roof = random_line_roof(4 * csr.nnz)
     out = {
         "metric": "query-pairs/sec (sample+SpJoin)", "value": world * B * K / elapsed, "unit": "query-pairs/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
@@ -375,7 +375,6 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
                    "num_walks": M, "num_steps_cli": k, "rng": rng, "parallelism": f"query-shard x{world}",
                    "set_members_last_step": sets.X, "distinct_lp_rows_last_step": sets.c,
                    "xz_rows_last_step": int(xz.shape[0]), "graph_nnz": csr.nnz,
-                   "graph_walked_through": "packed hop records (8 B per adjacency entry)" if recs else "plain CSR",
                    # S = roots/s of the sampler pipeline (walk .. SpG), J = pairs/s of the join alone
                    "S_roots_per_s": 2 * B / (1e-3 * sum(v for v in (timer.mean_ms(n_)[0] for n_ in
                                              ("walk_sets", "compact_sets", "uniq_rows", "spg_build")) if v)),
@@ -399,6 +398,8 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
                                           "achieved_lines_per_s": (lines / (walk_ms * 1e-3)) if (lines and walk_ms) else None,
                                           "frac": (lines / (walk_ms * 1e-3) / roof) if (lines and walk_ms) else None}},
     }
+    if small_batches:
+        out["config"]["batch_size_and_hip_graph"] = batch_size_and_graph(sp, csr, M, k, rng, K)
     if with_cpu_baseline and name != "twitter":   # 12 GB CSR: no host copy
         try:
             out["cpu_baseline"] = cpu_baseline(csr, edges[W], M, k)
@@ -408,12 +409,53 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
     return out
 
 
+def batch_size_and_graph(sp, csr, M, k, rng, K):
+    """Outside the clock (rank 0, 1 GPU): the reference's default batch of 1,024 pairs (main.py:32) and the headline's
+    65,536, each as eager launches and as ONE captured HIP graph per step (stepgraph.CapturedStep), same double-buffered
+    loop.  Pairs/s per variant."""
+    from surel_plus_amd.graphs import query_pairs
+    out = {}
+    for B in (1024, 65536):
+        steps = max(K, 20) if B == 1024 else K
+        edges = [query_pairs(csr, B, seed=7000 + s, device=csr.device) for s in range(steps + 3)]
+        for mode in ("eager", "graph"):
+            try:
+                _XZ_BUF.clear()
+                torch.cuda.empty_cache()
+                caps = [sp.CapturedStep(csr, B, num_walks=M, num_steps=k - 1, seed=1, rng=rng, uniq_capacity=UNIQ_CAPACITY)
+                        for _ in (0, 1)] if mode == "graph" else None
+
+                def loop(ids):
+                    pending = None
+                    for s in ids:
+                        e = edges[s % len(edges)]
+                        if caps is not None:
+                            q = caps[s & 1](e)
+                        else:
+                            q = hot_path_step(sp, csr, e, M, k, seed=1, rng=rng, slot=s & 1)
+                        if pending is not None:
+                            pending.finish() if caps is not None else finish_step(*pending)
+                        pending = q
+                    if pending is not None:
+                        pending.finish() if caps is not None else finish_step(*pending)
+                loop(range(3))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                loop(range(3, 3 + steps))
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                out[f"B={B} {mode}"] = {"pairs_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps}
+                del caps
+            except Exception as ex:
+                out[f"B={B} {mode}"] = {"failed": f"{type(ex).__name__}: {ex}"}
+    return out
+
+
 def summary(o):
     """what an `other_workloads` entry keeps of a full line"""
     keep = {k_: o[k_] for k_ in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype")}
     keep["config"] = {k_: o["config"].get(k_) for k_ in ("workload", "pairs_per_step_per_gpu", "rng", "set_members_last_step",
-                                                         "distinct_lp_rows_last_step", "xz_rows_last_step", "graph_nnz",
-                                                         "graph_walked_through", "spg_layout", "stage_ms", "spg_members",
+                                                         "distinct_lp_rows_last_step", "xz_rows_last_step", "graph_nnz", "spg_layout", "stage_ms", "spg_members",
                                                          "offline_ppr_stage_s") if k_ in o["config"]}
     keep["roofline"] = o["roofline"]
     if "cpu_baseline" in o:
@@ -477,7 +519,8 @@ def main():
         out = bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, WORKLOADS[args.workload][3], B, K, W)
     else:
         out = bench_lp(args, args.workload, args.rng, B, K, W, sp, sampler_mod, dev, rank, world, dist,
-                       with_cpu_baseline=(world == 1 and not args.no_cpu_baseline))
+                       with_cpu_baseline=(world == 1 and not args.no_cpu_baseline),
+                       small_batches=(world == 1 and not args.no_others))
     # BASELINE.json's other single-GPU configurations (and the reference-bit-exact rand_r stream on the headline one),
     # as short passes after the timed region: same code path, >= 5 timed steps each, their own roofline blocks
     # (configs[0], the reference's CPU-runnable collab case, rides on the collab entry as its cpu_baseline).

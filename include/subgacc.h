@@ -68,24 +68,7 @@ typedef struct subgacc_walk_cfg {
     int32_t cap_root_degree; /* 1: clamp the root degree to 1e6 (NEBMAX, subg_acc.c:750)        */
     int32_t indptr64;        /* CSR row offsets are int64 (else int32)                          */
     int32_t emit_walks;      /* 1: also write raw walks int32[n, M*(m+1)] (walk_sampler)        */
-    /* optional packed hop records (subgacc_hop_records_build; NULL = walk the plain CSR).  Same sets, bit for bit:
-     * a hop then costs ONE dependent read (neighbour id, its row begin and its degree arrive together) instead of
-     * the reference's two (indices[...] then indptr[neighbour], subg_acc.c:803-808). */
-    const uint64_t *hop_records;
-    int32_t rec_id_bits;     /* field widths of a record, from the top: [id | row begin | degree]        */
-    int32_t rec_beg_bits;
 } subgacc_walk_cfg;
-
-/* Packed hop records of a CSR graph: rec[e] = (v = indices[e], indptr[v], deg(v)) in one 64-bit word, for every
- * adjacency entry e -- an auxiliary, read-only view of the replicated graph (8 B per entry) built once per graph.
- * Widths: id_bits = bits of num_nodes-1, beg_bits = bits of nnz, the degree takes the rest; a degree that does not
- * fit is stored as all-ones and looked up in indptr by the walk (hubs: their row pointers are L2-hot anyway).
- * subgacc_hop_records_layout returns the degree width (>= 12 or the graph is not worth packing: returns 0, e.g.
- * the twitter-like graph with 26 + 32 bits).  subgacc_hop_records_build accepts wider id / offset fields than the
- * layout's (id_bits <= 32, id_bits + beg_bits <= 60). */
-int subgacc_hop_records_layout(int64_t num_nodes, int64_t nnz, int32_t *id_bits, int32_t *beg_bits);
-int subgacc_hop_records_build(const void *indptr, int32_t indptr64, const int32_t *indices, int64_t num_nodes, int64_t nnz,
-                              int32_t id_bits, int32_t beg_bits, uint64_t *out_records, void *stream);
 
 /* LP rows are carried as one packed 64-bit key: count of step j in bits [(m-j)*SHIFT, +SHIFT),
  * SHIFT = 32-clz(M), plus bit m*SHIFT (LEAD) on the root row -- the reference's `bithash`
@@ -249,6 +232,18 @@ int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t n_rows, int64_t row_
 int subgacc_sjoin_counts(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices, const int32_t *spg_data_i32,
                          const int64_t *own, const int64_t *partner, int64_t S, int64_t table_rows, float *out_counts,
                          int32_t max_len, int64_t pair_block, int32_t *flags, void *stream);
+
+/* Pair form of the join, for aggregations that are not linear in the rows (the attention gate, model.py:59-62): the
+ * first model stage maps an output row to e[pa] + e[pb] (e = pe_embedding of the Z_SF table), a function of the index
+ * pair (pa, pb) alone, and a segment of hundreds of rows holds a few dozen distinct pairs.  Segment j leaves as its
+ * DISTINCT pairs with multiplicities, in a reproducible order, at rows [seg[j], seg[j] + out_cnt[j]) of
+ *   out_pairs i32 [R,2] (pa, pb: SFptr+1 of the member in the own row, in the partner row or 0), out_mult i32 [R],
+ * with seg / R from subgacc_sjoin_sizes (the rows beyond out_cnt[j] of a segment stay unwritten).  Mirrored segment
+ * lists only (pair_block > 0); max_len <= 1024 (SUBGACC_ERR_LDS otherwise). */
+int subgacc_sjoin_pairs(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices, const int32_t *spg_data_i32,
+                        const int64_t *own, const int64_t *partner, int64_t S, const int64_t *seg, int32_t *out_pairs,
+                        int32_t *out_mult, int32_t *out_cnt, int32_t max_len, int64_t pair_block, int32_t *flags,
+                        void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Top-K approximate-PPR node sets -- replaces sampler/pprgo.py:9-38 (_calc_ppr_node, the

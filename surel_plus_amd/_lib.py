@@ -29,8 +29,7 @@ SYMBOLS = (
     "subgacc_sjoin_workspace_bytes", "subgacc_sjoin_sizes", "subgacc_sjoin_fill", "subgacc_sjoin_counts",
     "subgacc_ppr_slab_bytes", "subgacc_ppr_slab_reset", "subgacc_ppr_topk", "subgacc_ppr_normalize", "subgacc_ppr_encode",
     "subgacc_walk_join", "subgacc_sjoin_sizes_rows", "subgacc_sjoin_fill_rows",
-    "subgacc_encode_sizes", "subgacc_encode_fill",
-    "subgacc_hop_records_layout", "subgacc_hop_records_build",
+    "subgacc_encode_sizes", "subgacc_encode_fill", "subgacc_sjoin_pairs",
 )
 
 
@@ -38,8 +37,7 @@ class WalkCfg(C.Structure):
     """struct subgacc_walk_cfg"""
     _fields_ = [("num_walks", C.c_int32), ("num_steps", C.c_int32), ("bucket", C.c_int32), ("rng_mode", C.c_int32),
                 ("seed", C.c_uint32), ("first_hop_wo", C.c_int32), ("order", C.c_int32),
-                ("cap_root_degree", C.c_int32), ("indptr64", C.c_int32), ("emit_walks", C.c_int32),
-                ("hop_records", C.c_void_p), ("rec_id_bits", C.c_int32), ("rec_beg_bits", C.c_int32)]
+                ("cap_root_degree", C.c_int32), ("indptr64", C.c_int32), ("emit_walks", C.c_int32)]
 
 
 class SubgAccError(RuntimeError):
@@ -110,8 +108,7 @@ def lib():
     sig["subgacc_sjoin_fill_rows"] = (C.c_int, [vp, i64, i64, vp, vp, vp, i64, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, i64, vp, vp])
     sig["subgacc_encode_sizes"] = (C.c_int, [vp, vp, i64, vp, i32, vp, i32, vp, vp, vp])
     sig["subgacc_encode_fill"] = (C.c_int, [vp, vp, vp, i64, i32, vp, i32, vp, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp])
-    sig["subgacc_hop_records_layout"] = (C.c_int, [i64, i64, C.POINTER(i32), C.POINTER(i32)])
-    sig["subgacc_hop_records_build"] = (C.c_int, [vp, i32, vp, i64, i64, i32, i32, vp, vp])
+    sig["subgacc_sjoin_pairs"] = (C.c_int, [vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, i64, vp, vp])
     assert set(sig) == set(SYMBOLS)
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

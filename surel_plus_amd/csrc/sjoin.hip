@@ -366,6 +366,142 @@ __global__ __launch_bounds__(kPairThreads) void sjoin_counts_kernel(const JoinAr
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Pair form of the join (SURVEY.md 8(f).1 for the aggregations that are NOT linear in the rows -- the attention gate of
+// model.py:59-62).  Every output row of a segment is the feature pair (table[pa], table[pb]) and the model's first
+// stage maps it to pe_embedding(.).sum(-2) = e[pa] + e[pb]: a function of the index pair only.  A segment of ~400
+// rows holds a few dozen distinct pairs, so the segment leaves as (pair, multiplicity) rows; gate softmax and the
+// weighted sum over the segment are exact with the multiplicities as weights (spjoin.attn_stage).  The distinct pairs
+// are found in an ORDERED open-addressing table in LDS (each slot keeps the smallest key that probed it, the larger
+// one moves on: Amble-Knuth): its final layout does not depend on the order of the concurrent inserts, so the rows
+// leave in a reproducible order (table slot order) without a sort.  Rows of segment j go to [seg[j], seg[j]+cnt[j]).
+constexpr unsigned long long kPairEmpty = ~0ull;
+__global__ __launch_bounds__(kPairThreads) void sjoin_pairs_kernel(const JoinArgs a, int64_t pb, int ts_log2,
+                                                                   int32_t *__restrict__ out_pairs,
+                                                                   int32_t *__restrict__ out_mult,
+                                                                   int32_t *__restrict__ out_cnt) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int TS = 1 << ts_log2;
+    unsigned long long *tabK = (unsigned long long *)lds_raw;   // [2][TS] distinct (pa << 32 | pb) of block A, block B
+    int32_t *tabC = (int32_t *)(tabK + 2 * TS);                  // [2][TS] multiplicities
+    int32_t *valA = tabC + 2 * TS;                               // [max_len]
+    int32_t *valB = valA + a.max_len;
+    int32_t *idsA = valB + a.max_len;
+    int32_t *idsB = idsA + a.max_len;
+    __shared__ int32_t wsum[2][kPairThreads / kWave];
+
+    const int64_t p = xcd_item(blockIdx.x, gridDim.x);
+    if (p >= a.S / 2) return;
+    const int64_t j = (p / pb) * 2 * pb + (p % pb), j2 = j + pb;
+    const int tid = threadIdx.x;
+    const int64_t ra = a.own[j], rb = a.partner[j];
+    if (a.own[j2] != rb || a.partner[j2] != ra) {
+        if (tid == 0) atomicOr(&a.flags[3], 4);
+        return;
+    }
+    int64_t ab, na64, bb, nb64;
+    join_row(a, ra, ab, na64);
+    join_row(a, rb, bb, nb64);
+    if (na64 > a.max_len || nb64 > a.max_len) {
+        if (tid == 0) atomicOr(&a.flags[3], 1);
+        return;
+    }
+    const int na = (int)na64, nb = (int)nb64;
+    const int32_t *data = (const int32_t *)a.data;
+    for (int x = tid; x < 2 * TS; x += kPairThreads) {
+        tabK[x] = kPairEmpty;
+        tabC[x] = 0;
+    }
+    for (int r = tid; r < na; r += kPairThreads) {
+        idsA[r] = a.indices[ab + r];
+        valA[r] = data[ab + r];
+    }
+    for (int r = tid; r < nb; r += kPairThreads) {
+        idsB[r] = a.indices[bb + r];
+        valB[r] = data[bb + r];
+    }
+    __syncthreads();
+    const uint32_t tmask = (uint32_t)TS - 1u;
+    // the member's pair (searched once, kept in registers for the counting pass): <= 2 * max_len members, strided
+    constexpr int kPer = 8;                                      // 2 * max_len <= 8 * 256 (checked on the host)
+    unsigned long long mykey[kPer];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+        const int t = tid + u * kPairThreads;
+        mykey[u] = kPairEmpty;
+        if (t >= na + nb) continue;
+        const bool dirB = t >= na;
+        const int r = dirB ? t - na : t;
+        const int32_t *oid = dirB ? idsB : idsA, *oval = dirB ? valB : valA;
+        const int32_t *pid = dirB ? idsA : idsB, *pval = dirB ? valA : valB;
+        const int pn = dirB ? na : nb;
+        const int32_t id = oid[r];
+        int lo = 0, hi = pn;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (pid[mid] < id) lo = mid + 1;
+            else hi = mid;
+        }
+        const uint32_t pa = (uint32_t)oval[r], pbv = (lo < pn && pid[lo] == id) ? (uint32_t)pval[lo] : 0u;
+        unsigned long long k = ((unsigned long long)pa << 32) | pbv;
+        mykey[u] = k;
+        unsigned long long *tk = tabK + (dirB ? TS : 0);
+        uint32_t h = (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> (64 - ts_log2));
+        for (int probes = 0; probes < TS; ++probes) {            // ordered insert: the slot keeps the minimum
+            const unsigned long long old = atomicMin(&tk[h], k);
+            if (old == kPairEmpty || old == k) break;
+            k = old > k ? old : k;                               // the larger key moves on
+            h = (h + 1u) & tmask;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {                             // multiplicities: read-only probe, one add
+        const int t = tid + u * kPairThreads;
+        if (t >= na + nb) continue;
+        const bool dirB = t >= na;
+        const unsigned long long k = mykey[u];
+        const unsigned long long *tk = tabK + (dirB ? TS : 0);
+        uint32_t h = (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> (64 - ts_log2));
+        while (tk[h] != k) h = (h + 1u) & tmask;                 // present by construction
+        atomicAdd(&tabC[(dirB ? TS : 0) + h], 1);
+    }
+    __syncthreads();
+    // rows leave in table-slot order: per-thread run of consecutive slots, block-wide exclusive scan of the occupancy
+    const int per = TS / kPairThreads > 0 ? TS / kPairThreads : 1;
+    for (int dir = 0; dir < 2; ++dir) {
+        const unsigned long long *tk = tabK + dir * TS;
+        const int32_t *tc = tabC + dir * TS;
+        const int s0 = tid * per;
+        int mine = 0;
+        for (int x = s0; x < s0 + per && x < TS; ++x) mine += tk[x] != kPairEmpty;
+        int inc = mine;
+#pragma unroll
+        for (int dd = 1; dd < kWave; dd <<= 1) {
+            const int t2 = __shfl_up(inc, dd, kWave);
+            if ((tid & (kWave - 1)) >= dd) inc += t2;
+        }
+        if ((tid & (kWave - 1)) == kWave - 1) wsum[dir][tid / kWave] = inc;
+        __syncthreads();
+        int base = 0, total = 0;
+        for (int w2 = 0; w2 < kPairThreads / kWave; ++w2) {
+            if (w2 < tid / kWave) base += wsum[dir][w2];
+            total += wsum[dir][w2];
+        }
+        const int64_t jj = dir ? j2 : j;
+        if (tid == 0) out_cnt[jj] = total;
+        int64_t o = a.seg[jj] + base + inc - mine;
+        for (int x = s0; x < s0 + per && x < TS; ++x)
+            if (tk[x] != kPairEmpty) {
+                out_pairs[2 * o] = (int32_t)(tk[x] >> 32);
+                out_pairs[2 * o + 1] = (int32_t)(tk[x] & 0xFFFFFFFFu);
+                out_mult[o] = tc[x];
+                ++o;
+            }
+    }
+}
+
 }  // namespace subgacc
 
 using namespace subgacc;
@@ -561,6 +697,42 @@ extern "C" int subgacc_sjoin_counts(const int64_t *spg_indptr, int64_t n_rows, c
     SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_counts: too many segments in one call");
     hipLaunchKernelGGL(sjoin_counts_kernel, dim3((unsigned)grid), dim3(kPairThreads), lds, (hipStream_t)stream, a,
                        pair_block, out_counts);
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}
+
+extern "C" int subgacc_sjoin_pairs(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,
+                                   const int32_t *spg_data_i32, const int64_t *own, const int64_t *partner, int64_t S,
+                                   const int64_t *seg, int32_t *out_pairs, int32_t *out_mult, int32_t *out_cnt,
+                                   int32_t max_len, int64_t pair_block, int32_t *flags, void *stream) {
+    SG_REQUIRE(S >= 0 && max_len >= 0 && flags && n_rows >= 0, SUBGACC_ERR_BADARG, "sjoin_pairs: bad arguments");
+    if (S == 0) return SUBGACC_OK;
+    SG_REQUIRE(spg_indptr && spg_indices && spg_data_i32 && own && partner && seg && out_pairs && out_mult && out_cnt,
+               SUBGACC_ERR_BADARG, "sjoin_pairs: null argument");
+    SG_REQUIRE(pair_block > 0 && S % (2 * pair_block) == 0, SUBGACC_ERR_BADARG,
+               "sjoin_pairs: the segment list must be mirrored blocks (pair_block > 0, S a multiple of 2*pair_block)");
+    JoinArgs a;
+    a.indptr = spg_indptr, a.indices = spg_indices, a.data = spg_data_i32;
+    a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
+    a.table = nullptr, a.table_rows = 0, a.k = 0;
+    a.out_xz = nullptr, a.out_idx = nullptr, a.out_segid = nullptr;
+    a.max_len = max_len > 0 ? max_len : 1;
+    a.flags = flags;
+    a.row_len = nullptr, a.row_stride = 0, a.slot_id = nullptr, a.val_add = 0;
+    SG_REQUIRE(2 * (int64_t)a.max_len <= 8 * kPairThreads, SUBGACC_ERR_LDS,
+               "sjoin_pairs: rows of %d members are too long for the pair form (<= %d); use sjoin_fill", max_len,
+               4 * kPairThreads);
+    int ts_log2 = 6;                                           // distinct pairs of one block <= its row length
+    while ((1 << ts_log2) < a.max_len + a.max_len / 4 + 1) ++ts_log2;
+    const size_t lds = (size_t)2 * (1u << ts_log2) * 12 + (size_t)a.max_len * 16;
+    SG_REQUIRE(lds + 64 <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "sjoin_pairs: %zu B of LDS needed", lds);
+    if (lds > 64 * 1024)
+        SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds));
+    const int64_t grid = xcd_grid(S / 2);
+    SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_pairs: too many segments in one call");
+    hipLaunchKernelGGL(sjoin_pairs_kernel, dim3((unsigned)grid), dim3(kPairThreads), lds, (hipStream_t)stream, a,
+                       pair_block, ts_log2, out_pairs, out_mult, out_cnt);
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }

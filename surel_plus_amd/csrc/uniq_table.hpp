@@ -51,9 +51,10 @@ __device__ __forceinline__ int32_t uniq_global_insert(const UniqTable &t, unsign
         // atomicMin.  (Device-scope loads, the first version, leave the XCD for the fabric every time: two serial
         // ~2 us round trips per distinct LP row in every root's epilogue.)
         unsigned long long cur = t.keys[h];
+        const unsigned long long seen = t.mintag[h];   // asked for together with the key: one round trip, not two
         if (cur == kEmptyKey) cur = atomicCAS(&t.keys[h], kEmptyKey, key);
         if (cur == kEmptyKey || cur == key) {
-            if (t.mintag[h] > tag) atomicMin(&t.mintag[h], tag);
+            if (seen > tag) atomicMin(&t.mintag[h], tag);
             return (int32_t)h;
         }
         h = (h + 1) & t.mask;

@@ -80,9 +80,7 @@ __global__ void rng_positions_kernel(const int64_t *__restrict__ calls_excl, int
 #else
 #define SG_STAMP(k)
 #endif
-// REC: the graph is walked through its packed hop records (one dependent read per hop: the neighbour arrives with its
-// row begin and degree) instead of indices[] + indptr[] (two); same picks, same sets.
-template <bool IDX64, int RNG, bool SPG, bool REC>
+template <bool IDX64, int RNG, bool SPG>
 __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) void walk_sets_kernel(const WalkArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
 #if SG_EXPERIMENT == 7
@@ -110,6 +108,16 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
     const int tid = threadIdx.x;
     const int M = a.M, m = a.m, T = a.T;
     const int32_t root = a.query[i];
+    // while the root's two dependent loads (query -> row pointer) are in flight: clear what does not depend on them
+    for (int h = tid; h < T; h += kWalkThreads) pk[h] = 0ull;
+    for (int x = tid; x < a.nwords; x += kWalkThreads) bitmap[x] = 0u;
+    if (SPG) {
+        for (int s2 = tid; s2 < kSpgFold; s2 += kWalkThreads) {
+            fk[s2] = kEmptyKey;
+            ft[s2] = 0xFFFFFFFFu;
+        }
+        if (tid < 16) red[tid] = tid < 4 ? 0x7FFFFFFF : 0;   // [0..3] min id per wave, [4..7] max id, [8] member count
+    }
     if ((uint64_t)(int64_t)root >= (uint64_t)a.num_nodes) {   // the reference would read out of bounds here (no checks)
         if (tid == 0) {
             atomicOr(&a.flags[3], 16);
@@ -119,7 +127,14 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
     }
     int64_t rbeg, rdeg64;
     load_row<IDX64>(a.indptr, root, rbeg, rdeg64);
-    const int64_t rdeg_full = rdeg64;   // NEBMAX caps the root's first hop only (subg_acc.c:750)
+    {   // keys / minq, with the root already in its slot as member 0 (q = 0): no separate insert phase
+        const uint32_t hroot = ((uint32_t)root * 2654435761u) >> a.tshift;
+        for (int h = tid; h < T; h += kWalkThreads) {
+            const bool isroot = (uint32_t)h == hroot;
+            keys[h] = isroot ? root : -1;
+            minq[h] = isroot ? 0u : 0xFFFFFFFFu;
+        }
+    }
     if (a.cap_root && rdeg64 > kNeighCap) rdeg64 = kNeighCap;
     const int64_t obase = i * (int64_t)a.stride;
     const unsigned long long lead = 1ull << (m * a.shift);
@@ -136,20 +151,6 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
         if (a.walks)
             for (int x = tid; x < M * (m + 1); x += kWalkThreads) a.walks[i * (int64_t)M * (m + 1) + x] = root;
         return;
-    }
-
-    for (int h = tid; h < T; h += kWalkThreads) {
-        keys[h] = -1;
-        minq[h] = 0xFFFFFFFFu;
-        pk[h] = 0ull;
-    }
-    for (int x = tid; x < a.nwords; x += kWalkThreads) bitmap[x] = 0u;
-    if (SPG) {
-        for (int s2 = tid; s2 < kSpgFold; s2 += kWalkThreads) {
-            fk[s2] = kEmptyKey;
-            ft[s2] = 0xFFFFFFFFu;
-        }
-        if (tid < 16) red[tid] = tid < 4 ? 0x7FFFFFFF : 0;   // [0..3] min id per wave, [4..7] max id, [8] member count
     }
 
     uint32_t rpos = 0, rseed = a.seed;
@@ -175,12 +176,6 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
     }
     __syncthreads();
     SG_STAMP(0);
-    if (tid == 0) {  // the root is member 0 (q = 0)
-        const uint32_t h = ((uint32_t)root * 2654435761u) >> a.tshift;
-        keys[h] = root;
-        minq[h] = 0u;
-    }
-    __syncthreads();
     SG_STAMP(1);
 
     const uint32_t tmask = (uint32_t)T - 1u;
@@ -197,7 +192,6 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
         }
         int32_t *wrow = a.walks ? a.walks + (i * (int64_t)M + w) * (m + 1) : nullptr;
         if (wrow) wrow[0] = root;
-        int64_t cb = rbeg, cd = rdeg_full;   // REC: row (begin, degree) of the node the walk stands on
         for (int s = 0; s < m; ++s) {
             if (s == 0 && a.wo) {
                 uint32_t pick;
@@ -211,12 +205,10 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
                 } else {
                     pick = (uint32_t)w % rdeg;
                 }
-                if (REC) {
-                    bool esc;
-                    rec_unpack(a.recs[rbeg + pick], a.rec, cur, cb, cd, esc);
-                    if (esc && m > 1) load_row<IDX64>(a.indptr, cur, cb, cd);
-                } else {
-                    cur = SG_NEIGH_LOAD(&a.indices[rbeg + pick]);
+                cur = SG_NEIGH_LOAD(&a.indices[rbeg + pick]);
+                if (RNG == SUBGACC_RNG_PHILOX && m > 1) {   // the draws of hops 2.. while that load is in flight
+                    ph_blk = 0;
+                    philox4x32_10((uint32_t)root, (uint32_t)w, 0u, 0u, a.seed, kPhiloxKey1, ph);
                 }
             } else {
 #if SG_EXPERIMENT == 2   // dedup only: no graph reads after the first hop (timing experiment, results are wrong)
@@ -228,8 +220,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
                 b = ((int64_t)(uint32_t)cur * 21) % 62000000;
                 d = 20;
 #else
-                if (REC) b = cb, d = cd;
-                else load_row<IDX64>(a.indptr, cur, b, d);
+                load_row<IDX64>(a.indptr, cur, b, d);
 #endif
                 if (d > 0) {
                     uint32_t r;
@@ -244,13 +235,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
                         }
                         r = ph[idx & 3];
                     }
-                    if (REC) {
-                        bool esc;
-                        rec_unpack(a.recs[b + (int64_t)(r % (uint32_t)d)], a.rec, cur, cb, cd, esc);
-                        if (esc && s + 1 < m) load_row<IDX64>(a.indptr, cur, cb, cd);
-                    } else {
-                        cur = SG_NEIGH_LOAD(&a.indices[b + (int64_t)(r % (uint32_t)d)]);
-                    }
+                    cur = SG_NEIGH_LOAD(&a.indices[b + (int64_t)(r % (uint32_t)d)]);
                 } else if (RNG == SUBGACC_RNG_RAND_R) {
                     atomicOr(&a.flags[0], 1);  // dead end: the sequential stream is no longer reproducible
                 }
@@ -372,7 +357,9 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
                 unsigned long long cur = fk[f];
                 if (cur == kEmptyKey) cur = atomicCAS(&fk[f], kEmptyKey, key);
                 if (cur == kEmptyKey || cur == key) {
-                    atomicMin(&ft[f], tagoff);
+                    // a few dozen distinct keys per set: most lanes meet a tag that is already smaller, and a plain
+                    // read (it can only be stale towards larger values) spares the same-address atomic storm
+                    if (ft[f] > tagoff) atomicMin(&ft[f], tagoff);
                     slv[u] = -2 - (int32_t)f;   // resolved to the HBM slot after the fold table is flushed
                     done = true;
                     break;
@@ -422,25 +409,24 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
     }
     __syncthreads();
     SG_STAMP(5);
-    if (tid < kWave) {   // exclusive scan over the <= 256 buckets by one wave: 4 consecutive buckets per lane
-        const int per = (B + kWave - 1) / kWave;
-        const int b0 = tid * per;
-        int32_t sum = 0;
-        for (int b = b0; b < b0 + per && b < B; ++b) sum += cursor[b];
-        int32_t inc = sum;
+    {   // exclusive scan over the B <= 256 buckets, one bucket per lane: wave scan, then the wave totals through LDS
+        const int32_t c = tid < B ? cursor[tid] : 0;
+        int32_t inc = c;
 #pragma unroll
         for (int dd = 1; dd < kWave; dd <<= 1) {
             const int32_t t2 = __shfl_up(inc, dd, kWave);
-            if (tid >= dd) inc += t2;
+            if ((tid & (kWave - 1)) >= dd) inc += t2;
         }
-        int32_t run = inc - sum;
-        for (int b = b0; b < b0 + per && b < B; ++b) {
-            const int32_t c = cursor[b];
-            start[b] = run;
-            cursor[b] = run;
-            run += c;
+        if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc;
+        __syncthreads();
+        int32_t base = 0;
+        for (int w2 = 0; w2 < tid / kWave; ++w2) base += red[12 + w2];
+        const int32_t excl = base + inc - c;
+        if (tid < B) {
+            start[tid] = excl;
+            cursor[tid] = excl;
         }
-        if (tid == kWave - 1) start[B] = inc;
+        if (tid == B - 1) start[B] = excl + c;
     }
     __syncthreads();
     SG_STAMP(6);
@@ -659,15 +645,6 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
     a.set_slot = set_slot;
     a.table = spg ? uniq_view(uniq_table, uniq_capacity) : UniqTable{nullptr, nullptr, nullptr, 0};
     a.root_base = root_base;
-    a.recs = nullptr, a.rec = RecFmt{0, 0};
-    if (cfg->hop_records && !cfg->indptr64) {
-        SG_REQUIRE(cfg->rec_id_bits > 0 && cfg->rec_beg_bits > 0 && cfg->rec_id_bits <= 32 &&
-                       cfg->rec_id_bits + cfg->rec_beg_bits <= 60,
-                   SUBGACC_ERR_BADARG, "walk: hop_records given with field widths %d / %d (subgacc_hop_records_layout)",
-                   cfg->rec_id_bits, cfg->rec_beg_bits);
-        a.recs = (const unsigned long long *)cfg->hop_records;
-        a.rec = RecFmt{cfg->rec_id_bits, cfg->rec_beg_bits};
-    }
     SG_REQUIRE(a.T <= 65536, SUBGACC_ERR_LDS, "walk: M*m+1 = %d is too large for the per-root LDS tables", Q);
     // SUBGACC_LDS_PAD (dev-only): extra dynamic LDS per workgroup, i.e. fewer resident workgroups per CU -- the
     // occupancy response of the kernel (tools/README.md)
@@ -685,82 +662,28 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
     }
     const int64_t grid = xcd_grid(n);
     SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "walk: chunk of %lld roots too large, split it", (long long)n);
-#define SG_WALK_LAUNCH(I64, RNGM, SPGM, RECM)                                                                     \
+#define SG_WALK_LAUNCH(I64, RNGM, SPGM)                                                                           \
     do {                                                                                                          \
         if (lds > 64 * 1024)                                                                                      \
-            SG_CHECK_HIP(hipFuncSetAttribute((const void *)walk_sets_kernel<I64, RNGM, SPGM, RECM>,               \
+            SG_CHECK_HIP(hipFuncSetAttribute((const void *)walk_sets_kernel<I64, RNGM, SPGM>,                     \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
-        hipLaunchKernelGGL((walk_sets_kernel<I64, RNGM, SPGM, RECM>), dim3((unsigned)grid), dim3(kWalkThreads),   \
-                           lds, s, a);                                                                            \
+        hipLaunchKernelGGL((walk_sets_kernel<I64, RNGM, SPGM>), dim3((unsigned)grid), dim3(kWalkThreads), lds, s, \
+                           a);                                                                                    \
     } while (0)
-#define SG_WALK_RNG(I64, SPGM, RECM)                                                                              \
+#define SG_WALK_RNG(I64, SPGM)                                                                                    \
     do {                                                                                                          \
-        if (cfg->rng_mode == SUBGACC_RNG_RAND_R) SG_WALK_LAUNCH(I64, SUBGACC_RNG_RAND_R, SPGM, RECM);             \
-        else SG_WALK_LAUNCH(I64, SUBGACC_RNG_PHILOX, SPGM, RECM);                                                 \
+        if (cfg->rng_mode == SUBGACC_RNG_RAND_R) SG_WALK_LAUNCH(I64, SUBGACC_RNG_RAND_R, SPGM);                   \
+        else SG_WALK_LAUNCH(I64, SUBGACC_RNG_PHILOX, SPGM);                                                       \
     } while (0)
-    if (cfg->indptr64) {          // graphs with 64-bit row offsets are not packed (subgacc_hop_records_layout)
-        if (spg) SG_WALK_RNG(true, true, false);
-        else SG_WALK_RNG(true, false, false);
-    } else if (a.recs) {
-        if (spg) SG_WALK_RNG(false, true, true);
-        else SG_WALK_RNG(false, false, true);
+    if (cfg->indptr64) {
+        if (spg) SG_WALK_RNG(true, true);
+        else SG_WALK_RNG(true, false);
     } else {
-        if (spg) SG_WALK_RNG(false, true, false);
-        else SG_WALK_RNG(false, false, false);
+        if (spg) SG_WALK_RNG(false, true);
+        else SG_WALK_RNG(false, false);
     }
 #undef SG_WALK_RNG
 #undef SG_WALK_LAUNCH
-    SG_LAUNCH_CHECK();
-    return SUBGACC_OK;
-}
-
-// ------------------------------------------------------------------------------ packed hop records
-namespace subgacc {
-template <bool IDX64>
-__global__ void hop_records_kernel(const void *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t nnz,
-                                   int64_t num_nodes, RecFmt f, unsigned long long *__restrict__ out) {
-    const int deg_bits = 64 - f.id_bits - f.beg_bits;
-    const unsigned long long dmask = (1ull << deg_bits) - 1ull;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t v = indices[e];
-        int64_t beg = 0, deg = 0;
-        if ((uint64_t)(int64_t)v < (uint64_t)num_nodes) load_row<IDX64>(indptr, v, beg, deg);
-        const unsigned long long d = (unsigned long long)deg >= dmask ? dmask : (unsigned long long)deg;
-        out[e] = ((unsigned long long)(uint32_t)v << (64 - f.id_bits)) | ((unsigned long long)beg << deg_bits) | d;
-    }
-}
-}  // namespace subgacc
-
-extern "C" int subgacc_hop_records_layout(int64_t num_nodes, int64_t nnz, int32_t *id_bits, int32_t *beg_bits) {
-    SG_REQUIRE(num_nodes >= 0 && nnz >= 0 && id_bits && beg_bits, SUBGACC_ERR_BADARG, "hop_records_layout: bad arguments");
-    int ib = 1, bb = 1;
-    while (ib < 32 && (1ll << ib) < num_nodes) ++ib;
-    while (bb < 62 && (1ll << bb) <= nnz) ++bb;
-    *id_bits = ib, *beg_bits = bb;
-    const int db = 64 - ib - bb;
-    return db >= 12 ? db : 0;
-}
-
-extern "C" int subgacc_hop_records_build(const void *indptr, int32_t indptr64, const int32_t *indices, int64_t num_nodes,
-                                         int64_t nnz, int32_t id_bits, int32_t beg_bits, uint64_t *out_records,
-                                         void *stream) {
-    SG_REQUIRE(num_nodes >= 0 && nnz >= 0, SUBGACC_ERR_BADARG, "hop_records_build: negative size");
-    int32_t ib, bb;
-    subgacc_hop_records_layout(num_nodes, nnz, &ib, &bb);
-    // wider id / offset fields than the minimal layout are fine (a narrower degree field only means more look-ups)
-    SG_REQUIRE(id_bits >= ib && id_bits <= 32 && beg_bits >= bb && id_bits + beg_bits <= 60, SUBGACC_ERR_BADARG,
-               "hop_records_build: widths %d / %d cannot hold this graph (needs >= %d / %d, at least 4 bits left)", id_bits,
-               beg_bits, ib, bb);
-    if (nnz == 0) return SUBGACC_OK;
-    SG_REQUIRE(indptr && indices && out_records, SUBGACC_ERR_BADARG, "hop_records_build: null argument");
-    const RecFmt f{id_bits, beg_bits};
-    const unsigned grid = (unsigned)(ceil_div(nnz, 256) < 65536 ? ceil_div(nnz, 256) : 65536);
-    if (indptr64)
-        hipLaunchKernelGGL(hop_records_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, indptr, indices, nnz,
-                           num_nodes, f, (unsigned long long *)out_records);
-    else
-        hipLaunchKernelGGL(hop_records_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, indptr, indices, nnz,
-                           num_nodes, f, (unsigned long long *)out_records);
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }

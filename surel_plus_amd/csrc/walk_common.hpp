@@ -74,22 +74,6 @@ __device__ __forceinline__ void load_row(const void *indptr, int32_t node, int64
     }
 }
 
-// ------------------------------------------------------------------- packed hop records (subgacc_hop_records_build)
-// rec = [id : id_bits | row begin : beg_bits | degree : deg_bits], deg_bits = 64 - id_bits - beg_bits; a degree of
-// all-ones means "does not fit": the walk reads indptr for that node.
-struct RecFmt {
-    int32_t id_bits, beg_bits;
-};
-__device__ __forceinline__ void rec_unpack(unsigned long long r, const RecFmt &f, int32_t &id, int64_t &beg, int64_t &deg,
-                                           bool &escaped) {
-    const int deg_bits = 64 - f.id_bits - f.beg_bits;
-    const unsigned long long dmask = (1ull << deg_bits) - 1ull;
-    id = (int32_t)(r >> (64 - f.id_bits));
-    beg = (int64_t)((r >> deg_bits) & ((1ull << f.beg_bits) - 1ull));
-    deg = (int64_t)(r & dmask);
-    escaped = (r & dmask) == dmask;
-}
-
 struct WalkArgs {
     const void *indptr;
     const int32_t *indices;
@@ -111,8 +95,6 @@ struct WalkArgs {
     int32_t *set_slot;
     UniqTable table;
     int64_t root_base;   // global index of query[0]: tags (root_base+i)*stride + rank order the first occurrences
-    const unsigned long long *recs;   // packed hop records (REC kernels), else NULL
-    RecFmt rec;
 };
 
 constexpr int kSpgFold = 128;      // block-local table of the set's distinct LP keys

@@ -25,7 +25,7 @@
 
 namespace subgacc {
 
-template <bool IDX64, int RNG, int MH, bool REC>
+template <bool IDX64, int RNG, int MH>
 __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) void walk_pipe_kernel(const WalkArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     unsigned long long *pk = (unsigned long long *)lds_raw;     // [T]
@@ -61,8 +61,6 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
     uint32_t xB = 0, phB[4];
     int32_t pendN = 0;            // node whose load is in flight
     int64_t pendB = 0, pendD = 0; // row (begin, degree) whose load is in flight
-    unsigned long long pendR = 0; // REC: the hop record in flight (node, row begin and degree in one word)
-    bool pendRec = false;         // REC: pendR holds a record (false after a dead end: the walk stays where it is)
 #pragma unroll
     for (int s = 0; s < MH; ++s) visB[s] = 0;
 
@@ -114,26 +112,11 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
             }
             if (RNG == SUBGACC_RNG_RAND_R)
                 xB = lcg_jump(rseedB, rposB + 3u * ((shufB ? (uint32_t)M : 0u) + (uint32_t)tid * (uint32_t)(MH - 1)));
-            if (REC) {
-                pendR = a.recs[rbegB + pick];
-                pendRec = true;
-            } else {
-                pendN = SG_NEIGH_LOAD(&a.indices[rbegB + pick]);
-            }
+            pendN = SG_NEIGH_LOAD(&a.indices[rbegB + pick]);
         } else if constexpr (J % 2 == 1) {
             constexpr int hop = (J - 1) / 2;          // 0-based hop whose node just arrived
-            if (REC) {
-                if (pendRec) {                        // the record brings the node's row along: no second read
-                    bool esc;
-                    rec_unpack(pendR, a.rec, pendN, pendB, pendD, esc);
-                    if constexpr (hop + 1 < MH)
-                        if (esc) load_row<IDX64>(a.indptr, pendN, pendB, pendD);
-                }
-                visB[hop] = pendN;
-            } else {
-                visB[hop] = pendN;
-                if constexpr (hop + 1 < MH) load_row<IDX64>(a.indptr, pendN, pendB, pendD);
-            }
+            visB[hop] = pendN;
+            if constexpr (hop + 1 < MH) load_row<IDX64>(a.indptr, pendN, pendB, pendD);
         } else {
             constexpr int hop = J / 2;                // hop being taken now (1-based index into the RNG stream - 1)
             if (pendD > 0) {
@@ -146,14 +129,8 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
                         philox4x32_10((uint32_t)rootB, (uint32_t)tid, (uint32_t)(idx >> 2), 0u, a.seed, kPhiloxKey1, phB);
                     r = phB[idx & 3];
                 }
-                if (REC) {
-                    pendR = a.recs[pendB + (int64_t)(r % (uint32_t)pendD)];
-                    pendRec = true;
-                } else {
-                    pendN = SG_NEIGH_LOAD(&a.indices[pendB + (int64_t)(r % (uint32_t)pendD)]);
-                }
+                pendN = SG_NEIGH_LOAD(&a.indices[pendB + (int64_t)(r % (uint32_t)pendD)]);
             } else {
-                pendRec = false;
                 pendN = visB[hop - 1];                // dead end: stay (the rand_r stream is then not reproducible)
                 if (RNG == SUBGACC_RNG_RAND_R) atomicOr(&a.flags[0], 1);
             }
@@ -290,16 +267,16 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
 #undef SG_BSTEP
 }
 
-template <bool IDX64, int RNG, bool REC>
+template <bool IDX64, int RNG>
 static int launch_hops(const WalkArgs &a, size_t lds, int grid, hipStream_t s) {
 #define SG_PIPE(MHH)                                                                                              \
     case MHH: {                                                                                                   \
         if (lds > 64 * 1024 &&                                                                                    \
-            hipFuncSetAttribute((const void *)walk_pipe_kernel<IDX64, RNG, MHH, REC>,                             \
+            hipFuncSetAttribute((const void *)walk_pipe_kernel<IDX64, RNG, MHH>,                                  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)              \
             return 0;                                                                                             \
-        hipLaunchKernelGGL((walk_pipe_kernel<IDX64, RNG, MHH, REC>), dim3((unsigned)grid), dim3(kWalkThreads),    \
-                           lds, s, a);                                                                            \
+        hipLaunchKernelGGL((walk_pipe_kernel<IDX64, RNG, MHH>), dim3((unsigned)grid), dim3(kWalkThreads), lds, s, \
+                           a);                                                                                    \
         return 1;                                                                                                 \
     }
     switch (a.m) {
@@ -326,13 +303,10 @@ int launch_walk_pipe(const WalkArgs &a, bool indptr64, int rng_mode, bool spg, s
     if (grid > a.n) grid = a.n;
     const bool rr = rng_mode == SUBGACC_RNG_RAND_R;
     if (indptr64)
-        return rr ? launch_hops<true, SUBGACC_RNG_RAND_R, false>(a, lds, (int)grid, s)
-                  : launch_hops<true, SUBGACC_RNG_PHILOX, false>(a, lds, (int)grid, s);
-    if (a.recs)
-        return rr ? launch_hops<false, SUBGACC_RNG_RAND_R, true>(a, lds, (int)grid, s)
-                  : launch_hops<false, SUBGACC_RNG_PHILOX, true>(a, lds, (int)grid, s);
-    return rr ? launch_hops<false, SUBGACC_RNG_RAND_R, false>(a, lds, (int)grid, s)
-              : launch_hops<false, SUBGACC_RNG_PHILOX, false>(a, lds, (int)grid, s);
+        return rr ? launch_hops<true, SUBGACC_RNG_RAND_R>(a, lds, (int)grid, s)
+                  : launch_hops<true, SUBGACC_RNG_PHILOX>(a, lds, (int)grid, s);
+    return rr ? launch_hops<false, SUBGACC_RNG_RAND_R>(a, lds, (int)grid, s)
+              : launch_hops<false, SUBGACC_RNG_PHILOX>(a, lds, (int)grid, s);
 }
 
 }  // namespace subgacc

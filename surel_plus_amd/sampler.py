@@ -61,7 +61,6 @@ class DeviceCSR:
         self.indptr64 = self.indptr.dtype == torch.int64
         self.num_nodes = self.indptr.numel() - 1
         self.device = self.indptr.device
-        self._recs = False           # hop records: not built yet
         if self.indptr.dim() != 1 or self.indices.dim() != 1 or self.num_nodes < 0:
             raise TypeError("Input parsing error. (indptr / indices must be 1-D, indptr non-empty)")
         if validate:
@@ -80,27 +79,6 @@ class DeviceCSR:
     @property
     def nnz(self):
         return self.indices.numel()
-
-    def hop_records(self):
-        """Packed hop records of this graph (include/subgacc.h: subgacc_hop_records_build), built on first use and kept
-        with the graph: 8 B per adjacency entry, (neighbour, its row begin, its degree) in one word, so that a walk
-        step is ONE dependent read.  Returns (int64 tensor [nnz], id_bits, beg_bits) or None when the graph does not
-        pack (64-bit row offsets / fewer than 12 bits left for the degree) or SUBGACC_HOP_RECORDS=0."""
-        if self._recs is False:
-            import ctypes as C
-            import os
-            self._recs = None
-            ib, bb = C.c_int32(0), C.c_int32(0)
-            if os.environ.get("SUBGACC_HOP_RECORDS", "1") != "0" and not self.indptr64 and self.nnz > 0 and self.indices.is_cuda \
-                    and lib().subgacc_hop_records_layout(self.num_nodes, self.nnz, C.byref(ib), C.byref(bb)) > 0:
-                forced = int(os.environ.get("SUBGACC_REC_DEG_BITS", "0"))     # tests: a narrow degree field (escapes)
-                if forced:
-                    bb = C.c_int32(64 - ib.value - forced)
-                recs = torch.empty(self.nnz, dtype=torch.int64, device=self.device)
-                check(lib().subgacc_hop_records_build(ptr(self.indptr), 0, ptr(self.indices), self.num_nodes, self.nnz,
-                                                      ib.value, bb.value, ptr(recs), stream_ptr()))
-                self._recs = (recs, ib.value, bb.value)
-        return self._recs
 
 
 @dataclass
@@ -246,15 +224,13 @@ class SampledSets:
 
 
 def make_cfg(csr, num_walks, num_steps, bucket=-1, seed=111413, rng="rand_r", first_hop_wo=True,
-             order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False, hop_records=True):
+             order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False):
     rng_mode = {"rand_r": _lib.RNG_RAND_R, "philox": _lib.RNG_PHILOX}[rng]
     if num_walks <= 0 or num_steps <= 0:
         raise TypeError("Input parsing error. (num_walks and num_steps must be positive)")
-    recs = csr.hop_records() if (hop_records and csr.indices.is_cuda) else None
     return WalkCfg(int(num_walks), int(num_steps), int(bucket), rng_mode, int(seed) & 0xFFFFFFFF,
                    1 if first_hop_wo else 0, int(order), 1 if cap_root_degree else 0,
-                   1 if csr.indptr64 else 0, 1 if emit_walks else 0,
-                   recs[0].data_ptr() if recs else None, recs[1] if recs else 0, recs[2] if recs else 0)
+                   1 if csr.indptr64 else 0, 1 if emit_walks else 0)
 
 
 def _as_query(query, device):
@@ -300,7 +276,7 @@ def _cat(parts, dtype, dev):
 def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, rng="rand_r", first_hop_wo=True,
                 order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False, rng_streams=1,
                 calls_before=0, dedup=True, keep_keys=None, staging_bytes=STAGING_BYTES, uniq_capacity=UNIQ_CAPACITY,
-                uniq_small_limit=0, fused_rows=False, lazy=False, strided=False, hop_records=True):
+                uniq_small_limit=0, fused_rows=False, lazy=False, strided=False):
     """Run the sampler for `query` (roots) on the GPU.  See SampledSets.
 
     dedup=True numbers the distinct LP rows (ukeys, slot / get_sf()); the packed keys are then only kept when
@@ -314,8 +290,7 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     dev = csr.device
     q = _as_query(query, dev)
     n = q.numel()
-    cfg = make_cfg(csr, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order, cap_root_degree, emit_walks,
-                   hop_records)
+    cfg = make_cfg(csr, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order, cap_root_degree, emit_walks)
     check(L.subgacc_key_shift(cfg.num_walks, cfg.num_steps))   # AssertionError like subg_acc.c:911-915
     M, m = cfg.num_walks, cfg.num_steps
     stride = bucket if bucket > 0 else M * m + 1
@@ -386,8 +361,7 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
                 if st_host[2]:                    # the table of distinct LP rows overflowed: walk again with a larger one
                     return sample_sets(csr, q, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order,
                                        cap_root_degree, emit_walks, rng_streams, calls_before, dedup, keep_keys,
-                                       staging_bytes, uniq_capacity * 4, uniq_small_limit, fused_rows, lazy, strided,
-                                       hop_records)
+                                       staging_bytes, uniq_capacity * 4, uniq_small_limit, fused_rows, lazy, strided)
                 if st_host[4] > max_unique:       # more distinct rows than the direct ranking numbers: the caller
                     return None                   # (sample_spg) falls through to the packed forms
                 sets.resolve()
@@ -464,7 +438,7 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     if st_host[2]:
         return sample_sets(csr, q, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order, cap_root_degree,
                            emit_walks, rng_streams, calls_before, dedup, keep_keys, staging_bytes, uniq_capacity * 4,
-                           uniq_small_limit, fused_rows, lazy, strided, hop_records)
+                           uniq_small_limit, fused_rows, lazy, strided)
     sets.resolve()
     sets.ukeys = sets.ukeys.clone()
     return sets

@@ -306,3 +306,73 @@ def mean_stage(edge, x, encode, embed):
     C, sizes = gather_counts(edge, spg, table.shape[0])
     out = (C @ embed(table)) / sizes.clamp(min=1).to(torch.float32)[:, None]
     return out.view(2, -1, out.shape[-1])
+
+
+def gather_pairs(edge, x, device=None):
+    """Pair form of gather() (include/subgacc.h: subgacc_sjoin_pairs): every segment as its DISTINCT index pairs with
+    multiplicities -- (pairs int32 [R', 2], mult int32 [R'], indptr int64 [2B+1]), segments in gather()'s order (left
+    blocks, then right blocks).  pairs[r] = (SFptr+1 of a member in its own row, in the partner row or 0): the row
+    gather() would have emitted is encode[pairs[r]] and it occurs mult[r] times in its segment, so for a first model
+    stage of the form f(xz).sum(-2) = f(encode)[pa] + f(encode)[pb] (model.py:78) any aggregation that is a weighted
+    function of the rows -- mean, the attention gate of model.py:59-62 -- is exact over these rows with `mult` as
+    weights, at ~1/10 of the rows (a set of ~400 members carries a few dozen distinct LP rows)."""
+    spg = _as_spg(x)
+    if isinstance(spg, StridedSpG):
+        spg = spg.to_csr()
+    if spg.data.dtype != torch.int32:
+        raise TypeError("gather_pairs needs an SFptr (integer) SpG")
+    L, dev, st = lib(), spg.device, stream_ptr()
+    e = _as_rows(edge, dev)
+    B = e.shape[1]
+    own = torch.cat([e[0], e[1]]).contiguous()
+    partner = torch.cat([e[1], e[0]]).contiguous()
+    S = 2 * B
+    seg = torch.empty(S + 1, dtype=torch.int64, device=dev)
+    ws = torch.empty(L.subgacc_sjoin_workspace_bytes(S), dtype=torch.uint8, device=dev)
+    flags = torch.zeros(4, dtype=torch.int32, device=dev)
+    check(L.subgacc_sjoin_sizes(ptr(spg.indptr), spg.n_rows, ptr(own), ptr(partner), S, ptr(seg), ptr(flags), ptr(ws),
+                                ws.numel(), st))
+    R = _size_and_row_check(seg, S, flags, spg.n_rows)
+    pairs = torch.empty((R, 2), dtype=torch.int32, device=dev)
+    mult = torch.empty(R, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(S, dtype=torch.int32, device=dev)
+    with _timed("sjoin_pairs"):
+        check(L.subgacc_sjoin_pairs(ptr(spg.indptr), spg.n_rows, ptr(spg.indices), ptr(spg.data), ptr(own), ptr(partner), S,
+                                    ptr(seg), ptr(pairs), ptr(mult), ptr(cnt), spg.max_len, B, ptr(flags), st))
+    # rows of segment j sit at [seg[j], seg[j] + cnt[j]): close the gaps (R' ~ R/10 elements from here on)
+    indptr = torch.zeros(S + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(cnt, 0, out=indptr[1:])
+    Rc = int(indptr[-1].item())
+    segid = torch.repeat_interleave(torch.arange(S, device=dev), cnt.long(), output_size=Rc)
+    src = seg[:-1][segid] + (torch.arange(Rc, device=dev) - indptr[:-1][segid])
+    _checked(pairs, indptr, flags)
+    return pairs[src], mult[src], indptr
+
+
+def attn_stage(edge, x, encode, embed, gate_nn, value_nn=None):
+    """The reference's first model stage for --aggr attn, fused over the pair form of the join:  model.py:59-62,78-81
+        x = pe_embedding(xz).sum(dim=-2)
+        xl, xr = AttentionalAggregation(gate_nn, nn)(x, ptr=ptr).view(2, -1, H)
+              = segment_sum(softmax_segment(gate_nn(x)) * nn(x))
+    A row's x is e[pa] + e[pb] with e = embed(encode) ([c+1, H], tiny): gate and value are evaluated once per DISTINCT
+    pair of a segment and the softmax / weighted sum carry the multiplicities -- exact (up to fp32 summation order),
+    ~10x fewer rows than xz, and autograd reaches embed / gate_nn / value_nn through ordinary torch ops.
+    Returns float32 [2, B, H'] (left endpoints, right endpoints); empty segments give zero rows (as PyG's do)."""
+    table = encode if torch.is_tensor(encode) else torch.as_tensor(encode)
+    spg = _as_spg(x)
+    table = table.to(device=spg.device, dtype=torch.float32)
+    pairs, mult, indptr = gather_pairs(edge, spg)
+    if pairs.numel() and int(pairs.max().item()) >= table.shape[0]:
+        raise IndexError(f"index {int(pairs.max().item())} is out of bounds for the encode table with {table.shape[0]} rows")
+    S = indptr.numel() - 1
+    e = embed(table)
+    xr = e[pairs[:, 0].long()] + e[pairs[:, 1].long()]
+    g = gate_nn(xr).reshape(-1)
+    v = value_nn(xr) if value_nn is not None else xr
+    seg = torch.repeat_interleave(torch.arange(S, device=spg.device), indptr[1:] - indptr[:-1], output_size=pairs.shape[0])
+    gmax = torch.full((S,), float("-inf"), device=g.device, dtype=g.dtype).scatter_reduce(0, seg, g.detach(), "amax")
+    w = mult.to(g.dtype) * torch.exp(g - gmax[seg])                 # softmax numerators, with multiplicity
+    den = torch.zeros(S, device=g.device, dtype=g.dtype).index_add_(0, seg, w)
+    num = torch.zeros((S, v.shape[-1]), device=g.device, dtype=v.dtype).index_add_(0, seg, w[:, None] * v)
+    out = num / (den + 1e-16)[:, None]                              # torch_geometric.utils.softmax adds the same 1e-16
+    return out.view(2, -1, out.shape[-1])

@@ -1,0 +1,69 @@
+"""One step of the on-demand path (sample both endpoints of B pairs -> SpG rows -> SpJoin) captured as ONE HIP graph.
+
+The reference's online loop runs batches of 1,024 pairs (main.py:32, train.py:120-127).  At that size the GPU work of
+a step (tens of microseconds) is smaller than the cost of launching its ~25 kernels one by one, so the step is
+captured once for a fixed (B, M, m) -- the C ABI allocates nothing and never synchronises (include/subgacc.h), torch's
+allocator serves a capture from a private pool -- and replayed with new pairs copied into a static input buffer.
+Sizes and status flags stay on the device during the replay (the lazy forms of sampler / spjoin); finish() reads them
+back in one small copy.  Results are the ones the eager path gives (tests/test_gpu_parity.py).
+
+Philox streams are keyed by (seed, root id, walk, step) and the seed is baked into the captured launches: a root's set
+is the same in every replay -- the semantics of the reference's offline stage, where every node's set is sampled once
+and joined in every epoch (main.py:172-178).
+"""
+import torch
+
+from . import _lib
+from .sampler import check_walk_flags
+from .spjoin import sample_and_gather
+
+
+class CapturedStep:
+    def __init__(self, csr, pairs, num_walks=200, num_steps=3, seed=111413, rng="philox", uniq_capacity=1 << 17,
+                 strided=None, fused=None, warmup=2):
+        """pairs = B, the fixed number of query pairs per step; num_steps = walk hops."""
+        self.csr, self.B, self.M, self.m = csr, int(pairs), int(num_walks), int(num_steps)
+        dev = csr.device
+        self.edge = torch.zeros((2, self.B), dtype=torch.int64, device=dev)
+        self.out = torch.empty(2 * self.B * (self.M * self.m + 1) * 2 * (self.m + 1), dtype=torch.float32, device=dev)
+        self._kw = dict(num_walks=self.M, num_steps=self.m, seed=seed, rng=rng, out=self.out, lazy=True, strided=strided,
+                        fused=fused, uniq_capacity=uniq_capacity)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                   # allocator steady state + lazy code-object loads, uncaptured
+            for _ in range(max(int(warmup), 1)):
+                self._queue()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.xz, self.ind, self.sets = self._queue()
+            # flags[4], distinct LP rows, set members, join rows: everything finish() needs, in one device tensor
+            self.status = torch.cat([self.sets.status, self.ind[-1:]])
+        self._host = torch.empty(self.status.numel(), dtype=torch.int64, pin_memory=True)
+        self._event = torch.cuda.Event()
+
+    def _queue(self):
+        return sample_and_gather(self.csr, self.edge, **self._kw)
+
+    def __call__(self, edge):
+        """queue one step for `edge` [2, B] (node ids, on the device): copy-in, graph replay, status on its way to
+        pinned host memory.  Nothing waits for the GPU here."""
+        if tuple(edge.shape) != (2, self.B):
+            raise ValueError(f"this step was captured for [2, {self.B}] pairs")
+        self.edge.copy_(edge, non_blocking=True)
+        self.graph.replay()
+        self._host.copy_(self.status, non_blocking=True)
+        self._event.record()
+        return self
+
+    def finish(self):
+        """wait for the queued step, raise on its errors -> (xz float32 [R,2,k] view of the static buffer, indptr)"""
+        self._event.synchronize()
+        st = self._host.tolist()
+        check_walk_flags(self.sets, st[:4])
+        if st[2] or st[4] > self.sets.ukeys.numel():
+            raise _lib.SubgAccError("the table of distinct LP rows overflowed in a captured step: capture it again with a "
+                                    "larger uniq_capacity")
+        self.distinct_rows, self.members = st[4], st[5]
+        return self.xz[: st[6]], self.ind
