@@ -81,7 +81,7 @@ __global__ void rng_positions_kernel(const int64_t *__restrict__ calls_excl, int
 #define SG_STAMP(k)
 #endif
 template <bool IDX64, int RNG, bool SPG>
-__global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) void walk_sets_kernel(const WalkArgs a) {
+__global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80))) void walk_sets_kernel(const WalkArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
 #if SG_EXPERIMENT == 7
     unsigned long long t_prev__ = __builtin_readcyclecounter();
@@ -331,36 +331,68 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
     int32_t idv[kSpgPerLane], slv[kSpgPerLane];
     bool ok[kSpgPerLane];
     int mycount = 0;
+    // The lane's members are handled stage by stage, two at a time, not one after the other: a stage issues its LDS
+    // reads for both before either is consumed, so their latencies overlap (a workgroup's lifetime is a chain of such
+    // round trips; 8 workgroups per CU is all the latency hiding there is).
+    constexpr int kIlp = 2;   // members in flight per stage (4 would need more than the 64 VGPRs that keep 8 workgroups per CU)
 #pragma unroll
-    for (int u = 0; u < kSpgPerLane; ++u) {
-        // member u of this lane: by rank (bucket mode) or straight from its table slot
-        const int x = tid + u * kWalkThreads;
-        int h = 0;
-        uint32_t tagoff = 0;
-        if (need_rank) {
-            ok[u] = x < ns;
-            if (ok[u]) h = inv[x];
-            tagoff = (uint32_t)x;
-        } else {
-            ok[u] = x < T && keys[x] != -1;
-            h = x;
-            if (ok[u]) tagoff = minq[x];
+    for (int u0 = 0; u0 < kSpgPerLane; u0 += kIlp) {
+        unsigned long long mkey[kIlp], fcur[kIlp];
+        uint32_t mtag[kIlp], mf[kIlp], ftag[kIlp];
+#pragma unroll
+        for (int v = 0; v < kIlp; ++v) {   // stage 1: the member (by rank in bucket mode, else straight from its slot)
+            const int u = u0 + v;
+            const int x = tid + u * kWalkThreads;
+            int h = x;
+            if (need_rank) {
+                ok[u] = x < ns;
+                h = ok[u] ? (int)inv[x] : 0;
+                mtag[v] = (uint32_t)x;
+                idv[u] = keys[h];
+            } else {
+                ok[u] = x < T;
+                h = ok[u] ? x : 0;
+                idv[u] = keys[h];
+                mtag[v] = minq[h];
+                ok[u] = ok[u] && idv[u] != -1;
+            }
+            mkey[v] = pk[h];
         }
-        idv[u] = 0, slv[u] = -1;
-        if (ok[u]) {
-            ++mycount;
-            idv[u] = keys[h];
-            const unsigned long long key = pk[h] | (tagoff == 0 ? lead : 0ull);   // the root is rank 0 / visit 0
-            uint32_t f = (uint32_t)(mix64(key) >> 40) & (kSpgFold - 1);
+#pragma unroll
+        for (int v = 0; v < kIlp; ++v) {   // stage 2: key, fold slot, first probe
+            const int u = u0 + v;
+            mkey[v] |= (mtag[v] == 0 ? lead : 0ull);               // the root is rank 0 / visit 0
+            mf[v] = (uint32_t)(mix64(mkey[v]) >> 40) & (kSpgFold - 1);
+            slv[u] = -1;
+            if (!ok[u]) idv[u] = 0;
+            mycount += ok[u] ? 1 : 0;
+        }
+#pragma unroll
+        for (int v = 0; v < kIlp; ++v) {
+            fcur[v] = fk[mf[v]];
+            ftag[v] = ft[mf[v]];
+        }
+#pragma unroll
+        for (int v = 0; v < kIlp; ++v) {   // stage 3: a set holds a few dozen distinct keys -> mostly a hit right away
+            const int u = u0 + v;
+            if (!ok[u]) continue;
+            const unsigned long long key = mkey[v];
+            const uint32_t tagoff = mtag[v];
+            if (fcur[v] == key) {
+                // most lanes meet a tag that is already smaller: the plain read (stale only towards larger values)
+                // spares the same-address atomic storm
+                if (ftag[v] > tagoff) atomicMin(&ft[mf[v]], tagoff);
+                slv[u] = -2 - (int32_t)mf[v];       // resolved to the HBM slot after the fold table is flushed
+                continue;
+            }
+            uint32_t f = mf[v];
             bool done = false;
             for (int p = 0; p < 16; ++p) {
                 unsigned long long cur = fk[f];
                 if (cur == kEmptyKey) cur = atomicCAS(&fk[f], kEmptyKey, key);
                 if (cur == kEmptyKey || cur == key) {
-                    // a few dozen distinct keys per set: most lanes meet a tag that is already smaller, and a plain
-                    // read (it can only be stale towards larger values) spares the same-address atomic storm
                     if (ft[f] > tagoff) atomicMin(&ft[f], tagoff);
-                    slv[u] = -2 - (int32_t)f;   // resolved to the HBM slot after the fold table is flushed
+                    slv[u] = -2 - (int32_t)f;
                     done = true;
                     break;
                 }
@@ -440,11 +472,17 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
     int32_t *fin_id = (int32_t *)minq;                 // [ns] <= T
     int32_t *fin_sl = (int32_t *)(pk + a.stride + 1);   // [ns]: A occupies pk[0..ns), ns <= stride; (T - stride - 1) * 8 >= 4 * stride
     const bool staged = (int64_t)(T - a.stride - 1) * 8 >= (int64_t)4 * a.stride;
+    int blo[kSpgPerLane], bhi[kSpgPerLane];
+#pragma unroll
+    for (int u = 0; u < kSpgPerLane; ++u) {   // bucket bounds of all the lane's members first (overlapping reads)
+        blo[u] = ok[u] ? start[bk[u]] : 0;
+        bhi[u] = ok[u] ? start[bk[u] + 1] : 0;
+    }
 #pragma unroll
     for (int u = 0; u < kSpgPerLane; ++u)
         if (ok[u]) {
             const unsigned long long me = ((unsigned long long)(uint32_t)idv[u] << 32) | (uint32_t)slv[u];
-            const int lo = start[bk[u]], hi = start[bk[u] + 1];
+            const int lo = blo[u], hi = bhi[u];
             int rank = 0;
             for (int t2 = lo; t2 < hi; ++t2) rank += (A[t2] < me) ? 1 : 0;
             if (staged) {

@@ -144,9 +144,10 @@ class SampledSets:
             raise _lib.SubgAccError("the table of distinct LP rows overflowed: sample again with a larger "
                                     "uniq_capacity (or lazy=False, which retries by itself)")
         c, X = st[4], st[5]
-        if c > self.ukeys.numel():
-            raise _lib.SubgAccError(f"{c} distinct LP rows exceed the direct-ranking limit: sample with lazy=False")
-        self.ukeys = self.ukeys[:c]
+        if self.ukeys is not None:              # (None: strided rows sampled with number_rows=False, see number())
+            if c > self.ukeys.numel():
+                raise _lib.SubgAccError(f"{c} distinct LP rows exceed the direct-ranking limit: sample with lazy=False")
+            self.ukeys = self.ukeys[:c]
         if self.strided:
             self._members = X
             return self
@@ -164,7 +165,27 @@ class SampledSets:
 
     @property
     def c(self):
-        return self.resolve().ukeys.numel()
+        return self.resolve().number().ukeys.numel()
+
+    def number(self):
+        """Number the distinct LP rows (first-occurrence order, subg_acc.c:957-978) if that has not happened yet: strided
+        rows sampled with number_rows=False skip it -- a join by table slot (StridedSpG.slot_table()) consults no
+        numbering, and a transient batch is dropped after its join -- until ukeys / c / enc / to_csr() are asked for."""
+        if self.ukeys is not None:
+            return self
+        self.resolve()
+        L, dev, st = lib(), self.ids.device, stream_ptr()
+        count = torch.zeros(1, dtype=torch.int64, device=dev)
+        max_unique = min(self.capacity, RANK_LIMIT)
+        ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
+        ws = torch.empty(L.subgacc_uniq_number_workspace_bytes(self.capacity, 0), dtype=torch.uint8, device=dev)
+        check(L.subgacc_uniq_number(ptr(self.table), self.capacity, None, 0, ptr(ukeys), max_unique, ptr(count), RANK_LIMIT,
+                                    ptr(ws), ws.numel(), st))
+        c = int(count.item())
+        if c > max_unique:
+            raise _lib.SubgAccError(f"{c} distinct LP rows exceed the direct-ranking limit: sample with lazy=False")
+        self.ukeys = ukeys[:c]
+        return self
 
     def _count_dev(self):
         """device views of (distinct-row count, member count) while lazy, else (None, None)"""
@@ -186,6 +207,7 @@ class SampledSets:
 
     def enc_int16(self):
         """int16 [c, m+1]: the reference's `enc` (subg_acc.c:982-1000)."""
+        self.number()
         out = torch.empty((self.c, self.num_steps + 1), dtype=torch.int16, device=self.ids.device)
         check(lib().subgacc_unpack_lp(ptr(self.ukeys), self.c, None, self.num_walks, self.num_steps, ptr(out), None, None,
                                       0, stream_ptr()))
@@ -203,6 +225,7 @@ class SampledSets:
     def feature_table(self):
         """float32 [c+1, m+1] = [0-row ; enc / M]: Z_SF as main.py:174 + random_walks.py:81 build it.
         While lazy the table has one row per ukeys slot (rows past the real count are zero and never indexed)."""
+        self.number()
         rows = self.ukeys.numel()
         cdev, _ = self._count_dev()
         out = torch.empty((rows + 1, self.num_steps + 1), dtype=torch.float32, device=self.ids.device)
@@ -276,7 +299,7 @@ def _cat(parts, dtype, dev):
 def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, rng="rand_r", first_hop_wo=True,
                 order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False, rng_streams=1,
                 calls_before=0, dedup=True, keep_keys=None, staging_bytes=STAGING_BYTES, uniq_capacity=UNIQ_CAPACITY,
-                uniq_small_limit=0, fused_rows=False, lazy=False, strided=False):
+                uniq_small_limit=0, fused_rows=False, lazy=False, strided=False, number_rows=True):
     """Run the sampler for `query` (roots) on the GPU.  See SampledSets.
 
     dedup=True numbers the distinct LP rows (ukeys, slot / get_sf()); the packed keys are then only kept when
@@ -285,7 +308,8 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     configuration does not fit, the caller then takes the general pipeline).  lazy=True: see the module docstring.
     strided=True (with fused_rows, one chunk): the finished rows stay where the walk kernel left them -- row i at
     ids / slot [i*stride, +nsize[i]), slot = table slot -- for a join straight from there (spg.StridedSpG); no packed
-    copy, no row offsets."""
+    copy, no row offsets.  number_rows=False (strided only): the distinct LP rows are not numbered either until somebody
+    asks (SampledSets.number()); the join by table slot needs no numbering."""
     L = lib()
     dev = csr.device
     q = _as_query(query, dev)
@@ -343,7 +367,10 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
                                           ptr(walks[lo:]) if walks is not None else None, ptr(flags), st))
         if not strided:
             check(L.subgacc_exclusive_scan_i32(ptr(nsize[lo:]), cn, ptr(off_chunk), ptr(scan_ws), scan_ws.numel(), st))
-        numbered_early = fused_rows and chunk == n
+        numbered_early = fused_rows and chunk == n and (number_rows or not strided)
+        if strided and not numbered_early:
+            ukeys, max_unique = None, uniq_capacity
+            count = torch.full((1,), -1, dtype=torch.int64, device=dev)
         if numbered_early:    # one chunk: the table is complete -> number it now and let the copy emit SFptr+1
             count = torch.zeros(1, dtype=torch.int64, device=dev)
             max_unique = min(uniq_capacity, limit)
@@ -361,7 +388,8 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
                 if st_host[2]:                    # the table of distinct LP rows overflowed: walk again with a larger one
                     return sample_sets(csr, q, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order,
                                        cap_root_degree, emit_walks, rng_streams, calls_before, dedup, keep_keys,
-                                       staging_bytes, uniq_capacity * 4, uniq_small_limit, fused_rows, lazy, strided)
+                                       staging_bytes, uniq_capacity * 4, uniq_small_limit, fused_rows, lazy, strided,
+                                       number_rows)
                 if st_host[4] > max_unique:       # more distinct rows than the direct ranking numbers: the caller
                     return None                   # (sample_spg) falls through to the packed forms
                 sets.resolve()
@@ -438,7 +466,7 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     if st_host[2]:
         return sample_sets(csr, q, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order, cap_root_degree,
                            emit_walks, rng_streams, calls_before, dedup, keep_keys, staging_bytes, uniq_capacity * 4,
-                           uniq_small_limit, fused_rows, lazy, strided)
+                           uniq_small_limit, fused_rows, lazy, strided, number_rows)
     sets.resolve()
     sets.ukeys = sets.ukeys.clone()
     return sets

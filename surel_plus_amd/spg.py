@@ -126,13 +126,14 @@ class StridedSpG:
     @property
     def max_data(self):
         """largest SFptr+1 a member can carry: the distinct-row count (its capacity bound while the sets are lazy)"""
-        return self.sets.ukeys.numel()
+        return self.sets.number().ukeys.numel()
 
     @property
     def nnz(self):
         return self.sets.X
 
     def to_csr(self):
+        self.sets.number()           # the packed rows carry SFptr+1: the table must be numbered by now
         n, dev = self.n_rows, self.device
         row_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
         ws = torch.empty(max(lib().subgacc_scan_workspace_bytes(n), 8), dtype=torch.uint8, device=dev)

@@ -257,6 +257,8 @@ def sample_and_gather(csr, edge, num_walks=200, num_steps=3, seed=111413, rng="p
         rows = torch.arange(2 * B, device=e.device, dtype=torch.int64).view(2, B)
     if strided is None:
         strided = prefers_fused(csr, num_steps)
+    if strided:       # joined by table slot below: the distinct LP rows need no numbering (SampledSets.number() does it on demand)
+        kw.setdefault("number_rows", False)
     z, sets = sample_spg(csr, roots.to(torch.int32), num_walks=num_walks, num_steps=num_steps, seed=seed, rng=rng, lazy=lazy,
                          strided=strided, **kw)
     table = z.slot_table() if sets.strided else sets.feature_table()

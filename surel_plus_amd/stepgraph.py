@@ -62,8 +62,8 @@ class CapturedStep:
         self._event.synchronize()
         st = self._host.tolist()
         check_walk_flags(self.sets, st[:4])
-        if st[2] or st[4] > self.sets.ukeys.numel():
+        if st[2] or (self.sets.ukeys is not None and st[4] > self.sets.ukeys.numel()):
             raise _lib.SubgAccError("the table of distinct LP rows overflowed in a captured step: capture it again with a "
                                     "larger uniq_capacity")
-        self.distinct_rows, self.members = st[4], st[5]
+        self.distinct_rows, self.members = (st[4] if st[4] >= 0 else None), st[5]   # None: not numbered (join by table slot)
         return self.xz[: st[6]], self.ind
