@@ -9,6 +9,7 @@
 // feature pair straight from the Z_SF table (L2-resident, a few KB..MB) -- the [R,2] index array of the
 // reference never exists in memory unless asked for.
 #include "common.hpp"
+#include "blockscan.hpp"
 #ifndef SJ_EXPERIMENT
 #define SJ_EXPERIMENT 0   // dev-only timing variants, see tools/ab_sjoin.sh
 #endif
@@ -17,17 +18,64 @@ namespace subgacc {
 
 constexpr int kJoinThreads = 64;
 
+// Segment pointers = exclusive scan of the own rows' lengths (train.py:20-22), as two kernels (one for <= 2048
+// segments): the row length is looked up inside the scan's passes (no length array, no separate look-up kernel), and
+// every tile adds up the tile sums in front of it itself (at most a few thousand words) instead of a third launch.
 // A row number outside [0, n_rows) -- the reference's `x[edge[0]]` raises IndexError for it (train.py:15) -- is never
 // dereferenced: the row counts as empty and flags[3] |= 16 tells the host (which raises).
-__global__ void sjoin_len_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ row_len, int64_t n_rows,
-                                 const int64_t *__restrict__ own, const int64_t *__restrict__ partner, int64_t S,
-                                 int64_t *__restrict__ len, int32_t *__restrict__ flags) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j < S) {
+struct SegLen {
+    const int64_t *indptr;
+    const int32_t *row_len;
+    int64_t n_rows;
+    const int64_t *own, *partner;
+    int32_t *flags;
+    int64_t S;
+    __device__ __forceinline__ int64_t operator()(int64_t j, bool flag_it) const {
+        if (j >= S) return 0;
         const int64_t a = own[j];
         const bool bad = (uint64_t)a >= (uint64_t)n_rows;
-        if ((bad || (partner && (uint64_t)partner[j] >= (uint64_t)n_rows)) && flags) atomicOr(&flags[3], 16);
-        len[j] = bad ? 0 : (row_len ? (int64_t)row_len[a] : indptr[a + 1] - indptr[a]);
+        if (flag_it && (bad || (partner && (uint64_t)partner[j] >= (uint64_t)n_rows)) && flags) atomicOr(&flags[3], 16);
+        return bad ? 0 : (row_len ? (int64_t)row_len[a] : indptr[a + 1] - indptr[a]);
+    }
+};
+constexpr int kSegItems = 8;
+constexpr int kSegTile = kScanThreads * kSegItems;
+
+__global__ __launch_bounds__(kScanThreads) void sjoin_seg_reduce_kernel(const SegLen L, int64_t *__restrict__ partial) {
+    const int64_t base = (int64_t)blockIdx.x * kSegTile + (int64_t)threadIdx.x * kSegItems;
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kSegItems; ++k) s += L(base + k, true);
+    int64_t tot;
+    block_exclusive_scan(s, &tot);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// partial == nullptr: a single tile (which then also raises the flag)
+__global__ __launch_bounds__(kScanThreads) void sjoin_seg_scan_kernel(const SegLen L, const int64_t *__restrict__ partial,
+                                                                      int64_t *__restrict__ out) {
+    const int64_t base = (int64_t)blockIdx.x * kSegTile + (int64_t)threadIdx.x * kSegItems;
+    int64_t v[kSegItems];
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kSegItems; ++k) {
+        v[k] = L(base + k, partial == nullptr);
+        s += v[k];
+    }
+    int64_t front = 0;   // sum of the tiles in front of this one
+    if (partial) {
+        int64_t mine = 0;
+        for (int64_t t = threadIdx.x; t < (int64_t)blockIdx.x; t += kScanThreads) mine += partial[t];
+        int64_t ignore = block_exclusive_scan(mine, &front);
+        (void)ignore;
+    }
+    int64_t tot;
+    int64_t run = block_exclusive_scan(s, &tot) + front;
+#pragma unroll
+    for (int k = 0; k < kSegItems; ++k) {
+        if (base + k < L.S) out[base + k] = run;
+        run += v[k];
+        if (base + k == L.S - 1) out[L.S] = run;   // the grand total lands in out[S]
     }
 }
 
@@ -520,12 +568,19 @@ static int join_sizes(const int64_t *spg_indptr, const int32_t *row_len, int64_t
     SG_REQUIRE((spg_indptr || row_len) && own, SUBGACC_ERR_BADARG, "sjoin_sizes: null argument");
     SG_REQUIRE(workspace && workspace_bytes >= subgacc_sjoin_workspace_bytes(S), SUBGACC_ERR_WORKSPACE,
                "sjoin_sizes: workspace too small");
-    int64_t *len = (int64_t *)workspace;
-    char *ws = (char *)workspace + align_up((size_t)S * 8, 256);
-    hipLaunchKernelGGL(sjoin_len_kernel, dim3((unsigned)ceil_div(S, 256)), dim3(256), 0, s, spg_indptr, row_len, n_rows, own,
-                       partner, S, len, flags);
+    SegLen L{spg_indptr, row_len, n_rows, own, partner, flags, S};
+    const int64_t nb = ceil_div(S, kSegTile);
+    SG_REQUIRE(nb < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_sizes: too many segments");
+    if (nb == 1) {
+        hipLaunchKernelGGL(sjoin_seg_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, L, (const int64_t *)nullptr, out_seg);
+    } else {
+        int64_t *partial = (int64_t *)workspace;     // nb words <= S words
+        hipLaunchKernelGGL(sjoin_seg_reduce_kernel, dim3((unsigned)nb), dim3(kScanThreads), 0, s, L, partial);
+        hipLaunchKernelGGL(sjoin_seg_scan_kernel, dim3((unsigned)nb), dim3(kScanThreads), 0, s, L, (const int64_t *)partial,
+                           out_seg);
+    }
     SG_LAUNCH_CHECK();
-    return exclusive_scan_i64(len, S, out_seg, ws, workspace_bytes - align_up((size_t)S * 8, 256), s);
+    return SUBGACC_OK;
 }
 
 extern "C" int subgacc_sjoin_sizes(const int64_t *spg_indptr, int64_t n_rows, const int64_t *own, const int64_t *partner,

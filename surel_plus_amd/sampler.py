@@ -100,7 +100,7 @@ class SampledSets:
     slot: torch.Tensor = None    # int32 [X]   slot of the member's key in `table` (fused compaction + insert)
     table: torch.Tensor = None   # the HBM table of distinct LP rows (uint8 blob, layout of csrc/uniq_table.hpp)
     capacity: int = 0
-    status: torch.Tensor = None  # lazy form: device int64 [flags(4), distinct rows, members], not read back yet
+    status: torch.Tensor = None  # lazy form: device int64 [flags (4 x int32 in 2 words), distinct rows, members], see unpack_status
     data: torch.Tensor = None    # fused SpG form: SFptr+1 per member (capacity-sized while lazy)
     strided: bool = False        # ids / slot are the strided staging arrays (row i at i*stride), see sample_sets
     _members: int = 0
@@ -135,9 +135,10 @@ class SampledSets:
             ev.synchronize()
             st = host.tolist()
             self.extra = st[self.status.numel():]
+            st = unpack_status(st[: self.status.numel()])
             self._pending = None
         else:
-            st = self.status.tolist()
+            st = unpack_status(self.status.tolist())
         self.status = None
         check_walk_flags(self, st[:4])
         if st[2]:
@@ -191,7 +192,7 @@ class SampledSets:
         """device views of (distinct-row count, member count) while lazy, else (None, None)"""
         if self.status is None:
             return None, None
-        return self.status[4:5], self.status[5:6]
+        return self.status[2:3], self.status[3:4]
 
     # ------------------------------------------------------------------ views of the result
     def get_sf(self):
@@ -263,6 +264,14 @@ def _as_query(query, device):
     return torch.from_numpy(np.ascontiguousarray(np.asarray(query).astype(np.int32)).ravel()).to(device)
 
 
+def unpack_status(words):
+    """host list of the packed device status [flags0|flags1<<32, flags2|flags3<<32, distinct rows, members, ...] ->
+    [flags0, flags1, flags2, flags3, distinct rows, members, ...].  The four int32 flag words the kernels write share
+    one int64[.] buffer with the counts, so that a step zeroes, fills and reads back ONE small tensor."""
+    w = [int(v) for v in words]
+    return [w[0] & 0xFFFFFFFF, (w[0] >> 32) & 0xFFFFFFFF, w[1] & 0xFFFFFFFF, (w[1] >> 32) & 0xFFFFFFFF] + w[2:]
+
+
 def check_walk_flags(sets, fl):
     if fl[3] & 16:
         raise IndexError("query node ids outside [0, num_nodes) (such a root is never looked up on the device; the "
@@ -322,7 +331,8 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
                        or order != _lib.ORDER_WALK_MAJOR):
         return None
     st = stream_ptr()
-    flags = torch.zeros(4, dtype=torch.int32, device=dev)
+    status = torch.zeros(4, dtype=torch.int64, device=dev)     # [flags x4 (int32) | distinct rows | members]: one memset,
+    flags = status.view(torch.int32)[:4]                        # one read-back (unpack_status)
     if keep_keys is None:
         keep_keys = not dedup
     if fused_rows:
@@ -368,11 +378,10 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
         if not strided:
             check(L.subgacc_exclusive_scan_i32(ptr(nsize[lo:]), cn, ptr(off_chunk), ptr(scan_ws), scan_ws.numel(), st))
         numbered_early = fused_rows and chunk == n and (number_rows or not strided)
+        count = status[2:3]
         if strided and not numbered_early:
             ukeys, max_unique = None, uniq_capacity
-            count = torch.full((1,), -1, dtype=torch.int64, device=dev)
         if numbered_early:    # one chunk: the table is complete -> number it now and let the copy emit SFptr+1
-            count = torch.zeros(1, dtype=torch.int64, device=dev)
             max_unique = min(uniq_capacity, limit)
             ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
             nws = torch.empty(L.subgacc_uniq_number_workspace_bytes(uniq_capacity, 0), dtype=torch.uint8, device=dev)
@@ -382,9 +391,10 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
         if strided:           # rows are joined from the staging arrays themselves
             sets = SampledSets(nsize, None, st_ids, None, None, ukeys, M, m, stride, None)
             sets.slot, sets.table, sets.capacity, sets.strided = st_aux, table, uniq_capacity, True
-            sets.status = torch.cat([flags.long(), count, nsize.sum(dtype=torch.int64).view(1)])
+            torch.sum(nsize, dim=(0,), dtype=torch.int64, out=status[3])
+            sets.status = status
             if not lazy:      # eager: same recovery as the packed forms below
-                st_host = sets.status.tolist()
+                st_host = unpack_status(status.tolist())
                 if st_host[2]:                    # the table of distinct LP rows overflowed: walk again with a larger one
                     return sample_sets(csr, q, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order,
                                        cap_root_degree, emit_walks, rng_streams, calls_before, dedup, keep_keys,
@@ -434,7 +444,7 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     if n and fused_rows and chunk == n:
         pass                          # numbered before the copy, which already wrote SFptr+1
     elif fused_rows or lazy:          # table-only direct ranking (tags need not be element positions)
-        count = torch.zeros(1, dtype=torch.int64, device=dev)
+        count = status[2:3]
         max_unique = min(uniq_capacity, limit)
         ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
         ws = torch.empty(L.subgacc_uniq_number_workspace_bytes(uniq_capacity, 0), dtype=torch.uint8, device=dev)
@@ -444,7 +454,7 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
             if fused_rows:            # slot -> SFptr+1 in place: the rows are finished SpG rows
                 check(L.subgacc_uniq_translate(ptr(table), uniq_capacity, ptr(slot), slot.numel(), ptr(x_dev), 1, st))
     else:
-        count = torch.zeros(1, dtype=torch.int64, device=dev)
+        count = status[2:3]
         max_unique = min(max(X, 1), uniq_capacity)
         ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
         ws = torch.empty(L.subgacc_uniq_number_workspace_bytes(uniq_capacity, X), dtype=torch.uint8, device=dev)
@@ -456,11 +466,12 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
         sets.data = slot
     else:
         sets.slot = slot
-    sets.status = torch.cat([flags.long(), count, x_dev])
+    status[3:4].copy_(x_dev)
+    sets.status = status
     if lazy:
         return sets
     # eager: read the status now; grow the table and walk again if it overflowed
-    st_host = sets.status.tolist()
+    st_host = unpack_status(status.tolist())
     if fused_rows and not st_host[2] and st_host[4] > max_unique:
         return None           # more distinct rows than the direct ranking handles: the caller takes the general path
     if st_host[2]:

@@ -254,7 +254,7 @@ def sample_and_gather(csr, edge, num_walks=200, num_steps=3, seed=111413, rng="p
         rows = inv.view(2, B)
     else:
         roots = e.reshape(-1)
-        rows = torch.arange(2 * B, device=e.device, dtype=torch.int64).view(2, B)
+        rows = None                   # row i of the batch's SpG = endpoint i: the segment lists are constants of B
     if strided is None:
         strided = prefers_fused(csr, num_steps)
     if strided:       # joined by table slot below: the distinct LP rows need no numbering (SampledSets.number() does it on demand)
@@ -262,8 +262,25 @@ def sample_and_gather(csr, edge, num_walks=200, num_steps=3, seed=111413, rng="p
     z, sets = sample_spg(csr, roots.to(torch.int32), num_walks=num_walks, num_steps=num_steps, seed=seed, rng=rng, lazy=lazy,
                          strided=strided, **kw)
     table = z.slot_table() if sets.strided else sets.feature_table()
-    xz, ind = gather(rows, z, e.device, ptr=True, encode=table, out=out, lazy=lazy)
+    if rows is not None:
+        xz, ind = gather(rows, z, e.device, ptr=True, encode=table, out=out, lazy=lazy)
+    else:
+        own, partner = _arange_segments(B, e.device)
+        xz, ind = _checked(*sjoin(_as_spg(z), own, partner, table, ptr_mode=True, pair_block=B, out=out, lazy=lazy))
     return xz, ind, sets
+
+
+_ARANGE_SEGMENTS = {}
+
+
+def _arange_segments(B, device):
+    """gather()'s segment lists for edge = [[0..B), [B..2B)] -- the rows of a batch sampled endpoint by endpoint -- kept per
+    (B, device): a serving loop does not rebuild them (three small kernels) for every batch."""
+    key = (int(B), str(device))
+    if key not in _ARANGE_SEGMENTS:
+        own = torch.arange(2 * B, device=device, dtype=torch.int64)
+        _ARANGE_SEGMENTS[key] = (own, torch.cat([own[B:], own[:B]]).contiguous())
+    return _ARANGE_SEGMENTS[key]
 
 
 def gather_counts(edge, x, table_rows, device=None):

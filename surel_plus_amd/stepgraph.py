@@ -14,7 +14,7 @@ and joined in every epoch (main.py:172-178).
 import torch
 
 from . import _lib
-from .sampler import check_walk_flags
+from .sampler import check_walk_flags, unpack_status
 from .spjoin import sample_and_gather
 
 
@@ -38,9 +38,9 @@ class CapturedStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.xz, self.ind, self.sets = self._queue()
-            # flags[4], distinct LP rows, set members, join rows: everything finish() needs, in one device tensor
-            self.status = torch.cat([self.sets.status, self.ind[-1:]])
-        self._host = torch.empty(self.status.numel(), dtype=torch.int64, pin_memory=True)
+        # what finish() needs: the packed status of the sets (flags, distinct LP rows, members) and the join's row count
+        self.status, self._rows = self.sets.status, self.ind[-1:]
+        self._host = torch.empty(self.status.numel() + 1, dtype=torch.int64, pin_memory=True)
         self._event = torch.cuda.Event()
 
     def _queue(self):
@@ -53,17 +53,19 @@ class CapturedStep:
             raise ValueError(f"this step was captured for [2, {self.B}] pairs")
         self.edge.copy_(edge, non_blocking=True)
         self.graph.replay()
-        self._host.copy_(self.status, non_blocking=True)
+        self._host[:-1].copy_(self.status, non_blocking=True)
+        self._host[-1:].copy_(self._rows, non_blocking=True)
         self._event.record()
         return self
 
     def finish(self):
         """wait for the queued step, raise on its errors -> (xz float32 [R,2,k] view of the static buffer, indptr)"""
         self._event.synchronize()
-        st = self._host.tolist()
+        words = self._host.tolist()
+        st = unpack_status(words[:-1]) + words[-1:]
         check_walk_flags(self.sets, st[:4])
         if st[2] or (self.sets.ukeys is not None and st[4] > self.sets.ukeys.numel()):
             raise _lib.SubgAccError("the table of distinct LP rows overflowed in a captured step: capture it again with a "
                                     "larger uniq_capacity")
-        self.distinct_rows, self.members = (st[4] if st[4] >= 0 else None), st[5]   # None: not numbered (join by table slot)
+        self.distinct_rows, self.members = (st[4] if self.sets.ukeys is not None else None), st[5]   # None: not numbered
         return self.xz[: st[6]], self.ind
