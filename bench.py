@@ -66,8 +66,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # SUBGACC_FUSED: 1 = the walk kernel also emits finished SpG rows (walk_spg), 0 = general pipeline, unset = the
 # library's choice (fused for walks of >= 3 hops)
 FUSED = {"1": True, "0": False}.get(os.environ.get("SUBGACC_FUSED", ""), None)
-# join the batch from the walk kernel's strided rows (no packed CSR copy of a batch that is joined once and dropped);
-# unset = wherever the fused-row walk kernel is the faster one (spg.prefers_fused); SUBGACC_STRIDED=0 builds the CSR SpG per step
+# join the batch from its strided rows (no packed CSR copy of a batch that is joined once and dropped): unset = yes, rows
+# from the fused-row walk kernel or from the general one + finish_rows (spg.prefers_fused); SUBGACC_STRIDED=0 builds the CSR SpG per step
 STRIDED = {"1": True, "0": False}.get(os.environ.get("SUBGACC_STRIDED", ""), None)
 UNIQ_CAPACITY = 1 << int(os.environ.get("SUBGACC_UNIQ_LOG2", "17"))   # slots of the table of distinct LP rows (a batch holds ~10^3)
 LAZY = os.environ.get("SUBGACC_LAZY", "1") == "1"     # sizes stay on the device: one host round trip per step
@@ -122,8 +122,7 @@ def hot_path_step(sp, csr, edge, M, k, seed, rng, slot=0):
     for the GPU when LAZY (every size stays on the device); finish_step() reads the sizes / status back.
     Returns (xz buffer view, indptr, sets)."""
     B = edge.shape[1]
-    from surel_plus_amd.spg import prefers_fused
-    strided = (prefers_fused(csr, k - 1) and FUSED is not False) if STRIDED is None else STRIDED
+    strided = STRIDED     # None: the library's choice (a transient batch is joined in place from its strided rows)
     # the join output is written into re-used buffers sized for the worst case (every set full), two of them in
     # turn so that step s+1 never overwrites what step s handed out: a serving loop would do the same, and it keeps
     # GB-sized device allocations -- tens of ms on some hosts -- out of the steps

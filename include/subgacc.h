@@ -115,6 +115,14 @@ int subgacc_walk_spg(const subgacc_walk_cfg *cfg, const void *indptr, const int3
                      const int32_t *query, int64_t n, int64_t root_base, const uint32_t *rng_pos,
                      const uint32_t *rng_seed, void *uniq_table, int64_t uniq_capacity, int32_t *row_ids,
                      int32_t *row_slot, int32_t *nsize, int32_t *flags, void *stream);
+/* The same finished rows from the sets of subgacc_walk_sets (for the configurations where that kernel is the faster
+ * walk -- short walks over a cache-resident graph): row i of the staging area, row_ids / row_keys [i*stride, +nsize[i])
+ * in first-visit order, becomes (ids sorted by node id, slots in `uniq_table`) IN PLACE (row_ids) and in row_slot,
+ * the LP keys registered with tag (root_base+i)*stride + first-visit rank -- one pass, instead of
+ * subgacc_compact_sets + subgacc_uniq_number + subgacc_spg_build and a packed copy.  stride <= 1024. */
+int subgacc_finish_rows(int32_t *row_ids, const uint64_t *row_keys, const int32_t *nsize, int64_t n, int32_t stride,
+                        int64_t root_base, void *uniq_table, int64_t uniq_capacity, int32_t *row_slot, int32_t *flags,
+                        void *stream);
 /* strided -> packed copy of the rows of subgacc_walk_spg: row i goes to [row_off[i], +nsize[i]).  With uniq_table
  * (already numbered by subgacc_uniq_number) out_data receives SFptr+1 directly; without it the raw table slots. */
 int subgacc_compact_rows(const int32_t *row_ids, const int32_t *row_slot, const int32_t *nsize, const int64_t *row_off,

@@ -29,7 +29,7 @@ SYMBOLS = (
     "subgacc_sjoin_workspace_bytes", "subgacc_sjoin_sizes", "subgacc_sjoin_fill", "subgacc_sjoin_counts",
     "subgacc_ppr_slab_bytes", "subgacc_ppr_slab_reset", "subgacc_ppr_topk", "subgacc_ppr_normalize", "subgacc_ppr_encode",
     "subgacc_walk_join", "subgacc_sjoin_sizes_rows", "subgacc_sjoin_fill_rows",
-    "subgacc_encode_sizes", "subgacc_encode_fill", "subgacc_sjoin_pairs",
+    "subgacc_encode_sizes", "subgacc_encode_fill", "subgacc_sjoin_pairs", "subgacc_finish_rows",
 )
 
 
@@ -109,6 +109,7 @@ def lib():
     sig["subgacc_encode_sizes"] = (C.c_int, [vp, vp, i64, vp, i32, vp, i32, vp, vp, vp])
     sig["subgacc_encode_fill"] = (C.c_int, [vp, vp, vp, i64, i32, vp, i32, vp, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp])
     sig["subgacc_sjoin_pairs"] = (C.c_int, [vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, i64, vp, vp])
+    sig["subgacc_finish_rows"] = (C.c_int, [vp, vp, vp, i64, i32, i64, vp, i64, vp, vp, vp])
     assert set(sig) == set(SYMBOLS)
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

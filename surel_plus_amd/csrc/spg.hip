@@ -12,6 +12,7 @@
 // (which was LDS-bandwidth bound: 1.16 ms vs the walk kernel's 1.19 ms on the cit2-like batch; a register
 // rank sort, O(n^2) compares, was slower still at 1.45 ms).  Rows longer than 1024 use the bitonic fallback.
 #include "common.hpp"
+#include "uniq_table.hpp"
 
 namespace subgacc {
 
@@ -37,28 +38,13 @@ __device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
     return v;
 }
 
-// E = members per lane, compile time so that the row lives in registers: it is read from HBM exactly once
+// The sort proper: the row (ids x[], payload v[], E members per lane) is in registers; sorted by id it goes to
+// out_indices / out_data [beg, beg + ns).
 template <int E>
-__device__ __forceinline__ void bucket_sort_row(const int32_t *__restrict__ ids, const int32_t *__restrict__ sf,
-                                                const int32_t *__restrict__ slot_id,
-                                                int64_t beg, int ns, int lane, int bcap, unsigned long long *tmp,
-                                                int32_t *start, int32_t *cursor, int32_t *__restrict__ out_indices,
-                                                int32_t *__restrict__ out_data) {
-    int32_t x[E], v[E];
-    int32_t mn = 0x7FFFFFFF, mx = 0;
-#pragma unroll
-    for (int u = 0; u < E; ++u) {
-        const int r = lane + u * kSpgThreads;
-        x[u] = 0, v[u] = 0;
-        if (r < ns) {
-            x[u] = ids[beg + r];
-            v[u] = sf_of(sf, slot_id, beg + r) + 1;
-            mn = min(mn, x[u]);
-            mx = max(mx, x[u]);
-        }
-    }
-    mn = wave_min_i32(mn);
-    mx = wave_max_i32(mx);
+__device__ __forceinline__ void bucket_sort_regs(const int32_t (&x)[E], const int32_t (&v)[E], int32_t mn, int32_t mx,
+                                                 int64_t beg, int ns, int lane, int bcap, unsigned long long *tmp,
+                                                 int32_t *start, int32_t *cursor, int32_t *__restrict__ out_indices,
+                                                 int32_t *__restrict__ out_data) {
     int logb = 0;
     while ((1 << logb) < ns && (1 << logb) < bcap) ++logb;
     const int B = 1 << logb;
@@ -125,6 +111,145 @@ __device__ __forceinline__ void bucket_sort_row(const int32_t *__restrict__ ids,
         out_indices[beg + r] = (int32_t)(w >> 32);
         out_data[beg + r] = (int32_t)(uint32_t)w;
     }
+}
+
+// E = members per lane, compile time so that the row lives in registers: it is read from HBM exactly once
+template <int E>
+__device__ __forceinline__ void bucket_sort_row(const int32_t *__restrict__ ids, const int32_t *__restrict__ sf,
+                                                const int32_t *__restrict__ slot_id,
+                                                int64_t beg, int ns, int lane, int bcap, unsigned long long *tmp,
+                                                int32_t *start, int32_t *cursor, int32_t *__restrict__ out_indices,
+                                                int32_t *__restrict__ out_data) {
+    int32_t x[E], v[E];
+    int32_t mn = 0x7FFFFFFF, mx = 0;
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+        const int r = lane + u * kSpgThreads;
+        x[u] = 0, v[u] = 0;
+        if (r < ns) {
+            x[u] = ids[beg + r];
+            v[u] = sf_of(sf, slot_id, beg + r) + 1;
+            mn = min(mn, x[u]);
+            mx = max(mx, x[u]);
+        }
+    }
+    mn = wave_min_i32(mn);
+    mx = wave_max_i32(mx);
+    bucket_sort_regs<E>(x, v, mn, mx, beg, ns, lane, bcap, tmp, start, cursor, out_indices, out_data);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// finish_rows: the sets of subgacc_walk_sets (strided staging: ids in first-visit order + packed LP keys) become
+// finished SpG rows IN PLACE -- what subgacc_walk_spg emits directly -- in one pass, one wave per root: the set's LP
+// keys are folded in a wave-private LDS table (a few dozen distinct rows per set) and registered in the HBM table of
+// distinct rows with tag (root_base + i)*stride + first-visit rank (= the member's index in the staging row: the
+// numbering of subg_acc.c:957-978), then the members are bucket-sorted by node id from registers
+// (random_walks.py:79-80) and written back as (sorted ids, table slots).  Replaces compact_sets + spg_build (two
+// passes over all members through HBM and a packed copy) for a batch that is joined from its strided rows.
+constexpr int kFinFold = 256;
+template <int E>
+__device__ __forceinline__ void finish_row(int32_t *__restrict__ row_ids, const unsigned long long *__restrict__ row_keys,
+                                           int64_t obase, int ns, int lane, int bcap, UniqTable t, unsigned long long tag0,
+                                           unsigned char *lds, int cap, int32_t *__restrict__ row_slot, int32_t *flags) {
+    unsigned long long *wk = (unsigned long long *)lds;          // [kFinFold] distinct keys of the set
+    uint32_t *wt = (uint32_t *)(wk + kFinFold);                  // [kFinFold] smallest first-visit rank of the key
+    int32_t *ws = (int32_t *)(wt + kFinFold);                    // [kFinFold] its slot in the HBM table
+    int32_t x[E], v[E];
+    unsigned long long key[E];
+    int32_t mn = 0x7FFFFFFF, mx = 0;
+    for (int s2 = lane; s2 < kFinFold; s2 += kSpgThreads) {
+        wk[s2] = kEmptyKey;
+        wt[s2] = 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+        const int r = lane + u * kSpgThreads;
+        x[u] = 0, v[u] = -1, key[u] = 0;
+        if (r < ns) {
+            x[u] = row_ids[obase + r];
+            key[u] = row_keys[obase + r];
+            mn = min(mn, x[u]);
+            mx = max(mx, x[u]);
+        }
+    }
+    mn = wave_min_i32(mn);
+    mx = wave_max_i32(mx);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+        const int r = lane + u * kSpgThreads;
+        if (r >= ns) continue;
+        uint32_t f = (uint32_t)(mix64(key[u]) >> 40) & (kFinFold - 1);
+        bool done = false;
+        for (int p = 0; p < 16; ++p) {
+            unsigned long long cur = wk[f];
+            if (cur == kEmptyKey) cur = atomicCAS(&wk[f], kEmptyKey, key[u]);
+            if (cur == kEmptyKey || cur == key[u]) {
+                if (wt[f] > (uint32_t)r) atomicMin(&wt[f], (uint32_t)r);
+                v[u] = -2 - (int32_t)f;      // resolved below
+                done = true;
+                break;
+            }
+            f = (f + 1) & (kFinFold - 1);
+        }
+        if (!done) v[u] = uniq_global_insert(t, key[u], tag0 + (unsigned long long)r, flags);   // crowded fold table
+    }
+    __syncthreads();
+    for (int s2 = lane; s2 < kFinFold; s2 += kSpgThreads)
+        if (wk[s2] != kEmptyKey) ws[s2] = uniq_global_insert(t, wk[s2], tag0 + wt[s2], flags);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < E; ++u)
+        if (v[u] <= -2) v[u] = ws[-2 - v[u]];
+    __syncthreads();                                             // the fold tables are dead: the sort re-uses the LDS
+    unsigned long long *tmp = (unsigned long long *)lds;         // [cap]
+    int32_t *start = (int32_t *)(tmp + cap);                     // [bcap+1]
+    int32_t *cursor = start + bcap + 1;                          // [bcap]
+    bucket_sort_regs<E>(x, v, mn, mx, obase, ns, lane, bcap, tmp, start, cursor, row_ids, row_slot);
+}
+
+// EMAX = ceil(stride / 64): the longest row the launch can meet.  A compile-time bound so that the register budget
+// (and with it the number of resident waves: the kernel is latency x occupancy bound) is that of the rows that occur,
+// not of the 1024-member worst case.
+template <int EMAX>
+__global__ __launch_bounds__(kSpgThreads) void finish_rows_kernel(int32_t *__restrict__ row_ids,
+                                                                   const unsigned long long *__restrict__ row_keys,
+                                                                   const int32_t *__restrict__ nsize, int64_t n,
+                                                                   int32_t stride, int64_t root_base, UniqTable t,
+                                                                   int32_t cap, int32_t bcap,
+                                                                   int32_t *__restrict__ row_slot, int32_t *flags) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int64_t i = xcd_item(blockIdx.x, gridDim.x);
+    if (i >= n) return;
+    const int ns = nsize[i], lane = threadIdx.x;
+    if (ns > cap) {   // cannot happen for sets of subgacc_walk_sets (ns <= stride <= cap); never overrun LDS
+        if (lane == 0) atomicOr(&flags[3], 1);
+        return;
+    }
+    const int64_t obase = i * (int64_t)stride;
+    const unsigned long long tag0 = (unsigned long long)((root_base + i) * (int64_t)stride);
+#define SG_FIN(EE) finish_row<EE>(row_ids, row_keys, obase, ns, lane, bcap, t, tag0, lds_raw, cap, row_slot, flags)
+    const int e = (ns + kSpgThreads - 1) / kSpgThreads;
+    if (e == 0) return;
+    if constexpr (EMAX <= 4) {
+        if (e <= 2) SG_FIN(2);
+        else SG_FIN(4);
+    } else if constexpr (EMAX <= 7) {
+        if (e <= 2) SG_FIN(2);
+        else if (e <= 4) SG_FIN(4);
+        else SG_FIN(7);
+    } else if constexpr (EMAX <= 10) {
+        if (e <= 4) SG_FIN(4);
+        else if (e <= 7) SG_FIN(7);
+        else SG_FIN(10);
+    } else {
+        if (e <= 4) SG_FIN(4);
+        else if (e <= 7) SG_FIN(7);
+        else if (e <= 10) SG_FIN(10);
+        else if (e <= 13) SG_FIN(13);
+        else SG_FIN(16);
+    }
+#undef SG_FIN
 }
 
 __global__ __launch_bounds__(kSpgThreads) void spg_bucket_kernel(const int64_t *__restrict__ row_off, int64_t n,
@@ -242,6 +367,38 @@ extern "C" int subgacc_spg_build(const int64_t *row_off, int64_t n, const int32_
         SG_CHECK_HIP(hipFuncSetAttribute((const void *)spg_build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(spg_build_kernel, dim3((unsigned)grid), dim3(kSpgThreads), lds, (hipStream_t)stream, row_off, n,
                        ids, sf, slot_id, P, out_indices, out_data, flags);
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}
+
+extern "C" int subgacc_finish_rows(int32_t *row_ids, const uint64_t *row_keys, const int32_t *nsize, int64_t n,
+                                   int32_t stride, int64_t root_base, void *uniq_table, int64_t uniq_capacity,
+                                   int32_t *row_slot, int32_t *flags, void *stream) {
+    SG_REQUIRE(n >= 0 && stride > 0 && root_base >= 0 && flags, SUBGACC_ERR_BADARG, "finish_rows: bad arguments");
+    if (n == 0) return SUBGACC_OK;
+    SG_REQUIRE(row_ids && row_keys && nsize && row_slot, SUBGACC_ERR_BADARG, "finish_rows: null argument");
+    SG_REQUIRE(uniq_table && uniq_capacity > 0 && (uniq_capacity & (uniq_capacity - 1)) == 0 && uniq_capacity < (1ll << 31),
+               SUBGACC_ERR_BADARG, "finish_rows: needs a power-of-two table of distinct rows");
+    SG_REQUIRE(stride <= kBucketMaxLen, SUBGACC_ERR_LDS,
+               "finish_rows: rows of up to %d members (> %d): use subgacc_compact_sets + subgacc_spg_build", stride,
+               kBucketMaxLen);
+    const int cap = stride;
+    int bcap = 64;       // <= 256 buckets: ~2 members per bucket for the typical set, and the smaller LDS footprint lets
+    while (bcap < cap && bcap < 256) bcap <<= 1;   // ~30 rows (waves) be resident per CU -- the kernel is latency x occupancy bound
+    const size_t sort_b = (size_t)cap * 8 + (size_t)(2 * bcap + 1) * 4, fold_b = (size_t)kFinFold * 16;
+    const size_t lds = sort_b > fold_b ? sort_b : fold_b;
+    const int64_t grid = xcd_grid(n);
+    SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "finish_rows: too many rows in one call");
+    const int emax = (cap + kSpgThreads - 1) / kSpgThreads;
+#define SG_FIN_LAUNCH(EM)                                                                                               \
+    hipLaunchKernelGGL(finish_rows_kernel<EM>, dim3((unsigned)grid), dim3(kSpgThreads), lds, (hipStream_t)stream, row_ids, \
+                       (const unsigned long long *)row_keys, nsize, n, stride, root_base,                               \
+                       uniq_view(uniq_table, uniq_capacity), cap, bcap, row_slot, flags)
+    if (emax <= 4) SG_FIN_LAUNCH(4);
+    else if (emax <= 7) SG_FIN_LAUNCH(7);
+    else if (emax <= 10) SG_FIN_LAUNCH(10);
+    else SG_FIN_LAUNCH(16);
+#undef SG_FIN_LAUNCH
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }

@@ -665,6 +665,7 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
     }
     if (n == 0) return SUBGACC_OK;
     SG_REQUIRE(query, SUBGACC_ERR_BADARG, "walk: null query");   // `indices` may be NULL for an edgeless graph
+    SG_REQUIRE(num_nodes >= 1, SUBGACC_ERR_BADARG, "walk: %lld roots but a graph without nodes", (long long)n);
 
     WalkArgs a;
     a.indptr = indptr, a.indices = indices, a.query = query, a.n = n, a.num_nodes = num_nodes;

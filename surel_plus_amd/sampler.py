@@ -22,6 +22,7 @@ STAGING_BYTES = 6 << 30
 UNIQ_CAPACITY = 1 << 20
 FUSED_MAX_Q = 818       # subgacc_walk_spg keeps 4 table slots per lane in registers (per-root table <= 1024 slots)
 RANK_LIMIT = 16384      # distinct LP rows that the table-only numbering ranks directly
+FINISH_MAX_STRIDE = 1024   # subgacc_finish_rows sorts a row from registers (16 members per lane of one wave)
 
 # bench.py sets this to a callable(name) -> context manager that brackets one kernel launch with HIP events
 # on the launch stream (roofline.achieved is measured live, not taken from a profile)
@@ -315,9 +316,11 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     keep_keys is set.  fused_rows=True uses subgacc_walk_spg: `ids` come out sorted by node id per root and `data`
     holds SFptr+1 -- finished SpG rows (needs M*m+1 <= 818 and set_sampler order; returns None when the
     configuration does not fit, the caller then takes the general pipeline).  lazy=True: see the module docstring.
-    strided=True (with fused_rows, one chunk): the finished rows stay where the walk kernel left them -- row i at
-    ids / slot [i*stride, +nsize[i]), slot = table slot -- for a join straight from there (spg.StridedSpG); no packed
-    copy, no row offsets.  number_rows=False (strided only): the distinct LP rows are not numbered either until somebody
+    strided=True (one chunk): the finished rows stay in the walk kernel's staging layout -- row i at
+    ids / slot [i*stride, +nsize[i]), ids ascending, slot = table slot -- for a join straight from there
+    (spg.StridedSpG); no packed copy, no row offsets.  With fused_rows the walk kernel emits them itself
+    (subgacc_walk_spg); without, the general walk kernel is followed by subgacc_finish_rows (the faster pair for short
+    walks over a cache-resident graph, spg.prefers_fused).  number_rows=False (strided only): the distinct LP rows are not numbered either until somebody
     asks (SampledSets.number()); the join by table slot needs no numbering."""
     L = lib()
     dev = csr.device
@@ -341,7 +344,10 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     per_member = 8 if fused_rows else 12
     chunk = max(1, min(n, int(staging_bytes // (stride * per_member)), (1 << 31) - 16)) if n else 0
     lazy = bool(lazy and dedup and n > 0 and chunk == n)
-    if strided and not (fused_rows and n > 0 and chunk == n):
+    # strided rows come from the fused-row walk kernel, or (finish=True) from the general walk kernel + finish_rows
+    finish = bool(strided and not fused_rows and dedup and not emit_walks and order == _lib.ORDER_WALK_MAJOR
+                  and stride <= FINISH_MAX_STRIDE)
+    if strided and not ((fused_rows or finish) and n > 0 and chunk == n):
         return None
 
     rng_pos, rng_seed = _rng_positions(L, cfg, csr, q, n, rng_streams, calls_before, st)
@@ -377,7 +383,13 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
                                           ptr(walks[lo:]) if walks is not None else None, ptr(flags), st))
         if not strided:
             check(L.subgacc_exclusive_scan_i32(ptr(nsize[lo:]), cn, ptr(off_chunk), ptr(scan_ws), scan_ws.numel(), st))
-        numbered_early = fused_rows and chunk == n and (number_rows or not strided)
+        if finish:            # (ids in first-visit order, keys) -> (ids sorted, table slots), in place: finished rows
+            st_slot = torch.empty(chunk * stride, dtype=torch.int32, device=dev)
+            with _timed("spg_build"):
+                check(L.subgacc_finish_rows(ptr(st_ids), ptr(st_aux), ptr(nsize), cn, stride, 0, ptr(table), uniq_capacity,
+                                            ptr(st_slot), ptr(flags), st))
+            st_aux = st_slot
+        numbered_early = (fused_rows or finish) and chunk == n and (number_rows or not strided)
         count = status[2:3]
         if strided and not numbered_early:
             ukeys, max_unique = None, uniq_capacity

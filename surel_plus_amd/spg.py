@@ -151,8 +151,10 @@ FUSED_MIN_GRAPH_BYTES = 64 << 20     # adjacency beyond this no longer lives in 
 
 
 def prefers_fused(csr, hops):
-    """Is the fused-row walk kernel (and the strided join on top of it) the faster way through this graph?"""
-    return hops >= 3 or csr.nnz * 4 > FUSED_MIN_GRAPH_BYTES
+    """Is the fused-row walk kernel the faster way to the finished rows of a batch?  Walks of >= 3 hops: yes (cit2-like
+    1.90 vs 2.33 ms per step).  2-hop walks: the pipelined general kernel + finish_rows wins on a cache-resident graph
+    (collab-like 1.14 vs 1.37 ms) and ties beyond the caches (twitter-like 2.10 vs 2.12 ms)."""
+    return hops >= 3
 
 
 def sample_spg(csr, query, num_walks=200, num_steps=3, seed=111413, rng="rand_r", bucket=-1, fused=None, lazy=False,
@@ -168,15 +170,17 @@ def sample_spg(csr, query, num_walks=200, num_steps=3, seed=111413, rng="rand_r"
     recover by itself from a table of distinct LP rows that is too small (`uniq_capacity`, or more than
     sampler.RANK_LIMIT distinct rows): resolve() raises SubgAccError then and the batch is sampled again with
     lazy=False, which regrows the table / takes the packed path on its own (a serving loop: catch, re-run that batch).
-    strided=True: for a batch that is sampled, joined and dropped -- returns a StridedSpG (no packed copy of the rows)."""
+    strided=True: for a batch that is sampled, joined and dropped -- returns a StridedSpG (no packed copy of the rows):
+    the fused-row walk kernel's output, or the general walk kernel's sets finished in place (subgacc_finish_rows)."""
     sets = None
-    if strided:     # transient batch: rows stay in the walk kernel's own layout (falls through when it does not apply)
-        sets = sample_sets(csr, query, num_walks=num_walks, num_steps=num_steps, bucket=bucket, seed=seed, rng=rng,
-                           fused_rows=True, lazy=lazy, strided=True, **kw)
-        if sets is not None:
-            return StridedSpG(sets, csr.num_nodes), sets
     if fused is None:
         fused = prefers_fused(csr, num_steps)
+    if strided:     # transient batch: rows stay in the walk kernel's staging layout (falls through when it does not apply)
+        for fr in ((True, False) if fused else (False, True)):      # the faster walk kernel first, the other as fallback
+            sets = sample_sets(csr, query, num_walks=num_walks, num_steps=num_steps, bucket=bucket, seed=seed, rng=rng,
+                               fused_rows=fr, lazy=lazy, strided=True, **kw)
+            if sets is not None:
+                return StridedSpG(sets, csr.num_nodes), sets
     if fused:
         sets = sample_sets(csr, query, num_walks=num_walks, num_steps=num_steps, bucket=bucket, seed=seed, rng=rng,
                            fused_rows=True, lazy=lazy, **kw)

@@ -256,7 +256,7 @@ def sample_and_gather(csr, edge, num_walks=200, num_steps=3, seed=111413, rng="p
         roots = e.reshape(-1)
         rows = None                   # row i of the batch's SpG = endpoint i: the segment lists are constants of B
     if strided is None:
-        strided = prefers_fused(csr, num_steps)
+        strided = True        # a transient batch: joined in place, whichever walk kernel made the rows
     if strided:       # joined by table slot below: the distinct LP rows need no numbering (SampledSets.number() does it on demand)
         kw.setdefault("number_rows", False)
     z, sets = sample_spg(csr, roots.to(torch.int32), num_walks=num_walks, num_steps=num_steps, seed=seed, rng=rng, lazy=lazy,

@@ -1026,3 +1026,31 @@ def test_captured_step_replays_equal_the_eager_step(sp, B, hops, rng):
     xz, ind = step(query_pairs(csr, B, seed=2)).finish()          # and the step is usable afterwards
     exz, eind, _ = sp.sample_and_gather(csr, query_pairs(csr, B, seed=2), num_walks=100, num_steps=hops, seed=9, rng=rng)
     assert torch.equal(ind, eind) and torch.equal(xz, exz)
+
+
+@pytest.mark.parametrize("rng", ["rand_r", "philox"])
+@pytest.mark.parametrize("M,m,N,E,hubs,bucket", [(200, 2, 20000, 80000, 4, -1), (200, 3, 6000, 200000, 0, -1),
+                                                 (100, 4, 3000, 9000, 2, -1), (7, 5, 500, 1500, 1, -1),
+                                                 (255, 4, 2000, 100000, 1, -1), (64, 3, 3000, 9000, 2, 10), (1, 1, 300, 900, 0, -1)])
+def test_finished_rows_from_the_general_walk_kernel_match_oracle(sp, rng, M, m, N, E, hubs, bucket):
+    """subgacc_walk_sets + subgacc_finish_rows (the strided rows of the configurations where the general walk kernel is
+    the faster one): rows, numbering of the distinct LP rows and LP table are the oracle's, bit for bit; the join from
+    these rows equals the join from the oracle's SpG."""
+    from surel_plus_amd.spg import StridedSpG, sample_spg
+    ptr_, idx = sym_graph(N, E, seed=M + m, hubs=hubs)
+    q = np.random.default_rng(3).permutation(N)[: min(N, 3000)]
+    (oi, od, ov), oenc = _oracle_spg(ptr_, idx, q, M, m, 99, rng, bucket)
+    csr = sp.DeviceCSR(ptr_, idx)
+    for lazy in (False, True):
+        z, sets = sample_spg(csr, q, num_walks=M, num_steps=m, seed=99, rng=rng, bucket=bucket, fused=False, strided=True,
+                             lazy=lazy)
+        assert isinstance(z, StridedSpG) and sets.strided
+        zc = z.to_csr()
+        assert np.array_equal(zc.indptr.cpu().numpy(), oi) and np.array_equal(zc.indices.cpu().numpy(), od)
+        assert np.array_equal(zc.data.cpu().numpy(), ov)
+        assert np.array_equal(sets.enc_int16().cpu().numpy(), oenc)
+    edge = np.random.default_rng(5).integers(0, len(q), (2, 500))
+    table = oracle.enc_table(oenc).astype(np.float32) / np.float32(M)
+    oxz, oind = oracle.gather(edge, (oi, od, ov), ptr=True, encode=table)
+    xz, ind = sp.gather(edge, z, None, ptr=True, encode=z.slot_table())
+    assert np.array_equal(ind.cpu().numpy(), oind) and np.array_equal(xz.cpu().numpy(), oxz)
