@@ -8,6 +8,7 @@ set -e
 OUT=$1; TAG=$2; shift; shift
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
+mkdir -p $R/$OUT
 for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   d=$R/$OUT/$(echo $c | tr " " "_")
   rocprofv3 --pmc $c --output-format csv -d $d -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-others "$@" > $d.json 2> /dev/null
