@@ -96,6 +96,13 @@ def philox4x32_10(ctr, key):
     return out
 
 
+def philox2x32_10(ctr, key):
+    ctr = np.ascontiguousarray(ctr, np.uint32)
+    out = np.empty(2, np.uint32)
+    lib().orc_philox2x32_10(_p(ctr, C.c_uint32), C.c_uint32(int(key) & 0xFFFFFFFF), _p(out, C.c_uint32))
+    return out
+
+
 def gset_sampler(indptr, indices, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, rng="rand_r",
                  nthreads=1, debug=False):
     """subg_acc.c:649-1034.  Returns [nsize int32[n], remap int32[2,X], enc int16[c,m+1]] (+ raw when debug)."""

@@ -23,8 +23,9 @@
  * Deliberate deviations from the reference (documented in DESIGN.md):
  *   - an isolated root (degree 0) emits its own id as the single set member; the reference
  *     leaves that id uninitialised (subg_acc.c:753-761 vs :838-844).
- *   - a second RNG mode (ORC_RNG_PHILOX, counter-based Philox4x32-10 keyed by
- *     (seed, root id, walk, step)) that the reference does not have; it is the
+ *   - a second RNG mode (ORC_RNG_PHILOX, counter-based Philox2x32-10: key = seed,
+ *     counter = (root id, walk | draw block | stream tag); a draw r picks neighbour
+ *     (r * degree) >> 32) that the reference does not have; it is the
  *     schedule-independent mode of the HIP path and has to be checkable too.
  */
 #include <stdint.h>
@@ -74,25 +75,47 @@ static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t
     out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
 }
 
-#define ORC_PHILOX_KEY1 0x5355524Cu /* "SURL" */
-#define ORC_STREAM_SHUFFLE 0xFFFFFFFFu
+/* Philox2x32-10 (same paper): one 32x32 multiply per round; two draws per call -- what a walk of up to three
+ * hops needs after its first (deterministic) hop. */
+static void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t k, uint32_t out[2])
+{
+    for (int round = 0; round < 10; ++round)
+    {
+        uint64_t p = (uint64_t)0xD256D193u * c0;
+        uint32_t n0 = (uint32_t)(p >> 32) ^ k ^ c1;
+        c1 = (uint32_t)p;
+        c0 = n0;
+        k += 0x9E3779B9u;
+    }
+    out[0] = c0, out[1] = c1;
+}
+
+/* Stream layout of the Philox mode (shared with csrc/walk_common.hpp): key = seed, counter word 0 = root id,
+ * counter word 1 = lane (walk number or shuffle position, < 2^20) | block << 20 (draws 2*block, 2*block+1) |
+ * tag << 28 | shuffle-stream flag << 31. */
+#define ORC_PHILOX_BLOCK_SHIFT 20
+#define ORC_PHILOX_TAG_SHIFT 28
+#define ORC_PHILOX_SHUFFLE 0x80000000u
 
 /* draw #idx (0-based) of the stream (root, lane, tag) */
 static uint32_t philox_draw(uint32_t seed, uint32_t root, uint32_t lane, uint32_t idx, uint32_t tag)
 {
-    uint32_t ctr[4] = {root, lane, idx >> 2, tag}, key[2] = {seed, ORC_PHILOX_KEY1}, out[4];
-    philox4x32_10(ctr, key, out);
-    return out[idx & 3u];
+    uint32_t out[2];
+    philox2x32_10(root, lane | ((idx >> 1) << ORC_PHILOX_BLOCK_SHIFT) | (tag << ORC_PHILOX_TAG_SHIFT), seed, out);
+    return out[idx & 1u];
 }
 static uint32_t philox_shuffle_draw(uint32_t seed, uint32_t root, uint32_t k, uint32_t tag)
 {
-    uint32_t ctr[4] = {root, k, ORC_STREAM_SHUFFLE, tag}, key[2] = {seed, ORC_PHILOX_KEY1}, out[4];
-    philox4x32_10(ctr, key, out);
+    uint32_t out[2];
+    philox2x32_10(root, k | (tag << ORC_PHILOX_TAG_SHIFT) | ORC_PHILOX_SHUFFLE, seed, out);
     return out[0];
 }
+/* a draw -> an index below n: the high word of r*n (one multiply on the GPU; the rand_r mode keeps the reference's %) */
+static inline uint32_t philox_below(uint32_t r, uint32_t n) { return (uint32_t)(((uint64_t)r * n) >> 32); }
 
 /* exposed for the RNG known-answer tests */
 void orc_philox4x32_10(const uint32_t *ctr, const uint32_t *key, uint32_t *out) { philox4x32_10(ctr, key, out); }
+void orc_philox2x32_10(const uint32_t *ctr, uint32_t key, uint32_t *out) { philox2x32_10(ctr[0], ctr[1], key, out); }
 void orc_rand_r_stream(uint32_t seed, int64_t count, uint32_t *out)
 {
     for (int64_t i = 0; i < count; ++i)
@@ -215,7 +238,7 @@ static void walk_root(const walk_cfg_t *c, int32_t root, int without_repl, uint3
         {
             uint32_t r = c->rng_mode == ORC_RNG_RAND_R ? orc_rand_r(state)
                                                        : philox_shuffle_draw(c->seed, (uint32_t)root, (uint32_t)k, c->tag);
-            int32_t s = (int32_t)(r % (uint32_t)(deg - k)) + k;
+            int32_t s = (int32_t)(c->rng_mode == ORC_RNG_RAND_R ? r % (uint32_t)(deg - k) : philox_below(r, (uint32_t)(deg - k))) + k;
             int32_t vk = perm_get(perm, k), vs = perm_get(perm, s);
             perm_set(perm, k, vs);
             perm_set(perm, s, vk);
@@ -244,7 +267,7 @@ static void walk_root(const walk_cfg_t *c, int32_t root, int without_repl, uint3
                         r = orc_rand_r(state);
                     else
                         r = philox_draw(c->seed, (uint32_t)root, (uint32_t)w, (uint32_t)(without_repl ? s - 1 : s), c->tag);
-                    cur = c->indices[b + (int64_t)(r % (uint32_t)d)];
+                    cur = c->indices[b + (int64_t)(c->rng_mode == ORC_RNG_RAND_R ? r % (uint32_t)d : philox_below(r, (uint32_t)d))];
                 }
             }
             emit(cur, w, s, user);

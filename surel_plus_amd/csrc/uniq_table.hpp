@@ -35,6 +35,13 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     return x;
 }
 
+// Slot choice of the small per-set LDS fold tables (a few dozen distinct LP keys): four VALU instructions instead of
+// mix64's two 64-bit multiplies -- the fused walk kernel is bound by VALU issue (profiles/r02e_sq_*.csv).  BITS = log2(slots).
+template <int BITS>
+__device__ __forceinline__ uint32_t fold_hash(unsigned long long key) {
+    return (((uint32_t)key * 0x9E3779B1u) ^ ((uint32_t)(key >> 32) * 0x85EBCA77u)) >> (32 - BITS);
+}
+
 constexpr int kInsItems = 8;
 constexpr int kInsTile = 256 * kInsItems;
 constexpr int kInsLds = 1024;  // block-local table: a tile of 2048 members holds far fewer distinct LP rows

@@ -77,11 +77,30 @@ __global__ void rng_positions_kernel(const int64_t *__restrict__ calls_excl, int
             t_prev__ = now__;                                                                   \
         }                                                                                       \
     } while (0)
+#elif defined(SG_STOP_AFTER)   // dynamic instruction counts per phase (tools/walk_insts.sh): the workgroup ends at stamp k (results are wrong)
+#define SG_STAMP(k)                      \
+    do {                                 \
+        if (SG_STOP_AFTER == (k)) {      \
+            if (threadIdx.x == 0) {      /* a well-formed one-member row, so that the rest of the step stays in bounds */ \
+                a.nsize[i] = 1;          \
+                a.set_ids[i * (int64_t)a.stride] = root; \
+                if (SPG) a.set_slot[i * (int64_t)a.stride] = 0; \
+                else a.set_keys[i * (int64_t)a.stride] = 1ull << (a.m * a.shift); \
+            }                            \
+            return;                      \
+        }                                \
+    } while (0)
 #else
 #define SG_STAMP(k)
 #endif
+#ifndef SG_WALK_SGPR
+#define SG_WALK_SGPR 80
+#endif
+#ifndef SG_WALK_MINW
+#define SG_WALK_MINW 8
+#endif
 template <bool IDX64, int RNG, bool SPG>
-__global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80))) void walk_sets_kernel(const WalkArgs a) {
+__global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_num_sgpr(SG_WALK_SGPR))) void walk_sets_kernel(const WalkArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
 #if SG_EXPERIMENT == 7
     unsigned long long t_prev__ = __builtin_readcyclecounter();
@@ -160,18 +179,19 @@ __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80)
     }
     const bool shuffled = a.wo && rdeg64 > M;
     const uint32_t rdeg = (uint32_t)rdeg64;
+    const uint32_t ptag = (a.wo ? 0u : 1u) << kPhiloxTagShift;
     if (shuffled) {  // partial Fisher-Yates draws s_k = draw % (deg-k) + k  (subg_acc.c:769-775), one lane per k
         for (int k = tid; k < M; k += kWalkThreads) {
             uint32_t r;
             if (RNG == SUBGACC_RNG_RAND_R) {
                 uint32_t x = lcg_jump(rseed, rpos + 3u * (uint32_t)k);
                 r = rand_r_next(x);
+                sarr[k] = (int32_t)(r % (rdeg - (uint32_t)k)) + k;
             } else {
-                uint32_t o[4];
-                philox4x32_10((uint32_t)root, (uint32_t)k, kStreamShuffle, a.wo ? 0u : 1u, a.seed, kPhiloxKey1, o);
-                r = o[0];
+                uint32_t o1;
+                philox2x32_10((uint32_t)root, (uint32_t)k | ptag | kPhiloxShuffle, a.seed, r, o1);
+                sarr[k] = (int32_t)philox_below(r, rdeg - (uint32_t)k) + k;
             }
-            sarr[k] = (int32_t)(r % (rdeg - (uint32_t)k)) + k;
         }
     }
     __syncthreads();
@@ -184,7 +204,7 @@ __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80)
         // ---- first hop
         int32_t cur = root;
         uint32_t x = 0;         // rand_r state of this walk
-        uint32_t ph[4];         // cached Philox block
+        uint32_t ph[2];         // cached Philox block
         int ph_blk = -1;
         if (RNG == SUBGACC_RNG_RAND_R) {
             const uint32_t per_walk = (uint32_t)(a.wo ? m - 1 : m);
@@ -208,7 +228,7 @@ __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80)
                 cur = SG_NEIGH_LOAD(&a.indices[rbeg + pick]);
                 if (RNG == SUBGACC_RNG_PHILOX && m > 1) {   // the draws of hops 2.. while that load is in flight
                     ph_blk = 0;
-                    philox4x32_10((uint32_t)root, (uint32_t)w, 0u, 0u, a.seed, kPhiloxKey1, ph);
+                    philox2x32_10((uint32_t)root, (uint32_t)w | ptag, a.seed, ph[0], ph[1]);
                 }
             } else {
 #if SG_EXPERIMENT == 2   // dedup only: no graph reads after the first hop (timing experiment, results are wrong)
@@ -228,14 +248,15 @@ __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80)
                         r = rand_r_next(x);
                     } else {
                         const int idx = a.wo ? s - 1 : s;
-                        if ((idx >> 2) != ph_blk) {
-                            ph_blk = idx >> 2;
-                            philox4x32_10((uint32_t)root, (uint32_t)w, (uint32_t)ph_blk, a.wo ? 0u : 1u, a.seed,
-                                          kPhiloxKey1, ph);
+                        if ((idx >> 1) != ph_blk) {
+                            ph_blk = idx >> 1;
+                            philox2x32_10((uint32_t)root, (uint32_t)w | ((uint32_t)ph_blk << kPhiloxBlockShift) | ptag, a.seed,
+                                          ph[0], ph[1]);
                         }
-                        r = ph[idx & 3];
+                        r = ph[idx & 1];
                     }
-                    cur = SG_NEIGH_LOAD(&a.indices[b + (int64_t)(r % (uint32_t)d)]);
+                    cur = SG_NEIGH_LOAD(&a.indices[b + (int64_t)(RNG == SUBGACC_RNG_RAND_R ? r % (uint32_t)d
+                                                                                           : philox_below(r, (uint32_t)d))]);
                 } else if (RNG == SUBGACC_RNG_RAND_R) {
                     atomicOr(&a.flags[0], 1);  // dead end: the sequential stream is no longer reproducible
                 }
@@ -362,7 +383,7 @@ __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80)
         for (int v = 0; v < kIlp; ++v) {   // stage 2: key, fold slot, first probe
             const int u = u0 + v;
             mkey[v] |= (mtag[v] == 0 ? lead : 0ull);               // the root is rank 0 / visit 0
-            mf[v] = (uint32_t)(mix64(mkey[v]) >> 40) & (kSpgFold - 1);
+            mf[v] = fold_hash<kSpgFoldBits>(mkey[v]);
             slv[u] = -1;
             if (!ok[u]) idv[u] = 0;
             mycount += ok[u] ? 1 : 0;
@@ -423,6 +444,7 @@ __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80)
     const int B = 1 << logb;
     const uint32_t range = (uint32_t)(mx - mn) + 1u;
     const int Ls = (range <= 1u) ? 0 : (32 - __builtin_clz(range - 1u));
+    const int bshift = Ls > logb ? Ls - logb : 0;
     if (tid < B) cursor[tid] = 0;
     for (int s2 = tid; s2 < kSpgFold; s2 += kWalkThreads)    // flush the fold table to HBM (latency overlaps the sort)
 #if SG_EXPERIMENT == 8   // timing experiment: no registration in the HBM table (results are wrong)
@@ -435,7 +457,7 @@ __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80)
     uint32_t bk[kSpgPerLane];
 #pragma unroll
     for (int u = 0; u < kSpgPerLane; ++u) {
-        bk[u] = (uint32_t)(((uint64_t)(uint32_t)(idv[u] - mn) << logb) >> Ls);
+        bk[u] = (uint32_t)(idv[u] - mn) >> bshift;        // (id - mn) < 2^Ls and Ls >= logb unless the row is a single id
         if (ok[u]) atomicAdd(&cursor[bk[u]], 1);
         if (slv[u] <= -2) slv[u] = fs[-2 - slv[u]];
     }
@@ -472,6 +494,7 @@ __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80)
     int32_t *fin_id = (int32_t *)minq;                 // [ns] <= T
     int32_t *fin_sl = (int32_t *)(pk + a.stride + 1);   // [ns]: A occupies pk[0..ns), ns <= stride; (T - stride - 1) * 8 >= 4 * stride
     const bool staged = (int64_t)(T - a.stride - 1) * 8 >= (int64_t)4 * a.stride;
+    const uint32_t *Ahi = (const uint32_t *)A;
     int blo[kSpgPerLane], bhi[kSpgPerLane];
 #pragma unroll
     for (int u = 0; u < kSpgPerLane; ++u) {   // bucket bounds of all the lane's members first (overlapping reads)
@@ -481,10 +504,9 @@ __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80)
 #pragma unroll
     for (int u = 0; u < kSpgPerLane; ++u)
         if (ok[u]) {
-            const unsigned long long me = ((unsigned long long)(uint32_t)idv[u] << 32) | (uint32_t)slv[u];
             const int lo = blo[u], hi = bhi[u];
-            int rank = 0;
-            for (int t2 = lo; t2 < hi; ++t2) rank += (A[t2] < me) ? 1 : 0;
+            int rank = 0;       // ids are distinct within a set: the high word of A decides
+            for (int t2 = lo; t2 < hi; ++t2) rank += (Ahi[2 * t2 + 1] < (uint32_t)idv[u]) ? 1 : 0;
             if (staged) {
                 fin_id[lo + rank] = idv[u];
                 fin_sl[lo + rank] = slv[u];
@@ -696,6 +718,10 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
     // the persistent, software-pipelined form takes every launch it supports (SUBGACC_WALK_PIPE=0 forces this file's)
     static const bool use_pipe = !(getenv("SUBGACC_WALK_PIPE") && getenv("SUBGACC_WALK_PIPE")[0] == '0');
     if (use_pipe && launch_walk_pipe(a, cfg->indptr64 != 0, cfg->rng_mode, spg, lds, s)) {
+        SG_LAUNCH_CHECK();
+        return SUBGACC_OK;
+    }
+    if (spg && lds <= 64 * 1024 && launch_walk_rows(a, cfg->indptr64 != 0, cfg->rng_mode, lds, s)) {
         SG_LAUNCH_CHECK();
         return SUBGACC_OK;
     }

@@ -9,8 +9,6 @@ namespace subgacc {
 
 constexpr int kWalkThreads = 256;
 constexpr uint32_t kLcgA = 1103515245u, kLcgC = 12345u;
-constexpr uint32_t kPhiloxKey1 = 0x5355524Cu;  // "SURL"
-constexpr uint32_t kStreamShuffle = 0xFFFFFFFFu;
 constexpr int kNeighCap = 1000000;  // NEBMAX, subg_acc.c:13
 
 // ---------------------------------------------------------------------------------------- RNGs
@@ -34,19 +32,27 @@ __device__ __forceinline__ uint32_t rand_r_next(uint32_t &x) {
     r = (r << 10) ^ ((x >> 16) & 1023u);
     return r;
 }
-__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
-                                              uint32_t k1, uint32_t out[4]) {
+// Philox2x32-10 (same paper): ONE 32x32 multiply pair per round and two draws per call -- what a walk of up to three hops
+// needs after its first hop.  The walk kernels are bound by VALU issue (profiles/r02e_sq_*.csv: 85 % busy); the 4x32
+// form cost 72 vector instructions per walk, this one 30.
+__device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t k, uint32_t &o0, uint32_t &o1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
-        c0 = n0, c1 = l1, c2 = n2, c3 = l0;
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
+        const uint32_t hi = __umulhi(0xD256D193u, c0), lo = 0xD256D193u * c0;
+        c0 = hi ^ k ^ c1;
+        c1 = lo;
+        k += 0x9E3779B9u;
     }
-    out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+    o0 = c0, o1 = c1;
 }
+// Stream layout of rng = "philox" (the CPU checker restates it): key = seed, counter word 0 = root id, counter
+// word 1 = lane (walk number or shuffle position, < 2^20) | block << 20 (draws 2*block, 2*block+1) | tag << 28
+// (0: first hop without replacement, 1: every hop drawn) | shuffle-stream flag << 31.  A draw r picks index
+// (r * n) >> 32 below n: one multiply instead of the ~20 instructions of a 32-bit remainder (the rand_r mode keeps the
+// reference's %).
+constexpr int kPhiloxBlockShift = 20, kPhiloxTagShift = 28;
+constexpr uint32_t kPhiloxShuffle = 0x80000000u;
+__device__ __forceinline__ uint32_t philox_below(uint32_t r, uint32_t n) { return __umulhi(r, n); }
 
 // neighbour reads of the walk: SG_NT_NEIGH=1 marks them non-temporal (a random 4-byte read of `indices` pulls a line
 // that is rarely used again; streaming it keeps the row-pointer lines in L2) -- see tools/ab_walk.sh
@@ -97,7 +103,8 @@ struct WalkArgs {
     int64_t root_base;   // global index of query[0]: tags (root_base+i)*stride + rank order the first occurrences
 };
 
-constexpr int kSpgFold = 128;      // block-local table of the set's distinct LP keys
+constexpr int kSpgFoldBits = 7;
+constexpr int kSpgFold = 1 << kSpgFoldBits;   // block-local table of the set's distinct LP keys
 constexpr int kSpgPerLane = 4;     // members per lane kept in registers while LDS is re-used => M*m+1 <= 1024
 
 static inline int table_size_for(int64_t q) {
@@ -118,5 +125,7 @@ static inline size_t walk_lds_bytes(int T, int nwords, int M, int Q, bool spg, b
 
 // walk_pipe.hip: persistent software-pipelined form of the walk kernel; returns 1 when it took the launch
 int launch_walk_pipe(const WalkArgs &a, bool indptr64, int rng_mode, bool spg, size_t lds, hipStream_t s);
+// walk_rows.hip: the fused-row form specialised by hop count and table size; returns 1 when it took the launch
+int launch_walk_rows(const WalkArgs &a, bool indptr64, int rng_mode, size_t lds, hipStream_t s);
 
 }  // namespace subgacc

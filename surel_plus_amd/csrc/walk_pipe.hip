@@ -19,14 +19,21 @@
 // pushed this structure to ~110 VGPRs and half the residency -- takes walk_sets_kernel.
 // Measured (round 1): collab-like graph (L2 resident) 0.432 vs 0.463 ms, cit2-like 1.19 vs 1.16 ms (memory bound
 // either way).
+#include <stdlib.h>
 #include <type_traits>
 
 #include "walk_common.hpp"
 
+#ifndef SG_PIPE_MINW   // minimum waves per SIMD asked of the register allocator for the NT < 256 forms
+#define SG_PIPE_MINW 8
+#endif
+
 namespace subgacc {
 
-template <bool IDX64, int RNG, int MH>
-__global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) void walk_pipe_kernel(const WalkArgs a) {
+// NT lanes per workgroup, WPL = ceil(M / NT) walks per lane (their dependent loads are independent of each other and
+// all in flight together): NT = 128 / WPL = 2 puts twice as many roots on a CU in the same 32 wave slots.
+template <bool IDX64, int RNG, int MH, int NT, int WPL>
+__global__ __launch_bounds__(NT, NT == 256 ? 8 : SG_PIPE_MINW) __attribute__((amdgpu_num_sgpr(80))) void walk_pipe_kernel(const WalkArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     unsigned long long *pk = (unsigned long long *)lds_raw;     // [T]
     int32_t *keys = (int32_t *)(pk + a.T);                       // [T]
@@ -40,14 +47,16 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
     const int M = a.M, T = a.T;
     const uint32_t tmask = (uint32_t)T - 1u;
     const unsigned long long lead = 1ull << (MH * a.shift);
-    const bool walker = tid < M;                                 // one walk per lane
+    bool walker[WPL];                                            // walk tid + k*NT of the root
+#pragma unroll
+    for (int k = 0; k < WPL; ++k) walker[k] = tid + k * NT < M;
 
-    for (int h = tid; h < T; h += kWalkThreads) {                // the only full clear of the tables
+    for (int h = tid; h < T; h += NT) {                          // the only full clear of the tables
         keys[h] = -1;
         minq[h] = 0xFFFFFFFFu;
         pk[h] = 0ull;
     }
-    for (int x = tid; x < a.nwords; x += kWalkThreads) bitmap[x] = 0u;
+    for (int x = tid; x < a.nwords; x += NT) bitmap[x] = 0u;
     __syncthreads();
 
     // ------------------------------------------------------------------ state of the walk in flight ("B")
@@ -57,12 +66,16 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
     int64_t rbegB = 0;
     uint32_t rdegB = 0, rposB = 0, rseedB = a.seed;
     bool shufB = false;
-    int32_t visB[MH];
-    uint32_t xB = 0, phB[4];
-    int32_t pendN = 0;            // node whose load is in flight
-    int64_t pendB = 0, pendD = 0; // row (begin, degree) whose load is in flight
+    int32_t visB[WPL][MH];
+    uint32_t xB[WPL], phB[WPL][2];
+    int32_t pendN[WPL];            // node whose load is in flight
+    int64_t pendB[WPL], pendD[WPL]; // row (begin, degree) whose load is in flight
 #pragma unroll
-    for (int s = 0; s < MH; ++s) visB[s] = 0;
+    for (int k = 0; k < WPL; ++k) {
+        xB[k] = 0, pendN[k] = 0, pendB[k] = 0, pendD[k] = 0;
+#pragma unroll
+        for (int s = 0; s < MH; ++s) visB[k][s] = 0;
+    }
 
     bool sawBad = false;
     auto load_root = [&]() {      // block-uniform: every lane reads the same words
@@ -84,57 +97,67 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
         shufB = d64 > M;
     };
     auto draws_to_lds = [&]() {   // partial Fisher-Yates draws s_k = draw % (deg-k) + k (subg_acc.c:769-775)
-        if (walker) {
-            uint32_t r;
-            if (RNG == SUBGACC_RNG_RAND_R) {
-                uint32_t x = lcg_jump(rseedB, rposB + 3u * (uint32_t)tid);
-                r = rand_r_next(x);
-            } else {
-                uint32_t o[4];
-                philox4x32_10((uint32_t)rootB, (uint32_t)tid, kStreamShuffle, 0u, a.seed, kPhiloxKey1, o);
-                r = o[0];
+#pragma unroll
+        for (int k = 0; k < WPL; ++k)
+            if (walker[k]) {
+                const int w = tid + k * NT;
+                uint32_t r;
+                if (RNG == SUBGACC_RNG_RAND_R) {
+                    uint32_t x = lcg_jump(rseedB, rposB + 3u * (uint32_t)w);
+                    r = rand_r_next(x);
+                    sarr[w] = (int32_t)(r % (rdegB - (uint32_t)w)) + w;
+                } else {
+                    uint32_t o1;
+                    philox2x32_10((uint32_t)rootB, (uint32_t)w | kPhiloxShuffle, a.seed, r, o1);
+                    sarr[w] = (int32_t)philox_below(r, rdegB - (uint32_t)w) + w;
+                }
             }
-            sarr[tid] = (int32_t)(r % (rdegB - (uint32_t)tid)) + tid;
-        }
     };
     // step J of the chain of dependent loads of walk B.  J = 0: first hop; odd J: the node of hop (J+1)/2 has
     // arrived -> ask for its row; even J: the row has arrived -> draw, ask for the next node; J = 2*MH-1: last node.
     auto bstep = [&](auto jc) {
         constexpr int J = decltype(jc)::value;
-        if (!walker || rdegB == 0) return;
-        if constexpr (J == 0) {
-            uint32_t pick;
-            if (shufB) {
-                int32_t p = sarr[tid];
-                for (int j = tid - 1; j >= 0; --j)
-                    if (sarr[j] == p) p = j;
-                pick = (uint32_t)p;
-            } else {
-                pick = (uint32_t)tid % rdegB;
-            }
-            if (RNG == SUBGACC_RNG_RAND_R)
-                xB = lcg_jump(rseedB, rposB + 3u * ((shufB ? (uint32_t)M : 0u) + (uint32_t)tid * (uint32_t)(MH - 1)));
-            pendN = SG_NEIGH_LOAD(&a.indices[rbegB + pick]);
-        } else if constexpr (J % 2 == 1) {
-            constexpr int hop = (J - 1) / 2;          // 0-based hop whose node just arrived
-            visB[hop] = pendN;
-            if constexpr (hop + 1 < MH) load_row<IDX64>(a.indptr, pendN, pendB, pendD);
-        } else {
-            constexpr int hop = J / 2;                // hop being taken now (1-based index into the RNG stream - 1)
-            if (pendD > 0) {
-                uint32_t r;
-                if (RNG == SUBGACC_RNG_RAND_R) {
-                    r = rand_r_next(xB);
+        if (rdegB == 0) return;
+#pragma unroll
+        for (int k = 0; k < WPL; ++k) {
+            if (!walker[k]) continue;
+            const int w = tid + k * NT;
+            if constexpr (J == 0) {
+                uint32_t pick;
+                if (shufB) {
+                    int32_t p = sarr[w];
+                    for (int j = w - 1; j >= 0; --j)
+                        if (sarr[j] == p) p = j;
+                    pick = (uint32_t)p;
                 } else {
-                    constexpr int idx = hop - 1;
-                    if constexpr ((idx & 3) == 0)
-                        philox4x32_10((uint32_t)rootB, (uint32_t)tid, (uint32_t)(idx >> 2), 0u, a.seed, kPhiloxKey1, phB);
-                    r = phB[idx & 3];
+                    pick = (uint32_t)w % rdegB;
                 }
-                pendN = SG_NEIGH_LOAD(&a.indices[pendB + (int64_t)(r % (uint32_t)pendD)]);
+                if (RNG == SUBGACC_RNG_RAND_R)
+                    xB[k] = lcg_jump(rseedB, rposB + 3u * ((shufB ? (uint32_t)M : 0u) + (uint32_t)w * (uint32_t)(MH - 1)));
+                pendN[k] = SG_NEIGH_LOAD(&a.indices[rbegB + pick]);
+            } else if constexpr (J % 2 == 1) {
+                constexpr int hop = (J - 1) / 2;          // 0-based hop whose node just arrived
+                visB[k][hop] = pendN[k];
+                if constexpr (hop + 1 < MH) load_row<IDX64>(a.indptr, pendN[k], pendB[k], pendD[k]);
             } else {
-                pendN = visB[hop - 1];                // dead end: stay (the rand_r stream is then not reproducible)
-                if (RNG == SUBGACC_RNG_RAND_R) atomicOr(&a.flags[0], 1);
+                constexpr int hop = J / 2;                // hop being taken now (1-based index into the RNG stream - 1)
+                if (pendD[k] > 0) {
+                    uint32_t r;
+                    if (RNG == SUBGACC_RNG_RAND_R) {
+                        r = rand_r_next(xB[k]);
+                    } else {
+                        constexpr int idx = hop - 1;
+                        if constexpr ((idx & 1) == 0)
+                            philox2x32_10((uint32_t)rootB, (uint32_t)w | ((uint32_t)(idx >> 1) << kPhiloxBlockShift), a.seed,
+                                          phB[k][0], phB[k][1]);
+                        r = phB[k][idx & 1];
+                    }
+                    pendN[k] = SG_NEIGH_LOAD(&a.indices[pendB[k] + (int64_t)(RNG == SUBGACC_RNG_RAND_R ? r % (uint32_t)pendD[k]
+                                                                                                       : philox_below(r, (uint32_t)pendD[k]))]);
+                } else {
+                    pendN[k] = visB[k][hop - 1];          // dead end: stay (the rand_r stream is then not reproducible)
+                    if (RNG == SUBGACC_RNG_RAND_R) atomicOr(&a.flags[0], 1);
+                }
             }
         }
     };
@@ -164,9 +187,11 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
         const int64_t i = iB;
         const int32_t root = rootB;
         const bool isolated = rdegB == 0;
-        int32_t visA[MH];
+        int32_t visA[WPL][MH];
 #pragma unroll
-        for (int s = 0; s < MH; ++s) visA[s] = visB[s];
+        for (int k = 0; k < WPL; ++k)
+#pragma unroll
+            for (int s = 0; s < MH; ++s) visA[k][s] = visB[k][s];
         iB += gridDim.x;
         hasB = iB < a.n;
         if (hasB) {
@@ -186,18 +211,22 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
         }
         __syncthreads();                          // b0: root slot visible; B's Fisher-Yates draws visible
         SG_BSTEP(0);
-        if (!isolated && walker) {
+        if (!isolated) {
 #pragma unroll
-            for (int s = 0; s < MH; ++s) {
-                const int32_t cur = visA[s];
-                uint32_t h = ((uint32_t)cur * 2654435761u) >> a.tshift;
-                while (true) {
-                    const int32_t old = atomicCAS(&keys[h], -1, cur);
-                    if (old == -1 || old == cur) break;
-                    h = (h + 1u) & tmask;
+            for (int k = 0; k < WPL; ++k) {
+                if (!walker[k]) continue;
+#pragma unroll
+                for (int s = 0; s < MH; ++s) {
+                    const int32_t cur = visA[k][s];
+                    uint32_t h = ((uint32_t)cur * 2654435761u) >> a.tshift;
+                    while (true) {
+                        const int32_t old = atomicCAS(&keys[h], -1, cur);
+                        if (old == -1 || old == cur) break;
+                        h = (h + 1u) & tmask;
+                    }
+                    atomicMin(&minq[h], (uint32_t)((tid + k * NT) * MH + s + 1));
+                    atomicAdd(&pk[h], 1ull << ((MH - 1 - s) * a.shift));
                 }
-                atomicMin(&minq[h], (uint32_t)(tid * MH + s + 1));
-                atomicAdd(&pk[h], 1ull << ((MH - 1 - s) * a.shift));
             }
         }
         __syncthreads();                          // b1
@@ -218,14 +247,14 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
         }
 
         // ---- P2..P4: first-visit rank (the set_sampler output order), row write, tables handed back clean
-        for (int h = tid; h < T; h += kWalkThreads)
+        for (int h = tid; h < T; h += NT)
             if (keys[h] != -1) {
                 const uint32_t q = minq[h];
                 atomicOr(&bitmap[q >> 5], 1u << (q & 31u));
             }
         __syncthreads();                          // b2
         SG_BSTEP(2);
-        for (int x = tid; x <= a.nwords; x += kWalkThreads) {
+        for (int x = tid; x <= a.nwords; x += NT) {
             uint32_t s = 0;
             for (int j = 0; j < x; ++j) s += __popc(bitmap[j]);
             prefix[x] = s;
@@ -236,7 +265,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
         const int32_t ns = total < a.stride ? total : a.stride;
         // rank -> table slot first (LDS), then the row leaves with consecutive lanes on consecutive words: scattered
         // 4/8-byte stores cost the memory pipeline as much as the walk's random reads do
-        for (int h = tid; h < T; h += kWalkThreads)
+        for (int h = tid; h < T; h += NT)
             if (keys[h] != -1) {
                 const uint32_t q = minq[h];
                 const int32_t r = (int32_t)(prefix[q >> 5] + __popc(bitmap[q >> 5] & ((1u << (q & 31u)) - 1u)));
@@ -249,7 +278,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
                 }
             }
         __syncthreads();                          // b3': inv complete
-        for (int x = tid; x < ns; x += kWalkThreads) {
+        for (int x = tid; x < ns; x += NT) {
             const int h = inv[x];
             a.set_ids[obase + x] = keys[h];
             a.set_keys[obase + x] = pk[h] | (x == 0 ? lead : 0ull);
@@ -258,7 +287,7 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
             pk[h] = 0ull;
         }
         __syncthreads();                          // b4: tables clean again, bitmap no longer read
-        for (int x = tid; x < a.nwords; x += kWalkThreads) bitmap[x] = 0u;
+        for (int x = tid; x < a.nwords; x += NT) bitmap[x] = 0u;
         if (tid == 0) {
             a.nsize[i] = ns;
             if (total > a.stride) atomicAdd(&a.flags[1], 1);
@@ -270,15 +299,23 @@ __global__ __launch_bounds__(kWalkThreads) __attribute__((amdgpu_num_sgpr(80))) 
     if (sawBad && tid == 0) atomicOr(&a.flags[3], 16);
 }
 
-template <bool IDX64, int RNG>
-static int launch_hops(const WalkArgs &a, size_t lds, int grid, hipStream_t s) {
+template <bool IDX64, int RNG, int NT, int WPL>
+static int launch_hops(const WalkArgs &a, size_t lds, int per_cu, hipStream_t s) {
 #define SG_PIPE(MHH)                                                                                              \
     case MHH: {                                                                                                   \
+        const void *fn = (const void *)walk_pipe_kernel<IDX64, RNG, MHH, NT, WPL>;                                \
         if (lds > 64 * 1024 &&                                                                                    \
-            hipFuncSetAttribute((const void *)walk_pipe_kernel<IDX64, RNG, MHH>,                                  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)              \
+            hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)          \
             return 0;                                                                                             \
-        hipLaunchKernelGGL((walk_pipe_kernel<IDX64, RNG, MHH>), dim3((unsigned)grid), dim3(kWalkThreads), lds, s, \
+        /* the grid is exactly what stays resident (registers may admit fewer workgroups than LDS and wave slots) */ \
+        static int occ_lds = -1, occ = 0;                                                                         \
+        if (occ_lds != (int)lds) {                                                                                \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, NT, lds) != hipSuccess || occ < 1) occ = per_cu; \
+            occ_lds = (int)lds;                                                                                   \
+        }                                                                                                         \
+        int64_t grid = (int64_t)256 * (occ < per_cu ? occ : per_cu);                                              \
+        if (grid > a.n) grid = a.n;                                                                               \
+        hipLaunchKernelGGL((walk_pipe_kernel<IDX64, RNG, MHH, NT, WPL>), dim3((unsigned)grid), dim3(NT), lds, s,  \
                            a);                                                                                    \
         return 1;                                                                                                 \
     }
@@ -299,17 +336,26 @@ int launch_walk_pipe(const WalkArgs &a, bool indptr64, int rng_mode, bool spg, s
     // resident workgroups and made it 35 % slower than the plain form (measured, round 1).
     if (spg || !a.wo || a.step_major || a.walks || a.M > kWalkThreads || a.m < 1 || a.m > 6) return 0;
     if (lds > (size_t)kLdsBytes) return 0;
+    // lanes per workgroup: SUBGACC_PIPE_NT=64|128|256 (dev-only override)
+    static const int nt_env = getenv("SUBGACC_PIPE_NT") ? atoi(getenv("SUBGACC_PIPE_NT")) : 0;
+    const int nt = (nt_env == 64 || nt_env == 128 || nt_env == 256) ? nt_env : 256;
     int per_cu = (int)((size_t)kLdsBytes / lds);
-    if (per_cu > 8) per_cu = 8;                               // 32 waves per CU
+    const int slots = 32 / (nt / kWave);                      // 32 waves per CU
+    if (per_cu > slots) per_cu = slots;
     if (per_cu < 1) return 0;
-    int64_t grid = (int64_t)256 * per_cu;                     // every workgroup stays resident and strides over the roots
-    if (grid > a.n) grid = a.n;
     const bool rr = rng_mode == SUBGACC_RNG_RAND_R;
-    if (indptr64)
-        return rr ? launch_hops<true, SUBGACC_RNG_RAND_R>(a, lds, (int)grid, s)
-                  : launch_hops<true, SUBGACC_RNG_PHILOX>(a, lds, (int)grid, s);
-    return rr ? launch_hops<false, SUBGACC_RNG_RAND_R>(a, lds, (int)grid, s)
-              : launch_hops<false, SUBGACC_RNG_PHILOX>(a, lds, (int)grid, s);
+#define SG_PIPE_NT(NTT, WPLL)                                                                      \
+    do {                                                                                           \
+        if (indptr64)                                                                              \
+            return rr ? launch_hops<true, SUBGACC_RNG_RAND_R, NTT, WPLL>(a, lds, per_cu, s)     \
+                      : launch_hops<true, SUBGACC_RNG_PHILOX, NTT, WPLL>(a, lds, per_cu, s);    \
+        return rr ? launch_hops<false, SUBGACC_RNG_RAND_R, NTT, WPLL>(a, lds, per_cu, s)        \
+                  : launch_hops<false, SUBGACC_RNG_PHILOX, NTT, WPLL>(a, lds, per_cu, s);       \
+    } while (0)
+    if (nt == 64) SG_PIPE_NT(64, 4);
+    if (nt == 128) SG_PIPE_NT(128, 2);
+    SG_PIPE_NT(256, 1);
+#undef SG_PIPE_NT
 }
 
 }  // namespace subgacc

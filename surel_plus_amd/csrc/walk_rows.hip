@@ -1,0 +1,378 @@
+// walk_rows.hip -- the fused-row walk kernel, specialised (gfx950).
+//
+// walk_sets_kernel<SPG> (walk.hip) serves every configuration with one body: hop count, visit order, first-hop rule,
+// bucket truncation and table size are run-time values.  The SQ counters of round 2 (profiles/r02e_sq_cit2.csv) show what
+// that costs: 4,800 vector instructions per root, the vector ALUs 85 % busy, 240-320 `v_readlane` of scalar-register
+// spills (the kernel must stay under 80 SGPRs to keep 8 workgroups per CU) -- the kernel is bound by VALU issue as much
+// as by its random line fetches.  This file is the same algorithm for the shape every reference configuration with
+// walks of >= 3 hops has -- set_sampler order, first hop without replacement, no truncating bucket, M <= 256 walks, a
+// per-root table of 512 or 1,024 slots -- with the hop count MH and the slots per lane SPL as template parameters:
+//   * the walk is straight-line code (no step loop, no per-step mode tests), the later hops' Philox draws are issued
+//     while the first hop's neighbour is in flight, and each visit's LDS atomics run under the NEXT hop's row load;
+//   * a lane owns SPL consecutive table slots in the epilogue, read with 8/16-byte LDS loads;
+//   * the bucket sort takes its in-bucket arrival order from the histogram's returning atomic (one atomic pass, not two);
+//   * 32-bit compares / shifts wherever the 64-bit ones of the general kernel were only generality.
+// Bit-identical rows, sizes and table tags (tests/test_gpu_parity.py runs both forms against the oracle).
+#include <stdlib.h>
+
+#include "walk_common.hpp"
+
+namespace subgacc {
+
+// min / max over the 64 lanes of a wave (every lane returns the result)
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v) {
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d, kWave));
+    return v;
+}
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, kWave));
+    return v;
+}
+
+template <bool IDX64, int RNG, int MH, int SPL>
+__global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80))) void walk_rows_kernel(const WalkArgs a) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    constexpr int T = SPL * kWalkThreads;                         // 512 or 1,024 slots
+    constexpr int TSHIFT = SPL == 4 ? 22 : 23;                    // 32 - log2(T)
+    constexpr uint32_t TMASK = (uint32_t)T - 1u;
+    unsigned long long *pk = (unsigned long long *)lds_raw;      // [T] packed landing counts
+    int32_t *keys = (int32_t *)(pk + T);                          // [T] node ids
+    uint32_t *minq = (uint32_t *)(keys + T);                      // [T] first visit sequence number
+    int32_t *sarr = (int32_t *)(minq + T);                        // [M] Fisher-Yates draws
+    unsigned long long *fk = (unsigned long long *)(((uintptr_t)(sarr + a.M) + 7) & ~(uintptr_t)7);   // [kSpgFold]
+    uint32_t *ft = (uint32_t *)(fk + kSpgFold);                   // [kSpgFold] min visit number of the key inside the set
+    int32_t *fs = (int32_t *)(ft + kSpgFold);                     // [kSpgFold] HBM table slot of the key
+    int32_t *red = fs + kSpgFold;                                 // [16]
+
+    const int64_t i = xcd_item(blockIdx.x, gridDim.x);
+    if (i >= a.n) return;
+    const int tid = threadIdx.x;
+    const int M = a.M;
+    const int32_t root = a.query[i];
+    // while the root's two dependent loads (query -> row pointer) are in flight: clear what does not depend on them
+    if (SPL == 4) {
+        ((ulonglong2 *)pk)[2 * tid] = make_ulonglong2(0ull, 0ull);
+        ((ulonglong2 *)pk)[2 * tid + 1] = make_ulonglong2(0ull, 0ull);
+        ((uint4 *)minq)[tid] = make_uint4(~0u, ~0u, ~0u, ~0u);
+    } else {
+        ((ulonglong2 *)pk)[tid] = make_ulonglong2(0ull, 0ull);
+        ((uint2 *)minq)[tid] = make_uint2(~0u, ~0u);
+    }
+    if (tid < kSpgFold) {
+        fk[tid] = kEmptyKey;
+        ft[tid] = 0xFFFFFFFFu;
+    }
+    if (tid < 16) red[tid] = tid < 4 ? 0x7FFFFFFF : 0;   // [0..3] min id per wave, [4..7] max id, [8] member count
+    if ((uint64_t)(int64_t)root >= (uint64_t)a.num_nodes) {   // the reference would read out of bounds here
+        if (tid == 0) {
+            atomicOr(&a.flags[3], 16);
+            a.nsize[i] = 0;
+        }
+        return;
+    }
+    int64_t rbeg, rdeg64;
+    load_row<IDX64>(a.indptr, root, rbeg, rdeg64);
+    {   // keys, with the root already in its slot as member 0 (its minq = 0 is stored after the barrier-free clear above:
+        // same lane order is not guaranteed across waves, so the root's lane writes BOTH of its words here)
+        const uint32_t hroot = ((uint32_t)root * 2654435761u) >> TSHIFT;
+        const int x0 = tid * SPL;
+        if (SPL == 4) {
+            ((int4 *)keys)[tid] = make_int4((uint32_t)x0 == hroot ? root : -1, (uint32_t)(x0 + 1) == hroot ? root : -1,
+                                            (uint32_t)(x0 + 2) == hroot ? root : -1, (uint32_t)(x0 + 3) == hroot ? root : -1);
+        } else {
+            ((int2 *)keys)[tid] = make_int2((uint32_t)x0 == hroot ? root : -1, (uint32_t)(x0 + 1) == hroot ? root : -1);
+        }
+        if ((hroot / SPL) == (uint32_t)tid) minq[hroot] = 0u;     // the lane that cleared this word, after its clear
+    }
+    if (a.cap_root && rdeg64 > kNeighCap) rdeg64 = kNeighCap;
+    const int64_t obase = i * (int64_t)a.stride;
+    const unsigned long long lead = 1ull << (MH * a.shift);
+    const unsigned long long tag0 = (unsigned long long)((a.root_base + i) * (int64_t)a.stride);
+
+    if (rdeg64 == 0) {  // isolated root: one member, every count = M (subg_acc.c:753-761); id = the root
+        if (tid == 0) {
+            unsigned long long k = lead;
+            for (int s = 0; s < MH; ++s) k |= (unsigned long long)M << (s * a.shift);
+            a.set_ids[obase] = root;
+            a.set_slot[obase] = uniq_global_insert(a.table, k, tag0, a.flags);
+            a.nsize[i] = 1;
+        }
+        return;
+    }
+
+    uint32_t rpos = 0, rseed = a.seed;
+    if (RNG == SUBGACC_RNG_RAND_R) {
+        rpos = a.rng_pos[i];
+        rseed = a.rng_seed[i];
+    }
+    const bool shuffled = rdeg64 > M;
+    const uint32_t rdeg = (uint32_t)rdeg64;
+    if (shuffled && tid < M) {  // partial Fisher-Yates draws s_k = draw % (deg-k) + k  (subg_acc.c:769-775), one lane per k
+        uint32_t r;
+        if (RNG == SUBGACC_RNG_RAND_R) {
+            uint32_t x = lcg_jump(rseed, rpos + 3u * (uint32_t)tid);
+            r = rand_r_next(x);
+            sarr[tid] = (int32_t)(r % (rdeg - (uint32_t)tid)) + tid;
+        } else {
+            uint32_t o1;
+            philox2x32_10((uint32_t)root, (uint32_t)tid | kPhiloxShuffle, a.seed, r, o1);
+            sarr[tid] = (int32_t)philox_below(r, rdeg - (uint32_t)tid) + tid;
+        }
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ the walk: one lane per walk, straight-line
+    if (tid < M) {
+        uint32_t pick;
+        if (shuffled) {   // value the sequential swaps leave at position tid: follow the chain of earlier draws
+            int32_t p = sarr[tid];
+            for (int j = tid - 1; j >= 0; --j)
+                if (sarr[j] == p) p = j;
+            pick = (uint32_t)p;
+        } else {
+            pick = (uint32_t)tid % rdeg;
+        }
+        int32_t cur = SG_NEIGH_LOAD(&a.indices[rbeg + pick]);
+        uint32_t dr[MH > 1 ? 2 * (MH / 2) : 2];   // draws of hops 2..MH (Philox: computed while that load is in flight)
+        uint32_t x = 0;
+        if (RNG == SUBGACC_RNG_PHILOX) {
+#pragma unroll
+            for (int b = 0; 2 * b < MH - 1; ++b)
+                philox2x32_10((uint32_t)root, (uint32_t)tid | ((uint32_t)b << kPhiloxBlockShift), a.seed, dr[2 * b], dr[2 * b + 1]);
+        } else {
+            x = lcg_jump(rseed, rpos + 3u * ((shuffled ? (uint32_t)M : 0u) + (uint32_t)tid * (uint32_t)(MH - 1)));
+        }
+#pragma unroll
+        for (int s = 0; s < MH; ++s) {
+            int64_t b = 0, d = 0;
+            if (s + 1 < MH) load_row<IDX64>(a.indptr, cur, b, d);      // the next hop's row: in flight under the visit
+            {   // ---- visit: insert-or-find, first-visit sequence number, landing count
+                uint32_t h = ((uint32_t)cur * 2654435761u) >> TSHIFT;
+                while (true) {
+                    const int32_t old = atomicCAS(&keys[h], -1, cur);
+                    if (old == -1 || old == cur) break;
+                    h = (h + 1u) & TMASK;
+                }
+                atomicMin(&minq[h], (uint32_t)(tid * MH + s + 1));
+                atomicAdd(&pk[h], 1ull << ((MH - 1 - s) * a.shift));
+            }
+            if (s + 1 < MH) {
+                if (d > 0) {
+                    uint32_t off;
+                    if (RNG == SUBGACC_RNG_RAND_R) off = rand_r_next(x) % (uint32_t)d;
+                    else off = philox_below(dr[s], (uint32_t)d);
+                    cur = SG_NEIGH_LOAD(&a.indices[b + (int64_t)off]);
+                } else if (RNG == SUBGACC_RNG_RAND_R) {
+                    atomicOr(&a.flags[0], 1);  // dead end: the sequential stream is no longer reproducible
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ================= the set leaves as a finished SpG row =================
+    // (1) fold the set's LP keys (a few dozen distinct rows) and register them in the HBM table of distinct rows with
+    //     tag = (global root index)*stride + first visit number (any monotone function of the first-visit order numbers
+    //     the rows like the reference's sequential pass, subg_acc.c:957-978); (2) bucket-sort the members by node id in
+    //     the LDS the walk tables occupied (random_walks.py:79-80) and write them to their sorted position.
+    int32_t idv[SPL];
+    uint32_t mtag[SPL];
+    unsigned long long mkey[SPL];
+    if (SPL == 4) {
+        const int4 kk = ((const int4 *)keys)[tid];
+        const uint4 qq = ((const uint4 *)minq)[tid];
+        const ulonglong2 p0 = ((const ulonglong2 *)pk)[2 * tid], p1 = ((const ulonglong2 *)pk)[2 * tid + 1];
+        idv[0] = kk.x, idv[1] = kk.y, idv[SPL - 2] = kk.z, idv[SPL - 1] = kk.w;
+        mtag[0] = qq.x, mtag[1] = qq.y, mtag[SPL - 2] = qq.z, mtag[SPL - 1] = qq.w;
+        mkey[0] = p0.x, mkey[1] = p0.y, mkey[SPL - 2] = p1.x, mkey[SPL - 1] = p1.y;
+    } else {
+        const int2 kk = ((const int2 *)keys)[tid];
+        const uint2 qq = ((const uint2 *)minq)[tid];
+        const ulonglong2 p0 = ((const ulonglong2 *)pk)[tid];
+        idv[0] = kk.x, idv[1] = kk.y;
+        mtag[0] = qq.x, mtag[1] = qq.y;
+        mkey[0] = p0.x, mkey[1] = p0.y;
+    }
+    bool ok[SPL];
+    uint32_t mf[SPL];
+    int32_t slv[SPL];
+    int mycount = 0;
+    int32_t vmin = 0x7FFFFFFF, vmax = 0;
+#pragma unroll
+    for (int u = 0; u < SPL; ++u) {
+        ok[u] = idv[u] != -1;
+        mkey[u] |= (mtag[u] == 0 ? lead : 0ull);                 // the root is visit 0
+        mf[u] = fold_hash<kSpgFoldBits>(mkey[u]);
+        slv[u] = -1;
+        mycount += ok[u] ? 1 : 0;
+        vmin = min(vmin, ok[u] ? idv[u] : 0x7FFFFFFF);
+        vmax = max(vmax, ok[u] ? idv[u] : 0);
+    }
+    unsigned long long fcur[SPL];
+    uint32_t ftag[SPL];
+#pragma unroll
+    for (int u = 0; u < SPL; ++u) {
+        fcur[u] = fk[mf[u]];
+        ftag[u] = ft[mf[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < SPL; ++u) {   // a set holds a few dozen distinct keys -> mostly a hit right away
+        if (!ok[u]) continue;
+        const unsigned long long key = mkey[u];
+        const uint32_t tagoff = mtag[u];
+        if (fcur[u] == key) {
+            // most lanes meet a tag that is already smaller: the plain read (stale only towards larger values) spares
+            // the same-address atomic storm
+            if (ftag[u] > tagoff) atomicMin(&ft[mf[u]], tagoff);
+            slv[u] = -2 - (int32_t)mf[u];       // resolved to the HBM slot after the fold table is flushed
+            continue;
+        }
+        uint32_t f = mf[u];
+        bool done = false;
+        for (int p = 0; p < 16; ++p) {
+            unsigned long long cur = fk[f];
+            if (cur == kEmptyKey) cur = atomicCAS(&fk[f], kEmptyKey, key);
+            if (cur == kEmptyKey || cur == key) {
+                if (ft[f] > tagoff) atomicMin(&ft[f], tagoff);
+                slv[u] = -2 - (int32_t)f;
+                done = true;
+                break;
+            }
+            f = (f + 1) & (kSpgFold - 1);
+        }
+        if (!done) slv[u] = uniq_global_insert(a.table, key, tag0 + (unsigned long long)tagoff, a.flags);
+    }
+    {
+        vmin = wave_min_i32(vmin);
+        vmax = wave_max_i32(vmax);
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) mycount += __shfl_xor(mycount, d, kWave);
+        if ((tid & (kWave - 1)) == 0) {
+            red[tid / kWave] = vmin;
+            red[4 + tid / kWave] = vmax;
+            atomicAdd(&red[8], mycount);
+        }
+    }
+    __syncthreads();   // every lane holds its members in registers: the walk tables are free to be re-used
+    const int32_t ns = red[8];             // no truncating bucket here: every member stays (ns <= M*MH+1 = stride)
+    if (tid == 0) a.nsize[i] = ns;
+    const int32_t mn = min(min(red[0], red[1]), min(red[2], red[3]));
+    const int32_t mx = max(max(red[4], red[5]), max(red[6], red[7]));
+    unsigned long long *A = pk;                 // [ns] (id << 32 | slot) grouped by bucket
+    int32_t *start = keys;                      // [B+1] bucket counts, then their exclusive scan; B <= min(T/4, 256)
+    int logb = 0;
+    while ((1 << logb) < ns && (2 << logb) <= T / 4 && (2 << logb) <= kWalkThreads) ++logb;
+    const int B = 1 << logb;
+    const uint32_t range = (uint32_t)(mx - mn) + 1u;
+    const int Ls = (range <= 1u) ? 0 : (32 - __builtin_clz(range - 1u));
+    const int bshift = Ls > logb ? Ls - logb : 0;      // (id - mn) < 2^Ls, and ns <= range => logb <= Ls
+    if (tid <= B) start[tid] = 0;
+    if (tid < kSpgFold)    // flush the fold table to HBM (latency overlaps the sort)
+        if (fk[tid] != kEmptyKey) fs[tid] = uniq_global_insert(a.table, fk[tid], tag0 + ft[tid], a.flags);
+    __syncthreads();
+    uint32_t bk[SPL];
+    int32_t arr[SPL];                           // arrival order inside the bucket
+#pragma unroll
+    for (int u = 0; u < SPL; ++u) {
+        bk[u] = (uint32_t)(idv[u] - mn) >> bshift;
+        arr[u] = ok[u] ? atomicAdd(&start[bk[u]], 1) : 0;
+        if (slv[u] <= -2) slv[u] = fs[-2 - slv[u]];
+    }
+    __syncthreads();
+    {   // exclusive scan over the B <= 256 buckets, one bucket per lane: wave scan, then the wave totals through LDS
+        const int32_t c = tid < B ? start[tid] : 0;
+        int32_t inc = c;
+#pragma unroll
+        for (int dd = 1; dd < kWave; dd <<= 1) {
+            const int32_t t2 = __shfl_up(inc, dd, kWave);
+            if ((tid & (kWave - 1)) >= dd) inc += t2;
+        }
+        if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc;
+        __syncthreads();
+        int32_t base = 0;
+        for (int w2 = 0; w2 < tid / kWave; ++w2) base += red[12 + w2];
+        const int32_t excl = base + inc - c;
+        if (tid < B) start[tid] = excl;
+        if (tid == B - 1) start[B] = excl + c;
+    }
+    __syncthreads();
+    int blo[SPL], bhi[SPL];
+#pragma unroll
+    for (int u = 0; u < SPL; ++u) {   // bucket bounds, then the member goes to bucket start + arrival order
+        blo[u] = ok[u] ? start[bk[u]] : 0;
+        bhi[u] = ok[u] ? start[bk[u] + 1] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < SPL; ++u)
+        if (ok[u]) A[blo[u] + arr[u]] = ((unsigned long long)(uint32_t)idv[u] << 32) | (uint32_t)slv[u];
+    __syncthreads();
+    // order inside a bucket = number of smaller ids in it -> final position in the row.  The sorted row is assembled
+    // in LDS (ids over the dead minq table, slots behind the bucket offsets) and leaves with consecutive lanes on
+    // consecutive words.
+    int32_t *fin_id = (int32_t *)minq;          // [ns] <= T
+    int32_t *fin_sl = keys + B + 1;             // [ns] if it fits behind start[B+1]
+    const bool staged = ns + B + 1 <= T;
+    const uint32_t *Ahi = (const uint32_t *)A;
+#pragma unroll
+    for (int u = 0; u < SPL; ++u)
+        if (ok[u]) {
+            const int lo = blo[u], hi = bhi[u];
+            int rank = 0;       // ids are distinct within a set: the high word of A decides
+            for (int t2 = lo; t2 < hi; ++t2) rank += (Ahi[2 * t2 + 1] < (uint32_t)idv[u]) ? 1 : 0;
+            if (staged) {
+                fin_id[lo + rank] = idv[u];
+                fin_sl[lo + rank] = slv[u];
+            } else {
+                a.set_ids[obase + lo + rank] = idv[u];
+                a.set_slot[obase + lo + rank] = slv[u];
+            }
+        }
+    if (staged) {
+        __syncthreads();
+        for (int x = tid; x < ns; x += kWalkThreads) {
+            a.set_ids[obase + x] = fin_id[x];
+            a.set_slot[obase + x] = fin_sl[x];
+        }
+    }
+}
+
+// returns 1 when this specialised form took the launch (else the caller launches walk_sets_kernel<SPG>)
+int launch_walk_rows(const WalkArgs &a, bool indptr64, int rng_mode, size_t lds, hipStream_t s) {
+    static const bool off = getenv("SUBGACC_WALK_ROWS") && getenv("SUBGACC_WALK_ROWS")[0] == '0';
+    if (off) return 0;
+    if (!a.wo || a.step_major || a.walks || a.M > kWalkThreads || a.stride != a.M * a.m + 1) return 0;
+    if (a.m < 2 || a.m > 4 || (a.T != 512 && a.T != 1024)) return 0;
+    const int64_t grid = xcd_grid(a.n);
+    if (grid >= (1ll << 31)) return 0;
+    const bool rr = rng_mode == SUBGACC_RNG_RAND_R;
+#define SG_ROWS(I64, RNGM, MHH, SPLL)                                                                              \
+    do {                                                                                                           \
+        hipLaunchKernelGGL((walk_rows_kernel<I64, RNGM, MHH, SPLL>), dim3((unsigned)grid), dim3(kWalkThreads), lds, s, a); \
+        return 1;                                                                                                  \
+    } while (0)
+#define SG_ROWS_MH(I64, RNGM, SPLL)                      \
+    do {                                                 \
+        if (a.m == 2) SG_ROWS(I64, RNGM, 2, SPLL);       \
+        if (a.m == 3) SG_ROWS(I64, RNGM, 3, SPLL);       \
+        SG_ROWS(I64, RNGM, 4, SPLL);                     \
+    } while (0)
+#define SG_ROWS_SPL(I64, RNGM)                           \
+    do {                                                 \
+        if (a.T == 1024) SG_ROWS_MH(I64, RNGM, 4);       \
+        SG_ROWS_MH(I64, RNGM, 2);                        \
+    } while (0)
+    if (indptr64) {
+        if (rr) SG_ROWS_SPL(true, SUBGACC_RNG_RAND_R);
+        SG_ROWS_SPL(true, SUBGACC_RNG_PHILOX);
+    }
+    if (rr) SG_ROWS_SPL(false, SUBGACC_RNG_RAND_R);
+    SG_ROWS_SPL(false, SUBGACC_RNG_PHILOX);
+#undef SG_ROWS_SPL
+#undef SG_ROWS_MH
+#undef SG_ROWS
+    return 0;
+}
+
+}  // namespace subgacc

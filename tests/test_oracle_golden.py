@@ -29,6 +29,10 @@ def test_philox_known_answers():
     assert [hex(v) for v in oracle.philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344],
                                                  [0xa4093822, 0x299f31d0])] == \
         ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+    # ... and for philox2x32-10, the generator of the rng="philox" mode
+    assert [hex(v) for v in oracle.philox2x32_10([0, 0], 0)] == ["0xff1dae59", "0x6cd10df2"]
+    assert [hex(v) for v in oracle.philox2x32_10([0xFFFFFFFF] * 2, 0xFFFFFFFF)] == ["0x2c3f628b", "0xab4fd7ad"]
+    assert [hex(v) for v in oracle.philox2x32_10([0x243f6a88, 0x85a308d3], 0x13198a2e)] == ["0xdd7ce038", "0xf62a4c12"]
 
 
 @pytest.mark.parametrize("name", golden_files("gset_"))

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Dev-only: dynamic instruction counts of the fused walk kernel per phase -- variants that end every workgroup at stamp k
+# (-DSG_STOP_AFTER=k, results wrong by construction), one SQ counter pass each; cumulative counts per launch.
+#   tools/walk_insts.sh "0 2 3 4 5 6 7 8" [bench args]
+KS=$1; shift
+R=$GRAFT_REPO_ROOT
+cd $R/surel_plus_amd/csrc
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -ffp-contract=off"
+for K in $KS; do
+  ( /opt/rocm/bin/hipcc $FLAGS -DSG_STOP_AFTER=$K -c walk.hip -o /tmp/walk_s$K.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls build/*.o | grep -v -x -F -e build/walk.o) /tmp/walk_s$K.o -o /tmp/libsubgacc_s$K.so ) &
+done
+wait
+cd /tmp && export TMPDIR=/tmp
+for K in $KS full; do
+  if [ $K = full ]; then unset SUBGACC_LIB; else export SUBGACC_LIB=/tmp/libsubgacc_s$K.so; fi
+  rm -rf /tmp/pmc_s$K
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d /tmp/pmc_s$K/p -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-others "$@" > /tmp/pmc_s$K.json 2> /tmp/pmc_s$K.err
+  echo "== stop after stamp $K"
+  python3 $R/tools/pmc_mean.py /tmp/pmc_s$K | grep -E "^kernel|walk_"
+done
