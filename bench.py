@@ -287,6 +287,10 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
     sampler_mod.KERNEL_TIMER = timer
     last = None
     step_marks = []
+    # consecutive steps on alternating HIP streams (a serving loop may do that: the batches are independent).  Not what
+    # the timed region does -- its kernels run back to back on one stream, so that the HIP events around the walk kernel
+    # measure that kernel alone -- but reported next to it (config.two_stream_loop), outside the clock.
+    STREAMS = [torch.cuda.Stream(device=dev) for _ in range(2)] if os.environ.get("SUBGACC_STREAMS") == "2" else None
 
     def run_steps(step_ids):
         """Double-buffered serving loop: step s is queued before the sizes of step s-1 are read back (they travel to
@@ -296,7 +300,11 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
         pending = None
         for s in step_ids:
             e = edges[s % len(edges)]
-            queued = hot_path_step(sp, csr, e, M, k, seed=s, rng=rng, slot=s & 1)
+            if STREAMS is not None:      # SUBGACC_STREAMS=2 (experiment): consecutive steps on alternating streams
+                with torch.cuda.stream(STREAMS[s & 1]):
+                    queued = hot_path_step(sp, csr, e, M, k, seed=s, rng=rng, slot=s & 1)
+            else:
+                queued = hot_path_step(sp, csr, e, M, k, seed=s, rng=rng, slot=s & 1)
             if pending is not None:
                 xz, ind, sets = finish_step(*pending[1])
                 last = (pending[0], sets, xz)
@@ -347,6 +355,21 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
         torch.cuda.synchronize()
         csr_ms = (time.perf_counter() - t1) / max(K, 1) * 1e3
         last, STRIDED = keep_last, keep_strided
+    two_streams = None
+    if rank == 0 and world == 1 and STREAMS is None and last is not None:
+        keep_last = last
+        timer.enabled = False
+        STREAMS = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        for st_ in STREAMS:
+            st_.wait_stream(torch.cuda.current_stream(dev))
+        run_steps(range(4))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(range(W, W + K))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        two_streams = {"pairs_per_s": B * K / dt, "ms_per_step": dt / max(K, 1) * 1e3, "steps": K}
+        STREAMS, last = None, keep_last
     sampler_mod.KERNEL_TIMER = None
     if rank != 0:
         return None
@@ -357,6 +380,7 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
     abytes = algorithmic_walk_bytes(csr, edge.reshape(-1), sets, M, k - 1)   # the last step's launch
     achieved = abytes / (walk_ms * 1e-3) / 1e9 if walk_ms else None
     fused_rows = sets.data is not None or sets.strided
+    finished = timer.mean_ms("spg_build")[0] is not None and sets.strided    # rows came from the general kernel + finish_rows
     # HBM-side traffic / missed lines of the walk kernel: PMC passes (tools/pmc_traffic.py) of exactly these kernels
     # (matched by a hash of the kernel sources) and this configuration -- or null
     traffic = lines = None
@@ -380,13 +404,14 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
                    "J_pairs_per_s": (B / (1e-3 * join_ms)) if join_ms else None,
                    "fused_spg_rows": fused_rows, "spg_layout": "strided rows joined in place (no CSR copy of the batch)" if sets.strided else "csr",
                    "ms_per_step_with_a_packed_csr_spg_per_batch": csr_ms,
+                   "two_stream_loop": two_streams,
                    "device_allocs_in_timed_region": allocs_timed,
                    "host_step_ms_min_median_max": [round(1e3 * v, 3) for v in
                                                    (min(host_steps), sorted(host_steps)[len(host_steps) // 2], max(host_steps))]
                    if host_steps else None,
                    "stage_ms": {n_: timer.mean_ms(n_)[0] for n_ in
                                 ("walk_sets", "compact_sets", "uniq_rows", "spg_build", "sjoin_fill")}},
-        "roofline": {"bound": "hbm", "kernel": "walk_sets_kernel" + ("<SPG>" if fused_rows else ""),
+        "roofline": {"bound": "hbm", "kernel": sampler_mod.walk_kernel_name(csr, M, k - 1, fused_rows and not finished),
                      "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                      "kernel_ms": walk_ms, "launches_timed": launches, "algorithmic_bytes_per_launch": abytes,
@@ -454,7 +479,7 @@ def summary(o):
     """what an `other_workloads` entry keeps of a full line"""
     keep = {k_: o[k_] for k_ in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype")}
     keep["config"] = {k_: o["config"].get(k_) for k_ in ("workload", "pairs_per_step_per_gpu", "rng", "set_members_last_step",
-                                                         "distinct_lp_rows_last_step", "xz_rows_last_step", "graph_nnz", "spg_layout", "stage_ms", "spg_members",
+                                                         "distinct_lp_rows_last_step", "xz_rows_last_step", "graph_nnz", "spg_layout", "stage_ms", "two_stream_loop", "spg_members",
                                                          "offline_ppr_stage_s") if k_ in o["config"]}
     keep["roofline"] = o["roofline"]
     if "cpu_baseline" in o:

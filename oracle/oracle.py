@@ -385,6 +385,24 @@ def walk_join(walk, key, query, nthread=-1, return_idx=False):
     return [out, xrow] if return_idx else out
 
 
+def batch_sampler(ptr, neighs, query, num_walks=200, num_steps=8, thld=1000, seed_eff=111413):
+    """subg_acc.batch_sampler (subg_acc.c:391-507) with the rand_r state given outright: the reference starts from
+    seed + getpid(), pass that sum as `seed_eff`.  Returns int32[#unique] in insertion order."""
+    ptr = np.ascontiguousarray(ptr, np.int64)
+    neighs = np.ascontiguousarray(neighs, np.int32)
+    q = np.ascontiguousarray(np.asarray(query).astype(np.int32)).ravel()
+    n = q.size
+    cap = int(n * (num_walks * num_steps + 1)) + 1
+    cap = min(cap, int(ptr.size - 1) + 1)            # a set of node ids never exceeds the node count
+    out = np.empty(max(cap, 1), np.int32)
+    f = lib().orc_batch_sampler
+    f.restype = C.c_int64
+    rc = f(_p(ptr, C.c_int64), _p(neighs, C.c_int32), _p(q, C.c_int32), C.c_int64(n), C.c_int(num_walks), C.c_int(num_steps),
+           C.c_int(thld), C.c_uint32(int(seed_eff) & 0xFFFFFFFF), _p(out, C.c_int32), C.c_int64(out.size))
+    assert rc >= 0, rc
+    return out[:rc].copy()
+
+
 # ------------------------------------------------------------------ DEG / SPD encoders (utils.py:22-34) with SciPy
 def encoding_scipy(x, adj, encoding):
     """The reference's few lines of sparse algebra, executed by SciPy itself (utils.py cannot be imported here: its

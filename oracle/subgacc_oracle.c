@@ -867,3 +867,95 @@ int orc_walk_join(const int32_t *walk, int64_t n, int32_t stride, const int64_t 
     free(ent), free(roots);
     return 0;
 }
+
+/* ------------------------------------------------------------ batch_sampler
+ * Restates subg_acc/subg_acc.c:391-507 (legacy SUREL mini-batch former): the roots are walked one after the other with
+ * ONE rand_r stream, every visited node goes into one insertion-ordered set, and a root stops walking once the set holds
+ * (i+1)*thld/n nodes (checked after every walk, :474).  `seed_eff` is the state the reference builds as seed + getpid()
+ * (:421) -- the caller passes the sum, so a run of the reference in a known process can be reproduced.
+ * out (caller-allocated, out_cap entries) receives the nodes in insertion order; returns their number, or -1 when
+ * out_cap is too small, -2 on allocation failure.  A node without out-edges draws nothing (:466-471). */
+int64_t orc_batch_sampler(const int64_t *indptr, const int32_t *indices, const int32_t *query, int64_t n, int M, int S,
+                          int thld, uint32_t seed_eff, int32_t *out, int64_t out_cap)
+{
+    nodeset_t set;
+    if (nodeset_init(&set, out_cap))
+        return -2;
+    nodeset_clear(&set);
+    int64_t count = 0;
+    uint32_t state = seed_eff;
+    int32_t *rseq = NULL;
+    int64_t rcap = 0;
+    int64_t rc = 0;
+#define ORC_BATCH_ADD(v)                                 \
+    do                                                   \
+    {                                                    \
+        uint32_t h__ = nodeset_probe(&set, (v));         \
+        if (set.key[h__] == -1)                          \
+        {                                                \
+            if (count >= out_cap)                        \
+            {                                            \
+                rc = -1;                                 \
+                goto done;                               \
+            }                                            \
+            set.key[h__] = (v);                          \
+            out[count++] = (v);                          \
+        }                                                \
+    } while (0)
+    for (int64_t i = 0; i < n; ++i)
+    {
+        const int32_t root = query[i];
+        const int64_t rbeg = indptr[root];
+        const int32_t deg = (int32_t)(indptr[root + 1] - rbeg);
+        if (deg > M)
+        { /* partial Fisher-Yates over 0..deg-1 (:434-446) */
+            if (deg > rcap)
+            {
+                free(rseq);
+                rseq = (int32_t *)malloc(sizeof(int32_t) * (size_t)deg);
+                rcap = deg;
+                if (!rseq)
+                {
+                    rc = -2;
+                    goto done;
+                }
+            }
+            for (int32_t j = 0; j < deg; ++j)
+                rseq[j] = j;
+            for (int k = 0; k < M; ++k)
+            {
+                int32_t s = (int32_t)(orc_rand_r(&state) % (uint32_t)(deg - k)) + k;
+                int32_t t = rseq[k];
+                rseq[k] = rseq[s];
+                rseq[s] = t;
+            }
+        }
+        ORC_BATCH_ADD(root);
+        for (int w = 0; w < M; ++w)
+        {
+            int32_t cur = root;
+            if (deg < 1)
+                break;
+            cur = indices[rbeg + (deg <= M ? w % deg : rseq[w])];
+            ORC_BATCH_ADD(cur);
+            for (int step = 1; step < S; ++step)
+            {
+                const int64_t b = indptr[cur];
+                const int32_t d = (int32_t)(indptr[cur + 1] - b);
+                if (d > 0)
+                {
+                    cur = indices[b + (int64_t)(orc_rand_r(&state) % (uint32_t)d)];
+                    ORC_BATCH_ADD(cur);
+                }
+            }
+            if ((int)count >= (int)((i + 1) * thld / n))
+                break;
+        }
+    }
+    rc = count;
+done:
+#undef ORC_BATCH_ADD
+    free(rseq);
+    nodeset_free(&set);
+    return rc;
+}

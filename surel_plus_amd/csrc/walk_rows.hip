@@ -31,6 +31,22 @@ __device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
     return v;
 }
 
+#if defined(SG_STOP_AFTER)   // dynamic instruction counts per phase (tools/walk_insts.sh): the workgroup ends at stamp k (results are wrong)
+#define SG_RSTAMP(k)                                                                                         \
+    do {                                                                                                     \
+        if (SG_STOP_AFTER == (k)) {                                                                          \
+            if (threadIdx.x == 0) {      /* a well-formed one-member row, so that the rest of the step stays in bounds */ \
+                a.nsize[i] = 1;                                                                              \
+                a.set_ids[i * (int64_t)a.stride] = root;                                                     \
+                a.set_slot[i * (int64_t)a.stride] = 0;                                                       \
+            }                                                                                                \
+            return;                                                                                          \
+        }                                                                                                    \
+    } while (0)
+#else
+#define SG_RSTAMP(k)
+#endif
+
 template <bool IDX64, int RNG, int MH, int SPL>
 __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80))) void walk_rows_kernel(const WalkArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -122,6 +138,7 @@ __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80)
         }
     }
     __syncthreads();
+    SG_RSTAMP(0);
 
     // ------------------------------------------------------------------ the walk: one lane per walk, straight-line
     if (tid < M) {
@@ -171,6 +188,7 @@ __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80)
         }
     }
     __syncthreads();
+    SG_RSTAMP(2);
 
     // ================= the set leaves as a finished SpG row =================
     // (1) fold the set's LP keys (a few dozen distinct rows) and register them in the HBM table of distinct rows with
@@ -218,21 +236,25 @@ __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80)
         ftag[u] = ft[mf[u]];
     }
 #pragma unroll
-    for (int u = 0; u < SPL; ++u) {   // a set holds a few dozen distinct keys -> mostly a hit right away
+    for (int u = 0; u < SPL; ++u) {   // a set holds a few dozen distinct keys -> the first probe nearly always settles it
         if (!ok[u]) continue;
         const unsigned long long key = mkey[u];
         const uint32_t tagoff = mtag[u];
-        if (fcur[u] == key) {
+        unsigned long long cur = fcur[u];
+        // the reads above ran before anybody inserted: "empty" is claimed here, and losing the race to the same key is a hit
+        if (cur == kEmptyKey) cur = atomicCAS(&fk[mf[u]], kEmptyKey, key);
+        if (cur == kEmptyKey || cur == key) {
             // most lanes meet a tag that is already smaller: the plain read (stale only towards larger values) spares
             // the same-address atomic storm
             if (ftag[u] > tagoff) atomicMin(&ft[mf[u]], tagoff);
             slv[u] = -2 - (int32_t)mf[u];       // resolved to the HBM slot after the fold table is flushed
             continue;
         }
-        uint32_t f = mf[u];
+        uint32_t f = (mf[u] + 1) & (kSpgFold - 1);   // a real collision: probe on
         bool done = false;
-        for (int p = 0; p < 16; ++p) {
-            unsigned long long cur = fk[f];
+#pragma unroll 1
+        for (int p = 0; p < 15; ++p) {
+            cur = fk[f];
             if (cur == kEmptyKey) cur = atomicCAS(&fk[f], kEmptyKey, key);
             if (cur == kEmptyKey || cur == key) {
                 if (ft[f] > tagoff) atomicMin(&ft[f], tagoff);
@@ -256,6 +278,7 @@ __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80)
         }
     }
     __syncthreads();   // every lane holds its members in registers: the walk tables are free to be re-used
+    SG_RSTAMP(3);
     const int32_t ns = red[8];             // no truncating bucket here: every member stays (ns <= M*MH+1 = stride)
     if (tid == 0) a.nsize[i] = ns;
     const int32_t mn = min(min(red[0], red[1]), min(red[2], red[3]));
@@ -272,6 +295,7 @@ __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80)
     if (tid < kSpgFold)    // flush the fold table to HBM (latency overlaps the sort)
         if (fk[tid] != kEmptyKey) fs[tid] = uniq_global_insert(a.table, fk[tid], tag0 + ft[tid], a.flags);
     __syncthreads();
+    SG_RSTAMP(4);
     uint32_t bk[SPL];
     int32_t arr[SPL];                           // arrival order inside the bucket
 #pragma unroll
@@ -281,6 +305,7 @@ __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80)
         if (slv[u] <= -2) slv[u] = fs[-2 - slv[u]];
     }
     __syncthreads();
+    SG_RSTAMP(5);
     {   // exclusive scan over the B <= 256 buckets, one bucket per lane: wave scan, then the wave totals through LDS
         const int32_t c = tid < B ? start[tid] : 0;
         int32_t inc = c;
@@ -298,6 +323,7 @@ __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80)
         if (tid == B - 1) start[B] = excl + c;
     }
     __syncthreads();
+    SG_RSTAMP(6);
     int blo[SPL], bhi[SPL];
 #pragma unroll
     for (int u = 0; u < SPL; ++u) {   // bucket bounds, then the member goes to bucket start + arrival order
@@ -308,6 +334,7 @@ __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80)
     for (int u = 0; u < SPL; ++u)
         if (ok[u]) A[blo[u] + arr[u]] = ((unsigned long long)(uint32_t)idv[u] << 32) | (uint32_t)slv[u];
     __syncthreads();
+    SG_RSTAMP(7);
     // order inside a bucket = number of smaller ids in it -> final position in the row.  The sorted row is assembled
     // in LDS (ids over the dead minq table, slots behind the bucket offsets) and leaves with consecutive lanes on
     // consecutive words.
@@ -320,6 +347,7 @@ __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80)
         if (ok[u]) {
             const int lo = blo[u], hi = bhi[u];
             int rank = 0;       // ids are distinct within a set: the high word of A decides
+#pragma unroll 1         // a bucket holds one to a handful of members: an unrolled loop is all prologue
             for (int t2 = lo; t2 < hi; ++t2) rank += (Ahi[2 * t2 + 1] < (uint32_t)idv[u]) ? 1 : 0;
             if (staged) {
                 fin_id[lo + rank] = idv[u];

@@ -299,6 +299,18 @@ def _rng_positions(L, cfg, csr, q, n, rng_streams, calls_before, st):
     return rng_pos, rng_seed
 
 
+def walk_kernel_name(csr, num_walks, hops, fused_rows):
+    """which kernel a sample_sets(...) launch of this shape runs (set_sampler form; csrc/walk.hip:launch_walk decides):
+    reporting only -- bench.py labels its roofline block with it"""
+    q = num_walks * hops + 1
+    t = 64
+    while t < q + q // 4 + 1:
+        t <<= 1
+    if fused_rows:
+        return "walk_rows_kernel" if (2 <= hops <= 4 and t in (512, 1024) and num_walks <= 256) else "walk_sets_kernel<SPG>"
+    return "walk_pipe_kernel" if (num_walks <= 256 and 1 <= hops <= 6) else "walk_sets_kernel"
+
+
 def _cat(parts, dtype, dev):
     parts = [p_ for p_ in parts if p_ is not None]
     if not parts:

@@ -151,10 +151,11 @@ FUSED_MIN_GRAPH_BYTES = 64 << 20     # adjacency beyond this no longer lives in 
 
 
 def prefers_fused(csr, hops):
-    """Is the fused-row walk kernel the faster way to the finished rows of a batch?  Walks of >= 3 hops: yes (cit2-like
-    1.90 vs 2.33 ms per step).  2-hop walks: the pipelined general kernel + finish_rows wins on a cache-resident graph
-    (collab-like 1.14 vs 1.37 ms) and ties beyond the caches (twitter-like 2.10 vs 2.12 ms)."""
-    return hops >= 3
+    """Is the fused-row walk kernel the faster way to the finished rows of a batch?  From 2 hops on: yes -- the specialised
+    kernel (csrc/walk_rows.hip) beats the pipelined general kernel + finish_rows on the twitter-like graph (1.89 vs 1.99 ms
+    per step, 2 hops), ties on the L2-resident collab-like one (1.05 vs 1.06 ms) and wins clearly at 3 hops (cit2-like
+    1.73 vs 2.21 ms).  1-hop walks keep the general pair (walk_rows is not instantiated for them)."""
+    return hops >= 2
 
 
 def sample_spg(csr, query, num_walks=200, num_steps=3, seed=111413, rng="rand_r", bucket=-1, fused=None, lazy=False,
@@ -163,9 +164,8 @@ def sample_spg(csr, query, num_walks=200, num_steps=3, seed=111413, rng="rand_r"
 
     `num_steps` = walk hops (gset_sampler's meaning).  fused=True lets the walk kernel emit finished SpG rows
     (csrc/walk.hip SPG mode; falls back to the general pipeline when it does not apply); fused=None asks
-    prefers_fused(): walks of >= 3 hops, or any walk over a graph far beyond the caches -- there the per-root epilogue
-    hides behind the walk's line fetches (measured: cit2-like, 3 hops +10 % pairs/s; twitter-like, 2 hops +5 %;
-    collab-like, 2 hops, an 8 MB graph that lives in L2: -5 %).  lazy=True leaves every size on the
+    prefers_fused(): walks of >= 2 hops (measured: cit2-like, 3 hops +28 % pairs/s; twitter-like, 2 hops +5 %;
+    collab-like, 2 hops, an 8 MB graph that lives in L2: +1 %).  lazy=True leaves every size on the
     device (no host round trip until SampledSets.resolve() / SpG.nnz); arrays are capacity-sized.  A lazy batch cannot
     recover by itself from a table of distinct LP rows that is too small (`uniq_capacity`, or more than
     sampler.RANK_LIMIT distinct rows): resolve() raises SubgAccError then and the batch is sampled again with

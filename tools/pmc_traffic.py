@@ -29,7 +29,7 @@ walk = None
 for _, k, n, m in sorted(rows)[:10]:
     hbm = (2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024
     print(f"\"{k}\",{n},{m['FETCH_SIZE']:.0f},{m['WRITE_SIZE']:.0f},{m.get('TCC_REQ_sum', 0):.0f},{m.get('TCC_HIT_sum', 0):.0f},{m.get('TCC_MISS_sum', 0):.0f},{hbm:.0f}")
-    if walk is None and (k.startswith("walk_sets_kernel") or k.startswith("walk_pipe_kernel") or k.startswith("walk_wave_kernel")):
+    if walk is None and (k.startswith("walk_sets_kernel") or k.startswith("walk_rows_kernel") or k.startswith("walk_pipe_kernel") or k.startswith("walk_wave_kernel")):
         walk = (k, hbm, m.get("TCC_MISS_sum", 0), m.get("TCC_REQ_sum", 0), n)
 # the bench line of one of the passes tells the configuration (workload, B, M, k, layout, rng)
 line = None
