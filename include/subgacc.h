@@ -321,6 +321,24 @@ int subgacc_walk_join(const int32_t *walks, int64_t n, int32_t stride, const int
                       const int32_t *set_idx, int32_t max_len, const int32_t *qrow, int64_t Q, int32_t *out,
                       void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * batch_sampler of the legacy SUREL surface (subg_acc/subg_acc.c:391-507): one insertion-ordered set of nodes grown by
+ * walking the roots one after the other (num_walks walks of num_steps nodes each, first hop without replacement,
+ * one rand_r stream); root i stops walking once the set holds (i+1)*thld/n nodes (:474).
+ *   seed_eff   the state the reference starts from: its `seed` argument + getpid() (:421)
+ *   out        int32 [out_cap] nodes in insertion order; *out_count (device) receives their number.
+ *              A sufficient out_cap is min(num_nodes, n*(num_walks*num_steps+1)).  flags[1] |= 1 when it was too small,
+ *              flags[0] |= 1 when a walk reached a node without out-edges (the stream position of the later walks is then
+ *              data dependent and not reproduced), flags[3] |= 16 for a root outside [0, num_nodes) (skipped).
+ *   workspace  subgacc_batch_sampler_workspace_bytes(out_cap) bytes (the set's hash table)
+ * One workgroup: the loop over roots is sequential by definition; walks, dedup and ordering inside a root are parallel.
+ * ------------------------------------------------------------------------------------------- */
+size_t subgacc_batch_sampler_workspace_bytes(int64_t out_cap);
+int subgacc_batch_sampler(const void *indptr, int32_t indptr64, const int32_t *indices, int64_t num_nodes,
+                          const int32_t *query, int64_t n, int32_t num_walks, int32_t num_steps, int32_t thld,
+                          uint32_t seed_eff, int32_t *out, int64_t out_cap, int64_t *out_count, void *workspace,
+                          size_t workspace_bytes, int32_t *flags, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,10 @@ GPU box.  The fixtures it writes are data only: seeded inputs and the outputs th
   G5  hjoin_*.npz   train.hgather                                      train.py:48-72
   G6  rand_r.npz    glibc rand_r streams (libc.so.6 via ctypes), the RNG the reference calls
   G7  walkjoin_*.npz subg_acc.walk_join over walk_sampler's output (legacy SUREL join)  subg_acc/subg_acc.c:509-647
+  G8  batch_*.npz   subg_acc.batch_sampler (legacy SUREL mini-batch former); the reference seeds it with seed + getpid()
+                    (:421), so every fixture records the effective seed of the run that made it   subg_acc/subg_acc.c:391-507
+
+`python oracle/gen_golden.py [rand_r gset walk sjoin walkjoin batch]` regenerates the named groups (default: all).
 """
 import ctypes
 import os
@@ -194,6 +198,30 @@ def gen_walkjoin():
                             key_ids=np.concatenate(list(obj[:, 0])).astype(np.int32), query=q.astype(np.int32), out=out, xrow=xrow)
 
 
+def gen_batch():
+    """G8  batch_*.npz  subg_acc.batch_sampler   subg_acc/subg_acc.c:391-507"""
+    cases = {  # name: (N, E, graph seed, star, n roots, M, S, thld, seed)
+        "small": (300, 900, 3, 0, 24, 20, 4, 150, 7),
+        "hub": (500, 1500, 5, 120, 16, 30, 5, 400, 11),        # root 0 has degree > M: the Fisher-Yates first hop
+        "early": (400, 2400, 8, 0, 40, 50, 8, 60, 111413),      # a small threshold: most roots stop after one walk
+        "all": (250, 1000, 2, 0, 10, 8, 3, 100000, 5),          # a threshold nobody reaches: every walk is taken
+        "dup": (200, 800, 9, 0, 30, 12, 6, 120, 3),             # repeated roots
+    }
+    for name, (N, E, gs, star, n, M, S, thld, seed) in cases.items():
+        ptr, idx = sym_graph(N, E, gs, star=star, isolated=2)
+        rng = np.random.default_rng(gs)
+        roots = rng.permutation(N)[:n].astype(np.int32)
+        if name == "hub":
+            roots[3] = 0
+        if name == "dup":
+            roots[10:20] = roots[:10]
+        if name == "small":
+            roots[5] = N          # an isolated node (degree 0): only the root is added (:457-460)
+        out = ref.batch_sampler(ptr, idx, roots, num_walks=M, num_steps=S, thld=thld, seed=seed)
+        np.savez_compressed(os.path.join(OUT, f"batch_{name}.npz"), indptr=ptr, indices=idx, query=roots, M=M, S=S, thld=thld,
+                            seed_eff=np.uint32((seed + os.getpid()) & 0xFFFFFFFF), out=out.astype(np.int32))
+
+
 def gen_rand_r():
     libc = ctypes.CDLL("libc.so.6")
     libc.rand_r.restype = ctypes.c_int
@@ -206,10 +234,9 @@ def gen_rand_r():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gen_rand_r()
-    gen_gset()
-    gen_walk()
-    gen_sjoin()
-    gen_walkjoin()
+    groups = {"rand_r": gen_rand_r, "gset": gen_gset, "walk": gen_walk, "sjoin": gen_sjoin, "walkjoin": gen_walkjoin,
+              "batch": gen_batch}
+    for g in (sys.argv[1:] or list(groups)):
+        groups[g]()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"wrote {len(os.listdir(OUT))} fixtures, {tot / 1024:.0f} KiB -> {OUT}")

@@ -15,7 +15,7 @@ import torch
 from . import _lib
 from .sampler import DeviceCSR, sample_sets
 
-__all__ = ["gset_sampler", "walk_sampler", "walk_join", "add", "sjoin"]
+__all__ = ["gset_sampler", "walk_sampler", "walk_join", "batch_sampler", "add", "sjoin"]
 
 
 def _csr_from_host(indptr, indices):
@@ -135,6 +135,49 @@ def walk_join(walk, key, query, nthread=-1, return_idx=False):
                                   ptr(out), st))
     out = out.cpu().numpy()
     return [out, qrow.cpu().numpy()] if return_idx else out
+
+
+def batch_sampler(ptr, neighs, query, num_walks=200, num_steps=8, thld=1000, nthread=-1, seed=111413, pid=None):
+    """subg_acc.c:391-507 (legacy SUREL mini-batch former).  Returns int32 [#unique]: the nodes met by walking the roots
+    one after the other (first hop without replacement, num_steps nodes per walk), in order of first appearance; root i
+    stops walking once the set holds (i+1)*thld/n nodes.  As in the reference the rand_r stream starts from
+    seed + getpid() (:421) -- results differ from process to process by design; `pid` (extension) pins that term so that a
+    run can be reproduced (`pid=0`: the stream starts from `seed` itself).  `nthread` is accepted and unused, as in the
+    reference (the loop is sequential there too).  The graph must have no reachable dead ends (SubgAccError otherwise:
+    a node without out-edges draws nothing, which makes every later position of the stream data dependent)."""
+    import os
+
+    from ._lib import check, lib, stream_ptr
+    from ._lib import ptr as dptr
+    csr = ptr if isinstance(ptr, DeviceCSR) else _csr_from_host(ptr, neighs)
+    if num_walks <= 0 or num_steps <= 0:
+        raise TypeError("Input parsing error. (num_walks and num_steps must be positive)")
+    dev = csr.device
+    if torch.is_tensor(query):
+        q = query.to(device=dev, dtype=torch.int32).contiguous().view(-1)
+    else:
+        q = torch.from_numpy(np.ascontiguousarray(np.asarray(_checked_query(query, csr.num_nodes)).astype(np.int32)).ravel()).to(dev)
+    n = q.numel()
+    seed_eff = (int(seed) + (os.getpid() if pid is None else int(pid))) & 0xFFFFFFFF
+    # every walk adds at most num_steps nodes and a root stops at (i+1)*thld/n: |set| <= thld + n*(num_steps+1)
+    cap = max(1, min(csr.num_nodes, n * (int(num_walks) * int(num_steps) + 1), max(int(thld), 0) + n * (int(num_steps) + 1) + 1))
+    L = lib()
+    out = torch.empty(cap, dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    flags = torch.zeros(4, dtype=torch.int32, device=dev)
+    ws = torch.empty(L.subgacc_batch_sampler_workspace_bytes(cap), dtype=torch.uint8, device=dev)
+    check(L.subgacc_batch_sampler(dptr(csr.indptr), 1 if csr.indptr64 else 0, dptr(csr.indices), csr.num_nodes, dptr(q), n,
+                                  int(num_walks), int(num_steps), int(thld), seed_eff, dptr(out), cap, dptr(count), dptr(ws),
+                                  ws.numel(), dptr(flags), stream_ptr()))
+    st = torch.cat([flags.long(), count]).tolist()
+    if st[3] & 16:
+        raise IndexError("query node ids outside [0, num_nodes) (the reference reads out of bounds for them)")
+    if st[0]:
+        raise _lib.SubgAccError("batch_sampler: a walk reached a node without out-edges; the sequential rand_r stream cannot "
+                                "be reproduced on such a graph (the reference's graphs are symmetrised, dataloader.py:122-135)")
+    if st[1]:
+        raise _lib.SubgAccError("batch_sampler: output capacity exceeded (internal sizing error)")
+    return out[: st[4]].cpu().numpy()
 
 
 def add(i, j):

@@ -1054,3 +1054,40 @@ def test_finished_rows_from_the_general_walk_kernel_match_oracle(sp, rng, M, m, 
     oxz, oind = oracle.gather(edge, (oi, od, ov), ptr=True, encode=table)
     xz, ind = sp.gather(edge, z, None, ptr=True, encode=z.slot_table())
     assert np.array_equal(ind.cpu().numpy(), oind) and np.array_equal(xz.cpu().numpy(), oxz)
+
+
+# ------------------------------------------------------------------------------- batch_sampler (legacy SUREL mini-batches)
+@pytest.mark.parametrize("name", golden_files("batch_"))
+def test_batch_sampler_matches_reference_golden(sp, name):
+    """subg_acc.c:391-507; the fixture records the effective seed (seed + getpid()) of the reference run that made it"""
+    g = _load(name)
+    out = sp.batch_sampler(g["indptr"], g["indices"], g["query"], num_walks=int(g["M"]), num_steps=int(g["S"]),
+                           thld=int(g["thld"]), seed=int(g["seed_eff"]), pid=0)
+    assert out.dtype == np.int32
+    np.testing.assert_array_equal(out, g["out"])
+
+
+def test_batch_sampler_vs_oracle_and_its_process_seed(sp):
+    indptr, indices = sym_graph(20000, 120000, 17, hubs=2)          # hubs: degree > num_walks -> Fisher-Yates first hops
+    rng = np.random.default_rng(5)
+    for n, M, S, thld in ((64, 200, 8, 1000), (700, 50, 4, 5000), (33, 300, 6, 20000), (5, 7, 1, 10), (1, 1, 1, 1)):
+        q = rng.integers(0, 20000, n).astype(np.int32)
+        q[0] = 0                                                     # a hub root
+        for seed in (111413, 3):
+            out = sp.batch_sampler(indptr, indices, q, num_walks=M, num_steps=S, thld=thld, seed=seed, pid=12345)
+            ref_ = oracle.batch_sampler(indptr, indices, q, num_walks=M, num_steps=S, thld=thld, seed_eff=seed + 12345)
+            np.testing.assert_array_equal(out, ref_)
+    # pid=None: the reference's seed + getpid() (subg_acc.c:421)
+    out = sp.batch_sampler(indptr, indices, q, num_walks=9, num_steps=3, thld=50, seed=1)
+    np.testing.assert_array_equal(out, oracle.batch_sampler(indptr, indices, q, num_walks=9, num_steps=3, thld=50,
+                                                            seed_eff=1 + os.getpid()))
+    # int64 row offsets, device-resident graph, a root out of range, a graph with a dead end
+    from surel_plus_amd import DeviceCSR
+    csr64 = DeviceCSR(indptr.astype(np.int64), indices)
+    out64 = sp.batch_sampler(csr64, None, q, num_walks=9, num_steps=3, thld=50, seed=1)
+    np.testing.assert_array_equal(out64, out)
+    with pytest.raises(IndexError):
+        sp.batch_sampler(indptr, indices, np.array([1, 20000]), num_walks=4, num_steps=2)
+    dp = np.array([0, 1, 1], np.int32)                               # 0 -> 1, node 1 has no out-edges
+    with pytest.raises(sp.SubgAccError, match="out-edges"):
+        sp.batch_sampler(dp, np.array([1], np.int32), np.array([0]), num_walks=2, num_steps=3)

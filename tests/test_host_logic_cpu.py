@@ -49,6 +49,12 @@ def test_signatures_mirror_the_reference_module():
     assert list(w)[:8] == ["ptr", "neighs", "query", "num_walks", "num_steps", "nthread", "seed", "replacement"]
     assert (w["num_walks"].default, w["num_steps"].default, w["seed"].default, w["replacement"].default) == \
         (100, 3, 111413, False)
+    b = inspect.signature(mirror.batch_sampler).parameters      # kwlist of subg_acc.c:397, defaults of :395
+    assert list(b)[:8] == ["ptr", "neighs", "query", "num_walks", "num_steps", "thld", "nthread", "seed"]
+    assert (b["num_walks"].default, b["num_steps"].default, b["thld"].default, b["nthread"].default, b["seed"].default) == \
+        (200, 8, 1000, -1, 111413)
+    j = inspect.signature(mirror.walk_join).parameters          # kwlist of subg_acc.c:515
+    assert list(j) == ["walk", "key", "query", "nthread", "return_idx"]
     assert mirror.add(3, 4) == 3 * 2 + 4 * 7                    # subg_acc.c:116
     assert not hasattr(mirror, "run")                            # the system() wrapper is deliberately absent
     # train.py:13,48,75,88
@@ -60,6 +66,7 @@ def test_signatures_mirror_the_reference_module():
     assert list(inspect.signature(sp.subg_matrix).parameters)[:4] == ["G", "train_idx", "num_walks", "num_steps"]
     import subg_acc as top                                       # the drop-in module name
     assert top.gset_sampler is mirror.gset_sampler and top.walk_sampler is mirror.walk_sampler
+    assert top.batch_sampler is mirror.batch_sampler and top.walk_join is mirror.walk_join
 
 
 def test_synthetic_graph_is_symmetric_simple_and_sorted():

@@ -122,3 +122,14 @@ def test_oracle_walk_join_matches_reference(name):
     np.testing.assert_array_equal(xrow, g["xrow"])
     np.testing.assert_array_equal(out, g["out"])
     assert out.dtype == g["out"].dtype and out.shape == g["out"].shape
+
+
+# ------------------------------------------------------------------------------- batch_sampler (legacy SUREL mini-batches)
+@pytest.mark.parametrize("name", golden_files("batch_"))
+def test_oracle_batch_sampler_matches_reference(name):
+    """the reference seeds with seed + getpid() (subg_acc.c:421): the fixture carries the effective seed of its run"""
+    g = np.load(os.path.join(GOLDEN, name))
+    out = oracle.batch_sampler(g["indptr"], g["indices"], g["query"], num_walks=int(g["M"]), num_steps=int(g["S"]),
+                               thld=int(g["thld"]), seed_eff=int(g["seed_eff"]))
+    assert out.dtype == np.int32 and np.array_equal(out, g["out"])
+    assert len(set(out.tolist())) == len(out) and out[0] == g["query"][0]

@@ -5,6 +5,7 @@ fixtures: random graphs (isolated nodes, star hubs, K2 components), random M / m
     gset_sampler  nthread=1 (the only reproducible setting, subg_acc.c:731-732)        subg_acc.c:649-1034
     walk_sampler  nthread 1..8, both first-hop modes                                   subg_acc.c:316-389
     walk_join     over walk_sampler's own output                                       subg_acc.c:509-647
+    batch_sampler seeded with seed + getpid() by the reference (:421): same process, so the sum is known   subg_acc.c:391-507
 
 Skips cleanly where oracle/_ref does not exist (the GPU box may or may not carry it; nothing here needs a GPU).
 Every case has its own seeded stream: a failing case number reproduces alone."""
@@ -125,3 +126,20 @@ def test_walk_sampler_and_walk_join_random_sweep(block, capfd):
         assert np.array_equal(oout, out) and np.array_equal(oxrow, xrow), what
     ctypes.CDLL(None).fflush(None)
     capfd.readouterr()
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_batch_sampler_random_sweep(block):
+    import os
+    for case in range(block * CASES // 4, (block + 1) * CASES // 4):
+        rng = np.random.default_rng(30_000 + case)
+        ptr, idx = rand_graph(rng)
+        N = len(ptr) - 1
+        q = rand_query(rng, N).astype(np.int32)
+        M = int(rng.integers(1, 60))
+        S = int(rng.integers(1, 10))
+        thld = int(rng.integers(1, 4 * N))
+        seed = int(rng.integers(0, 2**30))
+        r = ref.batch_sampler(ptr, idx, q, num_walks=M, num_steps=S, thld=thld, seed=seed)
+        o = oracle.batch_sampler(ptr, idx, q, num_walks=M, num_steps=S, thld=thld, seed_eff=seed + os.getpid())
+        assert np.array_equal(o, r), f"case {case}: N={N} n={len(q)} M={M} S={S} thld={thld} seed={seed}"
