@@ -440,20 +440,26 @@ def batch_size_and_graph(sp, csr, M, k, rng, K):
     from surel_plus_amd.graphs import query_pairs
     out = {}
     for B in (1024, 65536):
-        steps = max(K, 20) if B == 1024 else K
+        steps = max(K, 40) if B == 1024 else K
         edges = [query_pairs(csr, B, seed=7000 + s, device=csr.device) for s in range(steps + 3)]
-        for mode in ("eager", "graph"):
+        for mode in ("eager", "graph", "graph, two streams"):
             try:
                 _XZ_BUF.clear()
                 torch.cuda.empty_cache()
                 caps = [sp.CapturedStep(csr, B, num_walks=M, num_steps=k - 1, seed=1, rng=rng, uniq_capacity=UNIQ_CAPACITY)
-                        for _ in (0, 1)] if mode == "graph" else None
+                        for _ in (0, 1)] if mode != "eager" else None
+                # two captured steps replayed on two streams: the dozen few-microsecond kernels of one step run under
+                # the walk kernel of the other (a 1,024-pair step does not fill the chip)
+                streams = [torch.cuda.Stream(device=csr.device) for _ in (0, 1)] if mode.endswith("two streams") else None
 
                 def loop(ids):
                     pending = None
                     for s in ids:
                         e = edges[s % len(edges)]
-                        if caps is not None:
+                        if streams is not None:
+                            with torch.cuda.stream(streams[s & 1]):
+                                q = caps[s & 1](e)
+                        elif caps is not None:
                             q = caps[s & 1](e)
                         else:
                             q = hot_path_step(sp, csr, e, M, k, seed=1, rng=rng, slot=s & 1)
@@ -462,10 +468,10 @@ def batch_size_and_graph(sp, csr, M, k, rng, K):
                         pending = q
                     if pending is not None:
                         pending.finish() if caps is not None else finish_step(*pending)
-                loop(range(3))
+                loop(range(4))
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                loop(range(3, 3 + steps))
+                loop(range(4, 4 + steps))
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
                 out[f"B={B} {mode}"] = {"pairs_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps}
