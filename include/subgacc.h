@@ -43,7 +43,7 @@ typedef enum subgacc_status {
 } subgacc_status;
 
 enum { SUBGACC_RNG_RAND_R = 0, /* glibc rand_r stream, bit-exact with the reference at nthread=1 */
-       SUBGACC_RNG_PHILOX = 1  /* Philox4x32-10 keyed by (seed, root id, walk, step): schedule independent */ };
+       SUBGACC_RNG_PHILOX = 1  /* Philox2x32-10, key = seed, counter = (root id, walk | draw block | stream tag): schedule independent */ };
 enum { SUBGACC_ORDER_WALK_MAJOR = 0, /* set_sampler's first-visit order, subg_acc.c:785-832 */
        SUBGACC_ORDER_STEP_MAJOR = 1  /* rpe_encoder's first-visit order, subg_acc.c:263-278 */ };
 
