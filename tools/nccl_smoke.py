@@ -1,0 +1,16 @@
+"""Dev-only: the collectives bench.py uses for N > 1 (barrier, all_reduce MAX on a float64 scalar, destroy) on the RCCL
+backend with the ranks this box has GPUs for (one GPU: world_size 1):
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 tools/nccl_smoke.py"""
+import os
+import torch
+import torch.distributed as dist
+rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+torch.cuda.set_device(local)
+dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+dist.barrier()
+t = torch.tensor([1.5 + rank], device="cuda", dtype=torch.float64)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+torch.cuda.synchronize()
+print("nccl ok", rank, world, float(t.item()), flush=True)
+dist.barrier()
+dist.destroy_process_group()
