@@ -280,6 +280,9 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
     from surel_plus_amd.graphs import preset_graph, query_pairs
     preset, M, k, desc, pos_frac = WORKLOADS[name]
     csr = preset_graph(preset, device=dev, scale=args.scale)
+    if os.environ.get("SUBGACC_DEGREE_ORDER") == "1":     # dev experiment: nodes renumbered hub-first
+        from surel_plus_amd.graphs import degree_ordered
+        csr = degree_ordered(csr)[0]
     # every step's pairs are resident in HBM before the clock starts; ranks and steps get different pairs
     edges = [query_pairs(csr, B, seed=1000 * rank + s, device=dev, pos_frac=pos_frac) for s in range(K + W)]
     _XZ_BUF.clear()

@@ -267,8 +267,12 @@ __global__ __launch_bounds__(kJoinThreads) void sjoin_fill_kernel(const JoinArgs
 // the segment (A,B) and its mirror (B,A): both SpG rows are read from HBM once into LDS and both output
 // blocks are produced from there (the generic kernel reads every row twice).
 constexpr int kPairThreads = 256;
+#ifndef SJ_PAIR_THREADS      // lanes of sjoin_pair_kernel's workgroups (tools/ab.py --files=sjoin.hip)
+#define SJ_PAIR_THREADS 128   // 128 lanes per pair: twice the pairs with their row loads in flight per CU (-4..6 % against 256, r02s)
+#endif
+constexpr int kPairEmit = SJ_PAIR_THREADS;
 template <bool F64, int KV>
-__global__ __launch_bounds__(kPairThreads) void sjoin_pair_kernel(const JoinArgs a, int64_t pb) {
+__global__ __launch_bounds__(kPairEmit) void sjoin_pair_kernel(const JoinArgs a, int64_t pb) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using Val = typename std::conditional<F64, double, int32_t>::type;
     Val *valA = (Val *)lds_raw;                       // [max_len]
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(kPairThreads) void sjoin_pair_kernel(const JoinArgs
     const int na = (int)na64, nb = (int)nb64;
     const Val *data = (const Val *)a.data;
     const bool xl = !F64 && a.slot_id != nullptr;    // strided rows carry table slots: SFptr+1 on the way into LDS
-    for (int r = tid; r < na; r += kPairThreads) {
+    for (int r = tid; r < na; r += kPairEmit) {
 #if SJ_EXPERIMENT == 4   // timing experiment: no row loads from HBM (results are wrong)
         idsA[r] = (int32_t)(ra & 1023) + 3 * r;
         valA[r] = (Val)(r & 127);
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(kPairThreads) void sjoin_pair_kernel(const JoinArgs
         valA[r] = v;
     }
     if (ra != rb) {
-        for (int r = tid; r < nb; r += kPairThreads) {
+        for (int r = tid; r < nb; r += kPairEmit) {
 #if SJ_EXPERIMENT == 4
             idsB[r] = (int32_t)(rb & 1023) + 2 * r;
             valB[r] = (Val)(r & 127);
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(kPairThreads) void sjoin_pair_kernel(const JoinArgs
     const int k = a.k, k2 = 2 * k;
     const uint32_t magic = k2 > 0 ? ((1u << 20) + (uint32_t)k2 - 1u) / (uint32_t)k2 : 0u;
     const int chunksA = (na + kWave - 1) / kWave, chunksB = (nb + kWave - 1) / kWave;
-    for (int c = wave; c < chunksA + chunksB; c += kPairThreads / kWave) {   // every wave takes whole 64-row spans
+    for (int c = wave; c < chunksA + chunksB; c += kPairEmit / kWave) {   // every wave takes whole 64-row spans
         if (c < chunksA)
             emit_rows<F64, KV, Val>(a, lane, idsA, valA, na, idsB, valB, nb, (int64_t)c * kWave, oA, j, k, k2, magic);
         else
@@ -645,7 +649,7 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, int64_t n_rows, con
         if (lds > 64 * 1024)                                                                                      \
             SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<F, KVV>,                             \
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
-        hipLaunchKernelGGL((sjoin_pair_kernel<F, KVV>), dim3((unsigned)grid), dim3(kPairThreads), lds, s, a,      \
+        hipLaunchKernelGGL((sjoin_pair_kernel<F, KVV>), dim3((unsigned)grid), dim3(kPairEmit), lds, s, a,         \
                            pair_block);                                                                           \
     } while (0)
     if (paired) {
@@ -712,11 +716,11 @@ extern "C" int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t n_rows, i
     if (vec4) {
         if (lds > 64 * 1024)
             SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((sjoin_pair_kernel<false, 4>), dim3((unsigned)grid), dim3(kPairThreads), lds, s, a, pair_block);
+        hipLaunchKernelGGL((sjoin_pair_kernel<false, 4>), dim3((unsigned)grid), dim3(kPairEmit), lds, s, a, pair_block);
     } else {
         if (lds > 64 * 1024)
             SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((sjoin_pair_kernel<false, 0>), dim3((unsigned)grid), dim3(kPairThreads), lds, s, a, pair_block);
+        hipLaunchKernelGGL((sjoin_pair_kernel<false, 0>), dim3((unsigned)grid), dim3(kPairEmit), lds, s, a, pair_block);
     }
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;

@@ -73,6 +73,25 @@ def directed_powerlaw_graph(N, avg_deg, seed=3, exponent=2.2, device="cuda", chu
     return DeviceCSR(indptr, indices, torch.device(device))
 
 
+def degree_ordered(csr):
+    """The same graph with its nodes renumbered by descending degree (dev experiment: does a hub-first placement of the
+    row pointers raise the walk's L2 hit rate?).  Returns (DeviceCSR, perm) with perm[new id] = old id; rows keep their
+    neighbour order (renumbered, not re-sorted)."""
+    ip = csr.indptr.long()
+    N = csr.num_nodes
+    deg = ip[1:] - ip[:-1]
+    perm = torch.argsort(deg, descending=True, stable=True)
+    rank = torch.empty_like(perm)
+    rank[perm] = torch.arange(N, device=perm.device)
+    ndeg = deg[perm]
+    nip = torch.zeros(N + 1, dtype=torch.int64, device=perm.device)
+    nip[1:] = torch.cumsum(ndeg, 0)
+    row = torch.repeat_interleave(torch.arange(N, device=perm.device), ndeg)
+    old_e = ip[perm][row] + (torch.arange(csr.nnz, device=perm.device) - nip[row])
+    nidx = rank[csr.indices[old_e].long()].to(torch.int32)
+    return DeviceCSR(nip.to(csr.indptr.dtype), nidx, csr.device), perm
+
+
 def preset_graph(name, device="cuda", scale=1.0):
     if name == "twitter":
         return directed_powerlaw_graph(max(int(41_652_230 * scale), 1000), 70.5, seed=3, device=device)

@@ -1056,6 +1056,25 @@ def test_finished_rows_from_the_general_walk_kernel_match_oracle(sp, rng, M, m, 
     assert np.array_equal(ind.cpu().numpy(), oind) and np.array_equal(xz.cpu().numpy(), oxz)
 
 
+@pytest.mark.parametrize("rng", ["rand_r", "philox"])
+@pytest.mark.parametrize("M,m,idx64", [(200, 3, False), (200, 4, True), (120, 4, False), (100, 3, True), (256, 2, False)])
+def test_specialised_fused_row_kernel_on_shuffled_roots(sp, rng, M, m, idx64):
+    """csrc/walk_rows.hip: every instantiation family (2..4 hops x 512 / 1,024 table slots x int32 / int64 row offsets)
+    on a graph whose roots all take the Fisher-Yates first hop (every degree > M), rows and numbering against the oracle"""
+    ptr_, idx = sym_graph(4000, 700000, seed=23)
+    assert int(np.diff(ptr_).min()) > M
+    q = np.random.default_rng(7).permutation(4000)[:2500]
+    from surel_plus_amd.sampler import DeviceCSR, walk_kernel_name
+    assert walk_kernel_name(None, M, m, True) == "walk_rows_kernel"
+    csr = DeviceCSR(ptr_.astype(np.int64) if idx64 else ptr_, idx)
+    (oi, ox, od), oenc = _oracle_spg(ptr_, idx, q, M, m, 13, rng, -1)
+    z, info = sp.sample_spg(csr, q, num_walks=M, num_steps=m, seed=13, rng=rng, fused=True)
+    assert np.array_equal(z.indptr.cpu().numpy(), oi)
+    assert np.array_equal(z.indices.cpu().numpy(), ox)
+    assert np.array_equal(z.data.cpu().numpy(), od)
+    assert np.array_equal(info.enc_int16().cpu().numpy(), oenc)
+
+
 # ------------------------------------------------------------------------------- batch_sampler (legacy SUREL mini-batches)
 @pytest.mark.parametrize("name", golden_files("batch_"))
 def test_batch_sampler_matches_reference_golden(sp, name):
