@@ -443,42 +443,47 @@ def batch_size_and_graph(sp, csr, M, k, rng, K):
     from surel_plus_amd.graphs import query_pairs
     out = {}
     for B in (1024, 65536):
-        steps = max(K, 40) if B == 1024 else K
+        steps = max(K, 64) if B == 1024 else K
         edges = [query_pairs(csr, B, seed=7000 + s, device=csr.device) for s in range(steps + 3)]
-        for mode in ("eager", "graph", "graph, two streams"):
+        for mode in ("eager", "graph", "graph, 2 lanes", "graph, 4 lanes", "graph, 8 lanes"):
             try:
                 _XZ_BUF.clear()
                 torch.cuda.empty_cache()
-                caps = [sp.CapturedStep(csr, B, num_walks=M, num_steps=k - 1, seed=1, rng=rng, uniq_capacity=UNIQ_CAPACITY)
-                        for _ in (0, 1)] if mode != "eager" else None
-                # two captured steps replayed on two streams: the dozen few-microsecond kernels of one step run under
-                # the walk kernel of the other (a 1,024-pair step does not fill the chip)
-                streams = [torch.cuda.Stream(device=csr.device) for _ in (0, 1)] if mode.endswith("two streams") else None
+                lanes = int(mode.split()[1]) if "lanes" in mode else 0
+                kw = dict(num_walks=M, num_steps=k - 1, seed=1, rng=rng, uniq_capacity=UNIQ_CAPACITY)
+                # stepgraph.CapturedStepPool: `lanes` captured steps replayed on their own streams -- the dozen
+                # few-microsecond kernels of one step run under the walk kernels of the others (a 1,024-pair step does
+                # not fill the chip)
+                pool = sp.CapturedStepPool(csr, B, lanes=lanes, **kw) if lanes else None
+                caps = [sp.CapturedStep(csr, B, **kw) for _ in (0, 1)] if mode == "graph" else None
 
                 def loop(ids):
-                    pending = None
+                    pending = []          # steps in flight
                     for s in ids:
                         e = edges[s % len(edges)]
-                        if streams is not None:
-                            with torch.cuda.stream(streams[s & 1]):
-                                q = caps[s & 1](e)
-                        elif caps is not None:
-                            q = caps[s & 1](e)
+                        if pool is not None:
+                            if len(pending) == lanes:
+                                pool.finish(pending.pop(0))
+                            pending.append(pool.submit(e))
+                            continue
+                        q = caps[s & 1](e) if caps is not None else hot_path_step(sp, csr, e, M, k, seed=1, rng=rng, slot=s & 1)
+                        pending.append(q)
+                        if len(pending) == 2:
+                            d = pending.pop(0)
+                            d.finish() if caps is not None else finish_step(*d)
+                    for d in pending:
+                        if pool is not None:
+                            pool.finish(d)
                         else:
-                            q = hot_path_step(sp, csr, e, M, k, seed=1, rng=rng, slot=s & 1)
-                        if pending is not None:
-                            pending.finish() if caps is not None else finish_step(*pending)
-                        pending = q
-                    if pending is not None:
-                        pending.finish() if caps is not None else finish_step(*pending)
-                loop(range(4))
+                            d.finish() if caps is not None else finish_step(*d)
+                loop(range(8))
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                loop(range(4, 4 + steps))
+                loop(range(8, 8 + steps))
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
                 out[f"B={B} {mode}"] = {"pairs_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps}
-                del caps
+                del caps, pool
             except Exception as ex:
                 out[f"B={B} {mode}"] = {"failed": f"{type(ex).__name__}: {ex}"}
     return out

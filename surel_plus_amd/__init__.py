@@ -13,4 +13,4 @@ from .spjoin import (attn_stage, bgather, gather, gather_counts, gather_pairs, h
                      sample_and_gather, sjoin)
 from .subg_acc import batch_sampler, gset_sampler, walk_join, walk_sampler  # noqa: F401
 from .ppr import topk_ppr_matrix  # noqa: F401
-from .stepgraph import CapturedStep  # noqa: F401
+from .stepgraph import CapturedStep, CapturedStepPool  # noqa: F401

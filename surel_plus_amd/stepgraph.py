@@ -69,3 +69,40 @@ class CapturedStep:
                                     "larger uniq_capacity")
         self.distinct_rows, self.members = (st[4] if self.sets.ukeys is not None else None), st[5]   # None: not numbered
         return self.xz[: st[6]], self.ind
+
+
+class CapturedStepPool:
+    """`lanes` captured steps, each replayed on its own HIP stream: a serving loop for small batches.
+
+    A step of 1,024 pairs (the reference's default, main.py:32) is 2,048 roots -- one workgroup per resident slot for the
+    length of one root's walk -- plus a dozen kernels of a few microseconds: it cannot fill the chip, and one stream
+    runs it in ~100 us.  Consecutive batches are independent, so several of them in flight overlap almost perfectly
+    (B = 1,024 on the cit2-like graph: 10 M pairs/s with one captured step in flight, 13 M with two, 19 M with four).
+
+        pool = CapturedStepPool(csr, 1024, lanes=4, num_walks=200, num_steps=3)
+        t = pool.submit(edge)             # queues the batch on the next lane (which must be free); nothing waits
+        xz, indptr = pool.finish(t)       # waits for that batch, raises on its errors, frees the lane
+
+    (xz, indptr) are views of the lane's static buffers: valid until that lane is submitted again, `lanes` submits later."""
+
+    def __init__(self, csr, pairs, lanes=4, **kw):
+        self.steps = [CapturedStep(csr, pairs, **kw) for _ in range(int(lanes))]
+        self.streams = [torch.cuda.Stream(device=csr.device) for _ in self.steps]
+        self._busy = [False] * len(self.steps)
+        self._next = 0
+
+    def submit(self, edge):
+        i = self._next
+        if self._busy[i]:
+            raise RuntimeError("every lane is in flight: finish() the oldest batch before submitting another")
+        self._next = (i + 1) % len(self.steps)
+        st = self.streams[i]
+        st.wait_stream(torch.cuda.current_stream(edge.device))      # `edge` may have been produced on the caller's stream
+        with torch.cuda.stream(st):
+            self.steps[i](edge)
+        self._busy[i] = True
+        return i
+
+    def finish(self, ticket):
+        self._busy[ticket] = False
+        return self.steps[ticket].finish()

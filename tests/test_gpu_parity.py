@@ -1028,6 +1028,33 @@ def test_captured_step_replays_equal_the_eager_step(sp, B, hops, rng):
     assert torch.equal(ind, eind) and torch.equal(xz, exz)
 
 
+def test_captured_step_pool_keeps_batches_in_flight_on_their_own_streams(sp):
+    """stepgraph.CapturedStepPool: four captured steps on four streams, three batches in flight; every batch equals the
+    eager step for the same pairs, whatever was in flight around it"""
+    from surel_plus_amd.graphs import query_pairs
+    ptr_, idx = sym_graph(20000, 120000, seed=13, hubs=3)
+    csr = sp.DeviceCSR(ptr_, idx)
+    B = 512
+    pool = sp.CapturedStepPool(csr, B, lanes=4, num_walks=100, num_steps=3, seed=9, rng="philox")
+    edges = [query_pairs(csr, B, seed=s) for s in range(10)]
+    want = [sp.sample_and_gather(csr, e, num_walks=100, num_steps=3, seed=9, rng="philox")[:2] for e in edges]
+    inflight, got = [], []
+    for s, e in enumerate(edges):
+        inflight.append((s, pool.submit(e)))
+        if len(inflight) == 4:
+            with pytest.raises(RuntimeError):
+                pool.submit(e)                                   # all four lanes busy
+            s0, t0 = inflight.pop(0)
+            xz, ind = pool.finish(t0)
+            got.append((s0, xz.clone(), ind.clone()))
+    for s0, t0 in inflight:
+        xz, ind = pool.finish(t0)
+        got.append((s0, xz.clone(), ind.clone()))
+    assert [g[0] for g in got] == list(range(10))
+    for s0, xz, ind in got:
+        assert torch.equal(ind, want[s0][1]) and torch.equal(xz, want[s0][0]), s0
+
+
 @pytest.mark.parametrize("rng", ["rand_r", "philox"])
 @pytest.mark.parametrize("M,m,N,E,hubs,bucket", [(200, 2, 20000, 80000, 4, -1), (200, 3, 6000, 200000, 0, -1),
                                                  (100, 4, 3000, 9000, 2, -1), (7, 5, 500, 1500, 1, -1),
