@@ -47,11 +47,14 @@ __device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
 #define SG_RSTAMP(k)
 #endif
 
-template <bool IDX64, int RNG, int MH, int SPL>
-__global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80))) void walk_rows_kernel(const WalkArgs a) {
+// NT lanes per workgroup (256, or 128 with two walks per lane: twice the roots per CU where the 512-slot table leaves the
+// LDS for them), SPL table slots per lane, T = NT * SPL.
+template <bool IDX64, int RNG, int MH, int SPL, int NT>
+__global__ __launch_bounds__(NT, 8) __attribute__((amdgpu_num_sgpr(80))) void walk_rows_kernel(const WalkArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    constexpr int T = SPL * kWalkThreads;                         // 512 or 1,024 slots
-    constexpr int TSHIFT = SPL == 4 ? 22 : 23;                    // 32 - log2(T)
+    constexpr int T = SPL * NT;                                   // 512 or 1,024 slots
+    constexpr int TSHIFT = T == 1024 ? 22 : 23;                   // 32 - log2(T)
+    constexpr int WPL = kWalkThreads / NT;                        // walks per lane (M <= 256)
     constexpr uint32_t TMASK = (uint32_t)T - 1u;
     unsigned long long *pk = (unsigned long long *)lds_raw;      // [T] packed landing counts
     int32_t *keys = (int32_t *)(pk + T);                          // [T] node ids
@@ -125,64 +128,96 @@ __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80)
     }
     const bool shuffled = rdeg64 > M;
     const uint32_t rdeg = (uint32_t)rdeg64;
-    if (shuffled && tid < M) {  // partial Fisher-Yates draws s_k = draw % (deg-k) + k  (subg_acc.c:769-775), one lane per k
-        uint32_t r;
-        if (RNG == SUBGACC_RNG_RAND_R) {
-            uint32_t x = lcg_jump(rseed, rpos + 3u * (uint32_t)tid);
-            r = rand_r_next(x);
-            sarr[tid] = (int32_t)(r % (rdeg - (uint32_t)tid)) + tid;
-        } else {
-            uint32_t o1;
-            philox2x32_10((uint32_t)root, (uint32_t)tid | kPhiloxShuffle, a.seed, r, o1);
-            sarr[tid] = (int32_t)philox_below(r, rdeg - (uint32_t)tid) + tid;
+    if (shuffled) {  // partial Fisher-Yates draws s_k = draw % (deg-k) + k  (subg_acc.c:769-775), one lane per k
+#pragma unroll
+        for (int kk = 0; kk < WPL; ++kk) {
+            const int k = tid + kk * NT;
+            if (k >= M) continue;
+            uint32_t r;
+            if (RNG == SUBGACC_RNG_RAND_R) {
+                uint32_t x = lcg_jump(rseed, rpos + 3u * (uint32_t)k);
+                r = rand_r_next(x);
+                sarr[k] = (int32_t)(r % (rdeg - (uint32_t)k)) + k;
+            } else {
+                uint32_t o1;
+                philox2x32_10((uint32_t)root, (uint32_t)k | kPhiloxShuffle, a.seed, r, o1);
+                sarr[k] = (int32_t)philox_below(r, rdeg - (uint32_t)k) + k;
+            }
         }
     }
     __syncthreads();
     SG_RSTAMP(0);
 
-    // ------------------------------------------------------------------ the walk: one lane per walk, straight-line
-    if (tid < M) {
-        uint32_t pick;
-        if (shuffled) {   // value the sequential swaps leave at position tid: follow the chain of earlier draws
-            int32_t p = sarr[tid];
-            for (int j = tid - 1; j >= 0; --j)
-                if (sarr[j] == p) p = j;
-            pick = (uint32_t)p;
-        } else {
-            pick = (uint32_t)tid % rdeg;
-        }
-        int32_t cur = SG_NEIGH_LOAD(&a.indices[rbeg + pick]);
-        uint32_t dr[MH > 1 ? 2 * (MH / 2) : 2];   // draws of hops 2..MH (Philox: computed while that load is in flight)
-        uint32_t x = 0;
-        if (RNG == SUBGACC_RNG_PHILOX) {
+    // ------------------------------------------------------------------ the walk: WPL walks per lane, straight-line,
+    // the walks of a lane interleaved hop by hop (their loads are independent and in flight together)
+    {
+        bool wk[WPL];
+        int32_t cur[WPL];
+        uint32_t dr[WPL][MH > 1 ? 2 * (MH / 2) : 2];   // draws of hops 2..MH (Philox: computed while the first load is in flight)
+        uint32_t x[WPL];
 #pragma unroll
-            for (int b = 0; 2 * b < MH - 1; ++b)
-                philox2x32_10((uint32_t)root, (uint32_t)tid | ((uint32_t)b << kPhiloxBlockShift), a.seed, dr[2 * b], dr[2 * b + 1]);
-        } else {
-            x = lcg_jump(rseed, rpos + 3u * ((shuffled ? (uint32_t)M : 0u) + (uint32_t)tid * (uint32_t)(MH - 1)));
+        for (int k = 0; k < WPL; ++k) {
+            const int w = tid + k * NT;
+            wk[k] = w < M;
+            cur[k] = root;
+            x[k] = 0;
+            if (!wk[k]) continue;
+            uint32_t pick;
+            if (shuffled) {   // value the sequential swaps leave at position w: follow the chain of earlier draws
+                int32_t p = sarr[w];
+                for (int j = w - 1; j >= 0; --j)
+                    if (sarr[j] == p) p = j;
+                pick = (uint32_t)p;
+            } else {
+                pick = (uint32_t)w % rdeg;
+            }
+            cur[k] = SG_NEIGH_LOAD(&a.indices[rbeg + pick]);
+        }
+#pragma unroll
+        for (int k = 0; k < WPL; ++k) {
+            if (!wk[k]) continue;
+            const int w = tid + k * NT;
+            if (RNG == SUBGACC_RNG_PHILOX) {
+#pragma unroll
+                for (int b = 0; 2 * b < MH - 1; ++b)
+                    philox2x32_10((uint32_t)root, (uint32_t)w | ((uint32_t)b << kPhiloxBlockShift), a.seed, dr[k][2 * b], dr[k][2 * b + 1]);
+            } else {
+                x[k] = lcg_jump(rseed, rpos + 3u * ((shuffled ? (uint32_t)M : 0u) + (uint32_t)w * (uint32_t)(MH - 1)));
+            }
         }
 #pragma unroll
         for (int s = 0; s < MH; ++s) {
-            int64_t b = 0, d = 0;
-            if (s + 1 < MH) load_row<IDX64>(a.indptr, cur, b, d);      // the next hop's row: in flight under the visit
-            {   // ---- visit: insert-or-find, first-visit sequence number, landing count
-                uint32_t h = ((uint32_t)cur * 2654435761u) >> TSHIFT;
+            int64_t b[WPL], d[WPL];
+#pragma unroll
+            for (int k = 0; k < WPL; ++k) {
+                b[k] = d[k] = 0;
+                if (wk[k] && s + 1 < MH) load_row<IDX64>(a.indptr, cur[k], b[k], d[k]);   // the next hop's row: in flight under the visit
+            }
+#pragma unroll
+            for (int k = 0; k < WPL; ++k) {
+                if (!wk[k]) continue;
+                // ---- visit: insert-or-find, first-visit sequence number, landing count
+                uint32_t h = ((uint32_t)cur[k] * 2654435761u) >> TSHIFT;
                 while (true) {
-                    const int32_t old = atomicCAS(&keys[h], -1, cur);
-                    if (old == -1 || old == cur) break;
+                    const int32_t old = atomicCAS(&keys[h], -1, cur[k]);
+                    if (old == -1 || old == cur[k]) break;
                     h = (h + 1u) & TMASK;
                 }
-                atomicMin(&minq[h], (uint32_t)(tid * MH + s + 1));
+                atomicMin(&minq[h], (uint32_t)((tid + k * NT) * MH + s + 1));
                 atomicAdd(&pk[h], 1ull << ((MH - 1 - s) * a.shift));
             }
             if (s + 1 < MH) {
-                if (d > 0) {
-                    uint32_t off;
-                    if (RNG == SUBGACC_RNG_RAND_R) off = rand_r_next(x) % (uint32_t)d;
-                    else off = philox_below(dr[s], (uint32_t)d);
-                    cur = SG_NEIGH_LOAD(&a.indices[b + (int64_t)off]);
-                } else if (RNG == SUBGACC_RNG_RAND_R) {
-                    atomicOr(&a.flags[0], 1);  // dead end: the sequential stream is no longer reproducible
+#pragma unroll
+                for (int k = 0; k < WPL; ++k) {
+                    if (!wk[k]) continue;
+                    if (d[k] > 0) {
+                        uint32_t off;
+                        if (RNG == SUBGACC_RNG_RAND_R) off = rand_r_next(x[k]) % (uint32_t)d[k];
+                        else off = philox_below(dr[k][s], (uint32_t)d[k]);
+                        cur[k] = SG_NEIGH_LOAD(&a.indices[b[k] + (int64_t)off]);
+                    } else if (RNG == SUBGACC_RNG_RAND_R) {
+                        atomicOr(&a.flags[0], 1);  // dead end: the sequential stream is no longer reproducible
+                    }
                 }
             }
         }
@@ -286,7 +321,7 @@ __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80)
     unsigned long long *A = pk;                 // [ns] (id << 32 | slot) grouped by bucket
     int32_t *start = keys;                      // [B+1] bucket counts, then their exclusive scan; B <= min(T/4, 256)
     int logb = 0;
-    while ((1 << logb) < ns && (2 << logb) <= T / 4 && (2 << logb) <= kWalkThreads) ++logb;
+    while ((1 << logb) < ns && (2 << logb) <= T / 4 && (2 << logb) <= NT) ++logb;
     const int B = 1 << logb;
     const uint32_t range = (uint32_t)(mx - mn) + 1u;
     const int Ls = (range <= 1u) ? 0 : (32 - __builtin_clz(range - 1u));
@@ -359,7 +394,7 @@ __global__ __launch_bounds__(kWalkThreads, 8) __attribute__((amdgpu_num_sgpr(80)
         }
     if (staged) {
         __syncthreads();
-        for (int x = tid; x < ns; x += kWalkThreads) {
+        for (int x = tid; x < ns; x += NT) {
             a.set_ids[obase + x] = fin_id[x];
             a.set_slot[obase + x] = fin_sl[x];
         }
@@ -375,21 +410,25 @@ int launch_walk_rows(const WalkArgs &a, bool indptr64, int rng_mode, size_t lds,
     const int64_t grid = xcd_grid(a.n);
     if (grid >= (1ll << 31)) return 0;
     const bool rr = rng_mode == SUBGACC_RNG_RAND_R;
-#define SG_ROWS(I64, RNGM, MHH, SPLL)                                                                              \
+    // 512-slot tables: 128 lanes x 2 walks (SUBGACC_ROWS_NT=256 forces one walk per lane; dev-only)
+    static const bool nt256 = getenv("SUBGACC_ROWS_NT") && atoi(getenv("SUBGACC_ROWS_NT")) == 256;
+    const bool half = a.T == 512 && !nt256;
+#define SG_ROWS(I64, RNGM, MHH, SPLL, NTT)                                                                         \
     do {                                                                                                           \
-        hipLaunchKernelGGL((walk_rows_kernel<I64, RNGM, MHH, SPLL>), dim3((unsigned)grid), dim3(kWalkThreads), lds, s, a); \
+        hipLaunchKernelGGL((walk_rows_kernel<I64, RNGM, MHH, SPLL, NTT>), dim3((unsigned)grid), dim3(NTT), lds, s, a); \
         return 1;                                                                                                  \
     } while (0)
-#define SG_ROWS_MH(I64, RNGM, SPLL)                      \
-    do {                                                 \
-        if (a.m == 2) SG_ROWS(I64, RNGM, 2, SPLL);       \
-        if (a.m == 3) SG_ROWS(I64, RNGM, 3, SPLL);       \
-        SG_ROWS(I64, RNGM, 4, SPLL);                     \
+#define SG_ROWS_MH(I64, RNGM, SPLL, NTT)                      \
+    do {                                                      \
+        if (a.m == 2) SG_ROWS(I64, RNGM, 2, SPLL, NTT);       \
+        if (a.m == 3) SG_ROWS(I64, RNGM, 3, SPLL, NTT);       \
+        SG_ROWS(I64, RNGM, 4, SPLL, NTT);                     \
     } while (0)
-#define SG_ROWS_SPL(I64, RNGM)                           \
-    do {                                                 \
-        if (a.T == 1024) SG_ROWS_MH(I64, RNGM, 4);       \
-        SG_ROWS_MH(I64, RNGM, 2);                        \
+#define SG_ROWS_SPL(I64, RNGM)                                \
+    do {                                                      \
+        if (a.T == 1024) SG_ROWS_MH(I64, RNGM, 4, 256);       \
+        if (half) SG_ROWS_MH(I64, RNGM, 4, 128);              \
+        SG_ROWS_MH(I64, RNGM, 2, 256);                        \
     } while (0)
     if (indptr64) {
         if (rr) SG_ROWS_SPL(true, SUBGACC_RNG_RAND_R);
