@@ -273,7 +273,7 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W):
 
 
 def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, with_cpu_baseline, csr_variant=True,
-             small_batches=False):
+             small_batches=False, two_stream_extra=True):
     """sample + SpJoin over one LP workload: W warm-up steps, K timed steps bracketed by barrier + synchronize, max over
     ranks.  Returns the JSON object (rank 0) or None."""
     global STRIDED
@@ -359,7 +359,7 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
         csr_ms = (time.perf_counter() - t1) / max(K, 1) * 1e3
         last, STRIDED = keep_last, keep_strided
     two_streams = None
-    if rank == 0 and world == 1 and STREAMS is None and last is not None:
+    if rank == 0 and world == 1 and STREAMS is None and last is not None and two_stream_extra:
         keep_last = last
         timer.enabled = False
         STREAMS = [torch.cuda.Stream(device=dev) for _ in range(2)]
@@ -558,7 +558,8 @@ def main():
     else:
         out = bench_lp(args, args.workload, args.rng, B, K, W, sp, sampler_mod, dev, rank, world, dist,
                        with_cpu_baseline=(world == 1 and not args.no_cpu_baseline),
-                       small_batches=(world == 1 and not args.no_others))
+                       small_batches=(world == 1 and not args.no_others),
+                       two_stream_extra=not args.no_others)      # --no-others: the profiled command, single-stream steps only
     # BASELINE.json's other single-GPU configurations (and the reference-bit-exact rand_r stream on the headline one),
     # as short passes after the timed region: same code path, >= 5 timed steps each, their own roofline blocks
     # (configs[0], the reference's CPU-runnable collab case, rides on the collab entry as its cpu_baseline).
