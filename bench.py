@@ -115,6 +115,8 @@ class KernelTimer:
 
 
 _XZ_BUF = {}
+_STEP_BUFS = {}
+BUFFERED = os.environ.get("SUBGACC_STEP_BUFFERS", "1") == "1"     # 0: the general (allocating) form of the step, for A/B
 
 
 def hot_path_step(sp, csr, edge, M, k, seed, rng, slot=0):
@@ -130,9 +132,20 @@ def hot_path_step(sp, csr, edge, M, k, seed, rng, slot=0):
     buf = _XZ_BUF.get((edge.device, cap, slot))
     if buf is None:
         buf = _XZ_BUF[(edge.device, cap, slot)] = torch.empty(cap, dtype=torch.float32, device=edge.device)
-    # the library's on-demand entry point: sample both endpoints of every pair -> SpG rows -> join
+    # the library's on-demand entry point: sample both endpoints of every pair -> SpG rows -> join.  A serving loop
+    # hands it preallocated StepBuffers (two sets in turn, like the output buffers): six launches per step, no allocation
+    bufs = None
+    if LAZY and BUFFERED and rng == "philox" and strided is not False and FUSED is not False:
+        key = (edge.device, B, M, k, slot)
+        bufs = _STEP_BUFS.get(key)
+        if bufs is None:
+            try:
+                bufs = _STEP_BUFS[key] = sp.StepBuffers(csr, B, M, k - 1, uniq_capacity=UNIQ_CAPACITY, out=buf)
+            except ValueError:
+                bufs = _STEP_BUFS[key] = False
     xz, ind, sets = sp.sample_and_gather(csr, edge, num_walks=M, num_steps=k - 1, seed=seed, rng=rng, out=buf if LAZY else None,
-                                         lazy=LAZY, strided=strided, fused=FUSED, uniq_capacity=UNIQ_CAPACITY)
+                                         lazy=LAZY, strided=strided, fused=FUSED, uniq_capacity=UNIQ_CAPACITY,
+                                         **({"buffers": bufs} if bufs else {}))
     if LAZY:    # sizes + status + the join's row count start their way to pinned host memory now, behind this step
         sets.prefetch(extra=ind[-1:])
     return xz, ind, sets
@@ -286,6 +299,7 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
     # every step's pairs are resident in HBM before the clock starts; ranks and steps get different pairs
     edges = [query_pairs(csr, B, seed=1000 * rank + s, device=dev, pos_frac=pos_frac) for s in range(K + W)]
     _XZ_BUF.clear()
+    _STEP_BUFS.clear()
     timer = KernelTimer()
     sampler_mod.KERNEL_TIMER = timer
     last = None
@@ -347,6 +361,12 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # what the JSON line says about the last timed step, taken NOW: the extra passes below re-use the step buffers
+    last_members = last_rows = last_distinct = last_abytes = None
+    if rank == 0 and last is not None:
+        last_members, last_rows = int(last[1].X), int(last[2].shape[0])
+        last_distinct = int(last[1].c)
+        last_abytes = algorithmic_walk_bytes(csr, last[0].reshape(-1), last[1], M, k - 1)   # the last timed launch
     # for the record, outside the clock: the same steps with a packed CSR SpG built for every batch (rank 0, 1 GPU)
     csr_ms = None
     if csr_variant and rank == 0 and world == 1 and last is not None and last[1].strided:
@@ -380,7 +400,7 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
     edge, sets, xz = last
     walk_ms, launches = timer.mean_ms("walk_sets")
     join_ms, _ = timer.mean_ms("sjoin_fill")
-    abytes = algorithmic_walk_bytes(csr, edge.reshape(-1), sets, M, k - 1)   # the last step's launch
+    abytes = last_abytes
     achieved = abytes / (walk_ms * 1e-3) / 1e9 if walk_ms else None
     fused_rows = sets.data is not None or sets.strided
     finished = timer.mean_ms("spg_build")[0] is not None and sets.strided    # rows came from the general kernel + finish_rows
@@ -399,8 +419,8 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
         "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": desc, "pairs_per_step_per_gpu": B, "roots_per_step_per_gpu": 2 * B,
                    "num_walks": M, "num_steps_cli": k, "rng": rng, "parallelism": f"query-shard x{world}",
-                   "set_members_last_step": sets.X, "distinct_lp_rows_last_step": sets.c,
-                   "xz_rows_last_step": int(xz.shape[0]), "graph_nnz": csr.nnz,
+                   "set_members_last_step": last_members, "distinct_lp_rows_last_step": last_distinct,
+                   "xz_rows_last_step": last_rows, "graph_nnz": csr.nnz,
                    # S = roots/s of the sampler pipeline (walk .. SpG), J = pairs/s of the join alone
                    "S_roots_per_s": 2 * B / (1e-3 * sum(v for v in (timer.mean_ms(n_)[0] for n_ in
                                              ("walk_sets", "compact_sets", "uniq_rows", "spg_build")) if v)),
@@ -448,6 +468,7 @@ def batch_size_and_graph(sp, csr, M, k, rng, K):
         for mode in ("eager", "graph", "graph, 2 lanes", "graph, 4 lanes", "graph, 8 lanes"):
             try:
                 _XZ_BUF.clear()
+                _STEP_BUFS.clear()
                 torch.cuda.empty_cache()
                 lanes = int(mode.split()[1]) if "lanes" in mode else 0
                 kw = dict(num_walks=M, num_steps=k - 1, seed=1, rng=rng, uniq_capacity=UNIQ_CAPACITY)

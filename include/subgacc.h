@@ -322,6 +322,15 @@ int subgacc_walk_join(const int32_t *walks, int64_t n, int32_t stride, const int
                       void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Prologue of one on-demand step (sample both endpoints of B query pairs -> rows -> SpJoin; train.py:120-127 calls the
+ * join once per batch of main.py:32's 1,024 pairs) in ONE launch: subgacc_uniq_reset of the table of distinct LP rows,
+ * `n_zero` status words zeroed, and the n = 2B endpoints `edge` (int64, [u.. | v..]) narrowed to the int32 roots the
+ * sampler takes (an id outside int32 becomes -1: out of range for the walk kernel, which flags it).
+ * ------------------------------------------------------------------------------------------- */
+int subgacc_step_prologue(void *uniq_table, int64_t capacity, int64_t *zero_words, int64_t n_zero, const int64_t *edge,
+                          int32_t *roots, int64_t n, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * batch_sampler of the legacy SUREL surface (subg_acc/subg_acc.c:391-507): one insertion-ordered set of nodes grown by
  * walking the roots one after the other (num_walks walks of num_steps nodes each, first hop without replacement,
  * one rand_r stream); root i stops walking once the set holds (i+1)*thld/n nodes (:474).

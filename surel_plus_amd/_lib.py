@@ -30,7 +30,7 @@ SYMBOLS = (
     "subgacc_ppr_slab_bytes", "subgacc_ppr_slab_reset", "subgacc_ppr_topk", "subgacc_ppr_normalize", "subgacc_ppr_encode",
     "subgacc_walk_join", "subgacc_sjoin_sizes_rows", "subgacc_sjoin_fill_rows",
     "subgacc_encode_sizes", "subgacc_encode_fill", "subgacc_sjoin_pairs", "subgacc_finish_rows",
-    "subgacc_batch_sampler_workspace_bytes", "subgacc_batch_sampler",
+    "subgacc_batch_sampler_workspace_bytes", "subgacc_batch_sampler", "subgacc_step_prologue",
 )
 
 
@@ -105,6 +105,7 @@ def lib():
     sig["subgacc_ppr_normalize"] = (C.c_int, [vp, i32, vp, i64, vp, i64, vp, vp, i32, vp, vp, vp])
     sig["subgacc_ppr_encode"] = (C.c_int, [vp, i64, vp, vp, vp])
     sig["subgacc_walk_join"] = (C.c_int, [vp, i64, i32, vp, vp, vp, i32, vp, i64, vp, vp])
+    sig["subgacc_step_prologue"] = (C.c_int, [vp, i64, vp, i64, vp, vp, i64, vp])
     sig["subgacc_batch_sampler_workspace_bytes"] = (sz, [i64])
     sig["subgacc_batch_sampler"] = (C.c_int, [vp, i32, vp, i64, vp, i64, i32, i32, i32, C.c_uint32, vp, i64, vp, vp, sz, vp, vp])
     sig["subgacc_sjoin_sizes_rows"] = (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, sz, vp])

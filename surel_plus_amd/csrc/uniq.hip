@@ -24,6 +24,24 @@ __global__ void uniq_reset_kernel(UniqTable t, int64_t cap) {
     }
 }
 
+// What an on-demand step (sample the endpoints of B pairs -> rows -> join) needs before its walk kernel, in ONE launch
+// instead of four: the table of distinct LP rows reset, the step's status words zeroed, the int64 endpoints of the pairs
+// narrowed to the int32 roots the sampler takes (force-cast like the reference's query, subg_acc.c:673).
+__global__ void step_prologue_kernel(UniqTable t, int64_t cap, int64_t *zero_words, int64_t n_zero, const int64_t *edge,
+                                     int32_t *roots, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) {
+        t.keys[i] = kEmptyKey;
+        t.mintag[i] = ~0ull;
+        t.id[i] = -1;
+    }
+    if (i < n_zero) zero_words[i] = 0;
+    if (i < n) {
+        const int64_t v = edge[i];     // ids beyond int32 cannot be nodes of an int32 graph: out of range for the walk kernel
+        roots[i] = (v < 0 || v > 0x7FFFFFFFll) ? -1 : (int32_t)v;
+    }
+}
+
 // The distinct LP rows are 10^2..10^5 while the members are 10^7..10^9, so almost every member repeats a key
 // its neighbours in the tile already carry.  Each block first folds its tile into an LDS table
 // (key -> min position, ds_cmpst_b64 / ds_min_u64) and only the block-distinct keys go to the HBM table:
@@ -224,6 +242,20 @@ extern "C" int subgacc_uniq_reset(void *table, int64_t capacity, void *stream) {
                "uniq_reset: capacity must be a power of two below 2^31");
     hipLaunchKernelGGL(uniq_reset_kernel, dim3((unsigned)ceil_div(capacity, 256)), dim3(256), 0, (hipStream_t)stream,
                        uniq_view(table, capacity), capacity);
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}
+
+extern "C" int subgacc_step_prologue(void *table, int64_t capacity, int64_t *zero_words, int64_t n_zero, const int64_t *edge,
+                                     int32_t *roots, int64_t n, void *stream) {
+    SG_REQUIRE(table && is_pow2(capacity) && capacity < (1ll << 31), SUBGACC_ERR_BADARG,
+               "step_prologue: capacity must be a power of two below 2^31");
+    SG_REQUIRE(n >= 0 && n_zero >= 0 && (n == 0 || (edge && roots)) && (n_zero == 0 || zero_words), SUBGACC_ERR_BADARG,
+               "step_prologue: null argument");
+    int64_t span = capacity > n ? capacity : n;
+    if (n_zero > span) span = n_zero;
+    hipLaunchKernelGGL(step_prologue_kernel, dim3((unsigned)ceil_div(span, 256)), dim3(256), 0, (hipStream_t)stream,
+                       uniq_view(table, capacity), capacity, zero_words, n_zero, edge, roots, n);
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }

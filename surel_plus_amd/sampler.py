@@ -107,6 +107,7 @@ class SampledSets:
     _members: int = 0
     _pending: tuple = None       # prefetch(): (pinned host copy of status, event, device source)
     extra: list = None           # values of prefetch(extra=...) once resolved
+    _tail: torch.Tensor = None   # StepBuffers form: int64 [5] = [rows of the join (= members), status words x4], contiguous
 
     # ------------------------------------------------------------------ lazy bookkeeping
     @property
@@ -119,7 +120,10 @@ class SampledSets:
         the stream holds by the time it is called -- a serving loop queues the next batch in between."""
         if self.status is None or self._pending is not None:
             return self
-        src = self.status if extra is None else torch.cat([self.status, extra.reshape(-1).to(torch.int64)])
+        if self._tail is not None:      # the step's buffers keep the join's row count next to the status words: no cat
+            src = self._tail
+        else:
+            src = self.status if extra is None else torch.cat([self.status, extra.reshape(-1).to(torch.int64)])
         host = torch.empty(src.numel(), dtype=torch.int64, pin_memory=True)
         host.copy_(src, non_blocking=True)
         ev = torch.cuda.Event()
@@ -135,11 +139,15 @@ class SampledSets:
             host, ev, _ = self._pending
             ev.synchronize()
             st = host.tolist()
-            self.extra = st[self.status.numel():]
-            st = unpack_status(st[: self.status.numel()])
             self._pending = None
         else:
-            st = unpack_status(self.status.tolist())
+            st = (self._tail if self._tail is not None else self.status).tolist()
+        if self._tail is not None:      # [rows, w0, w1, w2, w3]: every row of the join is a member of an own set
+            self.extra = st[:1]
+            st = unpack_status(st[1:4] + st[:1])
+        else:
+            self.extra = st[self.status.numel():]
+            st = unpack_status(st[: self.status.numel()])
         self.status = None
         check_walk_flags(self, st[:4])
         if st[2]:

@@ -234,8 +234,76 @@ def pgather(edge, M, device=None, encode=None, gather_func=None, ptr=True, njobs
     return gather(edge, M, device, ptr=ptr, encode=encode)
 
 
+class StepBuffers:
+    """Everything one on-demand step (sample_and_gather) touches, allocated once for a fixed (B, M, m): the int32 roots, the
+    strided rows and their sizes, the table of distinct LP rows and the feature table indexed by its slots, the segment
+    pointers with the step's status words right behind them (one small read-back carries sizes, flags and the join's row
+    count) and the output buffer.  With it a step is SIX launches -- prologue (table reset + status + root narrowing),
+    walk, segment reduce, segment scan, LP unpack, join -- and no allocation; without it torch's allocator and a dozen
+    few-microsecond helper kernels sit between them (1,024 pairs: ~100 us of which the walk and the join are 55).
+    Reuse is the caller's business: a buffer set is busy until its step has been resolved (bench.py alternates two)."""
+
+    def __init__(self, csr, pairs, num_walks=200, num_steps=3, uniq_capacity=1 << 17, out=None):
+        from .sampler import FUSED_MAX_Q
+        L, dev = lib(), csr.device
+        self.B, self.M, self.m = int(pairs), int(num_walks), int(num_steps)
+        n, self.stride, self.k = 2 * self.B, self.M * self.m + 1, self.m + 1
+        if self.stride > FUSED_MAX_Q or self.m < 1:
+            raise ValueError(f"StepBuffers: num_walks*num_steps+1 = {self.stride} exceeds what the fused-row walk kernel holds")
+        self.capacity = int(uniq_capacity)
+        self.roots = torch.empty(n, dtype=torch.int32, device=dev)
+        self.nsize = torch.empty(n, dtype=torch.int32, device=dev)
+        self.ids = torch.empty(n * self.stride, dtype=torch.int32, device=dev)
+        self.slot = torch.empty(n * self.stride, dtype=torch.int32, device=dev)
+        self.table = torch.empty(L.subgacc_uniq_table_bytes(self.capacity), dtype=torch.uint8, device=dev)
+        self.tail = torch.zeros(n + 1 + 4, dtype=torch.int64, device=dev)      # seg [n+1] | status [4]
+        self.seg, self.status = self.tail[: n + 1], self.tail[n + 1:]
+        self.ws = torch.empty(max(L.subgacc_sjoin_workspace_bytes(n), 8), dtype=torch.uint8, device=dev)
+        self.feat = torch.empty((self.capacity + 1, self.k), dtype=torch.float32, device=dev)
+        need = n * self.stride * 2 * self.k
+        if out is not None and (out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev or out.numel() < need):
+            raise ValueError("StepBuffers: out= must hold 2B * (M*m+1) * 2 * (m+1) float32 on the graph's device")
+        self.out = out if out is not None else torch.empty(need, dtype=torch.float32, device=dev)
+
+
+def _buffered_step(csr, e, bufs, seed, out):
+    """sample_and_gather through a StepBuffers: six launches, nothing allocated, nothing read back"""
+    from . import _lib as lib_mod
+    from .sampler import SampledSets, _timed, make_cfg
+    L, st, dev = lib(), stream_ptr(), csr.device
+    B, M, m, k, n = bufs.B, bufs.M, bufs.m, bufs.k, 2 * bufs.B
+    if tuple(e.shape) != (2, B):
+        raise ValueError(f"these StepBuffers were made for [2, {B}] pairs")
+    e = e.contiguous()
+    flags = bufs.status.view(torch.int32)[:4]
+    cfg = make_cfg(csr, M, m, -1, seed, "philox")
+    check(L.subgacc_key_shift(cfg.num_walks, cfg.num_steps))
+    check(L.subgacc_step_prologue(ptr(bufs.table), bufs.capacity, ptr(bufs.status), 4, ptr(e), ptr(bufs.roots), n, st))
+    with _timed("walk_sets"):
+        check(L.subgacc_walk_spg(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n, 0, None, None,
+                                 ptr(bufs.table), bufs.capacity, ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize), ptr(flags), st))
+    own, partner = _arange_segments(B, dev)
+    check(L.subgacc_sjoin_sizes_rows(ptr(bufs.nsize), n, ptr(own), ptr(partner), n, ptr(bufs.seg), ptr(flags), ptr(bufs.ws),
+                                     bufs.ws.numel(), st))
+    keys = bufs.table[: bufs.capacity * 8].view(torch.int64)
+    check(L.subgacc_unpack_lp(ptr(keys), bufs.capacity, None, M, m, None, None, ptr(bufs.feat), 1, st))
+    res = out if out is not None else bufs.out
+    if res.dtype != torch.float32 or not res.is_contiguous() or res.device != dev or res.numel() < n * bufs.stride * 2 * k:
+        raise ValueError("out= must hold 2B * (M*m+1) * 2 * (m+1) float32 on the graph's device")
+    rows = res.numel() // (2 * k)
+    xz = res.view(-1)[: rows * 2 * k].view(rows, 2, k)
+    with _timed("sjoin_fill"):
+        check(L.subgacc_sjoin_fill_rows(ptr(bufs.nsize), n, bufs.stride, ptr(bufs.ids), ptr(bufs.slot), None, 0, ptr(own),
+                                        ptr(partner), n, ptr(bufs.seg), ptr(bufs.feat), bufs.capacity + 1, k, ptr(xz), None, None,
+                                        B, ptr(flags), st))
+    sets = SampledSets(bufs.nsize, None, bufs.ids, None, None, None, M, m, bufs.stride, None)
+    sets.slot, sets.table, sets.capacity, sets.strided = bufs.slot, bufs.table, bufs.capacity, True
+    sets.status, sets._tail = bufs.status, bufs.tail[n: n + 5]
+    return xz, bufs.seg, sets
+
+
 def sample_and_gather(csr, edge, num_walks=200, num_steps=3, seed=111413, rng="philox", dedup_roots=False, out=None,
-                      lazy=False, strided=None, **kw):
+                      lazy=False, strided=None, buffers=None, **kw):
     """The on-demand form of the path in one call: sample the endpoints of `edge` [2, B] (node ids), build their SpG
     rows, join -> (xz, indptr, sets), the same (xz, indptr) as `gather(edge, subg_matrix(G, arange(N)))` would give for sets
     drawn with the same RNG (Philox keys every walk by (seed, root id, walk, step), so a root's set does not depend on
@@ -243,10 +311,18 @@ def sample_and_gather(csr, edge, num_walks=200, num_steps=3, seed=111413, rng="p
 
     dedup_roots=True samples every distinct endpoint once (needs rng="philox"): evaluation batches repeat a source
     against a thousand candidates (utils.py:92-95), so half of the endpoints of such a batch are duplicates.
-    strided=None picks the joined-in-place form where the fused walk kernel is the faster one (spg.prefers_fused)."""
+    strided=None picks the joined-in-place form where the fused walk kernel is the faster one (spg.prefers_fused).
+    buffers=StepBuffers(...): the same step without a single allocation or helper kernel (six launches; the result is
+    lazy: sets.prefetch() / sets.resolve() as with lazy=True, xz is a view of out= or of the buffers' own output)."""
     from .spg import prefers_fused, sample_spg
     e = _as_rows(edge, csr.device)
     B = e.shape[1]
+    if buffers is not None:     # the allocation-free form of a serving loop: same rows, same (xz, indptr), lazily resolved
+        if dedup_roots or rng != "philox" or strided is False or kw.get("fused") is False or kw.get("bucket", -1) > 0 or \
+                (num_walks, num_steps) != (buffers.M, buffers.m) or kw.get("uniq_capacity", buffers.capacity) != buffers.capacity:
+            raise ValueError("buffers= serves the plain on-demand step (rng='philox', fused strided rows, no root dedup) "
+                             "of the shape the StepBuffers were made for")
+        return _buffered_step(csr, e, buffers, seed, out)
     if dedup_roots:
         if rng != "philox":
             raise ValueError("dedup_roots=True needs rng='philox' (rand_r sets depend on the position in the stream)")

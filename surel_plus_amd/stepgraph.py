@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from .sampler import check_walk_flags, unpack_status
-from .spjoin import sample_and_gather
+from .spjoin import StepBuffers, sample_and_gather
 
 
 class CapturedStep:
@@ -28,6 +28,11 @@ class CapturedStep:
         self.out = torch.empty(2 * self.B * (self.M * self.m + 1) * 2 * (self.m + 1), dtype=torch.float32, device=dev)
         self._kw = dict(num_walks=self.M, num_steps=self.m, seed=seed, rng=rng, out=self.out, lazy=True, strided=strided,
                         fused=fused, uniq_capacity=uniq_capacity)
+        if rng == "philox" and strided is not False and fused is not False:
+            try:      # the allocation-free six-launch form of the step (spjoin.StepBuffers) where it applies
+                self._kw["buffers"] = StepBuffers(csr, self.B, self.M, self.m, uniq_capacity=uniq_capacity, out=self.out)
+            except ValueError:
+                pass
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                   # allocator steady state + lazy code-object loads, uncaptured
@@ -40,6 +45,7 @@ class CapturedStep:
             self.xz, self.ind, self.sets = self._queue()
         # what finish() needs: the packed status of the sets (flags, distinct LP rows, members) and the join's row count
         self.status, self._rows = self.sets.status, self.ind[-1:]
+        self._tail = self.sets._tail          # StepBuffers: [rows, status x4] contiguous -> one copy
         self._host = torch.empty(self.status.numel() + 1, dtype=torch.int64, pin_memory=True)
         self._event = torch.cuda.Event()
 
@@ -53,8 +59,11 @@ class CapturedStep:
             raise ValueError(f"this step was captured for [2, {self.B}] pairs")
         self.edge.copy_(edge, non_blocking=True)
         self.graph.replay()
-        self._host[:-1].copy_(self.status, non_blocking=True)
-        self._host[-1:].copy_(self._rows, non_blocking=True)
+        if self._tail is not None:
+            self._host.copy_(self._tail, non_blocking=True)
+        else:
+            self._host[:-1].copy_(self.status, non_blocking=True)
+            self._host[-1:].copy_(self._rows, non_blocking=True)
         self._event.record()
         return self
 
@@ -62,6 +71,9 @@ class CapturedStep:
         """wait for the queued step, raise on its errors -> (xz float32 [R,2,k] view of the static buffer, indptr)"""
         self._event.synchronize()
         words = self._host.tolist()
+        if self._tail is not None:
+            words = words[1:] + words[:1]
+            words[3] = words[4]               # members = rows of the join (every row belongs to an own set)
         st = unpack_status(words[:-1]) + words[-1:]
         check_walk_flags(self.sets, st[:4])
         if st[2] or (self.sets.ukeys is not None and st[4] > self.sets.ukeys.numel()):

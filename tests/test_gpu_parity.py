@@ -1028,6 +1028,34 @@ def test_captured_step_replays_equal_the_eager_step(sp, B, hops, rng):
     assert torch.equal(ind, eind) and torch.equal(xz, exz)
 
 
+@pytest.mark.parametrize("B,M,hops", [(512, 100, 3), (300, 200, 2), (64, 50, 4)])
+def test_buffered_step_equals_the_allocating_step(sp, B, M, hops):
+    """spjoin.StepBuffers: the on-demand step as six launches over preallocated buffers gives bit for bit what the general
+    form gives, batch after batch through the same buffers; errors surface at resolve() as they do for lazy=True"""
+    from surel_plus_amd.graphs import query_pairs
+    ptr_, idx = sym_graph(20000, 120000, seed=13, hubs=3)
+    csr = sp.DeviceCSR(ptr_, idx)
+    bufs = sp.StepBuffers(csr, B, num_walks=M, num_steps=hops)
+    for s in (1, 2, 3):
+        e = query_pairs(csr, B, seed=s)
+        xz, ind, sets = sp.sample_and_gather(csr, e, num_walks=M, num_steps=hops, seed=9, rng="philox", buffers=bufs)
+        sets.prefetch().resolve()
+        exz, eind, esets = sp.sample_and_gather(csr, e, num_walks=M, num_steps=hops, seed=9, rng="philox")
+        rows = int(sets.extra[0])
+        assert rows == exz.shape[0] == sets.X == esets.X
+        assert torch.equal(ind, eind) and torch.equal(xz[:rows], exz)
+        assert sets.c == esets.c and torch.equal(sets.number().ukeys, esets.number().ukeys)
+    bad = query_pairs(csr, B, seed=4)
+    bad[0, 3] = 20000
+    _, _, sets = sp.sample_and_gather(csr, bad, num_walks=M, num_steps=hops, seed=9, rng="philox", buffers=bufs)
+    with pytest.raises(IndexError):
+        sets.resolve()
+    with pytest.raises(ValueError):
+        sp.sample_and_gather(csr, bad, num_walks=M, num_steps=hops, seed=9, rng="rand_r", buffers=bufs)
+    with pytest.raises(ValueError):
+        sp.StepBuffers(csr, 8, num_walks=300, num_steps=4)             # 1,201 members: beyond the fused-row kernel
+
+
 def test_captured_step_pool_keeps_batches_in_flight_on_their_own_streams(sp):
     """stepgraph.CapturedStepPool: four captured steps on four streams, three batches in flight; every batch equals the
     eager step for the same pairs, whatever was in flight around it"""
