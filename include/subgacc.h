@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SUBGACC_ABI_VERSION 2
+#define SUBGACC_ABI_VERSION 3
 
 typedef enum subgacc_status {
     SUBGACC_OK = 0,
@@ -68,7 +68,24 @@ typedef struct subgacc_walk_cfg {
     int32_t cap_root_degree; /* 1: clamp the root degree to 1e6 (NEBMAX, subg_acc.c:750)        */
     int32_t indptr64;        /* CSR row offsets are int64 (else int32)                          */
     int32_t emit_walks;      /* 1: also write raw walks int32[n, M*(m+1)] (walk_sampler)        */
+    /* ABI 3: optional packed hop records of the graph (subgacc_hop_records_build), NULL = none.  The fused-row kernel
+     * then makes ONE dependent 8-byte read per hop (neighbour id + its row begin + its degree) instead of a neighbour
+     * read followed by a row-pointer read; results are identical.  rec_id_bits / rec_beg_bits as given to the build;
+     * both 0 = the 16-byte form.  The 8-byte form goes with int32 row offsets, the 16-byte form with int64 (a mismatch is
+     * ignored: the plain CSR is walked). */
+    const void *hop_records;
+    int32_t rec_id_bits, rec_beg_bits;
 } subgacc_walk_cfg;
+
+/* Hop records: rec[e] = [indices[e] : id_bits | indptr[indices[e]] : beg_bits | degree(indices[e]) : rest], one uint64 per
+ * CSR entry (8*nnz bytes).  subgacc_hop_records_format picks the field widths for a graph and returns the bits left for
+ * the degree (a degree that does not fit is stored as all ones: the kernel reads the row pointers for that node), or
+ * SUBGACC_ERR_BADARG when fewer than 8 are left (records are not worth building then).
+ * id_bits = beg_bits = 0 builds the 16-byte form {id : 32 | degree : 32, row begin : 64} (recs: 2 uint64 per entry, 16*nnz
+ * bytes) -- what a graph with int64 row offsets takes. */
+int subgacc_hop_records_format(int64_t num_nodes, int64_t nnz, int32_t *id_bits, int32_t *beg_bits);
+int subgacc_hop_records_build(const void *indptr, int32_t indptr64, const int32_t *indices, int64_t num_nodes, int64_t nnz,
+                              int32_t id_bits, int32_t beg_bits, uint64_t *recs, void *stream);
 
 /* LP rows are carried as one packed 64-bit key: count of step j in bits [(m-j)*SHIFT, +SHIFT),
  * SHIFT = 32-clz(M), plus bit m*SHIFT (LEAD) on the root row -- the reference's `bithash`

@@ -31,6 +31,7 @@ SYMBOLS = (
     "subgacc_walk_join", "subgacc_sjoin_sizes_rows", "subgacc_sjoin_fill_rows",
     "subgacc_encode_sizes", "subgacc_encode_fill", "subgacc_sjoin_pairs", "subgacc_finish_rows",
     "subgacc_batch_sampler_workspace_bytes", "subgacc_batch_sampler", "subgacc_step_prologue",
+    "subgacc_hop_records_format", "subgacc_hop_records_build",
 )
 
 
@@ -38,7 +39,8 @@ class WalkCfg(C.Structure):
     """struct subgacc_walk_cfg"""
     _fields_ = [("num_walks", C.c_int32), ("num_steps", C.c_int32), ("bucket", C.c_int32), ("rng_mode", C.c_int32),
                 ("seed", C.c_uint32), ("first_hop_wo", C.c_int32), ("order", C.c_int32),
-                ("cap_root_degree", C.c_int32), ("indptr64", C.c_int32), ("emit_walks", C.c_int32)]
+                ("cap_root_degree", C.c_int32), ("indptr64", C.c_int32), ("emit_walks", C.c_int32),
+                ("hop_records", C.c_void_p), ("rec_id_bits", C.c_int32), ("rec_beg_bits", C.c_int32)]
 
 
 class SubgAccError(RuntimeError):
@@ -105,6 +107,8 @@ def lib():
     sig["subgacc_ppr_normalize"] = (C.c_int, [vp, i32, vp, i64, vp, i64, vp, vp, i32, vp, vp, vp])
     sig["subgacc_ppr_encode"] = (C.c_int, [vp, i64, vp, vp, vp])
     sig["subgacc_walk_join"] = (C.c_int, [vp, i64, i32, vp, vp, vp, i32, vp, i64, vp, vp])
+    sig["subgacc_hop_records_format"] = (C.c_int, [i64, i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)])
+    sig["subgacc_hop_records_build"] = (C.c_int, [vp, i32, vp, i64, i64, i32, i32, vp, vp])
     sig["subgacc_step_prologue"] = (C.c_int, [vp, i64, vp, i64, vp, vp, i64, vp])
     sig["subgacc_batch_sampler_workspace_bytes"] = (sz, [i64])
     sig["subgacc_batch_sampler"] = (C.c_int, [vp, i32, vp, i64, vp, i64, i32, i32, i32, C.c_uint32, vp, i64, vp, vp, sz, vp, vp])
@@ -119,7 +123,7 @@ def lib():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    if L.subgacc_abi_version() != 2:
+    if L.subgacc_abi_version() != 3:
         raise SubgAccError("libsubgacc_hip.so ABI version mismatch")
     _lib = L
     return L

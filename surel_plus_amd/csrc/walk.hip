@@ -658,6 +658,79 @@ extern "C" int subgacc_rng_positions(const subgacc_walk_cfg *cfg, const void *in
     return SUBGACC_OK;
 }
 
+template <bool IDX64>
+__global__ void hop_records_kernel(const void *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t num_nodes,
+                                   int64_t nnz, RecFmt f, unsigned long long *__restrict__ recs) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    const int32_t v = indices[e];
+    int64_t beg = 0, deg = 0;
+    if ((uint64_t)(int64_t)v < (uint64_t)num_nodes) load_row<IDX64>(indptr, v, beg, deg);
+    const int deg_bits = 64 - f.id_bits - f.beg_bits;
+    const unsigned long long dmask = (1ull << deg_bits) - 1ull;
+    const unsigned long long dv = (unsigned long long)deg >= dmask ? dmask : (unsigned long long)deg;   // all ones = escape
+    recs[e] = ((unsigned long long)(uint32_t)v << (64 - f.id_bits)) | ((unsigned long long)beg << deg_bits) | dv;
+}
+
+// 16-byte form for graphs with int64 row offsets: {neighbour id : 32 | its degree : 32 (saturated), its row begin : 64}
+template <bool IDX64>
+__global__ void hop_records16_kernel(const void *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t num_nodes,
+                                     int64_t nnz, ulonglong2 *__restrict__ recs) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nnz) return;
+    const int32_t v = indices[e];
+    int64_t beg = 0, deg = 0;
+    if ((uint64_t)(int64_t)v < (uint64_t)num_nodes) load_row<IDX64>(indptr, v, beg, deg);
+    recs[e] = make_ulonglong2(((unsigned long long)(deg > 0xFFFFFFFFll ? 0xFFFFFFFFull : (unsigned long long)deg) << 32) | (uint32_t)v,
+                              (unsigned long long)beg);
+}
+
+extern "C" int subgacc_hop_records_format(int64_t num_nodes, int64_t nnz, int32_t *id_bits, int32_t *beg_bits) {
+    SG_REQUIRE(num_nodes >= 0 && nnz >= 0 && id_bits && beg_bits, SUBGACC_ERR_BADARG, "hop_records_format: bad arguments");
+    int ib = 1, bb = 1;
+    while (ib < 32 && ((int64_t)1 << ib) < num_nodes) ++ib;
+    while (bb < 40 && ((int64_t)1 << bb) <= nnz) ++bb;
+    *id_bits = ib, *beg_bits = bb;
+    const int deg_bits = 64 - ib - bb;
+    SG_REQUIRE(deg_bits >= 8, SUBGACC_ERR_BADARG, "hop_records_format: only %d bits left for the degree", deg_bits);
+    return deg_bits;
+}
+
+extern "C" int subgacc_hop_records_build(const void *indptr, int32_t indptr64, const int32_t *indices, int64_t num_nodes,
+                                         int64_t nnz, int32_t id_bits, int32_t beg_bits, uint64_t *recs, void *stream) {
+    SG_REQUIRE(indptr && num_nodes >= 0 && nnz >= 0, SUBGACC_ERR_BADARG, "hop_records_build: bad arguments");
+    if (id_bits == 0 && beg_bits == 0) {     // the 16-byte form (2 uint64 per entry)
+        if (nnz == 0) return SUBGACC_OK;
+        SG_REQUIRE(indices && recs, SUBGACC_ERR_BADARG, "hop_records_build: null argument");
+        const int64_t blocks16 = ceil_div(nnz, 256);
+        SG_REQUIRE(blocks16 < (1ll << 31), SUBGACC_ERR_BADARG, "hop_records_build: graph too large for one launch");
+        if (indptr64)
+            hipLaunchKernelGGL(hop_records16_kernel<true>, dim3((unsigned)blocks16), dim3(256), 0, (hipStream_t)stream, indptr,
+                               indices, num_nodes, nnz, (ulonglong2 *)recs);
+        else
+            hipLaunchKernelGGL(hop_records16_kernel<false>, dim3((unsigned)blocks16), dim3(256), 0, (hipStream_t)stream, indptr,
+                               indices, num_nodes, nnz, (ulonglong2 *)recs);
+        SG_LAUNCH_CHECK();
+        return SUBGACC_OK;
+    }
+    SG_REQUIRE(id_bits >= 1 && beg_bits >= 1 && id_bits + beg_bits <= 56, SUBGACC_ERR_BADARG, "hop_records_build: bad field widths");
+    SG_REQUIRE(num_nodes <= ((int64_t)1 << id_bits) && nnz < ((int64_t)1 << beg_bits), SUBGACC_ERR_BADARG,
+               "hop_records_build: the graph does not fit id_bits = %d / beg_bits = %d", id_bits, beg_bits);
+    if (nnz == 0) return SUBGACC_OK;
+    SG_REQUIRE(indices && recs, SUBGACC_ERR_BADARG, "hop_records_build: null argument");
+    const RecFmt f{id_bits, beg_bits};
+    const int64_t blocks = ceil_div(nnz, 256);
+    SG_REQUIRE(blocks < (1ll << 31), SUBGACC_ERR_BADARG, "hop_records_build: graph too large for one launch");
+    if (indptr64)
+        hipLaunchKernelGGL(hop_records_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, indptr, indices,
+                           num_nodes, nnz, f, (unsigned long long *)recs);
+    else
+        hipLaunchKernelGGL(hop_records_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, indptr, indices,
+                           num_nodes, nnz, f, (unsigned long long *)recs);
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}
+
 static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,
                        const int32_t *query, int64_t n, const uint32_t *rng_pos, const uint32_t *rng_seed,
                        int32_t *set_ids, uint64_t *set_keys, int32_t *set_slot, void *uniq_table, int64_t uniq_capacity,
@@ -706,6 +779,12 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
     a.set_slot = set_slot;
     a.table = spg ? uniq_view(uniq_table, uniq_capacity) : UniqTable{nullptr, nullptr, nullptr, 0};
     a.root_base = root_base;
+    a.recs = (const unsigned long long *)cfg->hop_records;
+    a.rec.id_bits = cfg->rec_id_bits, a.rec.beg_bits = cfg->rec_beg_bits;
+    SG_REQUIRE(!a.recs || (a.rec.id_bits == 0 && a.rec.beg_bits == 0) ||
+                   (a.rec.id_bits >= 1 && a.rec.beg_bits >= 1 && a.rec.id_bits + a.rec.beg_bits <= 56),
+               SUBGACC_ERR_BADARG, "walk: hop records with field widths %d / %d", a.rec.id_bits, a.rec.beg_bits);
+    if (a.recs && (cfg->indptr64 != 0) != (a.rec.id_bits == 0)) a.recs = nullptr;   // 8-byte form <-> int32 offsets, 16-byte <-> int64
     SG_REQUIRE(a.T <= 65536, SUBGACC_ERR_LDS, "walk: M*m+1 = %d is too large for the per-root LDS tables", Q);
     // SUBGACC_LDS_PAD (dev-only): extra dynamic LDS per workgroup, i.e. fewer resident workgroups per CU -- the
     // occupancy response of the kernel (tools/README.md)

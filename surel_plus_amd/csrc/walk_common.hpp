@@ -80,6 +80,23 @@ __device__ __forceinline__ void load_row(const void *indptr, int32_t node, int64
     }
 }
 
+// ------------------------------------------------------------------- packed hop records (experiment, round 2)
+// rec = [neighbour id : id_bits | its row begin : beg_bits | its degree : 64 - id_bits - beg_bits]: ONE dependent 8-byte read
+// per hop instead of a neighbour read followed by a row-pointer read.  A degree field of all ones means "does not fit":
+// the walk reads the row pointers for that node.
+struct RecFmt {
+    int32_t id_bits, beg_bits;
+};
+__device__ __forceinline__ void rec_unpack(unsigned long long r, const RecFmt &f, int32_t &id, int64_t &beg, int64_t &deg,
+                                           bool &escaped) {
+    const int deg_bits = 64 - f.id_bits - f.beg_bits;
+    const unsigned long long dmask = (1ull << deg_bits) - 1ull;
+    id = (int32_t)(r >> (64 - f.id_bits));
+    beg = (int64_t)((r >> deg_bits) & ((1ull << f.beg_bits) - 1ull));
+    deg = (int64_t)(r & dmask);
+    escaped = (r & dmask) == dmask;
+}
+
 struct WalkArgs {
     const void *indptr;
     const int32_t *indices;
@@ -101,6 +118,8 @@ struct WalkArgs {
     int32_t *set_slot;
     UniqTable table;
     int64_t root_base;   // global index of query[0]: tags (root_base+i)*stride + rank order the first occurrences
+    const unsigned long long *recs;   // packed hop records (walk_rows_kernel<REC>), else NULL
+    RecFmt rec;                       // id_bits = 0: the 16-byte form {id : 32 | degree : 32, row begin : 64} (int64 row offsets)
 };
 
 constexpr int kSpgFoldBits = 7;

@@ -49,7 +49,8 @@ __device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
 
 // NT lanes per workgroup (256, or 128 with two walks per lane: twice the roots per CU where the 512-slot table leaves the
 // LDS for them), SPL table slots per lane, T = NT * SPL.
-template <bool IDX64, int RNG, int MH, int SPL, int NT>
+// REC: 0 = plain CSR; 8 = packed 8-byte hop records (int32 row offsets); 16 = 16-byte records (int64 row offsets)
+template <bool IDX64, int RNG, int MH, int SPL, int NT, int REC = 0>
 __global__ __launch_bounds__(NT, 8) __attribute__((amdgpu_num_sgpr(80))) void walk_rows_kernel(const WalkArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     constexpr int T = SPL * NT;                                   // 512 or 1,024 slots
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(NT, 8) __attribute__((amdgpu_num_sgpr(80))) void wa
     {
         bool wk[WPL];
         int32_t cur[WPL];
+        unsigned long long rec[WPL], rec2[WPL];         // REC: the record of the node the walk stands on (rec2: its row begin, 16-byte form)
         uint32_t dr[WPL][MH > 1 ? 2 * (MH / 2) : 2];   // draws of hops 2..MH (Philox: computed while the first load is in flight)
         uint32_t x[WPL];
 #pragma unroll
@@ -160,6 +162,7 @@ __global__ __launch_bounds__(NT, 8) __attribute__((amdgpu_num_sgpr(80))) void wa
             const int w = tid + k * NT;
             wk[k] = w < M;
             cur[k] = root;
+            rec[k] = rec2[k] = 0ull;
             x[k] = 0;
             if (!wk[k]) continue;
             uint32_t pick;
@@ -171,7 +174,14 @@ __global__ __launch_bounds__(NT, 8) __attribute__((amdgpu_num_sgpr(80))) void wa
             } else {
                 pick = (uint32_t)w % rdeg;
             }
-            cur[k] = SG_NEIGH_LOAD(&a.indices[rbeg + pick]);
+            if (REC == 16) {
+                const ulonglong2 r2 = ((const ulonglong2 *)a.recs)[rbeg + pick];
+                rec[k] = r2.x, rec2[k] = r2.y;
+            } else if (REC == 8) {
+                rec[k] = a.recs[rbeg + pick];
+            } else {
+                cur[k] = SG_NEIGH_LOAD(&a.indices[rbeg + pick]);
+            }
         }
 #pragma unroll
         for (int k = 0; k < WPL; ++k) {
@@ -191,7 +201,35 @@ __global__ __launch_bounds__(NT, 8) __attribute__((amdgpu_num_sgpr(80))) void wa
 #pragma unroll
             for (int k = 0; k < WPL; ++k) {
                 b[k] = d[k] = 0;
-                if (wk[k] && s + 1 < MH) load_row<IDX64>(a.indptr, cur[k], b[k], d[k]);   // the next hop's row: in flight under the visit
+                if (!wk[k]) continue;
+                if (REC) {      // the record carries the node AND its row: the next record is asked for before the visit
+                    bool esc = false;
+                    if (REC == 16) {
+                        cur[k] = (int32_t)(uint32_t)rec[k];
+                        d[k] = (int64_t)(rec[k] >> 32);
+                        b[k] = (int64_t)rec2[k];
+                    } else {
+                        rec_unpack(rec[k], a.rec, cur[k], b[k], d[k], esc);
+                    }
+                    if (s + 1 < MH) {
+                        if (esc) load_row<IDX64>(a.indptr, cur[k], b[k], d[k]);
+                        if (d[k] > 0) {
+                            uint32_t off;
+                            if (RNG == SUBGACC_RNG_RAND_R) off = rand_r_next(x[k]) % (uint32_t)d[k];
+                            else off = philox_below(dr[k][s], (uint32_t)d[k]);
+                            if (REC == 16) {
+                                const ulonglong2 r2 = ((const ulonglong2 *)a.recs)[b[k] + (int64_t)off];
+                                rec[k] = r2.x, rec2[k] = r2.y;
+                            } else {
+                                rec[k] = a.recs[b[k] + (int64_t)off];
+                            }
+                        } else if (RNG == SUBGACC_RNG_RAND_R) {
+                            atomicOr(&a.flags[0], 1);
+                        }
+                    }
+                } else if (s + 1 < MH) {
+                    load_row<IDX64>(a.indptr, cur[k], b[k], d[k]);   // the next hop's row: in flight under the visit
+                }
             }
 #pragma unroll
             for (int k = 0; k < WPL; ++k) {
@@ -206,7 +244,7 @@ __global__ __launch_bounds__(NT, 8) __attribute__((amdgpu_num_sgpr(80))) void wa
                 atomicMin(&minq[h], (uint32_t)((tid + k * NT) * MH + s + 1));
                 atomicAdd(&pk[h], 1ull << ((MH - 1 - s) * a.shift));
             }
-            if (s + 1 < MH) {
+            if (!REC && s + 1 < MH) {
 #pragma unroll
                 for (int k = 0; k < WPL; ++k) {
                     if (!wk[k]) continue;
@@ -413,9 +451,13 @@ int launch_walk_rows(const WalkArgs &a, bool indptr64, int rng_mode, size_t lds,
     // 512-slot tables: 128 lanes x 2 walks (SUBGACC_ROWS_NT=256 forces one walk per lane; dev-only)
     static const bool nt256 = getenv("SUBGACC_ROWS_NT") && atoi(getenv("SUBGACC_ROWS_NT")) == 256;
     const bool half = a.T == 512 && !nt256;
+    const bool rec = a.recs != nullptr && indptr64 == (a.rec.id_bits == 0);   // hop records: one dependent read per hop
 #define SG_ROWS(I64, RNGM, MHH, SPLL, NTT)                                                                         \
     do {                                                                                                           \
-        hipLaunchKernelGGL((walk_rows_kernel<I64, RNGM, MHH, SPLL, NTT>), dim3((unsigned)grid), dim3(NTT), lds, s, a); \
+        if (rec)                                                                                                   \
+            hipLaunchKernelGGL((walk_rows_kernel<I64, RNGM, MHH, SPLL, NTT, I64 ? 16 : 8>), dim3((unsigned)grid), dim3(NTT), lds, s, a); \
+        else                                                                                                       \
+            hipLaunchKernelGGL((walk_rows_kernel<I64, RNGM, MHH, SPLL, NTT>), dim3((unsigned)grid), dim3(NTT), lds, s, a); \
         return 1;                                                                                                  \
     } while (0)
 #define SG_ROWS_MH(I64, RNGM, SPLL, NTT)                      \

@@ -9,6 +9,8 @@ n*(M*m+1), leaves every count on the device and reads nothing back: sizes, flags
 are fetched in one copy when the caller first asks for them (SampledSets.resolve()), so a whole
 sample -> SpG -> SpJoin step queues up asynchronously.
 """
+import ctypes
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -23,6 +25,15 @@ UNIQ_CAPACITY = 1 << 20
 FUSED_MAX_Q = 818       # subgacc_walk_spg keeps 4 table slots per lane in registers (per-root table <= 1024 slots)
 RANK_LIMIT = 16384      # distinct LP rows that the table-only numbering ranks directly
 FINISH_MAX_STRIDE = 1024   # subgacc_finish_rows sorts a row from registers (16 members per lane of one wave)
+
+# Packed hop records (csrc/walk_rows.hip, REC form): 8 bytes per CSR entry holding the neighbour, its row begin and its degree,
+# so that a hop of the fused-row kernel is ONE dependent random read instead of two (-8 % kernel time on the cit2-like graph,
+# -4 % on ppa; a graph that lives in L2 gains nothing from an array twice the size of its adjacency).  "auto": built (once
+# per DeviceCSR, on first use) for int32-offset graphs whose adjacency is beyond the L2s and whose degrees fit the field;
+# "1" / "0" force / forbid.  Results are identical either way.
+HOP_RECORDS = os.environ.get("SUBGACC_HOP_RECORDS", "auto")
+HOP_RECORDS_MIN_BYTES = 64 << 20      # adjacency bytes from which records are built in "auto" mode
+HOP_RECORDS_MIN_DEG_BITS = 12
 
 # bench.py sets this to a callable(name) -> context manager that brackets one kernel launch with HIP events
 # on the launch stream (roofline.achieved is measured live, not taken from a profile)
@@ -80,6 +91,43 @@ class DeviceCSR:
     @property
     def nnz(self):
         return self.indices.numel()
+
+    def hop_records(self, force=None, bits=None):
+        """(recs int64 [nnz], id_bits, beg_bits) -- the packed hop records of this graph (include/subgacc.h:
+        subgacc_hop_records_build), built once and kept -- or None where they do not apply (int64 row offsets, degrees
+        that do not fit, a graph that lives in the caches, SUBGACC_HOP_RECORDS=0).  int32 row offsets: 8 bytes per entry
+        (id_bits, beg_bits > 0); int64 row offsets: 16 bytes per entry (id_bits = beg_bits = 0).  `bits=(id_bits, beg_bits)`
+        overrides the field widths of the 8-byte form (tests: a narrow degree field exercises the escape path)."""
+        cached = getattr(self, "_recs", None)
+        if cached is not None and force is None and bits is None:
+            return cached[1]                       # decided before (by the policy, or by an explicit call): it sticks
+        mode = HOP_RECORDS if force is None else ("1" if force else "0")
+        key = tuple(bits) if bits is not None else None
+        if mode == "0" or self.nnz == 0:
+            self._recs = (key, None)
+            return None
+        L = lib()
+        out = None
+        big = mode == "1" or bits is not None or 4 * self.nnz >= HOP_RECORDS_MIN_BYTES
+        if self.indptr64:                           # 16-byte form: {id | degree, row begin}
+            if big:
+                recs = torch.empty(2 * self.nnz, dtype=torch.int64, device=self.device)
+                check(L.subgacc_hop_records_build(ptr(self.indptr), 1, ptr(self.indices), self.num_nodes, self.nnz, 0, 0, ptr(recs),
+                                                  stream_ptr()))
+                out = (recs, 0, 0)
+        else:
+            ib, bb = ctypes.c_int32(0), ctypes.c_int32(0)
+            deg_bits = L.subgacc_hop_records_format(self.num_nodes, self.nnz, ctypes.byref(ib), ctypes.byref(bb))
+            if bits is not None:
+                ib, bb = ctypes.c_int32(int(bits[0])), ctypes.c_int32(int(bits[1]))
+                deg_bits = 64 - ib.value - bb.value
+            if big and deg_bits >= (HOP_RECORDS_MIN_DEG_BITS if (mode == "auto" and bits is None) else 1):
+                recs = torch.empty(self.nnz, dtype=torch.int64, device=self.device)
+                check(L.subgacc_hop_records_build(ptr(self.indptr), 0, ptr(self.indices), self.num_nodes, self.nnz, ib.value,
+                                                  bb.value, ptr(recs), stream_ptr()))
+                out = (recs, ib.value, bb.value)
+        self._recs = (key, out)
+        return out
 
 
 @dataclass
@@ -261,9 +309,11 @@ def make_cfg(csr, num_walks, num_steps, bucket=-1, seed=111413, rng="rand_r", fi
     rng_mode = {"rand_r": _lib.RNG_RAND_R, "philox": _lib.RNG_PHILOX}[rng]
     if num_walks <= 0 or num_steps <= 0:
         raise TypeError("Input parsing error. (num_walks and num_steps must be positive)")
+    recs = csr.hop_records() if (first_hop_wo and not emit_walks and order == _lib.ORDER_WALK_MAJOR) else None
     return WalkCfg(int(num_walks), int(num_steps), int(bucket), rng_mode, int(seed) & 0xFFFFFFFF,
                    1 if first_hop_wo else 0, int(order), 1 if cap_root_degree else 0,
-                   1 if csr.indptr64 else 0, 1 if emit_walks else 0)
+                   1 if csr.indptr64 else 0, 1 if emit_walks else 0,
+                   recs[0].data_ptr() if recs else None, recs[1] if recs else 0, recs[2] if recs else 0)
 
 
 def _as_query(query, device):

@@ -1130,6 +1130,33 @@ def test_specialised_fused_row_kernel_on_shuffled_roots(sp, rng, M, m, idx64):
     assert np.array_equal(info.enc_int16().cpu().numpy(), oenc)
 
 
+@pytest.mark.parametrize("rng", ["rand_r", "philox"])
+@pytest.mark.parametrize("M,m,bits", [(200, 3, None), (100, 2, None), (200, 4, (24, 32)), (64, 4, (20, 36)), (200, 2, "i64"),
+                                      (100, 3, "i64")])
+def test_hop_records_give_the_same_rows(sp, rng, M, m, bits):
+    """DeviceCSR.hop_records(): one packed 8-byte record per CSR entry (neighbour, its row begin, its degree) lets the
+    fused-row kernel make one dependent read per hop; rows, sizes and numbering are what the plain CSR gives -- also when
+    the degree field is so narrow (bits=: 8 bits left) that hubs take the escape path back to the row pointers"""
+    ptr_, idx = sym_graph(6000, 60000, seed=29, hubs=4)            # hubs of degree ~1,500 next to degree-20 nodes
+    q = np.concatenate([np.random.default_rng(3).permutation(6000)[:3000], [0, 1, 2, 3]])
+    from surel_plus_amd.sampler import DeviceCSR
+    wide = bits == "i64"                                           # int64 row offsets: the 16-byte form of the records
+    bits = None if wide else bits
+    ptr_w = ptr_.astype(np.int64) if wide else ptr_
+    plain, recs = DeviceCSR(ptr_w, idx), DeviceCSR(ptr_w, idx)
+    assert plain.hop_records(force=False) is None
+    r = recs.hop_records(force=True, bits=bits)
+    assert r is not None and r[0].numel() == recs.nnz * (2 if wide else 1) and recs.hop_records() is r
+    assert (r[1] == 0) == wide
+    za, ia = sp.sample_spg(plain, q, num_walks=M, num_steps=m, seed=17, rng=rng, fused=True)
+    zb, ib = sp.sample_spg(recs, q, num_walks=M, num_steps=m, seed=17, rng=rng, fused=True)
+    for a_, b_ in ((za.indptr, zb.indptr), (za.indices, zb.indices), (za.data, zb.data), (ia.enc_int16(), ib.enc_int16())):
+        assert torch.equal(a_, b_)
+    (oi, ox, od), oenc = _oracle_spg(ptr_, idx, q, M, m, 17, rng, -1)
+    assert np.array_equal(zb.indptr.cpu().numpy(), oi) and np.array_equal(zb.indices.cpu().numpy(), ox)
+    assert np.array_equal(zb.data.cpu().numpy(), od) and np.array_equal(ib.enc_int16().cpu().numpy(), oenc)
+
+
 # ------------------------------------------------------------------------------- batch_sampler (legacy SUREL mini-batches)
 @pytest.mark.parametrize("name", golden_files("batch_"))
 def test_batch_sampler_matches_reference_golden(sp, name):
