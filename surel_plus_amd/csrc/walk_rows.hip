@@ -15,6 +15,8 @@
 // Bit-identical rows, sizes and table tags (tests/test_gpu_parity.py runs both forms against the oracle).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "walk_common.hpp"
 
 namespace subgacc {
@@ -50,18 +52,24 @@ __device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
 // NT lanes per workgroup (256, or 128 with two walks per lane: twice the roots per CU where the 512-slot table leaves the
 // LDS for them), SPL table slots per lane, T = NT * SPL.
 // REC: 0 = plain CSR; 8 = packed 8-byte hop records (int32 row offsets); 16 = 16-byte records (int64 row offsets)
-template <bool IDX64, int RNG, int MH, int SPL, int NT, int REC = 0>
-__global__ __launch_bounds__(NT, 8) __attribute__((amdgpu_num_sgpr(80))) void walk_rows_kernel(const WalkArgs a) {
+// K32: the packed landing counts (and the LP keys made of them) fit 32 bits (m*SHIFT+1 <= 31: every reference
+// configuration up to 3 hops) -- 12 bytes of LDS per table slot instead of 16, which is what lets the 1,024-slot table of the
+// 3-hop configurations run with 128 lanes x 8 slots per lane and 11 roots per CU instead of 8.
+template <bool IDX64, int RNG, int MH, int SPL, int NT, int REC = 0, bool K32 = false>
+__global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80))) void walk_rows_kernel(const WalkArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
+    using CntT = typename std::conditional<K32, uint32_t, unsigned long long>::type;
+    static_assert((SPL * sizeof(CntT)) % 16 == 0, "a lane's counts are cleared and read with 16-byte LDS accesses");
+    constexpr CntT kNoKey = (CntT)~(CntT)0;                       // empty marker of the fold table
     constexpr int T = SPL * NT;                                   // 512 or 1,024 slots
     constexpr int TSHIFT = T == 1024 ? 22 : 23;                   // 32 - log2(T)
     constexpr int WPL = kWalkThreads / NT;                        // walks per lane (M <= 256)
     constexpr uint32_t TMASK = (uint32_t)T - 1u;
-    unsigned long long *pk = (unsigned long long *)lds_raw;      // [T] packed landing counts
+    CntT *pk = (CntT *)lds_raw;                                   // [T] packed landing counts
     int32_t *keys = (int32_t *)(pk + T);                          // [T] node ids
     uint32_t *minq = (uint32_t *)(keys + T);                      // [T] first visit sequence number
     int32_t *sarr = (int32_t *)(minq + T);                        // [M] Fisher-Yates draws
-    unsigned long long *fk = (unsigned long long *)(((uintptr_t)(sarr + a.M) + 7) & ~(uintptr_t)7);   // [kSpgFold]
+    CntT *fk = (CntT *)(((uintptr_t)(sarr + a.M) + 7) & ~(uintptr_t)7);   // [kSpgFold]
     uint32_t *ft = (uint32_t *)(fk + kSpgFold);                   // [kSpgFold] min visit number of the key inside the set
     int32_t *fs = (int32_t *)(ft + kSpgFold);                     // [kSpgFold] HBM table slot of the key
     int32_t *red = fs + kSpgFold;                                 // [16]
@@ -72,16 +80,21 @@ __global__ __launch_bounds__(NT, 8) __attribute__((amdgpu_num_sgpr(80))) void wa
     const int M = a.M;
     const int32_t root = a.query[i];
     // while the root's two dependent loads (query -> row pointer) are in flight: clear what does not depend on them
-    if (SPL == 4) {
-        ((ulonglong2 *)pk)[2 * tid] = make_ulonglong2(0ull, 0ull);
-        ((ulonglong2 *)pk)[2 * tid + 1] = make_ulonglong2(0ull, 0ull);
-        ((uint4 *)minq)[tid] = make_uint4(~0u, ~0u, ~0u, ~0u);
-    } else {
-        ((ulonglong2 *)pk)[tid] = make_ulonglong2(0ull, 0ull);
-        ((uint2 *)minq)[tid] = make_uint2(~0u, ~0u);
+    {   // a lane clears the SPL consecutive slots it owns, with 16-byte stores (8-byte for the 2 x 4-byte case)
+        constexpr int PKB = SPL * (int)sizeof(CntT), MQB = SPL * 4;
+        uint4 *pp = (uint4 *)(pk + tid * SPL);
+#pragma unroll
+        for (int c = 0; c < PKB / 16; ++c) pp[c] = make_uint4(0u, 0u, 0u, 0u);
+        if (MQB % 16 == 0) {
+            uint4 *qp = (uint4 *)(minq + tid * SPL);
+#pragma unroll
+            for (int c = 0; c < MQB / 16; ++c) qp[c] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        } else {
+            ((uint2 *)minq)[tid] = make_uint2(~0u, ~0u);
+        }
     }
     if (tid < kSpgFold) {
-        fk[tid] = kEmptyKey;
+        fk[tid] = kNoKey;
         ft[tid] = 0xFFFFFFFFu;
     }
     if (tid < 16) red[tid] = tid < 4 ? 0x7FFFFFFF : 0;   // [0..3] min id per wave, [4..7] max id, [8] member count
@@ -98,22 +111,25 @@ __global__ __launch_bounds__(NT, 8) __attribute__((amdgpu_num_sgpr(80))) void wa
         // same lane order is not guaranteed across waves, so the root's lane writes BOTH of its words here)
         const uint32_t hroot = ((uint32_t)root * 2654435761u) >> TSHIFT;
         const int x0 = tid * SPL;
-        if (SPL == 4) {
-            ((int4 *)keys)[tid] = make_int4((uint32_t)x0 == hroot ? root : -1, (uint32_t)(x0 + 1) == hroot ? root : -1,
-                                            (uint32_t)(x0 + 2) == hroot ? root : -1, (uint32_t)(x0 + 3) == hroot ? root : -1);
+        int32_t kv[SPL];
+#pragma unroll
+        for (int u = 0; u < SPL; ++u) kv[u] = (uint32_t)(x0 + u) == hroot ? root : -1;
+        if (SPL % 4 == 0) {
+#pragma unroll
+            for (int c = 0; c < SPL / 4; ++c) ((int4 *)(keys + x0))[c] = make_int4(kv[4 * c], kv[4 * c + 1], kv[4 * c + (SPL > 2 ? 2 : 0)], kv[4 * c + (SPL > 2 ? 3 : 1)]);
         } else {
-            ((int2 *)keys)[tid] = make_int2((uint32_t)x0 == hroot ? root : -1, (uint32_t)(x0 + 1) == hroot ? root : -1);
+            ((int2 *)keys)[tid] = make_int2(kv[0], kv[1]);
         }
         if ((hroot / SPL) == (uint32_t)tid) minq[hroot] = 0u;     // the lane that cleared this word, after its clear
     }
     if (a.cap_root && rdeg64 > kNeighCap) rdeg64 = kNeighCap;
     const int64_t obase = i * (int64_t)a.stride;
-    const unsigned long long lead = 1ull << (MH * a.shift);
+    const CntT lead = (CntT)1 << (MH * a.shift);
     const unsigned long long tag0 = (unsigned long long)((a.root_base + i) * (int64_t)a.stride);
 
     if (rdeg64 == 0) {  // isolated root: one member, every count = M (subg_acc.c:753-761); id = the root
         if (tid == 0) {
-            unsigned long long k = lead;
+            unsigned long long k = (unsigned long long)lead;
             for (int s = 0; s < MH; ++s) k |= (unsigned long long)M << (s * a.shift);
             a.set_ids[obase] = root;
             a.set_slot[obase] = uniq_global_insert(a.table, k, tag0, a.flags);
@@ -242,7 +258,7 @@ __global__ __launch_bounds__(NT, 8) __attribute__((amdgpu_num_sgpr(80))) void wa
                     h = (h + 1u) & TMASK;
                 }
                 atomicMin(&minq[h], (uint32_t)((tid + k * NT) * MH + s + 1));
-                atomicAdd(&pk[h], 1ull << ((MH - 1 - s) * a.shift));
+                atomicAdd(&pk[h], (CntT)1 << ((MH - 1 - s) * a.shift));
             }
             if (!REC && s + 1 < MH) {
 #pragma unroll
@@ -270,21 +286,34 @@ __global__ __launch_bounds__(NT, 8) __attribute__((amdgpu_num_sgpr(80))) void wa
     //     the LDS the walk tables occupied (random_walks.py:79-80) and write them to their sorted position.
     int32_t idv[SPL];
     uint32_t mtag[SPL];
-    unsigned long long mkey[SPL];
-    if (SPL == 4) {
-        const int4 kk = ((const int4 *)keys)[tid];
-        const uint4 qq = ((const uint4 *)minq)[tid];
-        const ulonglong2 p0 = ((const ulonglong2 *)pk)[2 * tid], p1 = ((const ulonglong2 *)pk)[2 * tid + 1];
-        idv[0] = kk.x, idv[1] = kk.y, idv[SPL - 2] = kk.z, idv[SPL - 1] = kk.w;
-        mtag[0] = qq.x, mtag[1] = qq.y, mtag[SPL - 2] = qq.z, mtag[SPL - 1] = qq.w;
-        mkey[0] = p0.x, mkey[1] = p0.y, mkey[SPL - 2] = p1.x, mkey[SPL - 1] = p1.y;
+    CntT mkey[SPL];
+    if (SPL % 4 == 0) {
+#pragma unroll
+        for (int c = 0; c < SPL / 4; ++c) {
+            const int4 kk = ((const int4 *)(keys + tid * SPL))[c];
+            const uint4 qq = ((const uint4 *)(minq + tid * SPL))[c];
+            idv[4 * c] = kk.x, idv[4 * c + 1] = kk.y, idv[4 * c + (SPL > 2 ? 2 : 0)] = kk.z, idv[4 * c + (SPL > 2 ? 3 : 1)] = kk.w;
+            mtag[4 * c] = qq.x, mtag[4 * c + 1] = qq.y, mtag[4 * c + (SPL > 2 ? 2 : 0)] = qq.z, mtag[4 * c + (SPL > 2 ? 3 : 1)] = qq.w;
+        }
     } else {
         const int2 kk = ((const int2 *)keys)[tid];
         const uint2 qq = ((const uint2 *)minq)[tid];
-        const ulonglong2 p0 = ((const ulonglong2 *)pk)[tid];
         idv[0] = kk.x, idv[1] = kk.y;
         mtag[0] = qq.x, mtag[1] = qq.y;
-        mkey[0] = p0.x, mkey[1] = p0.y;
+    }
+    {
+        constexpr int PKW = SPL * (int)sizeof(CntT) / 16;      // 16-byte reads of the lane's counts
+        const uint4 *pp = (const uint4 *)(pk + tid * SPL);
+#pragma unroll
+        for (int c = 0; c < PKW; ++c) {
+            const uint4 v = pp[c];
+            if (K32) {
+                mkey[4 * c] = (CntT)v.x, mkey[4 * c + 1] = (CntT)v.y, mkey[4 * c + (SPL > 2 ? 2 : 0)] = (CntT)v.z, mkey[4 * c + (SPL > 2 ? 3 : 1)] = (CntT)v.w;
+            } else {
+                mkey[2 * c] = (CntT)(((unsigned long long)v.y << 32) | v.x);
+                mkey[2 * c + 1] = (CntT)(((unsigned long long)v.w << 32) | v.z);
+            }
+        }
     }
     bool ok[SPL];
     uint32_t mf[SPL];
@@ -294,14 +323,14 @@ __global__ __launch_bounds__(NT, 8) __attribute__((amdgpu_num_sgpr(80))) void wa
 #pragma unroll
     for (int u = 0; u < SPL; ++u) {
         ok[u] = idv[u] != -1;
-        mkey[u] |= (mtag[u] == 0 ? lead : 0ull);                 // the root is visit 0
+        mkey[u] |= (mtag[u] == 0 ? lead : (CntT)0);              // the root is visit 0
         mf[u] = fold_hash<kSpgFoldBits>(mkey[u]);
         slv[u] = -1;
         mycount += ok[u] ? 1 : 0;
         vmin = min(vmin, ok[u] ? idv[u] : 0x7FFFFFFF);
         vmax = max(vmax, ok[u] ? idv[u] : 0);
     }
-    unsigned long long fcur[SPL];
+    CntT fcur[SPL];
     uint32_t ftag[SPL];
 #pragma unroll
     for (int u = 0; u < SPL; ++u) {
@@ -311,12 +340,12 @@ __global__ __launch_bounds__(NT, 8) __attribute__((amdgpu_num_sgpr(80))) void wa
 #pragma unroll
     for (int u = 0; u < SPL; ++u) {   // a set holds a few dozen distinct keys -> the first probe nearly always settles it
         if (!ok[u]) continue;
-        const unsigned long long key = mkey[u];
+        const CntT key = mkey[u];
         const uint32_t tagoff = mtag[u];
-        unsigned long long cur = fcur[u];
+        CntT cur = fcur[u];
         // the reads above ran before anybody inserted: "empty" is claimed here, and losing the race to the same key is a hit
-        if (cur == kEmptyKey) cur = atomicCAS(&fk[mf[u]], kEmptyKey, key);
-        if (cur == kEmptyKey || cur == key) {
+        if (cur == kNoKey) cur = atomicCAS(&fk[mf[u]], kNoKey, key);
+        if (cur == kNoKey || cur == key) {
             // most lanes meet a tag that is already smaller: the plain read (stale only towards larger values) spares
             // the same-address atomic storm
             if (ftag[u] > tagoff) atomicMin(&ft[mf[u]], tagoff);
@@ -328,8 +357,8 @@ __global__ __launch_bounds__(NT, 8) __attribute__((amdgpu_num_sgpr(80))) void wa
 #pragma unroll 1
         for (int p = 0; p < 15; ++p) {
             cur = fk[f];
-            if (cur == kEmptyKey) cur = atomicCAS(&fk[f], kEmptyKey, key);
-            if (cur == kEmptyKey || cur == key) {
+            if (cur == kNoKey) cur = atomicCAS(&fk[f], kNoKey, key);
+            if (cur == kNoKey || cur == key) {
                 if (ft[f] > tagoff) atomicMin(&ft[f], tagoff);
                 slv[u] = -2 - (int32_t)f;
                 done = true;
@@ -337,7 +366,7 @@ __global__ __launch_bounds__(NT, 8) __attribute__((amdgpu_num_sgpr(80))) void wa
             }
             f = (f + 1) & (kSpgFold - 1);
         }
-        if (!done) slv[u] = uniq_global_insert(a.table, key, tag0 + (unsigned long long)tagoff, a.flags);
+        if (!done) slv[u] = uniq_global_insert(a.table, (unsigned long long)key, tag0 + (unsigned long long)tagoff, a.flags);
     }
     {
         vmin = wave_min_i32(vmin);
@@ -356,8 +385,10 @@ __global__ __launch_bounds__(NT, 8) __attribute__((amdgpu_num_sgpr(80))) void wa
     if (tid == 0) a.nsize[i] = ns;
     const int32_t mn = min(min(red[0], red[1]), min(red[2], red[3]));
     const int32_t mx = max(max(red[4], red[5]), max(red[6], red[7]));
-    unsigned long long *A = pk;                 // [ns] (id << 32 | slot) grouped by bucket
-    int32_t *start = keys;                      // [B+1] bucket counts, then their exclusive scan; B <= min(T/4, 256)
+    // the walk tables are dead: [ns] (id << 32 | slot) grouped by bucket goes over the counts (and, K32, the ids behind them);
+    // the bucket counts / offsets [B+1] (B <= min(T/4, NT)) over the ids -- K32: over the visit numbers
+    unsigned long long *A = (unsigned long long *)lds_raw;
+    int32_t *start = K32 ? (int32_t *)minq : keys;
     int logb = 0;
     while ((1 << logb) < ns && (2 << logb) <= T / 4 && (2 << logb) <= NT) ++logb;
     const int B = 1 << logb;
@@ -366,7 +397,7 @@ __global__ __launch_bounds__(NT, 8) __attribute__((amdgpu_num_sgpr(80))) void wa
     const int bshift = Ls > logb ? Ls - logb : 0;      // (id - mn) < 2^Ls, and ns <= range => logb <= Ls
     if (tid <= B) start[tid] = 0;
     if (tid < kSpgFold)    // flush the fold table to HBM (latency overlaps the sort)
-        if (fk[tid] != kEmptyKey) fs[tid] = uniq_global_insert(a.table, fk[tid], tag0 + ft[tid], a.flags);
+        if (fk[tid] != kNoKey) fs[tid] = uniq_global_insert(a.table, (unsigned long long)fk[tid], tag0 + ft[tid], a.flags);
     __syncthreads();
     SG_RSTAMP(4);
     uint32_t bk[SPL];
@@ -411,9 +442,11 @@ __global__ __launch_bounds__(NT, 8) __attribute__((amdgpu_num_sgpr(80))) void wa
     // order inside a bucket = number of smaller ids in it -> final position in the row.  The sorted row is assembled
     // in LDS (ids over the dead minq table, slots behind the bucket offsets) and leaves with consecutive lanes on
     // consecutive words.
-    int32_t *fin_id = (int32_t *)minq;          // [ns] <= T
-    int32_t *fin_sl = keys + B + 1;             // [ns] if it fits behind start[B+1]
-    const bool staged = ns + B + 1 <= T;
+    // (u64 counts: ids over minq, slots behind start[] in keys.  K32: A holds 8*ns <= 8*stride bytes of the 8*T-byte
+    //  counts + ids region, the ids go behind it and the slots behind start[] in minq.)
+    int32_t *fin_id = K32 ? (int32_t *)(lds_raw + 8 * (size_t)a.stride) : (int32_t *)minq;          // [ns]
+    int32_t *fin_sl = start + B + 1;                                                                 // [ns]
+    const bool staged = ns + B + 1 <= T && (!K32 || 12 * a.stride <= 8 * T);
     const uint32_t *Ahi = (const uint32_t *)A;
 #pragma unroll
     for (int u = 0; u < SPL; ++u)
@@ -452,6 +485,26 @@ int launch_walk_rows(const WalkArgs &a, bool indptr64, int rng_mode, size_t lds,
     static const bool nt256 = getenv("SUBGACC_ROWS_NT") && atoi(getenv("SUBGACC_ROWS_NT")) == 256;
     const bool half = a.T == 512 && !nt256;
     const bool rec = a.recs != nullptr && indptr64 == (a.rec.id_bits == 0);   // hop records: one dependent read per hop
+    // 1,024-slot table with counts that fit 32 bits: 128 lanes x 8 slots, 12 bytes of LDS per slot -> 11 roots per CU
+    // (SUBGACC_ROWS_NT=256 keeps the 256-lane form; dev-only).  int32 row offsets + 8-byte records / plain CSR only.
+    if (a.T == 1024 && !nt256 && !indptr64 && a.m * a.shift + 1 <= 31 && a.m <= 3) {
+        const size_t lds32 = (size_t)a.T * 12 + (size_t)a.M * 4 + 8 + (size_t)kSpgFold * 12 + 64 + 16;
+#define SG_ROWS32(RNGM, MHH)                                                                                        \
+    do {                                                                                                            \
+        if (rec)                                                                                                    \
+            hipLaunchKernelGGL((walk_rows_kernel<false, RNGM, MHH, 8, 128, 8, true>), dim3((unsigned)grid), dim3(128), lds32, s, a); \
+        else                                                                                                        \
+            hipLaunchKernelGGL((walk_rows_kernel<false, RNGM, MHH, 8, 128, 0, true>), dim3((unsigned)grid), dim3(128), lds32, s, a); \
+        return 1;                                                                                                   \
+    } while (0)
+        if (rr) {
+            if (a.m == 2) SG_ROWS32(SUBGACC_RNG_RAND_R, 2);
+            SG_ROWS32(SUBGACC_RNG_RAND_R, 3);
+        }
+        if (a.m == 2) SG_ROWS32(SUBGACC_RNG_PHILOX, 2);
+        SG_ROWS32(SUBGACC_RNG_PHILOX, 3);
+#undef SG_ROWS32
+    }
 #define SG_ROWS(I64, RNGM, MHH, SPLL, NTT)                                                                         \
     do {                                                                                                           \
         if (rec)                                                                                                   \
