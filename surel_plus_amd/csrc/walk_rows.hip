@@ -59,7 +59,7 @@ template <bool IDX64, int RNG, int MH, int SPL, int NT, int REC = 0, bool K32 = 
 __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80))) void walk_rows_kernel(const WalkArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using CntT = typename std::conditional<K32, uint32_t, unsigned long long>::type;
-    static_assert((SPL * sizeof(CntT)) % 16 == 0, "a lane's counts are cleared and read with 16-byte LDS accesses");
+    static_assert(SPL % 4 == 0 || (SPL == 2 && !K32), "slot ownership: 4-slot chunks, or two slots with 64-bit counts");
     constexpr CntT kNoKey = (CntT)~(CntT)0;                       // empty marker of the fold table
     constexpr int T = SPL * NT;                                   // 512 or 1,024 slots
     constexpr int TSHIFT = T == 1024 ? 22 : 23;                   // 32 - log2(T)
@@ -80,18 +80,24 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     const int M = a.M;
     const int32_t root = a.query[i];
     // while the root's two dependent loads (query -> row pointer) are in flight: clear what does not depend on them
-    {   // a lane clears the SPL consecutive slots it owns, with 16-byte stores (8-byte for the 2 x 4-byte case)
-        constexpr int PKB = SPL * (int)sizeof(CntT), MQB = SPL * 4;
-        uint4 *pp = (uint4 *)(pk + tid * SPL);
+    // Slot ownership (clears, and the epilogue's member fetch): a lane owns the 4-slot chunks g = c*NT + tid, c < SPL/4 --
+    // consecutive lanes on consecutive 16-byte words, so the 16-byte LDS accesses below are dense (a lane-contiguous
+    // layout, 32 bytes apart, cost 39 % of the LDS cycles in bank conflicts at SPL = 8).  SPL = 2: slots 2*tid, 2*tid+1.
+    if (SPL % 4 == 0) {
 #pragma unroll
-        for (int c = 0; c < PKB / 16; ++c) pp[c] = make_uint4(0u, 0u, 0u, 0u);
-        if (MQB % 16 == 0) {
-            uint4 *qp = (uint4 *)(minq + tid * SPL);
-#pragma unroll
-            for (int c = 0; c < MQB / 16; ++c) qp[c] = make_uint4(~0u, ~0u, ~0u, ~0u);
-        } else {
-            ((uint2 *)minq)[tid] = make_uint2(~0u, ~0u);
+        for (int c = 0; c < SPL / 4; ++c) {
+            const int g = c * NT + tid;
+            if (K32) {
+                ((uint4 *)pk)[g] = make_uint4(0u, 0u, 0u, 0u);
+            } else {
+                ((uint4 *)pk)[2 * g] = make_uint4(0u, 0u, 0u, 0u);
+                ((uint4 *)pk)[2 * g + 1] = make_uint4(0u, 0u, 0u, 0u);
+            }
+            ((uint4 *)minq)[g] = make_uint4(~0u, ~0u, ~0u, ~0u);
         }
+    } else {
+        ((uint4 *)pk)[tid] = make_uint4(0u, 0u, 0u, 0u);
+        ((uint2 *)minq)[tid] = make_uint2(~0u, ~0u);
     }
     if (tid < kSpgFold) {
         fk[tid] = kNoKey;
@@ -110,17 +116,19 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     {   // keys, with the root already in its slot as member 0 (its minq = 0 is stored after the barrier-free clear above:
         // same lane order is not guaranteed across waves, so the root's lane writes BOTH of its words here)
         const uint32_t hroot = ((uint32_t)root * 2654435761u) >> TSHIFT;
-        const int x0 = tid * SPL;
-        int32_t kv[SPL];
-#pragma unroll
-        for (int u = 0; u < SPL; ++u) kv[u] = (uint32_t)(x0 + u) == hroot ? root : -1;
         if (SPL % 4 == 0) {
 #pragma unroll
-            for (int c = 0; c < SPL / 4; ++c) ((int4 *)(keys + x0))[c] = make_int4(kv[4 * c], kv[4 * c + 1], kv[4 * c + (SPL > 2 ? 2 : 0)], kv[4 * c + (SPL > 2 ? 3 : 1)]);
+            for (int c = 0; c < SPL / 4; ++c) {
+                const uint32_t x0 = 4u * (uint32_t)(c * NT + tid);
+                ((int4 *)keys)[c * NT + tid] = make_int4(x0 == hroot ? root : -1, x0 + 1u == hroot ? root : -1,
+                                                         x0 + 2u == hroot ? root : -1, x0 + 3u == hroot ? root : -1);
+            }
+            if (((hroot >> 2) % (uint32_t)NT) == (uint32_t)tid) minq[hroot] = 0u;   // the lane that cleared this word, after its clear
         } else {
-            ((int2 *)keys)[tid] = make_int2(kv[0], kv[1]);
+            const uint32_t x0 = 2u * (uint32_t)tid;
+            ((int2 *)keys)[tid] = make_int2(x0 == hroot ? root : -1, x0 + 1u == hroot ? root : -1);
+            if ((hroot >> 1) == (uint32_t)tid) minq[hroot] = 0u;
         }
-        if ((hroot / SPL) == (uint32_t)tid) minq[hroot] = 0u;     // the lane that cleared this word, after its clear
     }
     if (a.cap_root && rdeg64 > kNeighCap) rdeg64 = kNeighCap;
     const int64_t obase = i * (int64_t)a.stride;
@@ -290,30 +298,30 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     if (SPL % 4 == 0) {
 #pragma unroll
         for (int c = 0; c < SPL / 4; ++c) {
-            const int4 kk = ((const int4 *)(keys + tid * SPL))[c];
-            const uint4 qq = ((const uint4 *)(minq + tid * SPL))[c];
+            const int g = c * NT + tid;
+            const int4 kk = ((const int4 *)keys)[g];
+            const uint4 qq = ((const uint4 *)minq)[g];
             idv[4 * c] = kk.x, idv[4 * c + 1] = kk.y, idv[4 * c + (SPL > 2 ? 2 : 0)] = kk.z, idv[4 * c + (SPL > 2 ? 3 : 1)] = kk.w;
             mtag[4 * c] = qq.x, mtag[4 * c + 1] = qq.y, mtag[4 * c + (SPL > 2 ? 2 : 0)] = qq.z, mtag[4 * c + (SPL > 2 ? 3 : 1)] = qq.w;
+            if (K32) {
+                const uint4 v = ((const uint4 *)pk)[g];
+                mkey[4 * c] = (CntT)v.x, mkey[4 * c + 1] = (CntT)v.y, mkey[4 * c + (SPL > 2 ? 2 : 0)] = (CntT)v.z, mkey[4 * c + (SPL > 2 ? 3 : 1)] = (CntT)v.w;
+            } else {
+                const uint4 v0 = ((const uint4 *)pk)[2 * g], v1 = ((const uint4 *)pk)[2 * g + 1];
+                mkey[4 * c] = (CntT)(((unsigned long long)v0.y << 32) | v0.x);
+                mkey[4 * c + 1] = (CntT)(((unsigned long long)v0.w << 32) | v0.z);
+                mkey[4 * c + (SPL > 2 ? 2 : 0)] = (CntT)(((unsigned long long)v1.y << 32) | v1.x);
+                mkey[4 * c + (SPL > 2 ? 3 : 1)] = (CntT)(((unsigned long long)v1.w << 32) | v1.z);
+            }
         }
     } else {
         const int2 kk = ((const int2 *)keys)[tid];
         const uint2 qq = ((const uint2 *)minq)[tid];
+        const uint4 v = ((const uint4 *)pk)[tid];
         idv[0] = kk.x, idv[1] = kk.y;
         mtag[0] = qq.x, mtag[1] = qq.y;
-    }
-    {
-        constexpr int PKW = SPL * (int)sizeof(CntT) / 16;      // 16-byte reads of the lane's counts
-        const uint4 *pp = (const uint4 *)(pk + tid * SPL);
-#pragma unroll
-        for (int c = 0; c < PKW; ++c) {
-            const uint4 v = pp[c];
-            if (K32) {
-                mkey[4 * c] = (CntT)v.x, mkey[4 * c + 1] = (CntT)v.y, mkey[4 * c + (SPL > 2 ? 2 : 0)] = (CntT)v.z, mkey[4 * c + (SPL > 2 ? 3 : 1)] = (CntT)v.w;
-            } else {
-                mkey[2 * c] = (CntT)(((unsigned long long)v.y << 32) | v.x);
-                mkey[2 * c + 1] = (CntT)(((unsigned long long)v.w << 32) | v.z);
-            }
-        }
+        mkey[0] = (CntT)(((unsigned long long)v.y << 32) | v.x);
+        mkey[1] = (CntT)(((unsigned long long)v.w << 32) | v.z);
     }
     bool ok[SPL];
     uint32_t mf[SPL];
