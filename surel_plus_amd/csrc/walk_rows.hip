@@ -153,6 +153,9 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     }
     const bool shuffled = rdeg64 > M;
     const uint32_t rdeg = (uint32_t)rdeg64;
+    // rand_r: the stream state at the root's first draw, once per workgroup (uniform operands: a scalar loop of up to 32
+    // rounds); a lane then jumps the few hundred steps to its own walk (<= 12 rounds) instead of all ~2^28 of them
+    const uint32_t xroot = RNG == SUBGACC_RNG_RAND_R ? lcg_jump(rseed, rpos) : 0u;
     if (shuffled) {  // partial Fisher-Yates draws s_k = draw % (deg-k) + k  (subg_acc.c:769-775), one lane per k
 #pragma unroll
         for (int kk = 0; kk < WPL; ++kk) {
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
             if (k >= M) continue;
             uint32_t r;
             if (RNG == SUBGACC_RNG_RAND_R) {
-                uint32_t x = lcg_jump(rseed, rpos + 3u * (uint32_t)k);
+                uint32_t x = lcg_jump(xroot, 3u * (uint32_t)k);      // a jump of < 2^10 steps from the root's state
                 r = rand_r_next(x);
                 sarr[k] = (int32_t)(r % (rdeg - (uint32_t)k)) + k;
             } else {
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
                 for (int b = 0; 2 * b < MH - 1; ++b)
                     philox2x32_10((uint32_t)root, (uint32_t)w | ((uint32_t)b << kPhiloxBlockShift), a.seed, dr[k][2 * b], dr[k][2 * b + 1]);
             } else {
-                x[k] = lcg_jump(rseed, rpos + 3u * ((shuffled ? (uint32_t)M : 0u) + (uint32_t)w * (uint32_t)(MH - 1)));
+                x[k] = lcg_jump(xroot, 3u * ((shuffled ? (uint32_t)M : 0u) + (uint32_t)w * (uint32_t)(MH - 1)));
             }
         }
 #pragma unroll

@@ -305,11 +305,13 @@ class SampledSets:
 
 
 def make_cfg(csr, num_walks, num_steps, bucket=-1, seed=111413, rng="rand_r", first_hop_wo=True,
-             order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False):
+             order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False, records=True):
+    """records=True: hand the graph's hop records (DeviceCSR.hop_records(), built on first use) to the kernel -- only the
+    fused-row kernel reads them, so the callers that launch something else pass False and nothing is built for them"""
     rng_mode = {"rand_r": _lib.RNG_RAND_R, "philox": _lib.RNG_PHILOX}[rng]
     if num_walks <= 0 or num_steps <= 0:
         raise TypeError("Input parsing error. (num_walks and num_steps must be positive)")
-    recs = csr.hop_records() if (first_hop_wo and not emit_walks and order == _lib.ORDER_WALK_MAJOR) else None
+    recs = csr.hop_records() if (records and first_hop_wo and not emit_walks and order == _lib.ORDER_WALK_MAJOR) else None
     return WalkCfg(int(num_walks), int(num_steps), int(bucket), rng_mode, int(seed) & 0xFFFFFFFF,
                    1 if first_hop_wo else 0, int(order), 1 if cap_root_degree else 0,
                    1 if csr.indptr64 else 0, 1 if emit_walks else 0,
@@ -396,7 +398,8 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     dev = csr.device
     q = _as_query(query, dev)
     n = q.numel()
-    cfg = make_cfg(csr, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order, cap_root_degree, emit_walks)
+    records = bool(fused_rows) and bucket <= 0 and num_walks * num_steps + 1 <= FUSED_MAX_Q and 2 <= num_steps <= 4
+    cfg = make_cfg(csr, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order, cap_root_degree, emit_walks, records)
     check(L.subgacc_key_shift(cfg.num_walks, cfg.num_steps))   # AssertionError like subg_acc.c:911-915
     M, m = cfg.num_walks, cfg.num_steps
     stride = bucket if bucket > 0 else M * m + 1
