@@ -21,17 +21,12 @@
 
 namespace subgacc {
 
-// min / max over the 64 lanes of a wave (every lane returns the result)
-__device__ __forceinline__ int32_t wave_min_i32(int32_t v) {
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d, kWave));
-    return v;
-}
-__device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, kWave));
-    return v;
-}
+// Wave-wide reductions / scan of the device library (DPP row shifts and broadcasts: a handful of vector instructions and no
+// LDS traffic, where six __shfl steps cost six ds_bpermute round trips each).  Every lane is active at the call sites.
+extern "C" __device__ __attribute__((const)) int __ockl_wfred_min_i32(int);
+extern "C" __device__ __attribute__((const)) int __ockl_wfred_max_i32(int);
+extern "C" __device__ __attribute__((const)) int __ockl_wfred_add_i32(int);
+extern "C" __device__ __attribute__((const)) int __ockl_wfscan_add_i32(int, bool);
 
 #if defined(SG_STOP_AFTER)   // dynamic instruction counts per phase (tools/walk_insts.sh): the workgroup ends at stamp k (results are wrong)
 #define SG_RSTAMP(k)                                                                                         \
@@ -380,10 +375,9 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
         if (!done) slv[u] = uniq_global_insert(a.table, (unsigned long long)key, tag0 + (unsigned long long)tagoff, a.flags);
     }
     {
-        vmin = wave_min_i32(vmin);
-        vmax = wave_max_i32(vmax);
-#pragma unroll
-        for (int d = kWave / 2; d > 0; d >>= 1) mycount += __shfl_xor(mycount, d, kWave);
+        vmin = __ockl_wfred_min_i32(vmin);
+        vmax = __ockl_wfred_max_i32(vmax);
+        mycount = __ockl_wfred_add_i32(mycount);
         if ((tid & (kWave - 1)) == 0) {
             red[tid / kWave] = vmin;
             red[4 + tid / kWave] = vmax;
@@ -423,12 +417,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     SG_RSTAMP(5);
     {   // exclusive scan over the B <= 256 buckets, one bucket per lane: wave scan, then the wave totals through LDS
         const int32_t c = tid < B ? start[tid] : 0;
-        int32_t inc = c;
-#pragma unroll
-        for (int dd = 1; dd < kWave; dd <<= 1) {
-            const int32_t t2 = __shfl_up(inc, dd, kWave);
-            if ((tid & (kWave - 1)) >= dd) inc += t2;
-        }
+        const int32_t inc = __ockl_wfscan_add_i32(c, true);     // inclusive scan over the wave
         if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc;
         __syncthreads();
         int32_t base = 0;
