@@ -339,13 +339,26 @@ int subgacc_walk_join(const int32_t *walks, int64_t n, int32_t stride, const int
                       void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Key rows: a batch that is sampled, joined and dropped needs neither the table of distinct LP rows nor their numbering.
+ * subgacc_walk_spg with uniq_table = NULL writes the member's 32-bit LP key itself as the row's payload (needs
+ * num_steps*SHIFT+1 <= 31, 2 or 3 hops, set_sampler order, no bucket, M <= 256: SUBGACC_ERR_BADARG otherwise), and
+ * subgacc_sjoin_fill_keyrows joins such rows: a feature row is the key's unpacked counts / num_walks -- what
+ * subgacc_unpack_lp writes into the feature table, computed on the fly (the partner's row is zero when it is absent).
+ * Same (xz, seg) as the table path; sizes by subgacc_sjoin_sizes_rows; mirrored segment lists only.
+ * ------------------------------------------------------------------------------------------- */
+int subgacc_sjoin_fill_keyrows(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
+                               const int32_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
+                               const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz, int64_t pair_block,
+                               int32_t *flags, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Prologue of one on-demand step (sample both endpoints of B query pairs -> rows -> SpJoin; train.py:120-127 calls the
  * join once per batch of main.py:32's 1,024 pairs) in ONE launch: subgacc_uniq_reset of the table of distinct LP rows,
  * `n_zero` status words zeroed, and the n = 2B endpoints `edge` (int64, [u.. | v..]) narrowed to the int32 roots the
  * sampler takes (an id outside int32 becomes -1: out of range for the walk kernel, which flags it).
  * ------------------------------------------------------------------------------------------- */
 int subgacc_step_prologue(void *uniq_table, int64_t capacity, int64_t *zero_words, int64_t n_zero, const int64_t *edge,
-                          int32_t *roots, int64_t n, void *stream);
+                          int32_t *roots, int64_t n, void *stream);   /* uniq_table may be NULL (key rows: no table) */
 
 /* ---------------------------------------------------------------------------------------------
  * batch_sampler of the legacy SUREL surface (subg_acc/subg_acc.c:391-507): one insertion-ordered set of nodes grown by

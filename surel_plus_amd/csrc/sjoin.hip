@@ -97,6 +97,9 @@ struct JoinArgs {
     // strided rows (subgacc_sjoin_*_rows): row r = [r*row_stride, +row_len[r]) of indices / data, data = table slots
     const int32_t *row_len;
     int64_t row_stride;
+    // key rows (subgacc_sjoin_fill_keyrows): the rows' payload is the member's 32-bit LP key; a feature row is its unpacked
+    // counts / num_walks (lut[c] = float(c) / float(M), built per workgroup), 0xFFFFFFFF = partner absent -> the zero row
+    int32_t key_M, key_m, key_shift;
     const int32_t *slot_id;   // slot -> SFptr (id plane of the numbered table of distinct LP rows); NULL with
     int32_t val_add;          // val_add = 1: the feature table is indexed by slot + 1 itself (row 0 = absent)
 };
@@ -141,10 +144,18 @@ __device__ __forceinline__ void join_row(const JoinArgs &a, int64_t r, int64_t &
 // Emit up to 64 consecutive output rows of one segment (one per lane): look the lane's member up in the
 // partner row (binary search over sorted ids held in LDS) and write the feature pairs of the whole 64-row span
 // with consecutive lanes on consecutive words.  KV = 4: k == 4, rows move as float4; KV = 0: any k <= 16.
-template <bool F64, int KV, typename Val>
+// element c of the feature row of LP key `key` (uniq.hip:unpack_lp_kernel restated): column 0 = 1 on the root's own row,
+// column j = count of step j / num_walks, from the per-workgroup table lut[c] = float(c) / float(num_walks)
+__device__ __forceinline__ float key_feature(uint32_t key, int c, int m, int shift, const float *lut) {
+    if (key == 0xFFFFFFFFu) return 0.0f;
+    if (c == 0) return ((key >> (m * shift)) & 1u) ? 1.0f : 0.0f;
+    return lut[(key >> ((m - c) * shift)) & ((1u << shift) - 1u)];
+}
+
+template <bool F64, int KV, typename Val, bool KEYS = false>
 __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int32_t *own_ids, const Val *own_val,
                                           int64_t na, const int32_t *pids, const Val *pval, int nb, int64_t t0,
-                                          int64_t o, int64_t segj, int k, int k2, uint32_t magic) {
+                                          int64_t o, int64_t segj, int k, int k2, uint32_t magic, const float *lut = nullptr) {
     const int64_t t = t0 + lane;
     const bool live = t < na;
     int32_t id = 0;
@@ -174,7 +185,7 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
             stream_store(reinterpret_cast<float2 *>(a.out_xz) + row0 + lane, v);
         }
     } else {
-        int32_t pa = (int32_t)va, pb = hit ? (int32_t)pval[lo] : 0;
+        int32_t pa = (int32_t)va, pb = hit ? (int32_t)pval[lo] : (KEYS ? -1 : 0);
         if (a.out_idx && live) {
             int2 v;
             v.x = pa;
@@ -182,7 +193,7 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
             stream_store(reinterpret_cast<int2 *>(a.out_idx) + row0 + lane, v);
         }
         if (a.out_xz) {
-            if (live && ((uint64_t)pa >= (uint64_t)a.table_rows || (uint64_t)pb >= (uint64_t)a.table_rows)) {
+            if (!KEYS && live && ((uint64_t)pa >= (uint64_t)a.table_rows || (uint64_t)pb >= (uint64_t)a.table_rows)) {
                 atomicOr(&a.flags[3], 2);  // SFptr outside the table: never read out of bounds
                 pa = pb = 0;
             }
@@ -204,7 +215,17 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
 #elif SJ_EXPERIMENT == 8 // plain (cached) stores, as before round 1's last change
                     if (r < nrows) dst4[f] = tab4[(f & 1) ? spb : spa];
 #else
-                    if (r < nrows) stream_store(dst4 + f, tab4[(f & 1) ? spb : spa]);
+                    if (KEYS) {      // k == 4 <=> 3 hops: the row is (root flag, c1, c2, c3) / M
+                        const uint32_t key = (uint32_t)((f & 1) ? spb : spa);
+                        const uint32_t fm = (1u << a.key_shift) - 1u;
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (key != 0xFFFFFFFFu)
+                            v = make_float4(((key >> (3 * a.key_shift)) & 1u) ? 1.0f : 0.0f, lut[(key >> (2 * a.key_shift)) & fm],
+                                            lut[(key >> a.key_shift) & fm], lut[key & fm]);
+                        if (r < nrows) stream_store(dst4 + f, v);
+                    } else if (r < nrows) {
+                        stream_store(dst4 + f, tab4[(f & 1) ? spb : spa]);
+                    }
 #endif
                 }
             } else {
@@ -214,7 +235,12 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
                     const int r = (int)(((uint32_t)f * magic) >> 20);
                     const int c = f - r * k2;
                     const int spa = __shfl(pa, r, kWave), spb = __shfl(pb, r, kWave);
-                    if (f < total) __builtin_nontemporal_store(a.table[(int64_t)(c < k ? spa : spb) * k + (c < k ? c : c - k)], dst + f);
+                    if (KEYS) {
+                        const float v = key_feature((uint32_t)(c < k ? spa : spb), c < k ? c : c - k, a.key_m, a.key_shift, lut);
+                        if (f < total) __builtin_nontemporal_store(v, dst + f);
+                    } else if (f < total) {
+                        __builtin_nontemporal_store(a.table[(int64_t)(c < k ? spa : spb) * k + (c < k ? c : c - k)], dst + f);
+                    }
                 }
             }
         }
@@ -271,7 +297,7 @@ constexpr int kPairThreads = 256;
 #define SJ_PAIR_THREADS 128   // 128 lanes per pair: twice the pairs with their row loads in flight per CU (-4..6 % against 256, r02s)
 #endif
 constexpr int kPairEmit = SJ_PAIR_THREADS;
-template <bool F64, int KV>
+template <bool F64, int KV, bool KEYS = false>
 __global__ __launch_bounds__(kPairEmit) void sjoin_pair_kernel(const JoinArgs a, int64_t pb) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using Val = typename std::conditional<F64, double, int32_t>::type;
@@ -279,6 +305,9 @@ __global__ __launch_bounds__(kPairEmit) void sjoin_pair_kernel(const JoinArgs a,
     Val *valB = valA + a.max_len;                     // [max_len]
     int32_t *idsA = (int32_t *)(valB + a.max_len);    // [max_len]
     int32_t *idsB = idsA + a.max_len;                 // [max_len]
+    float *lut = (float *)(idsB + a.max_len);         // KEYS: [key_M + 1] count -> count / num_walks (IEEE division, main.py:174)
+    if (KEYS)
+        for (int c = threadIdx.x; c <= a.key_M; c += kPairEmit) lut[c] = (float)c / (float)a.key_M;
 
     const int64_t p = xcd_item(blockIdx.x, gridDim.x);
     if (p >= a.S / 2) return;
@@ -307,7 +336,8 @@ __global__ __launch_bounds__(kPairEmit) void sjoin_pair_kernel(const JoinArgs a,
 #endif
         idsA[r] = stream_load(&a.indices[ab + r]);
         Val v = stream_load(&data[ab + r]);
-        if (xl) v = (Val)(a.slot_id[(int32_t)v] + 1);
+        if (KEYS) {}
+        else if (xl) v = (Val)(a.slot_id[(int32_t)v] + 1);
         else if (!F64) v = (Val)((int32_t)v + a.val_add);
         valA[r] = v;
     }
@@ -320,7 +350,8 @@ __global__ __launch_bounds__(kPairEmit) void sjoin_pair_kernel(const JoinArgs a,
 #endif
             idsB[r] = stream_load(&a.indices[bb + r]);
             Val v = stream_load(&data[bb + r]);
-            if (xl) v = (Val)(a.slot_id[(int32_t)v] + 1);
+            if (KEYS) {}
+            else if (xl) v = (Val)(a.slot_id[(int32_t)v] + 1);
             else if (!F64) v = (Val)((int32_t)v + a.val_add);
             valB[r] = v;
         }
@@ -335,10 +366,10 @@ __global__ __launch_bounds__(kPairEmit) void sjoin_pair_kernel(const JoinArgs a,
     const int chunksA = (na + kWave - 1) / kWave, chunksB = (nb + kWave - 1) / kWave;
     for (int c = wave; c < chunksA + chunksB; c += kPairEmit / kWave) {   // every wave takes whole 64-row spans
         if (c < chunksA)
-            emit_rows<F64, KV, Val>(a, lane, idsA, valA, na, idsB, valB, nb, (int64_t)c * kWave, oA, j, k, k2, magic);
+            emit_rows<F64, KV, Val, KEYS>(a, lane, idsA, valA, na, idsB, valB, nb, (int64_t)c * kWave, oA, j, k, k2, magic, lut);
         else
-            emit_rows<F64, KV, Val>(a, lane, idsB, valB, nb, idsA, valA, na, (int64_t)(c - chunksA) * kWave, oB, j2, k, k2,
-                                    magic);
+            emit_rows<F64, KV, Val, KEYS>(a, lane, idsB, valB, nb, idsA, valA, na, (int64_t)(c - chunksA) * kWave, oB, j2, k, k2,
+                                          magic, lut);
     }
 }
 
@@ -629,6 +660,7 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, int64_t n_rows, con
     a.max_len = max_len > 0 ? max_len : 1;
     a.flags = flags;
     a.row_len = nullptr, a.row_stride = 0, a.slot_id = nullptr, a.val_add = 0;
+    a.key_M = a.key_m = a.key_shift = 0;
     SG_REQUIRE(pair_block >= 0 && (pair_block == 0 || S % (2 * pair_block) == 0), SUBGACC_ERR_BADARG,
                "sjoin_fill: S = %lld is not a multiple of 2*pair_block", (long long)S);
     bool paired = pair_block > 0;
@@ -706,6 +738,7 @@ extern "C" int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t n_rows, i
     // numbered table given: slot -> SFptr+1 through its id plane (uniq_table.hpp); else the table is indexed by slot+1
     a.slot_id = uniq_table ? (const int32_t *)((const char *)uniq_table + (size_t)uniq_capacity * 16) : nullptr;
     a.val_add = uniq_table ? 0 : 1;
+    a.key_M = a.key_m = a.key_shift = 0;
     const size_t lds = (size_t)a.max_len * 16;
     SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "sjoin_fill_rows: rows of %lld members do not fit LDS",
                (long long)row_stride);
@@ -721,6 +754,50 @@ extern "C" int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t n_rows, i
         if (lds > 64 * 1024)
             SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((sjoin_pair_kernel<false, 0>), dim3((unsigned)grid), dim3(kPairEmit), lds, s, a, pair_block);
+    }
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}
+
+extern "C" int subgacc_sjoin_fill_keyrows(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
+                                          const int32_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
+                                          const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz,
+                                          int64_t pair_block, int32_t *flags, void *stream) {
+    SG_REQUIRE(S >= 0 && flags && n_rows >= 0 && row_stride > 0 && row_stride < (1ll << 31), SUBGACC_ERR_BADARG,
+               "sjoin_fill_keyrows: bad arguments");
+    const int shift = subgacc_key_shift(num_walks, num_steps);
+    if (shift < 0) return shift;
+    SG_REQUIRE(num_steps * shift + 1 <= 31 && num_steps + 1 <= 16, SUBGACC_ERR_KEYWIDTH,
+               "sjoin_fill_keyrows: LP keys of %d steps x %d bits do not fit 32 bits", num_steps, shift);
+    if (S == 0) return SUBGACC_OK;
+    SG_REQUIRE(row_len && row_ids && row_keys && own && partner && seg && out_xz, SUBGACC_ERR_BADARG,
+               "sjoin_fill_keyrows: null argument");
+    SG_REQUIRE(pair_block > 0 && S % (2 * pair_block) == 0, SUBGACC_ERR_BADARG,
+               "sjoin_fill_keyrows: the segment list must be mirrored blocks (pair_block > 0, S a multiple of 2*pair_block)");
+    JoinArgs a;
+    a.indptr = nullptr, a.indices = row_ids, a.data = row_keys;
+    a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
+    a.table = nullptr, a.table_rows = 0, a.k = num_steps + 1;
+    a.out_xz = out_xz, a.out_idx = nullptr, a.out_segid = nullptr;
+    a.max_len = (int32_t)row_stride;
+    a.flags = flags;
+    a.row_len = row_len, a.row_stride = row_stride, a.slot_id = nullptr, a.val_add = 0;
+    a.key_M = num_walks, a.key_m = num_steps, a.key_shift = shift;
+    const size_t lds = (size_t)a.max_len * 16 + (size_t)(num_walks + 1) * 4;
+    SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "sjoin_fill_keyrows: rows of %lld members do not fit LDS",
+               (long long)row_stride);
+    const int64_t grid = xcd_grid(S / 2);
+    SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_fill_keyrows: too many segments in one call");
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec4 = a.k == 4 && ((uintptr_t)out_xz % 16 == 0);
+    if (vec4) {
+        if (lds > 64 * 1024)
+            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((sjoin_pair_kernel<false, 4, true>), dim3((unsigned)grid), dim3(kPairEmit), lds, s, a, pair_block);
+    } else {
+        if (lds > 64 * 1024)
+            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((sjoin_pair_kernel<false, 0, true>), dim3((unsigned)grid), dim3(kPairEmit), lds, s, a, pair_block);
     }
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
@@ -745,6 +822,7 @@ extern "C" int subgacc_sjoin_counts(const int64_t *spg_indptr, int64_t n_rows, c
     a.max_len = max_len > 0 ? max_len : 1;
     a.flags = flags;
     a.row_len = nullptr, a.row_stride = 0, a.slot_id = nullptr, a.val_add = 0;
+    a.key_M = a.key_m = a.key_shift = 0;
     const size_t lds = (size_t)a.max_len * 16 + (size_t)table_rows * 8;
     SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS,
                "sjoin_counts: %lld distinct LP rows and rows of %d members need %zu B of LDS; use sjoin_fill",
@@ -778,6 +856,7 @@ extern "C" int subgacc_sjoin_pairs(const int64_t *spg_indptr, int64_t n_rows, co
     a.max_len = max_len > 0 ? max_len : 1;
     a.flags = flags;
     a.row_len = nullptr, a.row_stride = 0, a.slot_id = nullptr, a.val_add = 0;
+    a.key_M = a.key_m = a.key_shift = 0;
     SG_REQUIRE(2 * (int64_t)a.max_len <= 8 * kPairThreads, SUBGACC_ERR_LDS,
                "sjoin_pairs: rows of %d members are too long for the pair form (<= %d); use sjoin_fill", max_len,
                4 * kPairThreads);

@@ -30,7 +30,7 @@ __global__ void uniq_reset_kernel(UniqTable t, int64_t cap) {
 __global__ void step_prologue_kernel(UniqTable t, int64_t cap, int64_t *zero_words, int64_t n_zero, const int64_t *edge,
                                      int32_t *roots, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < cap) {
+    if (i < cap) {        // cap = 0: no table (key rows)
         t.keys[i] = kEmptyKey;
         t.mintag[i] = ~0ull;
         t.id[i] = -1;
@@ -248,14 +248,17 @@ extern "C" int subgacc_uniq_reset(void *table, int64_t capacity, void *stream) {
 
 extern "C" int subgacc_step_prologue(void *table, int64_t capacity, int64_t *zero_words, int64_t n_zero, const int64_t *edge,
                                      int32_t *roots, int64_t n, void *stream) {
-    SG_REQUIRE(table && is_pow2(capacity) && capacity < (1ll << 31), SUBGACC_ERR_BADARG,
+    SG_REQUIRE(!table || (is_pow2(capacity) && capacity < (1ll << 31)), SUBGACC_ERR_BADARG,
                "step_prologue: capacity must be a power of two below 2^31");
+    if (!table) capacity = 0;
     SG_REQUIRE(n >= 0 && n_zero >= 0 && (n == 0 || (edge && roots)) && (n_zero == 0 || zero_words), SUBGACC_ERR_BADARG,
                "step_prologue: null argument");
     int64_t span = capacity > n ? capacity : n;
     if (n_zero > span) span = n_zero;
+    if (span == 0) return SUBGACC_OK;
     hipLaunchKernelGGL(step_prologue_kernel, dim3((unsigned)ceil_div(span, 256)), dim3(256), 0, (hipStream_t)stream,
-                       uniq_view(table, capacity), capacity, zero_words, n_zero, edge, roots, n);
+                       table ? uniq_view(table, capacity) : UniqTable{nullptr, nullptr, nullptr, 0}, capacity, zero_words, n_zero,
+                       edge, roots, n);
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }

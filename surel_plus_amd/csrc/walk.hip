@@ -754,9 +754,9 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
         SG_REQUIRE(table_size_for(Q) <= kSpgPerLane * kWalkThreads, SUBGACC_ERR_LDS,
                    "walk_spg: M*m+1 = %d needs a per-root table above %d slots; use subgacc_walk_sets + subgacc_spg_build",
                    Q, kSpgPerLane * kWalkThreads);
-        SG_REQUIRE(uniq_table && uniq_capacity > 0 && (uniq_capacity & (uniq_capacity - 1)) == 0 &&
-                       uniq_capacity < (1ll << 31) && root_base >= 0,
-                   SUBGACC_ERR_BADARG, "walk_spg: needs a power-of-two table of distinct rows");
+        SG_REQUIRE(!uniq_table || (uniq_capacity > 0 && (uniq_capacity & (uniq_capacity - 1)) == 0 &&
+                                   uniq_capacity < (1ll << 31) && root_base >= 0),
+                   SUBGACC_ERR_BADARG, "walk_spg: needs a power-of-two table of distinct rows (or none: key rows)");
     }
     if (n == 0) return SUBGACC_OK;
     SG_REQUIRE(query, SUBGACC_ERR_BADARG, "walk: null query");   // `indices` may be NULL for an edgeless graph
@@ -777,7 +777,8 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
     a.step_major = cfg->order == SUBGACC_ORDER_STEP_MAJOR ? 1 : 0;
     a.cap_root = cfg->cap_root_degree ? 1 : 0;
     a.set_slot = set_slot;
-    a.table = spg ? uniq_view(uniq_table, uniq_capacity) : UniqTable{nullptr, nullptr, nullptr, 0};
+    a.table = (spg && uniq_table) ? uniq_view(uniq_table, uniq_capacity) : UniqTable{nullptr, nullptr, nullptr, 0};
+    a.keyrows = (spg && !uniq_table) ? 1 : 0;
     a.root_base = root_base;
     a.recs = (const unsigned long long *)cfg->hop_records;
     a.rec.id_bits = cfg->rec_id_bits, a.rec.beg_bits = cfg->rec_beg_bits;
@@ -804,6 +805,9 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
         SG_LAUNCH_CHECK();
         return SUBGACC_OK;
     }
+    SG_REQUIRE(!a.keyrows, SUBGACC_ERR_BADARG,
+               "walk_spg: key rows (no table of distinct rows) need set_sampler order, no bucket, M <= 256, 2 or 3 hops and "
+               "num_steps*SHIFT+1 <= 31; M = %d, m = %d", M, m);
     const int64_t grid = xcd_grid(n);
     SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "walk: chunk of %lld roots too large, split it", (long long)n);
 #define SG_WALK_LAUNCH(I64, RNGM, SPGM)                                                                           \

@@ -118,6 +118,7 @@ struct WalkArgs {
     int32_t *set_slot;
     UniqTable table;
     int64_t root_base;   // global index of query[0]: tags (root_base+i)*stride + rank order the first occurrences
+    int32_t keyrows;     // fused rows carry the member's 32-bit LP key itself instead of a table slot (no table of distinct rows)
     const unsigned long long *recs;   // packed hop records (walk_rows_kernel<REC>), else NULL
     RecFmt rec;                       // id_bits = 0: the 16-byte form {id : 32 | degree : 32, row begin : 64} (int64 row offsets)
 };

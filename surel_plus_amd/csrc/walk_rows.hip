@@ -50,8 +50,13 @@ extern "C" __device__ __attribute__((const)) int __ockl_wfscan_add_i32(int, bool
 // K32: the packed landing counts (and the LP keys made of them) fit 32 bits (m*SHIFT+1 <= 31: every reference
 // configuration up to 3 hops) -- 12 bytes of LDS per table slot instead of 16, which is what lets the 1,024-slot table of the
 // 3-hop configurations run with 128 lanes x 8 slots per lane and 11 roots per CU instead of 8.
-template <bool IDX64, int RNG, int MH, int SPL, int NT, int REC = 0, bool K32 = false>
+// KR ("key rows", needs K32): the row's payload is the member's 32-bit LP key itself.  A batch that is sampled, joined and
+// dropped needs neither the table of distinct LP rows nor their numbering -- the join turns a key into its feature row
+// arithmetically -- so the whole fold / registration / flush stage (a quarter of the kernel's vector instructions, its
+// global atomics) and the first-visit bookkeeping (minq: one LDS atomic per visit, 4 bytes of LDS per slot) fall away.
+template <bool IDX64, int RNG, int MH, int SPL, int NT, int REC = 0, bool K32 = false, bool KR = false>
 __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80))) void walk_rows_kernel(const WalkArgs a) {
+    static_assert(!KR || (K32 && SPL % 4 == 0), "key rows: 32-bit counts, 4-slot chunks");
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using CntT = typename std::conditional<K32, uint32_t, unsigned long long>::type;
     static_assert(SPL % 4 == 0 || (SPL == 2 && !K32), "slot ownership: 4-slot chunks, or two slots with 64-bit counts");
@@ -63,11 +68,11 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     CntT *pk = (CntT *)lds_raw;                                   // [T] packed landing counts
     int32_t *keys = (int32_t *)(pk + T);                          // [T] node ids
     uint32_t *minq = (uint32_t *)(keys + T);                      // [T] first visit sequence number
-    int32_t *sarr = (int32_t *)(minq + T);                        // [M] Fisher-Yates draws
+    int32_t *sarr = KR ? (int32_t *)(keys + T) : (int32_t *)(minq + T);   // [M] Fisher-Yates draws (KR: there is no minq)
     CntT *fk = (CntT *)(((uintptr_t)(sarr + a.M) + 7) & ~(uintptr_t)7);   // [kSpgFold]
     uint32_t *ft = (uint32_t *)(fk + kSpgFold);                   // [kSpgFold] min visit number of the key inside the set
     int32_t *fs = (int32_t *)(ft + kSpgFold);                     // [kSpgFold] HBM table slot of the key
-    int32_t *red = fs + kSpgFold;                                 // [16]
+    int32_t *red = KR ? (int32_t *)fk : fs + kSpgFold;            // [16] (KR: no fold table either)
 
     const int64_t i = xcd_item(blockIdx.x, gridDim.x);
     if (i >= a.n) return;
@@ -88,13 +93,13 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
                 ((uint4 *)pk)[2 * g] = make_uint4(0u, 0u, 0u, 0u);
                 ((uint4 *)pk)[2 * g + 1] = make_uint4(0u, 0u, 0u, 0u);
             }
-            ((uint4 *)minq)[g] = make_uint4(~0u, ~0u, ~0u, ~0u);
+            if (!KR) ((uint4 *)minq)[g] = make_uint4(~0u, ~0u, ~0u, ~0u);
         }
     } else {
         ((uint4 *)pk)[tid] = make_uint4(0u, 0u, 0u, 0u);
         ((uint2 *)minq)[tid] = make_uint2(~0u, ~0u);
     }
-    if (tid < kSpgFold) {
+    if (!KR && tid < kSpgFold) {
         fk[tid] = kNoKey;
         ft[tid] = 0xFFFFFFFFu;
     }
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
                 ((int4 *)keys)[c * NT + tid] = make_int4(x0 == hroot ? root : -1, x0 + 1u == hroot ? root : -1,
                                                          x0 + 2u == hroot ? root : -1, x0 + 3u == hroot ? root : -1);
             }
-            if (((hroot >> 2) % (uint32_t)NT) == (uint32_t)tid) minq[hroot] = 0u;   // the lane that cleared this word, after its clear
+            if (!KR && ((hroot >> 2) % (uint32_t)NT) == (uint32_t)tid) minq[hroot] = 0u;   // the lane that cleared this word, after its clear
         } else {
             const uint32_t x0 = 2u * (uint32_t)tid;
             ((int2 *)keys)[tid] = make_int2(x0 == hroot ? root : -1, x0 + 1u == hroot ? root : -1);
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
             unsigned long long k = (unsigned long long)lead;
             for (int s = 0; s < MH; ++s) k |= (unsigned long long)M << (s * a.shift);
             a.set_ids[obase] = root;
-            a.set_slot[obase] = uniq_global_insert(a.table, k, tag0, a.flags);
+            a.set_slot[obase] = KR ? (int32_t)k : uniq_global_insert(a.table, k, tag0, a.flags);
             a.nsize[i] = 1;
         }
         return;
@@ -263,7 +268,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
                     if (old == -1 || old == cur[k]) break;
                     h = (h + 1u) & TMASK;
                 }
-                atomicMin(&minq[h], (uint32_t)((tid + k * NT) * MH + s + 1));
+                if (!KR) atomicMin(&minq[h], (uint32_t)((tid + k * NT) * MH + s + 1));
                 atomicAdd(&pk[h], (CntT)1 << ((MH - 1 - s) * a.shift));
             }
             if (!REC && s + 1 < MH) {
@@ -284,6 +289,105 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     }
     __syncthreads();
     SG_RSTAMP(2);
+
+    if (KR) {
+        // ================= key rows: the set leaves sorted by node id with its members' LP keys =================
+        int32_t idv[SPL];
+        uint32_t kv[SPL];
+        bool ok[SPL];
+        int mycount = 0;
+        int32_t vmin = 0x7FFFFFFF, vmax = 0;
+#pragma unroll
+        for (int c = 0; c < SPL / 4; ++c) {
+            const int g = c * NT + tid;
+            const int4 kk = ((const int4 *)keys)[g];
+            const uint4 v = ((const uint4 *)pk)[g];
+            idv[4 * c] = kk.x, idv[4 * c + 1] = kk.y, idv[4 * c + 2] = kk.z, idv[4 * c + 3] = kk.w;
+            kv[4 * c] = v.x, kv[4 * c + 1] = v.y, kv[4 * c + 2] = v.z, kv[4 * c + 3] = v.w;
+        }
+#pragma unroll
+        for (int u = 0; u < SPL; ++u) {
+            ok[u] = idv[u] != -1;
+            kv[u] |= (idv[u] == root ? (uint32_t)lead : 0u);        // the root's own row carries the lead bit
+            mycount += ok[u] ? 1 : 0;
+            vmin = min(vmin, ok[u] ? idv[u] : 0x7FFFFFFF);
+            vmax = max(vmax, ok[u] ? idv[u] : 0);
+        }
+        vmin = __ockl_wfred_min_i32(vmin);
+        vmax = __ockl_wfred_max_i32(vmax);
+        mycount = __ockl_wfred_add_i32(mycount);
+        if ((tid & (kWave - 1)) == 0) {
+            red[tid / kWave] = vmin;
+            red[4 + tid / kWave] = vmax;
+            atomicAdd(&red[8], mycount);
+        }
+        __syncthreads();   // every lane holds its members in registers: the walk tables are free to be re-used
+        const int32_t ns = red[8];
+        if (tid == 0) a.nsize[i] = ns;
+        const int32_t mn = min(min(red[0], red[1]), min(red[2], red[3]));
+        const int32_t mx = max(max(red[4], red[5]), max(red[6], red[7]));
+        unsigned long long *A = (unsigned long long *)lds_raw;            // [ns <= stride] over the counts and the ids
+        int32_t *start = (int32_t *)(lds_raw + 8 * (size_t)a.stride);       // [B+1] behind it (8*stride + 4*(B+1) <= 8*T)
+        int logb = 0;
+        while ((1 << logb) < ns && (2 << logb) <= T / 4 && (2 << logb) <= NT) ++logb;
+        const int B = 1 << logb;
+        const uint32_t range = (uint32_t)(mx - mn) + 1u;
+        const int Ls = (range <= 1u) ? 0 : (32 - __builtin_clz(range - 1u));
+        const int bshift = Ls > logb ? Ls - logb : 0;
+        if (tid < B) start[tid] = 0;
+        __syncthreads();
+        uint32_t bk[SPL];
+        int32_t pos[SPL];                           // arrival order inside the bucket, then the final position
+#pragma unroll
+        for (int u = 0; u < SPL; ++u) {
+            bk[u] = (uint32_t)(idv[u] - mn) >> bshift;
+            pos[u] = ok[u] ? atomicAdd(&start[bk[u]], 1) : 0;
+        }
+        __syncthreads();
+        {
+            const int32_t c = tid < B ? start[tid] : 0;
+            const int32_t inc = __ockl_wfscan_add_i32(c, true);
+            if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc;
+            __syncthreads();
+            int32_t base = 0;
+            for (int w2 = 0; w2 < tid / kWave; ++w2) base += red[12 + w2];
+            const int32_t excl = base + inc - c;
+            if (tid < B) start[tid] = excl;
+            if (tid == B - 1) start[B] = excl + c;
+        }
+        __syncthreads();
+        int blo[SPL], bhi[SPL];
+#pragma unroll
+        for (int u = 0; u < SPL; ++u) {
+            blo[u] = ok[u] ? start[bk[u]] : 0;
+            bhi[u] = ok[u] ? start[bk[u] + 1] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < SPL; ++u)
+            if (ok[u]) A[blo[u] + pos[u]] = ((unsigned long long)(uint32_t)idv[u] << 32) | kv[u];
+        __syncthreads();
+        const uint32_t *Ahi = (const uint32_t *)A;
+#pragma unroll
+        for (int u = 0; u < SPL; ++u)
+            if (ok[u]) {
+                const int lo = blo[u], hi = bhi[u];
+                int rank = 0;       // ids are distinct within a set: the high word of A decides
+#pragma unroll 1
+                for (int t2 = lo; t2 < hi; ++t2) rank += (Ahi[2 * t2 + 1] < (uint32_t)idv[u]) ? 1 : 0;
+                pos[u] = lo + rank;
+            }
+        __syncthreads();        // every rank is known: the bucket-grouped array can become the sorted one, in place
+#pragma unroll
+        for (int u = 0; u < SPL; ++u)
+            if (ok[u]) A[pos[u]] = ((unsigned long long)(uint32_t)idv[u] << 32) | kv[u];
+        __syncthreads();
+        for (int x = tid; x < ns; x += NT) {
+            const unsigned long long v = A[x];
+            a.set_ids[obase + x] = (int32_t)(v >> 32);
+            a.set_slot[obase + x] = (int32_t)(uint32_t)v;
+        }
+        return;
+    }
 
     // ================= the set leaves as a finished SpG row =================
     // (1) fold the set's LP keys (a few dozen distinct rows) and register them in the HBM table of distinct rows with
@@ -485,6 +589,35 @@ int launch_walk_rows(const WalkArgs &a, bool indptr64, int rng_mode, size_t lds,
     static const bool nt256 = getenv("SUBGACC_ROWS_NT") && atoi(getenv("SUBGACC_ROWS_NT")) == 256;
     const bool half = a.T == 512 && !nt256;
     const bool rec = a.recs != nullptr && indptr64 == (a.rec.id_bits == 0);   // hop records: one dependent read per hop
+    if (a.keyrows) {      // rows that carry the LP key itself: 32-bit counts, 128 lanes, 2 or 3 hops -- or not at all
+        if (a.m * a.shift + 1 > 31 || a.m > 3 || 8 * (int64_t)a.stride + 4 * 129 > 8 * (int64_t)a.T) return 0;
+        const size_t ldsk = (size_t)a.T * 8 + (size_t)a.M * 4 + 8 + 64 + 16;
+#define SG_KR(I64, RNGM, MHH, SPLL)                                                                                  \
+    do {                                                                                                             \
+        if (rec)                                                                                                     \
+            hipLaunchKernelGGL((walk_rows_kernel<I64, RNGM, MHH, SPLL, 128, I64 ? 16 : 8, true, true>), dim3((unsigned)grid), dim3(128), ldsk, s, a); \
+        else                                                                                                         \
+            hipLaunchKernelGGL((walk_rows_kernel<I64, RNGM, MHH, SPLL, 128, 0, true, true>), dim3((unsigned)grid), dim3(128), ldsk, s, a); \
+        return 1;                                                                                                    \
+    } while (0)
+#define SG_KR_MH(I64, RNGM)                                  \
+    do {                                                     \
+        if (a.T == 1024) {                                   \
+            if (a.m == 2) SG_KR(I64, RNGM, 2, 8);            \
+            SG_KR(I64, RNGM, 3, 8);                          \
+        }                                                    \
+        if (a.m == 2) SG_KR(I64, RNGM, 2, 4);                \
+        SG_KR(I64, RNGM, 3, 4);                              \
+    } while (0)
+        if (indptr64) {
+            if (rr) SG_KR_MH(true, SUBGACC_RNG_RAND_R);
+            SG_KR_MH(true, SUBGACC_RNG_PHILOX);
+        }
+        if (rr) SG_KR_MH(false, SUBGACC_RNG_RAND_R);
+        SG_KR_MH(false, SUBGACC_RNG_PHILOX);
+#undef SG_KR_MH
+#undef SG_KR
+    }
     // 1,024-slot table with counts that fit 32 bits: 128 lanes x 8 slots, 12 bytes of LDS per slot -> 11 roots per CU
     // (SUBGACC_ROWS_NT=256 keeps the 256-lane form; dev-only).  int32 row offsets + 8-byte records / plain CSR only.
     if (a.T == 1024 && !nt256 && !indptr64 && a.m * a.shift + 1 <= 31 && a.m <= 3) {

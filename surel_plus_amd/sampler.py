@@ -35,6 +35,23 @@ HOP_RECORDS = os.environ.get("SUBGACC_HOP_RECORDS", "auto")
 HOP_RECORDS_MIN_BYTES = 64 << 20      # adjacency bytes from which records are built in "auto" mode
 HOP_RECORDS_MIN_DEG_BITS = 12
 
+# Key rows (csrc/walk_rows.hip KR form + subgacc_sjoin_fill_keyrows): a strided batch that will not be numbered carries its
+# members' 32-bit LP keys instead of slots of a table of distinct rows; the join unpacks a key into its feature row itself.
+# No table, no registration, no unpack pass: -14 % walk-kernel time on the cit2-like batch, -23 % on collab.  Asking such a
+# batch for its numbering afterwards (number(), c, enc_int16(), to_csr()) samples it again with the table form.
+KEY_ROWS = os.environ.get("SUBGACC_KEY_ROWS", "1") == "1"
+
+
+def key_rows_ok(num_walks, num_steps):
+    """does the fused-row kernel have a key-rows form for this shape? (32-bit keys, 2 or 3 hops, a 512 / 1,024-slot table)"""
+    q = num_walks * num_steps + 1
+    t = 64
+    while t < q + q // 4 + 1:
+        t <<= 1
+    return (num_steps in (2, 3) and num_steps * int(num_walks).bit_length() + 1 <= 31 and num_walks <= 256
+            and t in (512, 1024))
+
+
 # bench.py sets this to a callable(name) -> context manager that brackets one kernel launch with HIP events
 # on the launch stream (roofline.achieved is measured live, not taken from a profile)
 KERNEL_TIMER = None
@@ -156,6 +173,8 @@ class SampledSets:
     _pending: tuple = None       # prefetch(): (pinned host copy of status, event, device source)
     extra: list = None           # values of prefetch(extra=...) once resolved
     _tail: torch.Tensor = None   # StepBuffers form: int64 [5] = [rows of the join (= members), status words x4], contiguous
+    keyrows: bool = False        # strided rows whose payload (`slot`) is the member's 32-bit LP key: no table, no numbering
+    _resample: object = None     # keyrows: callable -> the same batch sampled with the table form (number() and friends)
 
     # ------------------------------------------------------------------ lazy bookkeeping
     @property
@@ -232,6 +251,10 @@ class SampledSets:
         if self.ukeys is not None:
             return self
         self.resolve()
+        if self.keyrows:        # the keys are all there, the first-visit order is not: sample the batch again, with the table
+            full = self._resample().number()
+            self.ukeys, self._full = full.ukeys, full
+            return self
         L, dev, st = lib(), self.ids.device, stream_ptr()
         count = torch.zeros(1, dtype=torch.int64, device=dev)
         max_unique = min(self.capacity, RANK_LIMIT)
@@ -295,6 +318,8 @@ class SampledSets:
     def feature_table_by_slot(self):
         """float32 [capacity+1, m+1]: row s+1 = enc/M of the LP row held in slot s of the table of distinct rows, row 0
         (and the rows of free slots, never indexed) zero -- Z_SF without the numbering, for joins over table slots."""
+        if self.keyrows:
+            raise ValueError("key rows are joined by subgacc_sjoin_fill_keyrows: there is no table to index")
         if self.table is None:
             raise ValueError("no table of distinct LP rows (sample_sets(..., dedup=True))")
         keys = self.table[: self.capacity * 8].view(torch.int64)
@@ -381,7 +406,7 @@ def _cat(parts, dtype, dev):
 def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, rng="rand_r", first_hop_wo=True,
                 order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False, rng_streams=1,
                 calls_before=0, dedup=True, keep_keys=None, staging_bytes=STAGING_BYTES, uniq_capacity=UNIQ_CAPACITY,
-                uniq_small_limit=0, fused_rows=False, lazy=False, strided=False, number_rows=True):
+                uniq_small_limit=0, fused_rows=False, lazy=False, strided=False, number_rows=True, key_rows=None):
     """Run the sampler for `query` (roots) on the GPU.  See SampledSets.
 
     dedup=True numbers the distinct LP rows (ukeys, slot / get_sf()); the packed keys are then only kept when
@@ -424,8 +449,13 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
         return None
 
     rng_pos, rng_seed = _rng_positions(L, cfg, csr, q, n, rng_streams, calls_before, st)
+    # key rows: strided fused rows that nobody asked to number carry LP keys instead of table slots (module header)
+    if key_rows is None:
+        key_rows = KEY_ROWS
+    key_rows = bool(key_rows and strided and fused_rows and not number_rows and bucket <= 0 and n > 0 and chunk == n
+                    and key_rows_ok(M, m))
     table = None
-    if dedup:
+    if dedup and not key_rows:
         table = torch.empty(L.subgacc_uniq_table_bytes(uniq_capacity), dtype=torch.uint8, device=dev)
         check(L.subgacc_uniq_reset(ptr(table), uniq_capacity, st))
 
@@ -446,7 +476,7 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
                 check(L.subgacc_walk_spg(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn, lo,
                                          ptr(rng_pos[lo:]) if rng_pos is not None else None,
                                          ptr(rng_seed[lo:]) if rng_seed is not None else None,
-                                         ptr(table), uniq_capacity, ptr(st_ids), ptr(st_aux), ptr(nsize[lo:]),
+                                         ptr(table), 0 if key_rows else uniq_capacity, ptr(st_ids), ptr(st_aux), ptr(nsize[lo:]),
                                          ptr(flags), st))
             else:
                 check(L.subgacc_walk_sets(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn,
@@ -475,7 +505,13 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
                                             ptr(nws), nws.numel(), st))
         if strided:           # rows are joined from the staging arrays themselves
             sets = SampledSets(nsize, None, st_ids, None, None, ukeys, M, m, stride, None)
-            sets.slot, sets.table, sets.capacity, sets.strided = st_aux, table, uniq_capacity, True
+            sets.slot, sets.table, sets.capacity, sets.strided = st_aux, table, (0 if key_rows else uniq_capacity), True
+            if key_rows:
+                sets.keyrows = True
+                sets._resample = lambda: sample_sets(csr, q, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order,
+                                                     cap_root_degree, emit_walks, rng_streams, calls_before, dedup, keep_keys,
+                                                     staging_bytes, uniq_capacity, uniq_small_limit, fused_rows, False, True,
+                                                     True, False)
             torch.sum(nsize, dim=(0,), dtype=torch.int64, out=status[3])
             sets.status = status
             if not lazy:      # eager: same recovery as the packed forms below

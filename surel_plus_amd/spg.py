@@ -101,6 +101,9 @@ class SpG:
                              shape=self.shape)
 
 
+KEY_ROWS_ENCODE = "key rows"      # StridedSpG.slot_table() of a key-rows batch: the join needs no table
+
+
 class StridedSpG:
     """The SpG of a transient batch in the layout the fused walk kernel writes: row i = indices / slot
     [i*stride, +nsize[i]), node ids ascending, payload = slot in the numbered table of distinct LP rows.
@@ -112,6 +115,7 @@ class StridedSpG:
         self.indices, self.slot, self.nsize = sets.ids, sets.slot, sets.nsize
         self.stride = self.max_len = int(sets.stride)
         self.table, self.capacity = sets.table, sets.capacity
+        self.keyrows = bool(getattr(sets, "keyrows", False))      # payload = LP keys (subgacc_sjoin_fill_keyrows joins them)
         self._slot_table = None
         self.n_rows = sets.nsize.numel()
         self.shape = (self.n_rows, n_cols)
@@ -120,6 +124,9 @@ class StridedSpG:
     def slot_table(self):
         """The feature table indexed by table slot (SampledSets.feature_table_by_slot): pass it as `encode` and the
         join skips the slot -> SFptr indirection altogether."""
+        if self.keyrows:          # nothing to index: the join unpacks the keys; the marker tells it so
+            self._slot_table = KEY_ROWS_ENCODE
+            return self._slot_table
         self._slot_table = self.sets.feature_table_by_slot()
         return self._slot_table
 
@@ -133,6 +140,8 @@ class StridedSpG:
         return self.sets.X
 
     def to_csr(self):
+        if self.keyrows:             # the packed rows carry SFptr+1: that needs the numbering, i.e. the table form of the batch
+            return StridedSpG(self.sets.number()._full, self.shape[1]).to_csr()
         self.sets.number()           # the packed rows carry SFptr+1: the table must be numbered by now
         n, dev = self.n_rows, self.device
         row_off = torch.empty(n + 1, dtype=torch.int64, device=dev)

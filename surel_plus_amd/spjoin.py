@@ -130,6 +130,30 @@ def _sjoin_strided(spg, own, partner, seg, ws, encode, ptr_mode, return_index, p
         return res, (seg if ptr_mode else segid), flags
     if encode is None:
         raise NotImplementedError("an integer SpG needs the encode table")
+    if getattr(spg, "keyrows", False):      # rows of LP keys: the feature rows are unpacked from the keys by the join itself
+        from .spg import KEY_ROWS_ENCODE
+        if encode is not KEY_ROWS_ENCODE:
+            raise ValueError("a key-rows batch is joined with encode=z.slot_table(); use z.to_csr() for another table")
+        M_, m_ = spg.sets.num_walks, spg.sets.num_steps
+        k = m_ + 1
+        if lazy:
+            if out is None or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev or \
+                    out.numel() < S * spg.max_len * 2 * k:
+                raise ValueError("lazy out= must hold S * SpG.max_len * 2 * k float32 on the SpG's device")
+            rows = out.numel() // (2 * k)
+            res = out.view(-1)[: rows * 2 * k].view(rows, 2, k)
+        elif out is not None:
+            if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() < R * 2 * k or out.device != dev:
+                raise ValueError("out= must be a contiguous float32 buffer on the SpG's device with >= R*2*k elements")
+            res = out.view(-1)[: R * 2 * k].view(R, 2, k)
+        else:
+            res = torch.empty((R, 2, k), dtype=torch.float32, device=dev)
+        if not ptr_mode:
+            raise ValueError("a key-rows batch is joined with segment pointers (ptr=True); use z.to_csr() for segment ids")
+        with _timed("sjoin_fill"):
+            check(L.subgacc_sjoin_fill_keyrows(ptr(spg.nsize), spg.n_rows, spg.stride, ptr(spg.indices), ptr(spg.slot), ptr(own),
+                                               ptr(partner), S, ptr(seg), M_, m_, ptr(res), pair_block, ptr(flags), st))
+        return res, seg, flags
     by_slot = encode is spg._slot_table and encode is not None      # StridedSpG.slot_table(): indexed by slot + 1
     enc = encode if by_slot else encode.to(device=dev, dtype=torch.float32).contiguous()
     k = enc.shape[1]
@@ -255,11 +279,13 @@ class StepBuffers:
         self.nsize = torch.empty(n, dtype=torch.int32, device=dev)
         self.ids = torch.empty(n * self.stride, dtype=torch.int32, device=dev)
         self.slot = torch.empty(n * self.stride, dtype=torch.int32, device=dev)
-        self.table = torch.empty(L.subgacc_uniq_table_bytes(self.capacity), dtype=torch.uint8, device=dev)
+        from .sampler import KEY_ROWS, key_rows_ok
+        self.keyrows = bool(KEY_ROWS and key_rows_ok(self.M, self.m))    # rows of LP keys: no table, no feature table
+        self.table = None if self.keyrows else torch.empty(L.subgacc_uniq_table_bytes(self.capacity), dtype=torch.uint8, device=dev)
         self.tail = torch.zeros(n + 1 + 4, dtype=torch.int64, device=dev)      # seg [n+1] | status [4]
         self.seg, self.status = self.tail[: n + 1], self.tail[n + 1:]
         self.ws = torch.empty(max(L.subgacc_sjoin_workspace_bytes(n), 8), dtype=torch.uint8, device=dev)
-        self.feat = torch.empty((self.capacity + 1, self.k), dtype=torch.float32, device=dev)
+        self.feat = None if self.keyrows else torch.empty((self.capacity + 1, self.k), dtype=torch.float32, device=dev)
         need = n * self.stride * 2 * self.k
         if out is not None and (out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev or out.numel() < need):
             raise ValueError("StepBuffers: out= must hold 2B * (M*m+1) * 2 * (m+1) float32 on the graph's device")
@@ -278,26 +304,38 @@ def _buffered_step(csr, e, bufs, seed, out):
     flags = bufs.status.view(torch.int32)[:4]
     cfg = make_cfg(csr, M, m, -1, seed, "philox")
     check(L.subgacc_key_shift(cfg.num_walks, cfg.num_steps))
-    check(L.subgacc_step_prologue(ptr(bufs.table), bufs.capacity, ptr(bufs.status), 4, ptr(e), ptr(bufs.roots), n, st))
+    kr = bufs.keyrows
+    check(L.subgacc_step_prologue(ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.status), 4, ptr(e), ptr(bufs.roots), n, st))
     with _timed("walk_sets"):
         check(L.subgacc_walk_spg(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n, 0, None, None,
-                                 ptr(bufs.table), bufs.capacity, ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize), ptr(flags), st))
+                                 ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize),
+                                 ptr(flags), st))
     own, partner = _arange_segments(B, dev)
     check(L.subgacc_sjoin_sizes_rows(ptr(bufs.nsize), n, ptr(own), ptr(partner), n, ptr(bufs.seg), ptr(flags), ptr(bufs.ws),
                                      bufs.ws.numel(), st))
-    keys = bufs.table[: bufs.capacity * 8].view(torch.int64)
-    check(L.subgacc_unpack_lp(ptr(keys), bufs.capacity, None, M, m, None, None, ptr(bufs.feat), 1, st))
+    if not kr:
+        keys = bufs.table[: bufs.capacity * 8].view(torch.int64)
+        check(L.subgacc_unpack_lp(ptr(keys), bufs.capacity, None, M, m, None, None, ptr(bufs.feat), 1, st))
     res = out if out is not None else bufs.out
     if res.dtype != torch.float32 or not res.is_contiguous() or res.device != dev or res.numel() < n * bufs.stride * 2 * k:
         raise ValueError("out= must hold 2B * (M*m+1) * 2 * (m+1) float32 on the graph's device")
     rows = res.numel() // (2 * k)
     xz = res.view(-1)[: rows * 2 * k].view(rows, 2, k)
     with _timed("sjoin_fill"):
-        check(L.subgacc_sjoin_fill_rows(ptr(bufs.nsize), n, bufs.stride, ptr(bufs.ids), ptr(bufs.slot), None, 0, ptr(own),
-                                        ptr(partner), n, ptr(bufs.seg), ptr(bufs.feat), bufs.capacity + 1, k, ptr(xz), None, None,
-                                        B, ptr(flags), st))
+        if kr:
+            check(L.subgacc_sjoin_fill_keyrows(ptr(bufs.nsize), n, bufs.stride, ptr(bufs.ids), ptr(bufs.slot), ptr(own), ptr(partner),
+                                               n, ptr(bufs.seg), M, m, ptr(xz), B, ptr(flags), st))
+        else:
+            check(L.subgacc_sjoin_fill_rows(ptr(bufs.nsize), n, bufs.stride, ptr(bufs.ids), ptr(bufs.slot), None, 0, ptr(own),
+                                            ptr(partner), n, ptr(bufs.seg), ptr(bufs.feat), bufs.capacity + 1, k, ptr(xz), None,
+                                            None, B, ptr(flags), st))
     sets = SampledSets(bufs.nsize, None, bufs.ids, None, None, None, M, m, bufs.stride, None)
-    sets.slot, sets.table, sets.capacity, sets.strided = bufs.slot, bufs.table, bufs.capacity, True
+    sets.slot, sets.table, sets.capacity, sets.strided = bufs.slot, bufs.table, (0 if kr else bufs.capacity), True
+    if kr:
+        from .sampler import sample_sets
+        sets.keyrows = True
+        sets._resample = lambda: sample_sets(csr, bufs.roots, M, m, -1, seed, "philox", fused_rows=True, strided=True,
+                                             number_rows=True, key_rows=False, uniq_capacity=bufs.capacity)
     sets.status, sets._tail = bufs.status, bufs.tail[n: n + 5]
     return xz, bufs.seg, sets
 

@@ -1028,6 +1028,37 @@ def test_captured_step_replays_equal_the_eager_step(sp, B, hops, rng):
     assert torch.equal(ind, eind) and torch.equal(xz, exz)
 
 
+@pytest.mark.parametrize("rng", ["rand_r", "philox"])
+@pytest.mark.parametrize("M,hops,idx64", [(200, 3, False), (200, 2, True), (100, 3, True), (120, 2, False)])
+def test_key_rows_join_like_table_rows(sp, rng, M, hops, idx64):
+    """rows that carry the 32-bit LP key instead of a table slot (csrc/walk_rows.hip KR form, subgacc_sjoin_fill_keyrows):
+    the same (xz, indptr) as the table form and as the oracle; numbering, enc and the packed CSR on demand (sampled again)"""
+    from surel_plus_amd.graphs import query_pairs
+    from surel_plus_amd.sampler import key_rows_ok
+    assert key_rows_ok(M, hops)
+    ptr_, idx = sym_graph(8000, 70000, seed=31, hubs=3)
+    csr = sp.DeviceCSR(ptr_.astype(np.int64) if idx64 else ptr_, idx)
+    e = query_pairs(csr, 700, seed=3)
+    e[:, 5] = e[0, 5]                                              # a (u, u) pair
+    xz, ind, sets = sp.sample_and_gather(csr, e, num_walks=M, num_steps=hops, seed=21, rng=rng)
+    assert sets.keyrows and sets.table is None
+    txz, tind, tsets = sp.sample_and_gather(csr, e, num_walks=M, num_steps=hops, seed=21, rng=rng, key_rows=False)
+    assert not tsets.keyrows and torch.equal(ind, tind) and torch.equal(xz, txz)
+    # against the oracle: sets of both endpoints -> SpG -> gather with Z_SF = enc / M
+    roots = e.reshape(-1).cpu().numpy()
+    (oi, ox, od), oenc = _oracle_spg(ptr_, idx, roots, M, hops, 21, rng, -1)
+    table = oracle.enc_table(oenc).astype(np.float32) / np.float32(M)
+    rows = np.arange(2 * 700, dtype=np.int64).reshape(2, 700)
+    oxz, oind = oracle.gather(rows, (oi, ox, od), ptr=True, encode=table)
+    assert np.array_equal(ind.cpu().numpy(), oind) and np.array_equal(xz.cpu().numpy(), oxz)
+    # what the key rows do not carry is sampled again on demand: numbering, enc, the packed store
+    assert sets.c == tsets.c and torch.equal(sets.number().ukeys, tsets.number().ukeys)
+    assert torch.equal(sets.enc_int16(), tsets.enc_int16())
+    z = sp.StridedSpG(sets, csr.num_nodes)
+    zc, tc = z.to_csr(), sp.StridedSpG(tsets, csr.num_nodes).to_csr()
+    assert torch.equal(zc.indptr, tc.indptr) and torch.equal(zc.indices, tc.indices) and torch.equal(zc.data, tc.data)
+
+
 @pytest.mark.parametrize("B,M,hops", [(512, 100, 3), (300, 200, 2), (64, 50, 4)])
 def test_buffered_step_equals_the_allocating_step(sp, B, M, hops):
     """spjoin.StepBuffers: the on-demand step as six launches over preallocated buffers gives bit for bit what the general
