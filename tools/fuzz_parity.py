@@ -12,7 +12,7 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 only = int(sys.argv[3]) if len(sys.argv) > 3 else None          # re-run one case verbosely
 bad = skipped = 0
-cov = {"directed": 0, "int64": 0, "ppr": 0, "strided_join": 0, "multichunk": 0, "members": 0}
+cov = {"directed": 0, "int64": 0, "ppr": 0, "strided_join": 0, "key_rows": 0, "multichunk": 0, "members": 0}
 t0 = time.time()
 for c in range(cases):
     if only is not None and c != only:
@@ -75,6 +75,15 @@ for c in range(cases):
         xz, ind = sp.gather(edge, zs, "cuda", ptr=True, encode=tab)
         if not (np.array_equal(ind.cpu().numpy(), wind) and np.array_equal(xz.cpu().numpy(), wxz)):
             fails.append("gather")
+        # the same batch as rows of LP keys (no table, no numbering) where the shape has that form
+        zk, sk = sp.sample_spg(csr, q, num_walks=M, num_steps=m, seed=seed, rng=rng, bucket=bucket, strided=True, number_rows=False)
+        if isinstance(zk, sp.StridedSpG) and zk.keyrows:
+            cov["key_rows"] += 1
+            xk, ik = sp.gather(edge, zk, "cuda", ptr=True, encode=zk.slot_table())
+            if not (np.array_equal(ik.cpu().numpy(), wind) and np.array_equal(xk.cpu().numpy(), wxz)):
+                fails.append("gather(key rows)")
+            if not np.array_equal(sk.enc_int16().cpu().numpy(), b[2]):      # numbering on demand (sampled again)
+                fails.append("enc(key rows)")
         T = int(rng0.choice([1, 3]))
         rep = bool(rng0.integers(0, 2))
         w1, o1 = sp.walk_sampler(ptr_, idx, q, num_walks=M, num_steps=m, nthread=T, seed=seed, replacement=rep, rng=rng)
