@@ -68,6 +68,19 @@ def test_cit2_scale_all_roots_then_a_million_pairs(sp):
             assert bool((xz[:, 0, :].abs().sum(-1) > 0).all())
         tot += xz.shape[0]
     assert tot > 3 * 10**8
+    # on demand == offline (main.py:172-178 samples all N once; sample_and_gather samples the endpoints of the batch): the
+    # batch of 65,536 pairs as rows of LP keys, through preallocated step buffers, against the join over the resident store
+    # (Philox sets are functions of the seed and the root) -- and against the table form of the same batch
+    edge = query_pairs(csr, 65536, seed=100)
+    wxz, wind = sp.gather(edge, z, "cuda", ptr=True, encode=table)
+    bufs = sp.StepBuffers(csr, 65536, num_walks=M, num_steps=m)
+    assert bufs.keyrows and csr.hop_records() is not None               # 252 MB of adjacency: hop records are in play
+    xz, ind, bsets = sp.sample_and_gather(csr, edge, num_walks=M, num_steps=m, seed=5, rng="philox", buffers=bufs)
+    bsets.prefetch().resolve()
+    rows = int(bsets.extra[0])
+    assert rows == wxz.shape[0] and torch.equal(ind, wind) and torch.equal(xz[:rows], wxz)
+    txz, tind, tsets = sp.sample_and_gather(csr, edge, num_walks=M, num_steps=m, seed=5, rng="philox", key_rows=False)
+    assert not tsets.keyrows and torch.equal(tind, wind) and torch.equal(txz, wxz)
 
 
 def test_twitter_scale_int64_offsets(sp):
