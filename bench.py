@@ -580,7 +580,8 @@ def main():
         out = bench_lp(args, args.workload, args.rng, B, K, W, sp, sampler_mod, dev, rank, world, dist,
                        with_cpu_baseline=(world == 1 and not args.no_cpu_baseline),
                        small_batches=(world == 1 and not args.no_others),
-                       two_stream_extra=not args.no_others)      # --no-others: the profiled command, single-stream steps only
+                       two_stream_extra=not args.no_others,      # --no-others: the profiled command, single-stream steps only
+                       csr_variant=not args.no_others)           # ... and no pass with the packed-CSR (table rows) variant
     # BASELINE.json's other single-GPU configurations (and the reference-bit-exact rand_r stream on the headline one),
     # as short passes after the timed region: same code path, >= 5 timed steps each, their own roofline blocks
     # (configs[0], the reference's CPU-runnable collab case, rides on the collab entry as its cpu_baseline).

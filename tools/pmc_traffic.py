@@ -26,10 +26,11 @@ for k, c in acc.items():
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
         rows.append((-(2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]), k, len(c["FETCH_SIZE"]), m))
 walk = None
-for _, k, n, m in sorted(rows)[:10]:
+for _, k, n, m in sorted(rows)[:12]:
     hbm = (2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024
     print(f"\"{k}\",{n},{m['FETCH_SIZE']:.0f},{m['WRITE_SIZE']:.0f},{m.get('TCC_REQ_sum', 0):.0f},{m.get('TCC_HIT_sum', 0):.0f},{m.get('TCC_MISS_sum', 0):.0f},{hbm:.0f}")
-    if walk is None and (k.startswith("walk_sets_kernel") or k.startswith("walk_rows_kernel") or k.startswith("walk_pipe_kernel") or k.startswith("walk_wave_kernel")):
+    if (k.startswith("walk_sets_kernel") or k.startswith("walk_rows_kernel") or k.startswith("walk_pipe_kernel")) and \
+            (walk is None or n > walk[4]):      # the walk kernel of the timed steps: the one with the most launches
         walk = (k, hbm, m.get("TCC_MISS_sum", 0), m.get("TCC_REQ_sum", 0), n)
 # the bench line of one of the passes tells the configuration (workload, B, M, k, layout, rng)
 line = None
