@@ -21,6 +21,10 @@
 
 namespace subgacc {
 
+#ifndef SG_LAST_HOP_ID     // 1: with hop records, the last hop reads the bare id from `indices` (A/B: tools/ab.py)
+#define SG_LAST_HOP_ID 1
+#endif
+
 // Wave-wide reductions / scan of the device library (DPP row shifts and broadcasts: a handful of vector instructions and no
 // LDS traffic, where six __shfl steps cost six ds_bpermute round trips each).  Every lane is active at the call sites.
 extern "C" __device__ __attribute__((const)) int __ockl_wfred_min_i32(int);
@@ -231,7 +235,9 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
                 if (!wk[k]) continue;
                 if (REC) {      // the record carries the node AND its row: the next record is asked for before the visit
                     bool esc = false;
-                    if (REC == 16) {
+                    if (SG_LAST_HOP_ID && s + 1 == MH && MH > 1) {
+                        cur[k] = (int32_t)(uint32_t)rec[k];       // the last hop fetched the bare neighbour id (below)
+                    } else if (REC == 16) {
                         cur[k] = (int32_t)(uint32_t)rec[k];
                         d[k] = (int64_t)(rec[k] >> 32);
                         b[k] = (int64_t)rec2[k];
@@ -244,7 +250,12 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
                             uint32_t off;
                             if (RNG == SUBGACC_RNG_RAND_R) off = rand_r_next(x[k]) % (uint32_t)d[k];
                             else off = philox_below(dr[k][s], (uint32_t)d[k]);
-                            if (REC == 16) {
+                            if (SG_LAST_HOP_ID && s + 2 == MH) {
+                                // the walk ends on this node: its row is never needed, so the 4-byte id from the plain
+                                // adjacency array will do -- half the bytes per entry, twice the entries of a hub's row
+                                // per line for the walkers that share it
+                                rec[k] = (unsigned long long)(uint32_t)SG_NEIGH_LOAD(&a.indices[b[k] + (int64_t)off]);
+                            } else if (REC == 16) {
                                 const ulonglong2 r2 = ((const ulonglong2 *)a.recs)[b[k] + (int64_t)off];
                                 rec[k] = r2.x, rec2[k] = r2.y;
                             } else {
