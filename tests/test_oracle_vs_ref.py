@@ -1,5 +1,5 @@
 """CPU, build container only: randomized sweep of the oracle (oracle/subgacc_oracle.c) against the REFERENCE ITSELF
-(oracle/_ref = /root/reference/subg_acc/subg_acc.c compiled by `make -C oracle ref`), beyond the 41 committed
+(oracle/_ref = /root/reference/subg_acc/subg_acc.c compiled by `make -C oracle ref`), beyond the 46 committed
 fixtures: random graphs (isolated nodes, star hubs, K2 components), random M / m / bucket / seeds / query shapes.
 
     gset_sampler  nthread=1 (the only reproducible setting, subg_acc.c:731-732)        subg_acc.c:649-1034
