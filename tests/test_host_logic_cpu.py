@@ -108,3 +108,18 @@ def test_make_cfg_rejects_bad_parameters():
         make_cfg(g, 10, 3, rng="mt19937")
     cfg = make_cfg(g, 200, 3, seed=-1)
     assert cfg.seed == 0xFFFFFFFF and cfg.indptr64 == 0 and cfg.first_hop_wo == 1
+
+
+def test_kernel_shape_rules_of_the_fused_row_path():
+    """which launches get key rows / the specialised kernel (host-side rules that mirror csrc/walk_rows.hip:launch_walk_rows)"""
+    from surel_plus_amd.sampler import key_rows_ok, walk_kernel_name
+    # every reference configuration up to 3 hops: 32-bit LP keys, a 512- or 1,024-slot table
+    assert key_rows_ok(200, 2) and key_rows_ok(200, 3) and key_rows_ok(100, 3) and key_rows_ok(120, 2)
+    assert not key_rows_ok(200, 4)        # 4*8+1 = 33 bits
+    assert not key_rows_ok(300, 2)        # more walks than lanes
+    assert not key_rows_ok(16, 2)         # a 64-slot table: the general kernel
+    assert not key_rows_ok(200, 1)
+    assert walk_kernel_name(None, 200, 3, True) == "walk_rows_kernel"
+    assert walk_kernel_name(None, 200, 5, True) == "walk_sets_kernel<SPG>"
+    assert walk_kernel_name(None, 200, 2, False) == "walk_pipe_kernel"
+    assert walk_kernel_name(None, 300, 2, False) == "walk_sets_kernel"
