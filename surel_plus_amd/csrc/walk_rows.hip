@@ -261,8 +261,9 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
                             } else {
                                 rec[k] = a.recs[b[k] + (int64_t)off];
                             }
-                        } else if (RNG == SUBGACC_RNG_RAND_R) {
-                            atomicOr(&a.flags[0], 1);
+                        } else {        // dead end: the walk stays on this node
+                            if (SG_LAST_HOP_ID && s + 2 == MH) rec[k] = (unsigned long long)(uint32_t)cur[k];   // (bare-id form)
+                            if (RNG == SUBGACC_RNG_RAND_R) atomicOr(&a.flags[0], 1);
                         }
                     }
                 } else if (s + 1 < MH) {

@@ -1188,6 +1188,33 @@ def test_hop_records_give_the_same_rows(sp, rng, M, m, bits):
     assert np.array_equal(zb.data.cpu().numpy(), od) and np.array_equal(ib.enc_int16().cpu().numpy(), oenc)
 
 
+@pytest.mark.parametrize("M,m,wide", [(200, 3, False), (200, 2, True), (64, 4, False), (256, 3, False)])
+def test_hop_records_on_a_graph_with_dead_ends(sp, M, m, wide):
+    """a directed graph: walks reach nodes without out-edges and stay there -- also when the hop that would have fetched
+    the last node's bare id finds nothing to fetch (a regression: the stale record was read as an id); Philox only
+    (rand_r refuses dead ends by design)"""
+    import scipy.sparse as sps
+    rng0 = np.random.default_rng(11)
+    N = 3000
+    r, c = rng0.integers(0, N, 9000), rng0.integers(0, N // 2, 9000)      # the upper half of the ids has no out-edges ... mostly
+    A = sps.csr_matrix((np.ones(len(r)), (r, c)), shape=(N, N))
+    A.sum_duplicates(); A.setdiag(0); A.eliminate_zeros(); A.sort_indices()
+    ptr_ = A.indptr.astype(np.int64 if wide else np.int32)
+    idx = A.indices.astype(np.int32)
+    assert int((np.diff(A.indptr) == 0).sum()) > 100
+    q = rng0.permutation(N)[:1500]
+    from surel_plus_amd.sampler import DeviceCSR
+    csr = DeviceCSR(ptr_, idx)
+    assert csr.hop_records(force=True) is not None
+    (oi, ox, od), oenc = _oracle_spg(A.indptr.astype(np.int32), idx, q, M, m, 19, "philox", -1)
+    z, info = sp.sample_spg(csr, q, num_walks=M, num_steps=m, seed=19, rng="philox", fused=True)
+    assert np.array_equal(z.indptr.cpu().numpy(), oi) and np.array_equal(z.indices.cpu().numpy(), ox)
+    assert np.array_equal(z.data.cpu().numpy(), od) and np.array_equal(info.enc_int16().cpu().numpy(), oenc)
+    zk, sk = sp.sample_spg(csr, q, num_walks=M, num_steps=m, seed=19, rng="philox", strided=True, number_rows=False)
+    zc = zk.to_csr()
+    assert np.array_equal(zc.indptr.cpu().numpy(), oi) and np.array_equal(zc.indices.cpu().numpy(), ox)
+
+
 # ------------------------------------------------------------------------------- batch_sampler (legacy SUREL mini-batches)
 @pytest.mark.parametrize("name", golden_files("batch_"))
 def test_batch_sampler_matches_reference_golden(sp, name):
