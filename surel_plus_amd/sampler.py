@@ -39,7 +39,8 @@ HOP_RECORDS_MIN_DEG_BITS = 12
 # members' 32-bit LP keys instead of slots of a table of distinct rows; the join unpacks a key into its feature row itself.
 # No table, no registration, no unpack pass: -14 % walk-kernel time on the cit2-like batch, -23 % on collab.  Asking such a
 # batch for its numbering afterwards (number(), c, enc_int16(), to_csr()) samples it again with the table form.
-KEY_ROWS = os.environ.get("SUBGACC_KEY_ROWS", "1") == "1"
+KEY_ROWS = os.environ.get("SUBGACC_KEY_ROWS", "1") == "1" and os.environ.get("SUBGACC_WALK_ROWS", "1") != "0"   # (the dev switch
+#                                                    that disables the specialised kernel takes its key-rows form with it)
 
 
 def key_rows_ok(num_walks, num_steps):
