@@ -34,7 +34,7 @@ for c in range(cases):
     A.sum_duplicates(); A.setdiag(0); A.eliminate_zeros(); A.sort_indices()
     wide = bool(rng0.integers(0, 4) == 0)              # int64 row offsets (the twitter-scale form)
     ptr_, idx = A.indptr.astype(np.int64 if wide else np.int32), A.indices.astype(np.int32)
-    M = int(rng0.choice([1, 3, 16, 64, 200, 256, 300]))
+    M = int(rng0.choice([1, 3, 16, 64, 100, 128, 150, 200, 255, 256, 300]))
     m = int(rng0.choice([1, 2, 3, 4, 5]))
     if (32 - (M.bit_length() and (32 - M.bit_length()))) and m * M.bit_length() + 1 > 63:
         m = 2
