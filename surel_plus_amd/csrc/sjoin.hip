@@ -155,7 +155,8 @@ __device__ __forceinline__ float key_feature(uint32_t key, int c, int m, int shi
 template <bool F64, int KV, typename Val, bool KEYS = false>
 __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int32_t *own_ids, const Val *own_val,
                                           int64_t na, const int32_t *pids, const Val *pval, int nb, int64_t t0,
-                                          int64_t o, int64_t segj, int k, int k2, uint32_t magic, const float *lut = nullptr) {
+                                          int64_t o, int64_t segj, int k, int k2, uint32_t magic, const float *lut = nullptr,
+                                          float *stage = nullptr) {
     const int64_t t = t0 + lane;
     const bool live = t < na;
     int32_t id = 0;
@@ -228,6 +229,24 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
                     }
 #endif
                 }
+            } else if (KEYS) {
+                // any other width: every lane unpacks its own row (no shuffles, no per-element index arithmetic) into the
+                // wave's LDS staging area, and the span leaves as consecutive 8-byte words (k2 = 2k floats per row)
+                if (live) {
+                    float *mine = stage + lane * k2;
+                    for (int c = 0; c < k; ++c) {
+                        mine[c] = key_feature((uint32_t)pa, c, a.key_m, a.key_shift, lut);
+                        mine[k + c] = key_feature((uint32_t)pb, c, a.key_m, a.key_shift, lut);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                float2 *dst2 = reinterpret_cast<float2 *>(a.out_xz + row0 * k2);
+                const float2 *src2 = reinterpret_cast<const float2 *>(stage);
+                for (int f = lane; f < nrows * k; f += kWave) stream_store(dst2 + f, src2[f]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the next span of this wave re-uses the area
+                __builtin_amdgcn_wave_barrier();
             } else {
                 float *dst = a.out_xz + row0 * k2;
                 const int total = nrows * k2;
@@ -235,12 +254,8 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
                     const int r = (int)(((uint32_t)f * magic) >> 20);
                     const int c = f - r * k2;
                     const int spa = __shfl(pa, r, kWave), spb = __shfl(pb, r, kWave);
-                    if (KEYS) {
-                        const float v = key_feature((uint32_t)(c < k ? spa : spb), c < k ? c : c - k, a.key_m, a.key_shift, lut);
-                        if (f < total) __builtin_nontemporal_store(v, dst + f);
-                    } else if (f < total) {
+                    if (f < total)
                         __builtin_nontemporal_store(a.table[(int64_t)(c < k ? spa : spb) * k + (c < k ? c : c - k)], dst + f);
-                    }
                 }
             }
         }
@@ -306,6 +321,7 @@ __global__ __launch_bounds__(kPairEmit) void sjoin_pair_kernel(const JoinArgs a,
     int32_t *idsA = (int32_t *)(valB + a.max_len);    // [max_len]
     int32_t *idsB = idsA + a.max_len;                 // [max_len]
     float *lut = (float *)(idsB + a.max_len);         // KEYS: [key_M + 1] count -> count / num_walks (IEEE division, main.py:174)
+    float *stage = lut + ((a.key_M + 2) & ~1) + (threadIdx.x / kWave) * kWave * 2 * a.k;   // KEYS: [64 rows][2k] per wave (8-byte aligned)
     if (KEYS)
         for (int c = threadIdx.x; c <= a.key_M; c += kPairEmit) lut[c] = (float)c / (float)a.key_M;
 
@@ -366,10 +382,10 @@ __global__ __launch_bounds__(kPairEmit) void sjoin_pair_kernel(const JoinArgs a,
     const int chunksA = (na + kWave - 1) / kWave, chunksB = (nb + kWave - 1) / kWave;
     for (int c = wave; c < chunksA + chunksB; c += kPairEmit / kWave) {   // every wave takes whole 64-row spans
         if (c < chunksA)
-            emit_rows<F64, KV, Val, KEYS>(a, lane, idsA, valA, na, idsB, valB, nb, (int64_t)c * kWave, oA, j, k, k2, magic, lut);
+            emit_rows<F64, KV, Val, KEYS>(a, lane, idsA, valA, na, idsB, valB, nb, (int64_t)c * kWave, oA, j, k, k2, magic, lut, stage);
         else
             emit_rows<F64, KV, Val, KEYS>(a, lane, idsB, valB, nb, idsA, valA, na, (int64_t)(c - chunksA) * kWave, oB, j2, k, k2,
-                                          magic, lut);
+                                          magic, lut, stage);
     }
 }
 
@@ -783,7 +799,8 @@ extern "C" int subgacc_sjoin_fill_keyrows(const int32_t *row_len, int64_t n_rows
     a.flags = flags;
     a.row_len = row_len, a.row_stride = row_stride, a.slot_id = nullptr, a.val_add = 0;
     a.key_M = num_walks, a.key_m = num_steps, a.key_shift = shift;
-    const size_t lds = (size_t)a.max_len * 16 + (size_t)(num_walks + 1) * 4;
+    const size_t lds = (size_t)a.max_len * 16 + (size_t)(num_walks + 2) * 4 +
+                       (a.k == 4 ? 0 : (size_t)(kPairEmit / kWave) * kWave * 2 * a.k * 4);   // staging: only the generic width uses it
     SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "sjoin_fill_keyrows: rows of %lld members do not fit LDS",
                (long long)row_stride);
     const int64_t grid = xcd_grid(S / 2);

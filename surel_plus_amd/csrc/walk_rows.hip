@@ -29,6 +29,7 @@ namespace subgacc {
 // LDS traffic, where six __shfl steps cost six ds_bpermute round trips each).  Every lane is active at the call sites.
 extern "C" __device__ __attribute__((const)) int __ockl_wfred_min_i32(int);
 extern "C" __device__ __attribute__((const)) int __ockl_wfred_max_i32(int);
+extern "C" __device__ __attribute__((const)) unsigned __ockl_wfred_min_u32(unsigned);
 extern "C" __device__ __attribute__((const)) int __ockl_wfred_add_i32(int);
 extern "C" __device__ __attribute__((const)) int __ockl_wfscan_add_i32(int, bool);
 
@@ -304,11 +305,13 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
 
     if (KR) {
         // ================= key rows: the set leaves sorted by node id with its members' LP keys =================
+        // A set fills a fifth to a third of the table: the members are first packed (any order -- the sort below fixes it),
+        // so that every later phase runs over ceil(ns / NT) elements per lane instead of SPL mostly empty slots.
         int32_t idv[SPL];
         uint32_t kv[SPL];
-        bool ok[SPL];
-        int mycount = 0;
-        int32_t vmin = 0x7FFFFFFF, vmax = 0;
+        int cnt = 0;
+        uint32_t umn = ~0u;         // an empty slot is -1: the largest unsigned value, the smallest signed one
+        int32_t vmax = -1;
 #pragma unroll
         for (int c = 0; c < SPL / 4; ++c) {
             const int g = c * NT + tid;
@@ -319,21 +322,21 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
         }
 #pragma unroll
         for (int u = 0; u < SPL; ++u) {
-            ok[u] = idv[u] != -1;
-            kv[u] |= (idv[u] == root ? (uint32_t)lead : 0u);        // the root's own row carries the lead bit
-            mycount += ok[u] ? 1 : 0;
-            vmin = min(vmin, ok[u] ? idv[u] : 0x7FFFFFFF);
-            vmax = max(vmax, ok[u] ? idv[u] : 0);
+            cnt += idv[u] != -1 ? 1 : 0;
+            umn = min(umn, (uint32_t)idv[u]);
+            vmax = max(vmax, idv[u]);
         }
-        vmin = __ockl_wfred_min_i32(vmin);
+        const int incl = __ockl_wfscan_add_i32(cnt, true);
+        umn = __ockl_wfred_min_u32(umn);
         vmax = __ockl_wfred_max_i32(vmax);
-        mycount = __ockl_wfred_add_i32(mycount);
-        if ((tid & (kWave - 1)) == 0) {
-            red[tid / kWave] = vmin;
+        int wbase = 0;
+        if ((tid & (kWave - 1)) == kWave - 1) {
+            wbase = atomicAdd(&red[8], incl);
+            red[tid / kWave] = (int32_t)min(umn, 0x7FFFFFFFu);
             red[4 + tid / kWave] = vmax;
-            atomicAdd(&red[8], mycount);
         }
-        __syncthreads();   // every lane holds its members in registers: the walk tables are free to be re-used
+        wbase = __builtin_amdgcn_readlane(wbase, kWave - 1);
+        __syncthreads();   // every lane holds its slots in registers: the walk tables are free to be re-used
         const int32_t ns = red[8];
         if (tid == 0) a.nsize[i] = ns;
         const int32_t mn = min(min(red[0], red[1]), min(red[2], red[3]));
@@ -347,13 +350,28 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
         const int Ls = (range <= 1u) ? 0 : (32 - __builtin_clz(range - 1u));
         const int bshift = Ls > logb ? Ls - logb : 0;
         if (tid < B) start[tid] = 0;
+        {
+            int p = wbase + incl - cnt;
+#pragma unroll
+            for (int u = 0; u < SPL; ++u)
+                if (idv[u] != -1) {
+                    A[p] = ((unsigned long long)(uint32_t)idv[u] << 32) | (kv[u] | (idv[u] == root ? (uint32_t)lead : 0u));
+                    ++p;
+                }
+        }
         __syncthreads();
+        unsigned long long el[SPL];
         uint32_t bk[SPL];
         int32_t pos[SPL];                           // arrival order inside the bucket, then the final position
 #pragma unroll
-        for (int u = 0; u < SPL; ++u) {
-            bk[u] = (uint32_t)(idv[u] - mn) >> bshift;
-            pos[u] = ok[u] ? atomicAdd(&start[bk[u]], 1) : 0;
+        for (int e = 0; e < SPL; ++e) {
+            if (e * NT >= ns) break;
+            const int x = e * NT + tid;
+            if (x < ns) {
+                el[e] = A[x];
+                bk[e] = ((uint32_t)(el[e] >> 32) - (uint32_t)mn) >> bshift;
+                pos[e] = atomicAdd(&start[bk[e]], 1);
+            }
         }
         __syncthreads();
         {
@@ -370,28 +388,33 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
         __syncthreads();
         int blo[SPL], bhi[SPL];
 #pragma unroll
-        for (int u = 0; u < SPL; ++u) {
-            blo[u] = ok[u] ? start[bk[u]] : 0;
-            bhi[u] = ok[u] ? start[bk[u] + 1] : 0;
+        for (int e = 0; e < SPL; ++e) {
+            if (e * NT >= ns) break;
+            if (e * NT + tid < ns) {
+                blo[e] = start[bk[e]];
+                bhi[e] = start[bk[e] + 1];
+                A[blo[e] + pos[e]] = el[e];         // every packed element was read before the last two barriers
+            }
         }
-#pragma unroll
-        for (int u = 0; u < SPL; ++u)
-            if (ok[u]) A[blo[u] + pos[u]] = ((unsigned long long)(uint32_t)idv[u] << 32) | kv[u];
         __syncthreads();
         const uint32_t *Ahi = (const uint32_t *)A;
 #pragma unroll
-        for (int u = 0; u < SPL; ++u)
-            if (ok[u]) {
-                const int lo = blo[u], hi = bhi[u];
+        for (int e = 0; e < SPL; ++e) {
+            if (e * NT >= ns) break;
+            if (e * NT + tid < ns) {
+                const uint32_t me = (uint32_t)(el[e] >> 32);
                 int rank = 0;       // ids are distinct within a set: the high word of A decides
 #pragma unroll 1
-                for (int t2 = lo; t2 < hi; ++t2) rank += (Ahi[2 * t2 + 1] < (uint32_t)idv[u]) ? 1 : 0;
-                pos[u] = lo + rank;
+                for (int t2 = blo[e]; t2 < bhi[e]; ++t2) rank += (Ahi[2 * t2 + 1] < me) ? 1 : 0;
+                pos[e] = blo[e] + rank;
             }
+        }
         __syncthreads();        // every rank is known: the bucket-grouped array can become the sorted one, in place
 #pragma unroll
-        for (int u = 0; u < SPL; ++u)
-            if (ok[u]) A[pos[u]] = ((unsigned long long)(uint32_t)idv[u] << 32) | kv[u];
+        for (int e = 0; e < SPL; ++e) {
+            if (e * NT >= ns) break;
+            if (e * NT + tid < ns) A[pos[e]] = el[e];
+        }
         __syncthreads();
         for (int x = tid; x < ns; x += NT) {
             const unsigned long long v = A[x];
