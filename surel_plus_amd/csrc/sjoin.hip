@@ -8,6 +8,7 @@
 // row, finds it in the partner row by binary search in LDS (sorted-set intersection), and writes the
 // feature pair straight from the Z_SF table (L2-resident, a few KB..MB) -- the [R,2] index array of the
 // reference never exists in memory unless asked for.
+#include <cstdlib>
 #include "common.hpp"
 #include "blockscan.hpp"
 #ifndef SJ_EXPERIMENT
@@ -102,7 +103,19 @@ struct JoinArgs {
     int32_t key_M, key_m, key_shift;
     const int32_t *slot_id;   // slot -> SFptr (id plane of the numbered table of distinct LP rows); NULL with
     int32_t val_add;          // val_add = 1: the feature table is indexed by slot + 1 itself (row 0 = absent)
+    int32_t split = 1;        // sjoin_pair_kernel: workgroups per pair (small batches: every one stages both rows and emits
+                              // its share of the 64-row spans, so that a batch of ~1,000 pairs still fills the chip)
 };
+
+// Workgroups per pair of sjoin_pair_kernel: batches far below the chip's ~4,096 resident workgroups are split in two
+// (B = 1,024 pairs: 22 -> 18 us; four or eight parts pay more for the repeated row loads than they gain: 21 / 25 us)
+static inline int pair_split(int64_t pairs) {
+    static const int forced = [] { const char *e = getenv("SUBGACC_JOIN_SPLIT"); return e ? atoi(e) : 0; }();   // dev switch
+    if (forced > 0) return forced;
+    int sp = 1;
+    while (sp < 2 && pairs * sp * 2 <= 4096) sp *= 2;
+    return sp;
+}
 
 // The join's outputs are written once and read by a later kernel, its SpG rows are read once per pair: non-temporal
 // (streaming) accesses keep them from displacing each other in L2 -- measured -12 % on the cit2 batch (0.57 -> 0.50 ms).
@@ -325,7 +338,9 @@ __global__ __launch_bounds__(kPairEmit) void sjoin_pair_kernel(const JoinArgs a,
     if (KEYS)
         for (int c = threadIdx.x; c <= a.key_M; c += kPairEmit) lut[c] = (float)c / (float)a.key_M;
 
-    const int64_t p = xcd_item(blockIdx.x, gridDim.x);
+    const int64_t wg = xcd_item(blockIdx.x, gridDim.x);
+    const int64_t p = wg / a.split;
+    const int part = (int)(wg % a.split);
     if (p >= a.S / 2) return;
     const int64_t j = (p / pb) * 2 * pb + (p % pb), j2 = j + pb;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
@@ -380,7 +395,7 @@ __global__ __launch_bounds__(kPairEmit) void sjoin_pair_kernel(const JoinArgs a,
     const int k = a.k, k2 = 2 * k;
     const uint32_t magic = k2 > 0 ? ((1u << 20) + (uint32_t)k2 - 1u) / (uint32_t)k2 : 0u;
     const int chunksA = (na + kWave - 1) / kWave, chunksB = (nb + kWave - 1) / kWave;
-    for (int c = wave; c < chunksA + chunksB; c += kPairEmit / kWave) {   // every wave takes whole 64-row spans
+    for (int c = wave + part * (kPairEmit / kWave); c < chunksA + chunksB; c += a.split * (kPairEmit / kWave)) {   // every wave takes whole 64-row spans
         if (c < chunksA)
             emit_rows<F64, KV, Val, KEYS>(a, lane, idsA, valA, na, idsB, valB, nb, (int64_t)c * kWave, oA, j, k, k2, magic, lut, stage);
         else
@@ -688,7 +703,8 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, int64_t n_rows, con
     const bool staged = lds <= (size_t)kLdsBytes;   // else: rows longer than LDS, searched in place (sjoin_fill_kernel<.., false>)
     if (!staged) lds = 0;
     SG_REQUIRE(k <= 16, SUBGACC_ERR_BADARG, "sjoin_fill: feature width k = %d > 16 is not supported", k);
-    const int64_t grid = xcd_grid(paired ? S / 2 : S);
+    if (paired) a.split = pair_split(S / 2);
+    const int64_t grid = xcd_grid(paired ? S / 2 * a.split : S);
     SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_fill: too many segments in one call");
     hipStream_t s = (hipStream_t)stream;
     const bool vec4 = !f64 && out_xz && k == 4 && ((uintptr_t)table % 16 == 0) && ((uintptr_t)out_xz % 16 == 0);
@@ -758,7 +774,8 @@ extern "C" int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t n_rows, i
     const size_t lds = (size_t)a.max_len * 16;
     SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "sjoin_fill_rows: rows of %lld members do not fit LDS",
                (long long)row_stride);
-    const int64_t grid = xcd_grid(S / 2);
+    a.split = pair_split(S / 2);
+    const int64_t grid = xcd_grid(S / 2 * a.split);
     SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_fill_rows: too many segments in one call");
     hipStream_t s = (hipStream_t)stream;
     const bool vec4 = out_xz && k == 4 && ((uintptr_t)table % 16 == 0) && ((uintptr_t)out_xz % 16 == 0);
@@ -803,7 +820,8 @@ extern "C" int subgacc_sjoin_fill_keyrows(const int32_t *row_len, int64_t n_rows
                        (a.k == 4 ? 0 : (size_t)(kPairEmit / kWave) * kWave * 2 * a.k * 4);   // staging: only the generic width uses it
     SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "sjoin_fill_keyrows: rows of %lld members do not fit LDS",
                (long long)row_stride);
-    const int64_t grid = xcd_grid(S / 2);
+    a.split = pair_split(S / 2);
+    const int64_t grid = xcd_grid(S / 2 * a.split);
     SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_fill_keyrows: too many segments in one call");
     hipStream_t s = (hipStream_t)stream;
     const bool vec4 = a.k == 4 && ((uintptr_t)out_xz % 16 == 0);
