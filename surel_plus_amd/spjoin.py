@@ -123,6 +123,9 @@ def _sjoin_strided(spg, own, partner, seg, ws, encode, ptr_mode, return_index, p
     if return_index:
         if lazy:
             raise ValueError("lazy=True needs the encode table")
+        if getattr(spg, "keyrows", False):
+            raise ValueError("a key-rows batch has no row numbers to return: join z.to_csr() (gather_index does)")
+        spg.sets.number()               # the pairs are SFptr+1: a transient batch is numbered only now
         res = torch.empty((R, 2), dtype=torch.int32, device=dev)
         check(L.subgacc_sjoin_fill_rows(ptr(spg.nsize), spg.n_rows, spg.stride, ptr(spg.indices), ptr(spg.slot), ptr(spg.table),
                                         spg.capacity, ptr(own), ptr(partner), S, ptr(seg), None, 0, 0, None, ptr(res),
@@ -508,4 +511,47 @@ def attn_stage(edge, x, encode, embed, gate_nn, value_nn=None):
     den = torch.zeros(S, device=g.device, dtype=g.dtype).index_add_(0, seg, w)
     num = torch.zeros((S, v.shape[-1]), device=g.device, dtype=v.dtype).index_add_(0, seg, w[:, None] * v)
     out = num / (den + 1e-16)[:, None]                              # torch_geometric.utils.softmax adds the same 1e-16
+    return out.view(2, -1, out.shape[-1])
+
+
+def gather_index(edge, x, device=None):
+    """Index form of gather() (the variant that writes 8 instead of 8k bytes per row): (pairs int32 [R, 2],
+    indptr int64 [2B+1]) with pairs[r] = (SFptr+1 of the member in its own row, in the partner row or 0) -- the row gather()
+    would have emitted is encode[pairs[r]], in gather()'s row order (members sorted by node id inside a segment)."""
+    spg = _as_spg(x)
+    if isinstance(spg, StridedSpG):     # index pairs need the numbering of the distinct LP rows (transient batches skip it)
+        if spg.keyrows:
+            spg = spg.to_csr()
+        else:
+            spg.sets.number()
+    e = _as_rows(edge, spg.device)
+    own = torch.cat([e[0], e[1]])
+    partner = torch.cat([e[1], e[0]])
+    return _checked(*sjoin(spg, own, partner, None, ptr_mode=True, return_index=True, pair_block=e.shape[1]))
+
+
+def lstm_stage(edge, x, encode, embed, lstm):
+    """The reference's first model stage for --aggr lstm, over the index form of the join:  model.py:63-65,78-83
+        x = pe_embedding(xz).sum(dim=-2);  xl, xr = LSTMAggregation(H, H)(x, index=ptr).view(2, -1, H)
+    LSTMAggregation packs the rows of every segment, in row order, into a dense [S, L, H] batch padded with zero rows
+    (L = the longest segment), runs `lstm` (batch_first) over it and returns the output at the LAST position L-1 -- the
+    padding is part of its arithmetic, so it is reproduced.  A row's x is e[pa] + e[pb] with e = embed(encode) ([c+1, H]):
+    the stage reads 8 bytes per row instead of xz's 8k and never evaluates the MLP on [R, 2, k].
+    Returns float32 [2, B, H'] (left endpoints, right endpoints)."""
+    table = encode if torch.is_tensor(encode) else torch.as_tensor(encode)
+    spg = _as_spg(x)
+    table = table.to(device=spg.device, dtype=torch.float32)
+    pairs, indptr = gather_index(edge, spg)
+    if pairs.numel() and int(pairs.max().item()) >= table.shape[0]:
+        raise IndexError(f"index {int(pairs.max().item())} is out of bounds for the encode table with {table.shape[0]} rows")
+    S = indptr.numel() - 1
+    lens = indptr[1:] - indptr[:-1]
+    L = int(lens.max().item()) if S else 0
+    e = embed(table)
+    rows = e[pairs[:, 0].long()] + e[pairs[:, 1].long()]
+    seg = torch.repeat_interleave(torch.arange(S, device=spg.device), lens, output_size=pairs.shape[0])
+    posn = torch.arange(pairs.shape[0], device=spg.device) - indptr[:-1][seg]
+    dense = rows.new_zeros((S, max(L, 1), rows.shape[-1]))
+    dense[seg, posn] = rows
+    out = lstm(dense)[0][:, -1]
     return out.view(2, -1, out.shape[-1])

@@ -1000,6 +1000,70 @@ def test_attn_stage_trains_like_the_reference_first_stage(sp):
         assert err_fused <= max(4 * err_ref32, 1e-4), (n, err_fused, err_ref32)
 
 
+def _reference_style_lstm(xz, ptr, embed, lstm):
+    """model.py:78-83 with LSTMAggregation as torch_geometric 2.x defines it: to_dense_batch (zero padding to the longest
+    segment) -> lstm -> the output at the last position"""
+    x = embed(xz).sum(dim=-2)
+    S = ptr.numel() - 1
+    lens = ptr[1:] - ptr[:-1]
+    dense = x.new_zeros((S, int(lens.max()), x.shape[-1]))
+    for j in range(S):
+        dense[j, : int(lens[j])] = x[int(ptr[j]): int(ptr[j + 1])]
+    return lstm(dense)[0][:, -1]
+
+
+def test_gather_index_and_lstm_stage_match_the_reference_first_stage(sp):
+    """Index form of the join == the index pairs behind gather()'s rows (bit-exact), from the packed, the strided and the
+    key-rows form of the batch; lstm_stage == pe_embedding(xz).sum(-2) + LSTM aggregation on the full xz (model.py:63-65,
+    78-83).  Tolerances: forward within 2e-5 of the largest entry of the float64 evaluation, parameter gradients within 5e-4
+    of their largest entry (the same bounds as the attention stage; an LSTM over <= 200 positions is well conditioned)."""
+    ptr_, idx = sym_graph(2000, 9000, seed=8, hubs=1)
+    csr = sp.DeviceCSR(ptr_, idx)
+    z, sets = sp.sample_spg(csr, np.arange(2000), num_walks=32, num_steps=3, seed=5, rng="philox")
+    table = sets.feature_table()
+    edge = torch.from_numpy(np.random.default_rng(9).integers(0, 2000, (2, 96))).cuda()
+    edge[:, 5] = edge[0, 5]                                            # a (u, u) pair
+    pairs, ind = sp.gather_index(edge, z)
+    xz, ind2 = sp.gather(edge, z, "cuda", ptr=True, encode=table)
+    assert pairs.dtype == torch.int32 and torch.equal(ind, ind2)
+    assert torch.equal(table[pairs.long()], xz)
+    o_xz, o_ind = oracle.gather(edge.cpu().numpy(), tuple(t.cpu().numpy() for t in (z.indptr, z.indices, z.data)), ptr=True,
+                                encode=None)
+    # ... and against the oracle's index form (train.py:25-33 before the table lookup)
+    assert np.array_equal(pairs.cpu().numpy(), o_xz.astype(np.int32).reshape(-1, 2)) and np.array_equal(ind.cpu().numpy(), o_ind)
+
+    # the transient forms of a batch (strided table rows, key rows) give the index pairs of their packed store
+    from surel_plus_amd.graphs import query_pairs
+    e = query_pairs(csr, 200, seed=3)
+    rows = torch.arange(400, device="cuda").view(2, 200)
+    for kr in (False, True):
+        _, bind, bsets = sp.sample_and_gather(csr, e, num_walks=32, num_steps=3, seed=5, rng="philox", key_rows=kr)
+        zs = sp.StridedSpG(bsets, csr.num_nodes)
+        bp, bi = sp.gather_index(rows, zs)
+        cp, ci = sp.gather_index(rows, zs.to_csr())
+        assert torch.equal(bp, cp) and torch.equal(bi, ci) and torch.equal(bi, bind)
+
+    def nets(dtype):
+        torch.manual_seed(11)
+        return [torch.nn.Sequential(torch.nn.Linear(4, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16)).cuda().to(dtype),
+                torch.nn.LSTM(16, 16, batch_first=True).cuda().to(dtype)]
+    fa, fb, f64 = nets(torch.float32), nets(torch.float32), nets(torch.float64)
+    torch.manual_seed(2)
+    w = torch.randn(2, 96, 16, device="cuda")
+    fused = sp.lstm_stage(edge, z, table, *fa)
+    (fused * w).sum().backward()
+    ref32 = _reference_style_lstm(xz, ind, *fb).view(2, -1, 16)
+    (ref32 * w).sum().backward()
+    truth = _reference_style_lstm(xz.double(), ind, *f64).view(2, -1, 16)
+    (truth * w.double()).sum().backward()
+    scale = float(truth.detach().abs().max())
+    assert float((fused.detach().double() - truth.detach()).abs().max()) <= 2e-5 * scale
+    for (n, pa), (_, pc) in zip([(n, p) for mod in fa for n, p in mod.named_parameters()],
+                                [(n, p) for mod in f64 for n, p in mod.named_parameters()]):
+        gs = float(pc.grad.abs().max())
+        assert float((pa.grad.double() - pc.grad).abs().max()) <= 5e-4 * max(gs, 1e-6), n
+
+
 @pytest.mark.parametrize("B,hops,rng", [(1024, 3, "philox"), (1024, 2, "philox"), (300, 3, "rand_r")])
 def test_captured_step_replays_equal_the_eager_step(sp, B, hops, rng):
     """sample -> SpG rows -> join as ONE HIP graph (stepgraph.CapturedStep, the reference's batch size of 1,024 pairs,
