@@ -622,6 +622,12 @@ int launch_walk_rows(const WalkArgs &a, bool indptr64, int rng_mode, size_t lds,
     const bool rr = rng_mode == SUBGACC_RNG_RAND_R;
     // 512-slot tables: 128 lanes x 2 walks (SUBGACC_ROWS_NT=256 forces one walk per lane; dev-only)
     static const bool nt256 = getenv("SUBGACC_ROWS_NT") && atoi(getenv("SUBGACC_ROWS_NT")) == 256;
+    // key rows, 512-slot table, 2 hops, int32 row offsets: ONE wave per root (64 lanes x 4 walks x 8 slots, 55 VGPRs) -- no
+    // barrier is a real one, the per-wave prologue and the scans are paid once: collab walk 0.296 -> 0.262 ms; neutral with
+    // int64 offsets (twitter), and 13 % slower for the 1,024-slot table (16 slots per lane: 95 VGPRs), so only here.
+    // SUBGACC_ROWS_NT=128 keeps two waves, =64 takes one wave with int64 offsets too (dev-only).
+    static const bool nt64 = getenv("SUBGACC_ROWS_NT") && atoi(getenv("SUBGACC_ROWS_NT")) == 64;
+    static const bool nt128 = getenv("SUBGACC_ROWS_NT") && atoi(getenv("SUBGACC_ROWS_NT")) == 128;
     const bool half = a.T == 512 && !nt256;
     const bool rec = a.recs != nullptr && indptr64 == (a.rec.id_bits == 0);   // hop records: one dependent read per hop
     if (a.keyrows) {      // rows that carry the LP key itself: 32-bit counts, 128 lanes, 2 or 3 hops -- or not at all
@@ -635,12 +641,21 @@ int launch_walk_rows(const WalkArgs &a, bool indptr64, int rng_mode, size_t lds,
             hipLaunchKernelGGL((walk_rows_kernel<I64, RNGM, MHH, SPLL, 128, 0, true, true>), dim3((unsigned)grid), dim3(128), ldsk, s, a); \
         return 1;                                                                                                    \
     } while (0)
+#define SG_KR64(I64, RNGM, MHH, SPLL)                                                                                \
+    do {                                                                                                             \
+        if (rec)                                                                                                     \
+            hipLaunchKernelGGL((walk_rows_kernel<I64, RNGM, MHH, SPLL, 64, I64 ? 16 : 8, true, true>), dim3((unsigned)grid), dim3(64), ldsk, s, a); \
+        else                                                                                                         \
+            hipLaunchKernelGGL((walk_rows_kernel<I64, RNGM, MHH, SPLL, 64, 0, true, true>), dim3((unsigned)grid), dim3(64), ldsk, s, a); \
+        return 1;                                                                                                    \
+    } while (0)
 #define SG_KR_MH(I64, RNGM)                                  \
     do {                                                     \
         if (a.T == 1024) {                                   \
             if (a.m == 2) SG_KR(I64, RNGM, 2, 8);            \
             SG_KR(I64, RNGM, 3, 8);                          \
         }                                                    \
+        if ((nt64 || (!I64 && !nt128)) && a.m == 2) SG_KR64(I64, RNGM, 2, 8); \
         if (a.m == 2) SG_KR(I64, RNGM, 2, 4);                \
         SG_KR(I64, RNGM, 3, 4);                              \
     } while (0)
@@ -651,6 +666,7 @@ int launch_walk_rows(const WalkArgs &a, bool indptr64, int rng_mode, size_t lds,
         if (rr) SG_KR_MH(false, SUBGACC_RNG_RAND_R);
         SG_KR_MH(false, SUBGACC_RNG_PHILOX);
 #undef SG_KR_MH
+#undef SG_KR64
 #undef SG_KR
     }
     // 1,024-slot table with counts that fit 32 bits: 128 lanes x 8 slots, 12 bytes of LDS per slot -> 11 roots per CU
