@@ -31,7 +31,7 @@ SYMBOLS = (
     "subgacc_walk_join", "subgacc_sjoin_sizes_rows", "subgacc_sjoin_fill_rows",
     "subgacc_encode_sizes", "subgacc_encode_fill", "subgacc_sjoin_pairs", "subgacc_finish_rows",
     "subgacc_batch_sampler_workspace_bytes", "subgacc_batch_sampler", "subgacc_step_prologue",
-    "subgacc_hop_records_format", "subgacc_hop_records_build", "subgacc_sjoin_fill_keyrows",
+    "subgacc_hop_records_format", "subgacc_hop_records_build", "subgacc_sjoin_fill_keyrows", "subgacc_sjoin_fill_keys",
 )
 
 
@@ -110,6 +110,7 @@ def lib():
     sig["subgacc_hop_records_format"] = (C.c_int, [i64, i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)])
     sig["subgacc_hop_records_build"] = (C.c_int, [vp, i32, vp, i64, i64, i32, i32, vp, vp])
     sig["subgacc_sjoin_fill_keyrows"] = (C.c_int, [vp, i64, i64, vp, vp, vp, vp, i64, vp, i32, i32, vp, i64, vp, vp])
+    sig["subgacc_sjoin_fill_keys"] = (C.c_int, [vp, i64, vp, vp, vp, vp, i64, vp, i32, i32, vp, i32, i64, vp, vp])
     sig["subgacc_step_prologue"] = (C.c_int, [vp, i64, vp, i64, vp, vp, i64, vp])
     sig["subgacc_batch_sampler_workspace_bytes"] = (sz, [i64])
     sig["subgacc_batch_sampler"] = (C.c_int, [vp, i32, vp, i64, vp, i64, i32, i32, i32, C.c_uint32, vp, i64, vp, vp, sz, vp, vp])

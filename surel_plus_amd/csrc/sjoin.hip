@@ -792,39 +792,25 @@ extern "C" int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t n_rows, i
     return SUBGACC_OK;
 }
 
-extern "C" int subgacc_sjoin_fill_keyrows(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
-                                          const int32_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
-                                          const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz,
-                                          int64_t pair_block, int32_t *flags, void *stream) {
-    SG_REQUIRE(S >= 0 && flags && n_rows >= 0 && row_stride > 0 && row_stride < (1ll << 31), SUBGACC_ERR_BADARG,
-               "sjoin_fill_keyrows: bad arguments");
+// key payload (strided rows of a transient batch, or a packed store whose payload was re-keyed): shared launcher
+static int launch_key_join(JoinArgs &a, int32_t num_walks, int32_t num_steps, int64_t S, int64_t pair_block, void *stream,
+                           const char *who) {
     const int shift = subgacc_key_shift(num_walks, num_steps);
     if (shift < 0) return shift;
     SG_REQUIRE(num_steps * shift + 1 <= 31 && num_steps + 1 <= 16, SUBGACC_ERR_KEYWIDTH,
-               "sjoin_fill_keyrows: LP keys of %d steps x %d bits do not fit 32 bits", num_steps, shift);
-    if (S == 0) return SUBGACC_OK;
-    SG_REQUIRE(row_len && row_ids && row_keys && own && partner && seg && out_xz, SUBGACC_ERR_BADARG,
-               "sjoin_fill_keyrows: null argument");
-    SG_REQUIRE(pair_block > 0 && S % (2 * pair_block) == 0, SUBGACC_ERR_BADARG,
-               "sjoin_fill_keyrows: the segment list must be mirrored blocks (pair_block > 0, S a multiple of 2*pair_block)");
-    JoinArgs a;
-    a.indptr = nullptr, a.indices = row_ids, a.data = row_keys;
-    a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
+               "%s: LP keys of %d steps x %d bits do not fit 32 bits", who, num_steps, shift);
     a.table = nullptr, a.table_rows = 0, a.k = num_steps + 1;
-    a.out_xz = out_xz, a.out_idx = nullptr, a.out_segid = nullptr;
-    a.max_len = (int32_t)row_stride;
-    a.flags = flags;
-    a.row_len = row_len, a.row_stride = row_stride, a.slot_id = nullptr, a.val_add = 0;
+    a.out_idx = nullptr, a.out_segid = nullptr;
+    a.slot_id = nullptr, a.val_add = 0;
     a.key_M = num_walks, a.key_m = num_steps, a.key_shift = shift;
     const size_t lds = (size_t)a.max_len * 16 + (size_t)(num_walks + 2) * 4 +
                        (a.k == 4 ? 0 : (size_t)(kPairEmit / kWave) * kWave * 2 * a.k * 4);   // staging: only the generic width uses it
-    SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "sjoin_fill_keyrows: rows of %lld members do not fit LDS",
-               (long long)row_stride);
+    SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "%s: rows of %d members do not fit LDS", who, (int)a.max_len);
     a.split = pair_split(S / 2);
     const int64_t grid = xcd_grid(S / 2 * a.split);
-    SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_fill_keyrows: too many segments in one call");
+    SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "%s: too many segments in one call", who);
     hipStream_t s = (hipStream_t)stream;
-    const bool vec4 = a.k == 4 && ((uintptr_t)out_xz % 16 == 0);
+    const bool vec4 = a.k == 4 && ((uintptr_t)a.out_xz % 16 == 0);
     if (vec4) {
         if (lds > 64 * 1024)
             SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -836,6 +822,47 @@ extern "C" int subgacc_sjoin_fill_keyrows(const int32_t *row_len, int64_t n_rows
     }
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
+}
+
+extern "C" int subgacc_sjoin_fill_keyrows(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
+                                          const int32_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
+                                          const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz,
+                                          int64_t pair_block, int32_t *flags, void *stream) {
+    SG_REQUIRE(S >= 0 && flags && n_rows >= 0 && row_stride > 0 && row_stride < (1ll << 31), SUBGACC_ERR_BADARG,
+               "sjoin_fill_keyrows: bad arguments");
+    if (S == 0) return subgacc_key_shift(num_walks, num_steps) < 0 ? subgacc_key_shift(num_walks, num_steps) : SUBGACC_OK;
+    SG_REQUIRE(row_len && row_ids && row_keys && own && partner && seg && out_xz, SUBGACC_ERR_BADARG,
+               "sjoin_fill_keyrows: null argument");
+    SG_REQUIRE(pair_block > 0 && S % (2 * pair_block) == 0, SUBGACC_ERR_BADARG,
+               "sjoin_fill_keyrows: the segment list must be mirrored blocks (pair_block > 0, S a multiple of 2*pair_block)");
+    JoinArgs a;
+    a.indptr = nullptr, a.indices = row_ids, a.data = row_keys;
+    a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
+    a.out_xz = out_xz;
+    a.max_len = (int32_t)row_stride;
+    a.flags = flags;
+    a.row_len = row_len, a.row_stride = row_stride;
+    return launch_key_join(a, num_walks, num_steps, S, pair_block, stream, "sjoin_fill_keyrows");
+}
+
+extern "C" int subgacc_sjoin_fill_keys(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,
+                                       const int32_t *spg_keys, const int64_t *own, const int64_t *partner, int64_t S,
+                                       const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz, int32_t max_len,
+                                       int64_t pair_block, int32_t *flags, void *stream) {
+    SG_REQUIRE(S >= 0 && flags && n_rows >= 0 && max_len >= 0, SUBGACC_ERR_BADARG, "sjoin_fill_keys: bad arguments");
+    if (S == 0) return subgacc_key_shift(num_walks, num_steps) < 0 ? subgacc_key_shift(num_walks, num_steps) : SUBGACC_OK;
+    SG_REQUIRE(spg_indptr && spg_indices && spg_keys && own && partner && seg && out_xz, SUBGACC_ERR_BADARG,
+               "sjoin_fill_keys: null argument");
+    SG_REQUIRE(pair_block > 0 && S % (2 * pair_block) == 0, SUBGACC_ERR_BADARG,
+               "sjoin_fill_keys: the segment list must be mirrored blocks (pair_block > 0, S a multiple of 2*pair_block)");
+    JoinArgs a;
+    a.indptr = spg_indptr, a.indices = spg_indices, a.data = spg_keys;
+    a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
+    a.out_xz = out_xz;
+    a.max_len = max_len > 0 ? max_len : 1;
+    a.flags = flags;
+    a.row_len = nullptr, a.row_stride = 0;
+    return launch_key_join(a, num_walks, num_steps, S, pair_block, stream, "sjoin_fill_keys");
 }
 
 extern "C" int subgacc_sjoin_counts(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,

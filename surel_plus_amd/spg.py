@@ -94,6 +94,44 @@ class SpG:
         enc = blob.get("encode")
         return z, (enc.to(device) if enc is not None else None)
 
+    keyrows = False       # keyed(): the payload is the member's LP key, joined by subgacc_sjoin_fill_keys
+
+    def keyed(self, enc, num_walks):
+        """The same store with every member's 32-bit LP KEY as payload instead of SFptr+1 (shares indptr / indices): the join
+        then unpacks a feature row from the key (counts / num_walks, the IEEE division of main.py:174) instead of gathering
+        16 bytes per output slot from the Z_SF table -- bit-identical `xz`, ~1.4x the join rate on the cit2-like store.  For
+        the reference's flow: `z, enc = subg_matrix(...)` once, `zk = z.keyed(enc, num_walks)` once, then per batch
+        `gather(edge, zk, encode=zk.slot_table())`.
+        enc: the LP rows as subg_matrix returns them -- integer counts [c+1, k], zero row in front, row p belongs to SFptr+1 = p,
+        column 0 = num_walks on a root's own row (subg_acc.c:900-955).  Needs (k-1) * bits(num_walks) + 1 <= 31."""
+        if self.data.dtype != torch.int32:
+            raise TypeError("keyed() re-keys an SFptr (integer) SpG")
+        tab = torch.as_tensor(enc).to(device=self.device, dtype=torch.int64)
+        if tab.ndim != 2 or tab.shape[1] < 2 or tab.shape[0] <= self.max_data:
+            raise IndexError(f"the LP table must be [c+1, k] with more than {self.max_data} rows")
+        m = tab.shape[1] - 1
+        shift = check(lib().subgacc_key_shift(int(num_walks), m))
+        if m * shift + 1 > 31:
+            raise AssertionError(f"LP keys of {m} steps x {shift} bits do not fit 32 bits")
+        if int(tab[:, 1:].max().item()) >= (1 << shift) or int(tab.min().item()) < 0:
+            raise ValueError("LP counts outside [0, 2^SHIFT): not the table of this num_walks")
+        key = (tab[:, 0] != 0).to(torch.int64) << (m * shift)
+        for j in range(1, m + 1):
+            key |= tab[:, j] << ((m - j) * shift)
+        keytab = key.to(torch.int32)
+        nnz = self.nnz
+        keys = torch.empty_like(self.data)
+        keys[:nnz] = torch.index_select(keytab, 0, self.data[:nnz])
+        z = SpG(self.indptr, self.indices, keys, max_len=self.max_len, shape=self.shape, max_data=0)
+        z.keyrows, z.key_M, z.key_m = True, int(num_walks), m
+        return z
+
+    def slot_table(self):
+        """what gather(..., encode=) takes for a keyed() store: the marker that the join unpacks the keys itself"""
+        if not self.keyrows:
+            raise ValueError("slot_table() belongs to a keyed() store; a plain SpG is joined with its Z_SF table")
+        return KEY_ROWS_ENCODE
+
     def to_scipy(self):
         import scipy.sparse as sp
         nnz = self.nnz

@@ -67,6 +67,28 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
     check(L.subgacc_sjoin_sizes(ptr(spg.indptr), spg.n_rows, ptr(own), ptr(partner), S, ptr(seg), ptr(flags), ptr(ws),
                                 ws.numel(), st))
     is_f64 = spg.data.dtype == torch.float64
+    if getattr(spg, "keyrows", False):       # SpG.keyed(): the payload is the LP key, the join unpacks it (no table)
+        from .spg import KEY_ROWS_ENCODE
+        if encode is not KEY_ROWS_ENCODE or return_index or not ptr_mode or pair_block <= 0:
+            raise ValueError("a keyed() store is joined by gather(edge, zk, encode=zk.slot_table(), ptr=True)")
+        k = spg.key_m + 1
+        R = None if lazy else _size_and_row_check(seg, S, flags, spg.n_rows)
+        if lazy:
+            if out is None or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev or \
+                    out.numel() < S * spg.max_len * 2 * k:
+                raise ValueError("lazy out= must hold S * SpG.max_len * 2 * k float32 on the SpG's device")
+            rows = out.numel() // (2 * k)
+            res = out.view(-1)[: rows * 2 * k].view(rows, 2, k)
+        elif out is not None:
+            if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() < R * 2 * k or out.device != dev:
+                raise ValueError("out= must be a contiguous float32 buffer on the SpG's device with >= R*2*k elements")
+            res = out.view(-1)[: R * 2 * k].view(R, 2, k)
+        else:
+            res = torch.empty((R, 2, k), dtype=torch.float32, device=dev)
+        with _timed("sjoin_fill"):
+            check(L.subgacc_sjoin_fill_keys(ptr(spg.indptr), spg.n_rows, ptr(spg.indices), ptr(spg.data), ptr(own), ptr(partner), S,
+                                            ptr(seg), spg.key_M, spg.key_m, ptr(res), spg.max_len, pair_block, ptr(flags), st))
+        return res, seg, flags
     if lazy and (out is None or not ptr_mode or return_index or is_f64 or encode is None):
         raise ValueError("lazy=True needs out=, ptr=True and an integer SpG with its encode table")
     R = None if lazy else _size_and_row_check(seg, S, flags, spg.n_rows)     # the one host round trip
@@ -408,8 +430,8 @@ def gather_counts(edge, x, table_rows, device=None):
     embedding f:  segment_sum_j(f(xz).sum(-2)) == C[j] @ f(Z_SF), so `x = f(xz).sum(-2); aggr(x, ptr)` of the
     reference's Net.forward becomes `(C @ f(Z_SF)) / sizes[:, None]` and the [R,2,k] tensor never exists."""
     spg = _as_spg(x)
-    if spg.data.dtype != torch.int32:
-        raise TypeError("gather_counts needs an SFptr (integer) SpG")
+    if spg.data.dtype != torch.int32 or getattr(spg, "keyrows", False):
+        raise TypeError("gather_counts needs an SFptr (integer) SpG (not a keyed() one)")
     if table_rows <= spg.max_data:
         raise IndexError(f"index {spg.max_data} is out of bounds for a table with {table_rows} rows")
     e = _as_rows(edge, spg.device)
@@ -455,8 +477,8 @@ def gather_pairs(edge, x, device=None):
     spg = _as_spg(x)
     if isinstance(spg, StridedSpG):
         spg = spg.to_csr()
-    if spg.data.dtype != torch.int32:
-        raise TypeError("gather_pairs needs an SFptr (integer) SpG")
+    if spg.data.dtype != torch.int32 or getattr(spg, "keyrows", False):
+        raise TypeError("gather_pairs needs an SFptr (integer) SpG (not a keyed() one)")
     L, dev, st = lib(), spg.device, stream_ptr()
     e = _as_rows(edge, dev)
     B = e.shape[1]

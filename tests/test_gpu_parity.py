@@ -1000,6 +1000,38 @@ def test_attn_stage_trains_like_the_reference_first_stage(sp):
         assert err_fused <= max(4 * err_ref32, 1e-4), (n, err_fused, err_ref32)
 
 
+@pytest.mark.parametrize("M,hops", [(200, 3), (200, 2), (64, 3), (100, 4), (255, 4)])
+def test_keyed_store_joins_like_the_table_join(sp, M, hops):
+    """SpG.keyed(): the resident store re-keyed once (payload = LP key instead of SFptr+1, subgacc_sjoin_fill_keys) gives bit for
+    bit the (xz, indptr) of the reference-style join with Z_SF = float32(enc) / M (main.py:174) -- and of the oracle"""
+    ptr_, idx = sym_graph(4000, 30000, seed=17, hubs=2)
+    csr = sp.DeviceCSR(ptr_, idx)
+    z, sets = sp.sample_spg(csr, np.arange(4000), num_walks=M, num_steps=hops, seed=3, rng="philox")
+    table = sets.feature_table()
+    enc = oracle.enc_table(sets.enc_int16().cpu().numpy())              # [c+1, k] counts, zero row in front
+    if hops * M.bit_length() + 1 > 31:                                  # the key does not fit 32 bits: refused, as the C ABI does
+        with pytest.raises(AssertionError):
+            z.keyed(enc, M)
+        return
+    zk = z.keyed(enc, M)
+    assert zk.keyrows and zk.indices.data_ptr() == z.indices.data_ptr()
+    edge = torch.from_numpy(np.random.default_rng(5).integers(0, 4000, (2, 3000))).cuda()
+    edge[:, 7] = edge[0, 7]
+    xz, ind = sp.gather(edge, z, "cuda", ptr=True, encode=table)
+    kxz, kind = sp.gather(edge, zk, "cuda", ptr=True, encode=zk.slot_table())
+    assert torch.equal(ind, kind) and torch.equal(xz, kxz)
+    oxz, oind = oracle.gather(edge.cpu().numpy(), tuple(t.cpu().numpy() for t in (z.indptr, z.indices, z.data)), ptr=True,
+                              encode=enc.astype(np.float32) / np.float32(M))
+    assert np.array_equal(kxz.cpu().numpy(), oxz) and np.array_equal(kind.cpu().numpy(), oind)
+    buf = torch.empty(int(xz.numel()) + 64, dtype=torch.float32, device="cuda")
+    bxz, _ = sp.gather(edge, zk, "cuda", ptr=True, encode=zk.slot_table(), out=buf)
+    assert torch.equal(bxz, xz) and bxz.data_ptr() == buf.data_ptr()
+    for bad in (lambda: sp.gather(edge, zk, "cuda", ptr=True, encode=table), lambda: sp.gather(edge, zk, "cuda", ptr=False, encode=zk.slot_table()),
+                lambda: sp.gather_counts(edge, zk, table.shape[0]), lambda: sp.gather_pairs(edge, zk)):
+        with pytest.raises((ValueError, TypeError)):
+            bad()
+
+
 def _reference_style_lstm(xz, ptr, embed, lstm):
     """model.py:78-83 with LSTMAggregation as torch_geometric 2.x defines it: to_dense_batch (zero padding to the longest
     segment) -> lstm -> the output at the last position"""

@@ -37,6 +37,17 @@ t_join, _ = sync_time(lambda: [sp.gather(e, z, "cuda", ptr=True, encode=tab, out
 J = 20 * 65536 / t_join
 print(f"  join from the resident SpG: {J / 1e6:.1f} M pairs/s; amortised (sample all N once + 1e8 pairs): "
       f"{1e8 / (t_dev + 1e8 / J) / 1e6:.1f} M pairs/s")
+# ... and from the same store re-keyed once (SpG.keyed: the payload is the LP key, no Z_SF gather per output row)
+zk = None
+for _ in range(3):
+    del zk              # steady-state allocator, as for the sampler above
+    t_key, zk = sync_time(lambda: z.keyed(enc, M))
+for e in edges[:2]:
+    sp.gather(e, zk, "cuda", ptr=True, encode=zk.slot_table(), out=buf, lazy=True)
+t_kjoin, _ = sync_time(lambda: [sp.gather(e, zk, "cuda", ptr=True, encode=zk.slot_table(), out=buf, lazy=True) for e in edges[2:]])
+JK = 20 * 65536 / t_kjoin
+print(f"  join from the keyed store:  {JK / 1e6:.1f} M pairs/s (re-keying once: {t_key * 1e3:.1f} ms); amortised: "
+      f"{1e8 / (t_dev + t_key + 1e8 / JK) / 1e6:.1f} M pairs/s")
 print(f"{name}: N={N} nnz={csr.nnz} M={M} --num_steps {k}: set members {z.nnz}, distinct LP rows {enc.shape[0] - 1}")
 print(f"  subg_matrix, graph resident (philox):        {t_dev:8.3f} s  = {N / t_dev / 1e6:7.2f} M roots/s")
 print(f"  subg_matrix, numpy CSR in (rand_r, exact):   {t_host_in:8.3f} s")
