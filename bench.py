@@ -117,6 +117,7 @@ class KernelTimer:
 _XZ_BUF = {}
 _STEP_BUFS = {}
 BUFFERED = os.environ.get("SUBGACC_STEP_BUFFERS", "1") == "1"     # 0: the general (allocating) form of the step, for A/B
+DEDUP = os.environ.get("SUBGACC_DEDUP_ROOTS", "0") == "1"        # 1: every distinct endpoint of a batch sampled once (Philox)
 
 
 def hot_path_step(sp, csr, edge, M, k, seed, rng, slot=0):
@@ -136,11 +137,11 @@ def hot_path_step(sp, csr, edge, M, k, seed, rng, slot=0):
     # hands it preallocated StepBuffers (two sets in turn, like the output buffers): six launches per step, no allocation
     bufs = None
     if LAZY and BUFFERED and rng == "philox" and strided is not False and FUSED is not False:
-        key = (edge.device, B, M, k, slot)
+        key = (edge.device, B, M, k, slot, DEDUP)
         bufs = _STEP_BUFS.get(key)
         if bufs is None:
             try:
-                bufs = _STEP_BUFS[key] = sp.StepBuffers(csr, B, M, k - 1, uniq_capacity=UNIQ_CAPACITY, out=buf)
+                bufs = _STEP_BUFS[key] = sp.StepBuffers(csr, B, M, k - 1, uniq_capacity=UNIQ_CAPACITY, out=buf, dedup_roots=DEDUP)
             except ValueError:
                 bufs = _STEP_BUFS[key] = False
     xz, ind, sets = sp.sample_and_gather(csr, edge, num_walks=M, num_steps=k - 1, seed=seed, rng=rng, out=buf if LAZY else None,
@@ -289,7 +290,7 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
              small_batches=False, two_stream_extra=True):
     """sample + SpJoin over one LP workload: W warm-up steps, K timed steps bracketed by barrier + synchronize, max over
     ranks.  Returns the JSON object (rank 0) or None."""
-    global STRIDED
+    global STRIDED, DEDUP
     from surel_plus_amd.graphs import preset_graph, query_pairs
     preset, M, k, desc, pos_frac = WORKLOADS[name]
     csr = preset_graph(preset, device=dev, scale=args.scale)
@@ -393,6 +394,25 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
         dt = time.perf_counter() - t1
         two_streams = {"pairs_per_s": B * K / dt, "ms_per_step": dt / max(K, 1) * 1e3, "steps": K}
         STREAMS, last = None, keep_last
+    # ... and, outside the clock as well: the same steps with every DISTINCT endpoint of a batch sampled once (Philox keys a walk by
+    # its root's id, so (xz, indptr) are the same -- tested); what a serving loop may do, not what the timed region does
+    dedup_loop = None
+    if rank == 0 and world == 1 and last is not None and two_stream_extra and BUFFERED and not DEDUP and rng == "philox":
+        keep_last, DEDUP = last, True
+        timer.enabled = False
+        try:
+            run_steps(range(4))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_steps(range(W, W + K))
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            nd = getattr(last[1], "n_distinct", None)
+            dedup_loop = {"pairs_per_s": B * K / dt, "ms_per_step": dt / max(K, 1) * 1e3, "steps": K,
+                          "distinct_roots_last_step": nd, "endpoints_last_step": 2 * B}
+        except ValueError as ex:
+            dedup_loop = {"skipped": str(ex)}
+        DEDUP, last = False, keep_last
     sampler_mod.KERNEL_TIMER = None
     if rank != 0:
         return None
@@ -427,7 +447,7 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
                    "J_pairs_per_s": (B / (1e-3 * join_ms)) if join_ms else None,
                    "fused_spg_rows": fused_rows, "spg_layout": "strided rows joined in place (no CSR copy of the batch)" if sets.strided else "csr",
                    "ms_per_step_with_a_packed_csr_spg_per_batch": csr_ms,
-                   "two_stream_loop": two_streams,
+                   "two_stream_loop": two_streams, "dedup_roots_loop": dedup_loop,
                    "device_allocs_in_timed_region": allocs_timed,
                    "host_step_ms_min_median_max": [round(1e3 * v, 3) for v in
                                                    (min(host_steps), sorted(host_steps)[len(host_steps) // 2], max(host_steps))]
@@ -514,7 +534,7 @@ def summary(o):
     """what an `other_workloads` entry keeps of a full line"""
     keep = {k_: o[k_] for k_ in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype")}
     keep["config"] = {k_: o["config"].get(k_) for k_ in ("workload", "pairs_per_step_per_gpu", "rng", "set_members_last_step",
-                                                         "distinct_lp_rows_last_step", "xz_rows_last_step", "graph_nnz", "spg_layout", "stage_ms", "two_stream_loop", "spg_members",
+                                                         "distinct_lp_rows_last_step", "xz_rows_last_step", "graph_nnz", "spg_layout", "stage_ms", "two_stream_loop", "dedup_roots_loop", "spg_members",
                                                          "offline_ppr_stage_s") if k_ in o["config"]}
     keep["roofline"] = o["roofline"]
     if "cpu_baseline" in o:

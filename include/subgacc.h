@@ -368,6 +368,28 @@ int subgacc_sjoin_fill_keys(const int64_t *spg_indptr, int64_t n_rows, const int
 int subgacc_step_prologue(void *uniq_table, int64_t capacity, int64_t *zero_words, int64_t n_zero, const int64_t *edge,
                           int32_t *roots, int64_t n, void *stream);   /* uniq_table may be NULL (key rows: no table) */
 
+/* The same prologue for a step that samples every DISTINCT endpoint once.  Philox keys a walk by (seed, root id, walk, hop), so a
+ * root's set does not depend on where or how often the root stands in the batch (the reference samples every node once, offline,
+ * main.py:172-178; its sequential rand_r stream has no such property, so this form is Philox only).  Two launches:
+ *   roots       int32 [n]: the distinct endpoints in rows 0 .. *n_distinct - 1 (row order = order of arrival: not reproducible,
+ *               the join's output is)
+ *   own, partner int64 [n]: gather()'s mirrored segment lists over those rows -- own[j] = row of endpoint j, partner[j] = row of
+ *               the other end of its pair (j +- n/2); what subgacc_sjoin_sizes_rows / _fill_rows / _fill_keyrows take
+ *   n_distinct  int64 [1] (device): the number of rows, for subgacc_walk_spg_n
+ *   generation  any value != 0 that differs from the previous call's on this workspace (slots are stamped, never cleared)
+ *   workspace   subgacc_step_dedup_workspace_bytes(n) bytes, ZEROED once by the caller before its first use
+ * ------------------------------------------------------------------------------------------- */
+size_t subgacc_step_dedup_workspace_bytes(int64_t n);
+int subgacc_step_prologue_dedup(void *uniq_table, int64_t capacity, int64_t *zero_words, int64_t n_zero, const int64_t *edge,
+                                int32_t *roots, int64_t *own, int64_t *partner, int64_t n, uint32_t generation, void *workspace,
+                                size_t workspace_bytes, int64_t *n_distinct, void *stream);
+/* subgacc_walk_spg for a root count that lives on the device (<= n_max; blocks past it leave at once).  Philox mode,
+ * set_sampler order, shapes the fused-row kernel serves (2..4 hops, M <= 256, M*m+1 <= 818, no bucket): SUBGACC_ERR_BADARG
+ * otherwise.  Row i belongs to query[i]; tags of the table of distinct rows start at 0. */
+int subgacc_walk_spg_n(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,
+                       const int32_t *query, int64_t n_max, const int64_t *n_dev, void *uniq_table, int64_t uniq_capacity,
+                       int32_t *row_ids, int32_t *row_slot, int32_t *nsize, int32_t *flags, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * batch_sampler of the legacy SUREL surface (subg_acc/subg_acc.c:391-507): one insertion-ordered set of nodes grown by
  * walking the roots one after the other (num_walks walks of num_steps nodes each, first hop without replacement,

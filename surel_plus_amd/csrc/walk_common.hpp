@@ -102,6 +102,7 @@ struct WalkArgs {
     const int32_t *indices;
     const int32_t *query;
     int64_t n;
+    const int64_t *n_dev;   // optional: the number of roots lives on the device (<= n: a step's DISTINCT endpoints, subgacc_step_prologue_dedup)
     int64_t num_nodes;   // a root outside [0, num_nodes) is never looked up: empty set, flags[3] |= 16 (the host raises)
     const uint32_t *rng_pos, *rng_seed;
     int32_t *set_ids;

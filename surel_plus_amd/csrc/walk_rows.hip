@@ -79,8 +79,18 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     int32_t *fs = (int32_t *)(ft + kSpgFold);                     // [kSpgFold] HBM table slot of the key
     int32_t *red = KR ? (int32_t *)fk : fs + kSpgFold;            // [16] (KR: no fold table either)
 
-    const int64_t i = xcd_item(blockIdx.x, gridDim.x);
-    if (i >= a.n) return;
+    int64_t i;
+    if (a.n_dev) {   // the root count is a device value: the first xcd_grid(count) blocks share the roots among the XCDs as usual
+        int64_t ne = *a.n_dev;
+        if (ne > a.n) ne = a.n;
+        const int64_t ge = (ne + kXcds - 1) / kXcds * kXcds;
+        if ((int64_t)blockIdx.x >= ge) return;
+        i = xcd_item(blockIdx.x, ge);
+        if (i >= ne) return;
+    } else {
+        i = xcd_item(blockIdx.x, gridDim.x);
+        if (i >= a.n) return;
+    }
     const int tid = threadIdx.x;
     const int M = a.M;
     const int32_t root = a.query[i];

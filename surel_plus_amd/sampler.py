@@ -174,6 +174,8 @@ class SampledSets:
     _pending: tuple = None       # prefetch(): (pinned host copy of status, event, device source)
     extra: list = None           # values of prefetch(extra=...) once resolved
     _tail: torch.Tensor = None   # StepBuffers form: int64 [5] = [rows of the join (= members), status words x4], contiguous
+    #                              ([6] with root dedup: + the number of distinct roots = rows that were sampled)
+    n_distinct: int = None       # StepBuffers(dedup_roots=True): rows 0 .. n_distinct-1 hold the batch's distinct endpoints
     keyrows: bool = False        # strided rows whose payload (`slot`) is the member's 32-bit LP key: no table, no numbering
     _resample: object = None     # keyrows: callable -> the same batch sampled with the table form (number() and friends)
 
@@ -212,6 +214,8 @@ class SampledSets:
             st = (self._tail if self._tail is not None else self.status).tolist()
         if self._tail is not None:      # [rows, w0, w1, w2, w3]: every row of the join is a member of an own set
             self.extra = st[:1]
+            if len(st) > 5:             # root dedup: the sets of the distinct endpoints are fewer than the join's rows
+                self.n_distinct = int(st[5])
             st = unpack_status(st[1:4] + st[:1])
         else:
             self.extra = st[self.status.numel():]
@@ -227,7 +231,7 @@ class SampledSets:
                 raise _lib.SubgAccError(f"{c} distinct LP rows exceed the direct-ranking limit: sample with lazy=False")
             self.ukeys = self.ukeys[:c]
         if self.strided:
-            self._members = X
+            self._members = X if self.n_distinct is None else int(self.nsize[: self.n_distinct].sum().item())
             return self
         self.ids = self.ids[:X]
         for name in ("slot", "keys", "data", "sf"):

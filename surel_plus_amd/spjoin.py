@@ -290,9 +290,12 @@ class StepBuffers:
     count) and the output buffer.  With it a step is SIX launches -- prologue (table reset + status + root narrowing),
     walk, segment reduce, segment scan, LP unpack, join -- and no allocation; without it torch's allocator and a dozen
     few-microsecond helper kernels sit between them (1,024 pairs: ~100 us of which the walk and the join are 55).
-    Reuse is the caller's business: a buffer set is busy until its step has been resolved (bench.py alternates two)."""
+    Reuse is the caller's business: a buffer set is busy until its step has been resolved (bench.py alternates two).
+    dedup_roots=True: every DISTINCT endpoint of the batch is sampled once (subgacc_step_prologue_dedup: a generation-stamped
+    hash of the endpoints, one more small launch; the walk kernel takes its root count from the device) -- Philox keys a walk
+    by its root's id, so (xz, indptr) do not change; the rows of the sets are then in order of arrival (sets.n_distinct of them)."""
 
-    def __init__(self, csr, pairs, num_walks=200, num_steps=3, uniq_capacity=1 << 17, out=None):
+    def __init__(self, csr, pairs, num_walks=200, num_steps=3, uniq_capacity=1 << 17, out=None, dedup_roots=False):
         from .sampler import FUSED_MAX_Q
         L, dev = lib(), csr.device
         self.B, self.M, self.m = int(pairs), int(num_walks), int(num_steps)
@@ -307,8 +310,17 @@ class StepBuffers:
         from .sampler import KEY_ROWS, key_rows_ok
         self.keyrows = bool(KEY_ROWS and key_rows_ok(self.M, self.m))    # rows of LP keys: no table, no feature table
         self.table = None if self.keyrows else torch.empty(L.subgacc_uniq_table_bytes(self.capacity), dtype=torch.uint8, device=dev)
-        self.tail = torch.zeros(n + 1 + 4, dtype=torch.int64, device=dev)      # seg [n+1] | status [4]
-        self.seg, self.status = self.tail[: n + 1], self.tail[n + 1:]
+        self.tail = torch.zeros(n + 1 + 4 + 1, dtype=torch.int64, device=dev)  # seg [n+1] | status [4] | distinct roots [1]
+        self.seg, self.status, self.n_distinct = self.tail[: n + 1], self.tail[n + 1: n + 5], self.tail[n + 5:]
+        self.dedup = bool(dedup_roots)
+        if self.dedup:
+            from .sampler import walk_kernel_name
+            if walk_kernel_name(csr, self.M, self.m, True) != "walk_rows_kernel":
+                raise ValueError("StepBuffers(dedup_roots=True) needs a shape the fused-row walk kernel serves (2..4 hops, M <= 256)")
+            self.own = torch.empty(n, dtype=torch.int64, device=dev)
+            self.partner = torch.empty(n, dtype=torch.int64, device=dev)
+            self.dedup_ws = torch.zeros(L.subgacc_step_dedup_workspace_bytes(n), dtype=torch.uint8, device=dev)
+            self.generation = 0
         self.ws = torch.empty(max(L.subgacc_sjoin_workspace_bytes(n), 8), dtype=torch.uint8, device=dev)
         self.feat = None if self.keyrows else torch.empty((self.capacity + 1, self.k), dtype=torch.float32, device=dev)
         need = n * self.stride * 2 * self.k
@@ -330,12 +342,23 @@ def _buffered_step(csr, e, bufs, seed, out):
     cfg = make_cfg(csr, M, m, -1, seed, "philox")
     check(L.subgacc_key_shift(cfg.num_walks, cfg.num_steps))
     kr = bufs.keyrows
-    check(L.subgacc_step_prologue(ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.status), 4, ptr(e), ptr(bufs.roots), n, st))
-    with _timed("walk_sets"):
-        check(L.subgacc_walk_spg(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n, 0, None, None,
-                                 ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize),
-                                 ptr(flags), st))
-    own, partner = _arange_segments(B, dev)
+    if bufs.dedup:      # distinct endpoints only: rows in order of arrival, the segment lists point at them
+        bufs.generation = bufs.generation % 0xFFFFFFF0 + 1
+        check(L.subgacc_step_prologue_dedup(ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.status), 4, ptr(e), ptr(bufs.roots),
+                                            ptr(bufs.own), ptr(bufs.partner), n, bufs.generation, ptr(bufs.dedup_ws),
+                                            bufs.dedup_ws.numel(), ptr(bufs.n_distinct), st))
+        with _timed("walk_sets"):
+            check(L.subgacc_walk_spg_n(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n, ptr(bufs.n_distinct),
+                                       ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize),
+                                       ptr(flags), st))
+        own, partner = bufs.own, bufs.partner
+    else:
+        check(L.subgacc_step_prologue(ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.status), 4, ptr(e), ptr(bufs.roots), n, st))
+        with _timed("walk_sets"):
+            check(L.subgacc_walk_spg(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n, 0, None, None,
+                                     ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize),
+                                     ptr(flags), st))
+        own, partner = _arange_segments(B, dev)
     check(L.subgacc_sjoin_sizes_rows(ptr(bufs.nsize), n, ptr(own), ptr(partner), n, ptr(bufs.seg), ptr(flags), ptr(bufs.ws),
                                      bufs.ws.numel(), st))
     if not kr:
@@ -359,9 +382,10 @@ def _buffered_step(csr, e, bufs, seed, out):
     if kr:
         from .sampler import sample_sets
         sets.keyrows = True
-        sets._resample = lambda: sample_sets(csr, bufs.roots, M, m, -1, seed, "philox", fused_rows=True, strided=True,
-                                             number_rows=True, key_rows=False, uniq_capacity=bufs.capacity)
-    sets.status, sets._tail = bufs.status, bufs.tail[n: n + 5]
+        sets._resample = lambda: sample_sets(csr, bufs.roots if sets.n_distinct is None else bufs.roots[: sets.n_distinct], M, m, -1,
+                                             seed, "philox", fused_rows=True, strided=True, number_rows=True, key_rows=False,
+                                             uniq_capacity=bufs.capacity)
+    sets.status, sets._tail = bufs.status, bufs.tail[n: n + (6 if bufs.dedup else 5)]
     return xz, bufs.seg, sets
 
 
@@ -381,10 +405,11 @@ def sample_and_gather(csr, edge, num_walks=200, num_steps=3, seed=111413, rng="p
     e = _as_rows(edge, csr.device)
     B = e.shape[1]
     if buffers is not None:     # the allocation-free form of a serving loop: same rows, same (xz, indptr), lazily resolved
-        if dedup_roots or rng != "philox" or strided is False or kw.get("fused") is False or kw.get("bucket", -1) > 0 or \
-                (num_walks, num_steps) != (buffers.M, buffers.m) or kw.get("uniq_capacity", buffers.capacity) != buffers.capacity:
-            raise ValueError("buffers= serves the plain on-demand step (rng='philox', fused strided rows, no root dedup) "
-                             "of the shape the StepBuffers were made for")
+        if (dedup_roots and not buffers.dedup) or rng != "philox" or strided is False or kw.get("fused") is False or \
+                kw.get("bucket", -1) > 0 or (num_walks, num_steps) != (buffers.M, buffers.m) or \
+                kw.get("uniq_capacity", buffers.capacity) != buffers.capacity:
+            raise ValueError("buffers= serves the on-demand step (rng='philox', fused strided rows; root dedup if the StepBuffers "
+                             "were made with dedup_roots=True) of the shape the StepBuffers were made for")
         return _buffered_step(csr, e, buffers, seed, out)
     if dedup_roots:
         if rng != "philox":

@@ -1000,6 +1000,37 @@ def test_attn_stage_trains_like_the_reference_first_stage(sp):
         assert err_fused <= max(4 * err_ref32, 1e-4), (n, err_fused, err_ref32)
 
 
+@pytest.mark.parametrize("B,M,hops,idx64", [(2048, 200, 3, False), (700, 200, 2, False), (512, 100, 3, True), (300, 64, 4, False)])
+def test_step_with_root_dedup_equals_the_plain_step(sp, B, M, hops, idx64):
+    """StepBuffers(dedup_roots=True): every distinct endpoint sampled once (subgacc_step_prologue_dedup + subgacc_walk_spg_n) --
+    bit for bit the (xz, indptr) of the step that samples every endpoint, batch after batch through the same buffers (the
+    generation-stamped hash is never cleared), for batches full of repeated endpoints; the distinct count is exact"""
+    ptr_, idx = sym_graph(3000, 40000, seed=23, hubs=3)
+    csr = sp.DeviceCSR(ptr_.astype(np.int64) if idx64 else ptr_, idx)
+    plain = sp.StepBuffers(csr, B, num_walks=M, num_steps=hops)
+    dd = sp.StepBuffers(csr, B, num_walks=M, num_steps=hops, dedup_roots=True)
+    rng = np.random.default_rng(3)
+    for s in range(4):
+        hi = (40, 3000, 300, 3000)[s]                       # 40 distinct nodes: nearly every endpoint repeats
+        e = torch.from_numpy(rng.integers(0, hi, (2, B))).cuda()
+        e[:, 3] = e[0, 3]                                   # a (u, u) pair
+        xz, ind, sets = sp.sample_and_gather(csr, e, num_walks=M, num_steps=hops, seed=9, rng="philox", buffers=plain)
+        sets.resolve()
+        R = int(ind[-1].item())
+        dxz, dind, dsets = sp.sample_and_gather(csr, e, num_walks=M, num_steps=hops, seed=9, rng="philox", buffers=dd,
+                                                dedup_roots=True)
+        dsets.prefetch().resolve()
+        assert torch.equal(ind, dind) and torch.equal(xz[:R], dxz[:R])
+        uniq = torch.unique(e)
+        assert dsets.n_distinct == uniq.numel()
+        assert torch.equal(torch.sort(dd.roots[: dsets.n_distinct].long()).values, uniq)
+        assert dsets.X == int(dd.nsize[: dsets.n_distinct].sum().item()) and dsets.X <= sets.X
+        if s == 0 and dsets.keyrows:                         # what key rows do not carry is sampled again from the distinct roots
+            assert dsets.number().ukeys.numel() == sets.number().ukeys.numel()
+    with pytest.raises(ValueError):
+        sp.sample_and_gather(csr, e, num_walks=M, num_steps=hops, seed=9, rng="philox", buffers=plain, dedup_roots=True)
+
+
 @pytest.mark.parametrize("M,hops", [(200, 3), (200, 2), (64, 3), (100, 4), (255, 4)])
 def test_keyed_store_joins_like_the_table_join(sp, M, hops):
     """SpG.keyed(): the resident store re-keyed once (payload = LP key instead of SFptr+1, subgacc_sjoin_fill_keys) gives bit for
