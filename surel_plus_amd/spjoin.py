@@ -343,6 +343,8 @@ def _buffered_step(csr, e, bufs, seed, out):
     check(L.subgacc_key_shift(cfg.num_walks, cfg.num_steps))
     kr = bufs.keyrows
     if bufs.dedup:      # distinct endpoints only: rows in order of arrival, the segment lists point at them
+        if torch.cuda.is_current_stream_capturing():
+            raise ValueError("root dedup stamps its hash with a per-step generation: not for a captured (replayed) step")
         bufs.generation = bufs.generation % 0xFFFFFFF0 + 1
         check(L.subgacc_step_prologue_dedup(ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.status), 4, ptr(e), ptr(bufs.roots),
                                             ptr(bufs.own), ptr(bufs.partner), n, bufs.generation, ptr(bufs.dedup_ws),
