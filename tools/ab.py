@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Dev-only A/B driver for ONE GPU box: variants = environment settings and / or compile-time flags of the walk kernels.
 
-    python tools/ab.py "name::ENV1=v,ENV2=v::-DFLAG=1 -DOTHER=2" ... [--wl cit2,collab] [--steps 10] [--reps 2] [--files walk.hip,walk_pipe.hip]
+    python tools/ab.py "name::ENV1=v,ENV2=v::-DFLAG=1 -DOTHER=2" ... [--wl=cit2,collab] [--steps=10] [--reps=2]
+                       [--files=walk.hip,walk_pipe.hip] [--bench="--pairs 1024"]          (options take the --key=value form)
 
 A variant with flags is compiled into /tmp and selected with SUBGACC_LIB (the shipped library is never touched); every
 variant runs `bench.py --no-cpu-baseline --no-others` per workload and prints the stage times of the step."""
