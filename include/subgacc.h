@@ -376,13 +376,14 @@ int subgacc_step_prologue(void *uniq_table, int64_t capacity, int64_t *zero_word
  *   own, partner int64 [n]: gather()'s mirrored segment lists over those rows -- own[j] = row of endpoint j, partner[j] = row of
  *               the other end of its pair (j +- n/2); what subgacc_sjoin_sizes_rows / _fill_rows / _fill_keyrows take
  *   n_distinct  int64 [1] (device): the number of rows, for subgacc_walk_spg_n
- *   generation  any value != 0 that differs from the previous call's on this workspace (slots are stamped, never cleared)
- *   workspace   subgacc_step_dedup_workspace_bytes(n) bytes, ZEROED once by the caller before its first use
+ *   workspace   subgacc_step_dedup_workspace_bytes(n) bytes, ZEROED once by the caller before its first use and left alone
+ *               afterwards: it keeps the stamp of the last step (slots are stamped, never cleared), so a captured (replayed)
+ *               step works like a launched one
  * ------------------------------------------------------------------------------------------- */
 size_t subgacc_step_dedup_workspace_bytes(int64_t n);
 int subgacc_step_prologue_dedup(void *uniq_table, int64_t capacity, int64_t *zero_words, int64_t n_zero, const int64_t *edge,
-                                int32_t *roots, int64_t *own, int64_t *partner, int64_t n, uint32_t generation, void *workspace,
-                                size_t workspace_bytes, int64_t *n_distinct, void *stream);
+                                int32_t *roots, int64_t *own, int64_t *partner, int64_t n, void *workspace, size_t workspace_bytes,
+                                int64_t *n_distinct, void *stream);
 /* subgacc_walk_spg for a root count that lives on the device (<= n_max; blocks past it leave at once).  Philox mode,
  * set_sampler order, shapes the fused-row kernel serves (2..4 hops, M <= 256, M*m+1 <= 818, no bucket): SUBGACC_ERR_BADARG
  * otherwise.  Row i belongs to query[i]; tags of the table of distinct rows start at 0. */

@@ -113,7 +113,7 @@ def lib():
     sig["subgacc_sjoin_fill_keyrows"] = (C.c_int, [vp, i64, i64, vp, vp, vp, vp, i64, vp, i32, i32, vp, i64, vp, vp])
     sig["subgacc_sjoin_fill_keys"] = (C.c_int, [vp, i64, vp, vp, vp, vp, i64, vp, i32, i32, vp, i32, i64, vp, vp])
     sig["subgacc_step_dedup_workspace_bytes"] = (C.c_size_t, [i64])
-    sig["subgacc_step_prologue_dedup"] = (C.c_int, [vp, i64, vp, i64, vp, vp, vp, vp, i64, C.c_uint32, vp, C.c_size_t, vp, vp])
+    sig["subgacc_step_prologue_dedup"] = (C.c_int, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, C.c_size_t, vp, vp])
     sig["subgacc_walk_spg_n"] = (C.c_int, [cfgp, vp, vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp])
     sig["subgacc_step_prologue"] = (C.c_int, [vp, i64, vp, i64, vp, vp, i64, vp])
     sig["subgacc_batch_sampler_workspace_bytes"] = (sz, [i64])

@@ -44,15 +44,17 @@ __global__ void step_prologue_kernel(UniqTable t, int64_t cap, int64_t *zero_wor
 
 // The same prologue for a step that samples every DISTINCT endpoint once (Philox keys a walk by its root's id: a root's set does
 // not depend on where or how often the root appears in the batch).  The n endpoints go into an open-addressing table in HBM
-// whose slots are stamped with the step's generation (nothing is ever cleared): the first lane to claim a root's slot gives it
+// whose slots are stamped with the step's generation (kept in the workspace; nothing is ever cleared): the first lane to claim a root's slot gives it
 // the next row (one atomicAdd per wavefront) and writes the root there; every endpoint remembers its slot, and a second small
 // kernel reads the rows back into the join's segment lists own[j] = row of endpoint j, partner[j] = row of its pair's other end.
 // The second kernel also hands the row count out (*n_distinct: what the walk kernel takes as its device-side n) and zeroes the
 // workspace's counter for the next step.  Row numbers depend on who wins the claims; (xz, indptr) do not.
 __global__ void step_dedup_claim_kernel(UniqTable t, int64_t cap, int64_t *zero_words, int64_t n_zero, const int64_t *edge,
                                         int32_t *roots, int32_t *slot_of, unsigned long long *hkeys, int32_t *hvals,
-                                        uint32_t hmask, int hshift, uint32_t gen, int64_t *counter, int64_t n) {
+                                        uint32_t hmask, int hshift, const int64_t *last_gen, int64_t *counter, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t gen = (uint32_t)*last_gen + 1u;     // the step's stamp lives in the workspace (the map kernel stores it back): a
+    if (gen == 0u) gen = 1u;                      // captured step replays with a fresh one; 0 = "never used" is skipped
     if (i < cap) {
         t.keys[i] = kEmptyKey;
         t.mintag[i] = ~0ull;
@@ -67,7 +69,9 @@ __global__ void step_dedup_claim_kernel(UniqTable t, int64_t cap, int64_t *zero_
         root = (v < 0 || v > 0x7FFFFFFFll) ? -1 : (int32_t)v;
         const unsigned long long key = ((unsigned long long)gen << 32) | (uint32_t)root;
         h = ((uint32_t)root * 2654435761u) >> hshift;
-        for (;;) {
+        // (bounded: a workspace that was not zeroed before its first use could hold nothing but current-looking stamps; the
+        // walk must end there too -- the results are then as undefined as the workspace was)
+        for (uint32_t probes = 0; probes <= hmask; ++probes) {
             unsigned long long cur = __hip_atomic_load(&hkeys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((uint32_t)(cur >> 32) != gen) {        // a slot of an earlier step: free
                 const unsigned long long prev = atomicCAS(&hkeys[h], cur, key);
@@ -98,11 +102,14 @@ __global__ void step_dedup_claim_kernel(UniqTable t, int64_t cap, int64_t *zero_
 
 __global__ void step_dedup_map_kernel(const int32_t *__restrict__ slot_of, const int32_t *__restrict__ hvals,
                                       int64_t *__restrict__ own, int64_t *__restrict__ partner, int64_t n, int64_t *counter,
-                                      int64_t *n_distinct) {
+                                      int64_t *last_gen, int64_t *n_distinct) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j == 0) {
         *n_distinct = *counter;
         *counter = 0;
+        uint32_t gen = (uint32_t)*last_gen + 1u;
+        if (gen == 0u) gen = 1u;
+        *last_gen = (int64_t)gen;
     }
     if (j >= n) return;
     const int64_t row = hvals[slot_of[j]];
@@ -345,19 +352,20 @@ extern "C" size_t subgacc_step_dedup_workspace_bytes(int64_t n) {
 }
 
 extern "C" int subgacc_step_prologue_dedup(void *table, int64_t capacity, int64_t *zero_words, int64_t n_zero, const int64_t *edge,
-                                           int32_t *roots, int64_t *own, int64_t *partner, int64_t n, uint32_t generation,
-                                           void *workspace, size_t workspace_bytes, int64_t *n_distinct, void *stream) {
+                                           int32_t *roots, int64_t *own, int64_t *partner, int64_t n, void *workspace,
+                                           size_t workspace_bytes, int64_t *n_distinct, void *stream) {
     SG_REQUIRE(!table || (is_pow2(capacity) && capacity < (1ll << 31)), SUBGACC_ERR_BADARG,
                "step_prologue_dedup: capacity must be a power of two below 2^31");
     if (!table) capacity = 0;
     SG_REQUIRE(n > 0 && n % 2 == 0 && n < (1ll << 30) && n_zero >= 0 && edge && roots && own && partner && n_distinct &&
-                   (n_zero == 0 || zero_words) && generation != 0,
-               SUBGACC_ERR_BADARG, "step_prologue_dedup: bad arguments (n = 2B endpoints, generation != 0)");
+                   (n_zero == 0 || zero_words),
+               SUBGACC_ERR_BADARG, "step_prologue_dedup: bad arguments (n = 2B endpoints)");
     SG_REQUIRE(workspace && workspace_bytes >= subgacc_step_dedup_workspace_bytes(n), SUBGACC_ERR_WORKSPACE,
                "step_prologue_dedup: workspace too small");
     const int64_t c = dedup_slots(n);
     char *w = (char *)workspace;
     int64_t *counter = (int64_t *)w;                        // zero when the workspace is handed over the first time, and after every call
+    int64_t *last_gen = counter + 1;                        // the stamp of the previous call on this workspace
     unsigned long long *hkeys = (unsigned long long *)(w + 256);
     int32_t *hvals = (int32_t *)(w + 256 + align_up((size_t)c * 8, 256));
     int32_t *slot_of = (int32_t *)((char *)hvals + align_up((size_t)c * 4, 256));
@@ -366,10 +374,10 @@ extern "C" int subgacc_step_prologue_dedup(void *table, int64_t capacity, int64_
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(step_dedup_claim_kernel, dim3((unsigned)ceil_div(span, 256)), dim3(256), 0, s,
                        table ? uniq_view(table, capacity) : UniqTable{nullptr, nullptr, nullptr, 0}, capacity, zero_words, n_zero,
-                       edge, roots, slot_of, hkeys, hvals, (uint32_t)(c - 1), 32 - (63 - __builtin_clzll((unsigned long long)c)), generation,
+                       edge, roots, slot_of, hkeys, hvals, (uint32_t)(c - 1), 32 - (63 - __builtin_clzll((unsigned long long)c)), last_gen,
                        counter, n);
     hipLaunchKernelGGL(step_dedup_map_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, slot_of, hvals, own, partner, n,
-                       counter, n_distinct);
+                       counter, last_gen, n_distinct);
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }

@@ -293,7 +293,8 @@ class StepBuffers:
     Reuse is the caller's business: a buffer set is busy until its step has been resolved (bench.py alternates two).
     dedup_roots=True: every DISTINCT endpoint of the batch is sampled once (subgacc_step_prologue_dedup: a generation-stamped
     hash of the endpoints, one more small launch; the walk kernel takes its root count from the device) -- Philox keys a walk
-    by its root's id, so (xz, indptr) do not change; the rows of the sets are then in order of arrival (sets.n_distinct of them)."""
+    by its root's id, so (xz, indptr) do not change; the rows of the sets are then in order of arrival (sets.n_distinct of them).
+    The hash is stamped with a per-step generation kept on the device: a captured step replays correctly."""
 
     def __init__(self, csr, pairs, num_walks=200, num_steps=3, uniq_capacity=1 << 17, out=None, dedup_roots=False):
         from .sampler import FUSED_MAX_Q
@@ -320,7 +321,6 @@ class StepBuffers:
             self.own = torch.empty(n, dtype=torch.int64, device=dev)
             self.partner = torch.empty(n, dtype=torch.int64, device=dev)
             self.dedup_ws = torch.zeros(L.subgacc_step_dedup_workspace_bytes(n), dtype=torch.uint8, device=dev)
-            self.generation = 0
         self.ws = torch.empty(max(L.subgacc_sjoin_workspace_bytes(n), 8), dtype=torch.uint8, device=dev)
         self.feat = None if self.keyrows else torch.empty((self.capacity + 1, self.k), dtype=torch.float32, device=dev)
         need = n * self.stride * 2 * self.k
@@ -343,12 +343,9 @@ def _buffered_step(csr, e, bufs, seed, out):
     check(L.subgacc_key_shift(cfg.num_walks, cfg.num_steps))
     kr = bufs.keyrows
     if bufs.dedup:      # distinct endpoints only: rows in order of arrival, the segment lists point at them
-        if torch.cuda.is_current_stream_capturing():
-            raise ValueError("root dedup stamps its hash with a per-step generation: not for a captured (replayed) step")
-        bufs.generation = bufs.generation % 0xFFFFFFF0 + 1
         check(L.subgacc_step_prologue_dedup(ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.status), 4, ptr(e), ptr(bufs.roots),
-                                            ptr(bufs.own), ptr(bufs.partner), n, bufs.generation, ptr(bufs.dedup_ws),
-                                            bufs.dedup_ws.numel(), ptr(bufs.n_distinct), st))
+                                            ptr(bufs.own), ptr(bufs.partner), n, ptr(bufs.dedup_ws), bufs.dedup_ws.numel(),
+                                            ptr(bufs.n_distinct), st))
         with _timed("walk_sets"):
             check(L.subgacc_walk_spg_n(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n, ptr(bufs.n_distinct),
                                        ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize),

@@ -20,8 +20,10 @@ from .spjoin import StepBuffers, sample_and_gather
 
 class CapturedStep:
     def __init__(self, csr, pairs, num_walks=200, num_steps=3, seed=111413, rng="philox", uniq_capacity=1 << 17,
-                 strided=None, fused=None, warmup=2):
-        """pairs = B, the fixed number of query pairs per step; num_steps = walk hops."""
+                 strided=None, fused=None, warmup=2, dedup_roots=False):
+        """pairs = B, the fixed number of query pairs per step; num_steps = walk hops.  dedup_roots=True: every distinct
+        endpoint of a batch is sampled once (StepBuffers(dedup_roots=True): its per-step stamp lives on the device, so the
+        replayed graph works like a launched step); `distinct_roots` after finish()."""
         self.csr, self.B, self.M, self.m = csr, int(pairs), int(num_walks), int(num_steps)
         dev = csr.device
         self.edge = torch.zeros((2, self.B), dtype=torch.int64, device=dev)
@@ -30,9 +32,14 @@ class CapturedStep:
                         fused=fused, uniq_capacity=uniq_capacity)
         if rng == "philox" and strided is not False and fused is not False:
             try:      # the allocation-free six-launch form of the step (spjoin.StepBuffers) where it applies
-                self._kw["buffers"] = StepBuffers(csr, self.B, self.M, self.m, uniq_capacity=uniq_capacity, out=self.out)
+                self._kw["buffers"] = StepBuffers(csr, self.B, self.M, self.m, uniq_capacity=uniq_capacity, out=self.out,
+                                                  dedup_roots=dedup_roots)
+                self._kw["dedup_roots"] = bool(dedup_roots)
             except ValueError:
-                pass
+                if dedup_roots:
+                    raise
+        elif dedup_roots:
+            raise ValueError("dedup_roots=True needs the buffered form of the step (rng='philox', fused strided rows)")
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                   # allocator steady state + lazy code-object loads, uncaptured
@@ -46,7 +53,9 @@ class CapturedStep:
         # what finish() needs: the packed status of the sets (flags, distinct LP rows, members) and the join's row count
         self.status, self._rows = self.sets.status, self.ind[-1:]
         self._tail = self.sets._tail          # StepBuffers: [rows, status x4] contiguous -> one copy
-        self._host = torch.empty(self.status.numel() + 1, dtype=torch.int64, pin_memory=True)
+        self._host = torch.empty(self._tail.numel() if self._tail is not None else self.status.numel() + 1, dtype=torch.int64,
+                                 pin_memory=True)
+        self.distinct_roots = None
         self._event = torch.cuda.Event()
 
     def _queue(self):
@@ -72,8 +81,11 @@ class CapturedStep:
         self._event.synchronize()
         words = self._host.tolist()
         if self._tail is not None:
+            if len(words) > 5:                # root dedup: [rows, status x4, distinct roots]
+                self.distinct_roots = int(words[5])
+                words = words[:5]
             words = words[1:] + words[:1]
-            words[3] = words[4]               # members = rows of the join (every row belongs to an own set)
+            words[3] = words[4]               # members = rows of the join (every row belongs to an own set; with root dedup: an upper bound)
         st = unpack_status(words[:-1]) + words[-1:]
         check_walk_flags(self.sets, st[:4])
         if st[2] or (self.sets.ukeys is not None and st[4] > self.sets.ukeys.numel()):

@@ -1029,6 +1029,15 @@ def test_step_with_root_dedup_equals_the_plain_step(sp, B, M, hops, idx64):
             assert dsets.number().ukeys.numel() == sets.number().ukeys.numel()
     with pytest.raises(ValueError):
         sp.sample_and_gather(csr, e, num_walks=M, num_steps=hops, seed=9, rng="philox", buffers=plain, dedup_roots=True)
+    # ... and as ONE captured HIP graph per step: the stamp of the hash lives on the device, every replay gets a fresh one
+    if B <= 1024:
+        step = sp.CapturedStep(csr, B, num_walks=M, num_steps=hops, seed=9, dedup_roots=True)
+        for s in range(3):
+            e = torch.from_numpy(rng.integers(0, (60, 3000, 500)[s], (2, B))).cuda()
+            xz, ind, _ = sp.sample_and_gather(csr, e, num_walks=M, num_steps=hops, seed=9, rng="philox", buffers=plain)
+            cxz, cind = step(e).finish()
+            assert torch.equal(ind, cind) and torch.equal(xz[: cxz.shape[0]], cxz) and cxz.shape[0] == int(ind[-1].item())
+            assert step.distinct_roots == torch.unique(e).numel()
 
 
 @pytest.mark.parametrize("M,hops", [(200, 3), (200, 2), (64, 3), (100, 4), (255, 4)])
