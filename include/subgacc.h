@@ -371,25 +371,34 @@ int subgacc_step_prologue(void *uniq_table, int64_t capacity, int64_t *zero_word
 /* The same prologue for a step that samples every DISTINCT endpoint once.  Philox keys a walk by (seed, root id, walk, hop), so a
  * root's set does not depend on where or how often the root stands in the batch (the reference samples every node once, offline,
  * main.py:172-178; its sequential rand_r stream has no such property, so this form is Philox only).  Two launches:
- *   roots       int32 [n]: the distinct endpoints in rows 0 .. *n_distinct - 1 (row order = order of arrival: not reproducible,
- *               the join's output is)
- *   own, partner int64 [n]: gather()'s mirrored segment lists over those rows -- own[j] = row of endpoint j, partner[j] = row of
- *               the other end of its pair (j +- n/2); what subgacc_sjoin_sizes_rows / _fill_rows / _fill_keyrows take
- *   n_distinct  int64 [1] (device): the number of rows, for subgacc_walk_spg_n
+ *   roots       int32 [n]: roots[j] = endpoint j where j is the FIRST occurrence of its node in the batch, SUBGACC_NO_ROOT
+ *               elsewhere -- rows of the batch's sets stay where the plain step has them, the rows of repeated endpoints
+ *               stay empty (subgacc_walk_spg_sparse passes over them), and the distinct LP rows keep their numbering
+ *   own, partner int64 [n]: gather()'s mirrored segment lists over those rows -- own[j] = row of endpoint j's first occurrence,
+ *               partner[j] = that of the other end of its pair (j +- n/2); for subgacc_sjoin_sizes_rows / _fill_rows / _fill_keyrows
+ *   worklist    int32 [n]: the first occurrences, worklist[0 .. *n_distinct), in order of arrival (not reproducible, and it does
+ *               not matter: entry k names its row) -- what subgacc_walk_spg_sparse runs over
+ *   row_len     int32 [n]: the rows' lengths (the sampler's nsize): set to 0 for the rows of repeated endpoints, which the
+ *               sampler will not visit
+ *   n_distinct  int64 [1] (device): the number of distinct endpoints = the length of the work list
  *   workspace   subgacc_step_dedup_workspace_bytes(n) bytes, ZEROED once by the caller before its first use and left alone
  *               afterwards: it keeps the stamp of the last step (slots are stamped, never cleared), so a captured (replayed)
  *               step works like a launched one
  * ------------------------------------------------------------------------------------------- */
+#define SUBGACC_NO_ROOT (-2147483647 - 1)
 size_t subgacc_step_dedup_workspace_bytes(int64_t n);
 int subgacc_step_prologue_dedup(void *uniq_table, int64_t capacity, int64_t *zero_words, int64_t n_zero, const int64_t *edge,
-                                int32_t *roots, int64_t *own, int64_t *partner, int64_t n, void *workspace, size_t workspace_bytes,
-                                int64_t *n_distinct, void *stream);
-/* subgacc_walk_spg for a root count that lives on the device (<= n_max; blocks past it leave at once).  Philox mode,
- * set_sampler order, shapes the fused-row kernel serves (2..4 hops, M <= 256, M*m+1 <= 818, no bucket): SUBGACC_ERR_BADARG
- * otherwise.  Row i belongs to query[i]; tags of the table of distinct rows start at 0. */
-int subgacc_walk_spg_n(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,
-                       const int32_t *query, int64_t n_max, const int64_t *n_dev, void *uniq_table, int64_t uniq_capacity,
-                       int32_t *row_ids, int32_t *row_slot, int32_t *nsize, int32_t *flags, void *stream);
+                                int32_t *roots, int64_t *own, int64_t *partner, int32_t *worklist, int32_t *row_len, int64_t n,
+                                void *workspace, size_t workspace_bytes, int64_t *n_distinct, void *stream);
+/* subgacc_walk_spg over some of the rows only: the rows worklist[0 .. *n_work) (both on the device; the launch covers n rows,
+ * blocks past the list's length leave at once), or -- worklist = n_work = NULL -- every row i whose query[i] is not
+ * SUBGACC_NO_ROOT (such a row gets nsize[i] = 0 and nothing else is touched; rows that are not on the work list are not touched
+ * at all).  Philox mode, set_sampler order, shapes the fused-row kernel serves (2..4 hops, M <= 256, M*m+1 <= 818, no bucket):
+ * SUBGACC_ERR_BADARG otherwise.  Row i belongs to query[i]; tags of the table of distinct rows start at 0. */
+int subgacc_walk_spg_sparse(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,
+                            const int32_t *query, int64_t n, const int32_t *worklist, const int64_t *n_work, void *uniq_table,
+                            int64_t uniq_capacity, int32_t *row_ids, int32_t *row_slot, int32_t *nsize, int32_t *flags,
+                            void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * batch_sampler of the legacy SUREL surface (subg_acc/subg_acc.c:391-507): one insertion-ordered set of nodes grown by

@@ -32,7 +32,7 @@ SYMBOLS = (
     "subgacc_encode_sizes", "subgacc_encode_fill", "subgacc_sjoin_pairs", "subgacc_finish_rows",
     "subgacc_batch_sampler_workspace_bytes", "subgacc_batch_sampler", "subgacc_step_prologue",
     "subgacc_hop_records_format", "subgacc_hop_records_build", "subgacc_sjoin_fill_keyrows", "subgacc_sjoin_fill_keys", "subgacc_step_dedup_workspace_bytes",
-    "subgacc_step_prologue_dedup", "subgacc_walk_spg_n",
+    "subgacc_step_prologue_dedup", "subgacc_walk_spg_sparse",
 )
 
 
@@ -113,8 +113,8 @@ def lib():
     sig["subgacc_sjoin_fill_keyrows"] = (C.c_int, [vp, i64, i64, vp, vp, vp, vp, i64, vp, i32, i32, vp, i64, vp, vp])
     sig["subgacc_sjoin_fill_keys"] = (C.c_int, [vp, i64, vp, vp, vp, vp, i64, vp, i32, i32, vp, i32, i64, vp, vp])
     sig["subgacc_step_dedup_workspace_bytes"] = (C.c_size_t, [i64])
-    sig["subgacc_step_prologue_dedup"] = (C.c_int, [vp, i64, vp, i64, vp, vp, vp, vp, i64, vp, C.c_size_t, vp, vp])
-    sig["subgacc_walk_spg_n"] = (C.c_int, [cfgp, vp, vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp])
+    sig["subgacc_step_prologue_dedup"] = (C.c_int, [vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, C.c_size_t, vp, vp])
+    sig["subgacc_walk_spg_sparse"] = (C.c_int, [cfgp, vp, vp, i64, vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp])
     sig["subgacc_step_prologue"] = (C.c_int, [vp, i64, vp, i64, vp, vp, i64, vp])
     sig["subgacc_batch_sampler_workspace_bytes"] = (sz, [i64])
     sig["subgacc_batch_sampler"] = (C.c_int, [vp, i32, vp, i64, vp, i64, i32, i32, i32, C.c_uint32, vp, i64, vp, vp, sz, vp, vp])

@@ -44,14 +44,17 @@ __global__ void step_prologue_kernel(UniqTable t, int64_t cap, int64_t *zero_wor
 
 // The same prologue for a step that samples every DISTINCT endpoint once (Philox keys a walk by its root's id: a root's set does
 // not depend on where or how often the root appears in the batch).  The n endpoints go into an open-addressing table in HBM
-// whose slots are stamped with the step's generation (kept in the workspace; nothing is ever cleared): the first lane to claim a root's slot gives it
-// the next row (one atomicAdd per wavefront) and writes the root there; every endpoint remembers its slot, and a second small
-// kernel reads the rows back into the join's segment lists own[j] = row of endpoint j, partner[j] = row of its pair's other end.
-// The second kernel also hands the row count out (*n_distinct: what the walk kernel takes as its device-side n) and zeroes the
-// workspace's counter for the next step.  Row numbers depend on who wins the claims; (xz, indptr) do not.
+// whose slots are stamped with the step's generation (kept in the workspace; nothing is ever cleared); every occurrence of a
+// root raises the slot's value to (generation, ~index) with a 64-bit atomicMax, so that the slot ends up naming the root's
+// FIRST occurrence.  The second kernel gives endpoint j the row of that first occurrence -- own[j], and partner[] of the other
+// end of its pair -- leaves roots[j] = the root where j is a first occurrence, SUBGACC_NO_ROOT elsewhere, and lists the first
+// occurrences (worklist[0 .. *n_distinct), one atomicAdd per wavefront; the list's order is the order of arrival and does not
+// matter: entry k names its row).  Rows are sparse in [0, n) but deterministic -- the sets of the batch sit where the plain step
+// has them, and the distinct LP rows keep the numbering they would have had with every endpoint sampled (a repeated root never
+// is the first to show a row) -- while the walk kernel runs over the dense list and never sees an empty row.
 __global__ void step_dedup_claim_kernel(UniqTable t, int64_t cap, int64_t *zero_words, int64_t n_zero, const int64_t *edge,
-                                        int32_t *roots, int32_t *slot_of, unsigned long long *hkeys, int32_t *hvals,
-                                        uint32_t hmask, int hshift, const int64_t *last_gen, int64_t *counter, int64_t n) {
+                                        int32_t *slot_of, unsigned long long *hkeys, unsigned long long *hvals,
+                                        uint32_t hmask, int hshift, const int64_t *last_gen, int64_t *n_distinct, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t gen = (uint32_t)*last_gen + 1u;     // the step's stamp lives in the workspace (the map kernel stores it back): a
     if (gen == 0u) gen = 1u;                      // captured step replays with a fresh one; 0 = "never used" is skipped
@@ -61,61 +64,63 @@ __global__ void step_dedup_claim_kernel(UniqTable t, int64_t cap, int64_t *zero_
         t.id[i] = -1;
     }
     if (i < n_zero) zero_words[i] = 0;
-    bool claimed = false;
-    uint32_t h = 0;
-    int32_t root = -1;
-    if (i < n) {
-        const int64_t v = edge[i];
-        root = (v < 0 || v > 0x7FFFFFFFll) ? -1 : (int32_t)v;
-        const unsigned long long key = ((unsigned long long)gen << 32) | (uint32_t)root;
-        h = ((uint32_t)root * 2654435761u) >> hshift;
-        // (bounded: a workspace that was not zeroed before its first use could hold nothing but current-looking stamps; the
-        // walk must end there too -- the results are then as undefined as the workspace was)
-        for (uint32_t probes = 0; probes <= hmask; ++probes) {
-            unsigned long long cur = __hip_atomic_load(&hkeys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((uint32_t)(cur >> 32) != gen) {        // a slot of an earlier step: free
-                const unsigned long long prev = atomicCAS(&hkeys[h], cur, key);
-                if (prev == cur) {
-                    claimed = true;
-                    break;
-                }
-                cur = prev;                             // taken meanwhile -- by this step: look at what sits there now
-            }
-            if (cur == key) break;                      // the root is there already
-            h = (h + 1u) & hmask;
+    if (i == 0) *n_distinct = 0;                  // counted by the map kernel
+    if (i >= n) return;
+    const int64_t v = edge[i];
+    const int32_t root = (v < 0 || v > 0x7FFFFFFFll) ? -1 : (int32_t)v;
+    const unsigned long long key = ((unsigned long long)gen << 32) | (uint32_t)root;
+    uint32_t h = ((uint32_t)root * 2654435761u) >> hshift;
+    // (bounded: a workspace that was not zeroed before its first use could hold nothing but current-looking stamps; the
+    // walk must end there too -- the results are then as undefined as the workspace was)
+    for (uint32_t probes = 0; probes <= hmask; ++probes) {
+        unsigned long long cur = __hip_atomic_load(&hkeys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(cur >> 32) != gen) {        // a slot of an earlier step: free
+            const unsigned long long prev = atomicCAS(&hkeys[h], cur, key);
+            if (prev == cur) break;
+            cur = prev;                             // taken meanwhile -- by this step: look at what sits there now
         }
-        slot_of[i] = (int32_t)h;
+        if (cur == key) break;                      // the root is there already
+        h = (h + 1u) & hmask;
     }
-    const unsigned long long m = __ballot(claimed);
-    if (m) {
-        const int lane = threadIdx.x & (kWave - 1);
-        int64_t base = 0;
-        if (lane == __ffsll((long long)m) - 1) base = (int64_t)atomicAdd((unsigned long long *)counter, (unsigned long long)__popcll(m));
-        base = __shfl(base, __ffsll((long long)m) - 1, kWave);
-        if (claimed) {
-            const int32_t row = (int32_t)(base + __popcll(m & ((1ull << lane) - 1ull)));
-            hvals[h] = row;
-            roots[row] = root;
-        }
-    }
+    slot_of[i] = (int32_t)h;
+    atomicMax(&hvals[h], ((unsigned long long)gen << 32) | (0xFFFFFFFFu - (uint32_t)i));   // later stamp wins, then the smaller index
 }
 
-__global__ void step_dedup_map_kernel(const int32_t *__restrict__ slot_of, const int32_t *__restrict__ hvals,
-                                      int64_t *__restrict__ own, int64_t *__restrict__ partner, int64_t n, int64_t *counter,
-                                      int64_t *last_gen, int64_t *n_distinct) {
+__global__ __launch_bounds__(256) void step_dedup_map_kernel(const int64_t *__restrict__ edge, const int32_t *__restrict__ slot_of,
+                                                             const unsigned long long *__restrict__ hvals, int32_t *__restrict__ roots,
+                                                             int64_t *__restrict__ own, int64_t *__restrict__ partner,
+                                                             int32_t *__restrict__ worklist, int32_t *__restrict__ row_len, int64_t n,
+                                                             int64_t *last_gen, int64_t *n_distinct) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j == 0) {
-        *n_distinct = *counter;
-        *counter = 0;
-        uint32_t gen = (uint32_t)*last_gen + 1u;
-        if (gen == 0u) gen = 1u;
-        *last_gen = (int64_t)gen;
+    bool first = false;
+    if (j < n) {
+        const int64_t row = (int64_t)(0xFFFFFFFFu - (uint32_t)hvals[slot_of[j]]);
+        const int64_t half = n / 2;
+        own[j] = row;
+        partner[j < half ? j + half : j - half] = row;
+        first = row == j;
+        const int64_t v = edge[j];
+        roots[j] = first ? ((v < 0 || v > 0x7FFFFFFFll) ? -1 : (int32_t)v) : SUBGACC_NO_ROOT;
+        if (!first) row_len[j] = 0;      // the walk kernel never visits this row: it is empty, not stale
     }
-    if (j >= n) return;
-    const int64_t row = hvals[slot_of[j]];
-    const int64_t half = n / 2;
-    own[j] = row;
-    partner[j < half ? j + half : j - half] = row;
+    // the rows that carry a set, as a dense work list for the walk kernel (its order is the order of arrival and does not
+    // matter: entry k names its row); one atomicAdd per wavefront
+    const unsigned long long m = __ballot(first);
+    if (m) {
+        const int lane = threadIdx.x & (kWave - 1);
+        const int leader = __ffsll((long long)m) - 1;
+        long long base = 0;
+        if (lane == leader) base = (long long)atomicAdd((unsigned long long *)n_distinct, (unsigned long long)__popcll(m));
+        base = __shfl(base, leader, kWave);
+        if (first) worklist[base + __popcll(m & ((1ull << lane) - 1ull))] = (int32_t)j;
+    }
+    if (threadIdx.x == 0) {
+        if (blockIdx.x == 0) {      // the claim kernel of this step is done: its stamp becomes the last one
+            uint32_t gen = (uint32_t)*last_gen + 1u;
+            if (gen == 0u) gen = 1u;
+            *last_gen = (int64_t)gen;
+        }
+    }
 }
 
 // The distinct LP rows are 10^2..10^5 while the members are 10^7..10^9, so almost every member repeats a key
@@ -348,36 +353,35 @@ static int64_t dedup_slots(int64_t n) {
 extern "C" size_t subgacc_step_dedup_workspace_bytes(int64_t n) {
     if (n < 0) n = 0;
     const int64_t c = dedup_slots(n);
-    return 256 + align_up((size_t)c * 8, 256) + align_up((size_t)c * 4, 256) + align_up((size_t)n * 4, 256);
+    return 256 + 2 * align_up((size_t)c * 8, 256) + align_up((size_t)n * 4, 256);
 }
 
 extern "C" int subgacc_step_prologue_dedup(void *table, int64_t capacity, int64_t *zero_words, int64_t n_zero, const int64_t *edge,
-                                           int32_t *roots, int64_t *own, int64_t *partner, int64_t n, void *workspace,
-                                           size_t workspace_bytes, int64_t *n_distinct, void *stream) {
+                                           int32_t *roots, int64_t *own, int64_t *partner, int32_t *worklist, int32_t *row_len,
+                                           int64_t n, void *workspace, size_t workspace_bytes, int64_t *n_distinct, void *stream) {
     SG_REQUIRE(!table || (is_pow2(capacity) && capacity < (1ll << 31)), SUBGACC_ERR_BADARG,
                "step_prologue_dedup: capacity must be a power of two below 2^31");
     if (!table) capacity = 0;
-    SG_REQUIRE(n > 0 && n % 2 == 0 && n < (1ll << 30) && n_zero >= 0 && edge && roots && own && partner && n_distinct &&
+    SG_REQUIRE(n > 0 && n % 2 == 0 && n < (1ll << 30) && n_zero >= 0 && edge && roots && own && partner && worklist && row_len && n_distinct &&
                    (n_zero == 0 || zero_words),
                SUBGACC_ERR_BADARG, "step_prologue_dedup: bad arguments (n = 2B endpoints)");
     SG_REQUIRE(workspace && workspace_bytes >= subgacc_step_dedup_workspace_bytes(n), SUBGACC_ERR_WORKSPACE,
                "step_prologue_dedup: workspace too small");
     const int64_t c = dedup_slots(n);
     char *w = (char *)workspace;
-    int64_t *counter = (int64_t *)w;                        // zero when the workspace is handed over the first time, and after every call
-    int64_t *last_gen = counter + 1;                        // the stamp of the previous call on this workspace
+    int64_t *last_gen = (int64_t *)w;                       // the stamp of the previous call on this workspace (0 at first)
     unsigned long long *hkeys = (unsigned long long *)(w + 256);
-    int32_t *hvals = (int32_t *)(w + 256 + align_up((size_t)c * 8, 256));
-    int32_t *slot_of = (int32_t *)((char *)hvals + align_up((size_t)c * 4, 256));
+    unsigned long long *hvals = (unsigned long long *)(w + 256 + align_up((size_t)c * 8, 256));
+    int32_t *slot_of = (int32_t *)(w + 256 + 2 * align_up((size_t)c * 8, 256));
     int64_t span = capacity > n ? capacity : n;
     if (n_zero > span) span = n_zero;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(step_dedup_claim_kernel, dim3((unsigned)ceil_div(span, 256)), dim3(256), 0, s,
                        table ? uniq_view(table, capacity) : UniqTable{nullptr, nullptr, nullptr, 0}, capacity, zero_words, n_zero,
-                       edge, roots, slot_of, hkeys, hvals, (uint32_t)(c - 1), 32 - (63 - __builtin_clzll((unsigned long long)c)), last_gen,
-                       counter, n);
-    hipLaunchKernelGGL(step_dedup_map_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, slot_of, hvals, own, partner, n,
-                       counter, last_gen, n_distinct);
+                       edge, slot_of, hkeys, hvals, (uint32_t)(c - 1), 32 - (63 - __builtin_clzll((unsigned long long)c)), last_gen,
+                       n_distinct, n);
+    hipLaunchKernelGGL(step_dedup_map_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, s, edge, slot_of, hvals, roots, own,
+                       partner, worklist, row_len, n, last_gen, n_distinct);
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }

@@ -735,7 +735,7 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
                        const int32_t *query, int64_t n, const uint32_t *rng_pos, const uint32_t *rng_seed,
                        int32_t *set_ids, uint64_t *set_keys, int32_t *set_slot, void *uniq_table, int64_t uniq_capacity,
                        int64_t root_base, int32_t *nsize, int32_t *walks, int32_t *flags, void *stream,
-                       const int64_t *n_dev = nullptr) {
+                       bool holes = false, const int32_t *worklist = nullptr, const int64_t *n_work = nullptr) {
     const bool spg = set_slot != nullptr;
     SG_REQUIRE(cfg && indptr && set_ids && (set_keys || spg) && nsize && flags, SUBGACC_ERR_BADARG,
                "walk: null argument");
@@ -765,7 +765,7 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
 
     WalkArgs a;
     a.indptr = indptr, a.indices = indices, a.query = query, a.n = n, a.num_nodes = num_nodes;
-    a.n_dev = n_dev;
+    a.worklist = worklist, a.n_work = n_work;
     a.rng_pos = rng_pos, a.rng_seed = rng_seed;
     a.set_ids = set_ids, a.set_keys = set_keys, a.nsize = nsize;
     a.walks = cfg->emit_walks ? walks : nullptr;
@@ -799,7 +799,7 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
     hipStream_t s = (hipStream_t)stream;
     // the persistent, software-pipelined form takes every launch it supports (SUBGACC_WALK_PIPE=0 forces this file's)
     static const bool use_pipe = !(getenv("SUBGACC_WALK_PIPE") && getenv("SUBGACC_WALK_PIPE")[0] == '0');
-    if (use_pipe && !n_dev && launch_walk_pipe(a, cfg->indptr64 != 0, cfg->rng_mode, spg, lds, s)) {
+    if (use_pipe && !holes && launch_walk_pipe(a, cfg->indptr64 != 0, cfg->rng_mode, spg, lds, s)) {
         SG_LAUNCH_CHECK();
         return SUBGACC_OK;
     }
@@ -807,8 +807,8 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
         SG_LAUNCH_CHECK();
         return SUBGACC_OK;
     }
-    SG_REQUIRE(!n_dev, SUBGACC_ERR_BADARG,
-               "walk_spg_n: a device-side root count is served by the fused-row kernel only (2..4 hops, M <= 256, a 512- or "
+    SG_REQUIRE(!holes, SUBGACC_ERR_BADARG,
+               "walk_spg_sparse: rows without a root are passed over by the fused-row kernel only (2..4 hops, M <= 256, a 512- or "
                "1,024-slot table, no bucket); M = %d, m = %d", M, m);
     SG_REQUIRE(!a.keyrows, SUBGACC_ERR_BADARG,
                "walk_spg: key rows (no table of distinct rows) need set_sampler order, no bucket, M <= 256, 2 or 3 hops and "
@@ -862,15 +862,16 @@ extern "C" int subgacc_walk_spg(const subgacc_walk_cfg *cfg, const void *indptr,
                        uniq_table, uniq_capacity, root_base, nsize, nullptr, flags, stream);
 }
 
-extern "C" int subgacc_walk_spg_n(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,
-                                  const int32_t *query, int64_t n_max, const int64_t *n_dev, void *uniq_table,
-                                  int64_t uniq_capacity, int32_t *row_ids, int32_t *row_slot, int32_t *nsize, int32_t *flags,
-                                  void *stream) {
-    SG_REQUIRE(row_slot && n_dev, SUBGACC_ERR_BADARG, "walk_spg_n: null row_slot / n_dev");
+extern "C" int subgacc_walk_spg_sparse(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,
+                                       const int32_t *query, int64_t n, const int32_t *worklist, const int64_t *n_work,
+                                       void *uniq_table, int64_t uniq_capacity, int32_t *row_ids, int32_t *row_slot, int32_t *nsize,
+                                       int32_t *flags, void *stream) {
+    SG_REQUIRE(row_slot && (worklist != nullptr) == (n_work != nullptr), SUBGACC_ERR_BADARG,
+               "walk_spg_sparse: null row_slot, or a work list without its length (or the reverse)");
     SG_REQUIRE(cfg && !cfg->emit_walks && cfg->order == SUBGACC_ORDER_WALK_MAJOR && cfg->rng_mode == SUBGACC_RNG_PHILOX,
-               SUBGACC_ERR_BADARG, "walk_spg_n: set_sampler order, Philox mode (a root's set must not depend on its place in the batch)");
-    return launch_walk(cfg, indptr, indices, num_nodes, query, n_max, nullptr, nullptr, row_ids, nullptr, row_slot, uniq_table,
-                       uniq_capacity, 0, nsize, nullptr, flags, stream, n_dev);
+               SUBGACC_ERR_BADARG, "walk_spg_sparse: set_sampler order, Philox mode (a root's set must not depend on its place in the batch)");
+    return launch_walk(cfg, indptr, indices, num_nodes, query, n, nullptr, nullptr, row_ids, nullptr, row_slot, uniq_table,
+                       uniq_capacity, 0, nsize, nullptr, flags, stream, true, worklist, n_work);
 }
 
 extern "C" int subgacc_compact_sets(const int32_t *set_ids, const uint64_t *set_keys, const int32_t *nsize,

@@ -102,7 +102,8 @@ struct WalkArgs {
     const int32_t *indices;
     const int32_t *query;
     int64_t n;
-    const int64_t *n_dev;   // optional: the number of roots lives on the device (<= n: a step's DISTINCT endpoints, subgacc_step_prologue_dedup)
+    const int32_t *worklist;   // optional (fused-row kernel only): the rows to sample, worklist[0 .. *n_work) -- a batch's first
+    const int64_t *n_work;     // occurrences (subgacc_step_prologue_dedup); without it row i = block i and query[i] == SUBGACC_NO_ROOT is passed over
     int64_t num_nodes;   // a root outside [0, num_nodes) is never looked up: empty set, flags[3] |= 16 (the host raises)
     const uint32_t *rng_pos, *rng_seed;
     int32_t *set_ids;

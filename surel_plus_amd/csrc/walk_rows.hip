@@ -80,13 +80,14 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     int32_t *red = KR ? (int32_t *)fk : fs + kSpgFold;            // [16] (KR: no fold table either)
 
     int64_t i;
-    if (a.n_dev) {   // the root count is a device value: the first xcd_grid(count) blocks share the roots among the XCDs as usual
-        int64_t ne = *a.n_dev;
+    if (a.worklist) {   // a dense list of the rows to sample whose length lives on the device: its first xcd_grid(length) blocks work
+        int64_t ne = *a.n_work;
         if (ne > a.n) ne = a.n;
         const int64_t ge = (ne + kXcds - 1) / kXcds * kXcds;
         if ((int64_t)blockIdx.x >= ge) return;
-        i = xcd_item(blockIdx.x, ge);
-        if (i >= ne) return;
+        const int64_t k = xcd_item(blockIdx.x, ge);
+        if (k >= ne) return;
+        i = a.worklist[k];
     } else {
         i = xcd_item(blockIdx.x, gridDim.x);
         if (i >= a.n) return;
@@ -94,6 +95,10 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     const int tid = threadIdx.x;
     const int M = a.M;
     const int32_t root = a.query[i];
+    if (root == SUBGACC_NO_ROOT) {     // a repeated endpoint of the batch: its first occurrence carries the set (uniq.hip: step dedup)
+        if (tid == 0) a.nsize[i] = 0;
+        return;
+    }
     // while the root's two dependent loads (query -> row pointer) are in flight: clear what does not depend on them
     // Slot ownership (clears, and the epilogue's member fetch): a lane owns the 4-slot chunks g = c*NT + tid, c < SPL/4 --
     // consecutive lanes on consecutive 16-byte words, so the 16-byte LDS accesses below are dense (a lane-contiguous

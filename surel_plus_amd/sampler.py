@@ -175,7 +175,7 @@ class SampledSets:
     extra: list = None           # values of prefetch(extra=...) once resolved
     _tail: torch.Tensor = None   # StepBuffers form: int64 [5] = [rows of the join (= members), status words x4], contiguous
     #                              ([6] with root dedup: + the number of distinct roots = rows that were sampled)
-    n_distinct: int = None       # StepBuffers(dedup_roots=True): rows 0 .. n_distinct-1 hold the batch's distinct endpoints
+    n_distinct: int = None       # StepBuffers(dedup_roots=True): so many rows (the first occurrences of the endpoints) hold sets
     keyrows: bool = False        # strided rows whose payload (`slot`) is the member's 32-bit LP key: no table, no numbering
     _resample: object = None     # keyrows: callable -> the same batch sampled with the table form (number() and friends)
 
@@ -231,7 +231,7 @@ class SampledSets:
                 raise _lib.SubgAccError(f"{c} distinct LP rows exceed the direct-ranking limit: sample with lazy=False")
             self.ukeys = self.ukeys[:c]
         if self.strided:
-            self._members = X if self.n_distinct is None else int(self.nsize[: self.n_distinct].sum().item())
+            self._members = X if self.n_distinct is None else int(self.nsize.sum().item())    # (rows of repeated endpoints: 0)
             return self
         self.ids = self.ids[:X]
         for name in ("slot", "keys", "data", "sf"):

@@ -13,6 +13,8 @@ import torch
 
 from . import _lib
 from ._lib import check, lib, ptr, stream_ptr
+
+NO_ROOT = -2 ** 31      # include/subgacc.h: SUBGACC_NO_ROOT
 from .sampler import _timed
 from .spg import SpG, StridedSpG
 
@@ -292,8 +294,9 @@ class StepBuffers:
     few-microsecond helper kernels sit between them (1,024 pairs: ~100 us of which the walk and the join are 55).
     Reuse is the caller's business: a buffer set is busy until its step has been resolved (bench.py alternates two).
     dedup_roots=True: every DISTINCT endpoint of the batch is sampled once (subgacc_step_prologue_dedup: a generation-stamped
-    hash of the endpoints, one more small launch; the walk kernel takes its root count from the device) -- Philox keys a walk
-    by its root's id, so (xz, indptr) do not change; the rows of the sets are then in order of arrival (sets.n_distinct of them).
+    hash of the endpoints names every node's first occurrence, one more small launch; the walk kernel runs over the list of
+    first occurrences) -- Philox keys a walk by its root's id, so (xz, indptr) do not change; the sets of the batch sit in the
+    rows of the first occurrences (sets.n_distinct of them; bufs.roots == NO_ROOT elsewhere), the other rows are empty.
     The hash is stamped with a per-step generation kept on the device: a captured step replays correctly."""
 
     def __init__(self, csr, pairs, num_walks=200, num_steps=3, uniq_capacity=1 << 17, out=None, dedup_roots=False):
@@ -320,6 +323,7 @@ class StepBuffers:
                 raise ValueError("StepBuffers(dedup_roots=True) needs a shape the fused-row walk kernel serves (2..4 hops, M <= 256)")
             self.own = torch.empty(n, dtype=torch.int64, device=dev)
             self.partner = torch.empty(n, dtype=torch.int64, device=dev)
+            self.worklist = torch.empty(n, dtype=torch.int32, device=dev)
             self.dedup_ws = torch.zeros(L.subgacc_step_dedup_workspace_bytes(n), dtype=torch.uint8, device=dev)
         self.ws = torch.empty(max(L.subgacc_sjoin_workspace_bytes(n), 8), dtype=torch.uint8, device=dev)
         self.feat = None if self.keyrows else torch.empty((self.capacity + 1, self.k), dtype=torch.float32, device=dev)
@@ -342,14 +346,14 @@ def _buffered_step(csr, e, bufs, seed, out):
     cfg = make_cfg(csr, M, m, -1, seed, "philox")
     check(L.subgacc_key_shift(cfg.num_walks, cfg.num_steps))
     kr = bufs.keyrows
-    if bufs.dedup:      # distinct endpoints only: rows in order of arrival, the segment lists point at them
+    if bufs.dedup:      # first occurrences only: the other rows stay empty, the segment lists point at the first occurrence
         check(L.subgacc_step_prologue_dedup(ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.status), 4, ptr(e), ptr(bufs.roots),
-                                            ptr(bufs.own), ptr(bufs.partner), n, ptr(bufs.dedup_ws), bufs.dedup_ws.numel(),
-                                            ptr(bufs.n_distinct), st))
+                                            ptr(bufs.own), ptr(bufs.partner), ptr(bufs.worklist), ptr(bufs.nsize), n,
+                                            ptr(bufs.dedup_ws), bufs.dedup_ws.numel(), ptr(bufs.n_distinct), st))
         with _timed("walk_sets"):
-            check(L.subgacc_walk_spg_n(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n, ptr(bufs.n_distinct),
-                                       ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize),
-                                       ptr(flags), st))
+            check(L.subgacc_walk_spg_sparse(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n,
+                                            ptr(bufs.worklist), ptr(bufs.n_distinct), ptr(bufs.table), 0 if kr else bufs.capacity,
+                                            ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize), ptr(flags), st))
         own, partner = bufs.own, bufs.partner
     else:
         check(L.subgacc_step_prologue(ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.status), 4, ptr(e), ptr(bufs.roots), n, st))
@@ -381,7 +385,9 @@ def _buffered_step(csr, e, bufs, seed, out):
     if kr:
         from .sampler import sample_sets
         sets.keyrows = True
-        sets._resample = lambda: sample_sets(csr, bufs.roots if sets.n_distinct is None else bufs.roots[: sets.n_distinct], M, m, -1,
+        # (root dedup: the first occurrences in batch order -- a repeated endpoint never is the first to show an LP row, so
+        # the numbering is the one of the whole batch)
+        sets._resample = lambda: sample_sets(csr, bufs.roots[bufs.roots != NO_ROOT] if bufs.dedup else bufs.roots, M, m, -1,
                                              seed, "philox", fused_rows=True, strided=True, number_rows=True, key_rows=False,
                                              uniq_capacity=bufs.capacity)
     sets.status, sets._tail = bufs.status, bufs.tail[n: n + (6 if bufs.dedup else 5)]

@@ -1002,9 +1002,10 @@ def test_attn_stage_trains_like_the_reference_first_stage(sp):
 
 @pytest.mark.parametrize("B,M,hops,idx64", [(2048, 200, 3, False), (700, 200, 2, False), (512, 100, 3, True), (300, 64, 4, False)])
 def test_step_with_root_dedup_equals_the_plain_step(sp, B, M, hops, idx64):
-    """StepBuffers(dedup_roots=True): every distinct endpoint sampled once (subgacc_step_prologue_dedup + subgacc_walk_spg_n) --
-    bit for bit the (xz, indptr) of the step that samples every endpoint, batch after batch through the same buffers (the
-    generation-stamped hash is never cleared), for batches full of repeated endpoints; the distinct count is exact"""
+    """StepBuffers(dedup_roots=True): every distinct endpoint sampled once, in the row of its first occurrence
+    (subgacc_step_prologue_dedup + subgacc_walk_spg_sparse) -- bit for bit the (xz, indptr) of the step that samples every
+    endpoint, batch after batch through the same buffers (the generation-stamped hash is never cleared), for batches full of
+    repeated endpoints; first occurrences, segment lists, distinct count and the numbering of the LP rows are exact"""
     ptr_, idx = sym_graph(3000, 40000, seed=23, hubs=3)
     csr = sp.DeviceCSR(ptr_.astype(np.int64) if idx64 else ptr_, idx)
     plain = sp.StepBuffers(csr, B, num_walks=M, num_steps=hops)
@@ -1021,12 +1022,17 @@ def test_step_with_root_dedup_equals_the_plain_step(sp, B, M, hops, idx64):
                                                 dedup_roots=True)
         dsets.prefetch().resolve()
         assert torch.equal(ind, dind) and torch.equal(xz[:R], dxz[:R])
-        uniq = torch.unique(e)
-        assert dsets.n_distinct == uniq.numel()
-        assert torch.equal(torch.sort(dd.roots[: dsets.n_distinct].long()).values, uniq)
-        assert dsets.X == int(dd.nsize[: dsets.n_distinct].sum().item()) and dsets.X <= sets.X
-        if s == 0 and dsets.keyrows:                         # what key rows do not carry is sampled again from the distinct roots
-            assert dsets.number().ukeys.numel() == sets.number().ukeys.numel()
+        flat = e.reshape(-1).cpu().numpy()
+        _, first_idx = np.unique(flat, return_index=True)
+        is_first = np.zeros(2 * B, bool)
+        is_first[first_idx] = True
+        roots = dd.roots.cpu().numpy()
+        assert dsets.n_distinct == len(first_idx)
+        assert np.array_equal(roots != -2 ** 31, is_first) and np.array_equal(roots[is_first], flat[is_first])
+        assert np.array_equal(dd.own.cpu().numpy(), np.array([np.flatnonzero(flat == v)[0] for v in flat]) if B <= 700 else dd.own.cpu().numpy())
+        assert dsets.X == int(dd.nsize.sum().item()) and dsets.X <= sets.X and int(dd.nsize[torch.from_numpy(~is_first).cuda()].sum()) == 0
+        if s in (0, 1):       # the distinct LP rows keep the numbering of the whole batch (a repeated root is never first to show a row)
+            assert torch.equal(dsets.number().ukeys, sets.number().ukeys)
     with pytest.raises(ValueError):
         sp.sample_and_gather(csr, e, num_walks=M, num_steps=hops, seed=9, rng="philox", buffers=plain, dedup_roots=True)
     # ... and as ONE captured HIP graph per step: the stamp of the hash lives on the device, every replay gets a fresh one
