@@ -325,12 +325,22 @@ class StepBuffers:
             self.partner = torch.empty(n, dtype=torch.int64, device=dev)
             self.worklist = torch.empty(n, dtype=torch.int32, device=dev)
             self.dedup_ws = torch.zeros(L.subgacc_step_dedup_workspace_bytes(n), dtype=torch.uint8, device=dev)
+            self.dedup_steps = 0
         self.ws = torch.empty(max(L.subgacc_sjoin_workspace_bytes(n), 8), dtype=torch.uint8, device=dev)
         self.feat = None if self.keyrows else torch.empty((self.capacity + 1, self.k), dtype=torch.float32, device=dev)
         need = n * self.stride * 2 * self.k
         if out is not None and (out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev or out.numel() < need):
             raise ValueError("StepBuffers: out= must hold 2B * (M*m+1) * 2 * (m+1) float32 on the graph's device")
         self.out = out if out is not None else torch.empty(need, dtype=torch.float32, device=dev)
+
+
+def _dedup_tick(bufs):
+    """the hash's 32-bit generation must never wrap (a stale stamp would outrank a fresh one): long before it could, the
+    workspace is zeroed again -- host side, once in 2^31 steps (every queued step of these buffers is behind it on the stream)"""
+    bufs.dedup_steps += 1
+    if bufs.dedup_steps >= (1 << 31):
+        bufs.dedup_ws.zero_()
+        bufs.dedup_steps = 0
 
 
 def _buffered_step(csr, e, bufs, seed, out):
@@ -347,6 +357,8 @@ def _buffered_step(csr, e, bufs, seed, out):
     check(L.subgacc_key_shift(cfg.num_walks, cfg.num_steps))
     kr = bufs.keyrows
     if bufs.dedup:      # first occurrences only: the other rows stay empty, the segment lists point at the first occurrence
+        if not torch.cuda.is_current_stream_capturing():
+            _dedup_tick(bufs)
         check(L.subgacc_step_prologue_dedup(ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.status), 4, ptr(e), ptr(bufs.roots),
                                             ptr(bufs.own), ptr(bufs.partner), ptr(bufs.worklist), ptr(bufs.nsize), n,
                                             ptr(bufs.dedup_ws), bufs.dedup_ws.numel(), ptr(bufs.n_distinct), st))

@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from .sampler import check_walk_flags, unpack_status
-from .spjoin import StepBuffers, sample_and_gather
+from .spjoin import StepBuffers, _dedup_tick, sample_and_gather
 
 
 class CapturedStep:
@@ -40,6 +40,7 @@ class CapturedStep:
                     raise
         elif dedup_roots:
             raise ValueError("dedup_roots=True needs the buffered form of the step (rng='philox', fused strided rows)")
+        self._dedup_bufs = self._kw["buffers"] if dedup_roots else None
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):                   # allocator steady state + lazy code-object loads, uncaptured
@@ -67,6 +68,8 @@ class CapturedStep:
         if tuple(edge.shape) != (2, self.B):
             raise ValueError(f"this step was captured for [2, {self.B}] pairs")
         self.edge.copy_(edge, non_blocking=True)
+        if self._dedup_bufs is not None:
+            _dedup_tick(self._dedup_bufs)
         self.graph.replay()
         if self._tail is not None:
             self._host.copy_(self._tail, non_blocking=True)
