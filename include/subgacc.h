@@ -354,10 +354,12 @@ int subgacc_sjoin_fill_keyrows(const int32_t *row_len, int64_t n_rows, int64_t r
  * = the LP key of member i's row of `enc` (key = sum_j count_j << ((num_steps - j) * SHIFT), bit num_steps*SHIFT set on a
  * root's own row, subg_acc.c:900-955) instead of SFptr+1.  For the reference's flow -- subg_matrix over all nodes once
  * (main.py:172-178), then one join per training batch (train.py:120-127) -- this takes the 16-byte gather from the Z_SF table
- * out of every output row: xz is bit-identical to subgacc_sjoin_fill with table = float32(enc) / num_walks (main.py:174). */
+ * out of every output row: xz is bit-identical to subgacc_sjoin_fill with table = float32(enc) / num_walks (main.py:174).
+ * out_segid (optional): int64 [R] segment id of every output row (hgather's second result, train.py:66-68). */
 int subgacc_sjoin_fill_keys(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices, const int32_t *spg_keys,
                             const int64_t *own, const int64_t *partner, int64_t S, const int64_t *seg, int32_t num_walks,
-                            int32_t num_steps, float *out_xz, int32_t max_len, int64_t pair_block, int32_t *flags, void *stream);
+                            int32_t num_steps, float *out_xz, int64_t *out_segid, int32_t max_len, int64_t pair_block,
+                            int32_t *flags, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Prologue of one on-demand step (sample both endpoints of B query pairs -> rows -> SpJoin; train.py:120-127 calls the

@@ -111,7 +111,7 @@ def lib():
     sig["subgacc_hop_records_format"] = (C.c_int, [i64, i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)])
     sig["subgacc_hop_records_build"] = (C.c_int, [vp, i32, vp, i64, i64, i32, i32, vp, vp])
     sig["subgacc_sjoin_fill_keyrows"] = (C.c_int, [vp, i64, i64, vp, vp, vp, vp, i64, vp, i32, i32, vp, i64, vp, vp])
-    sig["subgacc_sjoin_fill_keys"] = (C.c_int, [vp, i64, vp, vp, vp, vp, i64, vp, i32, i32, vp, i32, i64, vp, vp])
+    sig["subgacc_sjoin_fill_keys"] = (C.c_int, [vp, i64, vp, vp, vp, vp, i64, vp, i32, i32, vp, vp, i32, i64, vp, vp])
     sig["subgacc_step_dedup_workspace_bytes"] = (C.c_size_t, [i64])
     sig["subgacc_step_prologue_dedup"] = (C.c_int, [vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, C.c_size_t, vp, vp])
     sig["subgacc_walk_spg_sparse"] = (C.c_int, [cfgp, vp, vp, i64, vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp])

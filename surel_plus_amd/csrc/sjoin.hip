@@ -800,7 +800,7 @@ static int launch_key_join(JoinArgs &a, int32_t num_walks, int32_t num_steps, in
     SG_REQUIRE(num_steps * shift + 1 <= 31 && num_steps + 1 <= 16, SUBGACC_ERR_KEYWIDTH,
                "%s: LP keys of %d steps x %d bits do not fit 32 bits", who, num_steps, shift);
     a.table = nullptr, a.table_rows = 0, a.k = num_steps + 1;
-    a.out_idx = nullptr, a.out_segid = nullptr;
+    a.out_idx = nullptr;
     a.slot_id = nullptr, a.val_add = 0;
     a.key_M = num_walks, a.key_m = num_steps, a.key_shift = shift;
     const size_t lds = (size_t)a.max_len * 16 + (size_t)(num_walks + 2) * 4 +
@@ -838,7 +838,7 @@ extern "C" int subgacc_sjoin_fill_keyrows(const int32_t *row_len, int64_t n_rows
     JoinArgs a;
     a.indptr = nullptr, a.indices = row_ids, a.data = row_keys;
     a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
-    a.out_xz = out_xz;
+    a.out_xz = out_xz, a.out_segid = nullptr;
     a.max_len = (int32_t)row_stride;
     a.flags = flags;
     a.row_len = row_len, a.row_stride = row_stride;
@@ -847,8 +847,8 @@ extern "C" int subgacc_sjoin_fill_keyrows(const int32_t *row_len, int64_t n_rows
 
 extern "C" int subgacc_sjoin_fill_keys(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,
                                        const int32_t *spg_keys, const int64_t *own, const int64_t *partner, int64_t S,
-                                       const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz, int32_t max_len,
-                                       int64_t pair_block, int32_t *flags, void *stream) {
+                                       const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz,
+                                       int64_t *out_segid, int32_t max_len, int64_t pair_block, int32_t *flags, void *stream) {
     SG_REQUIRE(S >= 0 && flags && n_rows >= 0 && max_len >= 0, SUBGACC_ERR_BADARG, "sjoin_fill_keys: bad arguments");
     if (S == 0) return subgacc_key_shift(num_walks, num_steps) < 0 ? subgacc_key_shift(num_walks, num_steps) : SUBGACC_OK;
     SG_REQUIRE(spg_indptr && spg_indices && spg_keys && own && partner && seg && out_xz, SUBGACC_ERR_BADARG,
@@ -858,7 +858,7 @@ extern "C" int subgacc_sjoin_fill_keys(const int64_t *spg_indptr, int64_t n_rows
     JoinArgs a;
     a.indptr = spg_indptr, a.indices = spg_indices, a.data = spg_keys;
     a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
-    a.out_xz = out_xz;
+    a.out_xz = out_xz, a.out_segid = out_segid;
     a.max_len = max_len > 0 ? max_len : 1;
     a.flags = flags;
     a.row_len = nullptr, a.row_stride = 0;

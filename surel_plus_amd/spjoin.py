@@ -71,8 +71,8 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
     is_f64 = spg.data.dtype == torch.float64
     if getattr(spg, "keyrows", False):       # SpG.keyed(): the payload is the LP key, the join unpacks it (no table)
         from .spg import KEY_ROWS_ENCODE
-        if encode is not KEY_ROWS_ENCODE or return_index or not ptr_mode or pair_block <= 0:
-            raise ValueError("a keyed() store is joined by gather(edge, zk, encode=zk.slot_table(), ptr=True)")
+        if encode is not KEY_ROWS_ENCODE or return_index or pair_block <= 0 or (lazy and not ptr_mode):
+            raise ValueError("a keyed() store is joined by gather / hgather(…, encode=zk.slot_table())")
         k = spg.key_m + 1
         R = None if lazy else _size_and_row_check(seg, S, flags, spg.n_rows)
         if lazy:
@@ -87,10 +87,12 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
             res = out.view(-1)[: R * 2 * k].view(R, 2, k)
         else:
             res = torch.empty((R, 2, k), dtype=torch.float32, device=dev)
+        segid = None if ptr_mode else torch.empty(R, dtype=torch.int64, device=dev)
         with _timed("sjoin_fill"):
             check(L.subgacc_sjoin_fill_keys(ptr(spg.indptr), spg.n_rows, ptr(spg.indices), ptr(spg.data), ptr(own), ptr(partner), S,
-                                            ptr(seg), spg.key_M, spg.key_m, ptr(res), spg.max_len, pair_block, ptr(flags), st))
-        return res, seg, flags
+                                            ptr(seg), spg.key_M, spg.key_m, ptr(res), ptr(segid), spg.max_len, pair_block,
+                                            ptr(flags), st))
+        return res, (seg if ptr_mode else segid), flags
     if lazy and (out is None or not ptr_mode or return_index or is_f64 or encode is None):
         raise ValueError("lazy=True needs out=, ptr=True and an integer SpG with its encode table")
     R = None if lazy else _size_and_row_check(seg, S, flags, spg.n_rows)     # the one host round trip

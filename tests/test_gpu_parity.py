@@ -1072,7 +1072,14 @@ def test_keyed_store_joins_like_the_table_join(sp, M, hops):
     buf = torch.empty(int(xz.numel()) + 64, dtype=torch.float32, device="cuda")
     bxz, _ = sp.gather(edge, zk, "cuda", ptr=True, encode=zk.slot_table(), out=buf)
     assert torch.equal(bxz, xz) and bxz.data_ptr() == buf.data_ptr()
-    for bad in (lambda: sp.gather(edge, zk, "cuda", ptr=True, encode=table), lambda: sp.gather(edge, zk, "cuda", ptr=False, encode=zk.slot_table()),
+    sxz, sid = sp.gather(edge, z, "cuda", ptr=False, encode=table)                 # segment ids instead of pointers
+    ksxz, ksid = sp.gather(edge, zk, "cuda", ptr=False, encode=zk.slot_table())
+    assert torch.equal(sid, ksid) and torch.equal(sxz, ksxz)
+    hedge = torch.from_numpy(np.random.default_rng(6).integers(0, 4000, (3, 500))).cuda()     # hgather (train.py:48-72)
+    hxz, hid = sp.hgather(hedge, z, "cuda", encode=table)
+    khxz, khid = sp.hgather(hedge, zk, "cuda", encode=zk.slot_table())
+    assert torch.equal(hid, khid) and torch.equal(hxz, khxz)
+    for bad in (lambda: sp.gather(edge, zk, "cuda", ptr=True, encode=table),
                 lambda: sp.gather_counts(edge, zk, table.shape[0]), lambda: sp.gather_pairs(edge, zk)):
         with pytest.raises((ValueError, TypeError)):
             bad()
