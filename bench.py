@@ -485,12 +485,13 @@ def batch_size_and_graph(sp, csr, M, k, rng, K):
     for B in (1024, 65536):
         steps = max(K, 64) if B == 1024 else K
         edges = [query_pairs(csr, B, seed=7000 + s, device=csr.device) for s in range(steps + 3)]
-        for mode in ("eager", "graph", "graph, 2 lanes", "graph, 4 lanes", "graph, 8 lanes"):
+        for mode in ("eager", "graph", "graph, 2 lanes", "graph, 4 lanes", "graph, 8 lanes", "graph, 8 lanes, inputs ready"):
             try:
                 _XZ_BUF.clear()
                 _STEP_BUFS.clear()
                 torch.cuda.empty_cache()
                 lanes = int(mode.split()[1]) if "lanes" in mode else 0
+                ready = "inputs ready" in mode        # the batches were produced (and synchronised) long ago: submit(sync=False)
                 kw = dict(num_walks=M, num_steps=k - 1, seed=1, rng=rng, uniq_capacity=UNIQ_CAPACITY)
                 # stepgraph.CapturedStepPool: `lanes` captured steps replayed on their own streams -- the dozen
                 # few-microsecond kernels of one step run under the walk kernels of the others (a 1,024-pair step does
@@ -505,7 +506,7 @@ def batch_size_and_graph(sp, csr, M, k, rng, K):
                         if pool is not None:
                             if len(pending) == lanes:
                                 pool.finish(pending.pop(0))
-                            pending.append(pool.submit(e))
+                            pending.append(pool.submit(e, sync=not ready))
                             continue
                         q = caps[s & 1](e) if caps is not None else hot_path_step(sp, csr, e, M, k, seed=1, rng=rng, slot=s & 1)
                         pending.append(q)

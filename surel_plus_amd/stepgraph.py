@@ -48,35 +48,51 @@ class CapturedStep:
                 self._queue()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        # what finish() needs: the packed status of the sets (flags, distinct LP rows, members) and the join's row count --
+        # with StepBuffers they sit next to each other ([rows, status x4(, distinct roots)]) and their copy to pinned host
+        # memory is a node of the graph: a replay costs the host one launch, not one launch and one copy
+        bufs = self._kw.get("buffers")
+        tail_n = (6 if dedup_roots else 5) if bufs is not None else 0
+        self._host = torch.empty(tail_n if tail_n else 5, dtype=torch.int64, pin_memory=True)
+        self._copy_in_graph = False
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.xz, self.ind, self.sets = self._queue()
-        # what finish() needs: the packed status of the sets (flags, distinct LP rows, members) and the join's row count
+            if self.sets._tail is not None and self.sets._tail.numel() == self._host.numel():
+                self._host.copy_(self.sets._tail, non_blocking=True)
+                self._copy_in_graph = True
         self.status, self._rows = self.sets.status, self.ind[-1:]
         self._tail = self.sets._tail          # StepBuffers: [rows, status x4] contiguous -> one copy
-        self._host = torch.empty(self._tail.numel() if self._tail is not None else self.status.numel() + 1, dtype=torch.int64,
-                                 pin_memory=True)
+        if self._tail is None and self._host.numel() != self.status.numel() + 1:
+            self._host = torch.empty(self.status.numel() + 1, dtype=torch.int64, pin_memory=True)
         self.distinct_roots = None
         self._event = torch.cuda.Event()
 
     def _queue(self):
         return sample_and_gather(self.csr, self.edge, **self._kw)
 
-    def __call__(self, edge):
+    def __call__(self, edge, stream=None):
         """queue one step for `edge` [2, B] (node ids, on the device): copy-in, graph replay, status on its way to
-        pinned host memory.  Nothing waits for the GPU here."""
+        pinned host memory.  Nothing waits for the GPU here.  stream: the current stream, if the caller has it at hand
+        (spares torch's look-up of it, ~8 us)."""
         if tuple(edge.shape) != (2, self.B):
             raise ValueError(f"this step was captured for [2, {self.B}] pairs")
-        self.edge.copy_(edge, non_blocking=True)
+        if edge is not self.edge:
+            self.edge.copy_(edge, non_blocking=True)
         if self._dedup_bufs is not None:
             _dedup_tick(self._dedup_bufs)
         self.graph.replay()
-        if self._tail is not None:
+        if self._copy_in_graph:
+            pass
+        elif self._tail is not None:
             self._host.copy_(self._tail, non_blocking=True)
         else:
             self._host[:-1].copy_(self.status, non_blocking=True)
             self._host[-1:].copy_(self._rows, non_blocking=True)
-        self._event.record()
+        if stream is None:
+            self._event.record()
+        else:
+            self._event.record(stream)
         return self
 
     def finish(self):
@@ -117,16 +133,25 @@ class CapturedStepPool:
         self.streams = [torch.cuda.Stream(device=csr.device) for _ in self.steps]
         self._busy = [False] * len(self.steps)
         self._next = 0
+        self._caller = torch.cuda.current_stream(csr.device)     # looked up once: torch's stream bookkeeping costs ~6 us a call
 
-    def submit(self, edge):
+    def submit(self, edge, stream=None, sync=True):
+        """stream: the stream `edge` was produced on, if it is not the one this pool was created on.  sync=False: `edge` is
+        known to be complete (produced and synchronised earlier): the lane does not wait for the caller's stream (~10 us of
+        host time).  edge may be `pool.steps[lane].edge` itself (filled in place by the caller): no copy then."""
         i = self._next
         if self._busy[i]:
             raise RuntimeError("every lane is in flight: finish() the oldest batch before submitting another")
         self._next = (i + 1) % len(self.steps)
         st = self.streams[i]
-        st.wait_stream(torch.cuda.current_stream(edge.device))      # `edge` may have been produced on the caller's stream
-        with torch.cuda.stream(st):
-            self.steps[i](edge)
+        caller = self._caller if stream is None else stream
+        if sync:
+            st.wait_stream(caller)                     # `edge` may have been produced on the caller's stream just now
+        torch.cuda.set_stream(st)                      # (not `with torch.cuda.stream(st)`: it asks for the current stream twice)
+        try:
+            self.steps[i](edge, stream=st)
+        finally:
+            torch.cuda.set_stream(caller)
         self._busy[i] = True
         return i
 
