@@ -347,7 +347,6 @@ def _dedup_tick(bufs):
 
 def _buffered_step(csr, e, bufs, seed, out):
     """sample_and_gather through a StepBuffers: six launches, nothing allocated, nothing read back"""
-    from . import _lib as lib_mod
     from .sampler import SampledSets, _timed, make_cfg
     L, st, dev = lib(), stream_ptr(), csr.device
     B, M, m, k, n = bufs.B, bufs.M, bufs.m, bufs.k, 2 * bufs.B
@@ -420,7 +419,7 @@ def sample_and_gather(csr, edge, num_walks=200, num_steps=3, seed=111413, rng="p
     strided=None picks the joined-in-place form where the fused walk kernel is the faster one (spg.prefers_fused).
     buffers=StepBuffers(...): the same step without a single allocation or helper kernel (six launches; the result is
     lazy: sets.prefetch() / sets.resolve() as with lazy=True, xz is a view of out= or of the buffers' own output)."""
-    from .spg import prefers_fused, sample_spg
+    from .spg import sample_spg
     e = _as_rows(edge, csr.device)
     B = e.shape[1]
     if buffers is not None:     # the allocation-free form of a serving loop: same rows, same (xz, indptr), lazily resolved
