@@ -41,7 +41,7 @@ int main(int argc, char **argv) {
     SYM(subgacc_walk_sets); SYM(subgacc_scan_workspace_bytes); SYM(subgacc_exclusive_scan_i32); SYM(subgacc_compact_sets);
     SYM(subgacc_uniq_table_bytes); SYM(subgacc_uniq_reset); SYM(subgacc_uniq_number_workspace_bytes);
     SYM(subgacc_uniq_number); SYM(subgacc_spg_build); SYM(subgacc_sjoin_workspace_bytes); SYM(subgacc_sjoin_sizes);
-    SYM(subgacc_sjoin_fill); SYM(subgacc_unpack_lp);
+    SYM(subgacc_sjoin_fill); SYM(subgacc_unpack_lp); SYM(subgacc_sjoin_fill_keys);
     CHECK(p_subgacc_abi_version() == SUBGACC_ABI_VERSION);
     CHECK(p_subgacc_device_count() >= 1);
     CHECK(p_subgacc_key_shift(8, 2) == 4);
@@ -120,6 +120,22 @@ int main(int argc, char **argv) {
             for (int j = 0; j <= m; ++j) col[j] += tab_h[zd[e] * (m + 1) + j];
         }
         for (int j = 0; j <= m; ++j) CHECK(col[j] > 0.999f && col[j] < 1.001f);  /* every LP column sums to M (/M) */
+    }
+    /* the same join from the store re-keyed on the host (payload = the member's LP key = the low word of its row's 64-bit key):
+     * subgacc_sjoin_fill_keys unpacks the feature rows itself -- bit for bit the table join's xz */
+    {
+        uint64_t *uk_h = malloc(c * 8);
+        int32_t *zk_h = malloc(X * 4);
+        HIP(hipMemcpy(uk_h, ukeys, c * 8, hipMemcpyDeviceToHost));
+        for (int64_t e = 0; e < X; ++e) zk_h[e] = (int32_t)(uint32_t)uk_h[zd[e] - 1];
+        int32_t *z_key = dev(X * 4, zk_h);
+        float *xz2 = dev(R * 2 * (m + 1) * 4, NULL), *xz2_h = malloc(R * 2 * (m + 1) * 4);
+        CHECK(p_subgacc_sjoin_fill_keys(row_off, n, z_idx, z_key, own, partner, 4, seg, M, m, xz2, NULL, STRIDE, 2, flags, NULL) == 0);
+        HIP(hipDeviceSynchronize());
+        HIP(hipMemcpy(xz2_h, xz2, R * 2 * (m + 1) * 4, hipMemcpyDeviceToHost));
+        CHECK(memcmp(xz_h, xz2_h, R * 2 * (m + 1) * 4) == 0);
+        HIP(hipMemcpy(fl, flags, 16, hipMemcpyDeviceToHost));
+        CHECK(fl[3] == 0);
     }
     /* rows 1 and 2 are the same set (Philox is keyed by the root id): joined with each other both slots agree */
     CHECK(ns_h[1] == ns_h[2]);
