@@ -1,6 +1,7 @@
 """Dev-only: randomized parity sweep, HIP path vs oracle, bit-exact (usage: fuzz_parity.py [cases] [seed]).
 Every case draws a graph shape (incl. hubs, isolated nodes, directed), M, m, bucket, RNG mode, query (repeats, arbitrary
-order) and checks gset_sampler, the fused / general / strided SpG paths, walk_sampler and gather against the oracle."""
+order) and checks gset_sampler, the fused / general / strided SpG paths, key rows, the buffered on-demand step (with and
+without root dedup), walk_sampler, the PPR sampler and gather against the oracle."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["SUBGACC_QUIET"] = "1"
@@ -84,6 +85,22 @@ for c in range(cases):
                 fails.append("gather(key rows)")
             if not np.array_equal(sk.enc_int16().cpu().numpy(), b[2]):      # numbering on demand (sampled again)
                 fails.append("enc(key rows)")
+        # the on-demand step over preallocated buffers, every endpoint sampled / every DISTINCT endpoint sampled once (Philox:
+        # a node's set does not depend on where it stands), against the oracle's join of the same nodes' rows
+        if rng == "philox" and bucket <= 0:
+            for dd in (False, True):
+                try:
+                    bufs = sp.StepBuffers(csr, edge.shape[1], num_walks=M, num_steps=m, dedup_roots=dd)
+                except ValueError:
+                    break
+                cov["buffered"] = cov.get("buffered", 0) + 1
+                e_nodes = torch.from_numpy(np.asarray(q)[edge].astype(np.int64)).cuda()
+                bx, bi, bs = sp.sample_and_gather(csr, e_nodes, num_walks=M, num_steps=m, seed=seed, rng="philox", buffers=bufs,
+                                                  dedup_roots=dd)
+                bs.prefetch().resolve()
+                R = int(bi[-1].item())
+                if not (np.array_equal(bi.cpu().numpy(), wind) and np.array_equal(bx[:R].cpu().numpy(), wxz)):
+                    fails.append(f"buffered step (dedup_roots={dd})")
         T = int(rng0.choice([1, 3]))
         rep = bool(rng0.integers(0, 2))
         w1, o1 = sp.walk_sampler(ptr_, idx, q, num_walks=M, num_steps=m, nthread=T, seed=seed, replacement=rep, rng=rng)
