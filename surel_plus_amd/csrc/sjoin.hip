@@ -325,8 +325,8 @@ constexpr int kPairThreads = 256;
 #define SJ_PAIR_THREADS 128   // 128 lanes per pair: twice the pairs with their row loads in flight per CU (-4..6 % against 256, r02s)
 #endif
 constexpr int kPairEmit = SJ_PAIR_THREADS;
-template <bool F64, int KV, bool KEYS = false>
-__global__ __launch_bounds__(kPairEmit) void sjoin_pair_kernel(const JoinArgs a, int64_t pb) {
+template <bool F64, int KV, bool KEYS = false, int NT = kPairEmit>
+__global__ __launch_bounds__(NT) void sjoin_pair_kernel(const JoinArgs a, int64_t pb) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using Val = typename std::conditional<F64, double, int32_t>::type;
     Val *valA = (Val *)lds_raw;                       // [max_len]
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(kPairEmit) void sjoin_pair_kernel(const JoinArgs a,
     float *lut = (float *)(idsB + a.max_len);         // KEYS: [key_M + 1] count -> count / num_walks (IEEE division, main.py:174)
     float *stage = lut + ((a.key_M + 2) & ~1) + (threadIdx.x / kWave) * kWave * 2 * a.k;   // KEYS: [64 rows][2k] per wave (8-byte aligned)
     if (KEYS)
-        for (int c = threadIdx.x; c <= a.key_M; c += kPairEmit) lut[c] = (float)c / (float)a.key_M;
+        for (int c = threadIdx.x; c <= a.key_M; c += NT) lut[c] = (float)c / (float)a.key_M;
 
     const int64_t wg = xcd_item(blockIdx.x, gridDim.x);
     const int64_t p = wg / a.split;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(kPairEmit) void sjoin_pair_kernel(const JoinArgs a,
     const int na = (int)na64, nb = (int)nb64;
     const Val *data = (const Val *)a.data;
     const bool xl = !F64 && a.slot_id != nullptr;    // strided rows carry table slots: SFptr+1 on the way into LDS
-    for (int r = tid; r < na; r += kPairEmit) {
+    for (int r = tid; r < na; r += NT) {
 #if SJ_EXPERIMENT == 4   // timing experiment: no row loads from HBM (results are wrong)
         idsA[r] = (int32_t)(ra & 1023) + 3 * r;
         valA[r] = (Val)(r & 127);
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(kPairEmit) void sjoin_pair_kernel(const JoinArgs a,
         valA[r] = v;
     }
     if (ra != rb) {
-        for (int r = tid; r < nb; r += kPairEmit) {
+        for (int r = tid; r < nb; r += NT) {
 #if SJ_EXPERIMENT == 4
             idsB[r] = (int32_t)(rb & 1023) + 2 * r;
             valB[r] = (Val)(r & 127);
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(kPairEmit) void sjoin_pair_kernel(const JoinArgs a,
     const int k = a.k, k2 = 2 * k;
     const uint32_t magic = k2 > 0 ? ((1u << 20) + (uint32_t)k2 - 1u) / (uint32_t)k2 : 0u;
     const int chunksA = (na + kWave - 1) / kWave, chunksB = (nb + kWave - 1) / kWave;
-    for (int c = wave + part * (kPairEmit / kWave); c < chunksA + chunksB; c += a.split * (kPairEmit / kWave)) {   // every wave takes whole 64-row spans
+    for (int c = wave + part * (NT / kWave); c < chunksA + chunksB; c += a.split * (NT / kWave)) {   // every wave takes whole 64-row spans
         if (c < chunksA)
             emit_rows<F64, KV, Val, KEYS>(a, lane, idsA, valA, na, idsB, valB, nb, (int64_t)c * kWave, oA, j, k, k2, magic, lut, stage);
         else
@@ -717,7 +717,12 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, int64_t n_rows, con
                            pair_block);                                                                           \
     } while (0)
     if (paired) {
-        if (f64) SG_PAIR_LAUNCH(true, 0);
+        if (f64 && a.max_len <= 2 * kWave) {
+            // short float rows (the top-100 PPR store): ONE wave per pair -- twice the pairs in flight per CU for a kernel whose
+            // workgroups live on a chain of dependent loads, not on bandwidth (cit2-PPR join 0.154 -> 0.139 ms; integer rows
+            // with their 6-10 KB of LDS per pair are slower this way: collab 0.175 -> 0.20 ms)
+            hipLaunchKernelGGL((sjoin_pair_kernel<true, 0, false, kWave>), dim3((unsigned)grid), dim3(kWave), lds, s, a, pair_block);
+        } else if (f64) SG_PAIR_LAUNCH(true, 0);
         else if (vec4) SG_PAIR_LAUNCH(false, 4);
         else SG_PAIR_LAUNCH(false, 0);
         SG_LAUNCH_CHECK();

@@ -58,7 +58,7 @@ def main():
                                     "--no-cpu-baseline", "--no-others"] + extra, env=env, capture_output=True, text=True)
                 try:
                     d = json.loads(p.stdout.strip().splitlines()[-1])
-                    st = {k: round(x, 4) for k, x in d["config"]["stage_ms"].items() if x}
+                    st = {k: round(x, 4) for k, x in (d["config"].get("stage_ms") or {}).items() if x}
                     print(f"[{name}] {w}: step {d['ms_per_step']:.4f} ms  {d['value'] / 1e6:.2f} M pairs/s  {st}", flush=True)
                 except Exception:
                     print(f"[{name}] {w}: FAILED rc={p.returncode} {p.stderr[-400:]}", flush=True)
