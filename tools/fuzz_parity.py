@@ -18,6 +18,8 @@ t0 = time.time()
 for c in range(cases):
     if only is not None and c != only:
         continue
+    if c and c % 1000 == 0:       # a long sweep says that it is alive (the GPU box kills a command that is silent for 7 minutes)
+        print(f"... {c} cases, {bad} bad, {time.time() - t0:.0f} s", flush=True)
     rng0 = np.random.default_rng([seed0, c])                     # every case has its own stream: reproducible alone
     fails = []
     N = int(rng0.choice([50, 300, 2000, 9000]))
