@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SUBGACC_ABI_VERSION 3
+#define SUBGACC_ABI_VERSION 4
 
 typedef enum subgacc_status {
     SUBGACC_OK = 0,
@@ -401,6 +401,43 @@ int subgacc_walk_spg_sparse(const subgacc_walk_cfg *cfg, const void *indptr, con
                             const int32_t *query, int64_t n, const int32_t *worklist, const int64_t *n_work, void *uniq_table,
                             int64_t uniq_capacity, int32_t *row_ids, int32_t *row_slot, int32_t *nsize, int32_t *flags,
                             void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ABI 4 -- batched registration of key rows: the table of distinct LP rows (subg_acc.c:957-978) for a store that is KEPT
+ * (subg_matrix, sampler/random_walks.py:74-82; main.py:172-178 samples all N nodes once), built from the rows of the fast
+ * key-rows form of subgacc_walk_spg (uniq_table = NULL) instead of inside every root's walk:
+ *   1. subgacc_keyrows_register: one pass over the rows' 32-bit LP keys (row i = row_keys[i*stride, +nsize[i])); every
+ *      distinct key of a row goes to `uniq_table` with the COARSE tag (root_base+i)*stride + stride-1, and the rows whose
+ *      insert lowered a key's tag -- the candidates for a key's first appearance, always including the true one -- are
+ *      listed in cand[0 .. *n_cand) (int32 row numbers in arrival order; cand holds n entries, *n_cand is a device counter
+ *      the caller zeroes);
+ *   2. subgacc_walk_tags: the candidates alone (worklist = cand, *n_work = *n_cand; the launch covers min(n, work_cap)
+ *      rows, work_cap = 0: n; a longer list raises flags[3] |= 32) are walked again by the table form of the fused-row
+ *      kernel, which lowers their keys' tags to the exact (root_base+i)*stride + first-visit number and writes nothing
+ *      else -- after it every distinct key carries the tag subgacc_walk_spg(uniq_table) would have given it, and
+ *      subgacc_uniq_number numbers the table like the reference's sequential pass;
+ *   3. subgacc_keyrows_compact: strided key rows -> packed rows at row_off[i] (the CSR copy of the store).  With `ukeys`
+ *      (out_ukeys / out_count / max_unique of subgacc_uniq_number: one chunk of roots -- steps 1, 2, the numbering, then
+ *      this) the payload is SFptr+1, looked up on the way.  With ukeys = NULL (a job of several chunks, numbered at the
+ *      end) the pass registers the chunk's keys itself (as step 1, candidates listed; step 2 follows) and keeps the KEY as
+ *      payload; subgacc_keyrows_translate turns the packed payloads of all chunks into SFptr+1 once the table is numbered
+ *      (n_dev, optional: only the first min(n, *n_dev) entries).
+ * Shapes: what the key-rows form of subgacc_walk_spg serves (num_steps*SHIFT+1 <= 31, 2 or 3 hops, M <= 256, no bucket).
+ * rng_pos / rng_seed as for subgacc_walk_spg (RAND_R: positions of ALL n roots of the chunk; row i reads entry i).
+ * ------------------------------------------------------------------------------------------- */
+int subgacc_keyrows_register(const int32_t *row_keys, const int32_t *nsize, int64_t n, int32_t stride, int64_t root_base,
+                             void *uniq_table, int64_t uniq_capacity, int32_t *cand, int64_t *n_cand, int32_t *flags,
+                             void *stream);
+int subgacc_walk_tags(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,
+                      const int32_t *query, int64_t n, int64_t root_base, const uint32_t *rng_pos, const uint32_t *rng_seed,
+                      const int32_t *worklist, const int64_t *n_work, int64_t work_cap, void *uniq_table,
+                      int64_t uniq_capacity, int32_t *flags, void *stream);
+int subgacc_keyrows_compact(const int32_t *row_ids, const int32_t *row_keys, const int32_t *nsize, const int64_t *row_off,
+                            int64_t n, int32_t stride, int64_t root_base, void *uniq_table, int64_t uniq_capacity,
+                            const uint64_t *ukeys, const int64_t *n_ukeys, int64_t max_ukeys, int32_t *out_indices,
+                            int32_t *out_data, int32_t *cand, int64_t *n_cand, int32_t *flags, void *stream);
+int subgacc_keyrows_translate(int32_t *data_inout, int64_t n, const int64_t *n_dev, void *uniq_table, int64_t uniq_capacity,
+                              const uint64_t *ukeys, const int64_t *n_ukeys, int64_t max_ukeys, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * batch_sampler of the legacy SUREL surface (subg_acc/subg_acc.c:391-507): one insertion-ordered set of nodes grown by

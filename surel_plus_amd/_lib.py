@@ -33,6 +33,7 @@ SYMBOLS = (
     "subgacc_batch_sampler_workspace_bytes", "subgacc_batch_sampler", "subgacc_step_prologue",
     "subgacc_hop_records_format", "subgacc_hop_records_build", "subgacc_sjoin_fill_keyrows", "subgacc_sjoin_fill_keys", "subgacc_step_dedup_workspace_bytes",
     "subgacc_step_prologue_dedup", "subgacc_walk_spg_sparse",
+    "subgacc_keyrows_register", "subgacc_walk_tags", "subgacc_keyrows_compact", "subgacc_keyrows_translate",
 )
 
 
@@ -124,12 +125,16 @@ def lib():
     sig["subgacc_encode_fill"] = (C.c_int, [vp, vp, vp, i64, i32, vp, i32, vp, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp])
     sig["subgacc_sjoin_pairs"] = (C.c_int, [vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, i64, vp, vp])
     sig["subgacc_finish_rows"] = (C.c_int, [vp, vp, vp, i64, i32, i64, vp, i64, vp, vp, vp])
+    sig["subgacc_keyrows_register"] = (C.c_int, [vp, vp, i64, i32, i64, vp, i64, vp, vp, vp, vp])
+    sig["subgacc_walk_tags"] = (C.c_int, [cfgp, vp, vp, i64, vp, i64, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp])
+    sig["subgacc_keyrows_compact"] = (C.c_int, [vp, vp, vp, vp, i64, i32, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp])
+    sig["subgacc_keyrows_translate"] = (C.c_int, [vp, i64, vp, vp, i64, vp, vp, i64, vp])
     assert set(sig) == set(SYMBOLS)
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    if L.subgacc_abi_version() != 3:
+    if L.subgacc_abi_version() != 4:
         raise SubgAccError("libsubgacc_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -735,7 +735,8 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
                        const int32_t *query, int64_t n, const uint32_t *rng_pos, const uint32_t *rng_seed,
                        int32_t *set_ids, uint64_t *set_keys, int32_t *set_slot, void *uniq_table, int64_t uniq_capacity,
                        int64_t root_base, int32_t *nsize, int32_t *walks, int32_t *flags, void *stream,
-                       bool holes = false, const int32_t *worklist = nullptr, const int64_t *n_work = nullptr) {
+                       bool holes = false, const int32_t *worklist = nullptr, const int64_t *n_work = nullptr,
+                       bool tags_only = false, int64_t work_cap = 0) {
     const bool spg = set_slot != nullptr;
     SG_REQUIRE(cfg && indptr && set_ids && (set_keys || spg) && nsize && flags, SUBGACC_ERR_BADARG,
                "walk: null argument");
@@ -766,6 +767,7 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
     WalkArgs a;
     a.indptr = indptr, a.indices = indices, a.query = query, a.n = n, a.num_nodes = num_nodes;
     a.worklist = worklist, a.n_work = n_work;
+    a.work_cap = work_cap, a.tags_only = tags_only ? 1 : 0;
     a.rng_pos = rng_pos, a.rng_seed = rng_seed;
     a.set_ids = set_ids, a.set_keys = set_keys, a.nsize = nsize;
     a.walks = cfg->emit_walks ? walks : nullptr;
@@ -807,6 +809,9 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
         SG_LAUNCH_CHECK();
         return SUBGACC_OK;
     }
+    SG_REQUIRE(!tags_only, SUBGACC_ERR_BADARG,
+               "walk_tags: only the fused-row kernel registers tags alone (2..4 hops, M <= 256, a 512- or 1,024-slot table, no "
+               "bucket); M = %d, m = %d", M, m);
     SG_REQUIRE(!holes, SUBGACC_ERR_BADARG,
                "walk_spg_sparse: rows without a root are passed over by the fused-row kernel only (2..4 hops, M <= 256, a 512- or "
                "1,024-slot table, no bucket); M = %d, m = %d", M, m);
@@ -872,6 +877,19 @@ extern "C" int subgacc_walk_spg_sparse(const subgacc_walk_cfg *cfg, const void *
                SUBGACC_ERR_BADARG, "walk_spg_sparse: set_sampler order, Philox mode (a root's set must not depend on its place in the batch)");
     return launch_walk(cfg, indptr, indices, num_nodes, query, n, nullptr, nullptr, row_ids, nullptr, row_slot, uniq_table,
                        uniq_capacity, 0, nsize, nullptr, flags, stream, true, worklist, n_work);
+}
+
+extern "C" int subgacc_walk_tags(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,
+                                 const int32_t *query, int64_t n, int64_t root_base, const uint32_t *rng_pos, const uint32_t *rng_seed,
+                                 const int32_t *worklist, const int64_t *n_work, int64_t work_cap, void *uniq_table,
+                                 int64_t uniq_capacity, int32_t *flags, void *stream) {
+    SG_REQUIRE(worklist && n_work && uniq_table && work_cap >= 0, SUBGACC_ERR_BADARG, "walk_tags: needs a work list, its length and a table");
+    SG_REQUIRE(cfg && !cfg->emit_walks && cfg->order == SUBGACC_ORDER_WALK_MAJOR && cfg->bucket <= 0, SUBGACC_ERR_BADARG,
+               "walk_tags: set_sampler order, no raw walks, no bucket");
+    // no row is written in this mode: the kernel's row arguments only have to be non-null
+    int32_t *none = (int32_t *)flags;
+    return launch_walk(cfg, indptr, indices, num_nodes, query, n, rng_pos, rng_seed, none, nullptr, none, uniq_table, uniq_capacity,
+                       root_base, none, nullptr, flags, stream, true, worklist, n_work, true, work_cap);
 }
 
 extern "C" int subgacc_compact_sets(const int32_t *set_ids, const uint64_t *set_keys, const int32_t *nsize,

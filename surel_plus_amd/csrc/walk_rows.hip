@@ -83,6 +83,10 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     if (a.worklist) {   // a dense list of the rows to sample whose length lives on the device: its first xcd_grid(length) blocks work
         int64_t ne = *a.n_work;
         if (ne > a.n) ne = a.n;
+        if (ne > (int64_t)gridDim.x) {     // the caller promised a shorter list (work_cap): say so, stay inside the launch
+            if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&a.flags[3], 32);
+            ne = (int64_t)gridDim.x / kXcds * kXcds;
+        }
         const int64_t ge = (ne + kXcds - 1) / kXcds * kXcds;
         if ((int64_t)blockIdx.x >= ge) return;
         const int64_t k = xcd_item(blockIdx.x, ge);
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     const int M = a.M;
     const int32_t root = a.query[i];
     if (root == SUBGACC_NO_ROOT) {     // a repeated endpoint of the batch: its first occurrence carries the set (uniq.hip: step dedup)
-        if (tid == 0) a.nsize[i] = 0;
+        if (tid == 0 && !a.tags_only) a.nsize[i] = 0;
         return;
     }
     // while the root's two dependent loads (query -> row pointer) are in flight: clear what does not depend on them
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     if ((uint64_t)(int64_t)root >= (uint64_t)a.num_nodes) {   // the reference would read out of bounds here
         if (tid == 0) {
             atomicOr(&a.flags[3], 16);
-            a.nsize[i] = 0;
+            if (!a.tags_only) a.nsize[i] = 0;
         }
         return;
     }
@@ -159,9 +163,13 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
         if (tid == 0) {
             unsigned long long k = (unsigned long long)lead;
             for (int s = 0; s < MH; ++s) k |= (unsigned long long)M << (s * a.shift);
-            a.set_ids[obase] = root;
-            a.set_slot[obase] = KR ? (int32_t)k : uniq_global_insert(a.table, k, tag0, a.flags);
-            a.nsize[i] = 1;
+            if (!KR && a.tags_only) {
+                uniq_global_insert(a.table, k, tag0, a.flags);
+            } else {
+                a.set_ids[obase] = root;
+                a.set_slot[obase] = KR ? (int32_t)k : uniq_global_insert(a.table, k, tag0, a.flags);
+                a.nsize[i] = 1;
+            }
         }
         return;
     }
@@ -541,7 +549,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     __syncthreads();   // every lane holds its members in registers: the walk tables are free to be re-used
     SG_RSTAMP(3);
     const int32_t ns = red[8];             // no truncating bucket here: every member stays (ns <= M*MH+1 = stride)
-    if (tid == 0) a.nsize[i] = ns;
+    if (tid == 0 && !a.tags_only) a.nsize[i] = ns;
     const int32_t mn = min(min(red[0], red[1]), min(red[2], red[3]));
     const int32_t mx = max(max(red[4], red[5]), max(red[6], red[7]));
     // the walk tables are dead: [ns] (id << 32 | slot) grouped by bucket goes over the counts (and, K32, the ids behind them);
@@ -557,6 +565,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     if (tid <= B) start[tid] = 0;
     if (tid < kSpgFold)    // flush the fold table to HBM (latency overlaps the sort)
         if (fk[tid] != kNoKey) fs[tid] = uniq_global_insert(a.table, (unsigned long long)fk[tid], tag0 + ft[tid], a.flags);
+    if (a.tags_only) return;   // subgacc_walk_tags: the rows exist already (key rows); only the exact tags were wanted
     __syncthreads();
     SG_RSTAMP(4);
     uint32_t bk[SPL];
@@ -632,7 +641,7 @@ int launch_walk_rows(const WalkArgs &a, bool indptr64, int rng_mode, size_t lds,
     if (off) return 0;
     if (!a.wo || a.step_major || a.walks || a.M > kWalkThreads || a.stride != a.M * a.m + 1) return 0;
     if (a.m < 2 || a.m > 4 || (a.T != 512 && a.T != 1024)) return 0;
-    const int64_t grid = xcd_grid(a.n);
+    const int64_t grid = xcd_grid(a.worklist && a.work_cap > 0 && a.work_cap < a.n ? a.work_cap : a.n);
     if (grid >= (1ll << 31)) return 0;
     const bool rr = rng_mode == SUBGACC_RNG_RAND_R;
     // 512-slot tables: 128 lanes x 2 walks (SUBGACC_ROWS_NT=256 forces one walk per lane; dev-only)

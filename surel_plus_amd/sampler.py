@@ -43,6 +43,17 @@ KEY_ROWS = os.environ.get("SUBGACC_KEY_ROWS", "1") == "1" and os.environ.get("SU
 #                                                    that disables the specialised kernel takes its key-rows form with it)
 
 
+# Batched registration (csrc/keyrows.hip): a store that is KEPT (subg_matrix: packed rows + numbered LP rows) is sampled with the
+# key-rows kernel too; its keys are registered in the table of distinct rows by one pass over the rows, and only the few
+# thousand roots that may be the first to show a row are walked again for their first-visit order (subgacc_walk_tags).
+# "0": the table form of the walk kernel registers inside every root's epilogue, as before round 3 (A/B, and the shapes key rows do
+# not serve -- 4 hops, keys beyond 31 bits -- always take it).  Results are identical.
+BATCHED_REGISTRATION = os.environ.get("SUBGACC_BATCHED_REG", "1") == "1" and os.environ.get("SUBGACC_WALK_ROWS", "1") != "0"
+
+
+KR_TRANSLATE = os.environ.get("SUBGACC_KR_TRANSLATE", "0") == "1"    # dev A/B: see sample_sets
+
+
 def key_rows_ok(num_walks, num_steps):
     """does the fused-row kernel have a key-rows form for this shape? (32-bit keys, 2 or 3 hops, a 512 / 1,024-slot table)"""
     q = num_walks * num_steps + 1
@@ -177,7 +188,10 @@ class SampledSets:
     #                              ([6] with root dedup: + the number of distinct roots = rows that were sampled)
     n_distinct: int = None       # StepBuffers(dedup_roots=True): so many rows (the first occurrences of the endpoints) hold sets
     keyrows: bool = False        # strided rows whose payload (`slot`) is the member's 32-bit LP key: no table, no numbering
-    _resample: object = None     # keyrows: callable -> the same batch sampled with the table form (number() and friends)
+    _keyctx: dict = None         # keyrows: what number() needs to register the rows' keys (csr, roots, cfg, rng positions, capacity, fresh())
+    _ktable: torch.Tensor = None  # keyrows: the table of distinct LP rows once number() has built it (capacity _kcap)
+    _kcap: int = 0
+    _kcount: torch.Tensor = None  # ... and the number of distinct rows, on the device
 
     # ------------------------------------------------------------------ lazy bookkeeping
     @property
@@ -256,10 +270,8 @@ class SampledSets:
         if self.ukeys is not None:
             return self
         self.resolve()
-        if self.keyrows:        # the keys are all there, the first-visit order is not: sample the batch again, with the table
-            full = self._resample().number()
-            self.ukeys, self._full = full.ukeys, full
-            return self
+        if self.keyrows:        # the keys are all there: register them now, and ask the few candidate roots for their order
+            return self._number_keyrows()
         L, dev, st = lib(), self.ids.device, stream_ptr()
         count = torch.zeros(1, dtype=torch.int64, device=dev)
         max_unique = min(self.capacity, RANK_LIMIT)
@@ -271,6 +283,46 @@ class SampledSets:
         if c > max_unique:
             raise _lib.SubgAccError(f"{c} distinct LP rows exceed the direct-ranking limit: sample with lazy=False")
         self.ukeys = ukeys[:c]
+        return self
+
+    def _number_keyrows(self):
+        """Number the distinct LP rows of a key-rows batch after the fact (csrc/keyrows.hip): one pass over the rows registers
+        their keys (coarse tags), the candidate roots are walked again for their first-visit tags, the table is ranked.
+        The rows themselves are not touched; to_csr() then copies them with SFptr+1 looked up in this table."""
+        ctx = self._keyctx
+        if ctx is None or not ctx["fresh"]():
+            raise _lib.SubgAccError("this key-rows batch cannot be numbered any more: its step buffers hold a later batch "
+                                    "(number() / c / enc_int16() / to_csr() must be asked for before the buffers are re-used)")
+        L, dev, st = lib(), self.ids.device, stream_ptr()
+        csr, q, cfg, n = ctx["csr"], ctx["roots"], ctx["cfg"], self.nsize.numel()
+        cap = int(ctx["capacity"])
+        while True:
+            table = torch.empty(L.subgacc_uniq_table_bytes(cap), dtype=torch.uint8, device=dev)
+            check(L.subgacc_uniq_reset(ptr(table), cap, st))
+            words = torch.zeros(4, dtype=torch.int64, device=dev)      # [flags x4 (int32) | candidates | distinct rows]
+            flags = words.view(torch.int32)[:4]
+            cand = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+            check(L.subgacc_keyrows_register(ptr(self.slot), ptr(self.nsize), n, self.stride, 0, ptr(table), cap, ptr(cand),
+                                             ptr(words[2:3]), ptr(flags), st))
+            nc = int(words[2].item())
+            check(L.subgacc_walk_tags(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q), n, 0, ptr(ctx["rng_pos"]),
+                                      ptr(ctx["rng_seed"]), ptr(cand), ptr(words[2:3]), max(nc, 1), ptr(table), cap, ptr(flags), st))
+            max_unique = min(cap, RANK_LIMIT)
+            ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
+            ws = torch.empty(L.subgacc_uniq_number_workspace_bytes(cap, 0), dtype=torch.uint8, device=dev)
+            check(L.subgacc_uniq_number(ptr(table), cap, None, 0, ptr(ukeys), max_unique, ptr(words[3:4]), RANK_LIMIT, ptr(ws),
+                                        ws.numel(), st))
+            host = unpack_status(words[:2].tolist() + [int(words[3].item())])
+            if host[3] & 32:
+                raise _lib.SubgAccError("internal: the candidate list outgrew its launch")
+            if host[2]:                   # the table of distinct LP rows was too small: again with a larger one
+                cap *= 4
+                continue
+            break
+        c = host[4]
+        if c > max_unique:
+            raise _lib.SubgAccError(f"{c} distinct LP rows exceed the direct-ranking limit: sample with lazy=False")
+        self.ukeys, self._ktable, self._kcap, self._kcount = ukeys[:c], table, cap, words[3:4]
         return self
 
     def _count_dev(self):
@@ -364,6 +416,8 @@ def unpack_status(words):
 
 
 def check_walk_flags(sets, fl):
+    if fl[3] & 32:
+        raise _lib.SubgAccError("internal: the candidate list of the batched registration outgrew its launch")
     if fl[3] & 16:
         raise IndexError("query node ids outside [0, num_nodes) (such a root is never looked up on the device; the "
                          "reference reads out of bounds for it)")
@@ -410,7 +464,7 @@ def _cat(parts, dtype, dev):
 
 def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, rng="rand_r", first_hop_wo=True,
                 order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False, rng_streams=1,
-                calls_before=0, dedup=True, keep_keys=None, staging_bytes=STAGING_BYTES, uniq_capacity=UNIQ_CAPACITY,
+                calls_before=0, dedup=True, keep_keys=None, staging_bytes=None, uniq_capacity=UNIQ_CAPACITY,
                 uniq_small_limit=0, fused_rows=False, lazy=False, strided=False, number_rows=True, key_rows=None):
     """Run the sampler for `query` (roots) on the GPU.  See SampledSets.
 
@@ -445,6 +499,9 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
         keep_keys = False
     limit = uniq_small_limit if uniq_small_limit > 0 else RANK_LIMIT
     per_member = 8 if fused_rows else 12
+    if staging_bytes is None:     # 288 GB of HBM: one chunk of roots wherever a third of the free memory holds its staging rows
+        staging_bytes = max(STAGING_BYTES, int(0.35 * torch.cuda.mem_get_info(dev)[0])) if n * stride * per_member > STAGING_BYTES \
+            else STAGING_BYTES
     chunk = max(1, min(n, int(staging_bytes // (stride * per_member)), (1 << 31) - 16)) if n else 0
     lazy = bool(lazy and dedup and n > 0 and chunk == n)
     # strided rows come from the fused-row walk kernel, or (finish=True) from the general walk kernel + finish_rows
@@ -459,6 +516,8 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
         key_rows = KEY_ROWS
     key_rows = bool(key_rows and strided and fused_rows and not number_rows and bucket <= 0 and n > 0 and chunk == n
                     and key_rows_ok(M, m))
+    # a store that is kept: key rows as well, registered by one pass over the rows (csrc/keyrows.hip, module header)
+    batched = bool(BATCHED_REGISTRATION and fused_rows and dedup and not strided and bucket <= 0 and n > 0 and key_rows_ok(M, m))
     table = None
     if dedup and not key_rows:
         table = torch.empty(L.subgacc_uniq_table_bytes(uniq_capacity), dtype=torch.uint8, device=dev)
@@ -481,8 +540,8 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
                 check(L.subgacc_walk_spg(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn, lo,
                                          ptr(rng_pos[lo:]) if rng_pos is not None else None,
                                          ptr(rng_seed[lo:]) if rng_seed is not None else None,
-                                         ptr(table), 0 if key_rows else uniq_capacity, ptr(st_ids), ptr(st_aux), ptr(nsize[lo:]),
-                                         ptr(flags), st))
+                                         None if batched else ptr(table), 0 if (key_rows or batched) else uniq_capacity,
+                                         ptr(st_ids), ptr(st_aux), ptr(nsize[lo:]), ptr(flags), st))
             else:
                 check(L.subgacc_walk_sets(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn,
                                           ptr(rng_pos[lo:]) if rng_pos is not None else None,
@@ -498,7 +557,25 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
                                             ptr(st_slot), ptr(flags), st))
             st_aux = st_slot
         numbered_early = (fused_rows or finish) and chunk == n and (number_rows or not strided)
+        if batched and KR_TRANSLATE:      # one chunk handled like one of several: the copy registers, one flat pass translates
+            numbered_early = False
         count = status[2:3]
+        total = None
+        if batched:
+            cand = torch.empty(cn, dtype=torch.int32, device=dev)
+            ncand = torch.zeros(1, dtype=torch.int64, device=dev)
+            rp, rs = (ptr(rng_pos[lo:]), ptr(rng_seed[lo:])) if rng_pos is not None else (None, None)
+            if numbered_early:      # one chunk: register -> exact tags for the candidates -> number (below) -> copy with SFptr+1
+                with _timed("register_rows"):
+                    check(L.subgacc_keyrows_register(ptr(st_aux), ptr(nsize[lo:]), cn, stride, lo, ptr(table), uniq_capacity,
+                                                     ptr(cand), ptr(ncand), ptr(flags), st))
+                    if lazy:
+                        total, wcap = cn * stride, 0
+                    else:           # the one host read of the chunk carries the candidate count along
+                        total, wcap = (int(v) for v in torch.cat([off_chunk[cn:cn + 1], ncand]).tolist())
+                        wcap = max(wcap, 1)
+                    check(L.subgacc_walk_tags(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn, lo, rp, rs,
+                                              ptr(cand), ptr(ncand), wcap, ptr(table), uniq_capacity, ptr(flags), st))
         if strided and not numbered_early:
             ukeys, max_unique = None, uniq_capacity
         if numbered_early:    # one chunk: the table is complete -> number it now and let the copy emit SFptr+1
@@ -513,10 +590,8 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
             sets.slot, sets.table, sets.capacity, sets.strided = st_aux, table, (0 if key_rows else uniq_capacity), True
             if key_rows:
                 sets.keyrows = True
-                sets._resample = lambda: sample_sets(csr, q, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order,
-                                                     cap_root_degree, emit_walks, rng_streams, calls_before, dedup, keep_keys,
-                                                     staging_bytes, uniq_capacity, uniq_small_limit, fused_rows, False, True,
-                                                     True, False)
+                sets._keyctx = {"csr": csr, "roots": q, "cfg": cfg, "rng_pos": rng_pos, "rng_seed": rng_seed,
+                                "capacity": uniq_capacity, "fresh": lambda: True}
             torch.sum(nsize, dim=(0,), dtype=torch.int64, out=status[3])
             sets.status = status
             if not lazy:      # eager: same recovery as the packed forms below
@@ -531,12 +606,21 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
                 sets.resolve()
             return sets
         # packed arrays: exact size (one 8-byte host read) or, lazily, the upper bound n*stride
-        total = cn * stride if lazy else int(off_chunk[cn].item())
+        if total is None:
+            total = cn * stride if lazy else int(off_chunk[cn].item())
         ids_c = torch.empty(total, dtype=torch.int32, device=dev)
         keys_c = torch.empty(total, dtype=torch.int64, device=dev) if keep_keys else None
         slot_c = torch.empty(total, dtype=torch.int32, device=dev) if dedup else None
         with _timed("compact_sets"):
-            if fused_rows:
+            if batched:     # key rows -> packed rows: SFptr+1 looked up on the way, or (several chunks) the key kept as payload
+                check(L.subgacc_keyrows_compact(ptr(st_ids), ptr(st_aux), ptr(nsize[lo:]), ptr(off_chunk), cn, stride, lo, ptr(table),
+                                                uniq_capacity, ptr(ukeys) if numbered_early else None,
+                                                ptr(count) if numbered_early else None, max_unique if numbered_early else 0,
+                                                ptr(ids_c), ptr(slot_c), ptr(cand), ptr(ncand), ptr(flags), st))
+                if not numbered_early:    # the pass registered this chunk's keys itself: now the candidates' exact tags
+                    check(L.subgacc_walk_tags(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn, lo, rp, rs,
+                                              ptr(cand), ptr(ncand), 0, ptr(table), uniq_capacity, ptr(flags), st))
+            elif fused_rows:
                 check(L.subgacc_compact_rows(ptr(st_ids), ptr(st_aux), ptr(nsize[lo:]), ptr(off_chunk), cn, stride,
                                              ptr(ids_c), ptr(slot_c), ptr(table) if numbered_early else None,
                                              uniq_capacity if numbered_early else 0, st))
@@ -567,7 +651,7 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
 
     # number the distinct LP rows by first occurrence (subg_acc.c:957-1000)
     x_dev = row_off[n:n + 1]
-    if n and fused_rows and chunk == n:
+    if n and fused_rows and chunk == n and not (batched and KR_TRANSLATE):
         pass                          # numbered before the copy, which already wrote SFptr+1
     elif fused_rows or lazy:          # table-only direct ranking (tags need not be element positions)
         count = status[2:3]
@@ -577,7 +661,10 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
         with _timed("uniq_rows"):
             check(L.subgacc_uniq_number(ptr(table), uniq_capacity, None, 0, ptr(ukeys), max_unique, ptr(count), limit,
                                         ptr(ws), ws.numel(), st))
-            if fused_rows:            # slot -> SFptr+1 in place: the rows are finished SpG rows
+            if batched:               # LP key -> SFptr+1 in place (the chunks kept the keys as payload)
+                check(L.subgacc_keyrows_translate(ptr(slot), slot.numel(), ptr(x_dev), ptr(table), uniq_capacity, ptr(ukeys),
+                                                  ptr(count), max_unique, st))
+            elif fused_rows:          # slot -> SFptr+1 in place: the rows are finished SpG rows
                 check(L.subgacc_uniq_translate(ptr(table), uniq_capacity, ptr(slot), slot.numel(), ptr(x_dev), 1, st))
     else:
         count = status[2:3]

@@ -178,9 +178,7 @@ class StridedSpG:
         return self.sets.X
 
     def to_csr(self):
-        if self.keyrows:             # the packed rows carry SFptr+1: that needs the numbering, i.e. the table form of the batch
-            return StridedSpG(self.sets.number()._full, self.shape[1]).to_csr()
-        self.sets.number()           # the packed rows carry SFptr+1: the table must be numbered by now
+        self.sets.number()           # the packed rows carry SFptr+1: the table must be numbered by now (key rows: registered now)
         n, dev = self.n_rows, self.device
         row_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
         ws = torch.empty(max(lib().subgacc_scan_workspace_bytes(n), 8), dtype=torch.uint8, device=dev)
@@ -188,7 +186,13 @@ class StridedSpG:
         X = int(row_off[-1].item()) if n else 0
         ids = torch.empty(X, dtype=torch.int32, device=dev)
         data = torch.empty(X, dtype=torch.int32, device=dev)
-        if X:
+        if X and self.keyrows:       # rows of LP keys: SFptr+1 is looked up in the table number() has just built
+            flags = torch.zeros(4, dtype=torch.int32, device=dev)
+            uk = self.sets.ukeys
+            check(lib().subgacc_keyrows_compact(ptr(self.indices), ptr(self.slot), ptr(self.nsize), ptr(row_off), n, self.stride, 0,
+                                                ptr(self.sets._ktable), self.sets._kcap, ptr(uk), ptr(self.sets._kcount), uk.numel(),
+                                                ptr(ids), ptr(data), None, None, ptr(flags), stream_ptr()))
+        elif X:
             check(lib().subgacc_compact_rows(ptr(self.indices), ptr(self.slot), ptr(self.nsize), ptr(row_off), n, self.stride,
                                              ptr(ids), ptr(data), ptr(self.table), self.capacity, stream_ptr()))
         return SpG(row_off, ids, data, max_len=self.stride, shape=self.shape, max_data=self.max_data)

@@ -354,9 +354,10 @@ def _buffered_step(csr, e, bufs, seed, out):
         raise ValueError(f"these StepBuffers were made for [2, {B}] pairs")
     e = e.contiguous()
     flags = bufs.status.view(torch.int32)[:4]
-    cfg = make_cfg(csr, M, m, -1, seed, "philox")
+    cfg = make_cfg(csr, M, m, -1, seed, "philox", records=(2 <= m <= 4))     # (only the fused-row kernel of 2..4 hops reads hop records)
     check(L.subgacc_key_shift(cfg.num_walks, cfg.num_steps))
     kr = bufs.keyrows
+    bufs.step_id = step_id = getattr(bufs, "step_id", 0) + 1
     if bufs.dedup:      # first occurrences only: the other rows stay empty, the segment lists point at the first occurrence
         if not torch.cuda.is_current_stream_capturing():
             _dedup_tick(bufs)
@@ -396,13 +397,13 @@ def _buffered_step(csr, e, bufs, seed, out):
     sets = SampledSets(bufs.nsize, None, bufs.ids, None, None, None, M, m, bufs.stride, None)
     sets.slot, sets.table, sets.capacity, sets.strided = bufs.slot, bufs.table, (0 if kr else bufs.capacity), True
     if kr:
-        from .sampler import sample_sets
         sets.keyrows = True
-        # (root dedup: the first occurrences in batch order -- a repeated endpoint never is the first to show an LP row, so
-        # the numbering is the one of the whole batch)
-        sets._resample = lambda: sample_sets(csr, bufs.roots[bufs.roots != NO_ROOT] if bufs.dedup else bufs.roots, M, m, -1,
-                                             seed, "philox", fused_rows=True, strided=True, number_rows=True, key_rows=False,
-                                             uniq_capacity=bufs.capacity)
+        # number() registers the keys of the rows as they stand in the buffers (root dedup: the rows of repeated endpoints are
+        # empty, and a repeated endpoint never is the first to show an LP row, so the numbering is the one of the whole batch);
+        # once the buffers have taken a later batch -- or a captured step has been replayed -- the answer would describe that
+        # batch, so it is refused (stamp of the step that made these sets against the buffers' current one)
+        sets._keyctx = {"csr": csr, "roots": bufs.roots, "cfg": cfg, "rng_pos": None, "rng_seed": None, "capacity": bufs.capacity,
+                        "fresh": lambda: getattr(bufs, "step_id", 0) == step_id}
     sets.status, sets._tail = bufs.status, bufs.tail[n: n + (6 if bufs.dedup else 5)]
     return xz, bufs.seg, sets
 

@@ -11,11 +11,16 @@ Philox streams are keyed by (seed, root id, walk, step) and the seed is baked in
 is the same in every replay -- the semantics of the reference's offline stage, where every node's set is sampled once
 and joined in every epoch (main.py:172-178).
 """
+import os
+
 import torch
 
 from . import _lib
 from .sampler import check_walk_flags, unpack_status
 from .spjoin import StepBuffers, _dedup_tick, sample_and_gather
+
+
+_DEBUG = os.environ.get("SUBGACC_DEBUG", "0") == "1"
 
 
 class CapturedStep:
@@ -81,6 +86,12 @@ class CapturedStep:
             self.edge.copy_(edge, non_blocking=True)
         if self._dedup_bufs is not None:
             _dedup_tick(self._dedup_bufs)
+        bufs = self._kw.get("buffers")
+        if bufs is not None and self.sets._keyctx is not None:
+            # the buffers take a new batch: what number() said about the previous one is void, and self.sets now stands for this one
+            bufs.step_id = sid = getattr(bufs, "step_id", 0) + 1
+            self.sets._keyctx["fresh"] = lambda: getattr(bufs, "step_id", 0) == sid
+            self.sets.ukeys = self.sets._ktable = None
         self.graph.replay()
         if self._copy_in_graph:
             pass
@@ -136,7 +147,9 @@ class CapturedStepPool:
         self._caller = torch.cuda.current_stream(csr.device)     # looked up once: torch's stream bookkeeping costs ~6 us a call
 
     def submit(self, edge, stream=None, sync=True):
-        """stream: the stream `edge` was produced on, if it is not the one this pool was created on.  sync=False: `edge` is
+        """stream: the stream `edge` was produced on -- MANDATORY when the caller's current stream is not the one this pool was
+        created on (the pool does not look the current stream up: ~6 us of the ~35 us a step costs the host; afterwards the
+        current stream is `stream`, or the creation stream; SUBGACC_DEBUG=1 checks it).  sync=False: `edge` is
         known to be complete (produced and synchronised earlier): the lane does not wait for the caller's stream (~10 us of
         host time).  edge may be `pool.steps[lane].edge` itself (filled in place by the caller): no copy then."""
         i = self._next
@@ -145,6 +158,8 @@ class CapturedStepPool:
         self._next = (i + 1) % len(self.steps)
         st = self.streams[i]
         caller = self._caller if stream is None else stream
+        if _DEBUG and torch.cuda.current_stream(self.steps[i].csr.device) != caller:
+            raise RuntimeError("CapturedStepPool.submit: the current stream is not the pool's creation stream -- pass stream=")
         if sync:
             st.wait_stream(caller)                     # `edge` may have been produced on the caller's stream just now
         torch.cuda.set_stream(st)                      # (not `with torch.cuda.stream(st)`: it asks for the current stream twice)

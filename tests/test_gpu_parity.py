@@ -1399,3 +1399,63 @@ def test_batch_sampler_vs_oracle_and_its_process_seed(sp):
     dp = np.array([0, 1, 1], np.int32)                               # 0 -> 1, node 1 has no out-edges
     with pytest.raises(sp.SubgAccError, match="out-edges"):
         sp.batch_sampler(dp, np.array([1], np.int32), np.array([0]), num_walks=2, num_steps=3)
+
+
+# ------------------------------------------------------------------ batched registration of key rows (csrc/keyrows.hip, ABI 4)
+@pytest.mark.parametrize("rng", ["rand_r", "philox"])
+@pytest.mark.parametrize("M,hops,N,E,hubs,idx64", [(200, 3, 9000, 90000, 3, False), (200, 2, 20000, 80000, 4, True),
+                                                  (80, 3, 3000, 9000, 2, False), (255, 3, 1500, 200000, 0, False),
+                                                  (120, 2, 400, 700, 1, False)])
+def test_batched_registration_numbers_the_store_like_the_reference(sp, rng, M, hops, N, E, hubs, idx64):
+    """The store that is kept (subg_matrix: main.py:172-178) sampled with the key-rows kernel, its LP rows registered by one
+    pass over the rows and numbered after the candidate roots were walked again (subgacc_keyrows_register / subgacc_walk_tags /
+    subgacc_keyrows_compact): bit for bit the oracle's (nsize, SpG, enc) -- i.e. the reference's first-occurrence numbering,
+    subg_acc.c:957-978 -- and the table form's; one chunk, several chunks, sizes left on the device."""
+    from surel_plus_amd import sampler
+    from surel_plus_amd.spg import sample_spg
+    assert sampler.BATCHED_REGISTRATION and sampler.key_rows_ok(M, hops)
+    ptr_, idx = sym_graph(N, E, seed=M + hops, hubs=hubs)
+    q = np.random.default_rng(11).permutation(N)
+    csr = sp.DeviceCSR(ptr_.astype(np.int64) if idx64 else ptr_, idx)
+    (oi, ox, od), oenc = _oracle_spg(ptr_, idx, q, M, hops, 77, rng, -1)
+    stride = M * hops + 1
+    for kw in ({}, {"staging_bytes": stride * 8 * (N // 7 + 1)}, {"lazy": True}):
+        z, sets = sample_spg(csr, q, num_walks=M, num_steps=hops, seed=77, rng=rng, fused=True, **kw)
+        sets.resolve()
+        nnz = z.nnz
+        assert np.array_equal(z.indptr.cpu().numpy(), oi) and np.array_equal(z.indices[:nnz].cpu().numpy(), ox)
+        assert np.array_equal(z.data[:nnz].cpu().numpy(), od)
+        assert np.array_equal(sets.enc_int16().cpu().numpy(), oenc)
+    keep = sampler.BATCHED_REGISTRATION
+    sampler.BATCHED_REGISTRATION = False          # the table form of the walk kernel (every root registers its own rows)
+    try:
+        zt, tsets = sample_spg(csr, q, num_walks=M, num_steps=hops, seed=77, rng=rng, fused=True)
+    finally:
+        sampler.BATCHED_REGISTRATION = keep
+    assert torch.equal(zt.indptr, z.indptr) and torch.equal(zt.data[: zt.nnz], z.data[:nnz]) and torch.equal(tsets.ukeys, sets.ukeys)
+
+
+def test_batched_registration_regrows_a_small_table_and_numbers_transient_batches(sp):
+    """(a) a table of distinct rows that is too small is grown and the job repeated, as for the table form; (b) a key-rows
+    batch (StepBuffers) is numbered after the fact from the rows in its buffers -- and refused once the buffers moved on."""
+    from surel_plus_amd.graphs import query_pairs
+    from surel_plus_amd.spg import sample_spg
+    ptr_, idx = sym_graph(6000, 60000, seed=8, hubs=2)
+    csr = sp.DeviceCSR(ptr_, idx)
+    q = np.arange(6000)
+    (oi, ox, od), oenc = _oracle_spg(ptr_, idx, q, 200, 3, 5, "philox", -1)
+    z, sets = sample_spg(csr, q, num_walks=200, num_steps=3, seed=5, rng="philox", fused=True, uniq_capacity=64)
+    assert sets.capacity > 64 and np.array_equal(z.data[: z.nnz].cpu().numpy(), od) and np.array_equal(sets.enc_int16().cpu().numpy(), oenc)
+    bufs = sp.StepBuffers(csr, 256, num_walks=200, num_steps=3)
+    e1, e2 = query_pairs(csr, 256, seed=1), query_pairs(csr, 256, seed=2)
+    xz, ind, s1 = sp.sample_and_gather(csr, e1, num_walks=200, num_steps=3, seed=5, rng="philox", buffers=bufs)
+    s1.resolve()
+    (_, _, _), oenc1 = _oracle_spg(ptr_, idx, e1.reshape(-1).cpu().numpy(), 200, 3, 5, "philox", -1)
+    assert np.array_equal(s1.enc_int16().cpu().numpy(), oenc1)
+    xz, ind, s2 = sp.sample_and_gather(csr, e2, num_walks=200, num_steps=3, seed=5, rng="philox", buffers=bufs)
+    s2.resolve()
+    s1.ukeys = None
+    with pytest.raises(sp.SubgAccError):
+        s1.number()
+    (_, _, _), oenc2 = _oracle_spg(ptr_, idx, e2.reshape(-1).cpu().numpy(), 200, 3, 5, "philox", -1)
+    assert np.array_equal(s2.enc_int16().cpu().numpy(), oenc2)
