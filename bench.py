@@ -9,10 +9,13 @@ Nothing is cached between steps; every step gets fresh pairs.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cit2|collab|ppa] [--pairs B]
 
 N>1 is launched by the driver through torch.distributed.run (one rank per GPU); the graph is replicated, the
-pair batches are sharded (each rank its own), there is no data-path collective ("weak" scaling).
-Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around the walk_sets kernel on its
+pair batches are sharded (each rank its own: "weak"; --scaling strong splits one fixed batch), there is no data-path
+collective.  Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around the walk kernel on its
 launch stream; `cpu_baseline` times the reference's own OpenMP sampler (oracle/_ref, compiled from the
 reference sources in the build container) plus the oracle's C merge join on a bounded sample of the workload.
+After the timed region (rank 0, 1 GPU): the random-line roof of this box (subgacc_line_probe), BASELINE.json's other
+configurations, the reference's own offline-sample + resident-store-join flow (`offline_flow`), hgather and walk_sampler;
+every number of those blocks is also a scalar key of `config` (the driver keeps scalars only).
 """
 import argparse
 import contextlib
@@ -44,14 +47,33 @@ WORKLOADS = {
     "cit2ppr": (None, 0, 1, "cit2-like PPR encoder: float64 SpG = topk_ppr_matrix(alpha=0.1, eps=1e-4, top-100, 'sym') + encoding 'PPR' "
                             "over all N=2,927,963 nodes (built on the GPU in set-up), SpJoin only (train.py:39-43)", 0.5),
 }
-# Measured on this part (tools/line_probe.hip, profiles/r02_line_probe_pmc.csv): an L2 miss moves one whole 128-byte line
-# whatever the access width, and the chip sustains ~55 G random lines/s from tables up to 1 GiB (Infinity Cache or
-# HBM alike), ~48-50 G lines/s from 4-12 GiB.  This -- not bytes of useful data -- is what bounds a random walk.
+# tools/line_probe.hip (profiles/r02_line_probe_pmc.csv) established that an L2 miss moves one whole 128-byte line whatever
+# the access width and that the chip sustains ~55 G random lines/s from tables up to 1 GiB (Infinity Cache or HBM alike),
+# ~48-50 G lines/s from 4-12 GiB.  This -- not bytes of useful data -- is what bounds a random walk.  The rate is measured
+# again in every run, on the table the walk kernel reads (the hop records, else the adjacency array), right after the timed
+# region (subgacc_line_probe: the study's `gather4` shape; box-to-box spread is 2-4 %).
 LINE_BYTES = 128
 
 
-def random_line_roof(table_bytes):
-    return 55e9 if table_bytes <= (1 << 30) else 49e9
+def measure_line_roof(csr):
+    """-> (random reads = 128-byte lines per second, table bytes, what the table is); best of three ~1-2 ms launches"""
+    from surel_plus_amd._lib import check, lib, ptr, stream_ptr
+    recs = csr.hop_records()
+    table, what = (recs[0], "hop records") if recs else (csr.indices, "adjacency array")
+    nbytes = table.numel() * table.element_size()
+    sink = torch.zeros(1, dtype=torch.int32, device=table.device)
+    reads = ctypes.c_int64(0)
+    best = None
+    for rep in range(4):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        check(lib().subgacc_line_probe(ptr(table), nbytes, 32, 12345 + rep, ptr(sink), ctypes.byref(reads), stream_ptr()))
+        b.record()
+        b.synchronize()
+        ms = a.elapsed_time(b)
+        if rep and (best is None or ms < best):      # (the first launch warms the TLBs)
+            best = ms
+    return reads.value / (best * 1e-3), nbytes, what
 
 
 def kernel_source_sha():
@@ -216,6 +238,8 @@ def cpu_baseline(csr, edge_all, M, k, target_s=15.0):
     used = cores if best_nt < 0 else best_nt
     kind = "reference" if use_ref else "port"
     return {"value": B / t, "unit": "query-pairs/s", "cores": used if use_ref else threads, "kind": kind,
+            # the two halves, for the reference's own flow (offline_flow): sampler roots/s, and pairs/s of SpG build + join
+            "sampler_roots_per_s": 2 * B / ts, "join_pairs_per_s": B / max(t - ts, 1e-9),
             "sample": f"{B} pairs of the same workload ({2 * B} roots): sampler = "
                       + (f"the reference's subg_acc.gset_sampler (oracle/_ref) with nthread={used}, the fastest of "
                          f"all-cores/64/32/16/8 on this {cores}-thread host" if use_ref else f"oracle C port, {threads} threads")
@@ -277,7 +301,7 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W):
     abytes = B * 64 + rows_out * (12 + 8)
     return {"metric": "query-pairs/sec (SpJoin, PPR payload)", "value": world * B * K / elapsed, "unit": "query-pairs/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "pairs_per_step_per_gpu": B, "xz_rows_last_step": int(xz.shape[0]),
                        "spg_members": z.nnz, "offline_ppr_stage_s": prep_s},
             "roofline": {"bound": "hbm", "kernel": "sjoin_fill (sizes + scan + sjoin_pair_kernel<f64>)", "achieved": abytes / (ms * 1e-3) / 1e9,
@@ -287,12 +311,17 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W):
 
 
 def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, with_cpu_baseline, csr_variant=True,
-             small_batches=False, two_stream_extra=True):
+             small_batches=False, two_stream_extra=True, offline=False):
     """sample + SpJoin over one LP workload: W warm-up steps, K timed steps bracketed by barrier + synchronize, max over
     ranks.  Returns the JSON object (rank 0) or None."""
     global STRIDED, DEDUP
     from surel_plus_amd.graphs import preset_graph, query_pairs
     preset, M, k, desc, pos_frac = WORKLOADS[name]
+    if name == "twitter":      # 12 GB of CSR (+ transients of its generation) + ~8 GB of step buffers per rank: look before building
+        free, total = torch.cuda.mem_get_info(dev)     # (the 47 GB of hop records are the library's call: DeviceCSR.hop_records
+        need = int(24e9 * args.scale) + int(8e9)       #  builds them only within a quarter of the free memory)
+        if free < need:
+            raise RuntimeError(f"twitter workload: {free >> 30} GiB free of {total >> 30} GiB on {dev}, the graph and the step buffers need {need >> 30} GiB")
     csr = preset_graph(preset, device=dev, scale=args.scale)
     if os.environ.get("SUBGACC_DEGREE_ORDER") == "1":     # dev experiment (DESIGN.md 4.1): nodes renumbered hub-first
         from surel_plus_amd.graphs import degree_ordered
@@ -357,10 +386,13 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
     timer.enabled = False
     allocs_timed = torch.cuda.memory_stats().get("num_device_alloc", 0) - allocs0
     host_steps = [b - a for a, b in zip(step_marks, step_marks[1:])]
+    elapsed_local = elapsed
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    rank_records = gather_rank_records(dist, world, rank, dev, elapsed_local, timer.mean_ms("walk_sets")[0],
+                                       os.environ.get("SUBGACC_DIST_BACKEND", "nccl") if dist is not None else None)
 
     # what the JSON line says about the last timed step, taken NOW: the extra passes below re-use the step buffers
     last_members = last_rows = last_distinct = last_abytes = None
@@ -432,47 +464,75 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
         tj = json.load(open(tpath)).get(f"{name}:{B}:{M}:{k}:{'spg' if fused_rows else 'sets'}:{rng}", {})
         if tj.get("kernel_source_sha") == kernel_source_sha():
             traffic, lines = tj.get("walk_sets_hbm_bytes_per_launch"), tj.get("walk_sets_l2_miss_lines_per_launch")
-    roof = random_line_roof(4 * csr.nnz)
+    roof, roof_bytes, roof_table = measure_line_roof(csr) if rank == 0 else (None, None, None)
     out = {
         "metric": "query-pairs/sec (sample+SpJoin)", "value": world * B * K / elapsed, "unit": "query-pairs/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": desc, "pairs_per_step_per_gpu": B, "roots_per_step_per_gpu": 2 * B,
+                   "pairs_per_step_all_gpus": world * B,
+                   # one record per rank (all-gathered): the first multi-GPU run must show which devices really took part
+                   "ranks_seen": len(rank_records), "distinct_devices": len({r["device"] for r in rank_records}),
+                   "per_rank_ms_min": min(r["elapsed_ms"] for r in rank_records) / max(K, 1),
+                   "per_rank_ms_max": max(r["elapsed_ms"] for r in rank_records) / max(K, 1),
+                   "per_rank_walk_kernel_ms_min": min((r["walk_kernel_ms"] or 0.0) for r in rank_records),
+                   "per_rank_walk_kernel_ms_max": max((r["walk_kernel_ms"] or 0.0) for r in rank_records),
+                   "dist_backend": (os.environ.get("SUBGACC_DIST_BACKEND", "nccl") if dist is not None else "none"),
+                   "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist is not None else None,
+                   "rank_records": rank_records,
                    "num_walks": M, "num_steps_cli": k, "rng": rng, "parallelism": f"query-shard x{world}",
                    "set_members_last_step": last_members, "distinct_lp_rows_last_step": last_distinct,
                    "xz_rows_last_step": last_rows, "graph_nnz": csr.nnz,
-                   # S = roots/s of the sampler pipeline (walk .. SpG), J = pairs/s of the join alone
-                   "S_roots_per_s": 2 * B / (1e-3 * sum(v for v in (timer.mean_ms(n_)[0] for n_ in
-                                             ("walk_sets", "compact_sets", "uniq_rows", "spg_build")) if v)),
+                   # the on-demand step's sampler stages (key rows: the walk kernel alone -- nothing is numbered or packed);
+                   # SURVEY 8(d)'s S (walk -> register -> number -> packed SpG resident) is offline_S_roots_per_s below
+                   "S_on_demand_rows_roots_per_s": 2 * B / (1e-3 * sum(v for v in (timer.mean_ms(n_)[0] for n_ in
+                                                   ("walk_sets", "register_rows", "compact_sets", "uniq_rows", "spg_build")) if v)),
                    "J_pairs_per_s": (B / (1e-3 * join_ms)) if join_ms else None,
                    "fused_spg_rows": fused_rows, "spg_layout": "strided rows joined in place (no CSR copy of the batch)" if sets.strided else "csr",
-                   "ms_per_step_with_a_packed_csr_spg_per_batch": csr_ms,
+                   "packed_csr_ms_per_step": csr_ms,
                    "two_stream_loop": two_streams, "dedup_roots_loop": dedup_loop,
                    "device_allocs_in_timed_region": allocs_timed,
                    "host_step_ms_min_median_max": [round(1e3 * v, 3) for v in
                                                    (min(host_steps), sorted(host_steps)[len(host_steps) // 2], max(host_steps))]
                    if host_steps else None,
                    "stage_ms": {n_: timer.mean_ms(n_)[0] for n_ in
-                                ("walk_sets", "compact_sets", "uniq_rows", "spg_build", "sjoin_fill")}},
+                                ("walk_sets", "register_rows", "compact_sets", "uniq_rows", "spg_build", "sjoin_fill")}},
         "roofline": {"bound": "hbm", "kernel": sampler_mod.walk_kernel_name(csr, M, k - 1, fused_rows and not finished),
                      "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                      "kernel_ms": walk_ms, "launches_timed": launches, "algorithmic_bytes_per_launch": abytes,
                      # the roof this kernel actually sits under: random 128-byte lines per second
-                     "random_line_roof": {"lines_per_s": roof, "line_bytes": LINE_BYTES,
-                                          "source": "profiles/r02_line_probe_pmc.csv (tools/line_probe.hip)",
+                     "random_line_roof": {"lines_per_s": roof, "line_bytes": LINE_BYTES, "table_bytes": roof_bytes,
+                                          "source": f"subgacc_line_probe in this run: independent random 4-byte reads over the {roof_table} "
+                                                    f"({roof_bytes >> 20} MiB), 2048 x 256 lanes, best of 3 (study: profiles/r02_line_probe_pmc.csv)",
                                           "l2_miss_lines_per_launch": lines,
                                           "achieved_lines_per_s": (lines / (walk_ms * 1e-3)) if (lines and walk_ms) else None,
                                           "frac": (lines / (walk_ms * 1e-3) / roof) if (lines and walk_ms) else None}},
     }
     if small_batches:
         out["config"]["batch_size_and_hip_graph"] = batch_size_and_graph(sp, csr, M, k, rng, K)
+    if two_stream_extra and two_streams:
+        out["config"]["two_stream_pairs_per_s"] = two_streams["pairs_per_s"]
+    if dedup_loop and "pairs_per_s" in dedup_loop:
+        out["config"]["dedup_roots_pairs_per_s"] = dedup_loop["pairs_per_s"]
     if with_cpu_baseline and name != "twitter":   # 12 GB CSR: no host copy
         try:
             out["cpu_baseline"] = cpu_baseline(csr, edges[W], M, k)
         except Exception as ex:  # the baseline is a report, never a reason to lose the measurement
             out["cpu_baseline"] = {"value": None, "unit": "query-pairs/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": f"failed: {type(ex).__name__}: {ex}"}
+    if offline:      # the reference's own flow + the rest of the surface, outside the clock (rank 0, 1 GPU, the headline workload)
+        try:
+            torch.cuda.empty_cache()
+            flow, (z, table) = offline_flow(sp, csr, M, k, B, K, out.get("cpu_baseline"))
+            out["config"]["offline_flow"] = flow
+            try:
+                out["config"]["hgather"] = bench_hgather(sp, z, table, k, max(K, 5))
+            except Exception as ex:
+                out["config"]["hgather"] = {"failed": f"{type(ex).__name__}: {ex}"}
+            del z, table
+        except Exception as ex:     # an extra must never cost the headline line
+            out["config"]["offline_flow"] = {"failed": f"{type(ex).__name__}: {ex}"}
     return out
 
 
@@ -531,6 +591,210 @@ def batch_size_and_graph(sp, csr, M, k, rng, K):
     return out
 
 
+
+def offline_flow(sp, csr, M, k, B, K, cpu):
+    """The reference's OWN flow, outside the clock (rank 0, 1 GPU): main.py:172-178 samples every node once (subg_matrix over
+    all N: walk -> register -> number -> packed SpG resident in HBM = S of SURVEY 8(d)), train.py:120-127 then joins every
+    batch from the resident store (J), from the Z_SF-table store and from the store re-keyed once (SpG.keyed).  Amortised Q
+    for 1e8 pairs = 1e8 / (N / S + 1e8 / J); the same arithmetic with the CPU baseline's two halves beside it."""
+    from surel_plus_amd.graphs import query_pairs
+    from surel_plus_amd.spg import sample_spg
+    dev, N = csr.device, csr.num_nodes
+    out = {}
+    idx = torch.arange(N, dtype=torch.int32, device=dev)
+    z = sets = None
+    times = []
+    for _ in range(3):          # the previous store goes back to the allocator first: steady state, no fresh GB-sized hipMalloc
+        del z, sets
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        z, sets = sample_spg(csr, idx, num_walks=M, num_steps=k - 1, seed=111413, rng="philox", fused=True)
+        enc = sets.enc_int16()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    t_off = min(times[1:])
+    table = sets.feature_table()
+    edges = [query_pairs(csr, B, seed=9000 + s_, device=dev) for s_ in range(max(K, 5) + 2)]
+    cap = 2 * B * z.max_len * 2 * k
+    buf = _XZ_BUF.get((dev, cap, 0))
+    if buf is None:
+        buf = torch.empty(cap, dtype=torch.float32, device=dev)
+
+    def join_rate(store, tab):
+        for e in edges[:2]:
+            sp.gather(e, store, dev, ptr=True, encode=tab, out=buf, lazy=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for e in edges[2:]:
+            sp.gather(e, store, dev, ptr=True, encode=tab, out=buf, lazy=True)
+        torch.cuda.synchronize()
+        return (len(edges) - 2) * B / (time.perf_counter() - t1)
+    J = join_rate(z, table)
+    encz = torch.cat([torch.zeros((1, enc.shape[1]), dtype=enc.dtype, device=dev), enc])
+    zk = None
+    for _ in range(2):          # (steady-state allocator again: the second re-keying is the one that counts)
+        del zk
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        zk = z.keyed(encz, M)
+        torch.cuda.synchronize()
+        t_key = time.perf_counter() - t2
+    JK = join_rate(zk, zk.slot_table())
+    out = {"all_N_sample_to_resident_spg_ms": t_off * 1e3, "S_roots_per_s": N / t_off, "set_members": z.nnz,
+           "distinct_lp_rows": int(enc.shape[0]), "J_pairs_per_s_table_store": J, "J_pairs_per_s_keyed_store": JK,
+           "rekey_once_ms": t_key * 1e3, "pairs_per_batch": B,
+           "Q_amortised_at_1e8_pairs_table": 1e8 / (t_off + 1e8 / J), "Q_amortised_at_1e8_pairs_keyed": 1e8 / (t_off + t_key + 1e8 / JK),
+           "reference": "main.py:172-178 (subg_matrix over all N once) + train.py:120-127 (one join per batch from the resident store)"}
+    if cpu and cpu.get("sampler_roots_per_s"):
+        Sc, Jc = cpu["sampler_roots_per_s"], cpu["join_pairs_per_s"]
+        out["cpu_baseline"] = {"S_roots_per_s": Sc, "J_pairs_per_s": Jc, "Q_amortised_at_1e8_pairs": 1e8 / (N / Sc + 1e8 / Jc),
+                               "cores": cpu["cores"], "kind": cpu["kind"],
+                               "sample": "the two halves of cpu_baseline's bounded sample: the reference's gset_sampler (roots/s) and the "
+                                         "oracle's SpG build + merge join (pairs/s), extrapolated to all N roots and 1e8 pairs"}
+    return out, (z, table)
+
+
+def bench_hgather(sp, z, table, k, K):
+    """train.py:48-72 / main_horder.py:33: B = 2,048 triplets (u, v, w) -> xz [R4, 2, k] + ids, four blocks [U|w, W|u, V|w, W|v],
+    joined from the resident store.  Outside the clock; >= 5 steps timed with HIP events."""
+    dev, B = z.device, 2048
+    gens = [torch.Generator(device=dev).manual_seed(400 + s_) for s_ in range(K + 2)]
+    hedges = [torch.randint(0, z.n_rows, (3, B), device=dev, generator=g) for g in gens]
+    for h in hedges[:2]:
+        xz, ids = sp.hgather(h, z, dev, encode=table)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    a.record()
+    for h in hedges[2:]:
+        xz, ids = sp.hgather(h, z, dev, encode=table)
+    b.record()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms = a.elapsed_time(b) / K
+    rows = int(xz.shape[0])
+    # per output row: id + SFptr read (8), xz written (8k), segment id written (8); per triplet: 3 ids (24) + 8 row offsets (64)
+    abytes = rows * (8 + 8 * k + 8) + B * (24 + 64)
+    return {"metric": "triplets/sec (hgather from the resident store)", "value": B * K / wall, "unit": "triplets/s", "steps": K,
+            "ms_per_step": wall / K * 1e3, "triplets_per_step": B, "xz_rows_last_step": rows,
+            "roofline": {"bound": "hbm", "kernel": "sjoin_pair_kernel (4 blocks per triplet) + sizes + scan", "achieved": abytes / (ms * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "kernel_ms": ms, "algorithmic_bytes_per_launch": abytes,
+                         "note": "2,048 triplets are ~8k workgroups of one pair each: launch- and latency-bound, as the reference's batch size is"}}
+
+
+def bench_walk_sampler(sp, sampler_mod, dev, K):
+    """subg_acc.c:316-389 on the collab-like graph (configs[0]/[1] parameters: M = 200, 2 hops, first hop without replacement):
+    all N roots -> raw walks int32 [n, M*(m+1)] + per-root (ids, counts) in step-major first-visit order, device part only
+    (the drop-in's numpy hand-over is PCIe).  Outside the clock; >= 5 steps."""
+    from surel_plus_amd import _lib
+    from surel_plus_amd.graphs import preset_graph
+    csr = preset_graph("collab", device=dev)
+    M, m, n = 200, 2, csr.num_nodes
+    q = torch.arange(n, dtype=torch.int32, device=dev)
+
+    def run():
+        s_ = sampler_mod.sample_sets(csr, q, num_walks=M, num_steps=m, seed=5, rng="rand_r", first_hop_wo=True,
+                                     order=_lib.ORDER_STEP_MAJOR, cap_root_degree=False, emit_walks=True, rng_streams=4, dedup=False)
+        return s_, s_.counts_int32()
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        sets, counts = run()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    deg = (csr.indptr[1:] - csr.indptr[:-1]).long()
+    X = int(sets.X)
+    # reads as SURVEY 8(d)'s sampler formula; writes: the raw walks, the ids and the [count, m+1] landing counts (the reference's outputs)
+    abytes = int((4 + 8 + 4 * torch.clamp(deg, max=M) + 12 * M * (m - 1) * (deg > 0).long()).sum().item()) + n * 4 * M * (m + 1) + X * (4 + 4 * (m + 1))
+    ms = wall / K * 1e3
+    return {"metric": "roots/sec (walk_sampler, device part)", "value": n * K / wall, "unit": "roots/s", "steps": K, "ms_per_step": ms,
+            "roots_per_step": n, "set_members": X, "rng": "rand_r (4 streams)",
+            "roofline": {"bound": "hbm", "kernel": "walk_sets_kernel / walk_pipe_kernel (+ rng positions, scan, compaction, LP unpack)",
+                         "achieved": abytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": ms,
+                         "algorithmic_bytes_per_launch": abytes, "note": "whole call (several kernels + allocations), wall clock"}}
+
+
+def device_identity(dev):
+    """what tells two ranks' GPUs apart: PCI bus id / uuid where torch exposes them"""
+    p = torch.cuda.get_device_properties(dev)
+    parts = [str(getattr(p, a)) for a in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id") if hasattr(p, a)]
+    return f"{p.name}|{'|'.join(parts)}|idx{torch.cuda.current_device()}"
+
+
+def gather_rank_records(dist, world, rank, dev, elapsed_local, kernel_ms, backend):
+    """every rank's (rank, device identity, own elapsed, own walk-kernel ms) on rank 0 -- so that the first 8-GPU run is a record,
+    not a debugging session: ranks_seen, distinct devices, per-rank spread"""
+    rec = {"rank": rank, "device": device_identity(dev), "elapsed_ms": elapsed_local * 1e3, "walk_kernel_ms": kernel_ms,
+           "host": os.uname().nodename, "pid": os.getpid()}
+    if dist is None:
+        return [rec]
+    recs = [None] * world
+    dist.all_gather_object(recs, rec)
+    return recs
+
+
+def flatten(out):
+    """The driver keeps the SCALAR keys of `config` (names cut at 40 characters) and drops everything nested: every number
+    DESIGN.md quotes is therefore promoted to a scalar key here; the nested blocks stay for whoever reads the full line."""
+    c = out["config"]
+
+    def put(key, val):
+        assert len(key) <= 40, key
+        if val is not None:
+            c[key] = val
+    for name, short in (("cit2 (rng=rand_r: the reference's own stream, bit-exact mode)", "rand_r"), ("collab", "collab"), ("ppa", "ppa"),
+                        ("twitter", "twitter"), ("cit2ppr", "cit2ppr")):
+        o = (c.get("other_workloads") or {}).get(name) or {}
+        put(f"{short}_pairs_per_s", o.get("value"))
+        put(f"{short}_ms_per_step", o.get("ms_per_step"))
+        r = o.get("roofline") or {}
+        put(f"{short}_frac", r.get("frac"))
+        put(f"{short}_kernel_ms", r.get("kernel_ms"))
+        put(f"{short}_line_roof_frac", (r.get("random_line_roof") or {}).get("frac"))
+        put(f"{short}_traffic_bytes", r.get("traffic"))
+        put(f"{short}_join_ms", ((o.get("config") or {}).get("stage_ms") or {}).get("sjoin_fill"))
+        if "cpu_baseline" in o:
+            put(f"{short}_cpu_pairs_per_s", o["cpu_baseline"].get("value"))
+            put(f"{short}_cpu_cores", o["cpu_baseline"].get("cores"))
+    ws = (c.get("other_workloads") or {}).get("walk_sampler (collab)") or {}
+    put("walk_sampler_collab_roots_per_s", ws.get("value"))
+    put("walk_sampler_collab_frac", (ws.get("roofline") or {}).get("frac"))
+    hg = c.get("hgather") or {}
+    put("hgather_b2048_triplets_per_s", hg.get("value"))
+    put("hgather_b2048_ms_per_step", hg.get("ms_per_step"))
+    put("hgather_b2048_frac", (hg.get("roofline") or {}).get("frac"))
+    f = c.get("offline_flow") or {}
+    put("offline_all_N_ms", f.get("all_N_sample_to_resident_spg_ms"))
+    put("offline_S_roots_per_s", f.get("S_roots_per_s"))
+    put("offline_J_table_pairs_per_s", f.get("J_pairs_per_s_table_store"))
+    put("offline_J_keyed_pairs_per_s", f.get("J_pairs_per_s_keyed_store"))
+    put("offline_Q_1e8_table_pairs_per_s", f.get("Q_amortised_at_1e8_pairs_table"))
+    put("offline_Q_1e8_keyed_pairs_per_s", f.get("Q_amortised_at_1e8_pairs_keyed"))
+    fc = f.get("cpu_baseline") or {}
+    put("offline_cpu_S_roots_per_s", fc.get("S_roots_per_s"))
+    put("offline_cpu_J_pairs_per_s", fc.get("J_pairs_per_s"))
+    put("offline_cpu_Q_1e8_pairs_per_s", fc.get("Q_amortised_at_1e8_pairs"))
+    if "failed" in f:
+        put("offline_flow_failed", f["failed"])
+    bg = c.get("batch_size_and_hip_graph") or {}
+    for key, short in (("B=1024 eager", "b1024_pairs_per_s_eager"), ("B=1024 graph", "b1024_pairs_per_s_graph"),
+                       ("B=1024 graph, 4 lanes", "b1024_pairs_per_s_graph_4lanes"), ("B=1024 graph, 8 lanes", "b1024_pairs_per_s_graph_8lanes"),
+                       ("B=1024 graph, 8 lanes, inputs ready", "b1024_pairs_per_s_8lanes_ready"),
+                       ("B=65536 graph, 8 lanes", "b65536_pairs_per_s_graph_8lanes")):
+        put(short, (bg.get(key) or {}).get("pairs_per_s"))
+    rl = out.get("roofline") or {}
+    lr = rl.get("random_line_roof") or {}
+    rl["line_roof_lines_per_s"] = lr.get("lines_per_s")         # (the driver keeps the roofline block's scalars too)
+    rl["line_roof_frac"] = lr.get("frac")
+    rl["l2_miss_lines_per_launch"] = lr.get("l2_miss_lines_per_launch")
+    sm = c.get("stage_ms") or {}
+    put("walk_kernel_ms", sm.get("walk_sets"))
+    put("join_kernel_ms", sm.get("sjoin_fill"))
+
+
 def summary(o):
     """what an `other_workloads` entry keeps of a full line"""
     keep = {k_: o[k_] for k_ in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype")}
@@ -554,6 +818,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the short passes over BASELINE.json's other configs")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; invalidates the number)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --pairs per step PER GPU (the driver's scaling runs); strong: --pairs per step in all, split over "
+                         "the ranks as shard.shard_pairs splits a batch (contiguous shares)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -594,6 +861,13 @@ def main():
     from surel_plus_amd import sampler as sampler_mod
 
     B, K, W = args.pairs, args.steps, args.warmup
+    if args.scaling == "strong":      # one fixed batch per step, every rank its contiguous share (shard.shard_range)
+        from surel_plus_amd.shard import shard_range
+        lo, hi = shard_range(args.pairs, rank, world)
+        B = hi - lo
+        if args.pairs % world:
+            sys.exit(f"bench.py --scaling strong: --pairs {args.pairs} must be a multiple of the {world} ranks (equal shares keep "
+                     f"value = pairs / max-over-ranks time honest)")
     t_start = time.perf_counter()
     if WORKLOADS[args.workload][0] is None:
         out = bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, WORKLOADS[args.workload][3], B, K, W)
@@ -602,7 +876,8 @@ def main():
                        with_cpu_baseline=(world == 1 and not args.no_cpu_baseline),
                        small_batches=(world == 1 and not args.no_others),
                        two_stream_extra=not args.no_others,      # --no-others: the profiled command, single-stream steps only
-                       csr_variant=not args.no_others)           # ... and no pass with the packed-CSR (table rows) variant
+                       csr_variant=not args.no_others,           # ... and no pass with the packed-CSR (table rows) variant
+                       offline=(rank == 0 and world == 1 and not args.no_others and args.scale == 1.0))
     # BASELINE.json's other single-GPU configurations (and the reference-bit-exact rand_r stream on the headline one),
     # as short passes after the timed region: same code path, >= 5 timed steps each, their own roofline blocks
     # (configs[0], the reference's CPU-runnable collab case, rides on the collab entry as its cpu_baseline).
@@ -626,8 +901,14 @@ def main():
                 others[key] = summary(o)
             except Exception as ex:   # an extra must never cost the headline line
                 others[key] = {"failed": f"{type(ex).__name__}: {ex}"}
+        try:
+            torch.cuda.empty_cache()
+            others["walk_sampler (collab)"] = bench_walk_sampler(sp, sampler_mod, dev, 5)
+        except Exception as ex:
+            others["walk_sampler (collab)"] = {"failed": f"{type(ex).__name__}: {ex}"}
         out["config"]["other_workloads"] = others
     if rank == 0:
+        flatten(out)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

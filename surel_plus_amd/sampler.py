@@ -34,6 +34,7 @@ FINISH_MAX_STRIDE = 1024   # subgacc_finish_rows sorts a row from registers (16 
 HOP_RECORDS = os.environ.get("SUBGACC_HOP_RECORDS", "auto")
 HOP_RECORDS_MIN_BYTES = 64 << 20      # adjacency bytes from which records are built in "auto" mode
 HOP_RECORDS_MIN_DEG_BITS = 12
+HOP_RECORDS_MAX_FREE_FRACTION = 0.25    # of the free device memory, in "auto" mode
 
 # Key rows (csrc/walk_rows.hip KR form + subgacc_sjoin_fill_keyrows): a strided batch that will not be numbered carries its
 # members' 32-bit LP keys instead of slots of a table of distinct rows; the join unpacks a key into its feature row itself.
@@ -138,23 +139,33 @@ class DeviceCSR:
         L = lib()
         out = None
         big = mode == "1" or bits is not None or 4 * self.nnz >= HOP_RECORDS_MIN_BYTES
-        if self.indptr64:                           # 16-byte form: {id | degree, row begin}
-            if big:
-                recs = torch.empty(2 * self.nnz, dtype=torch.int64, device=self.device)
-                check(L.subgacc_hop_records_build(ptr(self.indptr), 1, ptr(self.indices), self.num_nodes, self.nnz, 0, 0, ptr(recs),
-                                                  stream_ptr()))
-                out = (recs, 0, 0)
-        else:
-            ib, bb = ctypes.c_int32(0), ctypes.c_int32(0)
-            deg_bits = L.subgacc_hop_records_format(self.num_nodes, self.nnz, ctypes.byref(ib), ctypes.byref(bb))
-            if bits is not None:
-                ib, bb = ctypes.c_int32(int(bits[0])), ctypes.c_int32(int(bits[1]))
-                deg_bits = 64 - ib.value - bb.value
-            if big and deg_bits >= (HOP_RECORDS_MIN_DEG_BITS if (mode == "auto" and bits is None) else 1):
-                recs = torch.empty(self.nnz, dtype=torch.int64, device=self.device)
-                check(L.subgacc_hop_records_build(ptr(self.indptr), 0, ptr(self.indices), self.num_nodes, self.nnz, ib.value,
-                                                  bb.value, ptr(recs), stream_ptr()))
-                out = (recs, ib.value, bb.value)
+        rec_bytes = (16 if self.indptr64 else 8) * self.nnz
+        if big and mode == "auto" and bits is None:
+            # "auto" never spends more than a quarter of the free memory on an array that buys ~8 % of the walk kernel (the
+            # twitter-like graph: 47 GB of records beside a 12 GB CSR), and a failed allocation means "walk the plain CSR"
+            big = rec_bytes <= HOP_RECORDS_MAX_FREE_FRACTION * torch.cuda.mem_get_info(self.device)[0]
+        try:
+            if self.indptr64:                           # 16-byte form: {id | degree, row begin}
+                if big:
+                    recs = torch.empty(2 * self.nnz, dtype=torch.int64, device=self.device)
+                    check(L.subgacc_hop_records_build(ptr(self.indptr), 1, ptr(self.indices), self.num_nodes, self.nnz, 0, 0, ptr(recs),
+                                                      stream_ptr()))
+                    out = (recs, 0, 0)
+            else:
+                ib, bb = ctypes.c_int32(0), ctypes.c_int32(0)
+                deg_bits = L.subgacc_hop_records_format(self.num_nodes, self.nnz, ctypes.byref(ib), ctypes.byref(bb))
+                if bits is not None:
+                    ib, bb = ctypes.c_int32(int(bits[0])), ctypes.c_int32(int(bits[1]))
+                    deg_bits = 64 - ib.value - bb.value
+                if big and deg_bits >= (HOP_RECORDS_MIN_DEG_BITS if (mode == "auto" and bits is None) else 1):
+                    recs = torch.empty(self.nnz, dtype=torch.int64, device=self.device)
+                    check(L.subgacc_hop_records_build(ptr(self.indptr), 0, ptr(self.indices), self.num_nodes, self.nnz, ib.value,
+                                                      bb.value, ptr(recs), stream_ptr()))
+                    out = (recs, ib.value, bb.value)
+        except torch.cuda.OutOfMemoryError:
+            if mode != "auto":
+                raise
+            out = None
         self._recs = (key, out)
         return out
 
