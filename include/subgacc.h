@@ -75,6 +75,10 @@ typedef struct subgacc_walk_cfg {
      * ignored: the plain CSR is walked). */
     const void *hop_records;
     int32_t rec_id_bits, rec_beg_bits;
+    /* ABI 4: RAND_R on a graph with dead ends -- the stream position (LCG steps from the stream's seed) of every WALK,
+     * uint32 [n * num_walks] for the n roots of the call, from subgacc_rng_replay; NULL = positions follow from the
+     * degrees (subgacc_rng_positions), the symmetrised graphs of the reference's loader. */
+    const uint32_t *walk_pos;
 } subgacc_walk_cfg;
 
 /* Hop records: rec[e] = [indices[e] : id_bits | indptr[indices[e]] : beg_bits | degree(indices[e]) : rest], one uint64 per
@@ -102,6 +106,16 @@ size_t subgacc_rng_positions_workspace_bytes(int64_t n);
 int subgacc_rng_positions(const subgacc_walk_cfg *cfg, const void *indptr, int64_t num_nodes, const int32_t *query, int64_t n,
                           int32_t rng_streams, uint64_t calls_before, uint32_t *rng_pos, uint32_t *rng_seed,
                           void *workspace, size_t workspace_bytes, void *stream);
+
+/* The same positions for a graph WITH dead ends (a reached node without out-edges draws nothing in the reference and the
+ * walk stays there, subg_acc.c:804-808, :168-172, :236-240: the position of every later draw then depends on how the earlier
+ * walks ended).  One wavefront per stream replays it -- 64 walks at a time, right up to the first walk that ended early --
+ * and writes rng_pos / rng_seed as above plus walk_pos [n * num_walks], which the walk entry points take through
+ * cfg->walk_pos (they then run their general kernel).  Costs one dependent read per hop per walk of the sequential stream:
+ * a fall-back for inputs the reference accepts, taken by the host mirror when a walk kernel reports flags[0] & 1. */
+int subgacc_rng_replay(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,
+                       const int32_t *query, int64_t n, int32_t rng_streams, uint64_t calls_before, uint32_t *rng_pos,
+                       uint32_t *rng_seed, uint32_t *walk_pos, void *stream);
 
 /* Sample n roots.  Outputs per root i, at fixed offsets i*stride (stride = bucket or M*m+1):
  *   set_ids [n*stride] int32   members in first-visit order (root first)

@@ -14,7 +14,11 @@ GPU box.  The fixtures it writes are data only: seeded inputs and the outputs th
   G8  batch_*.npz   subg_acc.batch_sampler (legacy SUREL mini-batch former); the reference seeds it with seed + getpid()
                     (:421), so every fixture records the effective seed of the run that made it   subg_acc/subg_acc.c:391-507
 
-`python oracle/gen_golden.py [rand_r gset walk sjoin walkjoin batch]` regenerates the named groups (default: all).
+  G9  gset_dir*.npz / walk_dir*.npz   the same two samplers on DIRECTED graphs: walks reach nodes without out-edges, draw
+                    nothing there and stay (subg_acc.c:804-808, :168-172, :236-240) -- the rand_r stream position of every
+                    later walk then depends on how the earlier ones ended
+
+`python oracle/gen_golden.py [rand_r gset walk sjoin walkjoin batch directed]` regenerates the named groups (default: all).
 """
 import ctypes
 import os
@@ -129,6 +133,49 @@ def gen_walk():
                                     nsize=nsize, ids=ids, counts=counts)
 
 
+def dir_graph(N, E, seed, star=0):
+    """Small DIRECTED simple graph (no G + G.T): about a third of the nodes end up without out-edges."""
+    rng = np.random.default_rng(seed)
+    r = rng.integers(0, (2 * N) // 3, E)          # only the first two thirds of the nodes have out-edges at all
+    c = rng.integers(0, N, E)
+    if star:
+        r = np.concatenate([r, np.zeros(star, int)])
+        c = np.concatenate([c, rng.choice(np.arange(1, N), star, replace=False)])
+    A = sp.csr_matrix((np.ones(len(r)), (r, c)), shape=(N, N))
+    A.sum_duplicates()
+    A.setdiag(0)
+    A.eliminate_zeros()
+    A.sort_indices()
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32)
+
+
+DIRECTED_CASES = {
+    # name: (N, E, gseed, star, M, m)
+    "dirsparse": (300, 500, 11, 0, 20, 3),       # most walks end early
+    "dirhub":    (400, 2400, 12, 120, 16, 4),    # a hub root with deg > M (shuffled first hop) in front of the dead ends
+    "dircollab": (1200, 5000, 13, 260, 200, 2),  # the collab parameters
+}
+
+
+def gen_directed():
+    for name, (N, E, gs, star, M, m) in DIRECTED_CASES.items():
+        ptr, idx = dir_graph(N, E, gs, star)
+        assert int((np.diff(ptr) == 0).sum()) > N // 4
+        q = np.arange(N) if N <= 400 else np.sort(np.random.default_rng(gs).choice(N, 300, replace=False))
+        nsize, remap, enc, raw = ref.gset_sampler(ptr, idx, q, num_walks=M, num_steps=m, bucket=-1, nthread=1, seed=111413, debug=1)
+        remap = mask_isolated(ptr, q, nsize, remap)
+        np.savez_compressed(os.path.join(OUT, f"gset_{name}_s111413.npz"), indptr=ptr, indices=idx, query=q, M=M, m=m, bucket=-1,
+                            seed=111413, nsize=nsize, remap=remap, enc=enc, raw=raw)
+        for rep in (False, True):
+            for T in (1, 3):
+                walks, obj = ref.walk_sampler(ptr, idx, q, num_walks=M, num_steps=m, nthread=T, seed=7, replacement=rep)
+                nsz = np.array([len(obj[i, 0]) for i in range(len(q))], np.int32)
+                ids = np.concatenate([obj[i, 0] for i in range(len(q))]).astype(np.int32)
+                counts = np.concatenate([obj[i, 1] for i in range(len(q))]).astype(np.int32)
+                np.savez_compressed(os.path.join(OUT, f"walk_{name}_r{int(rep)}_t{T}.npz"), indptr=ptr, indices=idx, query=q, M=M, m=m,
+                                    seed=7, nthread=T, replacement=rep, walks=walks, nsize=nsz, ids=ids, counts=counts)
+
+
 def random_spg(N, maxlen, c, seed, float_payload=False, empty_rows=()):
     """A synthetic SpG in the shape subg_matrix produces: sorted unique ids per row, data >= 1."""
     rng = np.random.default_rng(seed)
@@ -235,7 +282,7 @@ def gen_rand_r():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     groups = {"rand_r": gen_rand_r, "gset": gen_gset, "walk": gen_walk, "sjoin": gen_sjoin, "walkjoin": gen_walkjoin,
-              "batch": gen_batch}
+              "batch": gen_batch, "directed": gen_directed}
     for g in (sys.argv[1:] or list(groups)):
         groups[g]()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))

@@ -33,7 +33,7 @@ SYMBOLS = (
     "subgacc_batch_sampler_workspace_bytes", "subgacc_batch_sampler", "subgacc_step_prologue",
     "subgacc_hop_records_format", "subgacc_hop_records_build", "subgacc_sjoin_fill_keyrows", "subgacc_sjoin_fill_keys", "subgacc_step_dedup_workspace_bytes",
     "subgacc_step_prologue_dedup", "subgacc_walk_spg_sparse",
-    "subgacc_keyrows_register", "subgacc_walk_tags", "subgacc_keyrows_compact", "subgacc_keyrows_translate", "subgacc_line_probe",
+    "subgacc_keyrows_register", "subgacc_walk_tags", "subgacc_keyrows_compact", "subgacc_keyrows_translate", "subgacc_line_probe", "subgacc_rng_replay",
 )
 
 
@@ -42,7 +42,8 @@ class WalkCfg(C.Structure):
     _fields_ = [("num_walks", C.c_int32), ("num_steps", C.c_int32), ("bucket", C.c_int32), ("rng_mode", C.c_int32),
                 ("seed", C.c_uint32), ("first_hop_wo", C.c_int32), ("order", C.c_int32),
                 ("cap_root_degree", C.c_int32), ("indptr64", C.c_int32), ("emit_walks", C.c_int32),
-                ("hop_records", C.c_void_p), ("rec_id_bits", C.c_int32), ("rec_beg_bits", C.c_int32)]
+                ("hop_records", C.c_void_p), ("rec_id_bits", C.c_int32), ("rec_beg_bits", C.c_int32),
+                ("walk_pos", C.c_void_p)]
 
 
 class SubgAccError(RuntimeError):
@@ -130,6 +131,7 @@ def lib():
     sig["subgacc_keyrows_compact"] = (C.c_int, [vp, vp, vp, vp, i64, i32, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp])
     sig["subgacc_keyrows_translate"] = (C.c_int, [vp, i64, vp, vp, i64, vp, vp, i64, vp])
     sig["subgacc_line_probe"] = (C.c_int, [vp, i64, i32, C.c_uint32, vp, C.POINTER(C.c_int64), vp])
+    sig["subgacc_rng_replay"] = (C.c_int, [cfgp, vp, vp, i64, vp, i64, i32, u64, vp, vp, vp, vp])
     assert set(sig) == set(SYMBOLS)
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

@@ -208,7 +208,9 @@ __global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_n
         int ph_blk = -1;
         if (RNG == SUBGACC_RNG_RAND_R) {
             const uint32_t per_walk = (uint32_t)(a.wo ? m - 1 : m);
-            x = lcg_jump(rseed, rpos + 3u * ((shuffled ? (uint32_t)M : 0u) + (uint32_t)w * per_walk));
+            // (walk_pos: the graph has dead ends, the position of every walk was found by replaying the stream, replay.hip)
+            x = a.walk_pos ? lcg_jump(rseed, a.walk_pos[i * (int64_t)M + w])
+                           : lcg_jump(rseed, rpos + 3u * ((shuffled ? (uint32_t)M : 0u) + (uint32_t)w * per_walk));
         }
         int32_t *wrow = a.walks ? a.walks + (i * (int64_t)M + w) * (m + 1) : nullptr;
         if (wrow) wrow[0] = root;
@@ -257,8 +259,8 @@ __global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_n
                     }
                     cur = SG_NEIGH_LOAD(&a.indices[b + (int64_t)(RNG == SUBGACC_RNG_RAND_R ? r % (uint32_t)d
                                                                                            : philox_below(r, (uint32_t)d))]);
-                } else if (RNG == SUBGACC_RNG_RAND_R) {
-                    atomicOr(&a.flags[0], 1);  // dead end: the sequential stream is no longer reproducible
+                } else if (RNG == SUBGACC_RNG_RAND_R && !a.walk_pos) {
+                    atomicOr(&a.flags[0], 1);  // dead end: the positions computed from the degrees no longer hold (the host replays)
                 }
             }
 #if SG_EXPERIMENT == 2
@@ -768,6 +770,7 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
     a.indptr = indptr, a.indices = indices, a.query = query, a.n = n, a.num_nodes = num_nodes;
     a.worklist = worklist, a.n_work = n_work;
     a.work_cap = work_cap, a.tags_only = tags_only ? 1 : 0;
+    a.walk_pos = cfg->rng_mode == SUBGACC_RNG_RAND_R ? cfg->walk_pos : nullptr;
     a.rng_pos = rng_pos, a.rng_seed = rng_seed;
     a.set_ids = set_ids, a.set_keys = set_keys, a.nsize = nsize;
     a.walks = cfg->emit_walks ? walks : nullptr;
@@ -801,11 +804,12 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
     hipStream_t s = (hipStream_t)stream;
     // the persistent, software-pipelined form takes every launch it supports (SUBGACC_WALK_PIPE=0 forces this file's)
     static const bool use_pipe = !(getenv("SUBGACC_WALK_PIPE") && getenv("SUBGACC_WALK_PIPE")[0] == '0');
-    if (use_pipe && !holes && launch_walk_pipe(a, cfg->indptr64 != 0, cfg->rng_mode, spg, lds, s)) {
+    // (replayed stream positions, walk_pos: only the general kernel below reads them)
+    if (use_pipe && !holes && !a.walk_pos && launch_walk_pipe(a, cfg->indptr64 != 0, cfg->rng_mode, spg, lds, s)) {
         SG_LAUNCH_CHECK();
         return SUBGACC_OK;
     }
-    if (spg && lds <= 64 * 1024 && launch_walk_rows(a, cfg->indptr64 != 0, cfg->rng_mode, lds, s)) {
+    if (spg && lds <= 64 * 1024 && !a.walk_pos && launch_walk_rows(a, cfg->indptr64 != 0, cfg->rng_mode, lds, s)) {
         SG_LAUNCH_CHECK();
         return SUBGACC_OK;
     }

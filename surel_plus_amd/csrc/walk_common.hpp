@@ -123,6 +123,7 @@ struct WalkArgs {
     int32_t keyrows;     // fused rows carry the member's 32-bit LP key itself instead of a table slot (no table of distinct rows)
     const unsigned long long *recs;   // packed hop records (walk_rows_kernel<REC>), else NULL
     RecFmt rec;                       // id_bits = 0: the 16-byte form {id : 32 | degree : 32, row begin : 64} (int64 row offsets)
+    const uint32_t *walk_pos;   // rand_r on a graph with dead ends (replay.hip): the stream position of every WALK, [n*M]; else NULL
     int64_t work_cap;    // with a work list: the launch covers min(n, work_cap) rows (0 = n); a longer list raises flags[3] |= 32
     int32_t tags_only;   // table-form fused rows (subgacc_walk_tags): register the set's LP keys with their exact first-visit tags
                          // and leave -- no row, no nsize is written (the rows exist already, as key rows)

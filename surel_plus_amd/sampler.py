@@ -10,7 +10,9 @@ are fetched in one copy when the caller first asks for them (SampledSets.resolve
 sample -> SpG -> SpJoin step queues up asynchronously.
 """
 import ctypes
+import functools
 import os
+import threading
 from dataclasses import dataclass
 
 import numpy as np
@@ -68,6 +70,7 @@ def key_rows_ok(num_walks, num_steps):
 # bench.py sets this to a callable(name) -> context manager that brackets one kernel launch with HIP events
 # on the launch stream (roofline.achieved is measured live, not taken from a profile)
 KERNEL_TIMER = None
+_RECS_LOCK = threading.Lock()
 
 
 class _NoTimer:
@@ -131,10 +134,19 @@ class DeviceCSR:
         cached = getattr(self, "_recs", None)
         if cached is not None and force is None and bits is None:
             return cached[1]                       # decided before (by the policy, or by an explicit call): it sticks
+        with _RECS_LOCK:       # a DeviceCSR is shared between threads and streams: built once, complete before it is published
+            cached = getattr(self, "_recs", None)
+            if cached is not None and force is None and bits is None:
+                return cached[1]
+            out = self._build_hop_records(force, bits)
+            if out is not None and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream(self.device).synchronize()
+            self._recs = (tuple(bits) if bits is not None else None, out)
+            return out
+
+    def _build_hop_records(self, force, bits):
         mode = HOP_RECORDS if force is None else ("1" if force else "0")
-        key = tuple(bits) if bits is not None else None
         if mode == "0" or self.nnz == 0:
-            self._recs = (key, None)
             return None
         L = lib()
         out = None
@@ -166,7 +178,6 @@ class DeviceCSR:
             if mode != "auto":
                 raise
             out = None
-        self._recs = (key, out)
         return out
 
 
@@ -203,6 +214,7 @@ class SampledSets:
     _ktable: torch.Tensor = None  # keyrows: the table of distinct LP rows once number() has built it (capacity _kcap)
     _kcap: int = 0
     _kcount: torch.Tensor = None  # ... and the number of distinct rows, on the device
+    _join_flags: torch.Tensor = None   # sample_and_gather(lazy=True): the join's int32[4] status words (resolve() checks them)
 
     # ------------------------------------------------------------------ lazy bookkeeping
     @property
@@ -218,7 +230,10 @@ class SampledSets:
         if self._tail is not None:      # the step's buffers keep the join's row count next to the status words: no cat
             src = self._tail
         else:
-            src = self.status if extra is None else torch.cat([self.status, extra.reshape(-1).to(torch.int64)])
+            parts = [self.status] + ([extra.reshape(-1).to(torch.int64)] if extra is not None else [])
+            if self._join_flags is not None:      # a lazy join's status word rides along (last): resolve() raises for it
+                parts.append(self._join_flags[3:4].to(torch.int64))
+            src = parts[0] if len(parts) == 1 else torch.cat(parts)
         host = torch.empty(src.numel(), dtype=torch.int64, pin_memory=True)
         host.copy_(src, non_blocking=True)
         ev = torch.cuda.Event()
@@ -236,7 +251,16 @@ class SampledSets:
             st = host.tolist()
             self._pending = None
         else:
-            st = (self._tail if self._tail is not None else self.status).tolist()
+            src = self._tail if self._tail is not None else self.status
+            if self._tail is None and self._join_flags is not None:
+                src = torch.cat([src, self._join_flags[3:4].to(torch.int64)])
+            st = src.tolist()
+        if self._tail is None and self._join_flags is not None:
+            join_word, st = int(st[-1]), st[:-1]
+            self._join_flags = None
+            if join_word & 16:
+                self.status = None
+                raise IndexError("row index out of range for the SpG (lazy join: the row was joined as an empty row)")
         if self._tail is not None:      # [rows, w0, w1, w2, w3]: every row of the join is a member of an own set
             self.extra = st[:1]
             if len(st) > 5:             # root dedup: the sets of the distinct endpoints are fewer than the join's rows
@@ -426,17 +450,24 @@ def unpack_status(words):
     return [w[0] & 0xFFFFFFFF, (w[0] >> 32) & 0xFFFFFFFF, w[1] & 0xFFFFFFFF, (w[1] >> 32) & 0xFFFFFFFF] + w[2:]
 
 
+class RandRDeadEnd(_lib.SubgAccError):
+    """rng='rand_r': a walk stood on a node without out-edges, so the stream positions computed from the degrees do not hold.
+    sample_sets catches it and samples again with replayed positions (subgacc_rng_replay); a lazy batch, which reports it only
+    at resolve(), has to be sampled again by its caller (lazy=False)."""
+
+
 def check_walk_flags(sets, fl):
     if fl[3] & 32:
         raise _lib.SubgAccError("internal: the candidate list of the batched registration outgrew its launch")
     if fl[3] & 16:
         raise IndexError("query node ids outside [0, num_nodes) (such a root is never looked up on the device; the "
-                         "reference reads out of bounds for it)")
+                         "reference reads out of bounds for it) -- or, for a step whose join shares these status words "
+                         "(StepBuffers / CapturedStep), a join row number outside the store")
     if fl[0]:
-        raise _lib.SubgAccError(
-            "rng='rand_r' cannot reproduce the sequential stream on this graph: a walk reached a node without "
-            "out-edges, so the number of draws is data dependent (the reference's graphs are symmetrised, "
-            "dataloader.py:122-135). Use rng='philox'.")
+        raise RandRDeadEnd(
+            "rng='rand_r': a walk reached a node without out-edges, so the number of draws is data dependent (the "
+            "reference's graphs are symmetrised, dataloader.py:122-135) and the stream has to be replayed: sample this "
+            "batch again with lazy=False (which does so by itself), or use rng='philox'.")
     sets.n_overflow = fl[1]
     if fl[1] and _lib.VERBOSE:
         print(f"#SubGAcc: {fl[1]} keys exceed the buffer, try a larger bucket size > {sets.stride}.")
@@ -473,11 +504,29 @@ def _cat(parts, dtype, dev):
     return parts[0] if len(parts) == 1 else torch.cat(parts)
 
 
+def _replays_dead_ends(fn):
+    @functools.wraps(fn)
+    def wrapper(*a, **kw):
+        if kw.get("walk_replay"):
+            return fn(*a, **kw)
+        try:
+            return fn(*a, **kw)
+        except RandRDeadEnd:
+            return fn(*a, **dict(kw, walk_replay=True))
+    return wrapper
+
+
+@_replays_dead_ends
 def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, rng="rand_r", first_hop_wo=True,
                 order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False, rng_streams=1,
                 calls_before=0, dedup=True, keep_keys=None, staging_bytes=None, uniq_capacity=UNIQ_CAPACITY,
-                uniq_small_limit=0, fused_rows=False, lazy=False, strided=False, number_rows=True, key_rows=None):
+                uniq_small_limit=0, fused_rows=False, lazy=False, strided=False, number_rows=True, key_rows=None,
+                walk_replay=False):
     """Run the sampler for `query` (roots) on the GPU.  See SampledSets.
+
+    rng="rand_r" on a graph with dead ends (directed graphs: a reached node without out-edges draws nothing in the reference,
+    subg_acc.c:804-808): the first attempt notices (RandRDeadEnd) and the batch is sampled again with walk_replay=True -- the
+    stream is replayed by subgacc_rng_replay for the position of every walk, then the general walk kernel samples the sets.
 
     dedup=True numbers the distinct LP rows (ukeys, slot / get_sf()); the packed keys are then only kept when
     keep_keys is set.  fused_rows=True uses subgacc_walk_spg: `ids` come out sorted by node id per root and `data`
@@ -493,7 +542,8 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     dev = csr.device
     q = _as_query(query, dev)
     n = q.numel()
-    records = bool(fused_rows) and bucket <= 0 and num_walks * num_steps + 1 <= FUSED_MAX_Q and 2 <= num_steps <= 4
+    walk_replay = bool(walk_replay and rng == "rand_r")
+    records = bool(fused_rows) and bucket <= 0 and num_walks * num_steps + 1 <= FUSED_MAX_Q and 2 <= num_steps <= 4 and not walk_replay
     cfg = make_cfg(csr, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order, cap_root_degree, emit_walks, records)
     check(L.subgacc_key_shift(cfg.num_walks, cfg.num_steps))   # AssertionError like subg_acc.c:911-915
     M, m = cfg.num_walks, cfg.num_steps
@@ -521,14 +571,23 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     if strided and not ((fused_rows or finish) and n > 0 and chunk == n):
         return None
 
-    rng_pos, rng_seed = _rng_positions(L, cfg, csr, q, n, rng_streams, calls_before, st)
+    walk_pos = None
+    if walk_replay and n:      # the stream replayed: the position of every root and of every walk (subgacc_rng_replay)
+        rng_pos = torch.empty(n, dtype=torch.int32, device=dev)
+        rng_seed = torch.empty(n, dtype=torch.int32, device=dev)
+        walk_pos = torch.empty(n * M, dtype=torch.int32, device=dev)
+        check(L.subgacc_rng_replay(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q), n, int(rng_streams), int(calls_before),
+                                   ptr(rng_pos), ptr(rng_seed), ptr(walk_pos), st))
+    else:
+        rng_pos, rng_seed = _rng_positions(L, cfg, csr, q, n, rng_streams, calls_before, st)
     # key rows: strided fused rows that nobody asked to number carry LP keys instead of table slots (module header)
     if key_rows is None:
         key_rows = KEY_ROWS
     key_rows = bool(key_rows and strided and fused_rows and not number_rows and bucket <= 0 and n > 0 and chunk == n
-                    and key_rows_ok(M, m))
+                    and key_rows_ok(M, m) and not walk_replay)
     # a store that is kept: key rows as well, registered by one pass over the rows (csrc/keyrows.hip, module header)
-    batched = bool(BATCHED_REGISTRATION and fused_rows and dedup and not strided and bucket <= 0 and n > 0 and key_rows_ok(M, m))
+    batched = bool(BATCHED_REGISTRATION and fused_rows and dedup and not strided and bucket <= 0 and n > 0 and key_rows_ok(M, m)
+                   and not walk_replay)
     table = None
     if dedup and not key_rows:
         table = torch.empty(L.subgacc_uniq_table_bytes(uniq_capacity), dtype=torch.uint8, device=dev)
@@ -546,6 +605,8 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     X = 0
     for lo in range(0, n, chunk if chunk else 1):
         cn = min(chunk, n - lo)
+        if walk_pos is not None:
+            cfg.walk_pos = walk_pos[lo * M:].data_ptr()
         with _timed("walk_sets"):
             if fused_rows:
                 check(L.subgacc_walk_spg(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn, lo,
@@ -611,7 +672,7 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
                     return sample_sets(csr, q, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order,
                                        cap_root_degree, emit_walks, rng_streams, calls_before, dedup, keep_keys,
                                        staging_bytes, uniq_capacity * 4, uniq_small_limit, fused_rows, lazy, strided,
-                                       number_rows)
+                                       number_rows, walk_replay=walk_replay)
                 if st_host[4] > max_unique:       # more distinct rows than the direct ranking numbers: the caller
                     return None                   # (sample_spg) falls through to the packed forms
                 sets.resolve()
@@ -701,7 +762,7 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     if st_host[2]:
         return sample_sets(csr, q, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order, cap_root_degree,
                            emit_walks, rng_streams, calls_before, dedup, keep_keys, staging_bytes, uniq_capacity * 4,
-                           uniq_small_limit, fused_rows, lazy, strided, number_rows)
+                           uniq_small_limit, fused_rows, lazy, strided, number_rows, walk_replay=walk_replay)
     sets.resolve()
     sets.ukeys = sets.ukeys.clone()
     return sets

@@ -6,6 +6,7 @@ same argument meaning, same return values (xz float32 [R,2,k], indptr-or-segment
 as a float32 CUDA tensor or None for a float payload.  The work is done by csrc/sjoin.hip.
 """
 import os
+import threading
 import weakref
 
 import numpy as np
@@ -29,11 +30,18 @@ def _as_spg(x):
     except TypeError:
         hit = None
     if hit is None:
-        hit = SpG.from_scipy(x)
-        try:
-            _scipy_cache[x] = hit
-        except TypeError:
-            pass
+        with _CACHE_LOCK:       # uploaded once, complete before another thread / stream can pick it up
+            try:
+                hit = _scipy_cache.get(x)
+            except TypeError:
+                hit = None
+            if hit is None:
+                hit = SpG.from_scipy(x)
+                torch.cuda.current_stream(hit.device).synchronize()
+                try:
+                    _scipy_cache[x] = hit
+                except TypeError:
+                    pass
     return hit
 
 
@@ -224,7 +232,20 @@ def _size_and_row_check(seg, S, flags, n_rows):
 _DEBUG_FLAGS = os.environ.get("SUBGACC_DEBUG", "0") == "1"
 
 
-def _checked(out, ind, flags):
+def lazy_join_status(ind):
+    """A lazy join reads nothing back, so a row number outside the store -- an IndexError of scipy's x[edge[0]] in the reference,
+    train.py:15 -- cannot be raised when the join is queued: such a row reads as empty and the join's status word keeps the
+    fact.  This reads that word for the `ind` a lazy gather() returned (one small host read, whenever the caller resolves the
+    batch) and raises like the eager form; sample_and_gather(lazy=True) carries the word in its sets' status: resolve() raises."""
+    flags = getattr(ind, "join_flags", None)
+    if flags is not None and int(flags[3].item()) & 16:
+        raise IndexError("row index out of range for the SpG (lazy join: the row was joined as an empty row)")
+    return ind
+
+
+def _checked(out, ind, flags, lazy=False):
+    if lazy:
+        ind.join_flags = flags       # see lazy_join_status()
     if _DEBUG_FLAGS:
         f = int(flags[3].item())
         if f & 16:
@@ -243,7 +264,7 @@ def gather(edge, x, device=None, ptr=True, encode=None, out=None, lazy=False):
     e = _as_rows(edge, spg.device)
     own = torch.cat([e[0], e[1]])
     partner = torch.cat([e[1], e[0]])
-    return _checked(*sjoin(spg, own, partner, encode, ptr_mode=ptr, pair_block=e.shape[1], out=out, lazy=lazy))
+    return _checked(*sjoin(spg, own, partner, encode, ptr_mode=ptr, pair_block=e.shape[1], out=out, lazy=lazy), lazy=lazy)
 
 
 def hgather(hedge, x, device=None, encode=None):
@@ -449,21 +470,32 @@ def sample_and_gather(csr, edge, num_walks=200, num_steps=3, seed=111413, rng="p
         xz, ind = gather(rows, z, e.device, ptr=True, encode=table, out=out, lazy=lazy)
     else:
         own, partner = _arange_segments(B, e.device)
-        xz, ind = _checked(*sjoin(_as_spg(z), own, partner, table, ptr_mode=True, pair_block=B, out=out, lazy=lazy))
+        xz, ind = _checked(*sjoin(_as_spg(z), own, partner, table, ptr_mode=True, pair_block=B, out=out, lazy=lazy), lazy=lazy)
+    if lazy:      # the join's status word travels with the sets' own: resolve() raises IndexError for a row outside the store
+        sets._join_flags = getattr(ind, "join_flags", None)
     return xz, ind, sets
 
 
 _ARANGE_SEGMENTS = {}
+_CACHE_LOCK = threading.Lock()     # the reference's pgather calls the join from 4 Python threads (train.py:88-99)
 
 
 def _arange_segments(B, device):
     """gather()'s segment lists for edge = [[0..B), [B..2B)] -- the rows of a batch sampled endpoint by endpoint -- kept per
-    (B, device): a serving loop does not rebuild them (three small kernels) for every batch."""
+    (B, device): a serving loop does not rebuild them (three small kernels) for every batch.  Shared between threads and
+    streams: built under a lock and COMPLETE (the building stream is synchronised, once) before anybody else can see them."""
     key = (int(B), str(device))
-    if key not in _ARANGE_SEGMENTS:
-        own = torch.arange(2 * B, device=device, dtype=torch.int64)
-        _ARANGE_SEGMENTS[key] = (own, torch.cat([own[B:], own[:B]]).contiguous())
-    return _ARANGE_SEGMENTS[key]
+    hit = _ARANGE_SEGMENTS.get(key)
+    if hit is None:
+        with _CACHE_LOCK:
+            hit = _ARANGE_SEGMENTS.get(key)
+            if hit is None:
+                own = torch.arange(2 * B, device=device, dtype=torch.int64)
+                hit = (own, torch.cat([own[B:], own[:B]]).contiguous())
+                if not torch.cuda.is_current_stream_capturing():
+                    torch.cuda.current_stream(own.device).synchronize()
+                _ARANGE_SEGMENTS[key] = hit
+    return hit
 
 
 def gather_counts(edge, x, table_rows, device=None):

@@ -129,16 +129,63 @@ def test_philox_is_schedule_independent(sp):
     assert np.array_equal(full.keys.cpu().numpy()[off[1000]:off[1200]], part.keys.cpu().numpy())
 
 
-def test_rand_r_dead_end_is_reported(sp):
-    """A directed graph with a sink: the sequential rand_r stream is not reproducible in parallel -> loud error."""
+def dir_graph(N, E, seed, hubs=0):
+    """a directed graph: the last third of the nodes has no out-edges at all"""
+    import scipy.sparse as sps
+    rng = np.random.default_rng(seed)
+    r, c = rng.integers(0, (2 * N) // 3, E), rng.integers(0, N, E)
+    if hubs:
+        r = np.concatenate([r, np.repeat(np.arange(hubs), N // 3)])
+        c = np.concatenate([c, rng.integers(0, N, hubs * (N // 3))])
+    A = sps.csr_matrix((np.ones(len(r)), (r, c)), shape=(N, N))
+    A.sum_duplicates(); A.setdiag(0); A.eliminate_zeros(); A.sort_indices()
+    return A.indptr.astype(np.int32), A.indices.astype(np.int32)
+
+
+def test_rand_r_dead_end_is_replayed(sp):
+    """A directed graph with a sink: the reference draws nothing on it and carries on (subg_acc.c:804-808), so the stream
+    positions are data dependent -- the walk kernel reports it, the host replays the stream (subgacc_rng_replay) and the
+    result is the reference's (the directed goldens of tests/golden are checked by the golden tests above)."""
     indptr = np.array([0, 2, 3, 3], np.int32)      # node 2 has no out-edges
     indices = np.array([1, 2, 2], np.int32)
-    with pytest.raises(sp.SubgAccError, match="philox"):
-        sp.gset_sampler(indptr, indices, np.array([0, 1]), num_walks=4, num_steps=3)
-    out = sp.gset_sampler(indptr, indices, np.array([0, 1, 2]), num_walks=4, num_steps=3, rng="philox")
-    ref = oracle.gset_sampler(indptr, indices, np.array([0, 1, 2]), num_walks=4, num_steps=3, rng="philox")
-    for x, y in zip(out, ref):
+    for rng in ("rand_r", "philox"):
+        out = sp.gset_sampler(indptr, indices, np.array([0, 1, 2]), num_walks=4, num_steps=3, rng=rng, debug=1)
+        ref = oracle.gset_sampler(indptr, indices, np.array([0, 1, 2]), num_walks=4, num_steps=3, rng=rng, debug=True)
+        for x, y in zip(out, ref):
+            assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("M,m,N,E,hubs,idx64", [(200, 2, 3000, 9000, 2, False), (64, 3, 5000, 40000, 0, True), (20, 4, 800, 1500, 1, False),
+                                                (300, 2, 1500, 200000, 0, False), (7, 5, 400, 900, 3, False)])
+def test_rand_r_on_directed_graphs_matches_the_sequential_stream(sp, M, m, N, E, hubs, idx64):
+    """rng='rand_r' accepts what the reference accepts: graphs with dead ends.  gset_sampler, the SpG pipeline (fused and
+    general, several chunks) and walk_sampler with 1..5 streams against the oracle's sequential loops; a lazy batch cannot
+    replay by itself and says so at resolve()."""
+    from surel_plus_amd import sampler
+    from surel_plus_amd.spg import sample_spg
+    ptr_, idx = dir_graph(N, E, seed=M + m, hubs=hubs)
+    q = np.random.default_rng(2).permutation(N)[: min(N, 2500)]
+    ip = ptr_.astype(np.int64) if idx64 else ptr_
+    a = sp.gset_sampler(ip, idx, q, num_walks=M, num_steps=m, seed=17, debug=1)
+    b = oracle.gset_sampler(ptr_, idx, q, num_walks=M, num_steps=m, seed=17, debug=True)
+    for x, y in zip(a, b):
         assert np.array_equal(x, y)
+    csr = sp.DeviceCSR(ip, idx)
+    oi, ox, od = oracle.spg_build(b[0], b[1])
+    for kw in ({"fused": True}, {"fused": False}, {"fused": True, "staging_bytes": (M * m + 1) * 8 * (len(q) // 5 + 1)}):
+        z, sets = sample_spg(csr, q, num_walks=M, num_steps=m, seed=17, rng="rand_r", **kw)
+        assert np.array_equal(z.indptr.cpu().numpy(), oi) and np.array_equal(z.indices[: z.nnz].cpu().numpy(), ox)
+        assert np.array_equal(z.data[: z.nnz].cpu().numpy(), od) and np.array_equal(sets.enc_int16().cpu().numpy(), b[2])
+    for T, rep in ((1, False), (3, True), (5, True)):
+        w, obj = sp.walk_sampler(ip, idx, q, num_walks=M, num_steps=m, nthread=T, seed=5, replacement=rep)
+        ow, on, oi_, oc = oracle.walk_sampler(ptr_, idx, q, num_walks=M, num_steps=m, nthread=T, seed=5, replacement=rep)
+        assert np.array_equal(w, ow)
+        off = np.concatenate([[0], np.cumsum(on)])
+        assert all(np.array_equal(obj[i, 0], oi_[off[i]:off[i + 1]]) and np.array_equal(obj[i, 1], oc[off[i]:off[i + 1]])
+                   for i in range(len(q)))
+    lz = sampler.sample_sets(csr, q, num_walks=M, num_steps=m, seed=17, rng="rand_r", lazy=True)
+    with pytest.raises(sampler.RandRDeadEnd, match="lazy=False"):
+        lz.resolve()
 
 
 def test_reference_invariants_at_scale(sp):
@@ -1341,7 +1388,7 @@ def test_hop_records_give_the_same_rows(sp, rng, M, m, bits):
 def test_hop_records_on_a_graph_with_dead_ends(sp, M, m, wide):
     """a directed graph: walks reach nodes without out-edges and stay there -- also when the hop that would have fetched
     the last node's bare id finds nothing to fetch (a regression: the stale record was read as an id); Philox only
-    (rand_r refuses dead ends by design)"""
+    (rand_r: tested above, through the replayed stream)"""
     import scipy.sparse as sps
     rng0 = np.random.default_rng(11)
     N = 3000
@@ -1459,3 +1506,57 @@ def test_batched_registration_regrows_a_small_table_and_numbers_transient_batche
         s1.number()
     (_, _, _), oenc2 = _oracle_spg(ptr_, idx, e2.reshape(-1).cpu().numpy(), 200, 3, 5, "philox", -1)
     assert np.array_equal(s2.enc_int16().cpu().numpy(), oenc2)
+
+
+# ------------------------------------------------------------------ callable from pgather-style Python threads
+def test_four_threads_on_their_own_streams_give_the_serial_results(sp):
+    """The reference's pgather calls bgather from 4 Python threads (train.py:88-99); a maintainer who keeps that function and
+    imports only the join gets exactly this: threads, each on its own HIP stream, calling gather / bgather / sample_and_gather /
+    subg_matrix-style sampling concurrently on SHARED SpG / DeviceCSR objects (and on the module's shared caches: segment
+    lists, hop records).  Every result must equal the serial one, bit for bit."""
+    import threading
+    from surel_plus_amd import spjoin
+    from surel_plus_amd.graphs import query_pairs
+    ptr_, idx = sym_graph(12000, 90000, seed=4, hubs=3)
+    M, hops, B, T, ROUNDS = 200, 3, 384, 4, 6
+    csr = sp.DeviceCSR(ptr_, idx)
+    z, enc = sp.subg_matrix(csr, np.arange(12000), num_walks=M, num_steps=hops + 1, rng="philox")
+    table = torch.from_numpy(enc).cuda().float() / M
+    edges = [query_pairs(csr, B, seed=50 + j) for j in range(T * ROUNDS)]
+    torch.cuda.synchronize()
+
+    def one(e):
+        xz, ind = sp.gather(e, z, "cuda", ptr=True, encode=table)
+        out = np.empty(4, dtype=object)                                     # a row of pgather's out_blocks (train.py:89)
+        sp.bgather(e, z, out)                                               # train.py:75-85, the piece pgather's threads run
+        dxz, dind, _ = sp.sample_and_gather(csr, e, num_walks=M, num_steps=hops, seed=111413, rng="philox")
+        return (xz.cpu(), ind.cpu(), dxz.cpu(), dind.cpu()) + tuple(torch.from_numpy(np.ascontiguousarray(o)) for o in out)
+
+    want = [one(e) for e in edges]
+    for own_streams in (True, False):     # each thread on a stream of its own / all of them on the default stream, as the reference's are
+        spjoin._ARANGE_SEGMENTS.clear()
+        if hasattr(csr, "_recs"):
+            del csr._recs                 # the shared caches start cold: the threads race to fill them
+        results, errors = [None] * len(edges), []
+
+        def worker(t):
+            try:
+                if own_streams:
+                    st = torch.cuda.Stream()
+                    with torch.cuda.stream(st):
+                        for j in range(t, len(edges), T):
+                            results[j] = one(edges[j])
+                else:
+                    for j in range(t, len(edges), T):
+                        results[j] = one(edges[j])
+            except Exception as ex:       # noqa: BLE001 -- reported below
+                errors.append(repr(ex))
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        assert not errors, errors
+        torch.cuda.synchronize()
+        for j in range(len(edges)):
+            assert all(torch.equal(a, b) for a, b in zip(results[j], want[j])), f"batch {j} (own streams: {own_streams})"

@@ -31,7 +31,7 @@ for c in range(cases):
         r = np.concatenate([r, np.repeat(np.arange(hubs), N // 3)])
         cc = np.concatenate([cc, rng0.integers(0, N, hubs * (N // 3))])
     A = sps.csr_matrix((np.ones(len(r)), (r, cc)), shape=(N + iso, N + iso))
-    directed = bool(rng0.integers(0, 4) == 0)          # dead ends: Philox mode only (rand_r refuses them by design)
+    directed = bool(rng0.integers(0, 4) == 0)          # dead ends: rand_r replays the stream for them (subgacc_rng_replay)
     if not directed:
         A = sps.csr_matrix(A + A.T)
     A.sum_duplicates(); A.setdiag(0); A.eliminate_zeros(); A.sort_indices()
@@ -42,7 +42,7 @@ for c in range(cases):
     if (32 - (M.bit_length() and (32 - M.bit_length()))) and m * M.bit_length() + 1 > 63:
         m = 2
     bucket = int(rng0.choice([-1, -1, -1, 5, 40]))
-    rng = "philox" if directed else str(rng0.choice(["rand_r", "philox"]))
+    rng = str(rng0.choice(["rand_r", "philox"]))
     nq = int(rng0.choice([1, 17, 400, 1500]))
     q = rng0.integers(0, N + iso, nq)
     seed = int(rng0.integers(0, 2**31))
@@ -60,6 +60,8 @@ for c in range(cases):
         small = {"staging_bytes": 1 << 18} if rng0.integers(0, 5) == 0 else {}     # several chunks of roots per call
         cov["multichunk"] += bool(small)
         for kw in ({"fused": True, **small}, {"fused": False, **small}, {"strided": True}, {"fused": True, "lazy": True}):
+            if kw.get("lazy") and directed and rng == "rand_r":
+                continue        # a lazy batch cannot replay the stream by itself (RandRDeadEnd at resolve(): tested in the suite)
             z, sets = sp.sample_spg(csr, q, num_walks=M, num_steps=m, seed=seed, rng=rng, bucket=bucket, **kw)
             if kw.get("lazy") and b[2].shape[0] > 16384:
                 continue        # lazy numbering ranks at most RANK_LIMIT distinct rows directly; resolve() says so
@@ -121,8 +123,8 @@ for c in range(cases):
             if not (np.array_equal(got[0].cpu().numpy(), want[0]) and np.array_equal(got[1].cpu().numpy(), want[1])
                     and np.array_equal(got[2].cpu().numpy().view(np.int32), want[2].view(np.int32)) and got[3] == want[3]):
                 fails.append(f"ppr(alpha={alpha},eps={eps},topk={topk})")
-    except (RuntimeError, ValueError, AssertionError) as e:       # rand_r on a graph with dead ends is refused by design
-        if "dead end" in str(e) or "Philox" in str(e) or "philox" in str(e) or "hasing key" in str(e) or "key" in str(e).lower():
+    except (RuntimeError, ValueError, AssertionError) as e:       # a key wider than 64 bits is refused like the reference refuses it
+        if not isinstance(e, sp.sampler.RandRDeadEnd) and ("hasing key" in str(e) or "key space" in str(e) or "32 bits" in str(e)):
             skipped += 1
             continue
         print("EXC", tag, repr(e)); bad += 1
