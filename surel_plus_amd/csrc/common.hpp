@@ -7,6 +7,23 @@
 
 #include "../../include/subgacc.h"
 
+// Hook points of the dev-only timing experiments.  The experiments themselves (kernels that skip a phase and therefore give
+// WRONG results: "traversal only", "no stores", "stop after phase k", cycle stamps) live in tools/dev_hooks.hpp, which the
+// tools/*.sh scripts force-include (-include) into experiment builds under /tmp.  The product build never sees that file:
+// every hook below expands to nothing (or to the real expression), so no wrong-result code is compiled into libsubgacc_hip.so.
+#ifndef SG_DEV_HOOKS
+#define SG_HOOK_KERNEL_ENTRY()
+#define SG_HOOK_STAMP(k)
+#define SG_HOOK_RSTAMP(k)
+#define SG_HOOK_BEFORE_HOP(cur, w, s)
+#define SG_HOOK_LOAD_ROW(I64, indptr, cur, b, d) load_row<I64>(indptr, cur, b, d)
+#define SG_HOOK_VISIT_LABEL
+#define SG_HOOK_BEFORE_VISIT(cur, pk)
+#define SG_HOOK_FLUSH_SLOT(s2, real) (real)
+#define SJ_HOOK_SEARCH_RANGE(lo, hi)
+#define SJ_HOOK_ROW_LOAD(ids, val, row, r, mul)
+#endif
+
 namespace subgacc {
 
 constexpr int kWave = 64;            // CDNA4 wavefront

@@ -11,9 +11,6 @@
 #include <cstdlib>
 #include "common.hpp"
 #include "blockscan.hpp"
-#ifndef SJ_EXPERIMENT
-#define SJ_EXPERIMENT 0   // dev-only timing variants, see tools/ab_sjoin.sh
-#endif
 
 namespace subgacc {
 
@@ -179,9 +176,7 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
         va = own_val[t];
     }
     int lo = 0, hi = live ? nb : 0;
-#if SJ_EXPERIMENT == 1   // timing experiment: no search (results are wrong)
-    hi = 0;
-#endif
+    SJ_HOOK_SEARCH_RANGE(lo, hi);
     while (lo < hi) {   // sorted-set intersection: lower bound in the partner row
         const int mid = (lo + hi) >> 1;
         if (pids[mid] < id) lo = mid + 1;
@@ -222,12 +217,8 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
                     const int f = rnd * kWave + lane;   // float4 index inside the span
                     const int r = f >> 1;
                     const int spa = __shfl(pa, r, kWave), spb = __shfl(pb, r, kWave);
-#if SJ_EXPERIMENT == 2   // timing experiment: no output stores (results are wrong)
-                    if (r < nrows && spa == -12345) dst4[f] = tab4[(f & 1) ? spb : spa];
-#elif SJ_EXPERIMENT == 3 // timing experiment: stores without the feature-table read
-                    if (r < nrows) dst4[f] = make_float4((float)spa, (float)spb, 0.f, 0.f);
-#elif SJ_EXPERIMENT == 8 // plain (cached) stores, as before round 1's last change
-                    if (r < nrows) dst4[f] = tab4[(f & 1) ? spb : spa];
+#ifdef SJ_HOOK_STORE4        // (tools/dev_hooks.hpp: timing variants of this store; never defined in the product build)
+                    SJ_HOOK_STORE4(r, nrows, spa, spb, dst4, tab4, f);
 #else
                     if (KEYS) {      // k == 4 <=> 3 hops: the row is (root flag, c1, c2, c3) / M
                         const uint32_t key = (uint32_t)((f & 1) ? spb : spa);
@@ -360,11 +351,7 @@ __global__ __launch_bounds__(NT) void sjoin_pair_kernel(const JoinArgs a, int64_
     const Val *data = (const Val *)a.data;
     const bool xl = !F64 && a.slot_id != nullptr;    // strided rows carry table slots: SFptr+1 on the way into LDS
     for (int r = tid; r < na; r += NT) {
-#if SJ_EXPERIMENT == 4   // timing experiment: no row loads from HBM (results are wrong)
-        idsA[r] = (int32_t)(ra & 1023) + 3 * r;
-        valA[r] = (Val)(r & 127);
-        continue;
-#endif
+        SJ_HOOK_ROW_LOAD(idsA, valA, ra, r, 3);
         idsA[r] = stream_load(&a.indices[ab + r]);
         Val v = stream_load(&data[ab + r]);
         if (KEYS) {}
@@ -374,11 +361,7 @@ __global__ __launch_bounds__(NT) void sjoin_pair_kernel(const JoinArgs a, int64_
     }
     if (ra != rb) {
         for (int r = tid; r < nb; r += NT) {
-#if SJ_EXPERIMENT == 4
-            idsB[r] = (int32_t)(rb & 1023) + 2 * r;
-            valB[r] = (Val)(r & 127);
-            continue;
-#endif
+            SJ_HOOK_ROW_LOAD(idsB, valB, rb, r, 2);
             idsB[r] = stream_load(&a.indices[bb + r]);
             Val v = stream_load(&data[bb + r]);
             if (KEYS) {}

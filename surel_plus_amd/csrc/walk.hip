@@ -25,10 +25,6 @@
 #include "walk_common.hpp"
 #include <stdlib.h>
 
-#ifndef SG_EXPERIMENT
-#define SG_EXPERIMENT 0
-#endif
-
 namespace subgacc {
 
 template <bool IDX64>
@@ -68,31 +64,6 @@ __global__ void rng_positions_kernel(const int64_t *__restrict__ calls_excl, int
 // ------------------------------------------------------------------------------ the walk kernel
 // <= 80 SGPRs keeps 8 workgroups (32 waves) resident per CU; the allocator would otherwise take ~100 and the
 // hardware admits only 6 (MI355X_MICROARCH.md, residency formula) -- worth 14 % on the L2-resident collab graph
-#if SG_EXPERIMENT == 7   // per-phase cycle shares (tools/walk_phases.py): lane 0 adds the cycles since the last stamp to flags[8 + 2k]
-#define SG_STAMP(k)                                                                             \
-    do {                                                                                        \
-        if (threadIdx.x == 0 && (blockIdx.x & 63) == 0) {   /* 1 workgroup in 64: the atomics stay uncontended */ \
-            const unsigned long long now__ = __builtin_readcyclecounter();                      \
-            atomicAdd((unsigned long long *)(a.flags + 8) + (k), now__ - t_prev__);             \
-            t_prev__ = now__;                                                                   \
-        }                                                                                       \
-    } while (0)
-#elif defined(SG_STOP_AFTER)   // dynamic instruction counts per phase (tools/walk_insts.sh): the workgroup ends at stamp k (results are wrong)
-#define SG_STAMP(k)                      \
-    do {                                 \
-        if (SG_STOP_AFTER == (k)) {      \
-            if (threadIdx.x == 0) {      /* a well-formed one-member row, so that the rest of the step stays in bounds */ \
-                a.nsize[i] = 1;          \
-                a.set_ids[i * (int64_t)a.stride] = root; \
-                if (SPG) a.set_slot[i * (int64_t)a.stride] = 0; \
-                else a.set_keys[i * (int64_t)a.stride] = 1ull << (a.m * a.shift); \
-            }                            \
-            return;                      \
-        }                                \
-    } while (0)
-#else
-#define SG_STAMP(k)
-#endif
 #ifndef SG_WALK_SGPR
 #define SG_WALK_SGPR 80
 #endif
@@ -102,9 +73,7 @@ __global__ void rng_positions_kernel(const int64_t *__restrict__ calls_excl, int
 template <bool IDX64, int RNG, bool SPG>
 __global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_num_sgpr(SG_WALK_SGPR))) void walk_sets_kernel(const WalkArgs a) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-#if SG_EXPERIMENT == 7
-    unsigned long long t_prev__ = __builtin_readcyclecounter();
-#endif
+    SG_HOOK_KERNEL_ENTRY();
     unsigned long long *pk = (unsigned long long *)lds_raw;     // [T]
     int32_t *keys = (int32_t *)(pk + a.T);                       // [T]
     uint32_t *minq = (uint32_t *)(keys + a.T);                   // [T]
@@ -195,8 +164,8 @@ __global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_n
         }
     }
     __syncthreads();
-    SG_STAMP(0);
-    SG_STAMP(1);
+    SG_HOOK_STAMP(0);
+    SG_HOOK_STAMP(1);
 
     const uint32_t tmask = (uint32_t)T - 1u;
     int32_t vmin = root, vmax = root;   // id range of everything this lane visits (SPG mode: bucket scaling)
@@ -233,17 +202,9 @@ __global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_n
                     philox2x32_10((uint32_t)root, (uint32_t)w | ptag, a.seed, ph[0], ph[1]);
                 }
             } else {
-#if SG_EXPERIMENT == 2   // dedup only: no graph reads after the first hop (timing experiment, results are wrong)
-                cur = (int32_t)(((uint32_t)cur * 2654435761u + (uint32_t)w * 40503u + (uint32_t)s) % 2900000u);
-                goto visit;
-#endif
+                SG_HOOK_BEFORE_HOP(cur, w, s);
                 int64_t b, d;
-#if SG_EXPERIMENT == 6   // upper bound of any row-pointer optimisation: no indptr read at all (results are wrong)
-                b = ((int64_t)(uint32_t)cur * 21) % 62000000;
-                d = 20;
-#else
-                load_row<IDX64>(a.indptr, cur, b, d);
-#endif
+                SG_HOOK_LOAD_ROW(IDX64, a.indptr, cur, b, d);
                 if (d > 0) {
                     uint32_t r;
                     if (RNG == SUBGACC_RNG_RAND_R) {
@@ -263,14 +224,9 @@ __global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_n
                     atomicOr(&a.flags[0], 1);  // dead end: the positions computed from the degrees no longer hold (the host replays)
                 }
             }
-#if SG_EXPERIMENT == 2
-        visit:
-#endif
+            SG_HOOK_VISIT_LABEL
             if (wrow) wrow[s + 1] = cur;
-#if SG_EXPERIMENT == 1   // traversal only: no dedup (timing experiment, results are wrong)
-            if (cur == -7) atomicAdd(&pk[0], 1ull);
-            continue;
-#endif
+            SG_HOOK_BEFORE_VISIT(cur, pk);
             // ---- visit: insert-or-find, first-visit sequence number, landing count
             uint32_t h = ((uint32_t)cur * 2654435761u) >> a.tshift;
             while (true) {
@@ -299,7 +255,7 @@ __global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_n
         }
     }
     __syncthreads();
-    SG_STAMP(2);
+    SG_HOOK_STAMP(2);
 
     // ---- rank the members by first visit: bitmap over q, popcount prefix.  The SPG mode only needs an ORDER of
     // first visits for its tags -- the visit sequence number itself is one -- so it ranks only when a bucket can
@@ -430,7 +386,7 @@ __global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_n
         if ((tid & (kWave - 1)) == 0) atomicAdd(&red[8], mycount);
     }
     __syncthreads();   // every lane holds its members in registers: the walk tables are free to be re-used
-    SG_STAMP(3);
+    SG_HOOK_STAMP(3);
     if (!need_rank) total = ns = red[8];
     if (tid == 0) {
         a.nsize[i] = ns;
@@ -449,13 +405,9 @@ __global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_n
     const int bshift = Ls > logb ? Ls - logb : 0;
     if (tid < B) cursor[tid] = 0;
     for (int s2 = tid; s2 < kSpgFold; s2 += kWalkThreads)    // flush the fold table to HBM (latency overlaps the sort)
-#if SG_EXPERIMENT == 8   // timing experiment: no registration in the HBM table (results are wrong)
-        if (fk[s2] != kEmptyKey) fs[s2] = s2;
-#else
-        if (fk[s2] != kEmptyKey) fs[s2] = uniq_global_insert(a.table, fk[s2], tag0 + ft[s2], a.flags);
-#endif
+        if (fk[s2] != kEmptyKey) fs[s2] = SG_HOOK_FLUSH_SLOT(s2, uniq_global_insert(a.table, fk[s2], tag0 + ft[s2], a.flags));
     __syncthreads();
-    SG_STAMP(4);
+    SG_HOOK_STAMP(4);
     uint32_t bk[kSpgPerLane];
 #pragma unroll
     for (int u = 0; u < kSpgPerLane; ++u) {
@@ -464,7 +416,7 @@ __global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_n
         if (slv[u] <= -2) slv[u] = fs[-2 - slv[u]];
     }
     __syncthreads();
-    SG_STAMP(5);
+    SG_HOOK_STAMP(5);
     {   // exclusive scan over the B <= 256 buckets, one bucket per lane: wave scan, then the wave totals through LDS
         const int32_t c = tid < B ? cursor[tid] : 0;
         int32_t inc = c;
@@ -485,12 +437,12 @@ __global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_n
         if (tid == B - 1) start[B] = excl + c;
     }
     __syncthreads();
-    SG_STAMP(6);
+    SG_HOOK_STAMP(6);
 #pragma unroll
     for (int u = 0; u < kSpgPerLane; ++u)
         if (ok[u]) A[atomicAdd(&cursor[bk[u]], 1)] = ((unsigned long long)(uint32_t)idv[u] << 32) | (uint32_t)slv[u];
     __syncthreads();
-    SG_STAMP(7);
+    SG_HOOK_STAMP(7);
     // order inside a bucket = number of smaller ids in it -> final position in the row.  The sorted row is assembled
     // in LDS (ids over the dead minq table, slots behind A) and leaves with consecutive lanes on consecutive words.
     int32_t *fin_id = (int32_t *)minq;                 // [ns] <= T
@@ -524,7 +476,7 @@ __global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_n
             a.set_slot[obase + x] = fin_sl[x];
         }
     }
-    SG_STAMP(8);
+    SG_HOOK_STAMP(8);
 }
 
 // ------------------------------------------------------------------------------- compaction

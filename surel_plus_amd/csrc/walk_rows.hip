@@ -18,35 +18,12 @@
 #include <type_traits>
 
 #include "walk_common.hpp"
+#include "waveops.hpp"
 
 namespace subgacc {
 
 #ifndef SG_LAST_HOP_ID     // 1: with hop records, the last hop reads the bare id from `indices` (A/B: tools/ab.py)
 #define SG_LAST_HOP_ID 1
-#endif
-
-// Wave-wide reductions / scan of the device library (DPP row shifts and broadcasts: a handful of vector instructions and no
-// LDS traffic, where six __shfl steps cost six ds_bpermute round trips each).  Every lane is active at the call sites.
-extern "C" __device__ __attribute__((const)) int __ockl_wfred_min_i32(int);
-extern "C" __device__ __attribute__((const)) int __ockl_wfred_max_i32(int);
-extern "C" __device__ __attribute__((const)) unsigned __ockl_wfred_min_u32(unsigned);
-extern "C" __device__ __attribute__((const)) int __ockl_wfred_add_i32(int);
-extern "C" __device__ __attribute__((const)) int __ockl_wfscan_add_i32(int, bool);
-
-#if defined(SG_STOP_AFTER)   // dynamic instruction counts per phase (tools/walk_insts.sh): the workgroup ends at stamp k (results are wrong)
-#define SG_RSTAMP(k)                                                                                         \
-    do {                                                                                                     \
-        if (SG_STOP_AFTER == (k)) {                                                                          \
-            if (threadIdx.x == 0) {      /* a well-formed one-member row, so that the rest of the step stays in bounds */ \
-                a.nsize[i] = 1;                                                                              \
-                a.set_ids[i * (int64_t)a.stride] = root;                                                     \
-                a.set_slot[i * (int64_t)a.stride] = 0;                                                       \
-            }                                                                                                \
-            return;                                                                                          \
-        }                                                                                                    \
-    } while (0)
-#else
-#define SG_RSTAMP(k)
 #endif
 
 // NT lanes per workgroup (256, or 128 with two walks per lane: twice the roots per CU where the 512-slot table leaves the
@@ -202,7 +179,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
         }
     }
     __syncthreads();
-    SG_RSTAMP(0);
+    SG_HOOK_RSTAMP(0);
 
     // ------------------------------------------------------------------ the walk: WPL walks per lane, straight-line,
     // the walks of a lane interleaved hop by hop (their loads are independent and in flight together)
@@ -324,7 +301,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
         }
     }
     __syncthreads();
-    SG_RSTAMP(2);
+    SG_HOOK_RSTAMP(2);
 
     if (KR) {
         // ================= key rows: the set leaves sorted by node id with its members' LP keys =================
@@ -349,9 +326,9 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
             umn = min(umn, (uint32_t)idv[u]);
             vmax = max(vmax, idv[u]);
         }
-        const int incl = __ockl_wfscan_add_i32(cnt, true);
-        umn = __ockl_wfred_min_u32(umn);
-        vmax = __ockl_wfred_max_i32(vmax);
+        const int incl = wave_scan_add_i32_incl(cnt);
+        umn = wave_red_min_u32(umn);
+        vmax = wave_red_max_i32(vmax);
         int wbase = 0;
         if ((tid & (kWave - 1)) == kWave - 1) {
             wbase = atomicAdd(&red[8], incl);
@@ -399,7 +376,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
         __syncthreads();
         {
             const int32_t c = tid < B ? start[tid] : 0;
-            const int32_t inc = __ockl_wfscan_add_i32(c, true);
+            const int32_t inc = wave_scan_add_i32_incl(c);
             if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc;
             __syncthreads();
             int32_t base = 0;
@@ -537,9 +514,9 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
         if (!done) slv[u] = uniq_global_insert(a.table, (unsigned long long)key, tag0 + (unsigned long long)tagoff, a.flags);
     }
     {
-        vmin = __ockl_wfred_min_i32(vmin);
-        vmax = __ockl_wfred_max_i32(vmax);
-        mycount = __ockl_wfred_add_i32(mycount);
+        vmin = wave_red_min_i32(vmin);
+        vmax = wave_red_max_i32(vmax);
+        mycount = wave_red_add_i32(mycount);
         if ((tid & (kWave - 1)) == 0) {
             red[tid / kWave] = vmin;
             red[4 + tid / kWave] = vmax;
@@ -547,7 +524,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
         }
     }
     __syncthreads();   // every lane holds its members in registers: the walk tables are free to be re-used
-    SG_RSTAMP(3);
+    SG_HOOK_RSTAMP(3);
     const int32_t ns = red[8];             // no truncating bucket here: every member stays (ns <= M*MH+1 = stride)
     if (tid == 0 && !a.tags_only) a.nsize[i] = ns;
     const int32_t mn = min(min(red[0], red[1]), min(red[2], red[3]));
@@ -567,7 +544,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
         if (fk[tid] != kNoKey) fs[tid] = uniq_global_insert(a.table, (unsigned long long)fk[tid], tag0 + ft[tid], a.flags);
     if (a.tags_only) return;   // subgacc_walk_tags: the rows exist already (key rows); only the exact tags were wanted
     __syncthreads();
-    SG_RSTAMP(4);
+    SG_HOOK_RSTAMP(4);
     uint32_t bk[SPL];
     int32_t arr[SPL];                           // arrival order inside the bucket
 #pragma unroll
@@ -577,10 +554,10 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
         if (slv[u] <= -2) slv[u] = fs[-2 - slv[u]];
     }
     __syncthreads();
-    SG_RSTAMP(5);
+    SG_HOOK_RSTAMP(5);
     {   // exclusive scan over the B <= 256 buckets, one bucket per lane: wave scan, then the wave totals through LDS
         const int32_t c = tid < B ? start[tid] : 0;
-        const int32_t inc = __ockl_wfscan_add_i32(c, true);     // inclusive scan over the wave
+        const int32_t inc = wave_scan_add_i32_incl(c);     // inclusive scan over the wave
         if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc;
         __syncthreads();
         int32_t base = 0;
@@ -590,7 +567,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
         if (tid == B - 1) start[B] = excl + c;
     }
     __syncthreads();
-    SG_RSTAMP(6);
+    SG_HOOK_RSTAMP(6);
     int blo[SPL], bhi[SPL];
 #pragma unroll
     for (int u = 0; u < SPL; ++u) {   // bucket bounds, then the member goes to bucket start + arrival order
@@ -601,7 +578,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     for (int u = 0; u < SPL; ++u)
         if (ok[u]) A[blo[u] + arr[u]] = ((unsigned long long)(uint32_t)idv[u] << 32) | (uint32_t)slv[u];
     __syncthreads();
-    SG_RSTAMP(7);
+    SG_HOOK_RSTAMP(7);
     // order inside a bucket = number of smaller ids in it -> final position in the row.  The sorted row is assembled
     // in LDS (ids over the dead minq table, slots behind the bucket offsets) and leaves with consecutive lanes on
     // consecutive words.

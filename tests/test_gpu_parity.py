@@ -1560,3 +1560,22 @@ def test_four_threads_on_their_own_streams_give_the_serial_results(sp):
         torch.cuda.synchronize()
         for j in range(len(edges)):
             assert all(torch.equal(a, b) for a, b in zip(results[j], want[j])), f"batch {j} (own streams: {own_streams})"
+
+
+def test_shfl_fallback_of_the_wave_reductions_gives_the_same_rows():
+    """csrc/waveops.hpp: the DPP wave reductions are internals of ROCm's device library; should an update rename them, the
+    Makefile's probe builds the __shfl forms instead (-DSG_NO_OCKL_WAVE_OPS).  That build is made here (walk_rows.hip only,
+    into /tmp) and the key-rows / fused-row parity tests are run through it in a child process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    try:
+        from ab import build_variant
+    finally:
+        sys.path.pop(0)
+    lib = build_variant("-DSG_NO_OCKL_WAVE_OPS", ["walk_rows.hip"])
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-k",
+                        "key_rows_join_like or specialised_fused_row or batched_registration_numbers"],
+                       env=dict(os.environ, SUBGACC_LIB=lib), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,7 +1,7 @@
 """CPU: oracle/ppr_oracle.c (the checker of the GPU PPR sampler).  The reference function is numba code that cannot
 run here (parity UNPINNED), so the restatement is pinned to what can be checked without it: the defining property of
-the Andersen-Chung-Lang approximation against an exact PPR, the dict/list semantics of sampler/pprgo.py:9-38 against a
-literal Python transcription with NumPy float32 scalars where numba's typing and NumPy's agree, and the
+the Andersen-Chung-Lang approximation against an exact PPR, committed vectors of the push (tests/golden/ppr_push.npz, made by
+oracle/gen_ppr_fixture.py: a pure-Python second statement with NumPy scalars typed as numba types them), and the
 normalisation / encoding formulas against their NumPy one-liners (pprgo.py:88-108, utils.py:35-36)."""
 import numpy as np
 import scipy.sparse as sps
@@ -20,38 +20,19 @@ def _graph(N=400, E=1400, seed=0):
     return A
 
 
-def _calc_ppr_node(inode, indptr, indices, deg, alpha, epsilon):
-    """pprgo.py:9-38 transcribed; float32 where numba says float32, float64 where it says float64."""
-    f32 = np.float32
-    alpha, epsilon = f32(alpha), f32(epsilon)
-    alpha_eps = f32(alpha * epsilon)
-    p, r, q = {inode: f32(0)}, {inode: alpha}, [inode]
-    while q:
-        unode = q.pop()
-        res = r.get(unode, f32(0))
-        p[unode] = f32(p.get(unode, f32(0)) + res)
-        r[unode] = f32(0)
-        for vnode in indices[indptr[unode]:indptr[unode + 1]]:
-            vnode = int(vnode)
-            _val = f32((1.0 - float(alpha)) * float(res) / float(deg[unode]))
-            r[vnode] = f32(r.get(vnode, f32(0)) + _val)
-            if float(r[vnode]) >= float(alpha_eps) * float(deg[vnode]) and vnode not in q:
-                q.append(vnode)
-    return list(p.keys()), list(p.values())
-
-
-def test_oracle_matches_python_transcription():
-    A = _graph()
-    deg = np.diff(A.indptr)
-    roots = np.array([0, 1, 7, 99, 399], np.int32)
-    for alpha, eps in ((0.5, 1e-4), (0.15, 1e-3)):
-        off, ids, vals, _ = orc.ppr_topk(A.indptr, A.indices, roots, alpha, eps, A.shape[0], table_log2=12)
-        for i, s in enumerate(roots):
-            keys, pv = _calc_ppr_node(int(s), A.indptr, A.indices, deg, alpha, eps)
-            order = np.argsort(keys)
-            np.testing.assert_array_equal(ids[off[i]:off[i + 1]], np.asarray(keys)[order])
-            np.testing.assert_array_equal(vals[off[i]:off[i + 1]].view(np.int32),
-                                          np.asarray(pv, np.float32)[order].view(np.int32))
+def test_oracle_matches_the_committed_push_vectors():
+    """tests/golden/ppr_push.npz: the push of sampler/pprgo.py:9-38 evaluated once by a pure-Python second statement (dicts and
+    a LIFO list, NumPy scalars typed as numba types them) in the build container -- oracle/gen_ppr_fixture.py, committed
+    beside its output.  Node sets and score BIT PATTERNS must agree."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "ppr_push.npz"))
+    n = len(g["indptr"]) - 1
+    for j, (alpha, eps) in enumerate(g["params"]):
+        off, ids, vals, _ = orc.ppr_topk(g["indptr"], g["indices"], g["roots"], float(alpha), float(eps), n, table_log2=12)
+        np.testing.assert_array_equal(off, g[f"off_{j}"])
+        np.testing.assert_array_equal(ids, g[f"ids_{j}"])
+        np.testing.assert_array_equal(vals.view(np.int32), g[f"score_bits_{j}"])
 
 
 def test_oracle_topk_keeps_largest_scores_rows_sorted():

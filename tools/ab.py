@@ -25,9 +25,10 @@ def build_variant(flags, files):
     objs = [os.path.join(CSRC, "build", f) for f in os.listdir(os.path.join(CSRC, "build"))
             if f.endswith(".o") and f[:-2] + ".hip" not in files]
     procs = []
+    hooks = ["-include", os.path.join(ROOT, "tools", "dev_hooks.hpp")] if any(k in flags for k in ("SG_EXPERIMENT", "SJ_EXPERIMENT", "SG_STOP_AFTER")) else []
     for f in files:
         o = f"/tmp/{tag}_{f[:-4]}.o"
-        procs.append((o, subprocess.Popen(["/opt/rocm/bin/hipcc"] + FLAGS + flags.split() + ["-c", os.path.join(CSRC, f), "-o", o])))
+        procs.append((o, subprocess.Popen(["/opt/rocm/bin/hipcc"] + FLAGS + hooks + flags.split() + ["-c", os.path.join(CSRC, f), "-o", o])))
         objs.append(o)
     for o, p in procs:
         if p.wait() != 0:

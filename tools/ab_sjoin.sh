@@ -7,7 +7,7 @@ export SUBGACC_LIB=/tmp/libsubgacc_variant.so
 IFS='|' read -ra VS <<< "${VARIANTS:-}"
 OBJS=$(ls build/*.o | grep -v sjoin.o)
 for V in "" "${VS[@]}"; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -ffp-contract=off $V -c sjoin.hip -o /tmp/sjoin_v.o
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -ffp-contract=off -include $GRAFT_REPO_ROOT/tools/dev_hooks.hpp $V -c sjoin.hip -o /tmp/sjoin_v.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/sjoin_v.o -o $SUBGACC_LIB
   for W in ${WLS:-cit2}; do
     for rep in 1 2; do

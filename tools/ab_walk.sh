@@ -10,8 +10,8 @@ FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fhip-fp32-correctly-rounded-d
 OBJS=$(ls build/*.o | grep -v -x -F -e build/walk.o -e build/walk_pipe.o)
 IFS='|' read -ra VS <<< "${VARIANTS:-}"
 for V in "" "${VS[@]}"; do
-  /opt/rocm/bin/hipcc $FLAGS $V -c walk.hip -o /tmp/walk_v.o
-  /opt/rocm/bin/hipcc $FLAGS $V -c walk_pipe.hip -o /tmp/walk_pipe_v.o
+  /opt/rocm/bin/hipcc $FLAGS -include $GRAFT_REPO_ROOT/tools/dev_hooks.hpp $V -c walk.hip -o /tmp/walk_v.o
+  /opt/rocm/bin/hipcc $FLAGS -include $GRAFT_REPO_ROOT/tools/dev_hooks.hpp $V -c walk_pipe.hip -o /tmp/walk_pipe_v.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/walk_v.o /tmp/walk_pipe_v.o -o $SUBGACC_LIB
   for W in ${WLS:-cit2 collab}; do
     for rep in 1 2; do

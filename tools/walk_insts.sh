@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT
 cd $R/surel_plus_amd/csrc
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -ffp-contract=off"
 for K in $KS; do
-  ( /opt/rocm/bin/hipcc $FLAGS -DSG_STOP_AFTER=$K -c walk.hip -o /tmp/walk_s$K.o && /opt/rocm/bin/hipcc $FLAGS -DSG_STOP_AFTER=$K -c walk_rows.hip -o /tmp/walk_rows_s$K.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls build/*.o | grep -v -x -F -e build/walk.o -e build/walk_rows.o) /tmp/walk_s$K.o /tmp/walk_rows_s$K.o -o /tmp/libsubgacc_s$K.so ) &
+  ( /opt/rocm/bin/hipcc $FLAGS -include $GRAFT_REPO_ROOT/tools/dev_hooks.hpp -DSG_STOP_AFTER=$K -c walk.hip -o /tmp/walk_s$K.o && /opt/rocm/bin/hipcc $FLAGS -include $GRAFT_REPO_ROOT/tools/dev_hooks.hpp -DSG_STOP_AFTER=$K -c walk_rows.hip -o /tmp/walk_rows_s$K.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls build/*.o | grep -v -x -F -e build/walk.o -e build/walk_rows.o) /tmp/walk_s$K.o /tmp/walk_rows_s$K.o -o /tmp/libsubgacc_s$K.so ) &
 done
 wait
 cd /tmp && export TMPDIR=/tmp
