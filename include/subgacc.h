@@ -224,6 +224,9 @@ int subgacc_spg_build(const int64_t *row_off, int64_t n, const int32_t *ids, con
  * per member w of row own[j] in ascending id order with the pair
  *     ( value_own(w), value_partner(w) or 0 ).
  * gather(edge[2,B]):  own = [u..,v..], partner = [v..,u..];  hgather: [u,w,v,w] / [w,u,w,v].
+ * ABI 4: with a mirrored list (pair_block > 0, see subgacc_sjoin_fill) `partner` may be NULL in every fill entry point: the
+ * partner of segment j is then the own row of j's mirror (own[j + pair_block] in an even block, own[j - pair_block] in an odd
+ * one) -- gather() passes its [2,B] endpoint tensor as `own` as it stands and builds no second list.
  * ------------------------------------------------------------------------------------------- */
 /* out_seg[S+1] int64 = exclusive scan of the segment sizes (`indptr` of train.py:20-22).
  * n_rows = rows of the store.  A row number outside [0, n_rows) in own / partner (partner may be NULL: not checked

@@ -36,7 +36,10 @@ struct SegLen {
         return bad ? 0 : (row_len ? (int64_t)row_len[a] : indptr[a + 1] - indptr[a]);
     }
 };
-constexpr int kSegItems = 8;
+#ifndef SJ_SEG_ITEMS      // segments per lane of the two size kernels: 2 (131,072 segments = 256 workgroups; 8 per lane left 3/4 of the CUs idle: 17.8 -> 12 us)
+#define SJ_SEG_ITEMS 2
+#endif
+constexpr int kSegItems = SJ_SEG_ITEMS;
 constexpr int kSegTile = kScanThreads * kSegItems;
 
 __global__ __launch_bounds__(kScanThreads) void sjoin_seg_reduce_kernel(const SegLen L, int64_t *__restrict__ partial) {
@@ -100,6 +103,7 @@ struct JoinArgs {
     int32_t key_M, key_m, key_shift;
     const int32_t *slot_id;   // slot -> SFptr (id plane of the numbered table of distinct LP rows); NULL with
     int32_t val_add;          // val_add = 1: the feature table is indexed by slot + 1 itself (row 0 = absent)
+    int64_t pb = 0;           // pair_block of a mirrored list: with partner == NULL the partner of segment j is the own row of its mirror
     int32_t split = 1;        // sjoin_pair_kernel: workgroups per pair (small batches: every one stages both rows and emits
                               // its share of the 64-row spans, so that a batch of ~1,000 pairs still fills the chip)
 };
@@ -136,6 +140,12 @@ __device__ __forceinline__ void stream_store(int2 *p, const int2 &t) {
 }
 template <typename T>
 __device__ __forceinline__ T stream_load(const T *p) { return __builtin_nontemporal_load(p); }
+
+// partner row of segment j: given, or -- a mirrored list, block 2t+1 = block 2t with own and partner swapped -- the own row of j's mirror
+__device__ __forceinline__ int64_t join_partner(const JoinArgs &a, int64_t j) {
+    if (a.partner) return a.partner[j];
+    return a.own[((j / a.pb) & 1) ? j - a.pb : j + a.pb];
+}
 
 __device__ __forceinline__ void join_row(const JoinArgs &a, int64_t r, int64_t &beg, int64_t &len) {
     if ((uint64_t)r >= (uint64_t)a.n_rows) {   // never dereferenced (sjoin_len_kernel gave it length 0 and raised the flag)
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(kJoinThreads) void sjoin_fill_kernel(const JoinArgs
     const int64_t j = xcd_item(blockIdx.x, gridDim.x);
     if (j >= a.S) return;
     const int lane = threadIdx.x;
-    const int64_t ra = a.own[j], rb = a.partner[j];
+    const int64_t ra = a.own[j], rb = join_partner(a, j);
     int64_t ab, na, bb, nb64;
     join_row(a, ra, ab, na);
     join_row(a, rb, bb, nb64);
@@ -324,10 +334,13 @@ __global__ __launch_bounds__(NT) void sjoin_pair_kernel(const JoinArgs a, int64_
     Val *valB = valA + a.max_len;                     // [max_len]
     int32_t *idsA = (int32_t *)(valB + a.max_len);    // [max_len]
     int32_t *idsB = idsA + a.max_len;                 // [max_len]
-    float *lut = (float *)(idsB + a.max_len);         // KEYS: [key_M + 1] count -> count / num_walks (IEEE division, main.py:174)
-    float *stage = lut + ((a.key_M + 2) & ~1) + (threadIdx.x / kWave) * kWave * 2 * a.k;   // KEYS: [64 rows][2k] per wave (8-byte aligned)
+    // KEYS: [1 << key_shift] count -> count / num_walks (IEEE division, main.py:174).  One entry per value the SHIFT-bit field of
+    // a key can hold, not just per count <= num_walks: a caller-supplied key with a field in (M, 2^SHIFT) -- not a key of this
+    // num_walks -- then reads its own quotient instead of whatever lies behind the table
+    float *lut = (float *)(idsB + a.max_len);
+    float *stage = lut + (1 << a.key_shift) + (threadIdx.x / kWave) * kWave * 2 * a.k;   // KEYS: [64 rows][2k] per wave (8-byte aligned)
     if (KEYS)
-        for (int c = threadIdx.x; c <= a.key_M; c += NT) lut[c] = (float)c / (float)a.key_M;
+        for (int c = threadIdx.x; c < (1 << a.key_shift); c += NT) lut[c] = (float)c / (float)a.key_M;
 
     const int64_t wg = xcd_item(blockIdx.x, gridDim.x);
     const int64_t p = wg / a.split;
@@ -335,8 +348,8 @@ __global__ __launch_bounds__(NT) void sjoin_pair_kernel(const JoinArgs a, int64_
     if (p >= a.S / 2) return;
     const int64_t j = (p / pb) * 2 * pb + (p % pb), j2 = j + pb;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    const int64_t ra = a.own[j], rb = a.partner[j];
-    if (a.own[j2] != rb || a.partner[j2] != ra) {   // not a mirrored pair: the caller broke the precondition
+    const int64_t ra = a.own[j], rb = join_partner(a, j);
+    if (a.own[j2] != rb || join_partner(a, j2) != ra) {   // not a mirrored pair: the caller broke the precondition
         if (tid == 0) atomicOr(&a.flags[3], 4);
         return;
     }
@@ -408,8 +421,8 @@ __global__ __launch_bounds__(kPairThreads) void sjoin_counts_kernel(const JoinAr
     if (p >= a.S / 2) return;
     const int64_t j = (p / pb) * 2 * pb + (p % pb), j2 = j + pb;
     const int tid = threadIdx.x;
-    const int64_t ra = a.own[j], rb = a.partner[j];
-    if (a.own[j2] != rb || a.partner[j2] != ra) {
+    const int64_t ra = a.own[j], rb = join_partner(a, j);
+    if (a.own[j2] != rb || join_partner(a, j2) != ra) {
         if (tid == 0) atomicOr(&a.flags[3], 4);
         return;
     }
@@ -492,8 +505,8 @@ __global__ __launch_bounds__(kPairThreads) void sjoin_pairs_kernel(const JoinArg
     if (p >= a.S / 2) return;
     const int64_t j = (p / pb) * 2 * pb + (p % pb), j2 = j + pb;
     const int tid = threadIdx.x;
-    const int64_t ra = a.own[j], rb = a.partner[j];
-    if (a.own[j2] != rb || a.partner[j2] != ra) {
+    const int64_t ra = a.own[j], rb = join_partner(a, j);
+    if (a.own[j2] != rb || join_partner(a, j2) != ra) {
         if (tid == 0) atomicOr(&a.flags[3], 4);
         return;
     }
@@ -653,7 +666,7 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, int64_t n_rows, con
                                   int64_t pair_block, int32_t *flags, void *stream) {
     SG_REQUIRE(S >= 0 && max_len >= 0 && flags && n_rows >= 0, SUBGACC_ERR_BADARG, "sjoin_fill: bad arguments");
     if (S == 0) return SUBGACC_OK;
-    SG_REQUIRE(spg_indptr && spg_indices && own && partner && seg, SUBGACC_ERR_BADARG, "sjoin_fill: null argument");
+    SG_REQUIRE(spg_indptr && spg_indices && own && (partner || pair_block > 0) && seg, SUBGACC_ERR_BADARG, "sjoin_fill: null argument");
     SG_REQUIRE((spg_data_i32 != nullptr) != (spg_data_f64 != nullptr), SUBGACC_ERR_BADARG,
                "sjoin_fill: exactly one of spg_data_i32 / spg_data_f64");
     const bool f64 = spg_data_f64 != nullptr;
@@ -668,7 +681,7 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, int64_t n_rows, con
     JoinArgs a;
     a.indptr = spg_indptr, a.indices = spg_indices;
     a.data = f64 ? (const void *)spg_data_f64 : (const void *)spg_data_i32;
-    a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
+    a.pb = pair_block; a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
     a.table = table, a.table_rows = table_rows, a.k = k;
     a.out_xz = out_xz, a.out_idx = out_idx, a.out_segid = out_segid;
     a.max_len = max_len > 0 ? max_len : 1;
@@ -704,6 +717,10 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, int64_t n_rows, con
             // short float rows (the top-100 PPR store): ONE wave per pair -- twice the pairs in flight per CU for a kernel whose
             // workgroups live on a chain of dependent loads, not on bandwidth (cit2-PPR join 0.154 -> 0.139 ms; integer rows
             // with their 6-10 KB of LDS per pair are slower this way: collab 0.175 -> 0.20 ms)
+            // (round 3 tried persistent waves with a four-stage software pipeline over their pairs -- row numbers, row offsets, rows,
+            // search + store of four consecutive pairs in flight per wave: 91 us against this kernel's 77.  The kernel is not
+            // latency-bound: it moves ~300 MB of whole lines per launch -- rows of ~90 members begin and end inside lines -- at
+            // 3.9 TB/s of mixed reads and writes)
             hipLaunchKernelGGL((sjoin_pair_kernel<true, 0, false, kWave>), dim3((unsigned)grid), dim3(kWave), lds, s, a, pair_block);
         } else if (f64) SG_PAIR_LAUNCH(true, 0);
         else if (vec4) SG_PAIR_LAUNCH(false, 4);
@@ -740,7 +757,7 @@ extern "C" int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t n_rows, i
     SG_REQUIRE(S >= 0 && flags && n_rows >= 0 && row_stride > 0 && row_stride < (1ll << 31), SUBGACC_ERR_BADARG,
                "sjoin_fill_rows: bad arguments");
     if (S == 0) return SUBGACC_OK;
-    SG_REQUIRE(row_len && row_ids && row_slot && (!uniq_table || uniq_capacity > 0) && own && partner && seg,
+    SG_REQUIRE(row_len && row_ids && row_slot && (!uniq_table || uniq_capacity > 0) && own && (partner || pair_block > 0) && seg,
                SUBGACC_ERR_BADARG, "sjoin_fill_rows: null argument");
     SG_REQUIRE(out_xz || out_idx, SUBGACC_ERR_BADARG, "sjoin_fill_rows: no output requested");
     SG_REQUIRE(!out_xz || (table && table_rows > 0 && k > 0 && k <= 16), SUBGACC_ERR_BADARG,
@@ -749,7 +766,7 @@ extern "C" int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t n_rows, i
                "sjoin_fill_rows: the segment list must be mirrored blocks (pair_block > 0, S a multiple of 2*pair_block)");
     JoinArgs a;
     a.indptr = nullptr, a.indices = row_ids, a.data = row_slot;
-    a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
+    a.pb = pair_block; a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
     a.table = table, a.table_rows = table_rows, a.k = k;
     a.out_xz = out_xz, a.out_idx = out_idx, a.out_segid = out_segid;
     a.max_len = (int32_t)row_stride;
@@ -791,7 +808,7 @@ static int launch_key_join(JoinArgs &a, int32_t num_walks, int32_t num_steps, in
     a.out_idx = nullptr;
     a.slot_id = nullptr, a.val_add = 0;
     a.key_M = num_walks, a.key_m = num_steps, a.key_shift = shift;
-    const size_t lds = (size_t)a.max_len * 16 + (size_t)(num_walks + 2) * 4 +
+    const size_t lds = (size_t)a.max_len * 16 + ((size_t)4 << shift) +
                        (a.k == 4 ? 0 : (size_t)(kPairEmit / kWave) * kWave * 2 * a.k * 4);   // staging: only the generic width uses it
     SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "%s: rows of %d members do not fit LDS", who, (int)a.max_len);
     a.split = pair_split(S / 2);
@@ -819,13 +836,13 @@ extern "C" int subgacc_sjoin_fill_keyrows(const int32_t *row_len, int64_t n_rows
     SG_REQUIRE(S >= 0 && flags && n_rows >= 0 && row_stride > 0 && row_stride < (1ll << 31), SUBGACC_ERR_BADARG,
                "sjoin_fill_keyrows: bad arguments");
     if (S == 0) return subgacc_key_shift(num_walks, num_steps) < 0 ? subgacc_key_shift(num_walks, num_steps) : SUBGACC_OK;
-    SG_REQUIRE(row_len && row_ids && row_keys && own && partner && seg && out_xz, SUBGACC_ERR_BADARG,
+    SG_REQUIRE(row_len && row_ids && row_keys && own && (partner || pair_block > 0) && seg && out_xz, SUBGACC_ERR_BADARG,
                "sjoin_fill_keyrows: null argument");
     SG_REQUIRE(pair_block > 0 && S % (2 * pair_block) == 0, SUBGACC_ERR_BADARG,
                "sjoin_fill_keyrows: the segment list must be mirrored blocks (pair_block > 0, S a multiple of 2*pair_block)");
     JoinArgs a;
     a.indptr = nullptr, a.indices = row_ids, a.data = row_keys;
-    a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
+    a.pb = pair_block; a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
     a.out_xz = out_xz, a.out_segid = nullptr;
     a.max_len = (int32_t)row_stride;
     a.flags = flags;
@@ -839,13 +856,13 @@ extern "C" int subgacc_sjoin_fill_keys(const int64_t *spg_indptr, int64_t n_rows
                                        int64_t *out_segid, int32_t max_len, int64_t pair_block, int32_t *flags, void *stream) {
     SG_REQUIRE(S >= 0 && flags && n_rows >= 0 && max_len >= 0, SUBGACC_ERR_BADARG, "sjoin_fill_keys: bad arguments");
     if (S == 0) return subgacc_key_shift(num_walks, num_steps) < 0 ? subgacc_key_shift(num_walks, num_steps) : SUBGACC_OK;
-    SG_REQUIRE(spg_indptr && spg_indices && spg_keys && own && partner && seg && out_xz, SUBGACC_ERR_BADARG,
+    SG_REQUIRE(spg_indptr && spg_indices && spg_keys && own && (partner || pair_block > 0) && seg && out_xz, SUBGACC_ERR_BADARG,
                "sjoin_fill_keys: null argument");
     SG_REQUIRE(pair_block > 0 && S % (2 * pair_block) == 0, SUBGACC_ERR_BADARG,
                "sjoin_fill_keys: the segment list must be mirrored blocks (pair_block > 0, S a multiple of 2*pair_block)");
     JoinArgs a;
     a.indptr = spg_indptr, a.indices = spg_indices, a.data = spg_keys;
-    a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
+    a.pb = pair_block; a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
     a.out_xz = out_xz, a.out_segid = out_segid;
     a.max_len = max_len > 0 ? max_len : 1;
     a.flags = flags;
@@ -860,13 +877,13 @@ extern "C" int subgacc_sjoin_counts(const int64_t *spg_indptr, int64_t n_rows, c
     SG_REQUIRE(S >= 0 && max_len >= 0 && flags && table_rows > 0 && n_rows >= 0, SUBGACC_ERR_BADARG,
                "sjoin_counts: bad arguments");
     if (S == 0) return SUBGACC_OK;
-    SG_REQUIRE(spg_indptr && spg_indices && spg_data_i32 && own && partner && out_counts, SUBGACC_ERR_BADARG,
+    SG_REQUIRE(spg_indptr && spg_indices && spg_data_i32 && own && (partner || pair_block > 0) && out_counts, SUBGACC_ERR_BADARG,
                "sjoin_counts: null argument");
     SG_REQUIRE(pair_block > 0 && S % (2 * pair_block) == 0, SUBGACC_ERR_BADARG,
                "sjoin_counts: the segment list must be mirrored blocks (pair_block > 0, S a multiple of 2*pair_block)");
     JoinArgs a;
     a.indptr = spg_indptr, a.indices = spg_indices, a.data = spg_data_i32;
-    a.own = own, a.partner = partner, a.seg = nullptr, a.S = S, a.n_rows = n_rows;
+    a.pb = pair_block; a.own = own, a.partner = partner, a.seg = nullptr, a.S = S, a.n_rows = n_rows;
     a.table = nullptr, a.table_rows = table_rows, a.k = 0;
     a.out_xz = nullptr, a.out_idx = nullptr, a.out_segid = nullptr;
     a.max_len = max_len > 0 ? max_len : 1;
@@ -894,13 +911,13 @@ extern "C" int subgacc_sjoin_pairs(const int64_t *spg_indptr, int64_t n_rows, co
                                    int32_t max_len, int64_t pair_block, int32_t *flags, void *stream) {
     SG_REQUIRE(S >= 0 && max_len >= 0 && flags && n_rows >= 0, SUBGACC_ERR_BADARG, "sjoin_pairs: bad arguments");
     if (S == 0) return SUBGACC_OK;
-    SG_REQUIRE(spg_indptr && spg_indices && spg_data_i32 && own && partner && seg && out_pairs && out_mult && out_cnt,
+    SG_REQUIRE(spg_indptr && spg_indices && spg_data_i32 && own && (partner || pair_block > 0) && seg && out_pairs && out_mult && out_cnt,
                SUBGACC_ERR_BADARG, "sjoin_pairs: null argument");
     SG_REQUIRE(pair_block > 0 && S % (2 * pair_block) == 0, SUBGACC_ERR_BADARG,
                "sjoin_pairs: the segment list must be mirrored blocks (pair_block > 0, S a multiple of 2*pair_block)");
     JoinArgs a;
     a.indptr = spg_indptr, a.indices = spg_indices, a.data = spg_data_i32;
-    a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
+    a.pb = pair_block; a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
     a.table = nullptr, a.table_rows = 0, a.k = 0;
     a.out_xz = nullptr, a.out_idx = nullptr, a.out_segid = nullptr;
     a.max_len = max_len > 0 ? max_len : 1;

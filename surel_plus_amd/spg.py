@@ -113,8 +113,8 @@ class SpG:
         shift = check(lib().subgacc_key_shift(int(num_walks), m))
         if m * shift + 1 > 31:
             raise AssertionError(f"LP keys of {m} steps x {shift} bits do not fit 32 bits")
-        if int(tab[:, 1:].max().item()) >= (1 << shift) or int(tab.min().item()) < 0:
-            raise ValueError("LP counts outside [0, 2^SHIFT): not the table of this num_walks")
+        if int(tab[:, 1:].max().item()) > int(num_walks) or int(tab.min().item()) < 0:
+            raise ValueError("LP counts outside [0, num_walks]: not the table of this num_walks")
         key = (tab[:, 0] != 0).to(torch.int64) << (m * shift)
         for j in range(1, m + 1):
             key |= tab[:, j] << ((m - j) * shift)

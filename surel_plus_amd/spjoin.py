@@ -68,7 +68,12 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
     dev = spg.device
     st = stream_ptr()
     S = own.numel()
-    own, partner = own.contiguous(), partner.contiguous()
+    own = own.contiguous()
+    if partner is None:
+        if pair_block <= 0 and S > 0:
+            raise ValueError("partner=None needs a mirrored segment list (pair_block > 0)")
+    else:
+        partner = partner.contiguous()
     seg = torch.empty(S + 1, dtype=torch.int64, device=dev)
     ws = torch.empty(L.subgacc_sjoin_workspace_bytes(S), dtype=torch.uint8, device=dev)
     if isinstance(spg, StridedSpG):
@@ -101,16 +106,27 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
                                             ptr(seg), spg.key_M, spg.key_m, ptr(res), ptr(segid), spg.max_len, pair_block,
                                             ptr(flags), st))
         return res, (seg if ptr_mode else segid), flags
-    if lazy and (out is None or not ptr_mode or return_index or is_f64 or encode is None):
-        raise ValueError("lazy=True needs out=, ptr=True and an integer SpG with its encode table")
+    if lazy and (out is None or not ptr_mode or return_index or (encode is None and not is_f64)):
+        raise ValueError("lazy=True needs out=, ptr=True and an integer SpG with its encode table (or a float-payload SpG)")
     R = None if lazy else _size_and_row_check(seg, S, flags, spg.n_rows)     # the one host round trip
     segid = None if ptr_mode else torch.empty(R, dtype=torch.int64, device=dev)
     if is_f64:
         if encode is not None:
             raise TypeError("a float-payload SpG is joined without an encode table (train.py:39-43)")
-        xz = torch.empty((R, 2, 1), dtype=torch.float32, device=dev)
-        check(L.subgacc_sjoin_fill(ptr(spg.indptr), spg.n_rows, ptr(spg.indices), None, ptr(spg.data), ptr(own), ptr(partner), S,
-                                   ptr(seg), None, 0, 1, ptr(xz), None, ptr(segid), spg.max_len, pair_block, ptr(flags), st))
+        if lazy:      # worst case: every segment as long as the longest SpG row
+            if out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev or out.numel() < S * spg.max_len * 2:
+                raise ValueError("lazy out= must hold S * SpG.max_len * 2 float32 on the SpG's device")
+            rows = out.numel() // 2
+            xz = out.view(-1)[: rows * 2].view(rows, 2, 1)
+        elif out is not None:
+            if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() < R * 2 or out.device != dev:
+                raise ValueError("out= must be a contiguous float32 buffer on the SpG's device with >= R*2 elements")
+            xz = out.view(-1)[: R * 2].view(R, 2, 1)
+        else:
+            xz = torch.empty((R, 2, 1), dtype=torch.float32, device=dev)
+        with _timed("sjoin_fill"):
+            check(L.subgacc_sjoin_fill(ptr(spg.indptr), spg.n_rows, ptr(spg.indices), None, ptr(spg.data), ptr(own), ptr(partner), S,
+                                       ptr(seg), None, 0, 1, ptr(xz), None, ptr(segid), spg.max_len, pair_block, ptr(flags), st))
         out = xz
     elif return_index:
         out = torch.empty((R, 2), dtype=torch.int32, device=dev)
@@ -262,9 +278,9 @@ def gather(edge, x, device=None, ptr=True, encode=None, out=None, lazy=False):
     out= / lazy=: see sjoin (a serving loop's forms: caller-owned output buffer, no host round trip)."""
     spg = _as_spg(x)
     e = _as_rows(edge, spg.device)
-    own = torch.cat([e[0], e[1]])
-    partner = torch.cat([e[1], e[0]])
-    return _checked(*sjoin(spg, own, partner, encode, ptr_mode=ptr, pair_block=e.shape[1], out=out, lazy=lazy), lazy=lazy)
+    # own = [u.. | v..] is the contiguous [2, B] tensor itself; the mirrored partner list [v.. | u..] is derived by the kernels
+    own = e.contiguous().view(-1)
+    return _checked(*sjoin(spg, own, None, encode, ptr_mode=ptr, pair_block=e.shape[1], out=out, lazy=lazy), lazy=lazy)
 
 
 def hgather(hedge, x, device=None, encode=None):
@@ -274,9 +290,8 @@ def hgather(hedge, x, device=None, encode=None):
     spg = _as_spg(x)
     h = _as_rows(hedge, spg.device)
     u, v, w = h[0], h[1], h[2]
-    own = torch.cat([u, w, v, w])
-    partner = torch.cat([w, u, w, v])
-    xz, ind = _checked(*sjoin(spg, own, partner, encode, ptr_mode=False, pair_block=h.shape[1]))
+    own = torch.cat([u, w, v, w])          # the mirrored partner list [w, u, w, v] is derived by the kernels
+    xz, ind = _checked(*sjoin(spg, own, None, encode, ptr_mode=False, pair_block=h.shape[1]))
     assert xz.size(0) == ind.size(0)
     return xz, ind
 

@@ -1579,3 +1579,28 @@ def test_shfl_fallback_of_the_wave_reductions_gives_the_same_rows():
                         "key_rows_join_like or specialised_fused_row or batched_registration_numbers"],
                        env=dict(os.environ, SUBGACC_LIB=lib), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_captured_join_over_a_resident_store_equals_gather(sp):
+    """stepgraph.CapturedJoin: the three launches of a join from a resident store as one HIP graph, replayed batch after batch --
+    float payload (the PPR store), the Z_SF-table store and the keyed store; same (xz, indptr) as gather(), IndexError for a
+    row outside the store at finish()."""
+    from surel_plus_amd.graphs import ppr_like_spg, query_pairs
+    ptr_, idx = sym_graph(6000, 50000, seed=3, hubs=2)
+    csr = sp.DeviceCSR(ptr_, idx)
+    z, enc = sp.subg_matrix(csr, np.arange(6000), num_walks=100, num_steps=4, rng="philox")
+    table = torch.from_numpy(enc).cuda().float() / 100
+    zk = z.keyed(enc, 100)
+    zf = ppr_like_spg(6000, 100, seed=3)
+    B = 500
+    for store, encode in ((zf, None), (z, table), (zk, zk.slot_table())):
+        cj = sp.CapturedJoin(store, B, encode=encode)
+        for s_ in (1, 2, 3):
+            e = query_pairs(csr, B, seed=s_)
+            xz, ind = cj(e).finish()
+            wxz, wind = sp.gather(e, store, "cuda", ptr=True, encode=encode)
+            assert torch.equal(ind, wind) and torch.equal(xz, wxz)
+    bad = query_pairs(csr, B, seed=9)
+    bad[1, 7] = 6000
+    with pytest.raises(IndexError):
+        cj(bad).finish()

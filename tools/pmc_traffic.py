@@ -38,6 +38,22 @@ for f in glob.glob(os.path.join(out, "*.json")):
     for ln in open(f):
         if ln.startswith('{"metric"'):
             line = json.loads(ln)
+if line and "PPR" in line.get("metric", ""):      # the float join: its fill kernel's traffic, keyed like bench_ppr looks it up
+    import bench
+    join = [(k, m) for _, k, n, m in sorted(rows) if k.startswith("sjoin_pair_kernel")]
+    if join:
+        k, m = join[0]
+        B = line["config"]["pairs_per_step_per_gpu"]
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        tj = {kk: v for kk, v in tj.items() if isinstance(v, dict) and "kernel_source_sha" in v}
+        tj[f"cit2ppr:{B}:join"] = {"join_hbm_bytes_per_launch": (2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024,
+                                   "join_l2_miss_lines_per_launch": m.get("TCC_MISS_sum", 0), "kernel": k,
+                                   "kernel_source_sha": bench.kernel_source_sha(), "source": f"profiles/{tag}_pmc_per_launch.csv",
+                                   "how": "tools/pmc_collect.sh ... --workload cit2ppr (SUBGACC_PPR_EAGER=1: eager launches); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024"}
+        json.dump(tj, open(tpath, "w"), indent=1)
+        json.dump(tj, open(os.path.join(out, "traffic.json"), "w"), indent=1)
+    walk = None
 if walk and line:
     import bench
     cfg = line["config"]
