@@ -36,6 +36,10 @@ import torch  # noqa: E402
 WORKLOADS = {
     # name: (graph preset, num_walks M, CLI num_steps k (walk hops m = k-1), description, fraction of positive pairs)
     "cit2": ("cit2", 200, 4, "cit2-like LP: N=2,927,963 avg-deg 20.7 power-law graph, M=200, --num_steps 4 (m=3 hops)", 0.5),
+    # not a BASELINE config: the cit2 parameters on a graph WITH id locality (graphs.community_graph) -- does the walk's L2 miss
+    # count respond to structure / to a work list sorted by root id?  (SUBGACC_SORT_ROOTS=1 sorts the work list)
+    "cit2loc": ("cit2loc", 200, 4, "cit2-like LP on a community-structured graph: N=2,927,963 avg-deg 20.7, blocks of 2,048 consecutive ids, "
+                                   "75 % of the edges inside a block, M=200, --num_steps 4 (m=3 hops)", 0.5),
     "collab": ("collab", 200, 3, "collab-like LP: N=235,868 avg-deg 8.2 power-law graph, M=200, --num_steps 3 (m=2 hops)", 0.5),
     # configs[2]: --k 20 negatives per positive (README.md:86) -> 1 pair in 21 is an edge of the graph, 20 are uniform pairs
     "ppa": ("ppa", 200, 4, "ppa-like LP: N=576,289 avg-deg 73.7 power-law graph, M=200, --num_steps 4 (m=3 hops), "

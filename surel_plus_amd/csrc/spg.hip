@@ -40,11 +40,17 @@ __device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
 
 // The sort proper: the row (ids x[], payload v[], E members per lane) is in registers; sorted by id it goes to
 // out_indices / out_data [beg, beg + ns).
+// Level 1: B buckets of equal id width.  Level 2 (only where level 1 left a crowded bucket: ids with locality -- most of a set
+// inside one community of consecutive ids -- put hundreds of members into ONE bucket, and the ranking by counting below is
+// quadratic in the bucket size): bucket b gets as many sub-buckets as it has members, sub-bucket = offset inside b's id window
+// scaled by b's count, so that idx2 = start[b] + sub maps the ids monotonically onto [0, ns) following the row's own
+// distribution; `cnt2` holds the ns + 1 level-2 counters, two 16-bit counters per word (walk_rows.hip has the same sort).
+constexpr int kFineAbove = 12;
 template <int E>
 __device__ __forceinline__ void bucket_sort_regs(const int32_t (&x)[E], const int32_t (&v)[E], int32_t mn, int32_t mx,
                                                  int64_t beg, int ns, int lane, int bcap, unsigned long long *tmp,
                                                  int32_t *start, int32_t *cursor, int32_t *__restrict__ out_indices,
-                                                 int32_t *__restrict__ out_data) {
+                                                 int32_t *__restrict__ out_data, uint32_t *cnt2) {
     int logb = 0;
     while ((1 << logb) < ns && (1 << logb) < bcap) ++logb;
     const int B = 1 << logb;
@@ -54,17 +60,23 @@ __device__ __forceinline__ void bucket_sort_regs(const int32_t (&x)[E], const in
     for (int b = lane; b < B; b += kSpgThreads) cursor[b] = 0;
     __syncthreads();
     uint32_t bk[E];
+    int32_t arr[E];
 #pragma unroll
     for (int u = 0; u < E; ++u) {
         bk[u] = (uint32_t)(((uint64_t)(uint32_t)(x[u] - mn) << logb) >> Ls);
-        if (lane + u * kSpgThreads < ns) atomicAdd(&cursor[bk[u]], 1);
+        arr[u] = 0;
+        if (lane + u * kSpgThreads < ns) arr[u] = atomicAdd(&cursor[bk[u]], 1);
     }
     __syncthreads();
+    int32_t maxc = 0;
     {   // exclusive scan of the histogram: B/64 consecutive buckets per lane + one wave scan
         const int per = (B + kSpgThreads - 1) / kSpgThreads;
         const int b0 = lane * per;
         int32_t s = 0;
-        for (int b = b0; b < b0 + per && b < B; ++b) s += cursor[b];
+        for (int b = b0; b < b0 + per && b < B; ++b) {
+            s += cursor[b];
+            maxc = max(maxc, cursor[b]);
+        }
         int32_t inc = s;
 #pragma unroll
         for (int dd = 1; dd < kWave; dd <<= 1) {
@@ -75,30 +87,80 @@ __device__ __forceinline__ void bucket_sort_regs(const int32_t (&x)[E], const in
         for (int b = b0; b < b0 + per && b < B; ++b) {
             const int32_t c = cursor[b];
             start[b] = run;
-            cursor[b] = run;
             run += c;
         }
         if (lane == kSpgThreads - 1) start[B] = inc;
+        maxc = wave_max_i32(maxc);
     }
     __syncthreads();
+    int32_t lo[E], hi[E];
+    if (maxc <= kFineAbove || Ls <= logb) {        // evenly spread ids (or one bucket per id): level 1 is the sort
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            lo[u] = hi[u] = 0;
+            if (lane + u * kSpgThreads < ns) lo[u] = start[bk[u]], hi[u] = start[bk[u] + 1];
+        }
+    } else {
+        const int bshift = Ls - logb;
+        const int W2 = (ns + 2) / 2 + 1;
+        for (int w = lane; w < W2; w += kSpgThreads) cnt2[w] = 0u;
+        __syncthreads();
+        uint32_t idx2[E];
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            idx2[u] = 0;
+            if (lane + u * kSpgThreads < ns) {
+                const uint32_t lo1 = (uint32_t)start[bk[u]], kb = (uint32_t)start[bk[u] + 1] - lo1;
+                const uint32_t off = (uint32_t)(x[u] - mn) - (bk[u] << bshift);                     // < 2^bshift
+                idx2[u] = lo1 + __umulhi(off << (32 - bshift), kb);                               // floor(off * kb / 2^bshift) < kb
+                const uint32_t sh = (idx2[u] & 1u) * 16u;
+                arr[u] = (int32_t)((atomicAdd(&cnt2[idx2[u] >> 1], 1u << sh) >> sh) & 0xFFFFu);
+            }
+        }
+        __syncthreads();
+        {   // exclusive scan of the level-2 counters in place: consecutive words per lane + one wave scan
+            const int per = (W2 + kSpgThreads - 1) / kSpgThreads;
+            const int w0 = lane * per;
+            int32_t s = 0;
+            for (int w = w0; w < w0 + per && w < W2; ++w) s += (int32_t)((cnt2[w] & 0xFFFFu) + (cnt2[w] >> 16));
+            int32_t inc = s;
+#pragma unroll
+            for (int dd = 1; dd < kWave; dd <<= 1) {
+                const int32_t t = __shfl_up(inc, dd, kWave);
+                if (lane >= dd) inc += t;
+            }
+            int32_t run = inc - s;
+            for (int w = w0; w < w0 + per && w < W2; ++w) {
+                const uint32_t c = cnt2[w];
+                const uint32_t lo16 = (uint32_t)run;
+                run += (int32_t)(c & 0xFFFFu);
+                const uint32_t hi16 = (uint32_t)run;
+                run += (int32_t)(c >> 16);
+                cnt2[w] = lo16 | (hi16 << 16);
+            }
+        }
+        __syncthreads();
+        const uint16_t *off2 = (const uint16_t *)cnt2;
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            lo[u] = hi[u] = 0;
+            if (lane + u * kSpgThreads < ns) lo[u] = off2[idx2[u]], hi[u] = off2[idx2[u] + 1];
+        }
+    }
 #pragma unroll
     for (int u = 0; u < E; ++u)
-        if (lane + u * kSpgThreads < ns) {
-            const int slot = atomicAdd(&cursor[bk[u]], 1);
-            tmp[slot] = ((unsigned long long)(uint32_t)x[u] << 32) | (uint32_t)v[u];
-        }
+        if (lane + u * kSpgThreads < ns) tmp[lo[u] + arr[u]] = ((unsigned long long)(uint32_t)x[u] << 32) | (uint32_t)v[u];
     __syncthreads();
-    // order inside a bucket: final position = bucket start + number of smaller ids in the bucket
+    // order inside a (sub-)bucket: final position = its start + number of smaller ids in it
     int32_t pos[E];
 #pragma unroll
     for (int u = 0; u < E; ++u) {
         pos[u] = -1;
         if (lane + u * kSpgThreads < ns) {
             const unsigned long long me = ((unsigned long long)(uint32_t)x[u] << 32) | (uint32_t)v[u];
-            const int lo = start[bk[u]], hi = start[bk[u] + 1];
             int rank = 0;
-            for (int t = lo; t < hi; ++t) rank += (tmp[t] < me) ? 1 : 0;
-            pos[u] = lo + rank;
+            for (int t = lo[u]; t < hi[u]; ++t) rank += (tmp[t] < me) ? 1 : 0;
+            pos[u] = lo[u] + rank;
         }
     }
     __syncthreads();
@@ -135,7 +197,7 @@ __device__ __forceinline__ void bucket_sort_row(const int32_t *__restrict__ ids,
     }
     mn = wave_min_i32(mn);
     mx = wave_max_i32(mx);
-    bucket_sort_regs<E>(x, v, mn, mx, beg, ns, lane, bcap, tmp, start, cursor, out_indices, out_data);
+    bucket_sort_regs<E>(x, v, mn, mx, beg, ns, lane, bcap, tmp, start, cursor, out_indices, out_data, (uint32_t *)(cursor + bcap));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -205,7 +267,7 @@ __device__ __forceinline__ void finish_row(int32_t *__restrict__ row_ids, const 
     unsigned long long *tmp = (unsigned long long *)lds;         // [cap]
     int32_t *start = (int32_t *)(tmp + cap);                     // [bcap+1]
     int32_t *cursor = start + bcap + 1;                          // [bcap]
-    bucket_sort_regs<E>(x, v, mn, mx, obase, ns, lane, bcap, tmp, start, cursor, row_ids, row_slot);
+    bucket_sort_regs<E>(x, v, mn, mx, obase, ns, lane, bcap, tmp, start, cursor, row_ids, row_slot, (uint32_t *)(cursor + bcap));
 }
 
 // EMAX = ceil(stride / 64): the longest row the launch can meet.  A compile-time bound so that the register budget
@@ -353,7 +415,7 @@ extern "C" int subgacc_spg_build(const int64_t *row_off, int64_t n, const int32_
         int bcap = 64;
         while (bcap < cap && bcap < kBucketMax) bcap <<= 1;
         if (bcap > 512) bcap = 512;   // <= 2 members per bucket on average; halves the LDS footprint
-        const size_t lds_b = (size_t)cap * 8 + (size_t)(2 * bcap + 1) * 4;
+        const size_t lds_b = (size_t)cap * 8 + (size_t)(2 * bcap + 1) * 4 + ((size_t)(cap + 2) / 2 + 1) * 4;    // + the level-2 counters
         hipLaunchKernelGGL(spg_bucket_kernel, dim3((unsigned)grid), dim3(kSpgThreads), lds_b, (hipStream_t)stream,
                            row_off, n, ids, sf, slot_id, cap, bcap, out_indices, out_data, flags);
         SG_LAUNCH_CHECK();
@@ -385,7 +447,7 @@ extern "C" int subgacc_finish_rows(int32_t *row_ids, const uint64_t *row_keys, c
     const int cap = stride;
     int bcap = 64;       // <= 256 buckets: ~2 members per bucket for the typical set, and the smaller LDS footprint lets
     while (bcap < cap && bcap < 256) bcap <<= 1;   // ~30 rows (waves) be resident per CU -- the kernel is latency x occupancy bound
-    const size_t sort_b = (size_t)cap * 8 + (size_t)(2 * bcap + 1) * 4, fold_b = (size_t)kFinFold * 16;
+    const size_t sort_b = (size_t)cap * 8 + (size_t)(2 * bcap + 1) * 4 + ((size_t)(cap + 2) / 2 + 1) * 4, fold_b = (size_t)kFinFold * 16;
     const size_t lds = sort_b > fold_b ? sort_b : fold_b;
     const int64_t grid = xcd_grid(n);
     SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "finish_rows: too many rows in one call");

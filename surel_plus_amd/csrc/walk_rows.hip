@@ -341,14 +341,26 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
         if (tid == 0) a.nsize[i] = ns;
         const int32_t mn = min(min(red[0], red[1]), min(red[2], red[3]));
         const int32_t mx = max(max(red[4], red[5]), max(red[6], red[7]));
+        // The sort: a two-level distribution sort in LDS.  Level 1 is a histogram over B buckets of equal id WIDTH (the top bits of
+        // id - min); level 2 gives bucket b as many sub-buckets as it has members -- sub-bucket = offset inside b's window scaled by
+        // b's count -- so that idx2 = start1[b] + sub is a monotone map of the ids onto [0, ns) that follows the set's own
+        // distribution (a piecewise-linear equalisation).  With ids spread evenly over their range (a structureless graph) level 1
+        // alone had ~3 members per bucket; on a graph with id locality most of a set lies in one community = ONE bucket of 200+
+        // members, and ranking inside it by counting was quadratic (cit2-like graph with communities: 3.4x the vector instructions,
+        // the kernel 2x slower -- profiles/r05u_sq_locality.csv).  Sub-buckets hold ~1 member either way; the ranking by counting
+        // that remains runs over those.
         unsigned long long *A = (unsigned long long *)lds_raw;            // [ns <= stride] over the counts and the ids
-        int32_t *start = (int32_t *)(lds_raw + 8 * (size_t)a.stride);       // [B+1] behind it (8*stride + 4*(B+1) <= 8*T)
+        int32_t *start = (int32_t *)(lds_raw + 8 * (size_t)a.stride);       // [B+1] level-1 counts, then offsets
+        uint32_t *cnt2 = (uint32_t *)(start + NT + 1);                      // [(ns+2)/2 + 1] level-2 counts, two 16-bit counters per word
         int logb = 0;
         while ((1 << logb) < ns && (2 << logb) <= T / 4 && (2 << logb) <= NT) ++logb;
         const int B = 1 << logb;
         const uint32_t range = (uint32_t)(mx - mn) + 1u;
         const int Ls = (range <= 1u) ? 0 : (32 - __builtin_clz(range - 1u));
         const int bshift = Ls > logb ? Ls - logb : 0;
+        constexpr int kFineAbove = 12;                 // level 2 from this many members in one level-1 bucket on
+        constexpr int CW = 4;                          // level-2 words per lane in the scan: (stride + 2) / 2 + 1 <= CW * NT (checked at launch)
+        const int W2 = (ns + 2) / 2 + 1;               // words that hold counters 0 .. ns (counter ns stays 0: its offset is the total)
         if (tid < B) start[tid] = 0;
         {
             int p = wbase + incl - cnt;
@@ -362,7 +374,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
         __syncthreads();
         unsigned long long el[SPL];
         uint32_t bk[SPL];
-        int32_t pos[SPL];                           // arrival order inside the bucket, then the final position
+        int32_t pos[SPL];                           // arrival order inside the sub-bucket, then the final position
 #pragma unroll
         for (int e = 0; e < SPL; ++e) {
             if (e * NT >= ns) break;
@@ -374,27 +386,92 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
             }
         }
         __syncthreads();
+        int32_t maxc;
         {
             const int32_t c = tid < B ? start[tid] : 0;
             const int32_t inc = wave_scan_add_i32_incl(c);
-            if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc;
+            const int32_t mc = wave_red_max_i32(c);
+            if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc, red[4 + tid / kWave] = mc;
             __syncthreads();
             int32_t base = 0;
             for (int w2 = 0; w2 < tid / kWave; ++w2) base += red[12 + w2];
+            maxc = red[4];
+            for (int w2 = 1; w2 < NT / kWave; ++w2) maxc = max(maxc, red[4 + w2]);
             const int32_t excl = base + inc - c;
             if (tid < B) start[tid] = excl;
             if (tid == B - 1) start[B] = excl + c;
         }
         __syncthreads();
         int blo[SPL], bhi[SPL];
+        // level 2 only where level 1 left a crowded bucket (workgroup-uniform): evenly spread ids -- every set of a structureless
+        // graph -- keep the short path (collab: the kernel is bound by vector instructions, level 2 for every set cost it 8 %)
+        if (maxc <= kFineAbove) {
+#pragma unroll
+            for (int e = 0; e < SPL; ++e) {
+                if (e * NT >= ns) break;
+                if (e * NT + tid < ns) {
+                    blo[e] = start[bk[e]];
+                    bhi[e] = start[bk[e] + 1];
+                }
+            }
+        } else {
+#pragma unroll
+        for (int c = 0; c < CW; ++c)
+            if (c * NT + tid < W2) cnt2[c * NT + tid] = 0u;
+        __syncthreads();
+        uint32_t idx2[SPL];
 #pragma unroll
         for (int e = 0; e < SPL; ++e) {
             if (e * NT >= ns) break;
             if (e * NT + tid < ns) {
-                blo[e] = start[bk[e]];
-                bhi[e] = start[bk[e] + 1];
-                A[blo[e] + pos[e]] = el[e];         // every packed element was read before the last two barriers
+                const uint32_t lo1 = (uint32_t)start[bk[e]], kb = (uint32_t)start[bk[e] + 1] - lo1;
+                const uint32_t off = ((uint32_t)(el[e] >> 32) - (uint32_t)mn) - (bk[e] << bshift);      // < 2^bshift
+                const uint32_t sub = bshift ? __umulhi(off << (32 - bshift), kb) : 0u;                 // floor(off * kb / 2^bshift) < kb
+                idx2[e] = lo1 + sub;
+                const uint32_t sh = (idx2[e] & 1u) * 16u;
+                pos[e] = (int32_t)((atomicAdd(&cnt2[idx2[e] >> 1], 1u << sh) >> sh) & 0xFFFFu);
             }
+        }
+        __syncthreads();
+        {   // exclusive scan of the ns + 1 level-2 counters, in place (offsets <= ns < 2^16): CW consecutive words per lane
+            uint32_t w[CW];
+            int32_t s2 = 0;
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const int x = tid * CW + c;
+                w[c] = x < W2 ? cnt2[x] : 0u;
+                s2 += (int32_t)((w[c] & 0xFFFFu) + (w[c] >> 16));
+            }
+            const int32_t inc = wave_scan_add_i32_incl(s2);
+            if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc;
+            __syncthreads();
+            int32_t run = inc - s2;
+            for (int w2 = 0; w2 < tid / kWave; ++w2) run += red[12 + w2];
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const int x = tid * CW + c;
+                const uint32_t lo16 = (uint32_t)run;
+                run += (int32_t)(w[c] & 0xFFFFu);
+                const uint32_t hi16 = (uint32_t)run;
+                run += (int32_t)(w[c] >> 16);
+                if (x < W2) cnt2[x] = lo16 | (hi16 << 16);
+            }
+        }
+        __syncthreads();
+        const uint16_t *off2 = (const uint16_t *)cnt2;
+#pragma unroll
+        for (int e = 0; e < SPL; ++e) {
+            if (e * NT >= ns) break;
+            if (e * NT + tid < ns) {
+                blo[e] = off2[idx2[e]];
+                bhi[e] = off2[idx2[e] + 1];
+            }
+        }
+        }
+#pragma unroll
+        for (int e = 0; e < SPL; ++e) {
+            if (e * NT >= ns) break;
+            if (e * NT + tid < ns) A[blo[e] + pos[e]] = el[e];         // every packed element was read before the barriers above
         }
         __syncthreads();
         const uint32_t *Ahi = (const uint32_t *)A;
@@ -632,7 +709,11 @@ int launch_walk_rows(const WalkArgs &a, bool indptr64, int rng_mode, size_t lds,
     const bool half = a.T == 512 && !nt256;
     const bool rec = a.recs != nullptr && indptr64 == (a.rec.id_bits == 0);   // hop records: one dependent read per hop
     if (a.keyrows) {      // rows that carry the LP key itself: 32-bit counts, 128 lanes, 2 or 3 hops -- or not at all
-        if (a.m * a.shift + 1 > 31 || a.m > 3 || 8 * (int64_t)a.stride + 4 * 129 > 8 * (int64_t)a.T) return 0;
+        // (the epilogue's sort lives over the dead walk tables AND the Fisher-Yates draws behind them: packed members 8*stride,
+        //  level-1 offsets 4*(128+1) [start + NT + 1: NT <= 128], level-2 counters 2 bytes each; CW * NT words cover them)
+        if (a.m * a.shift + 1 > 31 || a.m > 3 ||
+            8 * (int64_t)a.stride + 4 * 129 + 4 * (((int64_t)a.stride + 2) / 2 + 1) > 8 * (int64_t)a.T + 4 * (int64_t)a.M ||
+            ((int64_t)a.stride + 2) / 2 + 1 > 4 * (a.T == 512 ? 64 : 128)) return 0;
         const size_t ldsk = (size_t)a.T * 8 + (size_t)a.M * 4 + 8 + 64 + 16;
 #define SG_KR(I64, RNGM, MHH, SPLL)                                                                                  \
     do {                                                                                                             \

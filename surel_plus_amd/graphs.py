@@ -44,6 +44,40 @@ def powerlaw_graph(N, avg_deg, seed=0, exponent=2.5, device="cuda", max_weight_f
     return DeviceCSR(indptr.to(ptr_dtype), col, torch.device(device))
 
 
+def community_graph(N, avg_deg, seed=4, exponent=2.5, block=2048, p_in=0.75, device="cuda", max_weight_frac=0.002):
+    """A heavy-tailed undirected graph WITH id locality: the nodes form blocks of `block` consecutive ids (communities laid out
+    contiguously, as the ids of a citation / co-author graph are by venue and year), every edge draws its first endpoint by
+    expected-degree weight and its second from the SAME block with probability p_in (by weight inside the block), else from the
+    whole graph.  Same degree law and density as powerlaw_graph; what differs is that a walk started in a block mostly stays
+    near it -- the structure the Chung-Lu graphs lack and real graphs have (does a sorted work list cut L2 misses?)."""
+    gen = torch.Generator(device=device).manual_seed(int(seed))
+    ranks = torch.arange(1, N + 1, device=device, dtype=torch.float64)
+    w = ranks.pow(-1.0 / (exponent - 1.0))
+    w = torch.minimum(w, w.sum() * max_weight_frac / avg_deg)
+    w = w[torch.randperm(N, device=device, generator=gen)]        # hubs are spread over the blocks
+    cdf = torch.cumsum(w, 0)
+    tot = cdf[-1].clone()
+    E = int(N * avg_deg / 2 * 1.06)
+    u = torch.searchsorted(cdf, torch.rand(E, device=device, generator=gen, dtype=torch.float64) * tot).clamp_(max=N - 1)
+    blk_lo = (u // block) * block
+    blk_hi = torch.clamp(blk_lo + block, max=N)
+    c_lo = torch.where(blk_lo > 0, cdf[(blk_lo - 1).clamp(min=0)], torch.zeros_like(tot))
+    c_hi = cdf[blk_hi - 1]
+    local = torch.rand(E, device=device, generator=gen) < p_in
+    r = torch.rand(E, device=device, generator=gen, dtype=torch.float64)
+    target = torch.where(local, c_lo + r * (c_hi - c_lo), r * tot)
+    v = torch.searchsorted(cdf, target).clamp_(max=N - 1)
+    keep = u != v
+    u, v = u[keep], v[keep]
+    key = torch.unique(torch.cat([u * N + v, v * N + u]))
+    row = torch.div(key, N, rounding_mode="floor")
+    col = (key - row * N).to(torch.int32)
+    counts = torch.bincount(row, minlength=N)
+    indptr = torch.zeros(N + 1, dtype=torch.int64, device=device)
+    indptr[1:] = torch.cumsum(counts, 0)
+    return DeviceCSR(indptr.to(torch.int32 if key.numel() < 2**31 - 1 else torch.int64), col, torch.device(device))
+
+
 def directed_powerlaw_graph(N, avg_deg, seed=3, exponent=2.2, device="cuda", chunk=1 << 28, max_weight_frac=0.0005):
     """Billion-edge stand-in for twitter-follower (41.65 M nodes, ~2.9 B adjacency entries after symmetrisation):
     every node gets max(1, d_i) out-neighbours drawn from a heavy-tailed popularity distribution, generated in
@@ -93,6 +127,8 @@ def degree_ordered(csr):
 
 
 def preset_graph(name, device="cuda", scale=1.0):
+    if name == "cit2loc":     # the cit2-like graph with communities of consecutive ids (community_graph)
+        return community_graph(max(int(2_927_963 * scale), 64), 20.7, seed=4, device=device)
     if name == "twitter":
         return directed_powerlaw_graph(max(int(41_652_230 * scale), 1000), 70.5, seed=3, device=device)
     p = PRESETS[name]

@@ -383,7 +383,7 @@ def _dedup_tick(bufs):
 
 def _buffered_step(csr, e, bufs, seed, out):
     """sample_and_gather through a StepBuffers: six launches, nothing allocated, nothing read back"""
-    from .sampler import SampledSets, _timed, make_cfg
+    from .sampler import SampledSets, _timed, make_cfg, walk_kernel_name
     L, st, dev = lib(), stream_ptr(), csr.device
     B, M, m, k, n = bufs.B, bufs.M, bufs.m, bufs.k, 2 * bufs.B
     if tuple(e.shape) != (2, B):
@@ -405,6 +405,20 @@ def _buffered_step(csr, e, bufs, seed, out):
                                             ptr(bufs.worklist), ptr(bufs.n_distinct), ptr(bufs.table), 0 if kr else bufs.capacity,
                                             ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize), ptr(flags), st))
         own, partner = bufs.own, bufs.partner
+    elif SORT_ROOTS and walk_kernel_name(csr, M, m, True) == "walk_rows_kernel":
+        # the rows stay where the batch has them; the walk kernel takes them in ascending order of their root's id (a work list):
+        # roots that are neighbours in id space -- the same community of a graph with id locality -- are walked at the same time on
+        # the same XCD and share its L2
+        check(L.subgacc_step_prologue(ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.status), 4, ptr(e), ptr(bufs.roots), n, st))
+        if not hasattr(bufs, "sorted_list"):
+            bufs.sorted_list = torch.empty(n, dtype=torch.int32, device=dev)
+            bufs.n_all = torch.full((1,), n, dtype=torch.int64, device=dev)
+        bufs.sorted_list.copy_(torch.argsort(bufs.roots))
+        with _timed("walk_sets"):
+            check(L.subgacc_walk_spg_sparse(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n,
+                                            ptr(bufs.sorted_list), ptr(bufs.n_all), ptr(bufs.table), 0 if kr else bufs.capacity,
+                                            ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize), ptr(flags), st))
+        own, partner = _arange_segments(B, dev)
     else:
         check(L.subgacc_step_prologue(ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.status), 4, ptr(e), ptr(bufs.roots), n, st))
         with _timed("walk_sets"):
@@ -491,6 +505,7 @@ def sample_and_gather(csr, edge, num_walks=200, num_steps=3, seed=111413, rng="p
     return xz, ind, sets
 
 
+SORT_ROOTS = os.environ.get("SUBGACC_SORT_ROOTS", "0") == "1"     # the buffered step walks its rows in ascending root id
 _ARANGE_SEGMENTS = {}
 _CACHE_LOCK = threading.Lock()     # the reference's pgather calls the join from 4 Python threads (train.py:88-99)
 

@@ -1604,3 +1604,23 @@ def test_captured_join_over_a_resident_store_equals_gather(sp):
     bad[1, 7] = 6000
     with pytest.raises(IndexError):
         cj(bad).finish()
+
+
+@pytest.mark.parametrize("M,hops", [(200, 3), (200, 2), (100, 4)])
+def test_sets_with_id_locality_sort_like_any_other(sp, M, hops):
+    """A graph whose communities are blocks of consecutive ids (graphs.community_graph): most of a set lies inside one block, i.e.
+    inside ONE bucket of a sort that buckets by equal id width.  The two-level distribution sort (walk_rows.hip key rows,
+    spg.hip bucket_sort_regs) must give the same rows as ever -- every path against the oracle -- and take its fine level here."""
+    from surel_plus_amd.graphs import community_graph, query_pairs
+    from surel_plus_amd.spg import sample_spg
+    csr = community_graph(30000, 20.7, seed=4, block=512, p_in=0.85)
+    ptr_, idx = csr.indptr.cpu().numpy(), csr.indices.cpu().numpy()
+    q = np.random.default_rng(1).permutation(30000)[:3000]
+    (oi, ox, od), oenc = _oracle_spg(ptr_, idx, q, M, hops, 13, "philox", -1)
+    assert int(np.diff(oi).max()) > 150                      # (sets big enough for a crowded bucket)
+    for kw in ({"fused": True}, {"fused": False}, {"strided": True}, {"strided": True, "fused": False}):
+        z, sets = sample_spg(csr, q, num_walks=M, num_steps=hops, seed=13, rng="philox", **kw)
+        if isinstance(z, sp.StridedSpG):
+            z = z.to_csr()
+        assert np.array_equal(z.indptr.cpu().numpy(), oi) and np.array_equal(z.indices[: z.nnz].cpu().numpy(), ox), kw
+        assert np.array_equal(z.data[: z.nnz].cpu().numpy(), od) and np.array_equal(sets.enc_int16().cpu().numpy(), oenc), kw
