@@ -474,6 +474,15 @@ int subgacc_batch_sampler(const void *indptr, int32_t indptr64, const int32_t *i
                           uint32_t seed_eff, int32_t *out, int64_t out_cap, int64_t *out_count, void *workspace,
                           size_t workspace_bytes, int32_t *flags, void *stream);
 
+/* ABI 4: the rows 0 .. n-1 of a batch as a work list in ascending order of their root's id (1,024 buckets of consecutive
+ * ids, any order inside a bucket; *n_work = n) -- what subgacc_walk_spg_sparse then runs over: roots that are neighbours in id
+ * space (the same community of a graph with id locality) or equal (repeated endpoints) are walked at the same time on the
+ * same XCD and share its L2.  The rows stay where they are; only the order of the walk changes, so no result does.  Two small
+ * launches; workspace = subgacc_worklist_workspace_bytes(n) bytes. */
+size_t subgacc_worklist_workspace_bytes(int64_t n);
+int subgacc_worklist_by_root(const int32_t *roots, int64_t n, int64_t num_nodes, int32_t *worklist, int64_t *n_work,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Measurement aid (no reference counterpart): 2048 x 256 lanes each make 4*rounds independent uniformly random 4-byte reads
  * of table[0 .. table_bytes) -- beyond the caches every read moves one 128-byte line, so reads / time is the random-line rate
