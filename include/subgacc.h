@@ -441,10 +441,11 @@ int subgacc_walk_spg_sparse(const subgacc_walk_cfg *cfg, const void *indptr, con
  *      (n_dev, optional: only the first min(n, *n_dev) entries).
  * Shapes: what the key-rows form of subgacc_walk_spg serves (num_steps*SHIFT+1 <= 31, 2 or 3 hops, M <= 256, no bucket).
  * rng_pos / rng_seed as for subgacc_walk_spg (RAND_R: positions of ALL n roots of the chunk; row i reads entry i).
- * ------------------------------------------------------------------------------------------- */
-int subgacc_keyrows_register(const int32_t *row_keys, const int32_t *nsize, int64_t n, int32_t stride, int64_t root_base,
-                             void *uniq_table, int64_t uniq_capacity, int32_t *cand, int64_t *n_cand, int32_t *flags,
-                             void *stream);
+ * cand: subgacc_keyrows_cand_capacity(n) entries (cand_cap says how many there are; every row is listed at most once). */
+int64_t subgacc_keyrows_cand_capacity(int64_t n);
+int subgacc_keyrows_register(const int32_t *row_keys, const int32_t *nsize, int64_t n, int32_t stride,
+                             int64_t root_base, void *uniq_table, int64_t uniq_capacity, int32_t *cand, int64_t cand_cap,
+                             int64_t *n_cand, int32_t *flags, void *stream);
 int subgacc_walk_tags(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,
                       const int32_t *query, int64_t n, int64_t root_base, const uint32_t *rng_pos, const uint32_t *rng_seed,
                       const int32_t *worklist, const int64_t *n_work, int64_t work_cap, void *uniq_table,
@@ -452,7 +453,7 @@ int subgacc_walk_tags(const subgacc_walk_cfg *cfg, const void *indptr, const int
 int subgacc_keyrows_compact(const int32_t *row_ids, const int32_t *row_keys, const int32_t *nsize, const int64_t *row_off,
                             int64_t n, int32_t stride, int64_t root_base, void *uniq_table, int64_t uniq_capacity,
                             const uint64_t *ukeys, const int64_t *n_ukeys, int64_t max_ukeys, int32_t *out_indices,
-                            int32_t *out_data, int32_t *cand, int64_t *n_cand, int32_t *flags, void *stream);
+                            int32_t *out_data, int32_t *cand, int64_t cand_cap, int64_t *n_cand, int32_t *flags, void *stream);
 int subgacc_keyrows_translate(int32_t *data_inout, int64_t n, const int64_t *n_dev, void *uniq_table, int64_t uniq_capacity,
                               const uint64_t *ukeys, const int64_t *n_ukeys, int64_t max_ukeys, void *stream);
 

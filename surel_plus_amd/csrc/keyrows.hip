@@ -40,7 +40,7 @@ namespace subgacc {
 #define KR_THREADS 512
 #endif
 #ifndef KR_UNROLL
-#define KR_UNROLL 4
+#define KR_UNROLL 8      // (8 members per lane in flight: find+copy 1.50 -> 1.28 ms per 10^6 cit2 rows; 2: 1.47, 4: 1.50 -- tools/keyrows_bench.py)
 #endif
 #ifndef KR_NT        // 1: non-temporal row loads / packed stores -- measured slower here (find+copy 2.21 vs 1.96 ms per 10^6 cit2 rows)
 #define KR_NT 0
@@ -55,10 +55,9 @@ namespace subgacc {
 constexpr int kKrThreads = KR_THREADS, kKrWaves = kKrThreads / kWave;
 constexpr int kKrDictBits = 12, kKrDict = 1 << kKrDictBits;     // 4,096 entries x 8 B = 32 KB: 4 blocks = 32 waves per CU
 constexpr int kKrDictMax = kKrDict * 3 / 4;                    // entries preloaded at most (the rest is asked for in HBM)
-constexpr int kKrProbes = 8;
+constexpr int kKrProbes = 32;    // (a key that finds no place within this many probes is asked for in HBM every time it turns up)
 constexpr int kKrUnroll = KR_UNROLL;                 // members per lane whose loads are in flight together
 constexpr int kKrMaxRows = 4096;             // rows per block (candidate bitmap)
-constexpr unsigned long long kKrEmpty64 = ~0ull;   // key word 0xFFFFFFFF is never a key: key rows need m*SHIFT+1 <= 31 bits
 enum { KR_REGISTER = 0, KR_REGISTER_COPY = 1, KR_FIND_WRITE = 2 };
 
 // claim-or-find like uniq_global_insert; `lowered` reports whether this call may have lowered the key's tag (then the
@@ -94,37 +93,103 @@ __device__ __forceinline__ int32_t uniq_global_find(const UniqTable &t, unsigned
     return -1;
 }
 
-__device__ __forceinline__ uint32_t kr_home(uint32_t key) { return (key * 0x9E3779B1u) >> (32 - kKrDictBits); }
+__device__ __forceinline__ uint32_t kr_home(uint32_t key) {       // LP keys are packed small counts: mix before taking the top bits
+    uint32_t h = key * 0x9E3779B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA77u;
+    return h >> (32 - kKrDictBits);
+}
 
-// dictionary look-up {payload | key}: the payload, or -1 when the key is not there
-__device__ __forceinline__ int32_t kr_lookup(const unsigned long long *dict, uint32_t key) {
+// The dictionary: two planes of 32-bit words in LDS -- keys (0xFFFFFFFF = empty) and payloads (SFptr+1, or the smallest row that
+// shows the key).  A set's members mostly carry the same dozen LP keys, so most lanes of a wave ask for the same few entries:
+// that is what LDS does best (tools/lds_probe.hip: 64 lanes on one word, or on ten hot words, read at the conflict-free rate,
+// ds_read_b32 and ds_read_b64 alike; only 64 random words cost 2x).  A translate pass over 3.4e8 members runs at 0.61 ms
+// against 0.55 ms for a plain copy of the same bytes (tools/keyrows_bench.py).
+struct KrDict {
+    uint32_t *k, *v;
+};
+constexpr uint32_t kKrEmpty = 0xFFFFFFFFu;     // never a key: key rows need m*SHIFT+1 <= 31 bits
+
+__device__ __forceinline__ void kr_clear(const KrDict d, int tid) {
+    for (int s = tid; s < kKrDict; s += kKrThreads) d.k[s] = kKrEmpty, d.v[s] = 0xFFFFFFFFu;
+}
+
+#if defined(KR_COUNT_MISS)      // dev-only: how often does a look-up leave the dictionary empty-handed? (tools/keyrows_bench.py)
+__device__ unsigned long long g_kr_miss;
+extern "C" long long subgacc_debug_kr_misses(void) {
+    unsigned long long v = 0, z = 0;
+    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_kr_miss), 8);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_kr_miss), &z, 8);
+    return (long long)v;
+}
+#endif
+#if defined(KR_ABLATE_LOOKUP) && KR_ABLATE_LOOKUP == 4      // 4: the whole probe loop, but a miss is 0 instead of a question to the HBM table
+#define KR_MISS 0
+#else
+#define KR_MISS (-1)
+#endif
+// look-up: the payload, or -1 when the key is not there
+__device__ __forceinline__ int32_t kr_lookup(const KrDict d, uint32_t key) {
+#if defined(KR_ABLATE_LOOKUP) && KR_ABLATE_LOOKUP == 1     // dev-only timing experiments (tools/keyrows_bench.py; results are wrong)
+    return (int32_t)(key ^ 1u);                              // 1: no dictionary at all
+#elif defined(KR_ABLATE_LOOKUP) && KR_ABLATE_LOOKUP == 2
+    return (int32_t)d.v[kr_home(key)];                       // 2: one LDS read, no probe loop, no compare
+#elif defined(KR_ABLATE_LOOKUP) && KR_ABLATE_LOOKUP == 3
+    {                                                        // 3: the first probe only (key + payload), no loop
+        const uint32_t h0 = kr_home(key);
+        return d.k[h0] == key ? (int32_t)d.v[h0] : 0;
+    }
+#endif
     uint32_t h = kr_home(key);
 #pragma unroll 1
     for (int p = 0; p < kKrProbes; ++p) {
-        const unsigned long long e = dict[h];
-        if ((uint32_t)e == key) return (int32_t)(e >> 32);
-        if (e == kKrEmpty64) return -1;
+        const uint32_t e = d.k[h];
+        if (e == key) return (int32_t)d.v[h];
+        if (e == kKrEmpty) break;
         h = (h + 1) & (kKrDict - 1);
     }
-    return -1;
+#if defined(KR_COUNT_MISS)
+    atomicAdd(&g_kr_miss, 1ull);
+#endif
+    return KR_MISS;
 }
 
 // registering: the entry of `key` ends up holding the smallest row that called; false when the neighbourhood is crowded
-__device__ __forceinline__ bool kr_note(unsigned long long *dict, uint32_t key, uint32_t row) {
-    const unsigned long long mine = ((unsigned long long)row << 32) | key;
+__device__ __forceinline__ bool kr_note(const KrDict d, uint32_t key, uint32_t row) {
     uint32_t h = kr_home(key);
 #pragma unroll 1
     for (int p = 0; p < kKrProbes; ++p) {
-        unsigned long long e = dict[h];
-        if (e == kKrEmpty64) e = atomicCAS(&dict[h], kKrEmpty64, mine);
-        if (e == kKrEmpty64) return true;
-        if ((uint32_t)e == key) {
-            if (e > mine) atomicMin(&dict[h], mine);       // (same key word: the row decides)
+        uint32_t e = d.k[h];
+        if (e == kKrEmpty) {
+            e = atomicCAS(&d.k[h], kKrEmpty, key);
+            if (e == kKrEmpty) e = key;
+        }
+        if (e == key) {
+            if (d.v[h] > row) atomicMin(&d.v[h], row);
             return true;
         }
         h = (h + 1) & (kKrDict - 1);
     }
     return false;
+}
+
+// the numbered keys, number + 1 as payload (a barrier must follow)
+__device__ __forceinline__ void kr_preload(const KrDict d, const unsigned long long *__restrict__ ukeys, const int64_t *__restrict__ n_ukeys,
+                                           int64_t max_ukeys, int tid) {
+    int64_t c = *n_ukeys;
+    if (c > max_ukeys) c = max_ukeys;
+    if (c > kKrDictMax) c = kKrDictMax;
+    for (int64_t x = tid; x < c; x += kKrThreads) {
+        const uint32_t key = (uint32_t)ukeys[x];
+        uint32_t h = kr_home(key);
+        for (int p = 0; p < kKrProbes; ++p) {
+            if (atomicCAS(&d.k[h], kKrEmpty, key) == kKrEmpty) {
+                d.v[h] = (uint32_t)(x + 1);
+                break;
+            }
+            h = (h + 1) & (kKrDict - 1);
+        }
+    }
 }
 
 template <int MODE>
@@ -136,28 +201,18 @@ __global__ __launch_bounds__(kKrThreads) void keyrows_pass_kernel(const int32_t 
                                                                   int32_t *__restrict__ out_indices, int32_t *__restrict__ out_data,
                                                                   int32_t *__restrict__ cand, unsigned long long *__restrict__ n_cand,
                                                                   int32_t *flags) {
-    __shared__ unsigned long long dict[kKrDict];
+    __shared__ uint32_t dmem[2 * kKrDict];
+    const KrDict dict{dmem, dmem + kKrDict};
     __shared__ uint32_t candbits[kKrMaxRows / 32];
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    for (int s = tid; s < kKrDict; s += kKrThreads) dict[s] = kKrEmpty64;
+    kr_clear(dict, tid);
     if (MODE != KR_FIND_WRITE)
         for (int s = tid; s < kKrMaxRows / 32; s += kKrThreads) candbits[s] = 0u;
     __syncthreads();
     const int64_t first = (int64_t)blockIdx.x * rows_per_block;
     const int64_t last = min(first + (int64_t)rows_per_block, n);
     if (MODE == KR_FIND_WRITE) {      // the numbered keys, number + 1 as payload
-        int64_t c = *n_ukeys;
-        if (c > max_ukeys) c = max_ukeys;
-        if (c > kKrDictMax) c = kKrDictMax;
-        for (int64_t x = tid; x < c; x += kKrThreads) {
-            const uint32_t key = (uint32_t)ukeys[x];
-            const unsigned long long mine = ((unsigned long long)(uint32_t)(x + 1) << 32) | key;
-            uint32_t h = kr_home(key);
-            for (int p = 0; p < kKrProbes; ++p) {
-                if (atomicCAS(&dict[h], kKrEmpty64, mine) == kKrEmpty64) break;
-                h = (h + 1) & (kKrDict - 1);
-            }
-        }
+        kr_preload(dict, ukeys, n_ukeys, max_ukeys, tid);
         __syncthreads();
     }
     // ---- the stream: wave w takes rows first + w, first + w + kKrWaves, ...; nothing below waits for another wave
@@ -215,11 +270,11 @@ __global__ __launch_bounds__(kKrThreads) void keyrows_pass_kernel(const int32_t 
     // ---- the range is done: its distinct keys go to the HBM table, each with the coarse tag of the smallest row that shows it
     __syncthreads();
     for (int s = tid; s < kKrDict; s += kKrThreads) {
-        const unsigned long long e = dict[s];
-        if (e == kKrEmpty64) continue;
-        const uint32_t rowl = (uint32_t)(e >> 32);
+        const uint32_t e = dict.k[s];
+        if (e == kKrEmpty) continue;
+        const uint32_t rowl = dict.v[s];
         bool lowered = false;
-        (void)uniq_global_insert_ex(t, (unsigned long long)(uint32_t)e,
+        (void)uniq_global_insert_ex(t, (unsigned long long)e,
                                     (unsigned long long)((root_base + first + rowl) * (int64_t)stride + (stride - 1)), flags, lowered);
         if (lowered) atomicOr(&candbits[rowl >> 5], 1u << (rowl & 31u));
     }
@@ -238,22 +293,12 @@ __global__ __launch_bounds__(kKrThreads) void keyrows_pass_kernel(const int32_t 
 __global__ __launch_bounds__(kKrThreads) void keyrows_translate_kernel(int32_t *__restrict__ data, int64_t n, const int64_t *__restrict__ n_dev,
                                                                        UniqTable t, const unsigned long long *__restrict__ ukeys,
                                                                        const int64_t *__restrict__ n_ukeys, int64_t max_ukeys) {
-    __shared__ unsigned long long dict[kKrDict];
+    __shared__ uint32_t dmem[2 * kKrDict];
+    const KrDict dict{dmem, dmem + kKrDict};
     const int tid = threadIdx.x;
-    for (int s = tid; s < kKrDict; s += kKrThreads) dict[s] = kKrEmpty64;
+    kr_clear(dict, tid);
     __syncthreads();
-    int64_t c = *n_ukeys;
-    if (c > max_ukeys) c = max_ukeys;
-    if (c > kKrDictMax) c = kKrDictMax;
-    for (int64_t x = tid; x < c; x += kKrThreads) {
-        const uint32_t key = (uint32_t)ukeys[x];
-        const unsigned long long mine = ((unsigned long long)(uint32_t)(x + 1) << 32) | key;
-        uint32_t h = kr_home(key);
-        for (int p = 0; p < kKrProbes; ++p) {
-            if (atomicCAS(&dict[h], kKrEmpty64, mine) == kKrEmpty64) break;
-            h = (h + 1) & (kKrDict - 1);
-        }
-    }
+    kr_preload(dict, ukeys, n_ukeys, max_ukeys, tid);
     __syncthreads();
     if (n_dev && *n_dev < n) n = *n_dev;
     const int64_t per = (int64_t)kKrThreads * 4 * 8;           // 8 x 16 bytes per lane and block
@@ -293,20 +338,24 @@ __global__ __launch_bounds__(kKrThreads) void keyrows_translate_kernel(int32_t *
 
 using namespace subgacc;
 
+extern "C" int64_t subgacc_keyrows_cand_capacity(int64_t n) { return (n > 0 ? n : 0) + 16; }     // at most one entry per row
+
 static int keyrows_launch(int mode, const int32_t *row_ids, const int32_t *row_keys, const int32_t *nsize, const int64_t *row_off,
                           int64_t n, int32_t stride, int64_t root_base, void *uniq_table, int64_t uniq_capacity,
                           const uint64_t *ukeys, const int64_t *n_ukeys, int64_t max_ukeys, int32_t *out_indices, int32_t *out_data,
-                          int32_t *cand, int64_t *n_cand, int32_t *flags, void *stream) {
+                          int32_t *cand, int64_t cand_cap, int64_t *n_cand, int32_t *flags, void *stream) {
     SG_REQUIRE(n >= 0 && stride > 0 && root_base >= 0, SUBGACC_ERR_BADARG, "keyrows: bad sizes");
     SG_REQUIRE(uniq_table && uniq_capacity > 0 && (uniq_capacity & (uniq_capacity - 1)) == 0 && uniq_capacity < (1ll << 31),
                SUBGACC_ERR_BADARG, "keyrows: needs a power-of-two table of distinct rows");
     if (n == 0) return SUBGACC_OK;
-    SG_REQUIRE(row_keys && nsize && flags, SUBGACC_ERR_BADARG, "keyrows: null argument");
-    SG_REQUIRE(mode == KR_FIND_WRITE || (cand && n_cand), SUBGACC_ERR_BADARG, "keyrows: the registering forms list their candidates");
+    SG_REQUIRE(row_keys && flags && nsize, SUBGACC_ERR_BADARG, "keyrows: null argument");
+    SG_REQUIRE(mode == KR_FIND_WRITE || (cand && n_cand && cand_cap >= subgacc_keyrows_cand_capacity(n)), SUBGACC_ERR_BADARG,
+               "keyrows: the registering forms list their candidates (cand: subgacc_keyrows_cand_capacity(n) entries)");
     SG_REQUIRE(mode != KR_FIND_WRITE || (ukeys && n_ukeys && max_ukeys >= 0), SUBGACC_ERR_BADARG,
                "keyrows: the look-up form needs the numbered keys (subgacc_uniq_number's out_ukeys / out_count)");
     SG_REQUIRE(mode == KR_REGISTER || (row_ids && row_off && out_indices && out_data), SUBGACC_ERR_BADARG,
                "keyrows: the copying forms need the rows' ids, their packed offsets and the output arrays");
+    const UniqTable t = uniq_view(uniq_table, uniq_capacity);
     // rows per block: a range long enough that its one flush of the dictionary does not matter, short enough that the launch has
     // several blocks per resident slot (4 blocks x 256 CUs) to even out what the rows' lengths leave uneven
     int64_t rpb = n / (4 * 256 * 4);
@@ -315,7 +364,6 @@ static int keyrows_launch(int mode, const int32_t *row_ids, const int32_t *row_k
     rpb = rpb < 32 ? 32 : (rpb > kKrMaxRows ? kKrMaxRows : rpb);
     const int64_t grid = ceil_div(n, rpb);
     SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "keyrows: too many rows in one call");
-    const UniqTable t = uniq_view(uniq_table, uniq_capacity);
 #define SG_KR_PASS(MODE)                                                                                                 \
     hipLaunchKernelGGL(keyrows_pass_kernel<MODE>, dim3((unsigned)grid), dim3(kKrThreads), 0, (hipStream_t)stream, row_ids, \
                        row_keys, nsize, row_off, n, stride, root_base, (int32_t)rpb, t, (const unsigned long long *)ukeys, \
@@ -328,19 +376,20 @@ static int keyrows_launch(int mode, const int32_t *row_ids, const int32_t *row_k
     return SUBGACC_OK;
 }
 
-extern "C" int subgacc_keyrows_register(const int32_t *row_keys, const int32_t *nsize, int64_t n, int32_t stride, int64_t root_base,
-                                        void *uniq_table, int64_t uniq_capacity, int32_t *cand, int64_t *n_cand, int32_t *flags,
-                                        void *stream) {
+extern "C" int subgacc_keyrows_register(const int32_t *row_keys, const int32_t *nsize, int64_t n, int32_t stride,
+                                        int64_t root_base, void *uniq_table, int64_t uniq_capacity, int32_t *cand, int64_t cand_cap,
+                                        int64_t *n_cand, int32_t *flags, void *stream) {
     return keyrows_launch(KR_REGISTER, nullptr, row_keys, nsize, nullptr, n, stride, root_base, uniq_table, uniq_capacity, nullptr,
-                          nullptr, 0, nullptr, nullptr, cand, n_cand, flags, stream);
+                          nullptr, 0, nullptr, nullptr, cand, cand_cap, n_cand, flags, stream);
 }
 
 extern "C" int subgacc_keyrows_compact(const int32_t *row_ids, const int32_t *row_keys, const int32_t *nsize, const int64_t *row_off,
                                        int64_t n, int32_t stride, int64_t root_base, void *uniq_table, int64_t uniq_capacity,
                                        const uint64_t *ukeys, const int64_t *n_ukeys, int64_t max_ukeys, int32_t *out_indices,
-                                       int32_t *out_data, int32_t *cand, int64_t *n_cand, int32_t *flags, void *stream) {
+                                       int32_t *out_data, int32_t *cand, int64_t cand_cap, int64_t *n_cand, int32_t *flags, void *stream) {
     return keyrows_launch(ukeys ? KR_FIND_WRITE : KR_REGISTER_COPY, row_ids, row_keys, nsize, row_off, n, stride, root_base,
-                          uniq_table, uniq_capacity, ukeys, n_ukeys, max_ukeys, out_indices, out_data, cand, n_cand, flags, stream);
+                          uniq_table, uniq_capacity, ukeys, n_ukeys, max_ukeys, out_indices, out_data, cand, cand_cap, n_cand, flags,
+                          stream);
 }
 
 extern "C" int subgacc_keyrows_translate(int32_t *data_inout, int64_t n, const int64_t *n_dev, void *uniq_table, int64_t uniq_capacity,

@@ -336,12 +336,13 @@ class SampledSets:
             check(L.subgacc_uniq_reset(ptr(table), cap, st))
             words = torch.zeros(4, dtype=torch.int64, device=dev)      # [flags x4 (int32) | candidates | distinct rows]
             flags = words.view(torch.int32)[:4]
-            cand = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+            ccap = L.subgacc_keyrows_cand_capacity(n)
+            cand = torch.empty(ccap, dtype=torch.int32, device=dev)
             check(L.subgacc_keyrows_register(ptr(self.slot), ptr(self.nsize), n, self.stride, 0, ptr(table), cap, ptr(cand),
-                                             ptr(words[2:3]), ptr(flags), st))
+                                             ccap, ptr(words[2:3]), ptr(flags), st))
             nc = int(words[2].item())
             check(L.subgacc_walk_tags(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q), n, 0, ptr(ctx["rng_pos"]),
-                                      ptr(ctx["rng_seed"]), ptr(cand), ptr(words[2:3]), max(nc, 1), ptr(table), cap, ptr(flags), st))
+                                      ptr(ctx["rng_seed"]), ptr(cand), ptr(words[2:3]), max(min(nc, n), 1), ptr(table), cap, ptr(flags), st))
             max_unique = min(cap, RANK_LIMIT)
             ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
             ws = torch.empty(L.subgacc_uniq_number_workspace_bytes(cap, 0), dtype=torch.uint8, device=dev)
@@ -634,18 +635,19 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
         count = status[2:3]
         total = None
         if batched:
-            cand = torch.empty(cn, dtype=torch.int32, device=dev)
+            ccap = L.subgacc_keyrows_cand_capacity(cn)
+            cand = torch.empty(ccap, dtype=torch.int32, device=dev)
             ncand = torch.zeros(1, dtype=torch.int64, device=dev)
             rp, rs = (ptr(rng_pos[lo:]), ptr(rng_seed[lo:])) if rng_pos is not None else (None, None)
             if numbered_early:      # one chunk: register -> exact tags for the candidates -> number (below) -> copy with SFptr+1
                 with _timed("register_rows"):
                     check(L.subgacc_keyrows_register(ptr(st_aux), ptr(nsize[lo:]), cn, stride, lo, ptr(table), uniq_capacity,
-                                                     ptr(cand), ptr(ncand), ptr(flags), st))
+                                                     ptr(cand), ccap, ptr(ncand), ptr(flags), st))
                     if lazy:
                         total, wcap = cn * stride, 0
                     else:           # the one host read of the chunk carries the candidate count along
                         total, wcap = (int(v) for v in torch.cat([off_chunk[cn:cn + 1], ncand]).tolist())
-                        wcap = max(wcap, 1)
+                        wcap = max(min(wcap, cn), 1)
                     check(L.subgacc_walk_tags(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn, lo, rp, rs,
                                               ptr(cand), ptr(ncand), wcap, ptr(table), uniq_capacity, ptr(flags), st))
         if strided and not numbered_early:
@@ -688,7 +690,7 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
                 check(L.subgacc_keyrows_compact(ptr(st_ids), ptr(st_aux), ptr(nsize[lo:]), ptr(off_chunk), cn, stride, lo, ptr(table),
                                                 uniq_capacity, ptr(ukeys) if numbered_early else None,
                                                 ptr(count) if numbered_early else None, max_unique if numbered_early else 0,
-                                                ptr(ids_c), ptr(slot_c), ptr(cand), ptr(ncand), ptr(flags), st))
+                                                ptr(ids_c), ptr(slot_c), ptr(cand), ccap, ptr(ncand), ptr(flags), st))
                 if not numbered_early:    # the pass registered this chunk's keys itself: now the candidates' exact tags
                     check(L.subgacc_walk_tags(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn, lo, rp, rs,
                                               ptr(cand), ptr(ncand), 0, ptr(table), uniq_capacity, ptr(flags), st))

@@ -191,7 +191,7 @@ class StridedSpG:
             uk = self.sets.ukeys
             check(lib().subgacc_keyrows_compact(ptr(self.indices), ptr(self.slot), ptr(self.nsize), ptr(row_off), n, self.stride, 0,
                                                 ptr(self.sets._ktable), self.sets._kcap, ptr(uk), ptr(self.sets._kcount), uk.numel(),
-                                                ptr(ids), ptr(data), None, None, ptr(flags), stream_ptr()))
+                                                ptr(ids), ptr(data), None, 0, None, ptr(flags), stream_ptr()))
         elif X:
             check(lib().subgacc_compact_rows(ptr(self.indices), ptr(self.slot), ptr(self.nsize), ptr(row_off), n, self.stride,
                                              ptr(ids), ptr(data), ptr(self.table), self.capacity, stream_ptr()))

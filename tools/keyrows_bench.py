@@ -31,7 +31,8 @@ def child(n):
     X = int(row_off[-1])
     cap = 1 << 20
     table = torch.empty(L.subgacc_uniq_table_bytes(cap), dtype=torch.uint8, device=dev)
-    cand = torch.empty(n, dtype=torch.int32, device=dev)
+    ccap = L.subgacc_keyrows_cand_capacity(n)
+    cand = torch.empty(ccap, dtype=torch.int32, device=dev)
     words = torch.zeros(4, dtype=torch.int64, device=dev)
     flags = words.view(torch.int32)[:4]
     out_i = torch.empty(X, dtype=torch.int32, device=dev)
@@ -48,20 +49,37 @@ def child(n):
         return a.elapsed_time(b) / reps
     def reg():
         check(L.subgacc_uniq_reset(ptr(table), cap, st)); words.zero_()
-        check(L.subgacc_keyrows_register(ptr(keys), ptr(nsize), n, stride, 0, ptr(table), cap, ptr(cand), ptr(words[2:3]), ptr(flags), st))
+        check(L.subgacc_keyrows_register(ptr(keys), ptr(nsize), n, stride, 0, ptr(table), cap, ptr(cand), ccap, ptr(words[2:3]), ptr(flags), st))
     t_reg = timed(reg)
     t_reset = timed(lambda: (check(L.subgacc_uniq_reset(ptr(table), cap, st)), words.zero_()))
     reg()
-    check(L.subgacc_uniq_number(ptr(table), cap, None, 0, ptr(ukeys), 16384, ptr(words[3:4]), 16384, ptr(ws), ws.numel(), st))
+    # (timing only: the numbering proper needs the candidates' exact tags -- subgacc_walk_tags -- or equal coarse tags collide in
+    #  out_ukeys; any numbering of the distinct keys fills the dictionary the same way)
+    valid = (torch.arange(stride, device=dev)[None, :] < nsize[:, None]).reshape(-1)
+    uk = torch.unique(keys.view(n, stride).reshape(-1)[valid].long() & 0xFFFFFFFF)
+    ukeys[: uk.numel()] = uk
+    words[3] = uk.numel()
+    del valid
     t_find = timed(lambda: check(L.subgacc_keyrows_compact(ptr(ids), ptr(keys), ptr(nsize), ptr(row_off), n, stride, 0, ptr(table), cap,
-                                                           ptr(ukeys), ptr(words[3:4]), 16384, ptr(out_i), ptr(out_d), None, None, ptr(flags), st)))
+                                                           ptr(ukeys), ptr(words[3:4]), 16384, ptr(out_i), ptr(out_d), None, 0, None, ptr(flags), st)))
     def regcopy():
         words[2:3].zero_()
         check(L.subgacc_keyrows_compact(ptr(ids), ptr(keys), ptr(nsize), ptr(row_off), n, stride, 0, ptr(table), cap,
-                                        None, None, 0, ptr(out_i), ptr(out_d), ptr(cand), ptr(words[2:3]), ptr(flags), st))
+                                        None, None, 0, ptr(out_i), ptr(out_d), ptr(cand), ccap, ptr(words[2:3]), ptr(flags), st))
     t_rc = timed(regcopy)
-    t_tr = timed(lambda: check(L.subgacc_keyrows_translate(ptr(out_d), X, None, ptr(table), cap, ptr(ukeys), ptr(words[3:4]), 16384, st)))
+    def translate():      # (in place: the payload must be keys again before every run)
+        out_d.copy_(keys_packed)
+        check(L.subgacc_keyrows_translate(ptr(out_d), X, None, ptr(table), cap, ptr(ukeys), ptr(words[3:4]), 16384, st))
+    regcopy()
+    keys_packed = out_d.clone()
+    t_tr = timed(translate) - timed(lambda: out_d.copy_(keys_packed))
     t_copy = timed(lambda: out_d.copy_(out_i))
+    import ctypes
+    if hasattr(L, "subgacc_debug_kr_misses"):
+        L.subgacc_debug_kr_misses.restype = ctypes.c_longlong
+        L.subgacc_debug_kr_misses()
+        translate(); torch.cuda.synchronize()
+        print("dictionary misses in one translate pass:", L.subgacc_debug_kr_misses(), "of", X, flush=True)
     print(f"rows {n} members {X} cand {int(words[2])} distinct {int(words[3])}: register {t_reg - t_reset:.3f} ms ({4 * X / (t_reg - t_reset) / 1e9:.2f} TB/s)  "
           f"find+copy {t_find:.3f} ms ({16 * X / t_find / 1e9:.2f} TB/s)  register+copy {t_rc:.3f} ms  translate {t_tr:.3f} ms ({8 * X / t_tr / 1e9:.2f} TB/s)  "
           f"[torch copy of {4 * X >> 20} MiB: {t_copy:.3f} ms = {8 * X / t_copy / 1e9:.2f} TB/s]", flush=True)
