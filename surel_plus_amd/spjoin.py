@@ -405,7 +405,7 @@ def _buffered_step(csr, e, bufs, seed, out):
                                             ptr(bufs.worklist), ptr(bufs.n_distinct), ptr(bufs.table), 0 if kr else bufs.capacity,
                                             ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize), ptr(flags), st))
         own, partner = bufs.own, bufs.partner
-    elif SORT_ROOTS and walk_kernel_name(csr, M, m, True) == "walk_rows_kernel":
+    elif SORT_ROOTS and n >= SORT_ROOTS_MIN and walk_kernel_name(csr, M, m, True) == "walk_rows_kernel":
         # the rows stay where the batch has them; the walk kernel takes them in ascending order of their root's id (a work list):
         # roots that are neighbours in id space -- the same community of a graph with id locality -- are walked at the same time on
         # the same XCD and share its L2
@@ -510,6 +510,7 @@ def sample_and_gather(csr, edge, num_walks=200, num_steps=3, seed=111413, rng="p
 # the buffered step walks its rows in ascending order of root id (csrc/worklist.hip: one radix pass, two small launches): cit2-like
 # step +5.7 % pairs/s, twitter-like +5.6 %, collab +1.8 %, ppa +2.1 %; "0": batch order (A/B).  Nothing observable changes.
 SORT_ROOTS = os.environ.get("SUBGACC_SORT_ROOTS", "1") == "1"
+SORT_ROOTS_MIN = 16384      # rows from which the two extra launches pay (a 1,024-pair step is 2,048 roots: one workgroup per resident slot)
 _ARANGE_SEGMENTS = {}
 _CACHE_LOCK = threading.Lock()     # the reference's pgather calls the join from 4 Python threads (train.py:88-99)
 

@@ -1,16 +1,23 @@
 #!/bin/bash
-# Dev-only: the end-of-round evidence on ONE box -- kernel-trace stats, PMC passes (separate runs), the full bench line.
-#   tools/final_profile.sh TAG      -> gpurun_out/TAG_*
+# Dev-only: the end-of-round evidence on ONE box -- kernel-trace stats, PMC passes (separate runs, never with a trace), the full
+# bench line.   tools/final_profile.sh TAG [workloads...]     -> gpurun_out/TAG_*   (copy what is to be judged into profiles/)
 set -x
-TAG=${1:-rXX}
+TAG=${1:-rXX}; shift
+WLS=${@:-cit2 collab ppa twitter cit2loc cit2ppr}
 R=$GRAFT_REPO_ROOT
+for W in $WLS; do
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_$W -- python3 $R/bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline --no-others > $R/gpurun_out/${TAG}_stats_$W.json 2>/dev/null
+  cd $R
+  cp $(find gpurun_out/${TAG}_stats_$W -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_${W}_kernel_stats.csv
+  if [ $W = cit2ppr ]; then export SUBGACC_PPR_EAGER=1; fi
+  bash tools/pmc_collect.sh gpurun_out/${TAG}_pmc_$W ${TAG}_$W --workload $W > gpurun_out/${TAG}_${W}_pmc_per_launch.csv 2>&1
+  unset SUBGACC_PPR_EAGER
+done
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_cit2 -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-others > $R/gpurun_out/${TAG}_stats_cit2.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_collab -- python3 $R/bench.py --workload collab --steps 5 --warmup 2 --no-cpu-baseline --no-others > $R/gpurun_out/${TAG}_stats_collab.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_offline -- python3 $R/tools/offline_run.py cit2 4 > $R/gpurun_out/${TAG}_offline_cit2.log 2>&1
 cd $R
-bash tools/pmc_collect.sh gpurun_out/${TAG}_pmc_cit2 ${TAG}_cit2 > gpurun_out/${TAG}_cit2_pmc_per_launch.csv 2>&1
-bash tools/pmc_collect.sh gpurun_out/${TAG}_pmc_collab ${TAG}_collab --workload collab > gpurun_out/${TAG}_collab_pmc_per_launch.csv 2>&1
+cp $(find gpurun_out/${TAG}_stats_offline -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_offline_cit2_kernel_stats.csv
 cp profiles/traffic.json gpurun_out/${TAG}_traffic.json
-( time python bench.py ) > gpurun_out/${TAG}_bench_cit2.json 2> gpurun_out/${TAG}_bench_cit2.err
+( time python bench.py --steps 20 --warmup 5 ) > gpurun_out/${TAG}_bench_cit2.json 2> gpurun_out/${TAG}_bench_cit2.err
 tail -c 1500 gpurun_out/${TAG}_bench_cit2.json; tail -5 gpurun_out/${TAG}_bench_cit2.err
-cat gpurun_out/${TAG}_cit2_pmc_per_launch.csv | tail -12
