@@ -162,12 +162,12 @@ def hot_path_step(sp, csr, edge, M, k, seed, rng, slot=0):
     # the library's on-demand entry point: sample both endpoints of every pair -> SpG rows -> join.  A serving loop
     # hands it preallocated StepBuffers (two sets in turn, like the output buffers): six launches per step, no allocation
     bufs = None
-    if LAZY and BUFFERED and rng == "philox" and strided is not False and FUSED is not False:
-        key = (edge.device, B, M, k, slot, DEDUP)
+    if LAZY and BUFFERED and strided is not False and FUSED is not False and not (DEDUP and rng != "philox"):
+        key = (edge.device, B, M, k, slot, DEDUP, rng)
         bufs = _STEP_BUFS.get(key)
         if bufs is None:
             try:
-                bufs = _STEP_BUFS[key] = sp.StepBuffers(csr, B, M, k - 1, uniq_capacity=UNIQ_CAPACITY, out=buf, dedup_roots=DEDUP)
+                bufs = _STEP_BUFS[key] = sp.StepBuffers(csr, B, M, k - 1, uniq_capacity=UNIQ_CAPACITY, out=buf, dedup_roots=DEDUP, rng=rng)
             except ValueError:
                 bufs = _STEP_BUFS[key] = False
     xz, ind, sets = sp.sample_and_gather(csr, edge, num_walks=M, num_steps=k - 1, seed=seed, rng=rng, out=buf if LAZY else None,

@@ -457,6 +457,15 @@ int subgacc_keyrows_compact(const int32_t *row_ids, const int32_t *row_keys, con
 int subgacc_keyrows_translate(int32_t *data_inout, int64_t n, const int64_t *n_dev, void *uniq_table, int64_t uniq_capacity,
                               const uint64_t *ukeys, const int64_t *n_ukeys, int64_t max_ukeys, void *stream);
 
+/* ABI 4: subgacc_walk_spg over ALL n rows but in the order of a work list (worklist[0 .. *n_work) names every row once:
+ * subgacc_worklist_by_root) -- either RNG mode: row i keeps its place in the batch AND in the rand_r stream (rng_pos[i] /
+ * rng_seed[i] from subgacc_rng_positions over the n roots in batch order; NULL for Philox), only the order in which the kernel
+ * takes the rows changes.  Shapes as for subgacc_walk_spg_sparse; tags of the table of distinct rows start at 0. */
+int subgacc_walk_spg_list(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,
+                          const int32_t *query, int64_t n, const uint32_t *rng_pos, const uint32_t *rng_seed,
+                          const int32_t *worklist, const int64_t *n_work, void *uniq_table, int64_t uniq_capacity,
+                          int32_t *row_ids, int32_t *row_slot, int32_t *nsize, int32_t *flags, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * batch_sampler of the legacy SUREL surface (subg_acc/subg_acc.c:391-507): one insertion-ordered set of nodes grown by
  * walking the roots one after the other (num_walks walks of num_steps nodes each, first hop without replacement,
@@ -476,7 +485,8 @@ int subgacc_batch_sampler(const void *indptr, int32_t indptr64, const int32_t *i
                           size_t workspace_bytes, int32_t *flags, void *stream);
 
 /* ABI 4: the rows 0 .. n-1 of a batch as a work list in ascending order of their root's id (1,024 buckets of consecutive
- * ids, any order inside a bucket; *n_work = n) -- what subgacc_walk_spg_sparse then runs over: roots that are neighbours in id
+ * ids, any order inside a bucket; rows whose root is SUBGACC_NO_ROOT -- the repeated endpoints subgacc_step_prologue_dedup
+ * marks -- are left out; *n_work = the rows listed) -- what subgacc_walk_spg_sparse / _list then runs over: roots that are neighbours in id
  * space (the same community of a graph with id locality) or equal (repeated endpoints) are walked at the same time on the
  * same XCD and share its L2.  The rows stay where they are; only the order of the walk changes, so no result does.  Two small
  * launches; workspace = subgacc_worklist_workspace_bytes(n) bytes. */

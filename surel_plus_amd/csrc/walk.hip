@@ -835,6 +835,17 @@ extern "C" int subgacc_walk_spg_sparse(const subgacc_walk_cfg *cfg, const void *
                        uniq_capacity, 0, nsize, nullptr, flags, stream, true, worklist, n_work);
 }
 
+extern "C" int subgacc_walk_spg_list(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,
+                                     const int32_t *query, int64_t n, const uint32_t *rng_pos, const uint32_t *rng_seed,
+                                     const int32_t *worklist, const int64_t *n_work, void *uniq_table, int64_t uniq_capacity,
+                                     int32_t *row_ids, int32_t *row_slot, int32_t *nsize, int32_t *flags, void *stream) {
+    SG_REQUIRE(row_slot && worklist && n_work, SUBGACC_ERR_BADARG, "walk_spg_list: null row_slot / work list / length");
+    SG_REQUIRE(cfg && !cfg->emit_walks && cfg->order == SUBGACC_ORDER_WALK_MAJOR, SUBGACC_ERR_BADARG,
+               "walk_spg_list: set_sampler order only, no raw walks");
+    return launch_walk(cfg, indptr, indices, num_nodes, query, n, rng_pos, rng_seed, row_ids, nullptr, row_slot, uniq_table,
+                       uniq_capacity, 0, nsize, nullptr, flags, stream, true, worklist, n_work);
+}
+
 extern "C" int subgacc_walk_tags(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,
                                  const int32_t *query, int64_t n, int64_t root_base, const uint32_t *rng_pos, const uint32_t *rng_seed,
                                  const int32_t *worklist, const int64_t *n_work, int64_t work_cap, void *uniq_table,

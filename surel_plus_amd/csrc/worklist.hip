@@ -34,7 +34,10 @@ __global__ __launch_bounds__(kWlThreads) void worklist_hist_kernel(const int32_t
 #pragma unroll
     for (int k = 0; k < kWlItems; ++k) {
         const int64_t i = base + (int64_t)k * kWlThreads + threadIdx.x;
-        if (i < n) atomicAdd(&h[wl_bucket(roots[i], shift)], 1);
+        if (i < n) {
+            const int32_t r = roots[i];
+            if (r != SUBGACC_NO_ROOT) atomicAdd(&h[wl_bucket(r, shift)], 1);      // a repeated endpoint's empty row is not listed
+        }
     }
     __syncthreads();
     for (int b = threadIdx.x; b < kWlBuckets; b += kWlThreads) hist[(int64_t)b * nblk + blockIdx.x] = h[b];
@@ -66,13 +69,16 @@ __global__ __launch_bounds__(kWlThreads) void worklist_scatter_kernel(const int3
         cur[threadIdx.x * PER + k] = run + before[k];      // where this block's rows of the bucket begin
         run += tot[k];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *n_work = n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_work = all;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * kWlTile;
 #pragma unroll
     for (int k = 0; k < kWlItems; ++k) {
         const int64_t i = base + (int64_t)k * kWlThreads + threadIdx.x;
-        if (i < n) worklist[atomicAdd(&cur[wl_bucket(roots[i], shift)], 1)] = (int32_t)i;
+        if (i < n) {
+            const int32_t r = roots[i];
+            if (r != SUBGACC_NO_ROOT) worklist[atomicAdd(&cur[wl_bucket(r, shift)], 1)] = (int32_t)i;
+        }
     }
 }
 

@@ -337,7 +337,7 @@ class StepBuffers:
     rows of the first occurrences (sets.n_distinct of them; bufs.roots == NO_ROOT elsewhere), the other rows are empty.
     The hash is stamped with a per-step generation kept on the device: a captured step replays correctly."""
 
-    def __init__(self, csr, pairs, num_walks=200, num_steps=3, uniq_capacity=1 << 17, out=None, dedup_roots=False):
+    def __init__(self, csr, pairs, num_walks=200, num_steps=3, uniq_capacity=1 << 17, out=None, dedup_roots=False, rng="philox"):
         from .sampler import FUSED_MAX_Q
         L, dev = lib(), csr.device
         self.B, self.M, self.m = int(pairs), int(num_walks), int(num_steps)
@@ -355,6 +355,13 @@ class StepBuffers:
         self.tail = torch.zeros(n + 1 + 4 + 1, dtype=torch.int64, device=dev)  # seg [n+1] | status [4] | distinct roots [1]
         self.seg, self.status, self.n_distinct = self.tail[: n + 1], self.tail[n + 1: n + 5], self.tail[n + 5:]
         self.dedup = bool(dedup_roots)
+        self.rng = rng
+        if rng not in ("philox", "rand_r") or (rng == "rand_r" and self.dedup):
+            raise ValueError("StepBuffers: rng is 'philox' or 'rand_r'; root dedup needs 'philox' (a rand_r set depends on its place in the stream)")
+        if rng == "rand_r":      # the rows' places in the reference's sequential stream (subgacc_rng_positions), per step
+            self.rng_pos = torch.empty(n, dtype=torch.int32, device=dev)
+            self.rng_seed = torch.empty(n, dtype=torch.int32, device=dev)
+            self.rng_ws = torch.empty(L.subgacc_rng_positions_workspace_bytes(n), dtype=torch.uint8, device=dev)
         if self.dedup:
             from .sampler import walk_kernel_name
             if walk_kernel_name(csr, self.M, self.m, True) != "walk_rows_kernel":
@@ -381,6 +388,17 @@ def _dedup_tick(bufs):
         bufs.dedup_steps = 0
 
 
+def _sorted_list(bufs, csr, n, L, st):
+    """the rows of the step as a work list in ascending order of root id (csrc/worklist.hip); its buffers are made on first use"""
+    if not hasattr(bufs, "sorted_list"):
+        dev = csr.device
+        bufs.sorted_list = torch.empty(n, dtype=torch.int32, device=dev)
+        bufs.n_all = torch.zeros(1, dtype=torch.int64, device=dev)
+        bufs.sort_ws = torch.empty(L.subgacc_worklist_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    check(L.subgacc_worklist_by_root(ptr(bufs.roots), n, csr.num_nodes, ptr(bufs.sorted_list), ptr(bufs.n_all), ptr(bufs.sort_ws),
+                                     bufs.sort_ws.numel(), st))
+
+
 def _buffered_step(csr, e, bufs, seed, out):
     """sample_and_gather through a StepBuffers: six launches, nothing allocated, nothing read back"""
     from .sampler import SampledSets, _timed, make_cfg, walk_kernel_name
@@ -390,7 +408,9 @@ def _buffered_step(csr, e, bufs, seed, out):
         raise ValueError(f"these StepBuffers were made for [2, {B}] pairs")
     e = e.contiguous()
     flags = bufs.status.view(torch.int32)[:4]
-    cfg = make_cfg(csr, M, m, -1, seed, "philox", records=(2 <= m <= 4))     # (only the fused-row kernel of 2..4 hops reads hop records)
+    cfg = make_cfg(csr, M, m, -1, seed, bufs.rng, records=(2 <= m <= 4))     # (only the fused-row kernel of 2..4 hops reads hop records)
+    rr = bufs.rng == "rand_r"
+    rp, rs = (ptr(bufs.rng_pos), ptr(bufs.rng_seed)) if rr else (None, None)
     check(L.subgacc_key_shift(cfg.num_walks, cfg.num_steps))
     kr = bufs.keyrows
     bufs.step_id = step_id = getattr(bufs, "step_id", 0) + 1
@@ -400,6 +420,8 @@ def _buffered_step(csr, e, bufs, seed, out):
         check(L.subgacc_step_prologue_dedup(ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.status), 4, ptr(e), ptr(bufs.roots),
                                             ptr(bufs.own), ptr(bufs.partner), ptr(bufs.worklist), ptr(bufs.nsize), n,
                                             ptr(bufs.dedup_ws), bufs.dedup_ws.numel(), ptr(bufs.n_distinct), st))
+        # (no sorted list here: what the order buys is mostly repeated endpoints standing next to each other, and those are gone --
+        # measured, cit2 walk kernel 0.647 ms either way, and the sort costs its 25 us)
         with _timed("walk_sets"):
             check(L.subgacc_walk_spg_sparse(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n,
                                             ptr(bufs.worklist), ptr(bufs.n_distinct), ptr(bufs.table), 0 if kr else bufs.capacity,
@@ -410,21 +432,22 @@ def _buffered_step(csr, e, bufs, seed, out):
         # roots that are neighbours in id space -- the same community of a graph with id locality -- are walked at the same time on
         # the same XCD and share its L2
         check(L.subgacc_step_prologue(ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.status), 4, ptr(e), ptr(bufs.roots), n, st))
-        if not hasattr(bufs, "sorted_list"):
-            bufs.sorted_list = torch.empty(n, dtype=torch.int32, device=dev)
-            bufs.n_all = torch.zeros(1, dtype=torch.int64, device=dev)
-            bufs.sort_ws = torch.empty(L.subgacc_worklist_workspace_bytes(n), dtype=torch.uint8, device=dev)
-        check(L.subgacc_worklist_by_root(ptr(bufs.roots), n, csr.num_nodes, ptr(bufs.sorted_list), ptr(bufs.n_all), ptr(bufs.sort_ws),
-                                         bufs.sort_ws.numel(), st))
+        _sorted_list(bufs, csr, n, L, st)
+        if rr:
+            check(L.subgacc_rng_positions(cfg, ptr(csr.indptr), csr.num_nodes, ptr(bufs.roots), n, 1, 0, ptr(bufs.rng_pos),
+                                          ptr(bufs.rng_seed), ptr(bufs.rng_ws), bufs.rng_ws.numel(), st))
         with _timed("walk_sets"):
-            check(L.subgacc_walk_spg_sparse(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n,
-                                            ptr(bufs.sorted_list), ptr(bufs.n_all), ptr(bufs.table), 0 if kr else bufs.capacity,
-                                            ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize), ptr(flags), st))
+            check(L.subgacc_walk_spg_list(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n, rp, rs,
+                                          ptr(bufs.sorted_list), ptr(bufs.n_all), ptr(bufs.table), 0 if kr else bufs.capacity,
+                                          ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize), ptr(flags), st))
         own, partner = _arange_segments(B, dev)
     else:
         check(L.subgacc_step_prologue(ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.status), 4, ptr(e), ptr(bufs.roots), n, st))
+        if rr:
+            check(L.subgacc_rng_positions(cfg, ptr(csr.indptr), csr.num_nodes, ptr(bufs.roots), n, 1, 0, ptr(bufs.rng_pos),
+                                          ptr(bufs.rng_seed), ptr(bufs.rng_ws), bufs.rng_ws.numel(), st))
         with _timed("walk_sets"):
-            check(L.subgacc_walk_spg(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n, 0, None, None,
+            check(L.subgacc_walk_spg(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n, 0, rp, rs,
                                      ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize),
                                      ptr(flags), st))
         own, partner = _arange_segments(B, dev)
@@ -454,7 +477,8 @@ def _buffered_step(csr, e, bufs, seed, out):
         # empty, and a repeated endpoint never is the first to show an LP row, so the numbering is the one of the whole batch);
         # once the buffers have taken a later batch -- or a captured step has been replayed -- the answer would describe that
         # batch, so it is refused (stamp of the step that made these sets against the buffers' current one)
-        sets._keyctx = {"csr": csr, "roots": bufs.roots, "cfg": cfg, "rng_pos": None, "rng_seed": None, "capacity": bufs.capacity,
+        sets._keyctx = {"csr": csr, "roots": bufs.roots, "cfg": cfg, "rng_pos": bufs.rng_pos if rr else None,
+                        "rng_seed": bufs.rng_seed if rr else None, "capacity": bufs.capacity,
                         "fresh": lambda: getattr(bufs, "step_id", 0) == step_id}
     sets.status, sets._tail = bufs.status, bufs.tail[n: n + (6 if bufs.dedup else 5)]
     return xz, bufs.seg, sets
@@ -476,10 +500,10 @@ def sample_and_gather(csr, edge, num_walks=200, num_steps=3, seed=111413, rng="p
     e = _as_rows(edge, csr.device)
     B = e.shape[1]
     if buffers is not None:     # the allocation-free form of a serving loop: same rows, same (xz, indptr), lazily resolved
-        if (dedup_roots and not buffers.dedup) or rng != "philox" or strided is False or kw.get("fused") is False or \
+        if (dedup_roots and not buffers.dedup) or rng != buffers.rng or strided is False or kw.get("fused") is False or \
                 kw.get("bucket", -1) > 0 or (num_walks, num_steps) != (buffers.M, buffers.m) or \
                 kw.get("uniq_capacity", buffers.capacity) != buffers.capacity:
-            raise ValueError("buffers= serves the on-demand step (rng='philox', fused strided rows; root dedup if the StepBuffers "
+            raise ValueError("buffers= serves the on-demand step (the StepBuffers' rng, fused strided rows; root dedup if the StepBuffers "
                              "were made with dedup_roots=True) of the shape the StepBuffers were made for")
         return _buffered_step(csr, e, buffers, seed, out)
     if dedup_roots:

@@ -1624,3 +1624,53 @@ def test_sets_with_id_locality_sort_like_any_other(sp, M, hops):
             z = z.to_csr()
         assert np.array_equal(z.indptr.cpu().numpy(), oi) and np.array_equal(z.indices[: z.nnz].cpu().numpy(), ox), kw
         assert np.array_equal(z.data[: z.nnz].cpu().numpy(), od) and np.array_equal(sets.enc_int16().cpu().numpy(), oenc), kw
+
+
+@pytest.mark.parametrize("B,M,hops", [(9000, 200, 3), (300, 200, 2)])
+def test_buffered_step_in_rand_r_mode_is_the_reference_stream(sp, B, M, hops):
+    """StepBuffers(rng='rand_r'): the allocation-free step in the reference's own RNG mode -- the rows' places in the sequential
+    stream come from subgacc_rng_positions per step, the walk takes them in order of root id (B >= 8,192: the sorted work
+    list) or in batch order -- bit for bit the allocating step and the oracle's sequential sampler + join."""
+    from surel_plus_amd.graphs import query_pairs
+    ptr_, idx = sym_graph(20000, 120000, seed=13, hubs=3)
+    csr = sp.DeviceCSR(ptr_, idx)
+    bufs = sp.StepBuffers(csr, B, num_walks=M, num_steps=hops, rng="rand_r")
+    for s_ in (1, 2):
+        e = query_pairs(csr, B, seed=s_)
+        xz, ind, sets = sp.sample_and_gather(csr, e, num_walks=M, num_steps=hops, seed=9, rng="rand_r", buffers=bufs)
+        sets.prefetch().resolve()
+        R = int(ind[-1].item())
+        wxz, wind, _ = sp.sample_and_gather(csr, e, num_walks=M, num_steps=hops, seed=9, rng="rand_r")
+        assert torch.equal(ind, wind) and torch.equal(xz[:R], wxz)
+    roots = e.reshape(-1).cpu().numpy()
+    (oi, ox, od), oenc = _oracle_spg(ptr_, idx, roots, M, hops, 9, "rand_r", -1)
+    table = oracle.enc_table(oenc).astype(np.float32) / np.float32(M)
+    oxz, oind = oracle.gather(np.arange(2 * B, dtype=np.int64).reshape(2, B), (oi, ox, od), ptr=True, encode=table)
+    assert np.array_equal(ind.cpu().numpy(), oind) and np.array_equal(xz[:R].cpu().numpy(), oxz)
+    assert np.array_equal(sets.enc_int16().cpu().numpy(), oenc)
+
+
+@pytest.mark.parametrize("n,num_nodes", [(1, 5), (4097, 1000), (70000, 3_000_000), (20000, 1024)])
+def test_worklist_by_root_lists_every_live_row_once_in_bucket_order(sp, n, num_nodes):
+    """subgacc_worklist_by_root: a permutation of the rows whose root is not SUBGACC_NO_ROOT, ascending in (root >> shift) with
+    1,024 buckets over [0, num_nodes); *n_work = the rows listed.  Checked through the C-ABI on its own."""
+    from surel_plus_amd._lib import lib, check, ptr
+    L = lib()
+    g = np.random.default_rng(n)
+    roots = g.integers(0, num_nodes, n).astype(np.int32)
+    dead = g.random(n) < 0.2 if n > 1 else np.zeros(1, bool)
+    roots[dead] = -2147483648
+    r = torch.from_numpy(roots).cuda()
+    wl = torch.full((n,), -7, dtype=torch.int32, device="cuda")
+    nw = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ws = torch.empty(L.subgacc_worklist_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+    check(L.subgacc_worklist_by_root(ptr(r), n, num_nodes, ptr(wl), ptr(nw), ptr(ws), ws.numel(), None))
+    torch.cuda.synchronize()
+    k = int(nw.item())
+    assert k == int((~dead).sum())
+    got = wl[:k].cpu().numpy()
+    assert np.array_equal(np.sort(got), np.flatnonzero(~dead)) and (wl[k:] == -7).all()
+    shift = 0
+    while ((num_nodes - 1) >> shift) >= 1024:
+        shift += 1
+    assert (np.diff(roots[got] >> shift) >= 0).all()
