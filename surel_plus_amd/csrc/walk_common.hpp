@@ -38,9 +38,9 @@ __device__ __forceinline__ uint32_t rand_r_next(uint32_t &x) {
 __device__ __forceinline__ void philox2x32_10(uint32_t c0, uint32_t c1, uint32_t k, uint32_t &o0, uint32_t &o1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi = __umulhi(0xD256D193u, c0), lo = 0xD256D193u * c0;
-        c0 = hi ^ k ^ c1;
-        c1 = lo;
+        const unsigned long long p = (unsigned long long)0xD256D193u * c0;      // ONE v_mad_u64_u32: it issues like a single 32-bit multiply
+        c0 = (uint32_t)(p >> 32) ^ k ^ c1;
+        c1 = (uint32_t)p;
         k += 0x9E3779B9u;
     }
     o0 = c0, o1 = c1;

@@ -22,6 +22,11 @@
 
 namespace subgacc {
 
+// The value of a load that the program then only uses under a condition: without this the optimizer moves the LOAD under that
+// condition too, and a load under a branch is waited for where it stands (see the walk section).  An empty asm that "uses" the
+// register keeps the load unconditional; it costs nothing but is a point where the value must have arrived.
+#define SG_KEEP_LOAD(v) asm volatile("" : "+v"(v))
+
 #ifndef SG_LAST_HOP_ID     // 1: with hop records, the last hop reads the bare id from `indices` (A/B: tools/ab.py)
 #define SG_LAST_HOP_ID 1
 #endif
@@ -114,6 +119,8 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     }
     int64_t rbeg, rdeg64;
     load_row<IDX64>(a.indptr, root, rbeg, rdeg64);
+    // the last entry of the adjacency array (uniform: a scalar load): what a dead end's dropped load is clamped to, below
+    const int64_t last = (IDX64 ? ((const int64_t *)a.indptr)[a.num_nodes] : (int64_t)((const int32_t *)a.indptr)[a.num_nodes]) - 1;
     {   // keys, with the root already in its slot as member 0 (its minq = 0 is stored after the barrier-free clear above:
         // same lane order is not guaranteed across waves, so the root's lane writes BOTH of its words here)
         const uint32_t hroot = ((uint32_t)root * 2654435761u) >> TSHIFT;
@@ -161,21 +168,115 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     // rand_r: the stream state at the root's first draw, once per workgroup (uniform operands: a scalar loop of up to 32
     // rounds); a lane then jumps the few hundred steps to its own walk (<= 12 rounds) instead of all ~2^28 of them
     const uint32_t xroot = RNG == SUBGACC_RNG_RAND_R ? lcg_jump(rseed, rpos) : 0u;
-    if (shuffled) {  // partial Fisher-Yates draws s_k = draw % (deg-k) + k  (subg_acc.c:769-775), one lane per k
+    uint32_t pickv[WPL];             // the first hop of this lane's walks: an index into the root's row
+    if (shuffled) {
+        // First hop without replacement (subg_acc.c:769-775): M sequential swaps a[k] <-> a[s_k], s_k = k + draw % (deg - k), over
+        // the identity; walk w takes a[w].  Followed backwards, a[w] is found by: p = s_w; then, repeatedly, the LARGEST j below
+        // the point reached so far with s_j == p, p = j.  Doing that by scanning j = w-1 .. 0 costs M^2/2 LDS reads per root (the
+        // roots that need it are the hubs, 4 % of a collab batch: 11 % of that kernel's vector instructions).  Here instead: the
+        // draws are grouped by target in a scratch hash over the still empty count table (key = target, value = the largest
+        // member), and the groups are peeled from the top -- round r finds every group's r-th largest member and tells it to the
+        // (r-1)-th as its predecessor; groups have one to a handful of members.  Then pred[w] is the first step of the chain and
+        // every later step is "the largest member of the group of target j" = what round 0 found, kept in L[j] (j < M).
+        constexpr int HS = (int)(T * sizeof(CntT) / 8);                  // hash slots: >= 256 >= M
+        constexpr int HSHIFT = HS == 256 ? 24 : (HS == 512 ? 23 : (HS == 1024 ? 22 : 21));
+        static_assert(HS == 256 || HS == 512 || HS == 1024 || HS == 2048, "scratch hash over the count table");
+        uint32_t *HK = (uint32_t *)pk, *HV = HK + HS;                    // target + 1 (0 = empty) | largest bidder + 1
+        int32_t *L = sarr;                                               // [M] largest j with s_j == position, -1 = none
+        uint32_t tj[WPL];
+        int hs[WPL], stt[WPL], prd[WPL];                                 // stt: 0 bidding, 1 top of its group (waits for its predecessor), 2 done
 #pragma unroll
         for (int kk = 0; kk < WPL; ++kk) {
             const int k = tid + kk * NT;
+            stt[kk] = k < M ? 0 : 2;
+            prd[kk] = -1;
+            hs[kk] = 0;
+            tj[kk] = 0u;
             if (k >= M) continue;
             uint32_t r;
             if (RNG == SUBGACC_RNG_RAND_R) {
                 uint32_t x = lcg_jump(xroot, 3u * (uint32_t)k);      // a jump of < 2^10 steps from the root's state
                 r = rand_r_next(x);
-                sarr[k] = (int32_t)(r % (rdeg - (uint32_t)k)) + k;
+                tj[kk] = r % (rdeg - (uint32_t)k) + (uint32_t)k;
             } else {
                 uint32_t o1;
                 philox2x32_10((uint32_t)root, (uint32_t)k | kPhiloxShuffle, a.seed, r, o1);
-                sarr[k] = (int32_t)philox_below(r, rdeg - (uint32_t)k) + k;
+                tj[kk] = philox_below(r, rdeg - (uint32_t)k) + (uint32_t)k;
             }
+            L[k] = -1;
+        }
+        __syncthreads();            // the count table is clear
+#pragma unroll
+        for (int kk = 0; kk < WPL; ++kk) {
+            if (stt[kk] == 2) continue;
+            uint32_t h = (tj[kk] * 2654435761u) >> HSHIFT;
+            while (true) {
+                const uint32_t old = atomicCAS(&HK[h], 0u, tj[kk] + 1u);
+                if (old == 0u || old == tj[kk] + 1u) break;
+                h = (h + 1u) & (uint32_t)(HS - 1);
+            }
+            hs[kk] = (int)h;
+        }
+        for (int round = 0;; ++round) {
+#pragma unroll
+            for (int kk = 0; kk < WPL; ++kk)
+                if (stt[kk] == 1) HV[hs[kk]] = 0u;
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < WPL; ++kk)
+                if (stt[kk] == 0) atomicMax(&HV[hs[kk]], (uint32_t)(tid + kk * NT) + 1u);
+            __syncthreads();
+            int more = 0;
+#pragma unroll
+            for (int kk = 0; kk < WPL; ++kk) {
+                if (stt[kk] == 2) continue;
+                const uint32_t v = HV[hs[kk]];
+                if (stt[kk] == 1) {
+                    prd[kk] = (int)v - 1;
+                    stt[kk] = 2;
+                } else {
+                    more = 1;
+                    if (v == (uint32_t)(tid + kk * NT) + 1u) {
+                        stt[kk] = 1;
+                        if (round == 0 && tj[kk] < (uint32_t)M) L[tj[kk]] = tid + kk * NT;
+                    }
+                }
+            }
+            if (!__syncthreads_or(more)) break;
+        }
+#pragma unroll
+        for (int kk = 0; kk < WPL; ++kk) {
+            int32_t j = prd[kk];
+            pickv[kk] = tj[kk];
+            if (j >= 0) {
+                for (int32_t nx = L[j]; nx >= 0; nx = L[j]) j = nx;
+                pickv[kk] = (uint32_t)j;
+            }
+        }
+        __syncthreads();
+        // the scratch hash goes back to being an empty count table (the same lanes on the same words as the clear above)
+        if (SPL % 4 == 0) {
+#pragma unroll
+            for (int c = 0; c < SPL / 4; ++c) {
+                const int g = c * NT + tid;
+                if (K32) {
+                    ((uint4 *)pk)[g] = make_uint4(0u, 0u, 0u, 0u);
+                } else {
+                    ((uint4 *)pk)[2 * g] = make_uint4(0u, 0u, 0u, 0u);
+                    ((uint4 *)pk)[2 * g + 1] = make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
+        } else {
+            ((uint4 *)pk)[tid] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    } else {
+        // w % deg for w < 256 and deg <= M <= 256 without a division per walk: with inv = ceil(2^16 / deg), floor(w * inv / 2^16) is the
+        // exact quotient (the error term w * (deg * inv - 2^16) stays below 2^16)
+        const uint32_t inv = 65535u / rdeg + 1u;
+#pragma unroll
+        for (int kk = 0; kk < WPL; ++kk) {
+            const uint32_t w = (uint32_t)(tid + kk * NT);
+            pickv[kk] = w - ((w * inv) >> 16) * rdeg;
         }
     }
     __syncthreads();
@@ -184,6 +285,12 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     // ------------------------------------------------------------------ the walk: WPL walks per lane, straight-line,
     // the walks of a lane interleaved hop by hop (their loads are independent and in flight together)
     {
+        // No load of this section stands under a branch.  A lane's walks beyond M (M = 200 on 64 lanes x 4: the fourth walk of 56
+        // lanes) are not skipped but walk root -> its first neighbour -> that node's first neighbour: the same address in every
+        // such lane, one request.  Only their VISITS are masked.  With `if (!walk) continue` around the loads, the compiler brought
+        // each load back through a select that waited for it on the spot (vmcnt is an in-order counter): the row and neighbour
+        // loads of a lane's four walks went out one after the other, nine dependent round trips per wavefront instead of three,
+        // and the 2-hop kernel was bound by that latency at 8 wavefronts per SIMD, not by its instructions.
         bool wk[WPL];
         int32_t cur[WPL];
         unsigned long long rec[WPL], rec2[WPL];         // REC: the record of the node the walk stands on (rec2: its row begin, 16-byte form)
@@ -196,16 +303,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
             cur[k] = root;
             rec[k] = rec2[k] = 0ull;
             x[k] = 0;
-            if (!wk[k]) continue;
-            uint32_t pick;
-            if (shuffled) {   // value the sequential swaps leave at position w: follow the chain of earlier draws
-                int32_t p = sarr[w];
-                for (int j = w - 1; j >= 0; --j)
-                    if (sarr[j] == p) p = j;
-                pick = (uint32_t)p;
-            } else {
-                pick = (uint32_t)w % rdeg;
-            }
+            const uint32_t pick = wk[k] ? pickv[k] : 0u;
             if (REC == 16) {
                 const ulonglong2 r2 = ((const ulonglong2 *)a.recs)[rbeg + pick];
                 rec[k] = r2.x, rec2[k] = r2.y;
@@ -217,23 +315,36 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
         }
 #pragma unroll
         for (int k = 0; k < WPL; ++k) {
-            if (!wk[k]) continue;
             const int w = tid + k * NT;
             if (RNG == SUBGACC_RNG_PHILOX) {
 #pragma unroll
-                for (int b = 0; 2 * b < MH - 1; ++b)
+                for (int b = 0; 2 * b < MH - 1; ++b) {
                     philox2x32_10((uint32_t)root, (uint32_t)w | ((uint32_t)b << kPhiloxBlockShift), a.seed, dr[k][2 * b], dr[k][2 * b + 1]);
+                    if (!wk[k]) dr[k][2 * b] = dr[k][2 * b + 1] = 0u;      // (a draw of 0 picks a row's first entry)
+                }
             } else {
                 x[k] = lcg_jump(xroot, 3u * ((shuffled ? (uint32_t)M : 0u) + (uint32_t)w * (uint32_t)(MH - 1)));
             }
         }
+        // offset of the next hop inside a row of dk entries.  dk == 0 is a dead end, the walk stays: offset 0, and the load that
+        // follows is made all the same and dropped -- its index is clamped to the array's last entry (a trailing empty row begins
+        // at nnz) rather than selected, because a select on `live` in front of the load is turned back into a branch around it
+        auto next_off = [&](int k, int s, uint32_t dk, bool live) -> uint32_t {
+            if (RNG == SUBGACC_RNG_RAND_R) {
+                uint32_t xn = x[k];
+                const uint32_t r = rand_r_next(xn);
+                if (live) x[k] = xn;
+                if (!live && wk[k]) atomicOr(&a.flags[0], 1);      // dead end: the sequential stream is no longer reproducible
+                return wk[k] ? r % (live ? dk : 1u) : 0u;
+            }
+            return philox_below(dr[k][s], dk);
+        };
 #pragma unroll
         for (int s = 0; s < MH; ++s) {
             int64_t b[WPL], d[WPL];
 #pragma unroll
             for (int k = 0; k < WPL; ++k) {
                 b[k] = d[k] = 0;
-                if (!wk[k]) continue;
                 if (REC) {      // the record carries the node AND its row: the next record is asked for before the visit
                     bool esc = false;
                     if (SG_LAST_HOP_ID && s + 1 == MH && MH > 1) {
@@ -246,25 +357,25 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
                         rec_unpack(rec[k], a.rec, cur[k], b[k], d[k], esc);
                     }
                     if (s + 1 < MH) {
-                        if (esc) load_row<IDX64>(a.indptr, cur[k], b[k], d[k]);
-                        if (d[k] > 0) {
-                            uint32_t off;
-                            if (RNG == SUBGACC_RNG_RAND_R) off = rand_r_next(x[k]) % (uint32_t)d[k];
-                            else off = philox_below(dr[k][s], (uint32_t)d[k]);
-                            if (SG_LAST_HOP_ID && s + 2 == MH) {
-                                // the walk ends on this node: its row is never needed, so the 4-byte id from the plain
-                                // adjacency array will do -- half the bytes per entry, twice the entries of a hub's row
-                                // per line for the walkers that share it
-                                rec[k] = (unsigned long long)(uint32_t)SG_NEIGH_LOAD(&a.indices[b[k] + (int64_t)off]);
-                            } else if (REC == 16) {
-                                const ulonglong2 r2 = ((const ulonglong2 *)a.recs)[b[k] + (int64_t)off];
-                                rec[k] = r2.x, rec2[k] = r2.y;
-                            } else {
-                                rec[k] = a.recs[b[k] + (int64_t)off];
-                            }
-                        } else {        // dead end: the walk stays on this node
-                            if (SG_LAST_HOP_ID && s + 2 == MH) rec[k] = (unsigned long long)(uint32_t)cur[k];   // (bare-id form)
-                            if (RNG == SUBGACC_RNG_RAND_R) atomicOr(&a.flags[0], 1);
+                        if (esc) load_row<IDX64>(a.indptr, cur[k], b[k], d[k]);       // (a row too long for the record: rare)
+                        const bool live = d[k] > 0;
+                        const int64_t at = min(b[k] + (int64_t)next_off(k, s, (uint32_t)d[k], live), last);
+                        if (SG_LAST_HOP_ID && s + 2 == MH) {
+                            // the walk ends on this node: its row is never needed, so the 4-byte id from the plain
+                            // adjacency array will do -- half the bytes per entry, twice the entries of a hub's row
+                            // per line for the walkers that share it
+                            uint32_t v = (uint32_t)SG_NEIGH_LOAD(&a.indices[at]);
+                            SG_KEEP_LOAD(v);
+                            rec[k] = (unsigned long long)(live ? v : (uint32_t)cur[k]);     // dead end: the walk stays on this node
+                        } else if (REC == 16) {
+                            ulonglong2 r2 = ((const ulonglong2 *)a.recs)[at];
+                            SG_KEEP_LOAD(r2.x);
+                            SG_KEEP_LOAD(r2.y);
+                            rec[k] = live ? r2.x : rec[k], rec2[k] = live ? r2.y : rec2[k];
+                        } else {
+                            unsigned long long r1 = a.recs[at];
+                            SG_KEEP_LOAD(r1);
+                            rec[k] = live ? r1 : rec[k];
                         }
                     }
                 } else if (s + 1 < MH) {
@@ -285,17 +396,16 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
                 atomicAdd(&pk[h], (CntT)1 << ((MH - 1 - s) * a.shift));
             }
             if (!REC && s + 1 < MH) {
+                int32_t nv[WPL];
 #pragma unroll
                 for (int k = 0; k < WPL; ++k) {
-                    if (!wk[k]) continue;
-                    if (d[k] > 0) {
-                        uint32_t off;
-                        if (RNG == SUBGACC_RNG_RAND_R) off = rand_r_next(x[k]) % (uint32_t)d[k];
-                        else off = philox_below(dr[k][s], (uint32_t)d[k]);
-                        cur[k] = SG_NEIGH_LOAD(&a.indices[b[k] + (int64_t)off]);
-                    } else if (RNG == SUBGACC_RNG_RAND_R) {
-                        atomicOr(&a.flags[0], 1);  // dead end: the sequential stream is no longer reproducible
-                    }
+                    const int64_t at = min(b[k] + (int64_t)next_off(k, s, (uint32_t)d[k], d[k] > 0), last);
+                    nv[k] = SG_NEIGH_LOAD(&a.indices[at]);
+                }
+#pragma unroll
+                for (int k = 0; k < WPL; ++k) {
+                    SG_KEEP_LOAD(nv[k]);
+                    cur[k] = d[k] > 0 ? nv[k] : cur[k];
                 }
             }
         }
@@ -337,6 +447,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
         }
         wbase = __builtin_amdgcn_readlane(wbase, kWave - 1);
         __syncthreads();   // every lane holds its slots in registers: the walk tables are free to be re-used
+        SG_HOOK_RSTAMP(10);
         const int32_t ns = red[8];
         if (tid == 0) a.nsize[i] = ns;
         const int32_t mn = min(min(red[0], red[1]), min(red[2], red[3]));
@@ -372,6 +483,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
                 }
         }
         __syncthreads();
+        SG_HOOK_RSTAMP(11);
         unsigned long long el[SPL];
         uint32_t bk[SPL];
         int32_t pos[SPL];                           // arrival order inside the sub-bucket, then the final position
@@ -386,6 +498,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
             }
         }
         __syncthreads();
+        SG_HOOK_RSTAMP(12);
         int32_t maxc;
         {
             const int32_t c = tid < B ? start[tid] : 0;
@@ -402,6 +515,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
             if (tid == B - 1) start[B] = excl + c;
         }
         __syncthreads();
+        SG_HOOK_RSTAMP(13);
         int blo[SPL], bhi[SPL];
         // level 2 only where level 1 left a crowded bucket (workgroup-uniform): evenly spread ids -- every set of a structureless
         // graph -- keep the short path (collab: the kernel is bound by vector instructions, level 2 for every set cost it 8 %)
@@ -474,6 +588,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
             if (e * NT + tid < ns) A[blo[e] + pos[e]] = el[e];         // every packed element was read before the barriers above
         }
         __syncthreads();
+        SG_HOOK_RSTAMP(14);
         const uint32_t *Ahi = (const uint32_t *)A;
 #pragma unroll
         for (int e = 0; e < SPL; ++e) {
@@ -487,6 +602,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
             }
         }
         __syncthreads();        // every rank is known: the bucket-grouped array can become the sorted one, in place
+        SG_HOOK_RSTAMP(15);
 #pragma unroll
         for (int e = 0; e < SPL; ++e) {
             if (e * NT >= ns) break;

@@ -35,7 +35,7 @@
 #define SG_HOOK_STAMP(k)                 \
     do {                                 \
         if (SG_STOP_AFTER == (k)) {      \
-            if (threadIdx.x == 0) {      /* a well-formed one-member row, so that the rest of the step stays in bounds */ \
+            if (threadIdx.x == 0 && !a.tags_only) {   /* a well-formed one-member row, so that the rest of the step stays in bounds (subgacc_walk_tags passes no rows at all) */ \
                 a.nsize[i] = 1;          \
                 a.set_ids[i * (int64_t)a.stride] = root; \
                 if (SPG) a.set_slot[i * (int64_t)a.stride] = 0; \
@@ -53,7 +53,7 @@
 #define SG_HOOK_RSTAMP(k)                                                                                    \
     do {                                                                                                     \
         if (SG_STOP_AFTER == (k)) {                                                                          \
-            if (threadIdx.x == 0) {                                                                          \
+            if (threadIdx.x == 0 && !a.tags_only) {   /* (subgacc_walk_tags: there are no rows to write) */   \
                 a.nsize[i] = 1;                                                                              \
                 a.set_ids[i * (int64_t)a.stride] = root;                                                     \
                 a.set_slot[i * (int64_t)a.stride] = 0;                                                       \
