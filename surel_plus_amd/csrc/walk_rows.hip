@@ -169,6 +169,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     // rounds); a lane then jumps the few hundred steps to its own walk (<= 12 rounds) instead of all ~2^28 of them
     const uint32_t xroot = RNG == SUBGACC_RNG_RAND_R ? lcg_jump(rseed, rpos) : 0u;
     uint32_t pickv[WPL];             // the first hop of this lane's walks: an index into the root's row
+    uint32_t inv = 0u;               // deg <= M: ceil(2^16 / deg) -- floor(x * inv / 2^16) = floor(x / deg) for x < 256
     if (shuffled) {
         // First hop without replacement (subg_acc.c:769-775): M sequential swaps a[k] <-> a[s_k], s_k = k + draw % (deg - k), over
         // the identity; walk w takes a[w].  Followed backwards, a[w] is found by: p = s_w; then, repeatedly, the LARGEST j below
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     } else {
         // w % deg for w < 256 and deg <= M <= 256 without a division per walk: with inv = ceil(2^16 / deg), floor(w * inv / 2^16) is the
         // exact quotient (the error term w * (deg * inv - 2^16) stays below 2^16)
-        const uint32_t inv = 65535u / rdeg + 1u;
+        inv = 65535u / rdeg + 1u;
 #pragma unroll
         for (int kk = 0; kk < WPL; ++kk) {
             const uint32_t w = (uint32_t)(tid + kk * NT);
@@ -342,9 +343,11 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
 #pragma unroll
         for (int s = 0; s < MH; ++s) {
             int64_t b[WPL], d[WPL];
+            unsigned long long nr[WPL], nr2[WPL];       // REC: what this hop's loads bring (taken over after the visits, below)
 #pragma unroll
             for (int k = 0; k < WPL; ++k) {
                 b[k] = d[k] = 0;
+                nr[k] = nr2[k] = 0ull;
                 if (REC) {      // the record carries the node AND its row: the next record is asked for before the visit
                     bool esc = false;
                     if (SG_LAST_HOP_ID && s + 1 == MH && MH > 1) {
@@ -364,18 +367,12 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
                             // the walk ends on this node: its row is never needed, so the 4-byte id from the plain
                             // adjacency array will do -- half the bytes per entry, twice the entries of a hub's row
                             // per line for the walkers that share it
-                            uint32_t v = (uint32_t)SG_NEIGH_LOAD(&a.indices[at]);
-                            SG_KEEP_LOAD(v);
-                            rec[k] = (unsigned long long)(live ? v : (uint32_t)cur[k]);     // dead end: the walk stays on this node
+                            nr[k] = (unsigned long long)(uint32_t)SG_NEIGH_LOAD(&a.indices[at]);
                         } else if (REC == 16) {
-                            ulonglong2 r2 = ((const ulonglong2 *)a.recs)[at];
-                            SG_KEEP_LOAD(r2.x);
-                            SG_KEEP_LOAD(r2.y);
-                            rec[k] = live ? r2.x : rec[k], rec2[k] = live ? r2.y : rec2[k];
+                            const ulonglong2 r2 = ((const ulonglong2 *)a.recs)[at];
+                            nr[k] = r2.x, nr2[k] = r2.y;
                         } else {
-                            unsigned long long r1 = a.recs[at];
-                            SG_KEEP_LOAD(r1);
-                            rec[k] = live ? r1 : rec[k];
+                            nr[k] = a.recs[at];
                         }
                     }
                 } else if (s + 1 < MH) {
@@ -386,6 +383,15 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
             for (int k = 0; k < WPL; ++k) {
                 if (!wk[k]) continue;
                 // ---- visit: insert-or-find, first-visit sequence number, landing count
+                CntT inc = (CntT)1 << ((MH - 1 - s) * a.shift);
+                if (s == 0 && !shuffled) {
+                    // deg <= M: walk w takes neighbour w % deg, so neighbour j is landed on by the walks j, j + deg, ... -- exactly
+                    // floor((M-1-j) / deg) + 1 of them.  Walk j makes that visit for all of them, the others make none: deg LDS
+                    // atomics instead of M, and none of the same-address pile-ups (a root of degree 7 had 28 lanes on one slot)
+                    const uint32_t w = (uint32_t)(tid + k * NT);
+                    if (w >= rdeg) continue;
+                    inc *= (CntT)(((((uint32_t)M - 1u - w) * inv) >> 16) + 1u);
+                }
                 uint32_t h = ((uint32_t)cur[k] * 2654435761u) >> TSHIFT;
                 while (true) {
                     const int32_t old = atomicCAS(&keys[h], -1, cur[k]);
@@ -393,7 +399,24 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
                     h = (h + 1u) & TMASK;
                 }
                 if (!KR) atomicMin(&minq[h], (uint32_t)((tid + k * NT) * MH + s + 1));
-                atomicAdd(&pk[h], (CntT)1 << ((MH - 1 - s) * a.shift));
+                atomicAdd(&pk[h], inc);
+            }
+            if (REC && s + 1 < MH) {
+                // (the loads' values are taken over here, after every walk of the lane has issued its own and made its visit)
+#pragma unroll
+                for (int k = 0; k < WPL; ++k) {
+                    const bool live = d[k] > 0;
+                    SG_KEEP_LOAD(nr[k]);
+                    if (SG_LAST_HOP_ID && s + 2 == MH) {
+                        rec[k] = live ? nr[k] : (unsigned long long)(uint32_t)cur[k];      // dead end: the walk stays on this node
+                    } else {
+                        if (REC == 16) {
+                            SG_KEEP_LOAD(nr2[k]);
+                            rec2[k] = live ? nr2[k] : rec2[k];
+                        }
+                        rec[k] = live ? nr[k] : rec[k];
+                    }
+                }
             }
             if (!REC && s + 1 < MH) {
                 int32_t nv[WPL];
@@ -440,18 +463,21 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
         umn = wave_red_min_u32(umn);
         vmax = wave_red_max_i32(vmax);
         int wbase = 0;
-        if ((tid & (kWave - 1)) == kWave - 1) {
-            wbase = atomicAdd(&red[8], incl);
-            red[tid / kWave] = (int32_t)min(umn, 0x7FFFFFFFu);
-            red[4 + tid / kWave] = vmax;
+        if (NT > kWave) {
+            if ((tid & (kWave - 1)) == kWave - 1) {
+                wbase = atomicAdd(&red[8], incl);
+                red[tid / kWave] = (int32_t)min(umn, 0x7FFFFFFFu);
+                red[4 + tid / kWave] = vmax;
+            }
+            wbase = __builtin_amdgcn_readlane(wbase, kWave - 1);
         }
-        wbase = __builtin_amdgcn_readlane(wbase, kWave - 1);
         __syncthreads();   // every lane holds its slots in registers: the walk tables are free to be re-used
         SG_HOOK_RSTAMP(10);
-        const int32_t ns = red[8];
+        // (one wavefront per root: the totals are the wave's own reductions -- no trip through the LDS)
+        const int32_t ns = NT > kWave ? red[8] : __builtin_amdgcn_readlane(incl, kWave - 1);
         if (tid == 0) a.nsize[i] = ns;
-        const int32_t mn = min(min(red[0], red[1]), min(red[2], red[3]));
-        const int32_t mx = max(max(red[4], red[5]), max(red[6], red[7]));
+        const int32_t mn = NT > kWave ? min(min(red[0], red[1]), min(red[2], red[3])) : (int32_t)min(umn, 0x7FFFFFFFu);
+        const int32_t mx = NT > kWave ? max(max(red[4], red[5]), max(red[6], red[7])) : vmax;
         // The sort: a two-level distribution sort in LDS.  Level 1 is a histogram over B buckets of equal id WIDTH (the top bits of
         // id - min); level 2 gives bucket b as many sub-buckets as it has members -- sub-bucket = offset inside b's window scaled by
         // b's count -- so that idx2 = start1[b] + sub is a monotone map of the ids onto [0, ns) that follows the set's own
@@ -504,12 +530,15 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
             const int32_t c = tid < B ? start[tid] : 0;
             const int32_t inc = wave_scan_add_i32_incl(c);
             const int32_t mc = wave_red_max_i32(c);
-            if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc, red[4 + tid / kWave] = mc;
-            __syncthreads();
             int32_t base = 0;
-            for (int w2 = 0; w2 < tid / kWave; ++w2) base += red[12 + w2];
-            maxc = red[4];
-            for (int w2 = 1; w2 < NT / kWave; ++w2) maxc = max(maxc, red[4 + w2]);
+            maxc = mc;
+            if (NT > kWave) {
+                if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc, red[4 + tid / kWave] = mc;
+                __syncthreads();
+                for (int w2 = 0; w2 < tid / kWave; ++w2) base += red[12 + w2];
+                maxc = red[4];
+                for (int w2 = 1; w2 < NT / kWave; ++w2) maxc = max(maxc, red[4 + w2]);
+            }
             const int32_t excl = base + inc - c;
             if (tid < B) start[tid] = excl;
             if (tid == B - 1) start[B] = excl + c;
@@ -557,10 +586,12 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
                 s2 += (int32_t)((w[c] & 0xFFFFu) + (w[c] >> 16));
             }
             const int32_t inc = wave_scan_add_i32_incl(s2);
-            if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc;
-            __syncthreads();
             int32_t run = inc - s2;
-            for (int w2 = 0; w2 < tid / kWave; ++w2) run += red[12 + w2];
+            if (NT > kWave) {
+                if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc;
+                __syncthreads();
+                for (int w2 = 0; w2 < tid / kWave; ++w2) run += red[12 + w2];
+            }
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
                 const int x = tid * CW + c;
