@@ -9,7 +9,7 @@ SRC_SUM=$(cat walk.hip walk_rows.hip walk_common.hpp common.hpp $R/tools/dev_hoo
 cd $R
 for K in $KS full; do
   if [ $K = full ]; then unset SUBGACC_LIB; else export SUBGACC_LIB=$R/tools/build/libsubgacc_s${K}_$SRC_SUM.so; [ -f $SUBGACC_LIB ] || { echo "missing $SUBGACC_LIB"; exit 1; }; fi
-  for rep in 1 2; do
+  for rep in $(seq ${REPS:-2}); do
     timeout -k 10 120 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-others "$@" 2>/dev/null | python3 -c "import json,sys; o=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('stamp $K: walk kernel', round(o['roofline']['kernel_ms'],4), 'ms')" || exit 1
   done
 done
