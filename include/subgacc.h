@@ -488,8 +488,10 @@ int subgacc_batch_sampler(const void *indptr, int32_t indptr64, const int32_t *i
  * ids, any order inside a bucket; rows whose root is SUBGACC_NO_ROOT -- the repeated endpoints subgacc_step_prologue_dedup
  * marks -- are left out; *n_work = the rows listed) -- what subgacc_walk_spg_sparse / _list then runs over: roots that are neighbours in id
  * space (the same community of a graph with id locality) or equal (repeated endpoints) are walked at the same time on the
- * same XCD and share its L2.  The rows stay where they are; only the order of the walk changes, so no result does.  Two small
- * launches; workspace = subgacc_worklist_workspace_bytes(n) bytes. */
+ * same XCD and share its L2.  The rows stay where they are; only the order of the walk changes, so no result does (the order
+ * INSIDE a bucket is the arrival order of atomics and differs from run to run).  Two small launches; workspace =
+ * subgacc_worklist_workspace_bytes(n) bytes, ZEROED ONCE by its owner before the first call -- every call leaves it zeroed for
+ * the next (one workspace serves one stream at a time). */
 size_t subgacc_worklist_workspace_bytes(int64_t n);
 int subgacc_worklist_by_root(const int32_t *roots, int64_t n, int64_t num_nodes, int32_t *worklist, int64_t *n_work,
                              void *workspace, size_t workspace_bytes, void *stream);

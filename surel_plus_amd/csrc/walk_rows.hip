@@ -42,7 +42,9 @@ namespace subgacc {
 // arithmetically -- so the whole fold / registration / flush stage (a quarter of the kernel's vector instructions, its
 // global atomics) and the first-visit bookkeeping (minq: one LDS atomic per visit, 4 bytes of LDS per slot) fall away.
 template <bool IDX64, int RNG, int MH, int SPL, int NT, int REC = 0, bool K32 = false, bool KR = false>
-__global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80))) void walk_rows_kernel(const WalkArgs a) {
+// (waves per SIMD asked of the register allocator: the table form with 32-bit counts holds 12 bytes of LDS per slot + the fold table,
+//  ~15 KB per workgroup of two waves = 5 waves per SIMD whatever the registers; 64-bit counts on 128 lanes, 10.5 KB: 7; the rest 8)
+__global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (NT == 128 ? 7 : 8)) __attribute__((amdgpu_num_sgpr(80))) void walk_rows_kernel(const WalkArgs a) {
     static_assert(!KR || (K32 && SPL % 4 == 0), "key rows: 32-bit counts, 4-slot chunks");
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using CntT = typename std::conditional<K32, uint32_t, unsigned long long>::type;
@@ -779,13 +781,17 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     }
     __syncthreads();
     SG_HOOK_RSTAMP(5);
+    int32_t maxc;
     {   // exclusive scan over the B <= 256 buckets, one bucket per lane: wave scan, then the wave totals through LDS
         const int32_t c = tid < B ? start[tid] : 0;
         const int32_t inc = wave_scan_add_i32_incl(c);     // inclusive scan over the wave
-        if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc;
+        const int32_t mc = wave_red_max_i32(c);
+        if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc, red[4 + tid / kWave] = mc;
         __syncthreads();
         int32_t base = 0;
         for (int w2 = 0; w2 < tid / kWave; ++w2) base += red[12 + w2];
+        maxc = red[4];
+        for (int w2 = 1; w2 < NT / kWave; ++w2) maxc = max(maxc, red[4 + w2]);
         const int32_t excl = base + inc - c;
         if (tid < B) start[tid] = excl;
         if (tid == B - 1) start[B] = excl + c;
@@ -793,10 +799,67 @@ __global__ __launch_bounds__(NT, K32 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80)
     __syncthreads();
     SG_HOOK_RSTAMP(6);
     int blo[SPL], bhi[SPL];
+    // A crowded bucket (a set whose ids sit in one community of a graph with id locality): the second level of the key-row
+    // epilogue's sort, above -- sub-bucket = offset inside the bucket's id window scaled by the bucket's count -- so that the ranking
+    // by counting below runs over ~1 member, not over the bucket (quadratic: section 4.10 of DESIGN.md).  The level-2 counters
+    // (16 bits each) live where the sorted row is staged later: behind the bucket offsets (K32) / over the visit numbers.
+    constexpr int kFineAbove = 12, CW = 4;
+    const int W2 = (ns + 2) / 2 + 1;
+    uint32_t *cnt2 = K32 ? (uint32_t *)(start + B + 1) : (uint32_t *)minq;
+    if (!(maxc > kFineAbove && W2 <= CW * NT && (!K32 || B + 1 + W2 <= T))) {
 #pragma unroll
-    for (int u = 0; u < SPL; ++u) {   // bucket bounds, then the member goes to bucket start + arrival order
-        blo[u] = ok[u] ? start[bk[u]] : 0;
-        bhi[u] = ok[u] ? start[bk[u] + 1] : 0;
+        for (int u = 0; u < SPL; ++u) {   // bucket bounds, then the member goes to bucket start + arrival order
+            blo[u] = ok[u] ? start[bk[u]] : 0;
+            bhi[u] = ok[u] ? start[bk[u] + 1] : 0;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < CW; ++c)
+            if (c * NT + tid < W2) cnt2[c * NT + tid] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < SPL; ++u) {      // (bk[u] becomes the member's sub-bucket: the level-1 bucket is not needed again)
+            if (!ok[u]) continue;
+            const uint32_t lo1 = (uint32_t)start[bk[u]], kb = (uint32_t)start[bk[u] + 1] - lo1;
+            const uint32_t off = (uint32_t)(idv[u] - mn) - (bk[u] << bshift);                      // < 2^bshift
+            const uint32_t sub = bshift ? __umulhi(off << (32 - bshift), kb) : 0u;                 // floor(off * kb / 2^bshift) < kb
+            bk[u] = lo1 + sub;
+            const uint32_t sh = (bk[u] & 1u) * 16u;
+            arr[u] = (int32_t)((atomicAdd(&cnt2[bk[u] >> 1], 1u << sh) >> sh) & 0xFFFFu);
+        }
+        __syncthreads();
+        {   // exclusive scan of the ns + 1 level-2 counters, in place (offsets <= ns < 2^16): CW consecutive words per lane
+            uint32_t w[CW];
+            int32_t s2 = 0;
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const int x = tid * CW + c;
+                w[c] = x < W2 ? cnt2[x] : 0u;
+                s2 += (int32_t)((w[c] & 0xFFFFu) + (w[c] >> 16));
+            }
+            const int32_t inc = wave_scan_add_i32_incl(s2);
+            if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc;
+            __syncthreads();
+            int32_t run = inc - s2;
+            for (int w2 = 0; w2 < tid / kWave; ++w2) run += red[12 + w2];
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const int x = tid * CW + c;
+                const uint32_t lo16 = (uint32_t)run;
+                run += (int32_t)(w[c] & 0xFFFFu);
+                const uint32_t hi16 = (uint32_t)run;
+                run += (int32_t)(w[c] >> 16);
+                if (x < W2) cnt2[x] = lo16 | (hi16 << 16);
+            }
+        }
+        __syncthreads();
+        const uint16_t *off2 = (const uint16_t *)cnt2;
+#pragma unroll
+        for (int u = 0; u < SPL; ++u) {
+            blo[u] = ok[u] ? off2[bk[u]] : 0;
+            bhi[u] = ok[u] ? off2[bk[u] + 1] : 0;
+        }
+        __syncthreads();     // every bound is in registers before the staging areas (the same words) are written
     }
 #pragma unroll
     for (int u = 0; u < SPL; ++u)

@@ -394,7 +394,7 @@ def _sorted_list(bufs, csr, n, L, st):
         dev = csr.device
         bufs.sorted_list = torch.empty(n, dtype=torch.int32, device=dev)
         bufs.n_all = torch.zeros(1, dtype=torch.int64, device=dev)
-        bufs.sort_ws = torch.empty(L.subgacc_worklist_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        bufs.sort_ws = torch.zeros(L.subgacc_worklist_workspace_bytes(n), dtype=torch.uint8, device=dev)      # (zeroed once: every call leaves it so)
     check(L.subgacc_worklist_by_root(ptr(bufs.roots), n, csr.num_nodes, ptr(bufs.sorted_list), ptr(bufs.n_all), ptr(bufs.sort_ws),
                                      bufs.sort_ws.numel(), st))
 
