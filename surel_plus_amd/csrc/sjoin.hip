@@ -52,9 +52,13 @@ __global__ __launch_bounds__(kScanThreads) void sjoin_seg_reduce_kernel(const Se
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
-// partial == nullptr: a single tile (which then also raises the flag)
+// partial == nullptr: a single tile (which then also raises the flag).  ITEMS = kSegItems for the tiles of a large batch;
+// 16 for a batch of up to 4,096 segments (the reference's 1,024 pairs: 2,048 segments) as ONE tile in ONE launch.
+constexpr int kSegItemsSmall = 16;
+template <int ITEMS>
 __global__ __launch_bounds__(kScanThreads) void sjoin_seg_scan_kernel(const SegLen L, const int64_t *__restrict__ partial,
                                                                       int64_t *__restrict__ out) {
+    constexpr int kSegItems = ITEMS, kSegTile = kScanThreads * ITEMS;
     const int64_t base = (int64_t)blockIdx.x * kSegTile + (int64_t)threadIdx.x * kSegItems;
     int64_t v[kSegItems];
     int64_t s = 0;
@@ -634,11 +638,13 @@ static int join_sizes(const int64_t *spg_indptr, const int32_t *row_len, int64_t
     const int64_t nb = ceil_div(S, kSegTile);
     SG_REQUIRE(nb < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_sizes: too many segments");
     if (nb == 1) {
-        hipLaunchKernelGGL(sjoin_seg_scan_kernel, dim3(1), dim3(kScanThreads), 0, s, L, (const int64_t *)nullptr, out_seg);
+        hipLaunchKernelGGL(sjoin_seg_scan_kernel<kSegItems>, dim3(1), dim3(kScanThreads), 0, s, L, (const int64_t *)nullptr, out_seg);
+    } else if (S <= (int64_t)kScanThreads * kSegItemsSmall) {
+        hipLaunchKernelGGL(sjoin_seg_scan_kernel<kSegItemsSmall>, dim3(1), dim3(kScanThreads), 0, s, L, (const int64_t *)nullptr, out_seg);
     } else {
         int64_t *partial = (int64_t *)workspace;     // nb words <= S words
         hipLaunchKernelGGL(sjoin_seg_reduce_kernel, dim3((unsigned)nb), dim3(kScanThreads), 0, s, L, partial);
-        hipLaunchKernelGGL(sjoin_seg_scan_kernel, dim3((unsigned)nb), dim3(kScanThreads), 0, s, L, (const int64_t *)partial,
+        hipLaunchKernelGGL(sjoin_seg_scan_kernel<kSegItems>, dim3((unsigned)nb), dim3(kScanThreads), 0, s, L, (const int64_t *)partial,
                            out_seg);
     }
     SG_LAUNCH_CHECK();
