@@ -100,7 +100,9 @@ int subgacc_key_shift(int32_t num_walks, int32_t num_steps);
  * calls(r) = (deg>M ? M : 0) + M*(m-1) draws per non-isolated root (first_hop_wo) or M*m
  * (plain walks), in root order; stream t of `rng_streams` owns libgomp's static chunk t of the n
  * roots and starts from seed+t (subg_acc.c:157-158,191-192; one stream for set_sampler :731-732).
- * Writes rng_pos[i] (LCG steps before root i, mod 2^32) and rng_seed[i].
+ * Writes the pair (rng_seed[i], rng_pos[i]) = (an LCG state, LCG steps to take from it) that names root i's first draw; the
+ * walk entry points only ever use it as lcg_jump(rng_seed[i], rng_pos[i] + ...).  It leaves NORMALISED -- rng_seed[i] = the
+ * state of stream t after the draws before root i, rng_pos[i] = 0 -- so that no workgroup has to make the jump again.
  * `calls_before` = draws consumed before query[0] (for sharded / chunked callers). */
 size_t subgacc_rng_positions_workspace_bytes(int64_t n);
 int subgacc_rng_positions(const subgacc_walk_cfg *cfg, const void *indptr, int64_t num_nodes, const int32_t *query, int64_t n,

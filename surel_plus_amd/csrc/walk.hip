@@ -57,8 +57,11 @@ __global__ void rng_positions_kernel(const int64_t *__restrict__ calls_excl, int
     }
     uint64_t c = (uint64_t)(calls_excl[i] - calls_excl[lo]);
     if (streams == 1) c += calls_before;
-    pos[i] = (uint32_t)(3ull * c);  // three LCG steps per rand_r call; the LCG has period 2^32
-    sd[i] = seed + (uint32_t)t;
+    // three LCG steps per rand_r call; the LCG has period 2^32.  The pair leaves NORMALISED: (state of the stream at the root's
+    // first draw, 0 further steps) names the same point of the stream as (seed + t, 3c) and spares every workgroup of the walk
+    // kernels the 32-round jump from the seed (they compute lcg_jump(seed, pos + ...): 0 rounds for pos = 0)
+    pos[i] = 0u;
+    sd[i] = lcg_jump(seed + (uint32_t)t, (uint32_t)(3ull * c));
 }
 
 // ------------------------------------------------------------------------------ the walk kernel
