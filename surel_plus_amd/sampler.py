@@ -280,7 +280,9 @@ class SampledSets:
                 raise _lib.SubgAccError(f"{c} distinct LP rows exceed the direct-ranking limit: sample with lazy=False")
             self.ukeys = self.ukeys[:c]
         if self.strided:
-            self._members = X if self.n_distinct is None else int(self.nsize.sum().item())    # (rows of repeated endpoints: 0)
+            # root dedup: the rows of repeated endpoints are empty, so the members are fewer than the join's rows -- counted when
+            # somebody asks (X): a reduction + read-back here would stall a serving loop once per step behind the NEXT step's launches
+            self._members = X if self.n_distinct is None else None
             return self
         self.ids = self.ids[:X]
         for name in ("slot", "keys", "data", "sf"):
@@ -292,6 +294,8 @@ class SampledSets:
     @property
     def X(self):
         self.resolve()
+        if self.strided and self._members is None:
+            self._members = int(self.nsize.sum().item())
         return self._members if self.strided else self.ids.numel()
 
     @property
