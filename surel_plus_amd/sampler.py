@@ -36,7 +36,11 @@ FINISH_MAX_STRIDE = 1024   # subgacc_finish_rows sorts a row from registers (16 
 HOP_RECORDS = os.environ.get("SUBGACC_HOP_RECORDS", "auto")
 HOP_RECORDS_MIN_BYTES = 64 << 20      # adjacency bytes from which records are built in "auto" mode
 HOP_RECORDS_MIN_DEG_BITS = 12
-HOP_RECORDS_MAX_FREE_FRACTION = 0.25    # of the free device memory, in "auto" mode
+HOP_RECORDS_MAX_FREE_FRACTION = 0.25
+# a single-chunk batch of this many roots or more is walked in ascending order of root id (sample_sets; the buffered step has its
+# own switch in spjoin.py: same default, same environment variable)
+SORT_ROOTS = os.environ.get("SUBGACC_SORT_ROOTS", "1") == "1"
+SORT_ROOTS_MIN = 16384    # of the free device memory, in "auto" mode
 
 # Key rows (csrc/walk_rows.hip KR form + subgacc_sjoin_fill_keyrows): a strided batch that will not be numbered carries its
 # members' 32-bit LP keys instead of slots of a table of distinct rows; the join unpacks a key into its feature row itself.
@@ -612,8 +616,25 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
         cn = min(chunk, n - lo)
         if walk_pos is not None:
             cfg.walk_pos = walk_pos[lo * M:].data_ptr()
+        # a batch sampled in one chunk walks its rows in ascending order of root id, like the buffered step (csrc/worklist.hip:
+        # repeated and neighbouring roots share their lines in L2; the rows stay where they are).  Several chunks = the offline
+        # stage over all nodes: those come in order already.
+        by_root = (fused_rows and chunk == n and cn >= SORT_ROOTS_MIN and SORT_ROOTS and walk_pos is None and
+                   walk_kernel_name(csr, M, m, True) == "walk_rows_kernel")
+        if by_root:
+            wl = torch.empty(cn, dtype=torch.int32, device=dev)
+            nwl = torch.zeros(1, dtype=torch.int64, device=dev)
+            wws = torch.zeros(L.subgacc_worklist_workspace_bytes(cn), dtype=torch.uint8, device=dev)
+            nsize.zero_()           # (a row that is not listed -- a root equal to SUBGACC_NO_ROOT -- reads as an empty set)
+            check(L.subgacc_worklist_by_root(ptr(q), cn, csr.num_nodes, ptr(wl), ptr(nwl), ptr(wws), wws.numel(), st))
         with _timed("walk_sets"):
-            if fused_rows:
+            if by_root:
+                check(L.subgacc_walk_spg_list(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q), cn,
+                                              ptr(rng_pos) if rng_pos is not None else None,
+                                              ptr(rng_seed) if rng_seed is not None else None, ptr(wl), ptr(nwl),
+                                              None if batched else ptr(table), 0 if (key_rows or batched) else uniq_capacity,
+                                              ptr(st_ids), ptr(st_aux), ptr(nsize), ptr(flags), st))
+            elif fused_rows:
                 check(L.subgacc_walk_spg(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn, lo,
                                          ptr(rng_pos[lo:]) if rng_pos is not None else None,
                                          ptr(rng_seed[lo:]) if rng_seed is not None else None,
