@@ -36,11 +36,11 @@ FINISH_MAX_STRIDE = 1024   # subgacc_finish_rows sorts a row from registers (16 
 HOP_RECORDS = os.environ.get("SUBGACC_HOP_RECORDS", "auto")
 HOP_RECORDS_MIN_BYTES = 64 << 20      # adjacency bytes from which records are built in "auto" mode
 HOP_RECORDS_MIN_DEG_BITS = 12
-HOP_RECORDS_MAX_FREE_FRACTION = 0.25
-# a single-chunk batch of this many roots or more is walked in ascending order of root id (sample_sets; the buffered step has its
-# own switch in spjoin.py: same default, same environment variable)
+HOP_RECORDS_MAX_FREE_FRACTION = 0.25    # of the free device memory, in "auto" mode
+# a single-chunk batch of SORT_ROOTS_MIN .. SORT_ROOTS_MAX roots is walked in ascending order of root id (sample_sets; the buffered
+# step has its own switch in spjoin.py: same default, same environment variable)
 SORT_ROOTS = os.environ.get("SUBGACC_SORT_ROOTS", "1") == "1"
-SORT_ROOTS_MIN = 16384    # of the free device memory, in "auto" mode
+SORT_ROOTS_MIN, SORT_ROOTS_MAX = 16384, 1 << 20
 
 # Key rows (csrc/walk_rows.hip KR form + subgacc_sjoin_fill_keyrows): a strided batch that will not be numbered carries its
 # members' 32-bit LP keys instead of slots of a table of distinct rows; the join unpacks a key into its feature row itself.
@@ -616,10 +616,10 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
         cn = min(chunk, n - lo)
         if walk_pos is not None:
             cfg.walk_pos = walk_pos[lo * M:].data_ptr()
-        # a batch sampled in one chunk walks its rows in ascending order of root id, like the buffered step (csrc/worklist.hip:
-        # repeated and neighbouring roots share their lines in L2; the rows stay where they are).  Several chunks = the offline
-        # stage over all nodes: those come in order already.
-        by_root = (fused_rows and chunk == n and cn >= SORT_ROOTS_MIN and SORT_ROOTS and walk_pos is None and
+        # a BATCH sampled in one chunk walks its rows in ascending order of root id, like the buffered step (csrc/worklist.hip:
+        # repeated and neighbouring roots share their lines in L2; the rows stay where they are).  Beyond a million roots the call
+        # is the offline stage over a whole graph, whose nodes come in order already (listing them again cost it 1.5 %).
+        by_root = (fused_rows and chunk == n and SORT_ROOTS_MIN <= cn <= SORT_ROOTS_MAX and SORT_ROOTS and walk_pos is None and
                    walk_kernel_name(csr, M, m, True) == "walk_rows_kernel")
         if by_root:
             wl = torch.empty(cn, dtype=torch.int32, device=dev)
