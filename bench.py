@@ -802,6 +802,7 @@ def flatten(out):
         put(f"{short}_line_roof_frac", (r.get("random_line_roof") or {}).get("frac"))
         put(f"{short}_traffic_bytes", r.get("traffic"))
         put(f"{short}_join_ms", ((o.get("config") or {}).get("stage_ms") or {}).get("sjoin_fill"))
+        put(f"{short}_dedup_pairs_per_s", ((o.get("config") or {}).get("dedup_roots_loop") or {}).get("pairs_per_s"))
         put(f"{short}_join_call_ms", (o.get("config") or {}).get("join_call_ms_three_launches"))
         put(f"{short}_frac_whole_join_call", (o.get("config") or {}).get("frac_of_hbm_peak_whole_join_call"))
         if "cpu_baseline" in o:
