@@ -250,19 +250,30 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
             } else if (KEYS) {
                 // any other width: every lane unpacks its own row (no shuffles, no per-element index arithmetic) into the
                 // wave's LDS staging area, and the span leaves as consecutive 8-byte words (k2 = 2k floats per row)
+                // (KV = 3: the 2-hop configurations, k known at compile time -- the loops unroll and the shifts are immediates)
+                const int kc = KV > 0 ? KV : k;
                 if (live) {
-                    float *mine = stage + lane * k2;
-                    for (int c = 0; c < k; ++c) {
-                        mine[c] = key_feature((uint32_t)pa, c, a.key_m, a.key_shift, lut);
-                        mine[k + c] = key_feature((uint32_t)pb, c, a.key_m, a.key_shift, lut);
+                    float *mine = stage + lane * 2 * kc;
+#pragma unroll
+                    for (int c = 0; c < (KV > 0 ? KV : 16); ++c) {
+                        if (c >= kc) break;
+                        mine[c] = key_feature((uint32_t)pa, c, kc - 1, a.key_shift, lut);
+                        mine[kc + c] = key_feature((uint32_t)pb, c, kc - 1, a.key_shift, lut);
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                float2 *dst2 = reinterpret_cast<float2 *>(a.out_xz + row0 * k2);
+                float2 *dst2 = reinterpret_cast<float2 *>(a.out_xz + row0 * 2 * kc);
                 const float2 *src2 = reinterpret_cast<const float2 *>(stage);
-                for (int f = lane; f < nrows * k; f += kWave) stream_store(dst2 + f, src2[f]);
+                if (KV > 0) {
+#pragma unroll
+                    for (int q = 0; q < KV; ++q) {
+                        const int f = lane + q * kWave;
+                        if (f < nrows * KV) stream_store(dst2 + f, src2[f]);
+                    }
+                } else
+                    for (int f = lane; f < nrows * k; f += kWave) stream_store(dst2 + f, src2[f]);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the next span of this wave re-uses the area
                 __builtin_amdgcn_wave_barrier();
             } else {
@@ -826,6 +837,10 @@ static int launch_key_join(JoinArgs &a, int32_t num_walks, int32_t num_steps, in
         if (lds > 64 * 1024)
             SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((sjoin_pair_kernel<false, 4, true>), dim3((unsigned)grid), dim3(kPairEmit), lds, s, a, pair_block);
+    } else if (a.k == 3) {      // 2 hops (the collab-like configurations)
+        if (lds > 64 * 1024)
+            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((sjoin_pair_kernel<false, 3, true>), dim3((unsigned)grid), dim3(kPairEmit), lds, s, a, pair_block);
     } else {
         if (lds > 64 * 1024)
             SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
