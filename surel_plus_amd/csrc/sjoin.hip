@@ -740,7 +740,8 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, int64_t n_rows, con
             // 3.9 TB/s of mixed reads and writes)
             hipLaunchKernelGGL((sjoin_pair_kernel<true, 0, false, kWave>), dim3((unsigned)grid), dim3(kWave), lds, s, a, pair_block);
         } else if (f64) SG_PAIR_LAUNCH(true, 0);
-        else if (vec4) SG_PAIR_LAUNCH(false, 4);
+        else if (vec4) SG_PAIR_LAUNCH(false, 4);      // (256 lanes per pair, as the key form takes for long rows below, cost THIS form
+                                                      //  5 %: its emit gathers feature rows from the Z_SF table)
         else SG_PAIR_LAUNCH(false, 0);
         SG_LAUNCH_CHECK();
         return SUBGACC_OK;
@@ -833,7 +834,14 @@ static int launch_key_join(JoinArgs &a, int32_t num_walks, int32_t num_steps, in
     SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "%s: too many segments in one call", who);
     hipStream_t s = (hipStream_t)stream;
     const bool vec4 = a.k == 4 && ((uintptr_t)a.out_xz % 16 == 0);
-    if (vec4) {
+    if (vec4 && a.max_len > 512 && a.split == 1) {
+        // rows of 3-hop sets (up to 601 members, ~380 on the cit2-like batch): 256 lanes per pair -- the two rows arrive in half
+        // the trips and eight wavefronts emit the ~12 spans (join kernel 0.437 -> 0.429 ms; 2-hop rows, ~120 members, lose 9 %
+        // with 256 lanes and keep 128: profiles/r12_ab_pair_threads.log)
+        if (lds > 64 * 1024)
+            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 4, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((sjoin_pair_kernel<false, 4, true, 256>), dim3((unsigned)grid), dim3(256), lds, s, a, pair_block);
+    } else if (vec4) {
         if (lds > 64 * 1024)
             SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((sjoin_pair_kernel<false, 4, true>), dim3((unsigned)grid), dim3(kPairEmit), lds, s, a, pair_block);
