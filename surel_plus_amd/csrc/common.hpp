@@ -18,6 +18,7 @@
 #define SG_HOOK_BEFORE_HOP(cur, w, s)
 #define SG_HOOK_LOAD_ROW(I64, indptr, cur, b, d) load_row<I64>(indptr, cur, b, d)
 #define SG_HOOK_VISIT_LABEL
+#define SG_HOOK_HOP_AT(at, last_hop)
 #define SG_HOOK_BEFORE_VISIT(cur, pk)
 #define SG_HOOK_FLUSH_SLOT(s2, real) (real)
 #define SJ_HOOK_SEARCH_RANGE(lo, hi)

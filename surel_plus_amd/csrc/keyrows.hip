@@ -359,8 +359,9 @@ static int keyrows_launch(int mode, const int32_t *row_ids, const int32_t *row_k
     // rows per block: a range long enough that its one flush of the dictionary does not matter, short enough that the launch has
     // several blocks per resident slot (4 blocks x 256 CUs) to even out what the rows' lengths leave uneven
     int64_t rpb = n / (4 * 256 * 4);
-    static const int64_t rpb_env = getenv("SUBGACC_KR_RPB") ? atol(getenv("SUBGACC_KR_RPB")) : 0;     // dev-only (tools/keyrows_bench.py)
-    if (rpb_env > 0) rpb = rpb_env;
+#ifdef SG_DEV_KR_RPB      // dev builds only (tools/keyrows_bench.py: -DSG_DEV_KR_RPB=n)
+    rpb = SG_DEV_KR_RPB;
+#endif
     rpb = rpb < 32 ? 32 : (rpb > kKrMaxRows ? kKrMaxRows : rpb);
     const int64_t grid = ceil_div(n, rpb);
     SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "keyrows: too many rows in one call");

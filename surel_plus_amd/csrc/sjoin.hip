@@ -115,8 +115,9 @@ struct JoinArgs {
 // Workgroups per pair of sjoin_pair_kernel: batches far below the chip's ~4,096 resident workgroups are split in two
 // (B = 1,024 pairs: 22 -> 18 us; four or eight parts pay more for the repeated row loads than they gain: 21 / 25 us)
 static inline int pair_split(int64_t pairs) {
-    static const int forced = [] { const char *e = getenv("SUBGACC_JOIN_SPLIT"); return e ? atoi(e) : 0; }();   // dev switch
-    if (forced > 0) return forced;
+#ifdef SG_DEV_JOIN_SPLIT      // dev builds only (tools/ab.py: -DSG_DEV_JOIN_SPLIT=n)
+    return SG_DEV_JOIN_SPLIT;
+#endif
     int sp = 1;
     while (sp < 2 && pairs * sp * 2 <= 4096) sp *= 2;
     return sp;

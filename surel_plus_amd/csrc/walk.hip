@@ -749,16 +749,20 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
                SUBGACC_ERR_BADARG, "walk: hop records with field widths %d / %d", a.rec.id_bits, a.rec.beg_bits);
     if (a.recs && (cfg->indptr64 != 0) != (a.rec.id_bits == 0)) a.recs = nullptr;   // 8-byte form <-> int32 offsets, 16-byte <-> int64
     SG_REQUIRE(a.T <= 65536, SUBGACC_ERR_LDS, "walk: M*m+1 = %d is too large for the per-root LDS tables", Q);
-    // SUBGACC_LDS_PAD (dev-only): extra dynamic LDS per workgroup, i.e. fewer resident workgroups per CU -- the
-    // occupancy response of the kernel (tools/README.md)
-    static const size_t lds_pad = getenv("SUBGACC_LDS_PAD") ? (size_t)atol(getenv("SUBGACC_LDS_PAD")) : 0;
-    const size_t lds = walk_lds_bytes(a.T, a.nwords, M, Q, spg, stride < Q) + lds_pad;
+#ifndef SG_DEV_LDS_PAD       // dev builds only: extra dynamic LDS per workgroup, i.e. fewer resident workgroups per CU -- the
+#define SG_DEV_LDS_PAD 0     // occupancy response of the kernel (tools/README.md)
+#endif
+    const size_t lds = walk_lds_bytes(a.T, a.nwords, M, Q, spg, stride < Q) + (size_t)SG_DEV_LDS_PAD;
     SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS,
                "walk: per-root tables need %zu B of LDS (> %d): M*m+1 = %d is too large", lds, kLdsBytes, Q);
 
     hipStream_t s = (hipStream_t)stream;
-    // the persistent, software-pipelined form takes every launch it supports (SUBGACC_WALK_PIPE=0 forces this file's)
-    static const bool use_pipe = !(getenv("SUBGACC_WALK_PIPE") && getenv("SUBGACC_WALK_PIPE")[0] == '0');
+    // the persistent, software-pipelined form takes every launch it supports (dev builds: -DSG_DEV_NO_WALK_PIPE forces this file's)
+#ifdef SG_DEV_NO_WALK_PIPE
+    const bool use_pipe = false;
+#else
+    const bool use_pipe = true;
+#endif
     // (replayed stream positions, walk_pos: only the general kernel below reads them)
     if (use_pipe && !holes && !a.walk_pos && launch_walk_pipe(a, cfg->indptr64 != 0, cfg->rng_mode, spg, lds, s)) {
         SG_LAUNCH_CHECK();

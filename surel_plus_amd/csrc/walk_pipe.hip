@@ -336,9 +336,11 @@ int launch_walk_pipe(const WalkArgs &a, bool indptr64, int rng_mode, bool spg, s
     // resident workgroups and made it 35 % slower than the plain form (measured, round 1).
     if (spg || !a.wo || a.step_major || a.walks || a.M > kWalkThreads || a.m < 1 || a.m > 6) return 0;
     if (lds > (size_t)kLdsBytes) return 0;
-    // lanes per workgroup: SUBGACC_PIPE_NT=64|128|256 (dev-only override)
-    static const int nt_env = getenv("SUBGACC_PIPE_NT") ? atoi(getenv("SUBGACC_PIPE_NT")) : 0;
-    const int nt = (nt_env == 64 || nt_env == 128 || nt_env == 256) ? nt_env : 256;
+    // lanes per workgroup (dev builds: -DSG_DEV_PIPE_NT=64|128)
+#ifndef SG_DEV_PIPE_NT
+#define SG_DEV_PIPE_NT 256
+#endif
+    const int nt = SG_DEV_PIPE_NT;
     int per_cu = (int)((size_t)kLdsBytes / lds);
     const int slots = 32 / (nt / kWave);                      // 32 waves per CU
     if (per_cu > slots) per_cu = slots;

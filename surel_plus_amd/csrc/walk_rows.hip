@@ -364,7 +364,8 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (NT == 128 ? 7 : 8)) __att
                     if (s + 1 < MH) {
                         if (esc) load_row<IDX64>(a.indptr, cur[k], b[k], d[k]);       // (a row too long for the record: rare)
                         const bool live = d[k] > 0;
-                        const int64_t at = min(b[k] + (int64_t)next_off(k, s, (uint32_t)d[k], live), last);
+                        int64_t at = min(b[k] + (int64_t)next_off(k, s, (uint32_t)d[k], live), last);
+                        SG_HOOK_HOP_AT(at, s + 2 == MH);
                         if (SG_LAST_HOP_ID && s + 2 == MH) {
                             // the walk ends on this node: its row is never needed, so the 4-byte id from the plain
                             // adjacency array will do -- half the bytes per entry, twice the entries of a hub's row
@@ -901,21 +902,25 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (NT == 128 ? 7 : 8)) __att
 
 // returns 1 when this specialised form took the launch (else the caller launches walk_sets_kernel<SPG>)
 int launch_walk_rows(const WalkArgs &a, bool indptr64, int rng_mode, size_t lds, hipStream_t s) {
-    static const bool off = getenv("SUBGACC_WALK_ROWS") && getenv("SUBGACC_WALK_ROWS")[0] == '0';
-    if (off) return 0;
+#ifdef SG_DEV_NO_WALK_ROWS      // dev builds only: every shape through walk_sets_kernel<SPG> (A/B)
+    return 0;
+#endif
     if (!a.wo || a.step_major || a.walks || a.M > kWalkThreads || a.stride != a.M * a.m + 1) return 0;
     if (a.m < 2 || a.m > 4 || (a.T != 512 && a.T != 1024)) return 0;
     const int64_t grid = xcd_grid(a.worklist && a.work_cap > 0 && a.work_cap < a.n ? a.work_cap : a.n);
     if (grid >= (1ll << 31)) return 0;
     const bool rr = rng_mode == SUBGACC_RNG_RAND_R;
-    // 512-slot tables: 128 lanes x 2 walks (SUBGACC_ROWS_NT=256 forces one walk per lane; dev-only)
-    static const bool nt256 = getenv("SUBGACC_ROWS_NT") && atoi(getenv("SUBGACC_ROWS_NT")) == 256;
+    // 512-slot tables: 128 lanes x 2 walks (dev builds: -DSG_DEV_ROWS_NT=256 forces one walk per lane)
+#ifndef SG_DEV_ROWS_NT
+#define SG_DEV_ROWS_NT 0
+#endif
+    constexpr bool nt256 = SG_DEV_ROWS_NT == 256;
     // key rows, 512-slot table, 2 hops, int32 row offsets: ONE wave per root (64 lanes x 4 walks x 8 slots, 55 VGPRs) -- no
     // barrier is a real one, the per-wave prologue and the scans are paid once: collab walk 0.296 -> 0.262 ms; neutral with
     // int64 offsets (twitter), and 13 % slower for the 1,024-slot table (16 slots per lane: 95 VGPRs), so only here.
-    // SUBGACC_ROWS_NT=128 keeps two waves, =64 takes one wave with int64 offsets too (dev-only).
-    static const bool nt64 = getenv("SUBGACC_ROWS_NT") && atoi(getenv("SUBGACC_ROWS_NT")) == 64;
-    static const bool nt128 = getenv("SUBGACC_ROWS_NT") && atoi(getenv("SUBGACC_ROWS_NT")) == 128;
+    // (dev builds: -DSG_DEV_ROWS_NT=128 keeps two waves, =64 takes one wave with int64 offsets too)
+    constexpr bool nt64 = SG_DEV_ROWS_NT == 64;
+    constexpr bool nt128 = SG_DEV_ROWS_NT == 128;
     const bool half = a.T == 512 && !nt256;
     const bool rec = a.recs != nullptr && indptr64 == (a.rec.id_bits == 0);   // hop records: one dependent read per hop
     if (a.keyrows) {      // rows that carry the LP key itself: 32-bit counts, 128 lanes, 2 or 3 hops -- or not at all
@@ -962,7 +967,7 @@ int launch_walk_rows(const WalkArgs &a, bool indptr64, int rng_mode, size_t lds,
 #undef SG_KR
     }
     // 1,024-slot table with counts that fit 32 bits: 128 lanes x 8 slots, 12 bytes of LDS per slot -> 11 roots per CU
-    // (SUBGACC_ROWS_NT=256 keeps the 256-lane form; dev-only).  int32 row offsets + 8-byte records / plain CSR only.
+    // (dev builds: -DSG_DEV_ROWS_NT=256 keeps the 256-lane form).  int32 row offsets + 8-byte records / plain CSR only.
     if (a.T == 1024 && !nt256 && !indptr64 && a.m * a.shift + 1 <= 31 && a.m <= 3) {
         const size_t lds32 = (size_t)a.T * 12 + (size_t)a.M * 4 + 8 + (size_t)kSpgFold * 12 + 64 + 16;
 #define SG_ROWS32(RNGM, MHH)                                                                                        \

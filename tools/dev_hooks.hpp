@@ -7,6 +7,7 @@
 //
 //   SG_EXPERIMENT (walk.hip)  1 traversal only, no dedup | 2 dedup only, no graph reads after the first hop | 6 no row-pointer read
 //                             7 per-phase cycle shares (tools/walk_phases.py) | 8 no registration in the HBM table
+//   SG_EXPERIMENT (walk_rows.hip) 9 the last hop's read hits L2 (no missed line) | 10 every later hop's does
 //   SG_STOP_AFTER = k         every workgroup of walk_sets_kernel / walk_rows_kernel ends at stamp k (tools/walk_insts.sh)
 //   SJ_EXPERIMENT (sjoin.hip) 1 no search | 2 no output stores | 3 stores without the feature-table read | 4 no row loads
 //                             8 plain (cached) stores
@@ -81,6 +82,17 @@
 #define SG_HOOK_LOAD_ROW(I64, indptr, cur, b, d) (b = ((int64_t)(uint32_t)(cur) * 21) % 62000000, d = 20)
 #else
 #define SG_HOOK_LOAD_ROW(I64, indptr, cur, b, d) load_row<I64>(indptr, cur, b, d)
+#endif
+
+// walk_rows.hip: what the random line fetches of the later hops cost the fused kernel -- the hop's read is folded into a 256 KB
+// window of the array (L2 resident: no missed line), 9 = the last hop only, 10 = every later hop.  The ceiling of what ANY
+// regrouping of the walkers (transit-parallel hops, tools/transit_probe.hip) could save.
+#if SG_EXPERIMENT == 9
+#define SG_HOOK_HOP_AT(at, last_hop) do { if (last_hop) at &= 0xFFFF; } while (0)
+#elif SG_EXPERIMENT == 10
+#define SG_HOOK_HOP_AT(at, last_hop) at &= ((last_hop) ? 0xFFFF : 0x7FFF)
+#else
+#define SG_HOOK_HOP_AT(at, last_hop)
 #endif
 
 #if SG_EXPERIMENT == 1      // traversal only: no dedup
