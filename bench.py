@@ -26,6 +26,7 @@ import sys
 import time
 
 os.environ.setdefault("SUBGACC_QUIET", "1")
+os.environ.setdefault("OMP_PROC_BIND", "close")      # BASELINE.md section 3 (the CPU baseline's OpenMP teams); read when libgomp loads
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -40,13 +41,20 @@ WORKLOADS = {
     # count respond to structure / to a work list sorted by root id?  (SUBGACC_SORT_ROOTS=1 sorts the work list)
     "cit2loc": ("cit2loc", 200, 4, "cit2-like LP on a community-structured graph: N=2,927,963 avg-deg 20.7, blocks of 2,048 consecutive ids, "
                                    "75 % of the edges inside a block, M=200, --num_steps 4 (m=3 hops)", 0.5),
+    # the paper's sampler figure (Fig. 6a: citation2, m = 4, M = 200 -- BASELINE.md section 1) read with m as the HOP count: CLI
+    # --num_steps 5; the LP key is 4 x 8 + 1 = 33 bits, i.e. beyond the 32-bit key rows of the 2- and 3-hop configurations
+    "cit2m4": ("cit2", 200, 5, "cit2-like LP, 4-hop walks: N=2,927,963 avg-deg 20.7 power-law graph, M=200, --num_steps 5 (m=4 hops)", 0.5),
     "collab": ("collab", 200, 3, "collab-like LP: N=235,868 avg-deg 8.2 power-law graph, M=200, --num_steps 3 (m=2 hops)", 0.5),
     # configs[2]: --k 20 negatives per positive (README.md:86) -> 1 pair in 21 is an edge of the graph, 20 are uniform pairs
     "ppa": ("ppa", 200, 4, "ppa-like LP: N=576,289 avg-deg 73.7 power-law graph, M=200, --num_steps 4 (m=3 hops), "
                            "1:20 positive:negative pairs (k=20)", 1.0 / 21.0),
     # configs[4]: twitter-follower scale (41.65 M nodes, ~2.9 B adjacency entries, int64 row offsets, 12 GB CSR
     # resident in HBM); the reference gives no walk parameters for it -- collab's are used
-    "twitter": ("twitter", 200, 3, "twitter-like LP: N=41,652,230, ~2.9e9 adjacency entries (int64 indptr), M=200, --num_steps 3", 0.5),
+    "twitter": ("twitter", 200, 3, "twitter-like LP: N=41,652,230, G + G.T of ~1.47e9 follows as dataloader.py:122-135 hands it over (undirected, "
+                                   "simple, rows sorted, ~2.9e9 adjacency entries, int64 indptr), M=200, --num_steps 3", 0.5),
+    # rounds 1-3's stand-in for the same scale: directed, a multigraph, rows unsorted (generated without any global sort)
+    "twitter_directed": ("twitter_directed", 200, 3, "twitter-like LP, DIRECTED multigraph stand-in: N=41,652,230, ~2.9e9 adjacency entries "
+                                                     "(int64 indptr), M=200, --num_steps 3", 0.5),
     # configs[3]: SpJoin over the float SpG of the PPR encoder (the store is built by the GPU PPR sampler in set-up)
     "cit2ppr": (None, 0, 1, "cit2-like PPR encoder: float64 SpG = topk_ppr_matrix(alpha=0.1, eps=1e-4, top-100, 'sym') + encoding 'PPR' "
                             "over all N=2,927,963 nodes (built on the GPU in set-up), SpJoin only (train.py:39-43)", 0.5),
@@ -61,7 +69,10 @@ LINE_BYTES = 128
 
 def measure_line_roof(csr):
     """-> (random reads = 128-byte lines per second, table bytes, what the table is); best of three ~1-2 ms launches"""
-    from surel_plus_amd._lib import check, lib, ptr, stream_ptr
+    from surel_plus_amd._lib import ptr, stream_ptr
+    probe = line_probe_lib()
+    if probe is None:
+        return None, None, None
     recs = csr.hop_records()
     table, what = (recs[0], "hop records") if recs else (csr.indices, "adjacency array")
     nbytes = table.numel() * table.element_size()
@@ -71,13 +82,33 @@ def measure_line_roof(csr):
     for rep in range(4):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
-        check(lib().subgacc_line_probe(ptr(table), nbytes, 32, 12345 + rep, ptr(sink), ctypes.byref(reads), stream_ptr()))
+        if probe.subgacc_line_probe(ptr(table), nbytes, 32, 12345 + rep, ptr(sink), ctypes.byref(reads), stream_ptr()) != 0:
+            return None, None, None
         b.record()
         b.synchronize()
         ms = a.elapsed_time(b)
         if rep and (best is None or ms < best):      # (the first launch warms the TLBs)
             best = ms
     return reads.value / (best * 1e-3), nbytes, what
+
+
+_PROBE = []
+
+
+def line_probe_lib():
+    """tools/build/libsubgacc_probe.so (tools/line_roof_lib.hip: a measurement aid OUTSIDE the product library and its ABI), built
+    by __graft_entry__.build(); None when it is not there (the roof is then not reported)"""
+    if not _PROBE:
+        path = os.path.join(ROOT, "tools", "build", "libsubgacc_probe.so")
+        try:
+            L = ctypes.CDLL(path)
+            vp = ctypes.c_void_p
+            L.subgacc_line_probe.restype = ctypes.c_int
+            L.subgacc_line_probe.argtypes = [vp, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint32, vp, ctypes.POINTER(ctypes.c_int64), vp]
+            _PROBE.append(L)
+        except OSError:
+            _PROBE.append(None)
+    return _PROBE[0]
 
 
 def kernel_source_sha():
@@ -197,11 +228,22 @@ def algorithmic_walk_bytes(csr, roots, sets, M, m):
     return int(per.sum().item()) + 8 * int(sets.X)
 
 
-def cpu_baseline(csr, edge_all, M, k, target_s=15.0):
-    """Reference (oracle/_ref: the real subg_acc.gset_sampler, OpenMP) + oracle C merge join, on a bounded number
-    of pairs of the same workload.  Rank 0, N=1 only.  The reference's OpenMP team size is probed first
-    (default = all cores, 64, 32, 16, 8 threads on a small sample) and the fastest setting is the one reported: the
-    reference shares one rand_r state between its threads (subg_acc.c:731-732) and slows down with many of them."""
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(csr, edge_all, M, k, target_s=4.0):
+    """BASELINE.md section 3's protocol, on this host: the reference (oracle/_ref: the real subg_acc.gset_sampler, OpenMP) + the
+    oracle's C merge join on a bounded number of pairs of the same workload, at 1 thread, 16 threads and the fastest team size
+    of a probe (all cores, 64, 32, 16, 8 -- the reference shares one rand_r state between its threads, subg_acc.c:731-732, and
+    slows down with many of them), OMP_PROC_BIND=close (set before libgomp loads, top of this file), best of 3 per setting, each
+    run sized to ~target_s seconds.  Rank 0, N=1 only.  `value` = the fastest setting's best run."""
     import oracle
     ref = oracle.ref_module()
     ptr_h = csr.indptr.cpu().numpy()
@@ -219,38 +261,87 @@ def cpu_baseline(csr, edge_all, M, k, target_s=15.0):
                 nsize, remap, enc = ref.gset_sampler(ptr_h, idx_h, roots, num_walks=M, num_steps=k - 1, nthread=nthread)
             else:
                 nsize, remap, enc = oracle.gset_sampler(ptr_h, idx_h, roots, num_walks=M, num_steps=k - 1, rng="philox",
-                                                        nthreads=threads)
+                                                        nthreads=threads if nthread < 0 else nthread)
         t1 = time.perf_counter()
-        spg = oracle.spg_build(nsize, remap, nthreads=threads)
+        jt = threads if nthread != 1 else 1
+        spg = oracle.spg_build(nsize, remap, nthreads=jt)
         table = oracle.enc_table(enc).astype(np.float32) / np.float32(M)
         rows = np.arange(2 * B, dtype=np.int64).reshape(2, B)
-        xz, ind = oracle.gather(rows, spg, ptr=True, encode=table, nthreads=threads)
+        xz, ind = oracle.gather(rows, spg, ptr=True, encode=table, nthreads=jt)
         t2 = time.perf_counter()
         return t2 - t0, t1 - t0
 
     Bmax = edge_all.shape[1]
-    B0 = min(1024, Bmax)
-    best_nt, best_t = -1, None
-    for nt in ([-1, 64, 32, 16, 8] if use_ref else [-1]):
+    B0 = min(512, Bmax)
+    probe = {}
+    for nt in ([-1, 64, 32, 16, 8, 1] if use_ref else [-1, 1]):
         if nt > cores:
             continue
-        t, _ = run(B0, nt)
-        if best_t is None or t < best_t:
-            best_nt, best_t = nt, t
-    B = int(min(Bmax, max(B0, B0 * target_s / max(best_t, 1e-6))))
-    t, ts = run(B, best_nt)
-    used = cores if best_nt < 0 else best_nt
+        probe[nt] = run(B0, nt)[0]
+    best_nt = min((nt for nt in probe if nt != 1), key=lambda nt: probe[nt])
+    settings = {}
+    for label, nt in (("t1", 1), ("t16", 16 if (16 in probe or not use_ref) else None), ("tbest", best_nt)):
+        if nt is None or (nt not in probe and nt > 0 and nt > cores):
+            continue
+        t_probe = probe.get(nt, probe[best_nt])
+        Bn = int(min(Bmax, max(B0, B0 * target_s / max(t_probe, 1e-6))))
+        runs = [run(Bn, nt) for _ in range(3)]
+        t, ts = min(runs)
+        settings[label] = {"nthread": cores if nt < 0 else nt, "pairs": Bn, "pairs_per_s": Bn / t, "sampler_roots_per_s": 2 * Bn / ts,
+                           "join_pairs_per_s": Bn / max(t - ts, 1e-9), "seconds_best_of_3": t, "sampler_seconds": ts}
+    b = settings["tbest"]
     kind = "reference" if use_ref else "port"
-    return {"value": B / t, "unit": "query-pairs/s", "cores": used if use_ref else threads, "kind": kind,
-            # the two halves, for the reference's own flow (offline_flow): sampler roots/s, and pairs/s of SpG build + join
-            "sampler_roots_per_s": 2 * B / ts, "join_pairs_per_s": B / max(t - ts, 1e-9),
-            "sample": f"{B} pairs of the same workload ({2 * B} roots): sampler = "
-                      + (f"the reference's subg_acc.gset_sampler (oracle/_ref) with nthread={used}, the fastest of "
-                         f"all-cores/64/32/16/8 on this {cores}-thread host" if use_ref else f"oracle C port, {threads} threads")
-                      + f", {ts:.2f}s of {t:.2f}s; SpG build + SpJoin = oracle C port ({threads} threads)"}
+    out = {"value": b["pairs_per_s"], "unit": "query-pairs/s", "cores": b["nthread"] if use_ref else threads, "kind": kind,
+           "cpu_model": cpu_model(), "host_threads": cores, "omp_proc_bind": os.environ.get("OMP_PROC_BIND"),
+           # the two halves, for the reference's own flow (offline_flow): sampler roots/s, and pairs/s of SpG build + join
+           "sampler_roots_per_s": b["sampler_roots_per_s"], "join_pairs_per_s": b["join_pairs_per_s"],
+           "t1_pairs_per_s": settings["t1"]["pairs_per_s"] if "t1" in settings else None,
+           "t16_pairs_per_s": settings["t16"]["pairs_per_s"] if "t16" in settings else None,
+           "tbest_pairs_per_s": b["pairs_per_s"], "tbest_nthread": b["nthread"], "settings": settings,
+           "probe_seconds_512_pairs": {str(cores if nt < 0 else nt): round(v, 4) for nt, v in probe.items()},
+           "sample": f"{b['pairs']} pairs of the same workload ({2 * b['pairs']} roots), best of 3: sampler = "
+                     + (f"the reference's subg_acc.gset_sampler (oracle/_ref) with nthread={b['nthread']}, the fastest of "
+                        f"all-cores/64/32/16/8 on this {cores}-thread host ({cpu_model()}), OMP_PROC_BIND=close" if use_ref
+                        else f"oracle C port, {threads} threads")
+                     + f", {b['sampler_seconds']:.2f}s of {b['seconds_best_of_3']:.2f}s; SpG build + SpJoin = oracle C port ({threads} threads); "
+                       f"also timed at 1 and 16 threads (t1_* / t16_*)"}
+    return out
 
 
-def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W):
+def literal_dropin(csr, M, k, n_cpu=32768, nthread_cpu=-1):
+    """What seam A alone buys: the body of the reference's subg_matrix, random_walks.py:77-81, run
+    literally -- NumPy arrays in, `gset_sampler`, scipy csr_matrix of the returned remap, np.insert of the zero row -- once over
+    this repo's drop-in module `subg_acc` (GPU inside, PCIe + NumPy hand-over included) for ALL N roots, and once over the compiled
+    reference (oracle/_ref) for the first n_cpu roots.  roots/s each."""
+    import scipy.sparse as sps
+    import oracle
+    import subg_acc as shim
+    ptr_h, idx_h = csr.indptr.cpu().numpy(), csr.indices.cpu().numpy()
+    N = csr.num_nodes
+
+    def body(mod, idx, **kw):
+        t0 = time.perf_counter()
+        with quiet_stdout():
+            nsize, remap, enc = mod.gset_sampler(ptr_h, idx_h, idx, num_walks=M, num_steps=k - 1, **kw)
+        z = sps.csr_matrix((remap[1] + 1, (np.repeat(idx, nsize), remap[0])), shape=(N, N))
+        assert z.has_sorted_indices
+        enc = np.insert(enc, 0, np.zeros((1, k), dtype=enc.dtype), axis=0)
+        return time.perf_counter() - t0
+    idx = np.arange(N, dtype=np.int32)
+    body(shim, idx[:4096])
+    t_gpu = min(body(shim, idx) for _ in range(2))
+    out = {"roots": N, "drop_in_seconds": t_gpu, "drop_in_roots_per_s": N / t_gpu,
+           "what": "random_walks.py:77-81 verbatim over `import subg_acc` of this repo: numpy in / numpy out, scipy csr_matrix, np.insert"}
+    ref = oracle.ref_module()
+    if ref is not None and ptr_h.dtype == np.int32:
+        n = min(n_cpu, N)
+        t_cpu = min(body(ref, idx[:n], nthread=nthread_cpu) for _ in range(2))
+        out.update({"reference_roots": n, "reference_seconds": t_cpu, "reference_roots_per_s": n / t_cpu,
+                    "reference_nthread": nthread_cpu})
+    return out
+
+
+def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W, extra_regions=0):
     """SpJoin over a resident float-payload SpG (the citation2 PPR configuration): one step = B pairs -> xz [R,2,1]."""
     from surel_plus_amd.graphs import ppr_like_spg, preset_graph
     if os.environ.get("SUBGACC_PPR_SYNTH", "0") == "1":      # stand-in payload: exactly 100 random ids per row
@@ -266,8 +357,13 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W):
         torch.cuda.synchronize()
         prep_s = time.perf_counter() - t_prep
         del csr
-    gens = [torch.Generator(device=dev).manual_seed(1000 * rank + s) for s in range(K + W)]
-    edges = [torch.randint(0, N, (2, B), device=dev, generator=g) for g in gens]
+    gens = [torch.Generator(device=dev).manual_seed(1000 * rank + s) for s in range(min(K + W, 103))]
+    all_edges = [torch.randint(0, N, (2, B), device=dev, generator=g) for g in gens]
+
+    class _Cyclic:       # (a long pass re-uses its ~100 resident batches in turn)
+        def __getitem__(self, i):
+            return all_edges[i % len(all_edges)]
+    edges = _Cyclic()
     timer = KernelTimer()
     sampler_mod.KERNEL_TIMER = timer         # spjoin brackets the fill kernel ("sjoin_fill"); "join" below = the whole call
     # a serving loop's form of the join: the three launches of one gather (segment reduce, segment scan, fill) captured as ONE HIP
@@ -310,6 +406,19 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    region_values = [world * B * K / elapsed]
+    for r_ in range(extra_regions if (world == 1 and rank == 0) else 0):      # more regions of K steps, outside the clock
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        pending = None
+        for s in range(W + r_, W + r_ + K):
+            cur = step(s)
+            if pending is not None:
+                resolve(pending)
+            pending = cur
+        resolve(pending)
+        torch.cuda.synchronize()
+        region_values.append(B * K / (time.perf_counter() - t1))
     sampler_mod.KERNEL_TIMER = None
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -317,6 +426,8 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W):
         elapsed = float(t.item())
     if rank != 0:
         return None
+    if extra_regions:
+        elapsed = world * B * K / median(region_values)
     call_ms, launches = timer.mean_ms("join")       # HIP events around the whole join: the replayed graph's three kernels back to back
     ms, _ = timer.mean_ms("sjoin_fill")             # the fill kernel alone (eager mode only: events do not time inside a replayed graph)
     if ms is None:                                  # ... so a few eager joins after the timed region time it, for the record
@@ -345,6 +456,8 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W):
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc, "pairs_per_step_per_gpu": B, "xz_rows_last_step": rows_out,
+                       "region_pairs_per_s": [round(v) for v in region_values], "pairs_per_s_min": min(region_values),
+                       "pairs_per_s_median": median(region_values), "pairs_per_s_max": max(region_values),
                        "spg_members": z.nnz, "offline_ppr_stage_s": prep_s,
                        "join_call_ms_three_launches": call_ms,
                        "frac_of_hbm_peak_whole_join_call": (abytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if call_ms else None},
@@ -356,14 +469,26 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W):
                          "launches_timed": launches, "algorithmic_bytes_per_launch": abytes}}
 
 
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+
 def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, with_cpu_baseline, csr_variant=True,
-             small_batches=False, two_stream_extra=True, offline=False):
+             small_batches=False, two_stream_extra=True, offline=False, extra_regions=(0, 0), value_is_median=False, captured=False):
     """sample + SpJoin over one LP workload: W warm-up steps, K timed steps bracketed by barrier + synchronize, max over
-    ranks.  Returns the JSON object (rank 0) or None."""
+    ranks.  Returns the JSON object (rank 0) or None.
+    extra_regions = (R, Kx): after the timed region, R more regions of Kx steps each in the same loop (rank 0, 1 GPU): their
+    pairs/s as min / median / max -- the timed region of the driver's K steps is ~25 ms, one host hiccup away from any number;
+    value_is_median: `value` is the median over the main region and the extras (the short passes over the other workloads).
+    captured: the timed loop replays the whole step as ONE HIP graph (stepgraph.CapturedStep, three in turn: the read-back of step s
+    is waited for after step s+2 has been queued) -- what a serving loop does for steps whose kernels (~0.4 ms: 2-hop walks,
+    small batches) are shorter than the host's six launches and one read-back on a busy box; the per-kernel times then come from a
+    few eager steps after the regions (HIP events cannot bracket a kernel inside a replayed graph)."""
     global STRIDED, DEDUP
     from surel_plus_amd.graphs import preset_graph, query_pairs
     preset, M, k, desc, pos_frac = WORKLOADS[name]
-    if name == "twitter":      # 12 GB of CSR (+ transients of its generation) + ~8 GB of step buffers per rank: look before building
+    if name.startswith("twitter"):      # 12 GB of CSR (+ transients of its generation) + ~8 GB of step buffers per rank: look before building
         free, total = torch.cuda.mem_get_info(dev)     # (the 47 GB of hop records are the library's call: DeviceCSR.hop_records
         need = int(24e9 * args.scale) + int(8e9)       #  builds them only within a quarter of the free memory)
         if free < need:
@@ -373,7 +498,7 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
         from surel_plus_amd.graphs import degree_ordered
         csr = degree_ordered(csr)[0]
     # every step's pairs are resident in HBM before the clock starts; ranks and steps get different pairs
-    edges = [query_pairs(csr, B, seed=1000 * rank + s, device=dev, pos_frac=pos_frac) for s in range(K + W)]
+    edges = [query_pairs(csr, B, seed=1000 * rank + s, device=dev, pos_frac=pos_frac) for s in range(max(K + W, min(extra_regions[1], 100)))]
     _XZ_BUF.clear()
     _STEP_BUFS.clear()
     timer = KernelTimer()
@@ -407,6 +532,23 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
             xz, ind, sets = finish_step(*pending[1])
             last = (pending[0], sets, xz)
 
+    caps = None
+    if captured:
+        caps = [sp.CapturedStep(csr, B, num_walks=M, num_steps=k - 1, seed=1, rng=rng, uniq_capacity=UNIQ_CAPACITY) for _ in range(3)]
+    eager_run_steps = run_steps
+
+    def run_steps_captured(step_ids):
+        pend = []
+        for s in step_ids:
+            pend.append(caps[s % 3](edges[s % len(edges)]))
+            if len(pend) == 3:        # the sizes / status of step s-2 are read now, two steps behind the queue
+                pend.pop(0).finish()
+            step_marks.append(time.perf_counter())
+        for q in pend:
+            q.finish()
+    if captured:
+        run_steps = run_steps_captured
+
     # Priming (part of set-up, like building the graph) + the W warm-up steps, in the same loop shape as the timed
     # region so that torch's caching allocator reaches its steady state (two steps in flight) here: a fresh GB-sized
     # hipMalloc inside the timed region costs ~10 ms on some hosts of the pool and is not part of the path.
@@ -437,6 +579,24 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    region_values = [world * B * K / elapsed]
+    if rank == 0 and world == 1 and extra_regions[0] > 0 and extra_regions[1] > 0:
+        timer.enabled = False
+        for r_ in range(extra_regions[0]):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_steps(range(W + r_, W + r_ + extra_regions[1]))
+            torch.cuda.synchronize()
+            region_values.append(B * extra_regions[1] / (time.perf_counter() - t1))
+    if captured:       # the stage times and the last step's sizes: eager launches of the same steps, outside the clock
+        run_steps = eager_run_steps
+        timer.enabled = False
+        run_steps(range(3))
+        torch.cuda.synchronize()
+        timer.enabled = True
+        run_steps(range(W, W + min(K, 10)))
+        torch.cuda.synchronize()
+        timer.enabled = False
     rank_records = gather_rank_records(dist, world, rank, dev, elapsed_local, timer.mean_ms("walk_sets")[0],
                                        os.environ.get("SUBGACC_DIST_BACKEND", "nccl") if dist is not None else None)
 
@@ -504,16 +664,25 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
     finished = timer.mean_ms("spg_build")[0] is not None and sets.strided    # rows came from the general kernel + finish_rows
     # HBM-side traffic / missed lines of the walk kernel: PMC passes (tools/pmc_traffic.py) of exactly these kernels
     # (matched by a hash of the kernel sources) and this configuration -- or null
-    traffic = lines = None
+    traffic = lines = join_traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         tj = json.load(open(tpath)).get(f"{name}:{B}:{M}:{k}:{'spg' if fused_rows else 'sets'}:{rng}", {})
         if tj.get("kernel_source_sha") == kernel_source_sha():
             traffic, lines = tj.get("walk_sets_hbm_bytes_per_launch"), tj.get("walk_sets_l2_miss_lines_per_launch")
+            join_traffic = tj.get("join_hbm_bytes_per_launch")
     roof, roof_bytes, roof_table = measure_line_roof(csr) if rank == 0 else (None, None, None)
+    # SURVEY 8(d), SpJoin: per pair 16 (query ids) + 32 (4 row offsets) + 16 (two segment pointers) and per output row 8 read
+    # (id + payload) + 8k written (float32 [.,2,k])
+    join_abytes = (B * 64 + last_rows * (8 + 8 * k)) if last_rows is not None else None
+    value = world * B * K / elapsed
+    ms_per_step = elapsed / K * 1e3
+    if value_is_median and len(region_values) > 1:
+        value = median(region_values)
+        ms_per_step = B / value * 1e3
     out = {
-        "metric": "query-pairs/sec (sample+SpJoin)", "value": world * B * K / elapsed, "unit": "query-pairs/s",
-        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+        "metric": "query-pairs/sec (sample+SpJoin)", "value": value, "unit": "query-pairs/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": args.scaling, "vs_baseline": None, "dtype": "int32", "data": "synthetic",
         "config": {"workload": desc, "pairs_per_step_per_gpu": B, "roots_per_step_per_gpu": 2 * B,
                    "pairs_per_step_all_gpus": world * B,
@@ -538,6 +707,12 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
                    "packed_csr_ms_per_step": csr_ms,
                    "two_stream_loop": two_streams, "dedup_roots_loop": dedup_loop,
                    "device_allocs_in_timed_region": allocs_timed,
+                   "timed_loop": ("one HIP graph per step (CapturedStep x3, read-back two steps behind)" if captured else
+                                  "eager launches (six per step), read-back one step behind"),
+                   # the main region followed by the extra regions (outside the driver's clock): pairs/s each
+                   "region_pairs_per_s": [round(v) for v in region_values], "extra_region_steps": extra_regions[1],
+                   "pairs_per_s_min": min(region_values), "pairs_per_s_median": median(region_values),
+                   "pairs_per_s_max": max(region_values),
                    "host_step_ms_min_median_max": [round(1e3 * v, 3) for v in
                                                    (min(host_steps), sorted(host_steps)[len(host_steps) // 2], max(host_steps))]
                    if host_steps else None,
@@ -547,13 +722,19 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
                      "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                      "kernel_ms": walk_ms, "launches_timed": launches, "algorithmic_bytes_per_launch": abytes,
+                     # the step's second kernel (sjoin_pair_kernel), same contract: algorithmic bytes / its own HIP-event time
+                     "join_kernel_ms": join_ms, "join_algorithmic_bytes_per_launch": join_abytes,
+                     "join_achieved": (join_abytes / (join_ms * 1e-3) / 1e9) if (join_ms and join_abytes) else None,
+                     "join_frac": (join_abytes / (join_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (join_ms and join_abytes) else None,
+                     "join_traffic": join_traffic,
                      # the roof this kernel actually sits under: random 128-byte lines per second
                      "random_line_roof": {"lines_per_s": roof, "line_bytes": LINE_BYTES, "table_bytes": roof_bytes,
-                                          "source": f"subgacc_line_probe in this run: independent random 4-byte reads over the {roof_table} "
-                                                    f"({roof_bytes >> 20} MiB), 2048 x 256 lanes, best of 3 (study: profiles/r02_line_probe_pmc.csv)",
+                                          "source": (f"tools/line_roof_lib.hip in this run: independent random 4-byte reads over the {roof_table} "
+                                                     f"({roof_bytes >> 20} MiB), 2048 x 256 lanes, best of 3 (study: profiles/r02_line_probe_pmc.csv)")
+                                          if roof else "tools/build/libsubgacc_probe.so not built",
                                           "l2_miss_lines_per_launch": lines,
                                           "achieved_lines_per_s": (lines / (walk_ms * 1e-3)) if (lines and walk_ms) else None,
-                                          "frac": (lines / (walk_ms * 1e-3) / roof) if (lines and walk_ms) else None}},
+                                          "frac": (lines / (walk_ms * 1e-3) / roof) if (lines and walk_ms and roof) else None}},
     }
     if small_batches:
         out["config"]["batch_size_and_hip_graph"] = batch_size_and_graph(sp, csr, M, k, rng, K)
@@ -561,7 +742,7 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
         out["config"]["two_stream_pairs_per_s"] = two_streams["pairs_per_s"]
     if dedup_loop and "pairs_per_s" in dedup_loop:
         out["config"]["dedup_roots_pairs_per_s"] = dedup_loop["pairs_per_s"]
-    if with_cpu_baseline and name != "twitter":   # 12 GB CSR: no host copy
+    if with_cpu_baseline and not name.startswith("twitter"):   # 12 GB CSR: no host copy
         try:
             out["cpu_baseline"] = cpu_baseline(csr, edges[W], M, k)
         except Exception as ex:  # the baseline is a report, never a reason to lose the measurement
@@ -576,6 +757,10 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
                 out["config"]["hgather"] = bench_hgather(sp, z, table, k, max(K, 5))
             except Exception as ex:
                 out["config"]["hgather"] = {"failed": f"{type(ex).__name__}: {ex}"}
+            try:
+                out["config"]["mean_stage"] = bench_mean_stage(sp, sampler_mod, z, table, csr, k, B, 10)
+            except Exception as ex:
+                out["config"]["mean_stage"] = {"failed": f"{type(ex).__name__}: {ex}"}
             del z, table
         except Exception as ex:     # an extra must never cost the headline line
             out["config"]["offline_flow"] = {"failed": f"{type(ex).__name__}: {ex}"}
@@ -588,10 +773,14 @@ def batch_size_and_graph(sp, csr, M, k, rng, K):
     loop.  Pairs/s per variant."""
     from surel_plus_amd.graphs import query_pairs
     out = {}
+    REPS = 3
     for B in (1024, 65536):
-        steps = max(K, 64) if B == 1024 else K
-        edges = [query_pairs(csr, B, seed=7000 + s, device=csr.device) for s in range(steps + 3)]
-        for mode in ("eager", "graph", "graph, 2 lanes", "graph, 4 lanes", "graph, 8 lanes", "graph, 8 lanes, inputs ready"):
+        steps = 300 if B == 1024 else max(K, 50)       # >= 20 ms per timed loop at either size; REPS loops, the median is reported
+        edges = [query_pairs(csr, B, seed=7000 + s, device=csr.device) for s in range(min(steps, 100) + 3)]
+        for mode in ("eager", "graph", "graph, 2 lanes", "graph, 4 lanes", "graph, 8 lanes", "graph, 8 lanes, inputs ready",
+                     "many: 64 batches per launch sequence"):
+            if mode.startswith("many") and B != 1024:
+                continue
             try:
                 _XZ_BUF.clear()
                 _STEP_BUFS.clear()
@@ -604,6 +793,23 @@ def batch_size_and_graph(sp, csr, M, k, rng, K):
                 # not fill the chip)
                 pool = sp.CapturedStepPool(csr, B, lanes=lanes, **kw) if lanes else None
                 caps = [sp.CapturedStep(csr, B, **kw) for _ in (0, 1)] if mode == "graph" else None
+                many = None
+                if mode.startswith("many"):
+                    # the reference's batch size at the chip's batch size: 64 batches of 1,024 pairs as ONE captured step
+                    # (StepBuffers(batch=1024)), cut into 64 reference-shaped (xz, indptr) on finish (spjoin.split_batches)
+                    NB = 64
+                    many = [sp.CapturedStep(csr, NB * B, batch=B, **kw) for _ in (0, 1)]
+                    stacks = [torch.stack([edges[(i * NB + j) % len(edges)] for j in range(NB)]) for i in range(4)]
+
+                def loop_many(n_groups):
+                    pend = None
+                    for g in range(n_groups):
+                        q = many[g & 1](stacks[g % len(stacks)])
+                        if pend is not None:
+                            parts = pend.finish_batches()
+                            assert len(parts) == NB
+                        pend = q
+                    pend.finish_batches()
 
                 def loop(ids):
                     pending = []          # steps in flight
@@ -624,14 +830,29 @@ def batch_size_and_graph(sp, csr, M, k, rng, K):
                             pool.finish(d)
                         else:
                             d.finish() if caps is not None else finish_step(*d)
-                loop(range(8))
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                loop(range(8, 8 + steps))
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t0
-                out[f"B={B} {mode}"] = {"pairs_per_s": B * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps}
-                del caps, pool
+                rates = []
+                if many is not None:
+                    groups = max(steps // NB, 8)
+                    loop_many(3)
+                    for _ in range(REPS):
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        loop_many(groups)
+                        torch.cuda.synchronize()
+                        rates.append(B * NB * groups / (time.perf_counter() - t0))
+                    n_steps = NB * groups
+                else:
+                    loop(range(8))
+                    for _ in range(REPS):
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        loop(range(8, 8 + steps))
+                        torch.cuda.synchronize()
+                        rates.append(B * steps / (time.perf_counter() - t0))
+                    n_steps = steps
+                out[f"B={B} {mode}"] = {"pairs_per_s": median(rates), "pairs_per_s_min": min(rates), "pairs_per_s_max": max(rates),
+                                        "ms_per_step": B / median(rates) * 1e3, "steps": n_steps, "repeats": REPS}
+                del caps, pool, many
             except Exception as ex:
                 out[f"B={B} {mode}"] = {"failed": f"{type(ex).__name__}: {ex}"}
     return out
@@ -669,12 +890,18 @@ def offline_flow(sp, csr, M, k, B, K, cpu):
     def join_rate(store, tab):
         for e in edges[:2]:
             sp.gather(e, store, dev, ptr=True, encode=tab, out=buf, lazy=True)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for e in edges[2:]:
-            sp.gather(e, store, dev, ptr=True, encode=tab, out=buf, lazy=True)
-        torch.cuda.synchronize()
-        return (len(edges) - 2) * B / (time.perf_counter() - t1)
+        rs = []
+        for _ in range(3):          # three loops of >= 50 joins (>= 20 ms each); the median is reported
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_j = 0
+            while n_j < 50:
+                for e in edges[2:]:
+                    sp.gather(e, store, dev, ptr=True, encode=tab, out=buf, lazy=True)
+                    n_j += 1
+            torch.cuda.synchronize()
+            rs.append(n_j * B / (time.perf_counter() - t1))
+        return median(rs)
     J = join_rate(z, table)
     encz = torch.cat([torch.zeros((1, enc.shape[1]), dtype=enc.dtype, device=dev), enc])
     zk = None
@@ -686,7 +913,53 @@ def offline_flow(sp, csr, M, k, B, K, cpu):
         torch.cuda.synchronize()
         t_key = time.perf_counter() - t2
     JK = join_rate(zk, zk.slot_table())
-    out = {"all_N_sample_to_resident_spg_ms": t_off * 1e3, "S_roots_per_s": N / t_off, "set_members": z.nnz,
+    # the reference's own loop AT the reference's batch size (main.py:32: 1,024 pairs; train.py:120-127), from the keyed store:
+    # one eager gather per batch, the same as ONE HIP graph per batch (CapturedJoin), and 64 batches per launch sequence
+    # (gather_many: the permutation of an epoch is known when it starts) -- 3 repeats each, the median is reported
+    b1024 = {}
+    try:
+        Bs, NB = 1024, 64
+        es = [query_pairs(csr, Bs, seed=9500 + s_, device=dev) for s_ in range(128)]
+        sbuf = torch.empty(NB * 2 * Bs * zk.max_len * 2 * k, dtype=torch.float32, device=dev)
+        stacks = [torch.stack(es[i * NB:(i + 1) * NB]) for i in range(2)]
+
+        def rate(fn, n_pairs):
+            fn()
+            rs = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                rs.append(n_pairs / (time.perf_counter() - t1))
+            return {"pairs_per_s": median(rs), "pairs_per_s_min": min(rs), "pairs_per_s_max": max(rs)}
+
+        def eager():
+            for e in es * 2:
+                sp.gather(e, zk, dev, ptr=True, encode=zk.slot_table(), out=sbuf, lazy=True)
+        b1024["eager"] = rate(eager, 2 * len(es) * Bs)
+        cjs = [sp.CapturedJoin(zk, Bs, encode=zk.slot_table()) for _ in (0, 1)]
+
+        def graph():
+            pend = None
+            for i, e in enumerate(es * 2):
+                q = cjs[i & 1](e)
+                if pend is not None:
+                    pend.finish()
+                pend = q
+            pend.finish()
+        b1024["graph"] = rate(graph, 2 * len(es) * Bs)
+        del cjs
+
+        def many():
+            for i in range(8):
+                parts = sp.gather_many(stacks[i & 1], zk, dev, ptr=True, encode=zk.slot_table(), out=sbuf)
+                assert len(parts) == NB
+        b1024["many_64"] = rate(many, 8 * NB * Bs)
+        del sbuf, stacks
+    except Exception as ex:
+        b1024["failed"] = f"{type(ex).__name__}: {ex}"
+    out = {"J_b1024_keyed": b1024, "all_N_sample_to_resident_spg_ms": t_off * 1e3, "S_roots_per_s": N / t_off, "set_members": z.nnz,
            "distinct_lp_rows": int(enc.shape[0]), "J_pairs_per_s_table_store": J, "J_pairs_per_s_keyed_store": JK,
            "rekey_once_ms": t_key * 1e3, "pairs_per_batch": B,
            "Q_amortised_at_1e8_pairs_table": 1e8 / (t_off + 1e8 / J), "Q_amortised_at_1e8_pairs_keyed": 1e8 / (t_off + t_key + 1e8 / JK),
@@ -727,6 +1000,88 @@ def bench_hgather(sp, z, table, k, K):
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                          "kernel_ms": ms, "algorithmic_bytes_per_launch": abytes,
                          "note": "2,048 triplets are ~8k workgroups of one pair each: launch- and latency-bound, as the reference's batch size is"}}
+
+
+def bench_mean_stage(sp, sampler_mod, z, table, csr, k, B, K):
+    """SURVEY 8(f).1 / model.py:78-83: the first model stage for mean aggregation, `pe_embedding(xz).sum(-2)` + segment mean, three ways
+    from the resident store, forward only, B pairs per step: (a) the reference's form over the materialised xz [R,2,k] (gather + the
+    MLP on every row + a segment reduce), (b) spjoin.mean_stage: the count form C [2B, c+1] @ pe_embedding(Z_SF) (xz never exists),
+    (c) the sparse form of C: the DISTINCT index pairs of every segment with their multiplicities (gather_pairs) -> gather-add of the
+    embedded table rows -> segment sum.  H = 96 (main.py:30) and 256.  Outside the clock; 3 repeats of K steps, medians."""
+    from surel_plus_amd.graphs import query_pairs
+    dev = z.device
+    edges = [query_pairs(csr, B, seed=9700 + s_, device=dev) for s_ in range(4)]
+    # (a) materialises [R, 2, H] activations -- 100 GB at B = 65,536, H = 256 -- so it runs on batches of 4,096 pairs
+    Bref = min(B, 4096)
+    out = {"pairs_per_step": B, "pairs_per_step_ref_style": Bref, "table_rows": int(table.shape[0])}
+    timer = KernelTimer()
+    for H in (96, 256):
+        torch.manual_seed(0)
+        embed = torch.nn.Sequential(torch.nn.Linear(k, H), torch.nn.ReLU(), torch.nn.Linear(H, H)).to(dev)
+        buf = torch.empty(2 * B * z.max_len * 2 * k, dtype=torch.float32, device=dev)
+
+        def ref_style(e):
+            xz, ind = sp.gather(e, z, dev, ptr=True, encode=table, out=buf)
+            x = embed(xz).sum(dim=-2)
+            return torch.segment_reduce(x, "mean", offsets=ind, axis=0).view(2, -1, H)
+
+        def fused(e):
+            return sp.mean_stage(e, z, table, embed)
+
+        def sparse(e):
+            pairs, mult, indptr = sp.gather_pairs(e, z)
+            t = embed(table)
+            rows = (t[pairs[:, 0].long()] + t[pairs[:, 1].long()]) * mult.to(torch.float32)[:, None]
+            S = indptr.numel() - 1
+            seg = torch.repeat_interleave(torch.arange(S, device=dev), indptr[1:] - indptr[:-1], output_size=pairs.shape[0])
+            num = torch.zeros((S, H), device=dev, dtype=torch.float32).index_add_(0, seg, rows)
+            own = torch.cat([e[0], e[1]])
+            sizes = (z.indptr[own + 1] - z.indptr[own]).clamp(min=1).to(torch.float32)
+            return (num / sizes[:, None]).view(2, -1, H)
+
+        with torch.no_grad():
+            e0 = edges[0][:, :Bref].contiguous()
+            a, b_, c_ = ref_style(e0), fused(e0), sparse(e0)
+            out[f"H{H}_max_abs_diff_fused_vs_ref_style"] = float((a - b_).abs().max().item())
+            out[f"H{H}_max_abs_diff_sparse_vs_ref_style"] = float((a - c_).abs().max().item())
+            del a, b_, c_
+            for nm, fn in (("ref_style", ref_style), ("fused", fused), ("sparse", sparse)):
+                rs = []
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    Bn = Bref if nm == "ref_style" else B
+                    for s_ in range(K):
+                        fn(edges[s_ % len(edges)][:, :Bn])
+                    torch.cuda.synchronize()
+                    rs.append(Bn * K / (time.perf_counter() - t0))
+                out[f"H{H}_{nm}_pairs_per_s"] = median(rs)
+            # the count kernel alone (HIP events) and the GEMM behind it
+            sampler_mod.KERNEL_TIMER = timer
+            timer.enabled = True
+            C, sizes = sp.gather_counts(edges[1], z, table.shape[0])
+            for s_ in range(5):
+                C, sizes = sp.gather_counts(edges[s_ % len(edges)], z, table.shape[0])
+            timer.enabled = False
+            sampler_mod.KERNEL_TIMER = None
+            t = embed(table)
+            a_, b2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            C @ t
+            a_.record()
+            for _ in range(5):
+                C @ t
+            b2.record()
+            torch.cuda.synchronize()
+            out[f"H{H}_gemm_ms"] = a_.elapsed_time(b2) / 5
+        rows = int(z.indptr[torch.cat([edges[1][0], edges[1][1]]) + 1].sum().item() - z.indptr[torch.cat([edges[1][0], edges[1][1]])].sum().item())
+        del buf, embed
+    ms, _ = timer.mean_ms("sjoin_counts")
+    # algorithmic bytes of the count kernel: per pair 16 + 32, per row of the two sets 8 read (id + SFptr), C written 2B * (c+1) * 4
+    abytes = B * 48 + rows * 8 + 2 * B * int(table.shape[0]) * 4
+    out.update({"counts_kernel_ms": ms, "counts_algorithmic_bytes_per_launch": abytes, "rows_last_step": rows,
+                "counts_frac_of_hbm_peak": (abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms else None,
+                "dense_C_bytes": 2 * B * int(table.shape[0]) * 4})
+    return out
 
 
 def bench_walk_sampler(sp, sampler_mod, dev, K):
@@ -791,12 +1146,23 @@ def flatten(out):
         assert len(key) <= 40, key
         if val is not None:
             c[key] = val
-    for name, short in (("cit2 (rng=rand_r: the reference's own stream, bit-exact mode)", "rand_r"), ("collab", "collab"), ("ppa", "ppa"),
-                        ("twitter", "twitter"), ("cit2ppr", "cit2ppr")):
+    # the headline: the driver's region is `value`; the three 100-step regions behind it as min / median / max
+    rv = c.get("region_pairs_per_s") or []
+    if len(rv) > 1:
+        put("headline_median_of_3_x100", median(rv[1:]))
+        put("headline_min_of_3_x100", min(rv[1:]))
+        put("headline_max_of_3_x100", max(rv[1:]))
+    for name, short in (("cit2 (rng=rand_r: the reference's own stream, bit-exact mode)", "rand_r"), ("cit2m4", "cit2m4"), ("collab", "collab"),
+                        ("ppa", "ppa"), ("twitter", "twitter"), ("cit2ppr", "cit2ppr")):
         o = (c.get("other_workloads") or {}).get(name) or {}
-        put(f"{short}_pairs_per_s", o.get("value"))
+        put(f"{short}_pairs_per_s", o.get("value"))             # the MEDIAN of three regions of >= 100 steps
+        put(f"{short}_pairs_per_s_min", (o.get("config") or {}).get("pairs_per_s_min"))
+        put(f"{short}_pairs_per_s_max", (o.get("config") or {}).get("pairs_per_s_max"))
         put(f"{short}_ms_per_step", o.get("ms_per_step"))
+        if "failed" in o:
+            put(f"{short}_failed", str(o["failed"])[:200])
         r = o.get("roofline") or {}
+        put(f"{short}_join_frac", r.get("join_frac"))
         put(f"{short}_frac", r.get("frac"))
         put(f"{short}_kernel_ms", r.get("kernel_ms"))
         put(f"{short}_line_roof_frac", (r.get("random_line_roof") or {}).get("frac"))
@@ -808,6 +1174,11 @@ def flatten(out):
         if "cpu_baseline" in o:
             put(f"{short}_cpu_pairs_per_s", o["cpu_baseline"].get("value"))
             put(f"{short}_cpu_cores", o["cpu_baseline"].get("cores"))
+            put(f"{short}_cpu_t1_pairs_per_s", o["cpu_baseline"].get("t1_pairs_per_s"))
+            put(f"{short}_cpu_t16_pairs_per_s", o["cpu_baseline"].get("t16_pairs_per_s"))
+        ld = o.get("literal_dropin") or {}
+        put(f"{short}_literal_dropin_roots_per_s", ld.get("drop_in_roots_per_s"))
+        put(f"{short}_literal_ref_roots_per_s", ld.get("reference_roots_per_s"))
     ws = (c.get("other_workloads") or {}).get("walk_sampler (collab)") or {}
     put("walk_sampler_collab_roots_per_s", ws.get("value"))
     put("walk_sampler_collab_frac", (ws.get("roofline") or {}).get("frac"))
@@ -815,7 +1186,30 @@ def flatten(out):
     put("hgather_b2048_triplets_per_s", hg.get("value"))
     put("hgather_b2048_ms_per_step", hg.get("ms_per_step"))
     put("hgather_b2048_frac", (hg.get("roofline") or {}).get("frac"))
+    cb = out.get("cpu_baseline") or {}
+    put("cpu_model", cb.get("cpu_model"))
+    put("cpu_t1_pairs_per_s", cb.get("t1_pairs_per_s"))
+    put("cpu_t16_pairs_per_s", cb.get("t16_pairs_per_s"))
+    put("cpu_tbest_pairs_per_s", cb.get("tbest_pairs_per_s"))
+    put("cpu_tbest_nthread", cb.get("tbest_nthread"))
+    ms_ = c.get("mean_stage") or {}
+    for H in (96, 256):
+        put(f"mean_stage_H{H}_pairs_per_s", ms_.get(f"H{H}_fused_pairs_per_s"))
+        put(f"mean_stage_H{H}_ref_style_pairs_per_s", ms_.get(f"H{H}_ref_style_pairs_per_s"))
+        put(f"mean_stage_H{H}_sparse_pairs_per_s", ms_.get(f"H{H}_sparse_pairs_per_s"))
+        put(f"mean_stage_H{H}_gemm_ms", ms_.get(f"H{H}_gemm_ms"))
+    put("mean_stage_counts_kernel_ms", ms_.get("counts_kernel_ms"))
+    put("mean_stage_counts_frac", ms_.get("counts_frac_of_hbm_peak"))
+    put("mean_stage_counts_alg_bytes", ms_.get("counts_algorithmic_bytes_per_launch"))
+    if "failed" in ms_:
+        put("mean_stage_failed", str(ms_["failed"])[:200])
     f = c.get("offline_flow") or {}
+    jb = f.get("J_b1024_keyed") or {}
+    put("offline_J_b1024_eager_pairs_per_s", (jb.get("eager") or {}).get("pairs_per_s"))
+    put("offline_J_b1024_graph_pairs_per_s", (jb.get("graph") or {}).get("pairs_per_s"))
+    put("offline_J_b1024_many64_pairs_per_s", (jb.get("many_64") or {}).get("pairs_per_s"))
+    if "failed" in jb:
+        put("offline_J_b1024_failed", str(jb["failed"])[:200])
     put("offline_all_N_ms", f.get("all_N_sample_to_resident_spg_ms"))
     put("offline_S_roots_per_s", f.get("S_roots_per_s"))
     put("offline_J_table_pairs_per_s", f.get("J_pairs_per_s_table_store"))
@@ -832,6 +1226,7 @@ def flatten(out):
     for key, short in (("B=1024 eager", "b1024_pairs_per_s_eager"), ("B=1024 graph", "b1024_pairs_per_s_graph"),
                        ("B=1024 graph, 4 lanes", "b1024_pairs_per_s_graph_4lanes"), ("B=1024 graph, 8 lanes", "b1024_pairs_per_s_graph_8lanes"),
                        ("B=1024 graph, 8 lanes, inputs ready", "b1024_pairs_per_s_8lanes_ready"),
+                       ("B=1024 many: 64 batches per launch sequence", "b1024_pairs_per_s_many64"),
                        ("B=65536 graph, 8 lanes", "b65536_pairs_per_s_graph_8lanes")):
         put(short, (bg.get(key) or {}).get("pairs_per_s"))
     rl = out.get("roofline") or {}
@@ -839,6 +1234,8 @@ def flatten(out):
     rl["line_roof_lines_per_s"] = lr.get("lines_per_s")         # (the driver keeps the roofline block's scalars too)
     rl["line_roof_frac"] = lr.get("frac")
     rl["l2_miss_lines_per_launch"] = lr.get("l2_miss_lines_per_launch")
+    put("join_frac", rl.get("join_frac"))
+    put("join_traffic_bytes", rl.get("join_traffic"))
     sm = c.get("stage_ms") or {}
     put("walk_kernel_ms", sm.get("walk_sets"))
     put("join_kernel_ms", sm.get("sjoin_fill"))
@@ -849,6 +1246,7 @@ def summary(o):
     keep = {k_: o[k_] for k_ in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype")}
     keep["config"] = {k_: o["config"].get(k_) for k_ in ("workload", "pairs_per_step_per_gpu", "rng", "set_members_last_step",
                                                          "distinct_lp_rows_last_step", "xz_rows_last_step", "graph_nnz", "spg_layout", "stage_ms", "two_stream_loop", "dedup_roots_loop", "spg_members",
+                                                         "timed_loop", "region_pairs_per_s", "pairs_per_s_min", "pairs_per_s_median", "pairs_per_s_max",
                                                          "offline_ppr_stage_s", "join_call_ms_three_launches",
                                                          "frac_of_hbm_peak_whole_join_call") if k_ in o["config"]}
     keep["roofline"] = o["roofline"]
@@ -927,7 +1325,9 @@ def main():
                        small_batches=(world == 1 and not args.no_others),
                        two_stream_extra=not args.no_others,      # --no-others: the profiled command, single-stream steps only
                        csr_variant=not args.no_others,           # ... and no pass with the packed-CSR (table rows) variant
-                       offline=(rank == 0 and world == 1 and not args.no_others and args.scale == 1.0))
+                       offline=(rank == 0 and world == 1 and not args.no_others and args.scale == 1.0),
+                       # the driver's K steps are the headline region; three regions of 100 steps follow, outside its clock
+                       extra_regions=((3, 100) if (world == 1 and not args.no_others) else (0, 0)))
     # BASELINE.json's other single-GPU configurations (and the reference-bit-exact rand_r stream on the headline one),
     # as short passes after the timed region: same code path, >= 5 timed steps each, their own roofline blocks
     # (configs[0], the reference's CPU-runnable collab case, rides on the collab entry as its cpu_baseline).
@@ -935,6 +1335,7 @@ def main():
         others = {}
         budget_s = float(os.environ.get("SUBGACC_OTHERS_BUDGET_S", "900"))
         for key, (wl, rng_o) in {"cit2 (rng=rand_r: the reference's own stream, bit-exact mode)": ("cit2", "rand_r"),
+                                 "cit2m4": ("cit2m4", "philox"),
                                  "collab": ("collab", "philox"), "ppa": ("ppa", "philox"),
                                  "cit2ppr": ("cit2ppr", "philox"), "twitter": ("twitter", "philox")}.items():
             if time.perf_counter() - t_start > budget_s:
@@ -942,13 +1343,23 @@ def main():
                 continue
             try:
                 torch.cuda.empty_cache()
-                Ko, Wo = max(5, min(K, 10)), 2
+                # every pass: three regions of 100 steps (>= 40 ms each; the join-only PPR pass 300), the MEDIAN is its value
+                Ko, Wo = 100, 3
                 if WORKLOADS[wl][0] is None:
-                    o = bench_ppr(args, sp, sampler_mod, dev, 0, 1, None, WORKLOADS[wl][3], B, Ko, Wo)
+                    o = bench_ppr(args, sp, sampler_mod, dev, 0, 1, None, WORKLOADS[wl][3], B, 300, Wo, extra_regions=2)
                 else:
                     o = bench_lp(args, wl, rng_o, B, Ko, Wo, sp, sampler_mod, dev, 0, 1, None,
-                                 with_cpu_baseline=(wl == "collab" and not args.no_cpu_baseline), csr_variant=False)
+                                 with_cpu_baseline=(wl == "collab" and not args.no_cpu_baseline), csr_variant=False,
+                                 extra_regions=(2, Ko), value_is_median=True,
+                                 # a 2-hop step is ~0.4 ms of kernels: replayed as one HIP graph, or the host is what gets measured
+                                 captured=(WORKLOADS[wl][2] <= 3))
                 others[key] = summary(o)
+                if wl == "collab" and not args.no_cpu_baseline:
+                    from surel_plus_amd.graphs import preset_graph
+                    try:
+                        others[key]["literal_dropin"] = literal_dropin(preset_graph("collab", device=dev), WORKLOADS[wl][1], WORKLOADS[wl][2])
+                    except Exception as ex:
+                        others[key]["literal_dropin"] = {"failed": f"{type(ex).__name__}: {ex}"}
             except Exception as ex:   # an extra must never cost the headline line
                 others[key] = {"failed": f"{type(ex).__name__}: {ex}"}
         try:

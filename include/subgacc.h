@@ -498,14 +498,6 @@ size_t subgacc_worklist_workspace_bytes(int64_t n);
 int subgacc_worklist_by_root(const int32_t *roots, int64_t n, int64_t num_nodes, int32_t *worklist, int64_t *n_work,
                              void *workspace, size_t workspace_bytes, void *stream);
 
-/* ---------------------------------------------------------------------------------------------
- * Measurement aid (no reference counterpart): 2048 x 256 lanes each make 4*rounds independent uniformly random 4-byte reads
- * of table[0 .. table_bytes) -- beyond the caches every read moves one 128-byte line, so reads / time is the random-line rate
- * of the memory system for a table of that size, the roof a random walk over such a table sits under.
- * sink: 4 writable bytes on the device.  *reads_out_host (host pointer, optional) receives the number of reads of the launch. */
-int subgacc_line_probe(const void *table, int64_t table_bytes, int32_t rounds, uint32_t seed, void *sink,
-                       int64_t *reads_out_host, void *stream);
-
 #ifdef __cplusplus
 }
 #endif

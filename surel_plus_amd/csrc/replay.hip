@@ -11,6 +11,14 @@
 // including that walk are final, and the round starts again behind it.  Output: the stream position of every root (its
 // shuffle draws) and of every WALK; the walk kernel (walk_sets_kernel, which takes `walk_pos`) then samples the sets in
 // parallel as usual, every walk entering the stream exactly where the reference's sequential loop has it.
+//
+// COST (bounded by the definition, not by the implementation): set_sampler has ONE stream (rng_streams = 1), so one wavefront
+// replays all n*M walks, m dependent global loads per round of up to 64 walks, and a walk that ended early restarts the round
+// behind it -- ~0.1 us per walk on a graph with few dead ends, more with many: an all-N offline stage over a directed graph
+// of millions of nodes takes tens of seconds with the rest of the chip idle.  The host mirror warns from 2^26 walks on
+// (sampler.REPLAY_WARN_WALKS) and remembers the discovery on the DeviceCSR, so a batch is never walked twice to find out again;
+// rng="philox" is the parallel answer for such graphs.  (A speculative pass per block of roots with a fix-up of the blocks behind a
+// short walk would parallelise the common case; not built: the reference's own loader symmetrises every graph, dataloader.py:122-135.)
 #include "walk_common.hpp"
 
 namespace subgacc {

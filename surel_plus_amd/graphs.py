@@ -107,6 +107,74 @@ def directed_powerlaw_graph(N, avg_deg, seed=3, exponent=2.2, device="cuda", chu
     return DeviceCSR(indptr, indices, torch.device(device))
 
 
+def symmetric_powerlaw_graph_big(N, avg_deg, seed=3, exponent=2.2, device="cuda", row_chunks=16, max_weight_frac=0.0005):
+    """The billion-edge graph as the reference's loader would hand it over (dataloader.py:122-135: G + G.T): undirected, SIMPLE,
+    rows sorted, ~N*avg_deg adjacency entries (twitter-follower: 41.65 M nodes, ~1.47 B follows -> up to 2.94 B entries, int64 row
+    offsets).  The directed edges are those of directed_powerlaw_graph at half the out-degree; symmetrising them is a sort of
+    ~3 B 64-bit keys, done here as `row_chunks` independent sorts in HBM: chunk c owns the rows [r0, r1), takes the forward edges
+    of its rows (a contiguous slice: the generator emits them row by row) and the reverse of every edge that POINTS into its
+    rows (one masked pass over the edge list), and sorts + de-duplicates row*N + col -- ~2 * nnz / row_chunks keys at a time.
+    Self loops are dropped.  Peak memory ~ 4 B (edge list) + 16 B * nnz / row_chunks (keys + sort) + the output."""
+    gen = torch.Generator(device=device).manual_seed(int(seed))
+    ranks = torch.arange(1, N + 1, device=device, dtype=torch.float64)
+    w = ranks.pow(-1.0 / (exponent - 1.0))
+    w = torch.minimum(w, w.sum() * max_weight_frac / avg_deg)
+    w = w[torch.randperm(N, device=device, generator=gen)]
+    odeg = torch.clamp((w * (N * avg_deg / 2 / w.sum())).round().to(torch.int64), min=1)       # out-degree: half the final degree
+    optr = torch.zeros(N + 1, dtype=torch.int64, device=device)
+    optr[1:] = torch.cumsum(odeg, 0)
+    E = int(optr[-1].item())
+    cdf = torch.cumsum(w, 0)
+    cdf = (cdf / cdf[-1]).to(torch.float32)
+    del ranks, w, odeg
+    dst = torch.empty(E, dtype=torch.int32, device=device)
+    step = 1 << 28
+    for lo in range(0, E, step):
+        hi = min(lo + step, E)
+        r = torch.rand(hi - lo, device=device, generator=gen, dtype=torch.float32)
+        dst[lo:hi] = torch.searchsorted(cdf, r).clamp_(max=N - 1).to(torch.int32)
+        del r
+    del cdf
+    counts = torch.zeros(N, dtype=torch.int64, device=device)
+    parts = []
+    bounds = [int(round(c * N / row_chunks)) for c in range(row_chunks + 1)]
+    for c in range(row_chunks):
+        r0, r1 = bounds[c], bounds[c + 1]
+        if r1 <= r0:
+            continue
+        e0, e1 = int(optr[r0].item()), int(optr[r1].item())
+        src_f = torch.repeat_interleave(torch.arange(r0, r1, device=device, dtype=torch.int64), optr[r0 + 1:r1 + 1] - optr[r0:r1])
+        key_f = src_f * N + dst[e0:e1].long()                        # forward: (u, v) with u in the chunk
+        del src_f
+        rev = []
+        for lo in range(0, E, step):                                 # reverse: (v, u) for every edge u -> v with v in the chunk
+            hi = min(lo + step, E)
+            d = dst[lo:hi]
+            idx = torch.nonzero((d >= r0) & (d < r1)).view(-1)
+            if idx.numel():
+                u = torch.searchsorted(optr, idx + lo, right=True) - 1
+                rev.append(d[idx].long() * N + u)
+            del d, idx
+        key = torch.cat([key_f] + rev)
+        del key_f, rev
+        key = torch.unique(key)                                       # sorted by (row, col); duplicate edges fall together
+        row = torch.div(key, N, rounding_mode="floor")
+        col = key - row * N
+        keep = row != col
+        row, col = row[keep], col[keep].to(torch.int32)
+        del key, keep
+        counts[r0:r1] = torch.bincount(row - r0, minlength=r1 - r0)
+        parts.append(col)
+        del row
+    indices = torch.cat(parts) if len(parts) > 1 else parts[0]
+    del parts, dst
+    indptr = torch.zeros(N + 1, dtype=torch.int64, device=device)
+    indptr[1:] = torch.cumsum(counts, 0)
+    if indices.numel() < 2**31 - 1:
+        indptr = indptr.to(torch.int32)
+    return DeviceCSR(indptr, indices, torch.device(device))
+
+
 def degree_ordered(csr):
     """The same graph with its nodes renumbered by descending degree (dev experiment: does a hub-first placement of the
     row pointers raise the walk's L2 hit rate?).  Returns (DeviceCSR, perm) with perm[new id] = old id; rows keep their
@@ -129,7 +197,9 @@ def degree_ordered(csr):
 def preset_graph(name, device="cuda", scale=1.0):
     if name == "cit2loc":     # the cit2-like graph with communities of consecutive ids (community_graph)
         return community_graph(max(int(2_927_963 * scale), 64), 20.7, seed=4, device=device)
-    if name == "twitter":
+    if name == "twitter":              # G + G.T of ~1.47 B follows, as dataloader.py:122-135 would hand it over (int64 row offsets)
+        return symmetric_powerlaw_graph_big(max(int(41_652_230 * scale), 1000), 70.5, seed=3, device=device)
+    if name == "twitter_directed":     # rounds 1-3's stand-in: directed, a multigraph, rows unsorted (no global sort needed)
         return directed_powerlaw_graph(max(int(41_652_230 * scale), 1000), 70.5, seed=3, device=device)
     p = PRESETS[name]
     return powerlaw_graph(max(int(p["N"] * scale), 16), p["avg_deg"], seed=p["seed"], device=device)

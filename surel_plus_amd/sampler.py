@@ -37,38 +37,42 @@ HOP_RECORDS = os.environ.get("SUBGACC_HOP_RECORDS", "auto")
 HOP_RECORDS_MIN_BYTES = 64 << 20      # adjacency bytes from which records are built in "auto" mode
 HOP_RECORDS_MIN_DEG_BITS = 12
 HOP_RECORDS_MAX_FREE_FRACTION = 0.25    # of the free device memory, in "auto" mode
-# a single-chunk batch of SORT_ROOTS_MIN .. SORT_ROOTS_MAX roots is walked in ascending order of root id (sample_sets; the buffered
-# step has its own switch in spjoin.py: same default, same environment variable)
-SORT_ROOTS = os.environ.get("SUBGACC_SORT_ROOTS", "1") == "1"
+# a single-chunk batch of SORT_ROOTS_MIN .. SORT_ROOTS_MAX roots is walked in ascending order of root id (sample_sets(sort_roots=True);
+# the buffered step: StepBuffers(sort_roots=True)).  Nothing observable changes; cit2-like step +5.7 % pairs/s, twitter-like +5.6 %.
 SORT_ROOTS_MIN, SORT_ROOTS_MAX = 16384, 1 << 20
 
 # Key rows (csrc/walk_rows.hip KR form + subgacc_sjoin_fill_keyrows): a strided batch that will not be numbered carries its
 # members' 32-bit LP keys instead of slots of a table of distinct rows; the join unpacks a key into its feature row itself.
 # No table, no registration, no unpack pass: -14 % walk-kernel time on the cit2-like batch, -23 % on collab.  Asking such a
 # batch for its numbering afterwards (number(), c, enc_int16(), to_csr()) samples it again with the table form.
-KEY_ROWS = os.environ.get("SUBGACC_KEY_ROWS", "1") == "1" and os.environ.get("SUBGACC_WALK_ROWS", "1") != "0"   # (the dev switch
-#                                                    that disables the specialised kernel takes its key-rows form with it)
+# sample_sets(key_rows=False) / StepBuffers(key_rows=False) keep the table form (tests cross both).
 
 
 # Batched registration (csrc/keyrows.hip): a store that is KEPT (subg_matrix: packed rows + numbered LP rows) is sampled with the
 # key-rows kernel too; its keys are registered in the table of distinct rows by one pass over the rows, and only the few
 # thousand roots that may be the first to show a row are walked again for their first-visit order (subgacc_walk_tags).
-# "0": the table form of the walk kernel registers inside every root's epilogue, as before round 3 (A/B, and the shapes key rows do
-# not serve -- 4 hops, keys beyond 31 bits -- always take it).  Results are identical.
-BATCHED_REGISTRATION = os.environ.get("SUBGACC_BATCHED_REG", "1") == "1" and os.environ.get("SUBGACC_WALK_ROWS", "1") != "0"
+# sample_sets(batched_registration=False): the table form of the walk kernel registers inside every root's epilogue, as before
+# round 3 (tests cross both; the shapes key rows do not serve -- keys beyond 31 bits -- always take it).  Results are identical.
 
 
-KR_TRANSLATE = os.environ.get("SUBGACC_KR_TRANSLATE", "0") == "1"    # dev A/B: see sample_sets
-
-
-def key_rows_ok(num_walks, num_steps):
-    """does the fused-row kernel have a key-rows form for this shape? (32-bit keys, 2 or 3 hops, a 512 / 1,024-slot table)"""
+def _table_slots(num_walks, num_steps):
     q = num_walks * num_steps + 1
     t = 64
     while t < q + q // 4 + 1:
         t <<= 1
+    return t
+
+
+def rows_kernel_takes(num_walks, num_steps, bucket=-1):
+    """does the specialised fused-row kernel (csrc/walk_rows.hip: launch_walk_rows) take this shape?  set_sampler order, first hop
+    without replacement and no raw walks are the caller's to check; a truncating `bucket` leaves it to walk_sets_kernel<SPG>."""
+    return (bucket <= 0 and 2 <= num_steps <= 4 and num_walks <= 256 and _table_slots(num_walks, num_steps) in (512, 1024))
+
+
+def key_rows_ok(num_walks, num_steps):
+    """does the fused-row kernel have a key-rows form for this shape? (32-bit keys, 2 or 3 hops, a 512 / 1,024-slot table)"""
     return (num_steps in (2, 3) and num_steps * int(num_walks).bit_length() + 1 <= 31 and num_walks <= 256
-            and t in (512, 1024))
+            and _table_slots(num_walks, num_steps) in (512, 1024))
 
 
 # bench.py sets this to a callable(name) -> context manager that brackets one kernel launch with HIP events
@@ -299,6 +303,10 @@ class SampledSets:
     def X(self):
         self.resolve()
         if self.strided and self._members is None:
+            # (root dedup: counted from the buffers' sizes on first use -- which by then may belong to a later batch)
+            if self._keyctx is not None and not self._keyctx["fresh"]():
+                raise _lib.SubgAccError("the member count of this batch was not asked for before its step buffers took a later "
+                                        "batch (X / nnz must be read before the buffers are re-used or the captured step replayed)")
             self._members = int(self.nsize.sum().item())
         return self._members if self.strided else self.ids.numel()
 
@@ -475,8 +483,9 @@ def check_walk_flags(sets, fl):
     if fl[0]:
         raise RandRDeadEnd(
             "rng='rand_r': a walk reached a node without out-edges, so the number of draws is data dependent (the "
-            "reference's graphs are symmetrised, dataloader.py:122-135) and the stream has to be replayed: sample this "
-            "batch again with lazy=False (which does so by itself), or use rng='philox'.")
+            "reference's graphs are symmetrised, dataloader.py:122-135) and the stream has to be replayed.  sample_sets / "
+            "sample_spg / sample_and_gather WITHOUT buffers= and with lazy=False do so by themselves; a lazy batch or "
+            "StepBuffers(rng='rand_r') cannot (nothing is read back before the join): use those forms, or rng='philox'.")
     sets.n_overflow = fl[1]
     if fl[1] and _lib.VERBOSE:
         print(f"#SubGAcc: {fl[1]} keys exceed the buffer, try a larger bucket size > {sets.stride}.")
@@ -494,15 +503,12 @@ def _rng_positions(L, cfg, csr, q, n, rng_streams, calls_before, st):
     return rng_pos, rng_seed
 
 
-def walk_kernel_name(csr, num_walks, hops, fused_rows):
+def walk_kernel_name(csr, num_walks, hops, fused_rows, bucket=-1):
     """which kernel a sample_sets(...) launch of this shape runs (set_sampler form; csrc/walk.hip:launch_walk decides):
-    reporting only -- bench.py labels its roofline block with it"""
-    q = num_walks * hops + 1
-    t = 64
-    while t < q + q // 4 + 1:
-        t <<= 1
+    bench.py labels its roofline block with it, and the callers that hand the kernel a work list ask it first (only
+    walk_rows_kernel reads one)"""
     if fused_rows:
-        return "walk_rows_kernel" if (2 <= hops <= 4 and t in (512, 1024) and num_walks <= 256) else "walk_sets_kernel<SPG>"
+        return "walk_rows_kernel" if rows_kernel_takes(num_walks, hops, bucket) else "walk_sets_kernel<SPG>"
     return "walk_pipe_kernel" if (num_walks <= 256 and 1 <= hops <= 6) else "walk_sets_kernel"
 
 
@@ -513,14 +519,28 @@ def _cat(parts, dtype, dev):
     return parts[0] if len(parts) == 1 else torch.cat(parts)
 
 
+REPLAY_WARN_WALKS = 1 << 26      # rand_r replay (csrc/replay.hip) is sequential per stream: warn from this many walks on
+
+
 def _replays_dead_ends(fn):
+    """rand_r on a graph with dead ends: the first batch that meets one raises RandRDeadEnd and is sampled again with the replayed
+    stream; the discovery is remembered on the DeviceCSR (`_rand_r_dead_ends`), so later calls replay straight away instead of
+    walking every batch twice (subg_matrix over all N of a directed graph used to)."""
     @functools.wraps(fn)
     def wrapper(*a, **kw):
+        csr = a[0] if a else kw.get("csr")
+        rng = kw.get("rng", a[6] if len(a) > 6 else "rand_r")
         if kw.get("walk_replay"):
             return fn(*a, **kw)
+        if rng == "rand_r" and getattr(csr, "_rand_r_dead_ends", False):
+            return fn(*a, **dict(kw, walk_replay=True))
         try:
             return fn(*a, **kw)
         except RandRDeadEnd:
+            try:
+                csr._rand_r_dead_ends = True
+            except AttributeError:
+                pass
             return fn(*a, **dict(kw, walk_replay=True))
     return wrapper
 
@@ -529,8 +549,8 @@ def _replays_dead_ends(fn):
 def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, rng="rand_r", first_hop_wo=True,
                 order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False, rng_streams=1,
                 calls_before=0, dedup=True, keep_keys=None, staging_bytes=None, uniq_capacity=UNIQ_CAPACITY,
-                uniq_small_limit=0, fused_rows=False, lazy=False, strided=False, number_rows=True, key_rows=None,
-                walk_replay=False):
+                uniq_small_limit=0, fused_rows=False, lazy=False, strided=False, number_rows=True, key_rows=True,
+                walk_replay=False, batched_registration=True, sort_roots=True):
     """Run the sampler for `query` (roots) on the GPU.  See SampledSets.
 
     rng="rand_r" on a graph with dead ends (directed graphs: a reached node without out-edges draws nothing in the reference,
@@ -581,6 +601,14 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
         return None
 
     walk_pos = None
+    if walk_replay and n and n * M >= REPLAY_WARN_WALKS:
+        # csrc/replay.hip: ONE wavefront per rand_r stream replays its walks 64 at a time, m dependent loads per round (the stream
+        # is sequential by definition, and set_sampler has a single stream): ~0.1 us per walk, i.e. tens of seconds from 10^8
+        # walks on -- the price of bit-exactness with the reference on a graph it was not written for.  rng="philox" has no such cost.
+        import warnings
+        warnings.warn(f"rng='rand_r' on a graph with dead ends: replaying the sequential stream of {n * M:,} walks on one "
+                      f"wavefront per stream (~{n * M * 1e-7:.0f} s); rng='philox' samples the same distribution in parallel",
+                      RuntimeWarning, stacklevel=3)
     if walk_replay and n:      # the stream replayed: the position of every root and of every walk (subgacc_rng_replay)
         rng_pos = torch.empty(n, dtype=torch.int32, device=dev)
         rng_seed = torch.empty(n, dtype=torch.int32, device=dev)
@@ -590,12 +618,10 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     else:
         rng_pos, rng_seed = _rng_positions(L, cfg, csr, q, n, rng_streams, calls_before, st)
     # key rows: strided fused rows that nobody asked to number carry LP keys instead of table slots (module header)
-    if key_rows is None:
-        key_rows = KEY_ROWS
     key_rows = bool(key_rows and strided and fused_rows and not number_rows and bucket <= 0 and n > 0 and chunk == n
                     and key_rows_ok(M, m) and not walk_replay)
     # a store that is kept: key rows as well, registered by one pass over the rows (csrc/keyrows.hip, module header)
-    batched = bool(BATCHED_REGISTRATION and fused_rows and dedup and not strided and bucket <= 0 and n > 0 and key_rows_ok(M, m)
+    batched = bool(batched_registration and fused_rows and dedup and not strided and bucket <= 0 and n > 0 and key_rows_ok(M, m)
                    and not walk_replay)
     table = None
     if dedup and not key_rows:
@@ -619,8 +645,8 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
         # a BATCH sampled in one chunk walks its rows in ascending order of root id, like the buffered step (csrc/worklist.hip:
         # repeated and neighbouring roots share their lines in L2; the rows stay where they are).  Beyond a million roots the call
         # is the offline stage over a whole graph, whose nodes come in order already (listing them again cost it 1.5 %).
-        by_root = (fused_rows and chunk == n and SORT_ROOTS_MIN <= cn <= SORT_ROOTS_MAX and SORT_ROOTS and walk_pos is None and
-                   walk_kernel_name(csr, M, m, True) == "walk_rows_kernel")
+        by_root = (fused_rows and chunk == n and SORT_ROOTS_MIN <= cn <= SORT_ROOTS_MAX and sort_roots and walk_pos is None and
+                   rows_kernel_takes(M, m, bucket))
         if by_root:
             wl = torch.empty(cn, dtype=torch.int32, device=dev)
             nwl = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -655,8 +681,6 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
                                             ptr(st_slot), ptr(flags), st))
             st_aux = st_slot
         numbered_early = (fused_rows or finish) and chunk == n and (number_rows or not strided)
-        if batched and KR_TRANSLATE:      # one chunk handled like one of several: the copy registers, one flat pass translates
-            numbered_early = False
         count = status[2:3]
         total = None
         if batched:
@@ -750,7 +774,7 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
 
     # number the distinct LP rows by first occurrence (subg_acc.c:957-1000)
     x_dev = row_off[n:n + 1]
-    if n and fused_rows and chunk == n and not (batched and KR_TRANSLATE):
+    if n and fused_rows and chunk == n:
         pass                          # numbered before the copy, which already wrote SFptr+1
     elif fused_rows or lazy:          # table-only direct ranking (tags need not be element positions)
         count = status[2:3]

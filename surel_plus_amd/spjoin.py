@@ -283,6 +283,62 @@ def gather(edge, x, device=None, ptr=True, encode=None, out=None, lazy=False):
     return _checked(*sjoin(spg, own, None, encode, ptr_mode=ptr, pair_block=e.shape[1], out=out, lazy=lazy), lazy=lazy)
 
 
+def split_batches(xz, seg, batch_pairs):
+    """The result of a join over nb batches laid out [u_0 | v_0 | u_1 | v_1 | ...] (gather_many, sample_and_gather_many, a
+    StepBuffers made with batch=) as nb reference-shaped results: [(xz_b, indptr_b)] with indptr_b int64 [2B+1] starting at 0
+    (train.py:21-22) and xz_b the rows of batch b -- views of `xz`, plus ONE [nb, 2B+1] tensor for all the pointers.  One small
+    host read (the nb+1 batch boundaries)."""
+    P = 2 * int(batch_pairs)
+    S = seg.numel() - 1
+    if P <= 0 or S % P:
+        raise ValueError(f"{S} segments are not a whole number of batches of {batch_pairs} pairs")
+    nb = S // P
+    bounds = seg[::P]                                         # [nb+1]: first row of every batch, and the total
+    ptrs = seg.as_strided((nb, P + 1), (P, 1)) - bounds[:nb, None]
+    b = bounds.tolist()
+    return [(xz[b[i]:b[i + 1]], ptrs[i]) for i in range(nb)]
+
+
+def gather_many(edges, x, device=None, ptr=True, encode=None, out=None):
+    """gather() for MANY reference-sized batches at once: `edges` [nb, 2, B] (the batches of an epoch are known when it starts:
+    train.py:120 draws the DataLoader permutation up front) joined in ONE launch sequence -- one size pass, one scan, one fill
+    over nb*B pairs -- instead of nb times three launches of 1,024 pairs that cannot fill the chip (main.py:32).  Returns
+    [(xz_b, ind_b)] * nb, bit for bit what `gather(edges[b], x, device, ptr, encode)` returns for every b: xz_b float32
+    [R_b, 2, k] (views of one buffer, `out` if given), ind_b int64 [2B+1] segment pointers from 0 (ptr=True) or int64 [R_b]
+    segment ids 0..2B-1 (ptr=False).  Two small host reads for the whole call (total rows, batch boundaries).
+    `edges` may also be a list of [2, B_i] arrays: runs of equal B are fused, the rest (an epoch's short last batch) joined singly."""
+    spg = _as_spg(x)
+    if isinstance(edges, (list, tuple)):
+        res, i = [], 0
+        while i < len(edges):
+            j = i
+            while j + 1 < len(edges) and tuple(edges[j + 1].shape) == tuple(edges[i].shape):
+                j += 1
+            if j == i:
+                res.append(gather(edges[i], spg, device, ptr=ptr, encode=encode))
+            else:
+                stack = torch.stack([_as_rows(e, spg.device) for e in edges[i:j + 1]])
+                res.extend(gather_many(stack, spg, device, ptr=ptr, encode=encode))
+            i = j + 1
+        return res
+    e = _as_rows(edges, spg.device)
+    if e.dim() != 3 or e.shape[1] != 2:
+        raise ValueError("gather_many: edges must be [nb, 2, B]")
+    nb, _, B = e.shape
+    if nb == 0 or B == 0:
+        return [gather(e[b], spg, device, ptr=ptr, encode=encode) for b in range(nb)]
+    own = e.contiguous().view(-1)                              # [u_0 | v_0 | u_1 | v_1 | ...]: mirrored blocks of B segments
+    xz, seg, flags = sjoin(spg, own, None, encode, ptr_mode=True, pair_block=B, out=out)
+    _checked(xz, seg, flags)
+    parts = split_batches(xz, seg, B)
+    if ptr:
+        return parts
+    out_l = []
+    for xz_b, p in parts:       # segment ids (train.py:25-30, the LSTM aggregator): one repeat_interleave per batch, rows known
+        out_l.append((xz_b, torch.repeat_interleave(torch.arange(2 * B, device=spg.device), p[1:] - p[:-1], output_size=xz_b.shape[0])))
+    return out_l
+
+
 def hgather(hedge, x, device=None, encode=None):
     """train.py:48-72.  Blocks [U|w ; W|u ; V|w ; W|v], always segment ids; encode is mandatory."""
     if encode is None:
@@ -337,10 +393,19 @@ class StepBuffers:
     rows of the first occurrences (sets.n_distinct of them; bufs.roots == NO_ROOT elsewhere), the other rows are empty.
     The hash is stamped with a per-step generation kept on the device: a captured step replays correctly."""
 
-    def __init__(self, csr, pairs, num_walks=200, num_steps=3, uniq_capacity=1 << 17, out=None, dedup_roots=False, rng="philox"):
+    def __init__(self, csr, pairs, num_walks=200, num_steps=3, uniq_capacity=1 << 17, out=None, dedup_roots=False, rng="philox",
+                 key_rows=True, sort_roots=True, batch=None):
         from .sampler import FUSED_MAX_Q
         L, dev = lib(), csr.device
         self.B, self.M, self.m = int(pairs), int(num_walks), int(num_steps)
+        # batch=b: the `pairs` of a step are pairs/b reference-sized batches of b pairs each, handed over as [nb, 2, b] (rows
+        # [u_0 | v_0 | u_1 | v_1 | ...]); the join pairs row j with its mirror inside ITS batch, and split_batches() cuts the
+        # result into the nb reference-shaped (xz, indptr).  None: one batch, [2, pairs].
+        self.batch = self.B if batch is None else int(batch)
+        if self.batch <= 0 or self.B % self.batch:
+            raise ValueError(f"StepBuffers: pairs = {self.B} is not a whole number of batches of {batch}")
+        if self.batch != self.B and dedup_roots:
+            raise ValueError("StepBuffers: root dedup works on one batch (batch=None)")
         n, self.stride, self.k = 2 * self.B, self.M * self.m + 1, self.m + 1
         if self.stride > FUSED_MAX_Q or self.m < 1:
             raise ValueError(f"StepBuffers: num_walks*num_steps+1 = {self.stride} exceeds what the fused-row walk kernel holds")
@@ -349,8 +414,9 @@ class StepBuffers:
         self.nsize = torch.empty(n, dtype=torch.int32, device=dev)
         self.ids = torch.empty(n * self.stride, dtype=torch.int32, device=dev)
         self.slot = torch.empty(n * self.stride, dtype=torch.int32, device=dev)
-        from .sampler import KEY_ROWS, key_rows_ok
-        self.keyrows = bool(KEY_ROWS and key_rows_ok(self.M, self.m))    # rows of LP keys: no table, no feature table
+        from .sampler import key_rows_ok
+        self.keyrows = bool(key_rows and key_rows_ok(self.M, self.m))    # rows of LP keys: no table, no feature table
+        self.sort_roots = bool(sort_roots)     # the walk kernel takes the rows in ascending order of root id (csrc/worklist.hip)
         self.table = None if self.keyrows else torch.empty(L.subgacc_uniq_table_bytes(self.capacity), dtype=torch.uint8, device=dev)
         self.tail = torch.zeros(n + 1 + 4 + 1, dtype=torch.int64, device=dev)  # seg [n+1] | status [4] | distinct roots [1]
         self.seg, self.status, self.n_distinct = self.tail[: n + 1], self.tail[n + 1: n + 5], self.tail[n + 5:]
@@ -358,6 +424,10 @@ class StepBuffers:
         self.rng = rng
         if rng not in ("philox", "rand_r") or (rng == "rand_r" and self.dedup):
             raise ValueError("StepBuffers: rng is 'philox' or 'rand_r'; root dedup needs 'philox' (a rand_r set depends on its place in the stream)")
+        if rng == "rand_r" and getattr(csr, "_rand_r_dead_ends", False):
+            raise ValueError("StepBuffers(rng='rand_r'): this graph has dead ends (a walk reached a node without out-edges), its "
+                             "rand_r stream has to be replayed per batch -- sample_and_gather(..., rng='rand_r') without buffers= "
+                             "does that; the buffered step cannot")
         if rng == "rand_r":      # the rows' places in the reference's sequential stream (subgacc_rng_positions), per step
             self.rng_pos = torch.empty(n, dtype=torch.int32, device=dev)
             self.rng_seed = torch.empty(n, dtype=torch.int32, device=dev)
@@ -404,8 +474,10 @@ def _buffered_step(csr, e, bufs, seed, out):
     from .sampler import SampledSets, _timed, make_cfg, walk_kernel_name
     L, st, dev = lib(), stream_ptr(), csr.device
     B, M, m, k, n = bufs.B, bufs.M, bufs.m, bufs.k, 2 * bufs.B
-    if tuple(e.shape) != (2, B):
-        raise ValueError(f"these StepBuffers were made for [2, {B}] pairs")
+    PB = bufs.batch              # pairs per mirrored block of the segment list
+    if tuple(e.shape) != ((2, B) if PB == B else (B // PB, 2, PB)):
+        raise ValueError(f"these StepBuffers were made for [2, {B}] pairs" if PB == B else
+                         f"these StepBuffers were made for [{B // PB}, 2, {PB}] pairs")
     e = e.contiguous()
     flags = bufs.status.view(torch.int32)[:4]
     cfg = make_cfg(csr, M, m, -1, seed, bufs.rng, records=(2 <= m <= 4))     # (only the fused-row kernel of 2..4 hops reads hop records)
@@ -427,7 +499,7 @@ def _buffered_step(csr, e, bufs, seed, out):
                                             ptr(bufs.worklist), ptr(bufs.n_distinct), ptr(bufs.table), 0 if kr else bufs.capacity,
                                             ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize), ptr(flags), st))
         own, partner = bufs.own, bufs.partner
-    elif SORT_ROOTS and n >= SORT_ROOTS_MIN and walk_kernel_name(csr, M, m, True) == "walk_rows_kernel":
+    elif bufs.sort_roots and n >= SORT_ROOTS_MIN and walk_kernel_name(csr, M, m, True) == "walk_rows_kernel":
         # the rows stay where the batch has them; the walk kernel takes them in ascending order of their root's id (a work list):
         # roots that are neighbours in id space -- the same community of a graph with id locality -- are walked at the same time on
         # the same XCD and share its L2
@@ -440,7 +512,7 @@ def _buffered_step(csr, e, bufs, seed, out):
             check(L.subgacc_walk_spg_list(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n, rp, rs,
                                           ptr(bufs.sorted_list), ptr(bufs.n_all), ptr(bufs.table), 0 if kr else bufs.capacity,
                                           ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize), ptr(flags), st))
-        own, partner = _arange_segments(B, dev)
+        own, partner = _arange_segments(B, dev, PB)
     else:
         check(L.subgacc_step_prologue(ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.status), 4, ptr(e), ptr(bufs.roots), n, st))
         if rr:
@@ -450,7 +522,7 @@ def _buffered_step(csr, e, bufs, seed, out):
             check(L.subgacc_walk_spg(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n, 0, rp, rs,
                                      ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize),
                                      ptr(flags), st))
-        own, partner = _arange_segments(B, dev)
+        own, partner = _arange_segments(B, dev, PB)
     check(L.subgacc_sjoin_sizes_rows(ptr(bufs.nsize), n, ptr(own), ptr(partner), n, ptr(bufs.seg), ptr(flags), ptr(bufs.ws),
                                      bufs.ws.numel(), st))
     if not kr:
@@ -464,11 +536,11 @@ def _buffered_step(csr, e, bufs, seed, out):
     with _timed("sjoin_fill"):
         if kr:
             check(L.subgacc_sjoin_fill_keyrows(ptr(bufs.nsize), n, bufs.stride, ptr(bufs.ids), ptr(bufs.slot), ptr(own), ptr(partner),
-                                               n, ptr(bufs.seg), M, m, ptr(xz), B, ptr(flags), st))
+                                               n, ptr(bufs.seg), M, m, ptr(xz), PB, ptr(flags), st))
         else:
             check(L.subgacc_sjoin_fill_rows(ptr(bufs.nsize), n, bufs.stride, ptr(bufs.ids), ptr(bufs.slot), None, 0, ptr(own),
                                             ptr(partner), n, ptr(bufs.seg), ptr(bufs.feat), bufs.capacity + 1, k, ptr(xz), None,
-                                            None, B, ptr(flags), st))
+                                            None, PB, ptr(flags), st))
     sets = SampledSets(bufs.nsize, None, bufs.ids, None, None, None, M, m, bufs.stride, None)
     sets.slot, sets.table, sets.capacity, sets.strided = bufs.slot, bufs.table, (0 if kr else bufs.capacity), True
     if kr:
@@ -498,7 +570,9 @@ def sample_and_gather(csr, edge, num_walks=200, num_steps=3, seed=111413, rng="p
     lazy: sets.prefetch() / sets.resolve() as with lazy=True, xz is a view of out= or of the buffers' own output)."""
     from .spg import sample_spg
     e = _as_rows(edge, csr.device)
-    B = e.shape[1]
+    if buffers is None and e.dim() != 2:
+        raise ValueError("sample_and_gather: edge must be [2, B] (many batches at once: sample_and_gather_many)")
+    B = e.shape[-1]
     if buffers is not None:     # the allocation-free form of a serving loop: same rows, same (xz, indptr), lazily resolved
         if (dedup_roots and not buffers.dedup) or rng != buffers.rng or strided is False or kw.get("fused") is False or \
                 kw.get("bucket", -1) > 0 or (num_walks, num_steps) != (buffers.M, buffers.m) or \
@@ -531,26 +605,56 @@ def sample_and_gather(csr, edge, num_walks=200, num_steps=3, seed=111413, rng="p
     return xz, ind, sets
 
 
+def sample_and_gather_many(csr, edges, num_walks=200, num_steps=3, seed=111413, rng="philox", out=None, buffers=None, **kw):
+    """sample_and_gather() for MANY reference-sized batches at once (main.py:32: 1,024 pairs -- 2,048 roots cannot fill the
+    chip): `edges` [nb, 2, B]; all nb*2B endpoints are sampled by ONE walk launch and joined by ONE join launch, and the result
+    is cut into nb reference-shaped pieces -- [(xz_b, indptr_b)] * nb, bit for bit what sample_and_gather(csr, edges[b], ...)
+    returns for every b with rng="philox" (a root's set is a function of (seed, root id)), plus the sets of the whole call.
+    buffers=StepBuffers(csr, nb*B, ..., batch=B): the allocation-free six-launch form; the sets are resolved here (one read)."""
+    e = _as_rows(edges, csr.device)
+    if e.dim() != 3 or e.shape[1] != 2:
+        raise ValueError("sample_and_gather_many: edges must be [nb, 2, B]")
+    nb, _, B = e.shape
+    if rng != "philox":
+        raise ValueError("sample_and_gather_many needs rng='philox' (a rand_r set depends on its root's place in the stream, i.e. on "
+                         "which other batches are sampled with it)")
+    if buffers is not None:
+        if buffers.batch != B or buffers.B != nb * B or buffers.dedup:
+            raise ValueError(f"buffers= must be StepBuffers(csr, {nb * B}, ..., batch={B})")
+        xz, seg, sets = sample_and_gather(csr, e, num_walks=num_walks, num_steps=num_steps, seed=seed, rng=rng, out=out, buffers=buffers, **kw)
+        sets.resolve()
+        return split_batches(xz, seg, B), sets
+    from .spg import sample_spg
+    kw.setdefault("number_rows", False)
+    z, sets = sample_spg(csr, e.reshape(-1).to(torch.int32), num_walks=num_walks, num_steps=num_steps, seed=seed, rng=rng,
+                         strided=True, **kw)
+    table = z.slot_table() if sets.strided else sets.feature_table()
+    own = torch.arange(nb * 2 * B, device=e.device, dtype=torch.int64)
+    xz, seg = _checked(*sjoin(_as_spg(z), own, None, table, ptr_mode=True, pair_block=B, out=out))
+    return split_batches(xz, seg, B), sets
+
+
 # the buffered step walks its rows in ascending order of root id (csrc/worklist.hip: one radix pass, two small launches): cit2-like
-# step +5.7 % pairs/s, twitter-like +5.6 %, collab +1.8 %, ppa +2.1 %; "0": batch order (A/B).  Nothing observable changes.
-SORT_ROOTS = os.environ.get("SUBGACC_SORT_ROOTS", "1") == "1"
+# step +5.7 % pairs/s, twitter-like +5.6 %, collab +1.8 %, ppa +2.1 %; StepBuffers(sort_roots=False): batch order.  Nothing observable changes.
 SORT_ROOTS_MIN = 16384      # rows from which the two extra launches pay (a 1,024-pair step is 2,048 roots: one workgroup per resident slot)
 _ARANGE_SEGMENTS = {}
 _CACHE_LOCK = threading.Lock()     # the reference's pgather calls the join from 4 Python threads (train.py:88-99)
 
 
-def _arange_segments(B, device):
+def _arange_segments(B, device, block=None):
     """gather()'s segment lists for edge = [[0..B), [B..2B)] -- the rows of a batch sampled endpoint by endpoint -- kept per
     (B, device): a serving loop does not rebuild them (three small kernels) for every batch.  Shared between threads and
-    streams: built under a lock and COMPLETE (the building stream is synchronised, once) before anybody else can see them."""
-    key = (int(B), str(device))
+    streams: built under a lock and COMPLETE (the building stream is synchronised, once) before anybody else can see them.
+    block = b < B: the B pairs are B/b batches laid out [u_0 | v_0 | u_1 | v_1 | ...], every row mirrored inside its batch."""
+    block = int(B) if block is None else int(block)
+    key = (int(B), str(device), block)
     hit = _ARANGE_SEGMENTS.get(key)
     if hit is None:
         with _CACHE_LOCK:
             hit = _ARANGE_SEGMENTS.get(key)
             if hit is None:
                 own = torch.arange(2 * B, device=device, dtype=torch.int64)
-                hit = (own, torch.cat([own[B:], own[:B]]).contiguous())
+                hit = (own, own.view(-1, 2, block).flip(1).contiguous().view(-1))
                 if not torch.cuda.is_current_stream_capturing():
                     torch.cuda.current_stream(own.device).synchronize()
                 _ARANGE_SEGMENTS[key] = hit

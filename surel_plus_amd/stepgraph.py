@@ -25,23 +25,27 @@ _DEBUG = os.environ.get("SUBGACC_DEBUG", "0") == "1"
 
 class CapturedStep:
     def __init__(self, csr, pairs, num_walks=200, num_steps=3, seed=111413, rng="philox", uniq_capacity=1 << 17,
-                 strided=None, fused=None, warmup=2, dedup_roots=False):
+                 strided=None, fused=None, warmup=2, dedup_roots=False, batch=None):
         """pairs = B, the fixed number of query pairs per step; num_steps = walk hops.  dedup_roots=True: every distinct
         endpoint of a batch is sampled once (StepBuffers(dedup_roots=True): its per-step stamp lives on the device, so the
         replayed graph works like a launched step); `distinct_roots` after finish()."""
         self.csr, self.B, self.M, self.m = csr, int(pairs), int(num_walks), int(num_steps)
         dev = csr.device
-        self.edge = torch.zeros((2, self.B), dtype=torch.int64, device=dev)
+        # batch=b: the step takes pairs/b reference-sized batches as [nb, 2, b] (StepBuffers(batch=b)); finish_batches() cuts the result
+        self.batch = self.B if batch is None else int(batch)
+        if self.batch != self.B and (rng != "philox" or strided is False or fused is False or dedup_roots):
+            raise ValueError("CapturedStep(batch=) needs the buffered form of the step (rng='philox', fused strided rows, no root dedup)")
+        self.edge = torch.zeros((2, self.B) if self.batch == self.B else (self.B // self.batch, 2, self.batch), dtype=torch.int64, device=dev)
         self.out = torch.empty(2 * self.B * (self.M * self.m + 1) * 2 * (self.m + 1), dtype=torch.float32, device=dev)
         self._kw = dict(num_walks=self.M, num_steps=self.m, seed=seed, rng=rng, out=self.out, lazy=True, strided=strided,
                         fused=fused, uniq_capacity=uniq_capacity)
         if rng == "philox" and strided is not False and fused is not False:
             try:      # the allocation-free six-launch form of the step (spjoin.StepBuffers) where it applies
                 self._kw["buffers"] = StepBuffers(csr, self.B, self.M, self.m, uniq_capacity=uniq_capacity, out=self.out,
-                                                  dedup_roots=dedup_roots)
+                                                  dedup_roots=dedup_roots, batch=batch)
                 self._kw["dedup_roots"] = bool(dedup_roots)
             except ValueError:
-                if dedup_roots:
+                if dedup_roots or self.batch != self.B:
                     raise
         elif dedup_roots:
             raise ValueError("dedup_roots=True needs the buffered form of the step (rng='philox', fused strided rows)")
@@ -80,8 +84,8 @@ class CapturedStep:
         """queue one step for `edge` [2, B] (node ids, on the device): copy-in, graph replay, status on its way to
         pinned host memory.  Nothing waits for the GPU here.  stream: the current stream, if the caller has it at hand
         (spares torch's look-up of it, ~8 us)."""
-        if tuple(edge.shape) != (2, self.B):
-            raise ValueError(f"this step was captured for [2, {self.B}] pairs")
+        if tuple(edge.shape) != tuple(self.edge.shape):
+            raise ValueError(f"this step was captured for {list(self.edge.shape)} pairs")
         if edge is not self.edge:
             self.edge.copy_(edge, non_blocking=True)
         if self._dedup_bufs is not None:
@@ -123,6 +127,13 @@ class CapturedStep:
                                     "larger uniq_capacity")
         self.distinct_rows, self.members = (st[4] if self.sets.ukeys is not None else None), st[5]   # None: not numbered
         return self.xz[: st[6]], self.ind
+
+
+    def finish_batches(self):
+        """finish() for a step captured with batch=b: [(xz_i, indptr_i)] for its pairs/b reference-sized batches (spjoin.split_batches)"""
+        from .spjoin import split_batches
+        xz, ind = self.finish()
+        return split_batches(xz, ind, self.batch)
 
 
 class CapturedStepPool:
@@ -213,16 +224,14 @@ class CapturedJoin:
             self._host.copy_(self._tail, non_blocking=True)
         self._event = torch.cuda.Event()
 
-    def __call__(self, edge, stream=None):
+    def __call__(self, edge):
+        """queue the join of `edge` [2, B] on the CURRENT stream (copy-in, replay and the completion event all go there)"""
         if tuple(edge.shape) != (2, self.B):
             raise ValueError(f"this join was captured for [2, {self.B}] pairs")
         if edge is not self.edge:
             self.edge.copy_(edge, non_blocking=True)
         self.graph.replay()
-        if stream is None:
-            self._event.record()
-        else:
-            self._event.record(stream)
+        self._event.record()
         return self
 
     def finish(self):

@@ -183,9 +183,15 @@ def test_rand_r_on_directed_graphs_matches_the_sequential_stream(sp, M, m, N, E,
         off = np.concatenate([[0], np.cumsum(on)])
         assert all(np.array_equal(obj[i, 0], oi_[off[i]:off[i + 1]]) and np.array_equal(obj[i, 1], oc[off[i]:off[i + 1]])
                    for i in range(len(q)))
-    lz = sampler.sample_sets(csr, q, num_walks=M, num_steps=m, seed=17, rng="rand_r", lazy=True)
+    # a lazy batch on a graph nobody has walked yet cannot replay by itself and says so at resolve() ...
+    fresh = sp.DeviceCSR(ip, idx)
+    lz = sampler.sample_sets(fresh, q, num_walks=M, num_steps=m, seed=17, rng="rand_r", lazy=True)
     with pytest.raises(sampler.RandRDeadEnd, match="lazy=False"):
         lz.resolve()
+    # ... while the graph above REMEMBERS its dead ends (round 4): the lazy batch replays the stream from the start
+    assert csr._rand_r_dead_ends
+    lz = sampler.sample_sets(csr, q, num_walks=M, num_steps=m, seed=17, rng="rand_r", lazy=True).resolve()
+    assert np.array_equal(lz.nsize.cpu().numpy(), b[0]) and np.array_equal(lz.ids.cpu().numpy(), b[1][0])
 
 
 def test_reference_invariants_at_scale(sp):
@@ -1460,7 +1466,7 @@ def test_batched_registration_numbers_the_store_like_the_reference(sp, rng, M, h
     subg_acc.c:957-978 -- and the table form's; one chunk, several chunks, sizes left on the device."""
     from surel_plus_amd import sampler
     from surel_plus_amd.spg import sample_spg
-    assert sampler.BATCHED_REGISTRATION and sampler.key_rows_ok(M, hops)
+    assert sampler.key_rows_ok(M, hops)
     ptr_, idx = sym_graph(N, E, seed=M + hops, hubs=hubs)
     q = np.random.default_rng(11).permutation(N)
     csr = sp.DeviceCSR(ptr_.astype(np.int64) if idx64 else ptr_, idx)
@@ -1473,12 +1479,8 @@ def test_batched_registration_numbers_the_store_like_the_reference(sp, rng, M, h
         assert np.array_equal(z.indptr.cpu().numpy(), oi) and np.array_equal(z.indices[:nnz].cpu().numpy(), ox)
         assert np.array_equal(z.data[:nnz].cpu().numpy(), od)
         assert np.array_equal(sets.enc_int16().cpu().numpy(), oenc)
-    keep = sampler.BATCHED_REGISTRATION
-    sampler.BATCHED_REGISTRATION = False          # the table form of the walk kernel (every root registers its own rows)
-    try:
-        zt, tsets = sample_spg(csr, q, num_walks=M, num_steps=hops, seed=77, rng=rng, fused=True)
-    finally:
-        sampler.BATCHED_REGISTRATION = keep
+    # the table form of the walk kernel (every root registers its own rows)
+    zt, tsets = sample_spg(csr, q, num_walks=M, num_steps=hops, seed=77, rng=rng, fused=True, batched_registration=False)
     assert torch.equal(zt.indptr, z.indptr) and torch.equal(zt.data[: zt.nnz], z.data[:nnz]) and torch.equal(tsets.ukeys, sets.ukeys)
 
 
@@ -1618,21 +1620,15 @@ def test_sets_with_id_locality_sort_like_any_other(sp, M, hops):
     q = np.random.default_rng(1).permutation(30000)[:3000]
     (oi, ox, od), oenc = _oracle_spg(ptr_, idx, q, M, hops, 13, "philox", -1)
     assert int(np.diff(oi).max()) > 150                      # (sets big enough for a crowded bucket)
-    from surel_plus_amd import sampler
-    keep = sampler.BATCHED_REGISTRATION
-    try:
-        # ... and with the table form of the fused walk kernel (every root registers its own rows: 32-bit counts for 2 and 3 hops,
-        # 64-bit for 4), whose epilogue has the same two levels
-        for batched in (True, False):
-            sampler.BATCHED_REGISTRATION = batched
-            for kw in ({"fused": True}, {"fused": False}, {"strided": True}, {"strided": True, "fused": False}):
-                z, sets = sample_spg(csr, q, num_walks=M, num_steps=hops, seed=13, rng="philox", **kw)
-                if isinstance(z, sp.StridedSpG):
-                    z = z.to_csr()
-                assert np.array_equal(z.indptr.cpu().numpy(), oi) and np.array_equal(z.indices[: z.nnz].cpu().numpy(), ox), (kw, batched)
-                assert np.array_equal(z.data[: z.nnz].cpu().numpy(), od) and np.array_equal(sets.enc_int16().cpu().numpy(), oenc), (kw, batched)
-    finally:
-        sampler.BATCHED_REGISTRATION = keep
+    # ... and with the table form of the fused walk kernel (every root registers its own rows: 32-bit counts for 2 and 3 hops,
+    # 64-bit for 4), whose epilogue has the same two levels
+    for batched in (True, False):
+        for kw in ({"fused": True}, {"fused": False}, {"strided": True}, {"strided": True, "fused": False}):
+            z, sets = sample_spg(csr, q, num_walks=M, num_steps=hops, seed=13, rng="philox", batched_registration=batched, **kw)
+            if isinstance(z, sp.StridedSpG):
+                z = z.to_csr()
+            assert np.array_equal(z.indptr.cpu().numpy(), oi) and np.array_equal(z.indices[: z.nnz].cpu().numpy(), ox), (kw, batched)
+            assert np.array_equal(z.data[: z.nnz].cpu().numpy(), od) and np.array_equal(sets.enc_int16().cpu().numpy(), oenc), (kw, batched)
 
 
 @pytest.mark.parametrize("B,M,hops", [(9000, 200, 3), (300, 200, 2)])

@@ -1,9 +1,12 @@
-// probe.hip -- a measurement aid, not part of the reference's surface: the random-line rate of the memory system, measured
+// line_roof_lib.hip -- DEV / BENCH ONLY, not part of libsubgacc_hip.so nor of include/subgacc.h (it left the product ABI in round 4):
+// built into tools/build/libsubgacc_probe.so by __graft_entry__.build() and loaded by bench.py alone.
+// A measurement aid, not part of the reference's surface: the random-line rate of the memory system, measured
 // in the same process and on the same table as the walk kernel it is the roof of (bench.py reports it beside the kernel's
 // own line rate).  tools/line_probe.hip is the stand-alone study (access shapes, PMC passes: profiles/r02_line_probe_pmc.csv);
 // this is its `gather4` shape -- independent random 4-byte reads, 2048 x 256 lanes (the walk kernel's residency), four in
 // flight per lane -- over a caller's table.  Every read beyond the caches moves one 128-byte line.
-#include "common.hpp"
+#include <hip/hip_runtime.h>
+#include <stdint.h>
 
 namespace subgacc {
 
@@ -27,13 +30,14 @@ __global__ __launch_bounds__(256) void line_probe_kernel(const uint32_t *__restr
 
 using namespace subgacc;
 
+// returns 0, or -1 for bad arguments / a failed launch
 extern "C" int subgacc_line_probe(const void *table, int64_t table_bytes, int32_t rounds, uint32_t seed, void *sink,
                                   int64_t *reads_out_host, void *stream) {
-    SG_REQUIRE(table && sink && table_bytes >= 4 && table_bytes < (1ll << 34) * 4 && rounds > 0, SUBGACC_ERR_BADARG, "line_probe: bad arguments");
+    if (!(table && sink && table_bytes >= 4 && table_bytes < (1ll << 34) * 4 && rounds > 0)) return -1;
     const unsigned blocks = 2048;
     hipLaunchKernelGGL(line_probe_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint32_t *)table,
                        (uint64_t)(table_bytes / 4), rounds, seed, (uint32_t *)sink);
-    SG_LAUNCH_CHECK();
+    if (hipGetLastError() != hipSuccess) return -1;
     if (reads_out_host) *reads_out_host = (int64_t)blocks * 256 * 4 * rounds;
-    return SUBGACC_OK;
+    return 0;
 }

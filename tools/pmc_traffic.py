@@ -26,12 +26,15 @@ for k, c in acc.items():
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
         rows.append((-(2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]), k, len(c["FETCH_SIZE"]), m))
 walk = None
+join_k = None
 for _, k, n, m in sorted(rows)[:12]:
     hbm = (2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024
     print(f"\"{k}\",{n},{m['FETCH_SIZE']:.0f},{m['WRITE_SIZE']:.0f},{m.get('TCC_REQ_sum', 0):.0f},{m.get('TCC_HIT_sum', 0):.0f},{m.get('TCC_MISS_sum', 0):.0f},{hbm:.0f}")
     if (k.startswith("walk_sets_kernel") or k.startswith("walk_rows_kernel") or k.startswith("walk_pipe_kernel")) and \
             (walk is None or n > walk[4]):      # the walk kernel of the timed steps: the one with the most launches
         walk = (k, hbm, m.get("TCC_MISS_sum", 0), m.get("TCC_REQ_sum", 0), n)
+    if k.startswith("sjoin_pair_kernel") and (join_k is None or n > join_k[3]):       # the join of the timed steps
+        join_k = (k, hbm, m.get("TCC_MISS_sum", 0), n)
 # the bench line of one of the passes tells the configuration (workload, B, M, k, layout, rng)
 line = None
 for f in glob.glob(os.path.join(out, "*.json")):
@@ -67,6 +70,8 @@ if walk and line:
     tj = {k: v for k, v in tj.items() if isinstance(v, dict) and "kernel_source_sha" in v}     # entries without a hash are stale
     tj[key] = {"walk_sets_hbm_bytes_per_launch": walk[1], "walk_sets_l2_miss_lines_per_launch": walk[2],
                "walk_sets_l2_requests_per_launch": walk[3], "kernel": walk[0], "launches_averaged": walk[4],
+               "join_hbm_bytes_per_launch": join_k[1] if join_k else None, "join_l2_miss_lines_per_launch": join_k[2] if join_k else None,
+               "join_kernel": join_k[0] if join_k else None,
                "kernel_source_sha": bench.kernel_source_sha(), "source": f"profiles/{tag}_pmc_per_launch.csv",
                "how": "tools/pmc_collect.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum "
                       "in separate passes over `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-others`; mean over the "
