@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SUBGACC_ABI_VERSION 4
+#define SUBGACC_ABI_VERSION 5
 
 typedef enum subgacc_status {
     SUBGACC_OK = 0,
@@ -360,7 +360,7 @@ int subgacc_walk_join(const int32_t *walks, int64_t n, int32_t stride, const int
 /* ---------------------------------------------------------------------------------------------
  * Key rows: a batch that is sampled, joined and dropped needs neither the table of distinct LP rows nor their numbering.
  * subgacc_walk_spg with uniq_table = NULL writes the member's 32-bit LP key itself as the row's payload (needs
- * num_steps*SHIFT+1 <= 31, 2 or 3 hops, set_sampler order, no bucket, M <= 256: SUBGACC_ERR_BADARG otherwise), and
+ * num_steps*SHIFT+1 <= 31, 2 to 4 hops, set_sampler order, no bucket, M <= 256: SUBGACC_ERR_BADARG otherwise), and
  * subgacc_sjoin_fill_keyrows joins such rows: a feature row is the key's unpacked counts / num_walks -- what
  * subgacc_unpack_lp writes into the feature table, computed on the fly (the partner's row is zero when it is absent).
  * Same (xz, seg) as the table path; sizes by subgacc_sjoin_sizes_rows; mirrored segment lists only.
@@ -369,6 +369,23 @@ int subgacc_sjoin_fill_keyrows(const int32_t *row_len, int64_t n_rows, int64_t r
                                const int32_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
                                const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz, int64_t pair_block,
                                int32_t *flags, void *stream);
+/* ABI 5 -- key rows for the 4-hop configurations.  The paper's sampler figure is citation2 with m = 4, M = 200 (Fig. 6a): its LP
+ * key -- the reference's 64-bit `bithash`, subg_acc.c:900-955 -- takes 4 x 8 + 1 = 33 bits.  subgacc_walk_spg(uniq_table = NULL)
+ * serves 2 to 4 hops while num_steps*SHIFT+1 <= 31 (4 hops: M <= 127, e.g. the reference's own citation2 setting M = 100,
+ * README.md:82-96); beyond that, subgacc_walk_keyrows64 writes the same rows with the whole 64-bit key as payload:
+ *   row_ids [n*stride] int32 (sorted by node id), row_keys [n*stride] uint64, nsize [n]; stride = M*m+1.
+ * Shapes: 4 hops, 32 <= num_steps*SHIFT+1 <= 63, a 1,024-slot table (M*4+1 <= 818), set_sampler order, no bucket.  worklist /
+ * n_work: optional (both or neither), as for subgacc_walk_spg_list / _sparse (rows that are not listed are left alone: zero nsize
+ * first); rng_pos / rng_seed as for subgacc_walk_spg.  subgacc_sjoin_fill_keyrows64 joins such rows (mirrored lists, sizes by
+ * subgacc_sjoin_sizes_rows): bit for bit the xz of the table path. */
+int subgacc_walk_keyrows64(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,
+                           const int32_t *query, int64_t n, const uint32_t *rng_pos, const uint32_t *rng_seed,
+                           const int32_t *worklist, const int64_t *n_work, int32_t *row_ids, uint64_t *row_keys,
+                           int32_t *nsize, int32_t *flags, void *stream);
+int subgacc_sjoin_fill_keyrows64(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
+                                 const uint64_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
+                                 const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz, int64_t pair_block,
+                                 int32_t *flags, void *stream);
 /* The same join over a PACKED store (spg_indptr form, sizes by subgacc_sjoin_sizes) whose payload was re-keyed once: spg_keys[i]
  * = the LP key of member i's row of `enc` (key = sum_j count_j << ((num_steps - j) * SHIFT), bit num_steps*SHIFT set on a
  * root's own row, subg_acc.c:900-955) instead of SFptr+1.  For the reference's flow -- subg_matrix over all nodes once
@@ -441,7 +458,7 @@ int subgacc_walk_spg_sparse(const subgacc_walk_cfg *cfg, const void *indptr, con
  *      end) the pass registers the chunk's keys itself (as step 1, candidates listed; step 2 follows) and keeps the KEY as
  *      payload; subgacc_keyrows_translate turns the packed payloads of all chunks into SFptr+1 once the table is numbered
  *      (n_dev, optional: only the first min(n, *n_dev) entries).
- * Shapes: what the key-rows form of subgacc_walk_spg serves (num_steps*SHIFT+1 <= 31, 2 or 3 hops, M <= 256, no bucket).
+ * Shapes: what the key-rows form of subgacc_walk_spg serves (num_steps*SHIFT+1 <= 31, 2 to 4 hops, M <= 256, no bucket).
  * rng_pos / rng_seed as for subgacc_walk_spg (RAND_R: positions of ALL n roots of the chunk; row i reads entry i).
  * cand: subgacc_keyrows_cand_capacity(n) entries (cand_cap says how many there are; every row is listed at most once). */
 int64_t subgacc_keyrows_cand_capacity(int64_t n);

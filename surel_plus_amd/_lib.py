@@ -33,7 +33,7 @@ SYMBOLS = (
     "subgacc_batch_sampler_workspace_bytes", "subgacc_batch_sampler", "subgacc_step_prologue",
     "subgacc_hop_records_format", "subgacc_hop_records_build", "subgacc_sjoin_fill_keyrows", "subgacc_sjoin_fill_keys", "subgacc_step_dedup_workspace_bytes",
     "subgacc_step_prologue_dedup", "subgacc_walk_spg_sparse",
-    "subgacc_keyrows_register", "subgacc_keyrows_cand_capacity", "subgacc_walk_tags", "subgacc_keyrows_compact", "subgacc_keyrows_translate", "subgacc_rng_replay", "subgacc_worklist_workspace_bytes", "subgacc_worklist_by_root", "subgacc_walk_spg_list",
+    "subgacc_keyrows_register", "subgacc_keyrows_cand_capacity", "subgacc_walk_tags", "subgacc_keyrows_compact", "subgacc_keyrows_translate", "subgacc_rng_replay", "subgacc_walk_keyrows64", "subgacc_sjoin_fill_keyrows64", "subgacc_worklist_workspace_bytes", "subgacc_worklist_by_root", "subgacc_walk_spg_list",
 )
 
 
@@ -131,6 +131,8 @@ def lib():
     sig["subgacc_walk_tags"] = (C.c_int, [cfgp, vp, vp, i64, vp, i64, i64, vp, vp, vp, vp, i64, vp, i64, vp, vp])
     sig["subgacc_keyrows_compact"] = (C.c_int, [vp, vp, vp, vp, i64, i32, i64, vp, i64, vp, vp, i64, vp, vp, vp, i64, vp, vp, vp])
     sig["subgacc_keyrows_translate"] = (C.c_int, [vp, i64, vp, vp, i64, vp, vp, i64, vp])
+    sig["subgacc_walk_keyrows64"] = (C.c_int, [cfgp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp])
+    sig["subgacc_sjoin_fill_keyrows64"] = (C.c_int, [vp, i64, i64, vp, vp, vp, vp, i64, vp, i32, i32, vp, i64, vp, vp])
     sig["subgacc_rng_replay"] = (C.c_int, [cfgp, vp, vp, i64, vp, i64, i32, u64, vp, vp, vp, vp])
     sig["subgacc_worklist_workspace_bytes"] = (sz, [i64])
     sig["subgacc_worklist_by_root"] = (C.c_int, [vp, i64, i64, vp, vp, vp, sz, vp])
@@ -140,7 +142,7 @@ def lib():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    if L.subgacc_abi_version() != 4:
+    if L.subgacc_abi_version() != 5:
         raise SubgAccError("libsubgacc_hip.so ABI version mismatch")
     _lib = L
     return L

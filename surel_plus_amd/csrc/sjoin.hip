@@ -177,7 +177,14 @@ __device__ __forceinline__ float key_feature(uint32_t key, int c, int m, int shi
     return lut[(key >> ((m - c) * shift)) & ((1u << shift) - 1u)];
 }
 
-template <bool F64, int KV, typename Val, bool KEYS = false>
+// the same for a 64-bit key (4-hop walks with M >= 128: 4 x 8 + 1 = 33 bits); ~0 = partner absent
+__device__ __forceinline__ float key_feature64(unsigned long long key, int c, int m, int shift, const float *lut) {
+    if (key == ~0ull) return 0.0f;
+    if (c == 0) return ((key >> (m * shift)) & 1ull) ? 1.0f : 0.0f;
+    return lut[(uint32_t)(key >> ((m - c) * shift)) & ((1u << shift) - 1u)];
+}
+
+template <bool F64, int KV, typename Val, bool KEYS = false, bool K64 = false>
 __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int32_t *own_ids, const Val *own_val,
                                           int64_t na, const int32_t *pids, const Val *pval, int nb, int64_t t0,
                                           int64_t o, int64_t segj, int k, int k2, uint32_t magic, const float *lut = nullptr,
@@ -209,11 +216,12 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
             stream_store(reinterpret_cast<float2 *>(a.out_xz) + row0 + lane, v);
         }
     } else {
-        int32_t pa = (int32_t)va, pb = hit ? (int32_t)pval[lo] : (KEYS ? -1 : 0);
-        if (a.out_idx && live) {
+        using PT = typename std::conditional<K64, unsigned long long, int32_t>::type;
+        PT pa = (PT)va, pb = hit ? (PT)pval[lo] : (PT)(KEYS ? -1 : 0);
+        if (!K64 && a.out_idx && live) {
             int2 v;
-            v.x = pa;
-            v.y = pb;
+            v.x = (int32_t)pa;
+            v.y = (int32_t)pb;
             stream_store(reinterpret_cast<int2 *>(a.out_idx) + row0 + lane, v);
         }
         if (a.out_xz) {
@@ -224,14 +232,14 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
             const int nrows = (int)((na - t0) < kWave ? (na - t0) : kWave);
             // the 64 rows of this trip are one contiguous span of the output: fetch each row's (pa, pb) from its
             // owner lane by a wave shuffle so that stores are fully coalesced
-            if (KV == 4) {
+            if (KV == 4 && !K64) {
                 const float4 *tab4 = reinterpret_cast<const float4 *>(a.table);
                 float4 *dst4 = reinterpret_cast<float4 *>(a.out_xz) + row0 * 2;
 #pragma unroll
                 for (int rnd = 0; rnd < 2; ++rnd) {
                     const int f = rnd * kWave + lane;   // float4 index inside the span
                     const int r = f >> 1;
-                    const int spa = __shfl(pa, r, kWave), spb = __shfl(pb, r, kWave);
+                    const int spa = __shfl((int)pa, r, kWave), spb = __shfl((int)pb, r, kWave);
 #ifdef SJ_HOOK_STORE4        // (tools/dev_hooks.hpp: timing variants of this store; never defined in the product build)
                     SJ_HOOK_STORE4(r, nrows, spa, spb, dst4, tab4, f);
 #else
@@ -258,8 +266,13 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
 #pragma unroll
                     for (int c = 0; c < (KV > 0 ? KV : 16); ++c) {
                         if (c >= kc) break;
-                        mine[c] = key_feature((uint32_t)pa, c, kc - 1, a.key_shift, lut);
-                        mine[kc + c] = key_feature((uint32_t)pb, c, kc - 1, a.key_shift, lut);
+                        if (K64) {
+                            mine[c] = key_feature64((unsigned long long)pa, c, kc - 1, a.key_shift, lut);
+                            mine[kc + c] = key_feature64((unsigned long long)pb, c, kc - 1, a.key_shift, lut);
+                        } else {
+                            mine[c] = key_feature((uint32_t)pa, c, kc - 1, a.key_shift, lut);
+                            mine[kc + c] = key_feature((uint32_t)pb, c, kc - 1, a.key_shift, lut);
+                        }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -283,7 +296,7 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
                 for (int f = lane; f < kWave * k2; f += kWave) {
                     const int r = (int)(((uint32_t)f * magic) >> 20);
                     const int c = f - r * k2;
-                    const int spa = __shfl(pa, r, kWave), spb = __shfl(pb, r, kWave);
+                    const int spa = __shfl((int)pa, r, kWave), spb = __shfl((int)pb, r, kWave);
                     if (f < total)
                         __builtin_nontemporal_store(a.table[(int64_t)(c < k ? spa : spb) * k + (c < k ? c : c - k)], dst + f);
                 }
@@ -342,10 +355,11 @@ constexpr int kPairThreads = 256;
 #define SJ_PAIR_THREADS 128   // 128 lanes per pair: twice the pairs with their row loads in flight per CU (-4..6 % against 256, r02s)
 #endif
 constexpr int kPairEmit = SJ_PAIR_THREADS;
-template <bool F64, int KV, bool KEYS = false, int NT = kPairEmit>
+template <bool F64, int KV, bool KEYS = false, int NT = kPairEmit, bool K64 = false>
 __global__ __launch_bounds__(NT) void sjoin_pair_kernel(const JoinArgs a, int64_t pb) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    using Val = typename std::conditional<F64, double, int32_t>::type;
+    static_assert(!K64 || (KEYS && !F64), "64-bit payloads are LP keys");
+    using Val = typename std::conditional<F64, double, typename std::conditional<K64, unsigned long long, int32_t>::type>::type;
     Val *valA = (Val *)lds_raw;                       // [max_len]
     Val *valB = valA + a.max_len;                     // [max_len]
     int32_t *idsA = (int32_t *)(valB + a.max_len);    // [max_len]
@@ -409,10 +423,10 @@ __global__ __launch_bounds__(NT) void sjoin_pair_kernel(const JoinArgs a, int64_
     const int chunksA = (na + kWave - 1) / kWave, chunksB = (nb + kWave - 1) / kWave;
     for (int c = wave + part * (NT / kWave); c < chunksA + chunksB; c += a.split * (NT / kWave)) {   // every wave takes whole 64-row spans
         if (c < chunksA)
-            emit_rows<F64, KV, Val, KEYS>(a, lane, idsA, valA, na, idsB, valB, nb, (int64_t)c * kWave, oA, j, k, k2, magic, lut, stage);
+            emit_rows<F64, KV, Val, KEYS, K64>(a, lane, idsA, valA, na, idsB, valB, nb, (int64_t)c * kWave, oA, j, k, k2, magic, lut, stage);
         else
-            emit_rows<F64, KV, Val, KEYS>(a, lane, idsB, valB, nb, idsA, valA, na, (int64_t)(c - chunksA) * kWave, oB, j2, k, k2,
-                                          magic, lut, stage);
+            emit_rows<F64, KV, Val, KEYS, K64>(a, lane, idsB, valB, nb, idsA, valA, na, (int64_t)(c - chunksA) * kWave, oB, j2, k, k2,
+                                               magic, lut, stage);
     }
 }
 
@@ -818,15 +832,34 @@ extern "C" int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t n_rows, i
 
 // key payload (strided rows of a transient batch, or a packed store whose payload was re-keyed): shared launcher
 static int launch_key_join(JoinArgs &a, int32_t num_walks, int32_t num_steps, int64_t S, int64_t pair_block, void *stream,
-                           const char *who) {
+                           const char *who, bool wide = false) {
     const int shift = subgacc_key_shift(num_walks, num_steps);
     if (shift < 0) return shift;
-    SG_REQUIRE(num_steps * shift + 1 <= 31 && num_steps + 1 <= 16, SUBGACC_ERR_KEYWIDTH,
-               "%s: LP keys of %d steps x %d bits do not fit 32 bits", who, num_steps, shift);
+    SG_REQUIRE(num_steps * shift + 1 <= (wide ? 63 : 31) && num_steps + 1 <= 16, SUBGACC_ERR_KEYWIDTH,
+               "%s: LP keys of %d steps x %d bits do not fit %d bits", who, num_steps, shift, wide ? 64 : 32);
     a.table = nullptr, a.table_rows = 0, a.k = num_steps + 1;
     a.out_idx = nullptr;
     a.slot_id = nullptr, a.val_add = 0;
     a.key_M = num_walks, a.key_m = num_steps, a.key_shift = shift;
+    if (wide) {      // 64-bit keys: 24 bytes of LDS per member of the two rows, every lane unpacks its own row
+        const size_t lds = (size_t)a.max_len * 24 + ((size_t)4 << shift) + (size_t)(256 / kWave) * kWave * 2 * a.k * 4;
+        SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "%s: rows of %d members do not fit LDS", who, (int)a.max_len);
+        a.split = pair_split(S / 2);
+        const int64_t grid = xcd_grid(S / 2 * a.split);
+        SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "%s: too many segments in one call", who);
+        hipStream_t s = (hipStream_t)stream;
+        if (a.k == 5 && a.max_len > 512 && a.split == 1) {     // 4-hop rows (up to 801 members): 256 lanes per pair, as for the 3-hop rows
+            if (lds > 64 * 1024)
+                SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 5, true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((sjoin_pair_kernel<false, 5, true, 256, true>), dim3((unsigned)grid), dim3(256), lds, s, a, pair_block);
+        } else {
+            if (lds > 64 * 1024)
+                SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 0, true, kPairEmit, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((sjoin_pair_kernel<false, 0, true, kPairEmit, true>), dim3((unsigned)grid), dim3(kPairEmit), lds, s, a, pair_block);
+        }
+        SG_LAUNCH_CHECK();
+        return SUBGACC_OK;
+    }
     const size_t lds = (size_t)a.max_len * 16 + ((size_t)4 << shift) +
                        (a.k == 4 ? 0 : (size_t)(kPairEmit / kWave) * kWave * 2 * a.k * 4);   // staging: only the generic width uses it
     SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "%s: rows of %d members do not fit LDS", who, (int)a.max_len);
@@ -878,6 +911,27 @@ extern "C" int subgacc_sjoin_fill_keyrows(const int32_t *row_len, int64_t n_rows
     a.flags = flags;
     a.row_len = row_len, a.row_stride = row_stride;
     return launch_key_join(a, num_walks, num_steps, S, pair_block, stream, "sjoin_fill_keyrows");
+}
+
+extern "C" int subgacc_sjoin_fill_keyrows64(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
+                                            const uint64_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
+                                            const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz,
+                                            int64_t pair_block, int32_t *flags, void *stream) {
+    SG_REQUIRE(S >= 0 && flags && n_rows >= 0 && row_stride > 0 && row_stride < (1ll << 31), SUBGACC_ERR_BADARG,
+               "sjoin_fill_keyrows64: bad arguments");
+    if (S == 0) return subgacc_key_shift(num_walks, num_steps) < 0 ? subgacc_key_shift(num_walks, num_steps) : SUBGACC_OK;
+    SG_REQUIRE(row_len && row_ids && row_keys && own && (partner || pair_block > 0) && seg && out_xz, SUBGACC_ERR_BADARG,
+               "sjoin_fill_keyrows64: null argument");
+    SG_REQUIRE(pair_block > 0 && S % (2 * pair_block) == 0, SUBGACC_ERR_BADARG,
+               "sjoin_fill_keyrows64: the segment list must be mirrored blocks (pair_block > 0, S a multiple of 2*pair_block)");
+    JoinArgs a;
+    a.indptr = nullptr, a.indices = row_ids, a.data = row_keys;
+    a.pb = pair_block; a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
+    a.out_xz = out_xz, a.out_segid = nullptr;
+    a.max_len = (int32_t)row_stride;
+    a.flags = flags;
+    a.row_len = row_len, a.row_stride = row_stride;
+    return launch_key_join(a, num_walks, num_steps, S, pair_block, stream, "sjoin_fill_keyrows64", true);
 }
 
 extern "C" int subgacc_sjoin_fill_keys(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,

@@ -779,8 +779,8 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
                "walk_spg_sparse: rows without a root are passed over by the fused-row kernel only (2..4 hops, M <= 256, a 512- or "
                "1,024-slot table, no bucket); M = %d, m = %d", M, m);
     SG_REQUIRE(!a.keyrows, SUBGACC_ERR_BADARG,
-               "walk_spg: key rows (no table of distinct rows) need set_sampler order, no bucket, M <= 256, 2 or 3 hops and "
-               "num_steps*SHIFT+1 <= 31; M = %d, m = %d", M, m);
+               "walk_spg: key rows (no table of distinct rows) need set_sampler order, no bucket, M <= 256, 2 to 4 hops, a 512- or "
+               "1,024-slot table and num_steps*SHIFT+1 <= 31 (subgacc_walk_keyrows64: 4 hops, <= 63 bits); M = %d, m = %d", M, m);
     const int64_t grid = xcd_grid(n);
     SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "walk: chunk of %lld roots too large, split it", (long long)n);
 #define SG_WALK_LAUNCH(I64, RNGM, SPGM)                                                                           \
@@ -851,6 +851,24 @@ extern "C" int subgacc_walk_spg_list(const subgacc_walk_cfg *cfg, const void *in
                "walk_spg_list: set_sampler order only, no raw walks");
     return launch_walk(cfg, indptr, indices, num_nodes, query, n, rng_pos, rng_seed, row_ids, nullptr, row_slot, uniq_table,
                        uniq_capacity, 0, nsize, nullptr, flags, stream, true, worklist, n_work);
+}
+
+extern "C" int subgacc_walk_keyrows64(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,
+                                      const int32_t *query, int64_t n, const uint32_t *rng_pos, const uint32_t *rng_seed,
+                                      const int32_t *worklist, const int64_t *n_work, int32_t *row_ids, uint64_t *row_keys,
+                                      int32_t *nsize, int32_t *flags, void *stream) {
+    SG_REQUIRE(row_keys && (worklist != nullptr) == (n_work != nullptr), SUBGACC_ERR_BADARG,
+               "walk_keyrows64: null row_keys, or a work list without its length (or the reverse)");
+    SG_REQUIRE(cfg && !cfg->emit_walks && cfg->order == SUBGACC_ORDER_WALK_MAJOR && cfg->bucket <= 0, SUBGACC_ERR_BADARG,
+               "walk_keyrows64: set_sampler order only, no raw walks, no bucket");
+    const int shift = subgacc_key_shift(cfg->num_walks, cfg->num_steps);
+    if (shift < 0) return shift;
+    SG_REQUIRE(cfg->num_steps * shift + 1 > 31, SUBGACC_ERR_BADARG,
+               "walk_keyrows64: the keys of M = %d, m = %d fit 32 bits -- subgacc_walk_spg(uniq_table = NULL) writes those",
+               cfg->num_walks, cfg->num_steps);
+    // (row_slot only has to be non-null: rows of 64-bit keys leave through set_keys; launch_walk_rows takes the launch or nobody does)
+    return launch_walk(cfg, indptr, indices, num_nodes, query, n, rng_pos, rng_seed, row_ids, row_keys, (int32_t *)row_keys, nullptr,
+                       0, 0, nsize, nullptr, flags, stream, worklist != nullptr, worklist, n_work);
 }
 
 extern "C" int subgacc_walk_tags(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,

@@ -37,15 +37,17 @@ namespace subgacc {
 // K32: the packed landing counts (and the LP keys made of them) fit 32 bits (m*SHIFT+1 <= 31: every reference
 // configuration up to 3 hops) -- 12 bytes of LDS per table slot instead of 16, which is what lets the 1,024-slot table of the
 // 3-hop configurations run with 128 lanes x 8 slots per lane and 11 roots per CU instead of 8.
-// KR ("key rows", needs K32): the row's payload is the member's 32-bit LP key itself.  A batch that is sampled, joined and
+// KR ("key rows"): the row's payload is the member's LP key itself -- 32 bits with K32 (a.set_slot), else 64 bits (a.set_keys: the
+// 4-hop configurations with M >= 128, 4 x 8 + 1 = 33 bits; round 4).  A batch that is sampled, joined and
 // dropped needs neither the table of distinct LP rows nor their numbering -- the join turns a key into its feature row
 // arithmetically -- so the whole fold / registration / flush stage (a quarter of the kernel's vector instructions, its
 // global atomics) and the first-visit bookkeeping (minq: one LDS atomic per visit, 4 bytes of LDS per slot) fall away.
 template <bool IDX64, int RNG, int MH, int SPL, int NT, int REC = 0, bool K32 = false, bool KR = false>
 // (waves per SIMD asked of the register allocator: the table form with 32-bit counts holds 12 bytes of LDS per slot + the fold table,
 //  ~15 KB per workgroup of two waves = 5 waves per SIMD whatever the registers; 64-bit counts on 128 lanes, 10.5 KB: 7; the rest 8)
-__global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (NT == 128 ? 7 : 8)) __attribute__((amdgpu_num_sgpr(80))) void walk_rows_kernel(const WalkArgs a) {
-    static_assert(!KR || (K32 && SPL % 4 == 0), "key rows: 32-bit counts, 4-slot chunks");
+__global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (KR ? 5 : (NT == 128 ? 7 : 8))) __attribute__((amdgpu_num_sgpr(80))) void walk_rows_kernel(const WalkArgs a) {
+    static_assert(!KR || SPL % 4 == 0, "key rows: 4-slot chunks");
+    constexpr bool KR64 = KR && !K32;      // rows of 64-bit LP keys
     extern __shared__ __align__(16) unsigned char lds_raw[];
     using CntT = typename std::conditional<K32, uint32_t, unsigned long long>::type;
     static_assert(SPL % 4 == 0 || (SPL == 2 && !K32), "slot ownership: 4-slot chunks, or two slots with 64-bit counts");
@@ -61,7 +63,8 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (NT == 128 ? 7 : 8)) __att
     CntT *fk = (CntT *)(((uintptr_t)(sarr + a.M) + 7) & ~(uintptr_t)7);   // [kSpgFold]
     uint32_t *ft = (uint32_t *)(fk + kSpgFold);                   // [kSpgFold] min visit number of the key inside the set
     int32_t *fs = (int32_t *)(ft + kSpgFold);                     // [kSpgFold] HBM table slot of the key
-    int32_t *red = KR ? (int32_t *)fk : fs + kSpgFold;            // [16] (KR: no fold table either)
+    // [16] (KR: no fold table either; behind the walk tables and behind everything the epilogue's sort lays over them)
+    int32_t *red = KR ? (int32_t *)(lds_raw + kr_red_offset(T, a.M, a.stride, NT, KR64)) : fs + kSpgFold;
 
     int64_t i;
     if (a.worklist) {   // a dense list of the rows to sample whose length lives on the device: its first xcd_grid(length) blocks work
@@ -153,7 +156,8 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (NT == 128 ? 7 : 8)) __att
                 uniq_global_insert(a.table, k, tag0, a.flags);
             } else {
                 a.set_ids[obase] = root;
-                a.set_slot[obase] = KR ? (int32_t)k : uniq_global_insert(a.table, k, tag0, a.flags);
+                if (KR64) a.set_keys[obase] = k;
+                else a.set_slot[obase] = KR ? (int32_t)k : uniq_global_insert(a.table, k, tag0, a.flags);
                 a.nsize[i] = 1;
             }
         }
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (NT == 128 ? 7 : 8)) __att
         // A set fills a fifth to a third of the table: the members are first packed (any order -- the sort below fixes it),
         // so that every later phase runs over ceil(ns / NT) elements per lane instead of SPL mostly empty slots.
         int32_t idv[SPL];
-        uint32_t kv[SPL];
+        CntT kv[SPL];
         int cnt = 0;
         uint32_t umn = ~0u;         // an empty slot is -1: the largest unsigned value, the smallest signed one
         int32_t vmax = -1;
@@ -452,9 +456,17 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (NT == 128 ? 7 : 8)) __att
         for (int c = 0; c < SPL / 4; ++c) {
             const int g = c * NT + tid;
             const int4 kk = ((const int4 *)keys)[g];
-            const uint4 v = ((const uint4 *)pk)[g];
             idv[4 * c] = kk.x, idv[4 * c + 1] = kk.y, idv[4 * c + 2] = kk.z, idv[4 * c + 3] = kk.w;
-            kv[4 * c] = v.x, kv[4 * c + 1] = v.y, kv[4 * c + 2] = v.z, kv[4 * c + 3] = v.w;
+            if (K32) {
+                const uint4 v = ((const uint4 *)pk)[g];
+                kv[4 * c] = (CntT)v.x, kv[4 * c + 1] = (CntT)v.y, kv[4 * c + 2] = (CntT)v.z, kv[4 * c + 3] = (CntT)v.w;
+            } else {
+                const uint4 v0 = ((const uint4 *)pk)[2 * g], v1 = ((const uint4 *)pk)[2 * g + 1];
+                kv[4 * c] = (CntT)(((unsigned long long)v0.y << 32) | v0.x);
+                kv[4 * c + 1] = (CntT)(((unsigned long long)v0.w << 32) | v0.z);
+                kv[4 * c + 2] = (CntT)(((unsigned long long)v1.y << 32) | v1.x);
+                kv[4 * c + 3] = (CntT)(((unsigned long long)v1.w << 32) | v1.z);
+            }
         }
 #pragma unroll
         for (int u = 0; u < SPL; ++u) {
@@ -490,7 +502,10 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (NT == 128 ? 7 : 8)) __att
         // the kernel 2x slower -- profiles/r05u_sq_locality.csv).  Sub-buckets hold ~1 member either way; the ranking by counting
         // that remains runs over those.
         unsigned long long *A = (unsigned long long *)lds_raw;            // [ns <= stride] over the counts and the ids
-        int32_t *start = (int32_t *)(lds_raw + 8 * (size_t)a.stride);       // [B+1] level-1 counts, then offsets
+        // 64-bit keys do not fit beside the id in a sort element: they stay where they were packed (KK[p], never moved) and the
+        // element carries p -- (id << 32 | p) sorts like (id << 32 | key), ids being distinct
+        unsigned long long *KK = A + a.stride;                            // [ns] (KR64 only)
+        int32_t *start = (int32_t *)(lds_raw + (KR64 ? 16 : 8) * (size_t)a.stride);       // [B+1] level-1 counts, then offsets
         uint32_t *cnt2 = (uint32_t *)(start + NT + 1);                      // [(ns+2)/2 + 1] level-2 counts, two 16-bit counters per word
         int logb = 0;
         while ((1 << logb) < ns && (2 << logb) <= T / 4 && (2 << logb) <= NT) ++logb;
@@ -507,7 +522,12 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (NT == 128 ? 7 : 8)) __att
 #pragma unroll
             for (int u = 0; u < SPL; ++u)
                 if (idv[u] != -1) {
-                    A[p] = ((unsigned long long)(uint32_t)idv[u] << 32) | (kv[u] | (idv[u] == root ? (uint32_t)lead : 0u));
+                    if (KR64) {
+                        A[p] = ((unsigned long long)(uint32_t)idv[u] << 32) | (unsigned long long)(uint32_t)p;
+                        KK[p] = (unsigned long long)(kv[u] | (idv[u] == root ? lead : (CntT)0));
+                    } else {
+                        A[p] = ((unsigned long long)(uint32_t)idv[u] << 32) | (uint32_t)(kv[u] | (idv[u] == root ? lead : (CntT)0));
+                    }
                     ++p;
                 }
         }
@@ -646,7 +666,8 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (NT == 128 ? 7 : 8)) __att
         for (int x = tid; x < ns; x += NT) {
             const unsigned long long v = A[x];
             a.set_ids[obase + x] = (int32_t)(v >> 32);
-            a.set_slot[obase + x] = (int32_t)(uint32_t)v;
+            if (KR64) a.set_keys[obase + x] = KK[(uint32_t)v];
+            else a.set_slot[obase + x] = (int32_t)(uint32_t)v;
         }
         return;
     }
@@ -923,13 +944,34 @@ int launch_walk_rows(const WalkArgs &a, bool indptr64, int rng_mode, size_t lds,
     constexpr bool nt128 = SG_DEV_ROWS_NT == 128;
     const bool half = a.T == 512 && !nt256;
     const bool rec = a.recs != nullptr && indptr64 == (a.rec.id_bits == 0);   // hop records: one dependent read per hop
-    if (a.keyrows) {      // rows that carry the LP key itself: 32-bit counts, 128 lanes, 2 or 3 hops -- or not at all
+    if (a.keyrows && a.m * a.shift + 1 > 31) {
+        // 64-bit key rows (round 4): the 4-hop shapes whose keys need 33+ bits (M = 128 .. 204: 4 x 8 + 1) -- 64-bit counts in the
+        // walk tables, the keys leave through set_keys.  1,024-slot table, 128 lanes x 2 walks x 8 slots, ~15 KB of LDS per root.
+        if (a.m != 4 || a.m * a.shift + 1 > 63 || a.T != 1024 || !a.set_keys || ((int64_t)a.stride + 2) / 2 + 1 > 4 * 128) return 0;
+        const size_t lds64 = kr_red_offset(1024, a.M, a.stride, 128, true) + 64 + 16;
+#define SG_KR64W(I64, RNGM)                                                                                           \
+    do {                                                                                                             \
+        if (rec)                                                                                                     \
+            hipLaunchKernelGGL((walk_rows_kernel<I64, RNGM, 4, 8, 128, I64 ? 16 : 8, false, true>), dim3((unsigned)grid), dim3(128), lds64, s, a); \
+        else                                                                                                         \
+            hipLaunchKernelGGL((walk_rows_kernel<I64, RNGM, 4, 8, 128, 0, false, true>), dim3((unsigned)grid), dim3(128), lds64, s, a); \
+        return 1;                                                                                                    \
+    } while (0)
+        if (indptr64) {
+            if (rr) SG_KR64W(true, SUBGACC_RNG_RAND_R);
+            SG_KR64W(true, SUBGACC_RNG_PHILOX);
+        }
+        if (rr) SG_KR64W(false, SUBGACC_RNG_RAND_R);
+        SG_KR64W(false, SUBGACC_RNG_PHILOX);
+#undef SG_KR64W
+    }
+    if (a.keyrows) {      // rows that carry the LP key itself: 32-bit counts, 128 lanes, 2 to 4 hops -- or not at all
         // (the epilogue's sort lives over the dead walk tables AND the Fisher-Yates draws behind them: packed members 8*stride,
         //  level-1 offsets 4*(128+1) [start + NT + 1: NT <= 128], level-2 counters 2 bytes each; CW * NT words cover them)
-        if (a.m * a.shift + 1 > 31 || a.m > 3 ||
-            8 * (int64_t)a.stride + 4 * 129 + 4 * (((int64_t)a.stride + 2) / 2 + 1) > 8 * (int64_t)a.T + 4 * (int64_t)a.M ||
-            ((int64_t)a.stride + 2) / 2 + 1 > 4 * (a.T == 512 ? 64 : 128)) return 0;
-        const size_t ldsk = (size_t)a.T * 8 + (size_t)a.M * 4 + 8 + 64 + 16;
+        if (a.m * a.shift + 1 > 31 || a.m > 4 || ((int64_t)a.stride + 2) / 2 + 1 > 4 * (a.T == 512 ? 64 : 128)) return 0;
+        // (the reduction words sit behind the walk tables and behind the epilogue's sort, whichever reaches further: kr_red_offset)
+        const bool one_wave = (nt64 || (!indptr64 && !nt128)) && a.m == 2 && a.T == 512;
+        const size_t ldsk = kr_red_offset(a.T, a.M, a.stride, one_wave ? 64 : 128, false) + 64 + 16;
 #define SG_KR(I64, RNGM, MHH, SPLL)                                                                                  \
     do {                                                                                                             \
         if (rec)                                                                                                     \
@@ -950,11 +992,13 @@ int launch_walk_rows(const WalkArgs &a, bool indptr64, int rng_mode, size_t lds,
     do {                                                     \
         if (a.T == 1024) {                                   \
             if (a.m == 2) SG_KR(I64, RNGM, 2, 8);            \
-            SG_KR(I64, RNGM, 3, 8);                          \
+            if (a.m == 3) SG_KR(I64, RNGM, 3, 8);            \
+            SG_KR(I64, RNGM, 4, 8);                          \
         }                                                    \
         if ((nt64 || (!I64 && !nt128)) && a.m == 2) SG_KR64(I64, RNGM, 2, 8); \
         if (a.m == 2) SG_KR(I64, RNGM, 2, 4);                \
-        SG_KR(I64, RNGM, 3, 4);                              \
+        if (a.m == 3) SG_KR(I64, RNGM, 3, 4);                \
+        SG_KR(I64, RNGM, 4, 4);                              \
     } while (0)
         if (indptr64) {
             if (rr) SG_KR_MH(true, SUBGACC_RNG_RAND_R);

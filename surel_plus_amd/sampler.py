@@ -69,10 +69,24 @@ def rows_kernel_takes(num_walks, num_steps, bucket=-1):
     return (bucket <= 0 and 2 <= num_steps <= 4 and num_walks <= 256 and _table_slots(num_walks, num_steps) in (512, 1024))
 
 
+def key_rows_form(num_walks, num_steps):
+    """the key-rows form of the fused-row kernel for this shape: 32 (the LP key fits 31 bits: 2 to 4 hops, a 512 / 1,024-slot
+    table -- every reference configuration up to 3 hops, and 4 hops up to M = 127), 64 (4 hops with a longer key: M = 128 .. 204,
+    e.g. the paper's citation2 sampler setting m = 4, M = 200 -- 33 bits; 1,024-slot table), or 0 (none: the table form)"""
+    bits = num_steps * int(num_walks).bit_length() + 1
+    t = _table_slots(num_walks, num_steps)
+    if num_walks > 256 or num_steps not in (2, 3, 4):
+        return 0
+    if bits <= 31 and t in (512, 1024):
+        return 32
+    if num_steps == 4 and bits <= 63 and t == 1024:
+        return 64
+    return 0
+
+
 def key_rows_ok(num_walks, num_steps):
-    """does the fused-row kernel have a key-rows form for this shape? (32-bit keys, 2 or 3 hops, a 512 / 1,024-slot table)"""
-    return (num_steps in (2, 3) and num_steps * int(num_walks).bit_length() + 1 <= 31 and num_walks <= 256
-            and _table_slots(num_walks, num_steps) in (512, 1024))
+    """32-bit key rows for this shape? (what the batched registration of a kept store, csrc/keyrows.hip, works on)"""
+    return key_rows_form(num_walks, num_steps) == 32
 
 
 # bench.py sets this to a callable(name) -> context manager that brackets one kernel launch with HIP events
@@ -217,7 +231,9 @@ class SampledSets:
     _tail: torch.Tensor = None   # StepBuffers form: int64 [5] = [rows of the join (= members), status words x4], contiguous
     #                              ([6] with root dedup: + the number of distinct roots = rows that were sampled)
     n_distinct: int = None       # StepBuffers(dedup_roots=True): so many rows (the first occurrences of the endpoints) hold sets
-    keyrows: bool = False        # strided rows whose payload (`slot`) is the member's 32-bit LP key: no table, no numbering
+    keyrows: bool = False        # strided rows whose payload (`slot`) is the member's LP key: no table, no numbering
+    key64: bool = False          # ... a 64-bit key (`slot` is int64: 4-hop walks with M >= 128), else 32 bits
+    _table_form: object = None   # key64: the same batch sampled again with the table form, once number() / to_csr() needed it
     _keyctx: dict = None         # keyrows: what number() needs to register the rows' keys (csr, roots, cfg, rng positions, capacity, fresh())
     _ktable: torch.Tensor = None  # keyrows: the table of distinct LP rows once number() has built it (capacity _kcap)
     _kcap: int = 0
@@ -321,6 +337,9 @@ class SampledSets:
         if self.ukeys is not None:
             return self
         self.resolve()
+        if self.keyrows and self.key64:
+            self.ukeys = self.table_form().ukeys
+            return self
         if self.keyrows:        # the keys are all there: register them now, and ask the few candidate roots for their order
             return self._number_keyrows()
         L, dev, st = lib(), self.ids.device, stream_ptr()
@@ -335,6 +354,22 @@ class SampledSets:
             raise _lib.SubgAccError(f"{c} distinct LP rows exceed the direct-ranking limit: sample with lazy=False")
         self.ukeys = ukeys[:c]
         return self
+
+    def table_form(self):
+        """64-bit key rows: csrc/keyrows.hip registers 32-bit keys, so what such a batch does not carry -- the numbering of its
+        distinct LP rows, enc, the packed CSR rows -- comes from sampling the batch AGAIN with the table form of the walk kernel
+        (a set is a function of (seed, root) under Philox, of the root's place in the stream under rand_r: the same rows)."""
+        if self._table_form is None:
+            ctx = self._keyctx
+            if ctx is None or not ctx["fresh"]():
+                raise _lib.SubgAccError("this key-rows batch cannot be numbered any more: its step buffers hold a later batch "
+                                        "(number() / c / enc_int16() / to_csr() must be asked for before the buffers are re-used)")
+            cfg = ctx["cfg"]
+            rng = "rand_r" if cfg.rng_mode == _lib.RNG_RAND_R else "philox"
+            self._table_form = sample_sets(ctx["csr"], ctx["roots"], num_walks=self.num_walks, num_steps=self.num_steps, seed=cfg.seed,
+                                           rng=rng, fused_rows=True, strided=True, number_rows=True, key_rows=False,
+                                           uniq_capacity=int(ctx["capacity"]), sort_roots=False)
+        return self._table_form
 
     def _number_keyrows(self):
         """Number the distinct LP rows of a key-rows batch after the fact (csrc/keyrows.hip): one pass over the rows registers
@@ -588,7 +623,8 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     if fused_rows:
         keep_keys = False
     limit = uniq_small_limit if uniq_small_limit > 0 else RANK_LIMIT
-    per_member = 8 if fused_rows else 12
+    kform = key_rows_form(M, m) if (key_rows and strided and fused_rows and not number_rows and bucket <= 0 and not walk_replay) else 0
+    per_member = (12 if kform == 64 else 8) if fused_rows else 12
     if staging_bytes is None:     # 288 GB of HBM: one chunk of roots wherever a third of the free memory holds its staging rows
         staging_bytes = max(STAGING_BYTES, int(0.35 * torch.cuda.mem_get_info(dev)[0])) if n * stride * per_member > STAGING_BYTES \
             else STAGING_BYTES
@@ -618,8 +654,8 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     else:
         rng_pos, rng_seed = _rng_positions(L, cfg, csr, q, n, rng_streams, calls_before, st)
     # key rows: strided fused rows that nobody asked to number carry LP keys instead of table slots (module header)
-    key_rows = bool(key_rows and strided and fused_rows and not number_rows and bucket <= 0 and n > 0 and chunk == n
-                    and key_rows_ok(M, m) and not walk_replay)
+    key_rows = bool(kform and n > 0 and chunk == n)
+    kform = kform if key_rows else 0
     # a store that is kept: key rows as well, registered by one pass over the rows (csrc/keyrows.hip, module header)
     batched = bool(batched_registration and fused_rows and dedup and not strided and bucket <= 0 and n > 0 and key_rows_ok(M, m)
                    and not walk_replay)
@@ -634,7 +670,7 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     off_chunk = None
     if n:
         st_ids = torch.empty(chunk * stride, dtype=torch.int32, device=dev)
-        st_aux = torch.empty(chunk * stride, dtype=torch.int32 if fused_rows else torch.int64, device=dev)
+        st_aux = torch.empty(chunk * stride, dtype=torch.int32 if (fused_rows and kform != 64) else torch.int64, device=dev)
         scan_ws = torch.empty(L.subgacc_scan_workspace_bytes(chunk), dtype=torch.uint8, device=dev)
         off_chunk = torch.empty(chunk + 1, dtype=torch.int64, device=dev)
     X = 0
@@ -654,7 +690,13 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
             nsize.zero_()           # (a row that is not listed -- a root equal to SUBGACC_NO_ROOT -- reads as an empty set)
             check(L.subgacc_worklist_by_root(ptr(q), cn, csr.num_nodes, ptr(wl), ptr(nwl), ptr(wws), wws.numel(), st))
         with _timed("walk_sets"):
-            if by_root:
+            if kform == 64:       # rows of 64-bit LP keys (4 hops, M >= 128): one chunk, optionally in work-list order
+                check(L.subgacc_walk_keyrows64(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q), cn,
+                                               ptr(rng_pos) if rng_pos is not None else None,
+                                               ptr(rng_seed) if rng_seed is not None else None,
+                                               ptr(wl) if by_root else None, ptr(nwl) if by_root else None,
+                                               ptr(st_ids), ptr(st_aux), ptr(nsize), ptr(flags), st))
+            elif by_root:
                 check(L.subgacc_walk_spg_list(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q), cn,
                                               ptr(rng_pos) if rng_pos is not None else None,
                                               ptr(rng_seed) if rng_seed is not None else None, ptr(wl), ptr(nwl),
@@ -712,7 +754,7 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
             sets = SampledSets(nsize, None, st_ids, None, None, ukeys, M, m, stride, None)
             sets.slot, sets.table, sets.capacity, sets.strided = st_aux, table, (0 if key_rows else uniq_capacity), True
             if key_rows:
-                sets.keyrows = True
+                sets.keyrows, sets.key64 = True, kform == 64
                 sets._keyctx = {"csr": csr, "roots": q, "cfg": cfg, "rng_pos": rng_pos, "rng_seed": rng_seed,
                                 "capacity": uniq_capacity, "fresh": lambda: True}
             torch.sum(nsize, dim=(0,), dtype=torch.int64, out=status[3])

@@ -178,6 +178,8 @@ class StridedSpG:
         return self.sets.X
 
     def to_csr(self):
+        if self.keyrows and self.sets.key64:      # 64-bit key rows: the packed rows come from the table form of the same batch
+            return StridedSpG(self.sets.table_form(), self.shape[1]).to_csr()
         self.sets.number()           # the packed rows carry SFptr+1: the table must be numbered by now (key rows: registered now)
         n, dev = self.n_rows, self.device
         row_off = torch.empty(n + 1, dtype=torch.int64, device=dev)

@@ -204,8 +204,9 @@ def _sjoin_strided(spg, own, partner, seg, ws, encode, ptr_mode, return_index, p
         if not ptr_mode:
             raise ValueError("a key-rows batch is joined with segment pointers (ptr=True); use z.to_csr() for segment ids")
         with _timed("sjoin_fill"):
-            check(L.subgacc_sjoin_fill_keyrows(ptr(spg.nsize), spg.n_rows, spg.stride, ptr(spg.indices), ptr(spg.slot), ptr(own),
-                                               ptr(partner), S, ptr(seg), M_, m_, ptr(res), pair_block, ptr(flags), st))
+            fill = L.subgacc_sjoin_fill_keyrows64 if spg.sets.key64 else L.subgacc_sjoin_fill_keyrows
+            check(fill(ptr(spg.nsize), spg.n_rows, spg.stride, ptr(spg.indices), ptr(spg.slot), ptr(own),
+                       ptr(partner), S, ptr(seg), M_, m_, ptr(res), pair_block, ptr(flags), st))
         return res, seg, flags
     by_slot = encode is spg._slot_table and encode is not None      # StridedSpG.slot_table(): indexed by slot + 1
     enc = encode if by_slot else encode.to(device=dev, dtype=torch.float32).contiguous()
@@ -413,9 +414,11 @@ class StepBuffers:
         self.roots = torch.empty(n, dtype=torch.int32, device=dev)
         self.nsize = torch.empty(n, dtype=torch.int32, device=dev)
         self.ids = torch.empty(n * self.stride, dtype=torch.int32, device=dev)
-        self.slot = torch.empty(n * self.stride, dtype=torch.int32, device=dev)
-        from .sampler import key_rows_ok
-        self.keyrows = bool(key_rows and key_rows_ok(self.M, self.m))    # rows of LP keys: no table, no feature table
+        from .sampler import key_rows_form
+        form = key_rows_form(self.M, self.m) if key_rows else 0
+        self.keyrows = bool(form)                 # rows of LP keys: no table, no feature table
+        self.key64 = form == 64                   # ... 64-bit keys (4-hop walks with M >= 128): `slot` is int64
+        self.slot = torch.empty(n * self.stride, dtype=torch.int64 if self.key64 else torch.int32, device=dev)
         self.sort_roots = bool(sort_roots)     # the walk kernel takes the rows in ascending order of root id (csrc/worklist.hip)
         self.table = None if self.keyrows else torch.empty(L.subgacc_uniq_table_bytes(self.capacity), dtype=torch.uint8, device=dev)
         self.tail = torch.zeros(n + 1 + 4 + 1, dtype=torch.int64, device=dev)  # seg [n+1] | status [4] | distinct roots [1]
@@ -495,9 +498,14 @@ def _buffered_step(csr, e, bufs, seed, out):
         # (no sorted list here: what the order buys is mostly repeated endpoints standing next to each other, and those are gone --
         # measured, cit2 walk kernel 0.647 ms either way, and the sort costs its 25 us)
         with _timed("walk_sets"):
-            check(L.subgacc_walk_spg_sparse(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n,
-                                            ptr(bufs.worklist), ptr(bufs.n_distinct), ptr(bufs.table), 0 if kr else bufs.capacity,
-                                            ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize), ptr(flags), st))
+            if bufs.key64:
+                check(L.subgacc_walk_keyrows64(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n, None, None,
+                                               ptr(bufs.worklist), ptr(bufs.n_distinct), ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize),
+                                               ptr(flags), st))
+            else:
+                check(L.subgacc_walk_spg_sparse(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n,
+                                                ptr(bufs.worklist), ptr(bufs.n_distinct), ptr(bufs.table), 0 if kr else bufs.capacity,
+                                                ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize), ptr(flags), st))
         own, partner = bufs.own, bufs.partner
     elif bufs.sort_roots and n >= SORT_ROOTS_MIN and walk_kernel_name(csr, M, m, True) == "walk_rows_kernel":
         # the rows stay where the batch has them; the walk kernel takes them in ascending order of their root's id (a work list):
@@ -509,9 +517,14 @@ def _buffered_step(csr, e, bufs, seed, out):
             check(L.subgacc_rng_positions(cfg, ptr(csr.indptr), csr.num_nodes, ptr(bufs.roots), n, 1, 0, ptr(bufs.rng_pos),
                                           ptr(bufs.rng_seed), ptr(bufs.rng_ws), bufs.rng_ws.numel(), st))
         with _timed("walk_sets"):
-            check(L.subgacc_walk_spg_list(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n, rp, rs,
-                                          ptr(bufs.sorted_list), ptr(bufs.n_all), ptr(bufs.table), 0 if kr else bufs.capacity,
-                                          ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize), ptr(flags), st))
+            if bufs.key64:
+                check(L.subgacc_walk_keyrows64(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n, rp, rs,
+                                               ptr(bufs.sorted_list), ptr(bufs.n_all), ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize),
+                                               ptr(flags), st))
+            else:
+                check(L.subgacc_walk_spg_list(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n, rp, rs,
+                                              ptr(bufs.sorted_list), ptr(bufs.n_all), ptr(bufs.table), 0 if kr else bufs.capacity,
+                                              ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize), ptr(flags), st))
         own, partner = _arange_segments(B, dev, PB)
     else:
         check(L.subgacc_step_prologue(ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.status), 4, ptr(e), ptr(bufs.roots), n, st))
@@ -519,9 +532,13 @@ def _buffered_step(csr, e, bufs, seed, out):
             check(L.subgacc_rng_positions(cfg, ptr(csr.indptr), csr.num_nodes, ptr(bufs.roots), n, 1, 0, ptr(bufs.rng_pos),
                                           ptr(bufs.rng_seed), ptr(bufs.rng_ws), bufs.rng_ws.numel(), st))
         with _timed("walk_sets"):
-            check(L.subgacc_walk_spg(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n, 0, rp, rs,
-                                     ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize),
-                                     ptr(flags), st))
+            if bufs.key64:
+                check(L.subgacc_walk_keyrows64(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n, rp, rs,
+                                               None, None, ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize), ptr(flags), st))
+            else:
+                check(L.subgacc_walk_spg(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(bufs.roots), n, 0, rp, rs,
+                                         ptr(bufs.table), 0 if kr else bufs.capacity, ptr(bufs.ids), ptr(bufs.slot), ptr(bufs.nsize),
+                                         ptr(flags), st))
         own, partner = _arange_segments(B, dev, PB)
     check(L.subgacc_sjoin_sizes_rows(ptr(bufs.nsize), n, ptr(own), ptr(partner), n, ptr(bufs.seg), ptr(flags), ptr(bufs.ws),
                                      bufs.ws.numel(), st))
@@ -535,8 +552,9 @@ def _buffered_step(csr, e, bufs, seed, out):
     xz = res.view(-1)[: rows * 2 * k].view(rows, 2, k)
     with _timed("sjoin_fill"):
         if kr:
-            check(L.subgacc_sjoin_fill_keyrows(ptr(bufs.nsize), n, bufs.stride, ptr(bufs.ids), ptr(bufs.slot), ptr(own), ptr(partner),
-                                               n, ptr(bufs.seg), M, m, ptr(xz), PB, ptr(flags), st))
+            fill = L.subgacc_sjoin_fill_keyrows64 if bufs.key64 else L.subgacc_sjoin_fill_keyrows
+            check(fill(ptr(bufs.nsize), n, bufs.stride, ptr(bufs.ids), ptr(bufs.slot), ptr(own), ptr(partner),
+                       n, ptr(bufs.seg), M, m, ptr(xz), PB, ptr(flags), st))
         else:
             check(L.subgacc_sjoin_fill_rows(ptr(bufs.nsize), n, bufs.stride, ptr(bufs.ids), ptr(bufs.slot), None, 0, ptr(own),
                                             ptr(partner), n, ptr(bufs.seg), ptr(bufs.feat), bufs.capacity + 1, k, ptr(xz), None,
@@ -544,7 +562,7 @@ def _buffered_step(csr, e, bufs, seed, out):
     sets = SampledSets(bufs.nsize, None, bufs.ids, None, None, None, M, m, bufs.stride, None)
     sets.slot, sets.table, sets.capacity, sets.strided = bufs.slot, bufs.table, (0 if kr else bufs.capacity), True
     if kr:
-        sets.keyrows = True
+        sets.keyrows, sets.key64 = True, bufs.key64
         # number() registers the keys of the rows as they stand in the buffers (root dedup: the rows of repeated endpoints are
         # empty, and a repeated endpoint never is the first to show an LP row, so the numbering is the one of the whole batch);
         # once the buffers have taken a later batch -- or a captured step has been replayed -- the answer would describe that

@@ -1053,7 +1053,7 @@ def test_attn_stage_trains_like_the_reference_first_stage(sp):
         assert err_fused <= max(4 * err_ref32, 1e-4), (n, err_fused, err_ref32)
 
 
-@pytest.mark.parametrize("B,M,hops,idx64", [(2048, 200, 3, False), (700, 200, 2, False), (512, 100, 3, True), (300, 64, 4, False)])
+@pytest.mark.parametrize("B,M,hops,idx64", [(2048, 200, 3, False), (700, 200, 2, False), (512, 100, 3, True), (300, 64, 4, False), (400, 200, 4, False), (300, 110, 4, True)])
 def test_step_with_root_dedup_equals_the_plain_step(sp, B, M, hops, idx64):
     """StepBuffers(dedup_roots=True): every distinct endpoint sampled once, in the row of its first occurrence
     (subgacc_step_prologue_dedup + subgacc_walk_spg_sparse) -- bit for bit the (xz, indptr) of the step that samples every
@@ -1231,19 +1231,22 @@ def test_captured_step_replays_equal_the_eager_step(sp, B, hops, rng):
 
 
 @pytest.mark.parametrize("rng", ["rand_r", "philox"])
-@pytest.mark.parametrize("M,hops,idx64", [(200, 3, False), (200, 2, True), (100, 3, True), (120, 2, False)])
+@pytest.mark.parametrize("M,hops,idx64", [(200, 3, False), (200, 2, True), (100, 3, True), (120, 2, False),
+                                          # round 4: 4 hops -- 32-bit keys up to M = 127 (512- and 1,024-slot tables), 64-bit keys beyond
+                                          # (the paper's Fig. 6a setting m = 4, M = 200: 33 bits; subgacc_walk_keyrows64)
+                                          (100, 4, False), (120, 4, True), (200, 4, False), (128, 4, True), (204, 4, False)])
 def test_key_rows_join_like_table_rows(sp, rng, M, hops, idx64):
-    """rows that carry the 32-bit LP key instead of a table slot (csrc/walk_rows.hip KR form, subgacc_sjoin_fill_keyrows):
+    """rows that carry the LP key instead of a table slot (csrc/walk_rows.hip KR form, subgacc_sjoin_fill_keyrows / _keyrows64):
     the same (xz, indptr) as the table form and as the oracle; numbering, enc and the packed CSR on demand (sampled again)"""
     from surel_plus_amd.graphs import query_pairs
-    from surel_plus_amd.sampler import key_rows_ok
-    assert key_rows_ok(M, hops)
+    from surel_plus_amd.sampler import key_rows_form
+    assert key_rows_form(M, hops) == (64 if (hops == 4 and M >= 128) else 32)
     ptr_, idx = sym_graph(8000, 70000, seed=31, hubs=3)
     csr = sp.DeviceCSR(ptr_.astype(np.int64) if idx64 else ptr_, idx)
     e = query_pairs(csr, 700, seed=3)
     e[:, 5] = e[0, 5]                                              # a (u, u) pair
     xz, ind, sets = sp.sample_and_gather(csr, e, num_walks=M, num_steps=hops, seed=21, rng=rng)
-    assert sets.keyrows and sets.table is None
+    assert sets.keyrows and sets.table is None and sets.key64 == (key_rows_form(M, hops) == 64)
     txz, tind, tsets = sp.sample_and_gather(csr, e, num_walks=M, num_steps=hops, seed=21, rng=rng, key_rows=False)
     assert not tsets.keyrows and torch.equal(ind, tind) and torch.equal(xz, txz)
     # against the oracle: sets of both endpoints -> SpG -> gather with Z_SF = enc / M
@@ -1261,7 +1264,7 @@ def test_key_rows_join_like_table_rows(sp, rng, M, hops, idx64):
     assert torch.equal(zc.indptr, tc.indptr) and torch.equal(zc.indices, tc.indices) and torch.equal(zc.data, tc.data)
 
 
-@pytest.mark.parametrize("B,M,hops", [(512, 100, 3), (300, 200, 2), (64, 50, 4)])
+@pytest.mark.parametrize("B,M,hops", [(512, 100, 3), (300, 200, 2), (64, 50, 4), (300, 200, 4), (200, 100, 4)])
 def test_buffered_step_equals_the_allocating_step(sp, B, M, hops):
     """spjoin.StepBuffers: the on-demand step as six launches over preallocated buffers gives bit for bit what the general
     form gives, batch after batch through the same buffers; errors surface at resolve() as they do for lazy=True"""
