@@ -420,18 +420,21 @@ __global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_n
     }
     __syncthreads();
     SG_HOOK_STAMP(5);
+    int32_t maxc;
     {   // exclusive scan over the B <= 256 buckets, one bucket per lane: wave scan, then the wave totals through LDS
         const int32_t c = tid < B ? cursor[tid] : 0;
-        int32_t inc = c;
+        int32_t inc = c, mc = c;
 #pragma unroll
         for (int dd = 1; dd < kWave; dd <<= 1) {
             const int32_t t2 = __shfl_up(inc, dd, kWave);
             if ((tid & (kWave - 1)) >= dd) inc += t2;
+            mc = max(mc, __shfl_xor(mc, dd, kWave));
         }
-        if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc;
+        if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc, red[4 + tid / kWave] = mc;   // (the id range is in registers)
         __syncthreads();
         int32_t base = 0;
         for (int w2 = 0; w2 < tid / kWave; ++w2) base += red[12 + w2];
+        maxc = max(max(red[4], red[5]), max(red[6], red[7]));
         const int32_t excl = base + inc - c;
         if (tid < B) {
             start[tid] = excl;
@@ -441,9 +444,78 @@ __global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_n
     }
     __syncthreads();
     SG_HOOK_STAMP(6);
+    // A crowded bucket -- a set whose ids sit in one community of a graph with id locality -- made the ranking by counting below
+    // quadratic (walk_rows.hip met the same).  The same second level here: bucket b gets as many sub-buckets
+    // as it has members (sub = offset inside b's id window scaled by b's count), so that start[b] + sub is a monotone map of the ids
+    // onto [0, ns) that follows the set's own distribution, and the counting runs over ~1 member.  Evenly spread ids keep the
+    // short path.  The level-2 counters (16 bits each) live behind the level-1 offsets and cursors, in the dead id table.
+    constexpr int kFineAbove = 12, CW = 2;
+    const int W2 = (ns + 2) / 2 + 1;
+    uint32_t *cnt2 = (uint32_t *)(keys + T / 2 + 2);                     // [W2] <= T/2 - 2 words (W2 <= 0.4 T + 2)
+    int blo[kSpgPerLane], bhi[kSpgPerLane];
+    if (!(maxc > kFineAbove && W2 <= CW * kWalkThreads && W2 <= T / 2 - 2)) {
 #pragma unroll
-    for (int u = 0; u < kSpgPerLane; ++u)
-        if (ok[u]) A[atomicAdd(&cursor[bk[u]], 1)] = ((unsigned long long)(uint32_t)idv[u] << 32) | (uint32_t)slv[u];
+        for (int u = 0; u < kSpgPerLane; ++u)
+            if (ok[u]) A[atomicAdd(&cursor[bk[u]], 1)] = ((unsigned long long)(uint32_t)idv[u] << 32) | (uint32_t)slv[u];
+#pragma unroll
+        for (int u = 0; u < kSpgPerLane; ++u) {   // bucket bounds of all the lane's members (overlapping reads)
+            blo[u] = ok[u] ? start[bk[u]] : 0;
+            bhi[u] = ok[u] ? start[bk[u] + 1] : 0;
+        }
+    } else {
+        for (int x = tid; x < W2; x += kWalkThreads) cnt2[x] = 0u;
+        __syncthreads();
+        int32_t arr[kSpgPerLane];
+#pragma unroll
+        for (int u = 0; u < kSpgPerLane; ++u) {      // (bk[u] becomes the member's sub-bucket)
+            arr[u] = 0;
+            if (!ok[u]) continue;
+            const uint32_t lo1 = (uint32_t)start[bk[u]], kb = (uint32_t)start[bk[u] + 1] - lo1;
+            const uint32_t off = (uint32_t)(idv[u] - mn) - (bk[u] << bshift);                      // < 2^bshift
+            const uint32_t sub = bshift ? __umulhi(off << (32 - bshift), kb) : 0u;                 // floor(off * kb / 2^bshift) < kb
+            bk[u] = lo1 + sub;
+            const uint32_t sh = (bk[u] & 1u) * 16u;
+            arr[u] = (int32_t)((atomicAdd(&cnt2[bk[u] >> 1], 1u << sh) >> sh) & 0xFFFFu);
+        }
+        __syncthreads();
+        {   // exclusive scan of the ns + 1 level-2 counters, in place (offsets <= ns < 2^16): CW consecutive words per lane
+            uint32_t w[CW];
+            int32_t s2 = 0;
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const int x = tid * CW + c;
+                w[c] = x < W2 ? cnt2[x] : 0u;
+                s2 += (int32_t)((w[c] & 0xFFFFu) + (w[c] >> 16));
+            }
+            int32_t inc = s2;
+#pragma unroll
+            for (int dd = 1; dd < kWave; dd <<= 1) {
+                const int32_t t2 = __shfl_up(inc, dd, kWave);
+                if ((tid & (kWave - 1)) >= dd) inc += t2;
+            }
+            if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc;
+            __syncthreads();
+            int32_t run = inc - s2;
+            for (int w2 = 0; w2 < tid / kWave; ++w2) run += red[12 + w2];
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const int x = tid * CW + c;
+                const uint32_t lo16 = (uint32_t)run;
+                run += (int32_t)(w[c] & 0xFFFFu);
+                const uint32_t hi16 = (uint32_t)run;
+                run += (int32_t)(w[c] >> 16);
+                if (x < W2) cnt2[x] = lo16 | (hi16 << 16);
+            }
+        }
+        __syncthreads();
+        const uint16_t *off2 = (const uint16_t *)cnt2;
+#pragma unroll
+        for (int u = 0; u < kSpgPerLane; ++u) {
+            blo[u] = ok[u] ? off2[bk[u]] : 0;
+            bhi[u] = ok[u] ? off2[bk[u] + 1] : 0;
+            if (ok[u]) A[blo[u] + arr[u]] = ((unsigned long long)(uint32_t)idv[u] << 32) | (uint32_t)slv[u];
+        }
+    }
     __syncthreads();
     SG_HOOK_STAMP(7);
     // order inside a bucket = number of smaller ids in it -> final position in the row.  The sorted row is assembled
@@ -452,12 +524,6 @@ __global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_n
     int32_t *fin_sl = (int32_t *)(pk + a.stride + 1);   // [ns]: A occupies pk[0..ns), ns <= stride; (T - stride - 1) * 8 >= 4 * stride
     const bool staged = (int64_t)(T - a.stride - 1) * 8 >= (int64_t)4 * a.stride;
     const uint32_t *Ahi = (const uint32_t *)A;
-    int blo[kSpgPerLane], bhi[kSpgPerLane];
-#pragma unroll
-    for (int u = 0; u < kSpgPerLane; ++u) {   // bucket bounds of all the lane's members first (overlapping reads)
-        blo[u] = ok[u] ? start[bk[u]] : 0;
-        bhi[u] = ok[u] ? start[bk[u] + 1] : 0;
-    }
 #pragma unroll
     for (int u = 0; u < kSpgPerLane; ++u)
         if (ok[u]) {

@@ -1611,7 +1611,10 @@ def test_captured_join_over_a_resident_store_equals_gather(sp):
         cj(bad).finish()
 
 
-@pytest.mark.parametrize("M,hops", [(200, 3), (200, 2), (100, 4)])
+@pytest.mark.parametrize("M,hops", [(200, 3), (200, 2), (100, 4), (200, 4),
+                                    # shapes that walk_rows_kernel does not take: the general fused kernel (walk.hip), whose epilogue
+                                    # got the second sort level in round 4 -- more than 256 walks, and (below) a truncating bucket
+                                    (300, 2), (260, 3)])
 def test_sets_with_id_locality_sort_like_any_other(sp, M, hops):
     """A graph whose communities are blocks of consecutive ids (graphs.community_graph): most of a set lies inside one block, i.e.
     inside ONE bucket of a sort that buckets by equal id width.  The two-level distribution sort (walk_rows.hip key rows,
@@ -1632,6 +1635,14 @@ def test_sets_with_id_locality_sort_like_any_other(sp, M, hops):
                 z = z.to_csr()
             assert np.array_equal(z.indptr.cpu().numpy(), oi) and np.array_equal(z.indices[: z.nnz].cpu().numpy(), ox), (kw, batched)
             assert np.array_equal(z.data[: z.nnz].cpu().numpy(), od) and np.array_equal(sets.enc_int16().cpu().numpy(), oenc), (kw, batched)
+    # a bucket that truncates (members ranked past it are dropped, subg_acc.c:814-828): walk_sets_kernel<SPG> in its ranking form,
+    # crowded buckets included (the first `bucket` members of a set still lie in one community)
+    bucket = 180
+    (oi, ox, od), oenc = _oracle_spg(ptr_, idx, q, M, hops, 13, "philox", bucket)
+    assert int(np.diff(oi).max()) == bucket
+    z, sets = sample_spg(csr, q, num_walks=M, num_steps=hops, seed=13, rng="philox", bucket=bucket, fused=True)
+    assert np.array_equal(z.indptr.cpu().numpy(), oi) and np.array_equal(z.indices[: z.nnz].cpu().numpy(), ox)
+    assert np.array_equal(z.data[: z.nnz].cpu().numpy(), od) and np.array_equal(sets.enc_int16().cpu().numpy(), oenc)
 
 
 @pytest.mark.parametrize("B,M,hops", [(9000, 200, 3), (300, 200, 2)])
