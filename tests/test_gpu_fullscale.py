@@ -84,12 +84,80 @@ def test_cit2_scale_all_roots_then_a_million_pairs(sp):
     assert not tsets.keyrows and torch.equal(tind, wind) and torch.equal(txz, wxz)
 
 
+@pytest.mark.parametrize("preset,M,m,pos_frac", [("collab", 200, 2, 0.5), ("ppa", 200, 3, 1.0 / 21.0)])
+def test_collab_and_ppa_presets_at_full_size(sp, preset, M, m, pos_frac):
+    """BASELINE.json configs[1] / [2] at their full N (235,868 / 576,289 nodes) under pytest, not only in bench.py: all N roots
+    -> the resident store (the reference's invariants, subg_acc/test/test.py:34-45, on a sample of rows; a random subset of roots
+    bit-exact against the oracle), then a batch of 65,536 pairs joined from the store, from the keyed store and on demand through
+    the step buffers -- the three must agree bit for bit (Philox sets are functions of (seed, root))."""
+    from surel_plus_amd.graphs import preset_graph, query_pairs
+    csr = preset_graph(preset)
+    N = csr.num_nodes
+    roots = torch.arange(N, dtype=torch.int32, device="cuda")
+    z, sets = sp.sample_spg(csr, roots, num_walks=M, num_steps=m, seed=5, rng="philox", fused=True)
+    X = z.nnz
+    assert X == int(sets.nsize.long().sum()) and int(z.data.max()) == sets.c and int(z.data.min()) >= 1
+    table = sets.feature_table()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    sample = torch.randint(0, N, (200,), device="cuda", generator=g)
+    _row_checks(z, table, roots, M, sample)
+    sub = sample[:100].cpu().numpy()
+    o_nsize, o_remap, o_enc = oracle.gset_sampler(csr.indptr.cpu().numpy(), csr.indices.cpu().numpy(), sub, num_walks=M,
+                                                  num_steps=m, seed=5, rng="philox", nthreads=8)
+    oi, ox, od = oracle.spg_build(o_nsize, o_remap)
+    enc_full = sets.enc_int16().cpu().numpy()
+    for j, r in enumerate(sub.tolist()):
+        lo, hi = int(z.indptr[r]), int(z.indptr[r + 1])
+        assert np.array_equal(z.indices[lo:hi].cpu().numpy(), ox[oi[j]:oi[j + 1]])
+        assert np.array_equal(enc_full[z.data[lo:hi].cpu().numpy() - 1], o_enc[od[oi[j]:oi[j + 1]] - 1])
+    edge = query_pairs(csr, 65536, seed=100, pos_frac=pos_frac)
+    wxz, wind = sp.gather(edge, z, "cuda", ptr=True, encode=table)
+    lens = z.indptr[1:] - z.indptr[:-1]
+    assert torch.equal(wind[1:] - wind[:-1], torch.cat([lens[edge[0]], lens[edge[1]]])) and wxz.shape[0] == int(wind[-1])
+    enc0 = torch.cat([torch.zeros((1, m + 1), dtype=torch.int16, device="cuda"), sets.enc_int16()])
+    zk = z.keyed(enc0, M)
+    kxz, kind = sp.gather(edge, zk, "cuda", ptr=True, encode=zk.slot_table())
+    assert torch.equal(kind, wind) and torch.equal(kxz, wxz)
+    bufs = sp.StepBuffers(csr, 65536, num_walks=M, num_steps=m)
+    xz, ind, bsets = sp.sample_and_gather(csr, edge, num_walks=M, num_steps=m, seed=5, rng="philox", buffers=bufs)
+    bsets.prefetch().resolve()
+    rows = int(bsets.extra[0])
+    assert rows == wxz.shape[0] and torch.equal(ind, wind) and torch.equal(xz[:rows], wxz)
+    # ... and as 64 reference-sized batches of 1,024 pairs in one launch sequence (round 4)
+    many = sp.gather_many(edge.view(2, 64, 1024).permute(1, 0, 2).contiguous(), zk, "cuda", encode=zk.slot_table())
+    e3 = edge.view(2, 64, 1024)
+    for b in (0, 17, 63):
+        gx, gi = sp.gather(e3[:, b], zk, "cuda", ptr=True, encode=zk.slot_table())
+        assert torch.equal(many[b][0], gx) and torch.equal(many[b][1], gi)
+
+
 def test_twitter_scale_int64_offsets(sp):
-    """41.65 M nodes, 2.9e9 adjacency entries (int64 CSR offsets); 10 M roots -> more than 2^31 set members, so
-    the SpG row offsets leave the int32 range as well."""
+    """41.65 M nodes, ~2.9e9 adjacency entries (int64 CSR offsets), the graph as dataloader.py:122-135 would hand it over (G + G.T:
+    undirected, simple, rows sorted -- built by graphs.symmetric_powerlaw_graph_big, round 4); 10 M roots -> more than 2^31 set
+    members, so the SpG row offsets leave the int32 range as well."""
     from surel_plus_amd.graphs import preset_graph
     csr = preset_graph("twitter")
     assert csr.indptr.dtype == torch.int64 and csr.nnz > 2**31
+    # the loader's guarantees, checked on a slice of rows (a global check would need a second copy of the 12 GB adjacency)
+    ip = csr.indptr
+    for r0 in (0, 20_000_000, csr.num_nodes - 200_000):
+        lo, hi = int(ip[r0]), int(ip[r0 + 200_000])
+        seg = csr.indices[lo:hi].long()
+        row = torch.repeat_interleave(torch.arange(r0, r0 + 200_000, device="cuda"), ip[r0 + 1:r0 + 200_001] - ip[r0:r0 + 200_000])
+        key = row * csr.num_nodes + seg
+        assert bool((key[1:] > key[:-1]).all()) and bool((row != seg).all())            # sorted, simple, no self loops
+        # symmetric: every (u, v) of the slice has its (v, u) -- looked up by binary search in v's sorted row
+        pick = torch.randint(0, seg.numel(), (20000,), device="cuda")
+        u, v = row[pick], seg[pick]
+        vb, ve = ip[v], ip[v + 1]
+        steps = int(torch.log2((ve - vb).max().float()).ceil().item()) + 1
+        lo_, hi_ = vb.clone(), ve.clone()
+        for _ in range(steps):
+            mid = (lo_ + hi_) // 2
+            act = lo_ < hi_
+            go = csr.indices[mid.clamp(max=csr.nnz - 1)].long() < u
+            lo_, hi_ = torch.where(go & act, mid + 1, lo_), torch.where(~go & act, mid, hi_)
+        assert bool(((lo_ < ve) & (csr.indices[lo_.clamp(max=csr.nnz - 1)].long() == u)).all())
     M, m = 200, 2
     g = torch.Generator(device="cuda").manual_seed(3)
     roots = torch.randint(0, csr.num_nodes, (10_000_000,), device="cuda", generator=g, dtype=torch.int64).int()

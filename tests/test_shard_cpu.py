@@ -75,6 +75,43 @@ def test_two_rank_sharded_spg_is_replicated_identically(tmp_path):
         assert np.array_equal(p["row_off"], indptr) and np.array_equal(p["ids"], ids) and np.array_equal(p["data"], data)
 
 
+def test_eight_rank_sharded_sampling_and_replication_keep_the_single_process_order(tmp_path):
+    """world size 8 (the node the driver scales to), gloo on the CPU: the eight per-rank LP-row tables merge in rank order to the
+    single-process numbering (merge_unique_tables), and the eight row slices are replicated into the single-process SpG
+    (replicate_rows: slices of very different sizes -- the golden query of 37 roots leaves some ranks 4 roots and others 5)."""
+    world, port = 8, 33500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_spg_worker, args=(world, port + 1, str(tmp_path)), nprocs=world, join=True)
+    g = np.load(os.path.join(GOLDEN, "gset_mixeddeg_s1.npz"))
+    M, m = int(g["M"]), int(g["m"])
+    nsize, remap, enc = oracle.gset_sampler(g["indptr"], g["indices"], g["query"], num_walks=M, num_steps=m, seed=9, rng="philox")
+    indptr, ids, data = oracle.spg_build(nsize, remap)
+    parts = [np.load(os.path.join(str(tmp_path), f"r{r}.npz")) for r in range(world)]
+    assert parts[0]["lo"] == 0 and parts[-1]["hi"] == len(g["query"])
+    assert all(int(a["hi"]) == int(b["lo"]) for a, b in zip(parts, parts[1:]))
+    assert np.array_equal(np.concatenate([p["nsize"] for p in parts]), nsize)
+    assert np.array_equal(np.concatenate([p["ids"] for p in parts]), remap[0])
+    assert np.array_equal(np.concatenate([p["sf"] for p in parts]), remap[1])      # global LP-row numbers, first-occurrence order
+    for r in range(world):
+        assert np.array_equal(parts[r]["gkeys"], pack_keys(enc, M))
+        p = np.load(os.path.join(str(tmp_path), f"spg{r}.npz"))
+        assert np.array_equal(p["row_off"], indptr) and np.array_equal(p["ids"], ids) and np.array_equal(p["data"], data)
+
+
+def test_merge_unique_tables_over_eight_tables_is_rank_order_first_occurrence():
+    rs = np.random.default_rng(0)
+    tables = [torch.from_numpy(rs.permutation(40)[: rs.integers(0, 25)].astype(np.int64)) for _ in range(8)]
+    gk, maps = shard.merge_unique_tables(tables)
+    want = []
+    for t in tables:
+        for v in t.tolist():
+            if v not in want:
+                want.append(v)
+    assert gk.tolist() == want
+    for t, mp_ in zip(tables, maps):
+        assert [want[i] for i in mp_.tolist()] == t.tolist()
+
+
 def test_shard_range_covers_everything():
     for n in (0, 1, 7, 8, 1000):
         for w in (1, 2, 3, 8):
