@@ -3,7 +3,7 @@
 # bench line.   tools/final_profile.sh TAG [workloads...]     -> gpurun_out/TAG_*   (copy what is to be judged into profiles/)
 set -x
 TAG=${1:-rXX}; shift
-WLS=${@:-cit2 collab ppa twitter cit2loc cit2ppr}
+WLS=${@:-cit2 cit2m4 collab ppa twitter cit2loc cit2ppr}
 R=$GRAFT_REPO_ROOT
 for W in $WLS; do
   cd /tmp && export TMPDIR=/tmp
