@@ -38,7 +38,7 @@ WORKLOADS = {
     # name: (graph preset, num_walks M, CLI num_steps k (walk hops m = k-1), description, fraction of positive pairs)
     "cit2": ("cit2", 200, 4, "cit2-like LP: N=2,927,963 avg-deg 20.7 power-law graph, M=200, --num_steps 4 (m=3 hops)", 0.5),
     # not a BASELINE config: the cit2 parameters on a graph WITH id locality (graphs.community_graph) -- does the walk's L2 miss
-    # count respond to structure / to a work list sorted by root id?  (SUBGACC_SORT_ROOTS=1 sorts the work list)
+    # count respond to structure / to a work list sorted by root id?  (bench-only switch SUBGACC_SORT_ROOTS=0: batch order)
     "cit2loc": ("cit2loc", 200, 4, "cit2-like LP on a community-structured graph: N=2,927,963 avg-deg 20.7, blocks of 2,048 consecutive ids, "
                                    "75 % of the edges inside a block, M=200, --num_steps 4 (m=3 hops)", 0.5),
     # the paper's sampler figure (Fig. 6a: citation2, m = 4, M = 200 -- BASELINE.md section 1) read with m as the HOP count: CLI
@@ -198,7 +198,8 @@ def hot_path_step(sp, csr, edge, M, k, seed, rng, slot=0):
         bufs = _STEP_BUFS.get(key)
         if bufs is None:
             try:
-                bufs = _STEP_BUFS[key] = sp.StepBuffers(csr, B, M, k - 1, uniq_capacity=UNIQ_CAPACITY, out=buf, dedup_roots=DEDUP, rng=rng)
+                bufs = _STEP_BUFS[key] = sp.StepBuffers(csr, B, M, k - 1, uniq_capacity=UNIQ_CAPACITY, out=buf, dedup_roots=DEDUP, rng=rng,
+                                                        sort_roots=os.environ.get("SUBGACC_SORT_ROOTS", "1") == "1")
             except ValueError:
                 bufs = _STEP_BUFS[key] = False
     xz, ind, sets = sp.sample_and_gather(csr, edge, num_walks=M, num_steps=k - 1, seed=seed, rng=rng, out=buf if LAZY else None,

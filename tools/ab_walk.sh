@@ -1,7 +1,7 @@
 #!/bin/bash
 # Dev-only A/B of compile-time variants of walk.hip / walk_pipe.hip on ONE box:
 #   VARIANTS="-DSG_NT_NEIGH=1|-DSG_EXPERIMENT=1" WLS="cit2 collab" tools/ab_walk.sh
-# (SUBGACC_WALK_PIPE=0 keeps the hooks of walk_sets_kernel in play for the set_sampler form.)
+# (add -DSG_DEV_NO_WALK_PIPE to a variant to keep the hooks of walk_sets_kernel in play for the set_sampler form.)
 set -e
 cd $GRAFT_REPO_ROOT/surel_plus_amd/csrc
 # variants are linked into /tmp and selected with SUBGACC_LIB: the shipped library is never touched

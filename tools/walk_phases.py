@@ -27,7 +27,7 @@ for it in range(3):
                              1 << 20, ptr(ids), ptr(slot), ptr(nsize), ptr(flags), stream_ptr()))
     b.record()
 torch.cuda.synchronize()
-print(f"kernel {a.elapsed_time(b):.3f} ms (stamps on 1 workgroup in 64), LDS pad {os.environ.get('SUBGACC_LDS_PAD', '0')}")
+print(f"kernel {a.elapsed_time(b):.3f} ms (stamps on 1 workgroup in 64), LDS pad {os.environ.get('LDS_PAD', '0')} (a build flag of tools/walk_phases.sh)")
 c = flags[8:8 + 18].view(torch.int64).tolist()
 n = (n + 63) // 64          # sampled workgroups
 names = ["init tables + fisher-yates draws", "root insert", "WALK + visits", "member load + fold (LDS)", "flush fold to HBM + zero buckets",
