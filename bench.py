@@ -881,6 +881,24 @@ def offline_flow(sp, csr, M, k, B, K, cpu):
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
     t_off = min(times[1:])
+    # the paper's own sampler figure (Fig. 6a: citation2, m = 4, M = 200 -- 143..302 s on 16..1 CPU threads "incl. encoding + SpG
+    # conversion") read with m as the hop count: all N roots, 4 hops, store resident + enc numbered
+    t_m4 = None
+    try:
+        tm = []
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            z4, s4 = sample_spg(csr, idx, num_walks=M, num_steps=4, seed=111413, rng="philox", fused=True)
+            e4 = s4.enc_int16()
+            torch.cuda.synchronize()
+            tm.append(time.perf_counter() - t0)
+            m4_members, m4_rows = z4.nnz, int(e4.shape[0])
+            del z4, s4, e4
+        t_m4 = min(tm)
+    except Exception as ex:
+        t_m4 = None
+        m4_members = m4_rows = f"{type(ex).__name__}: {ex}"
     table = sets.feature_table()
     edges = [query_pairs(csr, B, seed=9000 + s_, device=dev) for s_ in range(max(K, 5) + 2)]
     cap = 2 * B * z.max_len * 2 * k
@@ -960,7 +978,9 @@ def offline_flow(sp, csr, M, k, B, K, cpu):
         del sbuf, stacks
     except Exception as ex:
         b1024["failed"] = f"{type(ex).__name__}: {ex}"
-    out = {"J_b1024_keyed": b1024, "all_N_sample_to_resident_spg_ms": t_off * 1e3, "S_roots_per_s": N / t_off, "set_members": z.nnz,
+    out = {"J_b1024_keyed": b1024, "all_N_4hop_sample_to_resident_spg_ms": t_m4 * 1e3 if t_m4 else None,
+           "all_N_4hop_roots_per_s": N / t_m4 if t_m4 else None, "all_N_4hop_set_members": m4_members, "all_N_4hop_distinct_lp_rows": m4_rows,
+           "all_N_sample_to_resident_spg_ms": t_off * 1e3, "S_roots_per_s": N / t_off, "set_members": z.nnz,
            "distinct_lp_rows": int(enc.shape[0]), "J_pairs_per_s_table_store": J, "J_pairs_per_s_keyed_store": JK,
            "rekey_once_ms": t_key * 1e3, "pairs_per_batch": B,
            "Q_amortised_at_1e8_pairs_table": 1e8 / (t_off + 1e8 / J), "Q_amortised_at_1e8_pairs_keyed": 1e8 / (t_off + t_key + 1e8 / JK),
@@ -995,7 +1015,25 @@ def bench_hgather(sp, z, table, k, K):
     rows = int(xz.shape[0])
     # per output row: id + SFptr read (8), xz written (8k), segment id written (8); per triplet: 3 ids (24) + 8 row offsets (64)
     abytes = rows * (8 + 8 * k + 8) + B * (24 + 64)
+    # ... and 32 such batches per launch sequence (spjoin.hgather_many: bit for bit the per-batch results), 3 repeats, median
+    many = None
+    try:
+        NB = 32
+        stack = torch.stack([hedges[i % len(hedges)] for i in range(NB)])
+        sp.hgather_many(stack, z, dev, encode=table)
+        rs = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _r in range(4):
+                parts = sp.hgather_many(stack, z, dev, encode=table)
+            torch.cuda.synchronize()
+            rs.append(4 * NB * B / (time.perf_counter() - t1))
+        many = median(rs)
+    except Exception as ex:
+        many = f"{type(ex).__name__}: {ex}"
     return {"metric": "triplets/sec (hgather from the resident store)", "value": B * K / wall, "unit": "triplets/s", "steps": K,
+            "many32_triplets_per_s": many,
             "ms_per_step": wall / K * 1e3, "triplets_per_step": B, "xz_rows_last_step": rows,
             "roofline": {"bound": "hbm", "kernel": "sjoin_pair_kernel (4 blocks per triplet) + sizes + scan", "achieved": abytes / (ms * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
@@ -1187,6 +1225,7 @@ def flatten(out):
     put("hgather_b2048_triplets_per_s", hg.get("value"))
     put("hgather_b2048_ms_per_step", hg.get("ms_per_step"))
     put("hgather_b2048_frac", (hg.get("roofline") or {}).get("frac"))
+    put("hgather_b2048_many32_triplets_per_s", hg.get("many32_triplets_per_s"))
     cb = out.get("cpu_baseline") or {}
     put("cpu_model", cb.get("cpu_model"))
     put("cpu_t1_pairs_per_s", cb.get("t1_pairs_per_s"))
@@ -1212,6 +1251,8 @@ def flatten(out):
     if "failed" in jb:
         put("offline_J_b1024_failed", str(jb["failed"])[:200])
     put("offline_all_N_ms", f.get("all_N_sample_to_resident_spg_ms"))
+    put("offline_all_N_4hop_ms", f.get("all_N_4hop_sample_to_resident_spg_ms"))
+    put("offline_4hop_roots_per_s", f.get("all_N_4hop_roots_per_s"))
     put("offline_S_roots_per_s", f.get("S_roots_per_s"))
     put("offline_J_table_pairs_per_s", f.get("J_pairs_per_s_table_store"))
     put("offline_J_keyed_pairs_per_s", f.get("J_pairs_per_s_keyed_store"))

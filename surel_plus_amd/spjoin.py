@@ -334,9 +334,13 @@ def gather_many(edges, x, device=None, ptr=True, encode=None, out=None):
     parts = split_batches(xz, seg, B)
     if ptr:
         return parts
-    out_l = []
-    for xz_b, p in parts:       # segment ids (train.py:25-30, the LSTM aggregator): one repeat_interleave per batch, rows known
-        out_l.append((xz_b, torch.repeat_interleave(torch.arange(2 * B, device=spg.device), p[1:] - p[:-1], output_size=xz_b.shape[0])))
+    # segment ids (train.py:25-30, the LSTM aggregator): 0..2B-1 inside every batch -- ONE repeat_interleave for all of them
+    S = seg.numel() - 1
+    ids_all = torch.repeat_interleave(torch.arange(S, device=spg.device) % (2 * B), seg[1:] - seg[:-1], output_size=xz.shape[0])
+    out_l, lo = [], 0
+    for xz_b, _ in parts:
+        out_l.append((xz_b, ids_all[lo:lo + xz_b.shape[0]]))
+        lo += xz_b.shape[0]
     return out_l
 
 
@@ -351,6 +355,28 @@ def hgather(hedge, x, device=None, encode=None):
     xz, ind = _checked(*sjoin(spg, own, None, encode, ptr_mode=False, pair_block=h.shape[1]))
     assert xz.size(0) == ind.size(0)
     return xz, ind
+
+
+def hgather_many(hedges, x, device=None, encode=None):
+    """hgather() for MANY batches of triplets at once (main_horder.py:33: 2,048 triplets per batch, ~8k one-pair workgroups that
+    cannot fill the chip): `hedges` [nb, 3, B] joined in one launch sequence; returns [(xz_b, ids_b)] * nb, bit for bit what
+    hgather(hedges[b], x, device, encode) returns (segment ids 0..4B-1 per batch, train.py:57-68)."""
+    if encode is None:
+        raise NotImplementedError
+    spg = _as_spg(x)
+    h = _as_rows(hedges, spg.device)
+    if h.dim() != 3 or h.shape[1] != 3:
+        raise ValueError("hgather_many: hedges must be [nb, 3, B]")
+    nb, _, B = h.shape
+    if nb == 0 or B == 0:
+        return [hgather(h[b], spg, device, encode) for b in range(nb)]
+    own = torch.stack([h[:, 0], h[:, 2], h[:, 1], h[:, 2]], dim=1).contiguous().view(-1)      # per batch [u | w | v | w]: two mirrored pairs of blocks
+    xz, seg, flags = sjoin(spg, own, None, encode, ptr_mode=True, pair_block=B)
+    _checked(xz, seg, flags)
+    P = 4 * B
+    bounds = seg[::P].tolist()
+    ids_all = torch.repeat_interleave(torch.arange(nb * P, device=spg.device) % P, seg[1:] - seg[:-1], output_size=xz.shape[0])
+    return [(xz[bounds[b]:bounds[b + 1]], ids_all[bounds[b]:bounds[b + 1]]) for b in range(nb)]
 
 
 def bgather(edge, x, out):

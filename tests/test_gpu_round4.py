@@ -65,6 +65,29 @@ def test_gather_many_is_gather_batch_by_batch(sp, ptr, store):
         sp.gather_many(bad, x, "cuda", ptr=ptr, encode=table)
 
 
+@pytest.mark.parametrize("store", ["table", "keyed"])
+def test_hgather_many_is_hgather_batch_by_batch(sp, store):
+    """train.py:48-72 at main_horder.py:33's batch size, many batches per launch sequence: per batch the blocks [U|w ; W|u ; V|w ; W|v]
+    with their segment ids, bit for bit the single-batch call and the oracle"""
+    N, M = 3000, 40
+    csr, z, enc, o_spg, _ = _store(sp, N=N, M=M)
+    zsf = enc.astype(np.float32) / np.float32(M)
+    x, table = (z.keyed(enc, M), None) if store == "keyed" else (z, torch.from_numpy(zsf).cuda())
+    if store == "keyed":
+        table = x.slot_table()
+    hedges = np.random.default_rng(6).integers(0, N, (5, 3, 41))
+    hedges[1, :, 3] = hedges[1, 0, 3]
+    many = sp.hgather_many(hedges, x, "cuda", encode=table)
+    assert len(many) == 5
+    for b in range(5):
+        xz1, ids1 = sp.hgather(hedges[b], x, "cuda", encode=table)
+        assert torch.equal(many[b][0], xz1) and torch.equal(many[b][1], ids1), b
+        oxz, oids = oracle.hgather(hedges[b], o_spg, zsf)
+        assert np.array_equal(many[b][0].cpu().numpy(), oxz) and np.array_equal(many[b][1].cpu().numpy(), oids), b
+    with pytest.raises(NotImplementedError):
+        sp.hgather_many(hedges, x, "cuda", encode=None)
+
+
 @pytest.mark.parametrize("M,hops,idx64", [(40, 3, False), (200, 2, True), (24, 4, False)])
 def test_sample_and_gather_many_is_sample_and_gather_batch_by_batch(sp, M, hops, idx64):
     """nb batches of B pairs sampled by ONE walk launch and joined by ONE join launch: every batch's (xz, indptr) is what the
