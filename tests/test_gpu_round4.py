@@ -63,6 +63,13 @@ def test_gather_many_is_gather_batch_by_batch(sp, ptr, store):
         bad = edges.copy()
         bad[3, 1, 2] = N + 5
         sp.gather_many(bad, x, "cuda", ptr=ptr, encode=table)
+    # edge cases: no batches, empty batches, a single batch
+    assert sp.gather_many(edges[:0], x, "cuda", ptr=ptr, encode=table) == []
+    empty = sp.gather_many(edges[:2, :, :0], x, "cuda", ptr=ptr, encode=table)
+    assert len(empty) == 2 and all(e_[0].shape[0] == 0 for e_ in empty)
+    one = sp.gather_many(edges[:1], x, "cuda", ptr=ptr, encode=table)
+    xz1, ind1 = sp.gather(edges[0], x, "cuda", ptr=ptr, encode=table)
+    assert len(one) == 1 and torch.equal(one[0][0], xz1) and torch.equal(one[0][1], ind1)
 
 
 @pytest.mark.parametrize("store", ["table", "keyed"])
