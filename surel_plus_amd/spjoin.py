@@ -84,7 +84,7 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
     is_f64 = spg.data.dtype == torch.float64
     if getattr(spg, "keyrows", False):       # SpG.keyed(): the payload is the LP key, the join unpacks it (no table)
         from .spg import KEY_ROWS_ENCODE
-        if encode is not KEY_ROWS_ENCODE or return_index or pair_block <= 0 or (lazy and not ptr_mode):
+        if encode is not KEY_ROWS_ENCODE or return_index or (pair_block <= 0 and S > 0) or (lazy and not ptr_mode):
             raise ValueError("a keyed() store is joined by gather / hgather(…, encode=zk.slot_table())")
         k = spg.key_m + 1
         R = None if lazy else _size_and_row_check(seg, S, flags, spg.n_rows)

@@ -220,3 +220,29 @@ def test_twitter_like_generator_is_symmetric_simple_and_sorted(sp):
     assert bool((key[1:] > key[:-1]).all()) and bool((row != ix).all())
     assert torch.equal(torch.sort(ix * N + row).values, key)
     assert 25.0 < g.nnz / N < 31.0
+
+
+def test_the_epoch_loop_of_integration_md(sp):
+    """INTEGRATION.md, "the reference's loop at the reference's batch size": train.py:120-128 regrouped -- the DataLoader's permutation
+    drawn up front, 64 batches per gather_many call, a short last batch -- gives every batch exactly what the reference's loop body
+    (`pgather(edge, g, device, rpe, bgather, ptr)` per batch, train.py:127) gives, and a first model stage consumes it unchanged."""
+    from torch.utils.data import DataLoader
+    N, M, batch_size = 3000, 40, 128
+    csr, g, enc, o_spg, _ = _store(sp, N=N, M=M)
+    rpe = torch.from_numpy(enc).cuda().float() / M                     # main.py:174
+    edges = torch.from_numpy(np.random.default_rng(12).integers(0, N, (2, 1000)))      # 7 full batches + one of 104
+    torch.manual_seed(3)
+    perms = list(DataLoader(range(edges.size(1)), batch_size, shuffle=True))
+    embed = torch.nn.Linear(enc.shape[1], 8).cuda()
+    seen = 0
+    for lo in range(0, len(perms), 64):
+        group = [edges[:, p] for p in perms[lo:lo + 64]]
+        for perm, (x, ind) in zip(perms[lo:lo + 64], sp.gather_many(group, g, "cuda", ptr=True, encode=rpe)):
+            rx, rind = sp.pgather(edges[:, perm], g, "cuda", rpe, sp.bgather, ptr=True)          # the reference's loop body
+            assert torch.equal(x, rx) and torch.equal(ind, rind)
+            oxz, oind = oracle.gather(edges[:, perm].numpy(), o_spg, ptr=True, encode=rpe.cpu().numpy())
+            assert np.array_equal(x.cpu().numpy(), oxz) and np.array_equal(ind.cpu().numpy(), oind)
+            h = torch.segment_reduce(embed(x).sum(dim=-2), "mean", offsets=ind, axis=0).view(2, -1, 8)     # model.py:78-83, mean aggregation
+            assert h.shape[1] == perm.numel() and bool(torch.isfinite(h).all())
+            seen += perm.numel()
+    assert seen == edges.size(1)
