@@ -957,16 +957,16 @@ def offline_flow(sp, csr, M, k, B, K, cpu):
             for e in es * 2:
                 sp.gather(e, zk, dev, ptr=True, encode=zk.slot_table(), out=sbuf, lazy=True)
         b1024["eager"] = rate(eager, 2 * len(es) * Bs)
-        cjs = [sp.CapturedJoin(zk, Bs, encode=zk.slot_table()) for _ in (0, 1)]
+        cjs = [sp.CapturedJoin(zk, Bs, encode=zk.slot_table()) for _ in range(4)]
 
-        def graph():
-            pend = None
+        def graph():      # four captured joins in turn, each resolved (rows + status read back) three batches behind the queue
+            pend = []
             for i, e in enumerate(es * 2):
-                q = cjs[i & 1](e)
-                if pend is not None:
-                    pend.finish()
-                pend = q
-            pend.finish()
+                pend.append(cjs[i & 3](e))
+                if len(pend) == 4:
+                    pend.pop(0).finish()
+            for q in pend:
+                q.finish()
         b1024["graph"] = rate(graph, 2 * len(es) * Bs)
         del cjs
 
