@@ -105,7 +105,7 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
             check(L.subgacc_sjoin_fill_keys(ptr(spg.indptr), spg.n_rows, ptr(spg.indices), ptr(spg.data), ptr(own), ptr(partner), S,
                                             ptr(seg), spg.key_M, spg.key_m, ptr(res), ptr(segid), spg.max_len, pair_block,
                                             ptr(flags), st))
-        return res, (seg if ptr_mode else segid), flags
+        return res, (seg if ptr_mode else _with_pointers(segid, seg)), flags
     if lazy and (out is None or not ptr_mode or return_index or (encode is None and not is_f64)):
         raise ValueError("lazy=True needs out=, ptr=True and an integer SpG with its encode table (or a float-payload SpG)")
     R = None if lazy else _size_and_row_check(seg, S, flags, spg.n_rows)     # the one host round trip
@@ -155,7 +155,7 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
             check(L.subgacc_sjoin_fill(ptr(spg.indptr), spg.n_rows, ptr(spg.indices), ptr(spg.data), None, ptr(own), ptr(partner), S,
                                        ptr(seg), ptr(enc), enc.shape[0], k, ptr(out), None, ptr(segid), spg.max_len,
                                        pair_block, ptr(flags), st))
-    return out, (seg if ptr_mode else segid), flags
+    return out, (seg if ptr_mode else _with_pointers(segid, seg)), flags
 
 
 def _sjoin_strided(spg, own, partner, seg, ws, encode, ptr_mode, return_index, pair_block, out, lazy):
@@ -180,7 +180,7 @@ def _sjoin_strided(spg, own, partner, seg, ws, encode, ptr_mode, return_index, p
         check(L.subgacc_sjoin_fill_rows(ptr(spg.nsize), spg.n_rows, spg.stride, ptr(spg.indices), ptr(spg.slot), ptr(spg.table),
                                         spg.capacity, ptr(own), ptr(partner), S, ptr(seg), None, 0, 0, None, ptr(res),
                                         ptr(segid), pair_block, ptr(flags), st))
-        return res, (seg if ptr_mode else segid), flags
+        return res, (seg if ptr_mode else _with_pointers(segid, seg)), flags
     if encode is None:
         raise NotImplementedError("an integer SpG needs the encode table")
     if getattr(spg, "keyrows", False):      # rows of LP keys: the feature rows are unpacked from the keys by the join itself
@@ -230,7 +230,13 @@ def _sjoin_strided(spg, own, partner, seg, ws, encode, ptr_mode, return_index, p
         check(L.subgacc_sjoin_fill_rows(ptr(spg.nsize), spg.n_rows, spg.stride, ptr(spg.indices), ptr(spg.slot), ptr(tab), cap,
                                         ptr(own), ptr(partner), S, ptr(seg), ptr(enc), enc.shape[0], k,
                                         ptr(res), None, ptr(segid), pair_block, ptr(flags), st))
-    return res, (seg if ptr_mode else segid), flags
+    return res, (seg if ptr_mode else _with_pointers(segid, seg)), flags
+
+
+def _with_pointers(segid, seg):
+    """segment ids as the join's second result; the pointers they were made from ride along (gather_many / hgather_many cut by them)"""
+    segid.seg_pointers = seg
+    return segid
 
 
 def _size_and_row_check(seg, S, flags, n_rows):
@@ -329,19 +335,15 @@ def gather_many(edges, x, device=None, ptr=True, encode=None, out=None):
     if nb == 0 or B == 0:
         return [gather(e[b], spg, device, ptr=ptr, encode=encode) for b in range(nb)]
     own = e.contiguous().view(-1)                              # [u_0 | v_0 | u_1 | v_1 | ...]: mirrored blocks of B segments
-    xz, seg, flags = sjoin(spg, own, None, encode, ptr_mode=True, pair_block=B, out=out)
-    _checked(xz, seg, flags)
-    parts = split_batches(xz, seg, B)
+    xz, ind, flags = sjoin(spg, own, None, encode, ptr_mode=ptr, pair_block=B, out=out)
+    _checked(xz, ind, flags)
     if ptr:
-        return parts
-    # segment ids (train.py:25-30, the LSTM aggregator): 0..2B-1 inside every batch -- ONE repeat_interleave for all of them
-    S = seg.numel() - 1
-    ids_all = torch.repeat_interleave(torch.arange(S, device=spg.device) % (2 * B), seg[1:] - seg[:-1], output_size=xz.shape[0])
-    out_l, lo = [], 0
-    for xz_b, _ in parts:
-        out_l.append((xz_b, ids_all[lo:lo + xz_b.shape[0]]))
-        lo += xz_b.shape[0]
-    return out_l
+        return split_batches(xz, ind, B)
+    # segment ids (train.py:25-30, the LSTM aggregator): the kernel wrote the ids over ALL segments; inside a batch they are 0..2B-1
+    seg = ind.seg_pointers
+    bounds = seg[::2 * B].tolist()
+    ind.remainder_(2 * B)
+    return [(xz[bounds[b]:bounds[b + 1]], ind[bounds[b]:bounds[b + 1]]) for b in range(nb)]
 
 
 def hgather(hedge, x, device=None, encode=None):
@@ -371,12 +373,12 @@ def hgather_many(hedges, x, device=None, encode=None):
     if nb == 0 or B == 0:
         return [hgather(h[b], spg, device, encode) for b in range(nb)]
     own = torch.stack([h[:, 0], h[:, 2], h[:, 1], h[:, 2]], dim=1).contiguous().view(-1)      # per batch [u | w | v | w]: two mirrored pairs of blocks
-    xz, seg, flags = sjoin(spg, own, None, encode, ptr_mode=True, pair_block=B)
-    _checked(xz, seg, flags)
+    xz, ids, flags = sjoin(spg, own, None, encode, ptr_mode=False, pair_block=B)
+    _checked(xz, ids, flags)
     P = 4 * B
-    bounds = seg[::P].tolist()
-    ids_all = torch.repeat_interleave(torch.arange(nb * P, device=spg.device) % P, seg[1:] - seg[:-1], output_size=xz.shape[0])
-    return [(xz[bounds[b]:bounds[b + 1]], ids_all[bounds[b]:bounds[b + 1]]) for b in range(nb)]
+    bounds = ids.seg_pointers[::P].tolist()
+    ids.remainder_(P)                                          # the kernel numbered the segments of all batches: 0..4B-1 inside a batch
+    return [(xz[bounds[b]:bounds[b + 1]], ids[bounds[b]:bounds[b + 1]]) for b in range(nb)]
 
 
 def bgather(edge, x, out):
