@@ -970,12 +970,19 @@ def offline_flow(sp, csr, M, k, B, K, cpu):
         b1024["graph"] = rate(graph, 2 * len(es) * Bs)
         del cjs
 
-        def many():
+        sbuf2 = torch.empty_like(sbuf)
+
+        def many():     # a group of 64 batches is queued (no host read: lazy) before the previous group is consumed batch by batch
+            prev = None
             for i in range(8):
-                parts = sp.gather_many(stacks[i & 1], zk, dev, ptr=True, encode=zk.slot_table(), out=sbuf)
-                assert len(parts) == NB
+                cur = sp.gather_many(stacks[i & 1], zk, dev, ptr=True, encode=zk.slot_table(), out=(sbuf, sbuf2)[i & 1], lazy=True)
+                if prev is not None:
+                    n_b = sum(1 for xz_b, ind_b in prev)          # boundaries read, 64 (xz, indptr) views made
+                    assert n_b == NB
+                prev = cur
+            assert sum(1 for xz_b, ind_b in prev) == NB
         b1024["many_64"] = rate(many, 8 * NB * Bs)
-        del sbuf, stacks
+        del sbuf, sbuf2, stacks
     except Exception as ex:
         b1024["failed"] = f"{type(ex).__name__}: {ex}"
     out = {"J_b1024_keyed": b1024, "all_N_4hop_sample_to_resident_spg_ms": t_m4 * 1e3 if t_m4 else None,

@@ -290,29 +290,73 @@ def gather(edge, x, device=None, ptr=True, encode=None, out=None, lazy=False):
     return _checked(*sjoin(spg, own, None, encode, ptr_mode=ptr, pair_block=e.shape[1], out=out, lazy=lazy), lazy=lazy)
 
 
+class BatchViews:
+    """The nb reference-shaped results of a join over nb batches laid out [u_0 | v_0 | u_1 | v_1 | ...]: a sequence of
+    (xz_b, indptr_b) -- xz_b float32 [R_b, 2, k] the rows of batch b (a view of the one output buffer), indptr_b int64 [2B+1]
+    starting at 0 (train.py:21-22; a row of ONE [nb, 2B+1] tensor), or segment ids 0..P-1 where the caller asked for ids.
+    The nb+1 batch boundaries (and the join's status word) are read from the device when the first batch is TAKEN, in one small
+    copy, and the views are made batch by batch as they are taken: a loop that queues the next group of batches before it
+    consumes this one never waits for the GPU in between.  A row number outside the store raises IndexError at that point."""
+
+    def __init__(self, xz, seg, seg_per_batch, ids=None, flags=None, n_rows=None):
+        P = int(seg_per_batch)
+        S = seg.numel() - 1
+        if P <= 0 or S % P:
+            raise ValueError(f"{S} segments are not a whole number of batches of {P} segments")
+        self.xz, self.seg, self.P, self.nb, self.ids = xz, seg, P, S // P, ids
+        self._flags, self._n_rows, self._bounds, self._ptrs = flags, n_rows, None, None
+
+    def _resolve(self):
+        if self._bounds is None:
+            src = self.seg[::self.P]                           # [nb+1]: first row of every batch, and the total
+            if self._flags is not None:
+                src = torch.cat([src, self._flags[3:4].to(torch.int64)])
+            words = src.tolist()
+            if self._flags is not None:
+                if words.pop() & 16:
+                    raise IndexError(f"row index out of range for an SpG with {self._n_rows} rows")
+            self._bounds = words
+            if self.ids is None:
+                self._ptrs = self.seg.as_strided((self.nb, self.P + 1), (self.P, 1)) - self.seg[:-1:self.P][:, None]
+        return self._bounds
+
+    def __len__(self):
+        return self.nb
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self.nb))]
+        if i < 0:
+            i += self.nb
+        if not 0 <= i < self.nb:
+            raise IndexError(i)
+        b = self._resolve()
+        if self.ids is not None:
+            return self.xz[b[i]:b[i + 1]], self.ids[b[i]:b[i + 1]]
+        return self.xz[b[i]:b[i + 1]], self._ptrs[i]
+
+    def __iter__(self):
+        return (self[i] for i in range(self.nb))
+
+    def __eq__(self, other):                    # (an empty result compares equal to []: gather_many(edges[:0]) == [])
+        return list(self) == other if isinstance(other, list) else NotImplemented
+
+
 def split_batches(xz, seg, batch_pairs):
-    """The result of a join over nb batches laid out [u_0 | v_0 | u_1 | v_1 | ...] (gather_many, sample_and_gather_many, a
-    StepBuffers made with batch=) as nb reference-shaped results: [(xz_b, indptr_b)] with indptr_b int64 [2B+1] starting at 0
-    (train.py:21-22) and xz_b the rows of batch b -- views of `xz`, plus ONE [nb, 2B+1] tensor for all the pointers.  One small
-    host read (the nb+1 batch boundaries)."""
-    P = 2 * int(batch_pairs)
-    S = seg.numel() - 1
-    if P <= 0 or S % P:
-        raise ValueError(f"{S} segments are not a whole number of batches of {batch_pairs} pairs")
-    nb = S // P
-    bounds = seg[::P]                                         # [nb+1]: first row of every batch, and the total
-    ptrs = seg.as_strided((nb, P + 1), (P, 1)) - bounds[:nb, None]
-    b = bounds.tolist()
-    return [(xz[b[i]:b[i + 1]], ptrs[i]) for i in range(nb)]
+    """The result of a join over nb batches of `batch_pairs` pairs (gather_many, sample_and_gather_many, a StepBuffers made with
+    batch=) as its nb reference-shaped pieces: see BatchViews."""
+    return BatchViews(xz, seg, 2 * int(batch_pairs))
 
 
-def gather_many(edges, x, device=None, ptr=True, encode=None, out=None):
+def gather_many(edges, x, device=None, ptr=True, encode=None, out=None, lazy=False):
     """gather() for MANY reference-sized batches at once: `edges` [nb, 2, B] (the batches of an epoch are known when it starts:
     train.py:120 draws the DataLoader permutation up front) joined in ONE launch sequence -- one size pass, one scan, one fill
     over nb*B pairs -- instead of nb times three launches of 1,024 pairs that cannot fill the chip (main.py:32).  Returns
     [(xz_b, ind_b)] * nb, bit for bit what `gather(edges[b], x, device, ptr, encode)` returns for every b: xz_b float32
     [R_b, 2, k] (views of one buffer, `out` if given), ind_b int64 [2B+1] segment pointers from 0 (ptr=True) or int64 [R_b]
-    segment ids 0..2B-1 (ptr=False).  Two small host reads for the whole call (total rows, batch boundaries).
+    segment ids 0..2B-1 (ptr=False).  One small host read when the call is made (the total number of rows, to size xz) and one when
+    the first batch is taken (BatchViews); lazy=True (needs out= for the worst case -- nb*2B * SpG.max_len * 2k float32 -- and
+    ptr=True) makes the call itself free of host reads: the next group can be queued before this one is consumed.
     `edges` may also be a list of [2, B_i] arrays: runs of equal B are fused, the rest (an epoch's short last batch) joined singly."""
     spg = _as_spg(x)
     if isinstance(edges, (list, tuple)):
@@ -335,15 +379,15 @@ def gather_many(edges, x, device=None, ptr=True, encode=None, out=None):
     if nb == 0 or B == 0:
         return [gather(e[b], spg, device, ptr=ptr, encode=encode) for b in range(nb)]
     own = e.contiguous().view(-1)                              # [u_0 | v_0 | u_1 | v_1 | ...]: mirrored blocks of B segments
-    xz, ind, flags = sjoin(spg, own, None, encode, ptr_mode=ptr, pair_block=B, out=out)
+    if lazy and not ptr:
+        raise ValueError("gather_many(lazy=True) needs ptr=True (segment ids are sized by the row count)")
+    xz, ind, flags = sjoin(spg, own, None, encode, ptr_mode=ptr, pair_block=B, out=out, lazy=lazy)
     _checked(xz, ind, flags)
     if ptr:
-        return split_batches(xz, ind, B)
+        return BatchViews(xz, ind, 2 * B, flags=flags if lazy else None, n_rows=spg.n_rows)
     # segment ids (train.py:25-30, the LSTM aggregator): the kernel wrote the ids over ALL segments; inside a batch they are 0..2B-1
-    seg = ind.seg_pointers
-    bounds = seg[::2 * B].tolist()
     ind.remainder_(2 * B)
-    return [(xz[bounds[b]:bounds[b + 1]], ind[bounds[b]:bounds[b + 1]]) for b in range(nb)]
+    return BatchViews(xz, ind.seg_pointers, 2 * B, ids=ind)
 
 
 def hgather(hedge, x, device=None, encode=None):
@@ -375,10 +419,8 @@ def hgather_many(hedges, x, device=None, encode=None):
     own = torch.stack([h[:, 0], h[:, 2], h[:, 1], h[:, 2]], dim=1).contiguous().view(-1)      # per batch [u | w | v | w]: two mirrored pairs of blocks
     xz, ids, flags = sjoin(spg, own, None, encode, ptr_mode=False, pair_block=B)
     _checked(xz, ids, flags)
-    P = 4 * B
-    bounds = ids.seg_pointers[::P].tolist()
-    ids.remainder_(P)                                          # the kernel numbered the segments of all batches: 0..4B-1 inside a batch
-    return [(xz[bounds[b]:bounds[b + 1]], ids[bounds[b]:bounds[b + 1]]) for b in range(nb)]
+    ids.remainder_(4 * B)                                      # the kernel numbered the segments of all batches: 0..4B-1 inside a batch
+    return BatchViews(xz, ids.seg_pointers, 4 * B, ids=ids)
 
 
 def bgather(edge, x, out):

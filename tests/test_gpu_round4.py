@@ -246,3 +246,29 @@ def test_the_epoch_loop_of_integration_md(sp):
             assert h.shape[1] == perm.numel() and bool(torch.isfinite(h).all())
             seen += perm.numel()
     assert seen == edges.size(1)
+
+
+def test_gather_many_lazy_reads_nothing_until_a_batch_is_taken(sp):
+    """gather_many(out=, lazy=True): the call queues the join without a host read; the batch boundaries (and the status word) arrive
+    with the first batch that is taken -- same results, and a row number outside the store raises THERE"""
+    N, M = 3000, 40
+    csr, z, enc, o_spg, _ = _store(sp, N=N, M=M)
+    zk = z.keyed(enc, M)
+    nb, B = 6, 64
+    edges = torch.from_numpy(np.random.default_rng(2).integers(0, N, (nb, 2, B))).cuda()
+    out = torch.empty(nb * 2 * B * zk.max_len * 2 * enc.shape[1], dtype=torch.float32, device="cuda")
+    lazy = sp.gather_many(edges, zk, "cuda", encode=zk.slot_table(), out=out, lazy=True)
+    assert lazy._bounds is None                                   # nothing has been read back yet
+    eager = sp.gather_many(edges, zk, "cuda", encode=zk.slot_table())
+    for (a, ai), (b_, bi) in zip(lazy, eager):
+        assert torch.equal(a, b_) and torch.equal(ai, bi)
+    assert len(lazy[1:3]) == 2 and torch.equal(lazy[-1][0], eager[nb - 1][0])
+    bad = edges.clone()
+    bad[2, 0, 5] = N + 3
+    q = sp.gather_many(bad, zk, "cuda", encode=zk.slot_table(), out=out, lazy=True)
+    with pytest.raises(IndexError):
+        q[0]
+    with pytest.raises(ValueError):
+        sp.gather_many(edges, zk, "cuda", ptr=False, encode=zk.slot_table(), out=out, lazy=True)
+    with pytest.raises(ValueError):
+        sp.gather_many(edges, zk, "cuda", encode=zk.slot_table(), out=out[:1000], lazy=True)
