@@ -728,6 +728,10 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
                      "join_achieved": (join_abytes / (join_ms * 1e-3) / 1e9) if (join_ms and join_abytes) else None,
                      "join_frac": (join_abytes / (join_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (join_ms and join_abytes) else None,
                      "join_traffic": join_traffic,
+                     # the step as a whole at the memory side of L2 (walk + join, PMC): what the two kernels queue on together --
+                     # a plain copy reaches ~6.3 TB/s on this part (profiles/r04d_stream_probe.csv)
+                     "step_traffic": (traffic + join_traffic) if (traffic and join_traffic) else None,
+                     "step_traffic_TBps": ((traffic + join_traffic) / (ms_per_step * 1e-3) / 1e12) if (traffic and join_traffic) else None,
                      # the roof this kernel actually sits under: random 128-byte lines per second
                      "random_line_roof": {"lines_per_s": roof, "line_bytes": LINE_BYTES, "table_bytes": roof_bytes,
                                           "source": (f"tools/line_roof_lib.hip in this run: independent random 4-byte reads over the {roof_table} "
@@ -1285,6 +1289,7 @@ def flatten(out):
     rl["l2_miss_lines_per_launch"] = lr.get("l2_miss_lines_per_launch")
     put("join_frac", rl.get("join_frac"))
     put("join_traffic_bytes", rl.get("join_traffic"))
+    put("step_traffic_TBps", rl.get("step_traffic_TBps"))
     sm = c.get("stage_ms") or {}
     put("walk_kernel_ms", sm.get("walk_sets"))
     put("join_kernel_ms", sm.get("sjoin_fill"))
