@@ -623,6 +623,7 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     if fused_rows:
         keep_keys = False
     limit = uniq_small_limit if uniq_small_limit > 0 else RANK_LIMIT
+    key_rows_arg = key_rows          # (what the caller asked for: a retry with a larger table asks for the same)
     kform = key_rows_form(M, m) if (key_rows and strided and fused_rows and not number_rows and bucket <= 0 and not walk_replay) else 0
     per_member = (12 if kform == 64 else 8) if fused_rows else 12
     if staging_bytes is None:     # 288 GB of HBM: one chunk of roots wherever a third of the free memory holds its staging rows
@@ -765,7 +766,8 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
                     return sample_sets(csr, q, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order,
                                        cap_root_degree, emit_walks, rng_streams, calls_before, dedup, keep_keys,
                                        staging_bytes, uniq_capacity * 4, uniq_small_limit, fused_rows, lazy, strided,
-                                       number_rows, walk_replay=walk_replay)
+                                       number_rows, key_rows=key_rows_arg, walk_replay=walk_replay,
+                                       batched_registration=batched_registration, sort_roots=sort_roots)
                 if st_host[4] > max_unique:       # more distinct rows than the direct ranking numbers: the caller
                     return None                   # (sample_spg) falls through to the packed forms
                 sets.resolve()
@@ -855,7 +857,8 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     if st_host[2]:
         return sample_sets(csr, q, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order, cap_root_degree,
                            emit_walks, rng_streams, calls_before, dedup, keep_keys, staging_bytes, uniq_capacity * 4,
-                           uniq_small_limit, fused_rows, lazy, strided, number_rows, walk_replay=walk_replay)
+                           uniq_small_limit, fused_rows, lazy, strided, number_rows, key_rows=key_rows_arg, walk_replay=walk_replay,
+                           batched_registration=batched_registration, sort_roots=sort_roots)
     sets.resolve()
     sets.ukeys = sets.ukeys.clone()
     return sets
