@@ -711,7 +711,9 @@ def sample_and_gather_many(csr, edges, num_walks=200, num_steps=3, seed=111413, 
             raise ValueError(f"buffers= must be StepBuffers(csr, {nb * B}, ..., batch={B})")
         xz, seg, sets = sample_and_gather(csr, e, num_walks=num_walks, num_steps=num_steps, seed=seed, rng=rng, out=out, buffers=buffers, **kw)
         sets.resolve()
-        return split_batches(xz, seg, B), sets
+        views = split_batches(xz, seg, B)
+        views._resolve()      # (the pointers live in the step buffers: read now, before the buffers take another step)
+        return views, sets
     from .spg import sample_spg
     kw.setdefault("number_rows", False)
     z, sets = sample_spg(csr, e.reshape(-1).to(torch.int32), num_walks=num_walks, num_steps=num_steps, seed=seed, rng=rng,

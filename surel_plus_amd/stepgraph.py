@@ -133,7 +133,9 @@ class CapturedStep:
         """finish() for a step captured with batch=b: [(xz_i, indptr_i)] for its pairs/b reference-sized batches (spjoin.split_batches)"""
         from .spjoin import split_batches
         xz, ind = self.finish()
-        return split_batches(xz, ind, self.batch)
+        views = split_batches(xz, ind, self.batch)
+        views._resolve()      # (the pointers live in the step's static buffers: read them now, before the next replay rewrites them)
+        return views
 
 
 class CapturedStepPool:
