@@ -123,3 +123,53 @@ def test_kernel_shape_rules_of_the_fused_row_path():
     assert walk_kernel_name(None, 200, 5, True) == "walk_sets_kernel<SPG>"
     assert walk_kernel_name(None, 200, 2, False) == "walk_pipe_kernel"
     assert walk_kernel_name(None, 300, 2, False) == "walk_sets_kernel"
+
+
+def test_key_row_forms_and_the_launcher_mirror_of_round_4():
+    """4 hops: 32-bit key rows up to M = 127 (512- and 1,024-slot tables), 64-bit key rows for M = 128 .. 204, the table form beyond;
+    a truncating bucket or more than 256 walks leave the launch to the general fused kernel (sampler.rows_kernel_takes)"""
+    from surel_plus_amd.sampler import key_rows_form, key_rows_ok, rows_kernel_takes, walk_kernel_name
+    assert key_rows_form(100, 4) == 32 and key_rows_form(127, 4) == 32          # 4*7+1 = 29 bits
+    assert key_rows_form(128, 4) == 64 and key_rows_form(200, 4) == 64 and key_rows_form(204, 4) == 64      # 33 bits, 1,024 slots
+    assert key_rows_form(205, 4) == 0                                            # 821 members: beyond the 1,024-slot table
+    assert key_rows_form(50, 4) == 0                                             # a 256-slot table: the general kernel
+    assert key_rows_form(200, 3) == 32 and key_rows_form(200, 5) == 0 and key_rows_form(300, 2) == 0
+    assert key_rows_ok(100, 4) and not key_rows_ok(200, 4)                       # batched registration works on 32-bit keys
+    assert rows_kernel_takes(200, 3) and not rows_kernel_takes(200, 3, bucket=50) and not rows_kernel_takes(300, 2)
+    assert walk_kernel_name(None, 200, 2, True, 50) == "walk_sets_kernel<SPG>"
+
+
+def test_batch_views_cut_a_many_batch_join_into_reference_shaped_pieces():
+    """spjoin.BatchViews (what gather_many / sample_and_gather_many / hgather_many return) on host tensors: per-batch rows, pointers
+    from 0 (train.py:21-22) or segment ids, laziness, the status word, the error cases -- no GPU needed for the bookkeeping"""
+    from surel_plus_amd.spjoin import BatchViews, split_batches
+    B, nb = 3, 4
+    lens = torch.arange(1, 2 * B * nb + 1) % 5                     # segment lengths, some empty
+    seg = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(lens, 0)])
+    R = int(seg[-1])
+    xz = torch.arange(R * 2 * 2, dtype=torch.float32).view(R, 2, 2)
+    v = split_batches(xz, seg, B)
+    assert len(v) == nb and v._bounds is None                      # nothing read yet
+    for b in range(nb):
+        xb, pb = v[b]
+        lo, hi = int(seg[2 * B * b]), int(seg[2 * B * (b + 1)])
+        assert torch.equal(xb, xz[lo:hi]) and pb.dtype == torch.int64 and pb.numel() == 2 * B + 1
+        assert int(pb[0]) == 0 and torch.equal(pb[1:] - pb[:-1], lens[2 * B * b: 2 * B * (b + 1)])
+    assert torch.equal(v[-1][0], v[nb - 1][0]) and len(v[1:3]) == 2 and [x.shape[0] for x, _ in v] == [int(seg[6 * (b + 1)] - seg[6 * b]) for b in range(nb)]
+    with pytest.raises(IndexError):
+        v[nb]
+    # segment ids instead of pointers (ptr=False / hgather): ids restart at 0 in every batch
+    ids = torch.repeat_interleave(torch.arange(2 * B * nb) % (2 * B), lens)
+    w = BatchViews(xz, seg, 2 * B, ids=ids)
+    for b in range(nb):
+        xb, ib = w[b]
+        assert ib.numel() == xb.shape[0] and (ib.numel() == 0 or (int(ib.min()) >= 0 and int(ib.max()) < 2 * B))
+    # the lazy form carries the join's status word: a row number outside the store raises when the first batch is taken
+    flags = torch.zeros(4, dtype=torch.int32)
+    flags[3] = 16
+    bad = BatchViews(xz, seg, 2 * B, flags=flags, n_rows=7)
+    with pytest.raises(IndexError, match="7 rows"):
+        bad[0]
+    with pytest.raises(ValueError):
+        BatchViews(xz, seg, 5)                                      # 24 segments are not a whole number of batches of 5
+    assert BatchViews(xz[:0], torch.zeros(1, dtype=torch.int64), 2 * B) == []
