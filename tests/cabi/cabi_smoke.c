@@ -42,6 +42,8 @@ int main(int argc, char **argv) {
     SYM(subgacc_uniq_table_bytes); SYM(subgacc_uniq_reset); SYM(subgacc_uniq_number_workspace_bytes);
     SYM(subgacc_uniq_number); SYM(subgacc_spg_build); SYM(subgacc_sjoin_workspace_bytes); SYM(subgacc_sjoin_sizes);
     SYM(subgacc_sjoin_fill); SYM(subgacc_unpack_lp); SYM(subgacc_sjoin_fill_keys);
+    SYM(subgacc_step_prologue); SYM(subgacc_walk_keyrows64); SYM(subgacc_walk_spg); SYM(subgacc_sjoin_sizes_rows);
+    SYM(subgacc_sjoin_fill_keyrows64); SYM(subgacc_sjoin_fill_keyrows);
     CHECK(p_subgacc_abi_version() == SUBGACC_ABI_VERSION);
     CHECK(p_subgacc_device_count() >= 1);
     CHECK(p_subgacc_key_shift(8, 2) == 4);
@@ -136,6 +138,74 @@ int main(int argc, char **argv) {
         CHECK(memcmp(xz_h, xz2_h, R * 2 * (m + 1) * 4) == 0);
         HIP(hipMemcpy(fl, flags, 16, hipMemcpyDeviceToHost));
         CHECK(fl[3] == 0);
+    }
+    /* ABI 5: the on-demand step with KEY ROWS, as a C serving loop runs it -- endpoints of two pairs -> prologue (int64 -> int32 roots,
+     * status zeroed) -> fused-row walk whose rows carry the members' LP keys (4 hops: M = 200 needs 33 bits -> subgacc_walk_keyrows64;
+     * M = 100 fits 32 -> subgacc_walk_spg without a table) -> segment sizes -> join that unpacks the keys itself.  Checked here: the
+     * reference's invariants (subg_acc/test/test.py:34-45) on rows and on xz; parity with the oracle is the Python suite's job. */
+    for (int wide = 0; wide < 2; ++wide) {
+        enum { M4 = 0, m4 = 4 };
+        const int Mw = wide ? 200 : 100, S4 = Mw * m4 + 1, sh = wide ? 8 : 7;
+        const int64_t edge_h[4] = {0, 3, 3, 5};                                  /* pairs (0,3) and (3,5): [u0 u1 | v0 v1] */
+        int64_t *edge = dev(sizeof edge_h, edge_h), *status = dev(32, NULL), *seg2 = dev(5 * 8, NULL);
+        int32_t *roots = dev(4 * 4, NULL), *rid = dev(4 * S4 * 4, NULL), *ns2 = dev(4 * 4, NULL);
+        void *rkey = dev((size_t)4 * S4 * 8, NULL);
+        subgacc_walk_cfg c4 = {Mw, m4, -1, SUBGACC_RNG_PHILOX, 7u, 1, SUBGACC_ORDER_WALK_MAJOR, 1, 0, 0};
+        CHECK(p_subgacc_step_prologue(NULL, 0, status, 4, edge, roots, 4, NULL) == 0);
+        if (wide)
+            CHECK(p_subgacc_walk_keyrows64(&c4, indptr, indices, N, roots, 4, NULL, NULL, NULL, NULL, rid, (uint64_t *)rkey, ns2,
+                                           (int32_t *)status, NULL) == 0);
+        else
+            CHECK(p_subgacc_walk_spg(&c4, indptr, indices, N, roots, 4, 0, NULL, NULL, NULL, 0, rid, (int32_t *)rkey, ns2,
+                                     (int32_t *)status, NULL) == 0);
+        const int64_t own2_h[4] = {0, 1, 2, 3};                                   /* row i = endpoint i; partner = the mirror block */
+        int64_t *own2 = dev(sizeof own2_h, own2_h);
+        CHECK(p_subgacc_sjoin_sizes_rows(ns2, 4, own2, NULL, 4, seg2, (int32_t *)status, jws, jwb, NULL) == 0);
+        int64_t s2[5];
+        HIP(hipMemcpy(s2, seg2, sizeof s2, hipMemcpyDeviceToHost));
+        const int64_t R2 = s2[4];
+        float *xzk = dev(R2 * 2 * (m4 + 1) * 4, NULL), *xzk_h = malloc(R2 * 2 * (m4 + 1) * 4);
+        if (wide)
+            CHECK(p_subgacc_sjoin_fill_keyrows64(ns2, 4, S4, rid, (const uint64_t *)rkey, own2, NULL, 4, seg2, Mw, m4, xzk, 2,
+                                                 (int32_t *)status, NULL) == 0);
+        else
+            CHECK(p_subgacc_sjoin_fill_keyrows(ns2, 4, S4, rid, (const int32_t *)rkey, own2, NULL, 4, seg2, Mw, m4, xzk, 2,
+                                               (int32_t *)status, NULL) == 0);
+        HIP(hipDeviceSynchronize());
+        int32_t nsh[4], st32[8], *rid_h = malloc(4 * S4 * 4);
+        uint64_t *rk_h = malloc((size_t)4 * S4 * 8);
+        HIP(hipMemcpy(nsh, ns2, sizeof nsh, hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(st32, status, 32, hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(rid_h, rid, 4 * S4 * 4, hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(rk_h, rkey, (size_t)4 * S4 * (wide ? 8 : 4), hipMemcpyDeviceToHost));
+        HIP(hipMemcpy(xzk_h, xzk, R2 * 2 * (m4 + 1) * 4, hipMemcpyDeviceToHost));
+        CHECK(st32[0] == 0 && st32[1] == 0 && st32[2] == 0 && st32[3] == 0);
+        for (int i = 0; i < 4; ++i) {
+            CHECK(nsh[i] >= 1 && nsh[i] <= N && s2[i + 1] - s2[i] == nsh[i]);
+            long col[m4 + 1];
+            memset(col, 0, sizeof col);
+            int has_root = 0;
+            for (int e = 0; e < nsh[i]; ++e) {
+                const int32_t id = rid_h[i * S4 + e];
+                const uint64_t key = wide ? rk_h[(size_t)i * S4 + e] : (uint64_t)((const uint32_t *)rk_h)[(size_t)i * S4 + e];
+                if (e) CHECK(id > rid_h[i * S4 + e - 1]);                        /* sorted, distinct */
+                const int lead = (int)((key >> (m4 * sh)) & 1u);
+                CHECK(lead == (id == (int32_t)edge_h[i]));                       /* the root's row carries the LEAD bit, nobody else */
+                has_root |= lead;
+                for (int j = 1; j <= m4; ++j) col[j] += (long)((key >> ((m4 - j) * sh)) & ((1u << sh) - 1u));
+            }
+            CHECK(has_root);
+            for (int j = 1; j <= m4; ++j) CHECK(col[j] == Mw);                   /* every landing-count column sums to M */
+            float fc[m4 + 1];                                                    /* ... and so do the own-slot feature rows of xz (/M) */
+            memset(fc, 0, sizeof fc);
+            for (int64_t r = s2[i]; r < s2[i + 1]; ++r)
+                for (int j = 0; j <= m4; ++j) fc[j] += xzk_h[(r * 2 + 0) * (m4 + 1) + j];
+            CHECK(fc[0] > 0.999f && fc[0] < 1.001f);
+            for (int j = 1; j <= m4; ++j) CHECK(fc[j] > 0.999f && fc[j] < 1.001f);
+        }
+        CHECK(nsh[1] == nsh[2]);                                                 /* endpoints 1 and 2 are both node 3: the same set */
+        for (int e = 0; e < nsh[1]; ++e) CHECK(rid_h[1 * S4 + e] == rid_h[2 * S4 + e]);
+        printf("cabi_smoke key rows (%d-bit keys): M=%d m=%d R=%lld ok\n", wide ? 64 : 32, Mw, m4, (long long)R2);
     }
     /* rows 1 and 2 are the same set (Philox is keyed by the root id): joined with each other both slots agree */
     CHECK(ns_h[1] == ns_h[2]);
