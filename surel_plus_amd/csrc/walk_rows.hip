@@ -27,6 +27,16 @@ namespace subgacc {
 // register keeps the load unconditional; it costs nothing but is a point where the value must have arrived.
 #define SG_KEEP_LOAD(v) asm volatile("" : "+v"(v))
 
+// the key rows' final stores: written once, read by the join a kernel later -- SG_NT_ROWS=1 streams them past L2 (A/B: tools/ab.py)
+#ifndef SG_NT_ROWS
+#define SG_NT_ROWS 0
+#endif
+#if SG_NT_ROWS
+#define SG_ROW_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define SG_ROW_STORE(p, v) (*(p) = (v))
+#endif
+
 #ifndef SG_LAST_HOP_ID     // 1: with hop records, the last hop reads the bare id from `indices` (A/B: tools/ab.py)
 #define SG_LAST_HOP_ID 1
 #endif
@@ -665,9 +675,9 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (KR ? 5 : (NT == 128 ? 7 :
         __syncthreads();
         for (int x = tid; x < ns; x += NT) {
             const unsigned long long v = A[x];
-            a.set_ids[obase + x] = (int32_t)(v >> 32);
-            if (KR64) a.set_keys[obase + x] = KK[(uint32_t)v];
-            else a.set_slot[obase + x] = (int32_t)(uint32_t)v;
+            SG_ROW_STORE(&a.set_ids[obase + x], (int32_t)(v >> 32));
+            if (KR64) SG_ROW_STORE(&a.set_keys[obase + x], (uint64_t)KK[(uint32_t)v]);
+            else SG_ROW_STORE(&a.set_slot[obase + x], (int32_t)(uint32_t)v);
         }
         return;
     }
