@@ -298,20 +298,38 @@ class BatchViews:
     copy, and the views are made batch by batch as they are taken: a loop that queues the next group of batches before it
     consumes this one never waits for the GPU in between.  A row number outside the store raises IndexError at that point."""
 
-    def __init__(self, xz, seg, seg_per_batch, ids=None, flags=None, n_rows=None):
+    def __init__(self, xz, seg, seg_per_batch, ids=None, flags=None, n_rows=None, prefetch=False):
         P = int(seg_per_batch)
         S = seg.numel() - 1
         if P <= 0 or S % P:
             raise ValueError(f"{S} segments are not a whole number of batches of {P} segments")
         self.xz, self.seg, self.P, self.nb, self.ids = xz, seg, P, S // P, ids
-        self._flags, self._n_rows, self._bounds, self._ptrs = flags, n_rows, None, None
+        self._flags, self._n_rows, self._bounds, self._ptrs, self._pending = flags, n_rows, None, None, None
+        if prefetch and seg.is_cuda:
+            # the boundaries start their way to pinned host memory NOW, behind this join's kernels: taking the first batch later waits
+            # for exactly this copy, not for whatever the stream holds by then (the next group of batches, queued in between)
+            src = self._words()
+            host = torch.empty(src.numel(), dtype=torch.int64, pin_memory=True)
+            host.copy_(src, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending = (host, ev, src)
+
+    def _words(self):
+        src = self.seg[::self.P]                               # [nb+1]: first row of every batch, and the total
+        if self._flags is not None:
+            src = torch.cat([src, self._flags[3:4].to(torch.int64)])
+        return src
 
     def _resolve(self):
         if self._bounds is None:
-            src = self.seg[::self.P]                           # [nb+1]: first row of every batch, and the total
-            if self._flags is not None:
-                src = torch.cat([src, self._flags[3:4].to(torch.int64)])
-            words = src.tolist()
+            if self._pending is not None:
+                host, ev, _ = self._pending
+                ev.synchronize()
+                words = host.tolist()
+                self._pending = None
+            else:
+                words = self._words().tolist()
             if self._flags is not None:
                 if words.pop() & 16:
                     raise IndexError(f"row index out of range for an SpG with {self._n_rows} rows")
@@ -384,7 +402,7 @@ def gather_many(edges, x, device=None, ptr=True, encode=None, out=None, lazy=Fal
     xz, ind, flags = sjoin(spg, own, None, encode, ptr_mode=ptr, pair_block=B, out=out, lazy=lazy)
     _checked(xz, ind, flags)
     if ptr:
-        return BatchViews(xz, ind, 2 * B, flags=flags if lazy else None, n_rows=spg.n_rows)
+        return BatchViews(xz, ind, 2 * B, flags=flags if lazy else None, n_rows=spg.n_rows, prefetch=lazy)
     # segment ids (train.py:25-30, the LSTM aggregator): the kernel wrote the ids over ALL segments; inside a batch they are 0..2B-1
     ind.remainder_(2 * B)
     return BatchViews(xz, ind.seg_pointers, 2 * B, ids=ind)
