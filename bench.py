@@ -729,7 +729,7 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
                      "join_frac": (join_abytes / (join_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (join_ms and join_abytes) else None,
                      "join_traffic": join_traffic,
                      # the step as a whole at the memory side of L2 (walk + join, PMC): what the two kernels queue on together --
-                     # a plain copy reaches ~6.3 TB/s on this part (profiles/r04d_stream_probe.csv)
+                     # plain streams reach 5.1-5.6 TB/s on this pool's boxes (profiles/r17_stream_probe.csv), the guide's float4 copy 6.29 TB/s
                      "step_traffic": (traffic + join_traffic) if (traffic and join_traffic) else None,
                      "step_traffic_TBps": ((traffic + join_traffic) / (ms_per_step * 1e-3) / 1e12) if (traffic and join_traffic) else None,
                      # the roof this kernel actually sits under: random 128-byte lines per second
