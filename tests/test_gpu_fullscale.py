@@ -181,3 +181,35 @@ def test_twitter_scale_int64_offsets(sp):
     edge = torch.stack([sample[:100], sample[50:150]])
     xz, ind = sp.gather(edge, z, "cuda", ptr=True, encode=table)
     assert xz.shape[0] == int(ind[-1])
+
+
+def test_cit2_scale_four_hop_batch_with_64_bit_key_rows(sp):
+    """The paper's sampler setting (Fig. 6a: citation2, m = 4, M = 200) at the bench's batch size: 65,536 pairs on demand through the
+    step buffers -- rows of 64-bit LP keys (subgacc_walk_keyrows64 / subgacc_sjoin_fill_keyrows64) -- against the table form of the
+    same batch, bit for bit; a random subset of the endpoints against the oracle; the invariants of subg_acc/test/test.py:34-45."""
+    from surel_plus_amd.graphs import preset_graph, query_pairs
+    csr = preset_graph("cit2")
+    M, m, B = 200, 4, 65536
+    edge = query_pairs(csr, B, seed=321)
+    bufs = sp.StepBuffers(csr, B, num_walks=M, num_steps=m)
+    assert bufs.keyrows and bufs.key64
+    xz, ind, sets = sp.sample_and_gather(csr, edge, num_walks=M, num_steps=m, seed=5, rng="philox", buffers=bufs)
+    sets.prefetch().resolve()
+    rows = int(sets.extra[0])
+    txz, tind, tsets = sp.sample_and_gather(csr, edge, num_walks=M, num_steps=m, seed=5, rng="philox", key_rows=False)
+    assert not tsets.keyrows and rows == txz.shape[0] and torch.equal(ind, tind) and torch.equal(xz[:rows], txz)
+    # own-slot feature rows of every segment: the root flag once, every landing-count column sums to 1 (= M / M)
+    seg_sum = torch.segment_reduce(xz[:rows, 0, :].double(), "sum", offsets=ind, axis=0)
+    assert torch.allclose(seg_sum, torch.ones_like(seg_sum), atol=1e-6)
+    # 64 endpoints against the oracle (Philox sets are functions of (seed, root)): set sizes and sorted members
+    g = torch.Generator(device="cuda").manual_seed(2)
+    pick = torch.randint(0, 2 * B, (64,), device="cuda", generator=g)
+    roots = edge.reshape(-1)[pick].cpu().numpy()
+    o_nsize, o_remap, o_enc = oracle.gset_sampler(csr.indptr.cpu().numpy(), csr.indices.cpu().numpy(), roots, num_walks=M, num_steps=m,
+                                                  seed=5, rng="philox", nthreads=8)
+    oi, ox, od = oracle.spg_build(o_nsize, o_remap)
+    stride = M * m + 1
+    for j, i in enumerate(pick.tolist()):
+        n_i = int(bufs.nsize[i])
+        assert n_i == int(o_nsize[j])
+        assert np.array_equal(bufs.ids[i * stride: i * stride + n_i].cpu().numpy(), ox[oi[j]:oi[j + 1]])
