@@ -10,12 +10,14 @@ Nothing is cached between steps; every step gets fresh pairs.
 
 N>1 is launched by the driver through torch.distributed.run (one rank per GPU); the graph is replicated, the
 pair batches are sharded (each rank its own: "weak"; --scaling strong splits one fixed batch), there is no data-path
-collective.  Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events around the walk kernel on its
+collective.  Rank 0 prints ONE JSON line, the last line of stdout, < 6 KB (compact_line(); the full record with every nested
+block goes to bench_detail.json).  `roofline` is measured live with HIP events around the walk kernel on its
 launch stream; `cpu_baseline` times the reference's own OpenMP sampler (oracle/_ref, compiled from the
 reference sources in the build container) plus the oracle's C merge join on a bounded sample of the workload.
-After the timed region (rank 0, 1 GPU): the random-line roof of this box (subgacc_line_probe), BASELINE.json's other
-configurations, the reference's own offline-sample + resident-store-join flow (`offline_flow`), hgather and walk_sampler;
-every number of those blocks is also a scalar key of `config` (the driver keeps scalars only).
+After the timed region (rank 0, 1 GPU): the random-line roof of this box (tools/line_roof_lib.hip), three more regions of 100
+steps, and BASELINE.json's other configurations as passes of 3 x 100 steps (their medians are scalars of `config`).  `--full` adds the
+side studies (the reference's offline-sample + resident-store-join flow, B = 1,024 loops, hgather, the mean stage, walk_sampler,
+two-stream and root-dedup loops): minutes, bench_detail.json only.
 """
 import argparse
 import contextlib
@@ -239,13 +241,15 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(csr, edge_all, M, k, target_s=4.0):
+def cpu_baseline(csr, edge_all, M, k, target_s=2.5, repeats=2, teams=(-1, 64, 32, 16, 8, 1), with_t1=True):
     """BASELINE.md section 3's protocol, on this host: the reference (oracle/_ref: the real subg_acc.gset_sampler, OpenMP) + the
     oracle's C merge join on a bounded number of pairs of the same workload, at 1 thread, 16 threads and the fastest team size
     of a probe (all cores, 64, 32, 16, 8 -- the reference shares one rand_r state between its threads, subg_acc.c:731-732, and
-    slows down with many of them), OMP_PROC_BIND=close (set before libgomp loads, top of this file), best of 3 per setting, each
-    run sized to ~target_s seconds.  Rank 0, N=1 only.  `value` = the fastest setting's best run."""
+    slows down with many of them), OMP_PROC_BIND=close (set before libgomp loads, top of this file), best of `repeats` per setting
+    (the 1-thread setting runs once), each run sized to ~target_s seconds: ~15-20 s of CPU work in all.  Rank 0, N=1 only.
+    `value` = the fastest full-size run; `cores` = the team size of THAT run."""
     import oracle
+    t_begin = time.perf_counter()
     ref = oracle.ref_module()
     ptr_h = csr.indptr.cpu().numpy()
     idx_h = csr.indices.cpu().numpy()
@@ -275,37 +279,38 @@ def cpu_baseline(csr, edge_all, M, k, target_s=4.0):
     Bmax = edge_all.shape[1]
     B0 = min(2048, Bmax)          # (512 pairs were too few: the call's fixed costs decided the probe, not the team size)
     probe = {}
-    for nt in ([-1, 64, 32, 16, 8, 1] if use_ref else [-1, 1]):
+    for nt in (teams if use_ref else [-1, 1]):
         if nt > cores:
             continue
         probe[nt] = run(B0 if nt != 1 else min(512, Bmax), nt)[0] * (1 if nt != 1 else B0 / min(512, Bmax))
-    best_nt = min((nt for nt in probe if nt != 1), key=lambda nt: probe[nt])
+    probe_best = min((nt for nt in probe if nt != 1), key=lambda nt: probe[nt])
+    # the full-size runs: 1 thread, 16 threads and -- when it is another one -- the probe's pick; `value`
+    # is the fastest of THESE runs and `cores` / `best_nthread` name the team that produced it (the probe only chooses what to run)
     settings = {}
-    for label, nt in (("t1", 1), ("t16", 16 if (16 in probe or not use_ref) else None), ("tbest", best_nt)):
-        if nt is None or (nt not in probe and nt > 0 and nt > cores):
+    for label, nt in (("t1", 1), ("t16", 16 if (16 in probe or not use_ref) else None), ("probe_best", probe_best)):
+        if nt is None or nt not in probe or (label == "probe_best" and any(v["nthread_arg"] == nt for v in settings.values())):
             continue
-        t_probe = probe.get(nt, probe[best_nt])
-        Bn = int(min(Bmax, max(B0, B0 * target_s / max(t_probe, 1e-6))))
-        runs = [run(Bn, nt) for _ in range(3)]
+        if label == "t1" and not with_t1:
+            continue
+        Bn = int(min(Bmax, max(B0, B0 * target_s / max(probe[nt], 1e-6))))
+        runs = [run(Bn, nt) for _ in range(1 if nt == 1 else repeats)]
         t, ts = min(runs)
-        settings[label] = {"nthread": cores if nt < 0 else nt, "pairs": Bn, "pairs_per_s": Bn / t, "sampler_roots_per_s": 2 * Bn / ts,
-                           "join_pairs_per_s": Bn / max(t - ts, 1e-9), "seconds_best_of_3": t, "sampler_seconds": ts}
+        settings[label] = {"nthread": cores if nt < 0 else nt, "nthread_arg": nt, "pairs": Bn, "runs": len(runs), "pairs_per_s": Bn / t,
+                           "sampler_roots_per_s": 2 * Bn / ts, "join_pairs_per_s": Bn / max(t - ts, 1e-9), "seconds_best": t, "sampler_seconds": ts}
     b = max(settings.values(), key=lambda v: v["pairs_per_s"])      # `value`: the fastest of the full-size settings
     kind = "reference" if use_ref else "port"
+    sampler_name = (f"the reference's subg_acc.gset_sampler (oracle/_ref), nthread={b['nthread']}" if use_ref else f"oracle C port, {threads} threads")
     out = {"value": b["pairs_per_s"], "unit": "query-pairs/s", "cores": b["nthread"] if use_ref else threads, "kind": kind,
            "cpu_model": cpu_model(), "host_threads": cores, "omp_proc_bind": os.environ.get("OMP_PROC_BIND"),
            # the two halves, for the reference's own flow (offline_flow): sampler roots/s, and pairs/s of SpG build + join
            "sampler_roots_per_s": b["sampler_roots_per_s"], "join_pairs_per_s": b["join_pairs_per_s"],
            "t1_pairs_per_s": settings["t1"]["pairs_per_s"] if "t1" in settings else None,
            "t16_pairs_per_s": settings["t16"]["pairs_per_s"] if "t16" in settings else None,
-           "tbest_pairs_per_s": b["pairs_per_s"], "tbest_nthread": b["nthread"], "settings": settings,
+           "best_nthread": b["nthread"], "probe_best_nthread": cores if probe_best < 0 else probe_best,
+           "cpu_seconds": time.perf_counter() - t_begin, "settings": settings,
            "probe_seconds_2048_pairs": {str(cores if nt < 0 else nt): round(v, 4) for nt, v in probe.items()},
-           "sample": f"{b['pairs']} pairs of the same workload ({2 * b['pairs']} roots), best of 3: sampler = "
-                     + (f"the reference's subg_acc.gset_sampler (oracle/_ref) with nthread={b['nthread']}, the fastest of "
-                        f"1 / 16 / the probe's best of all-cores/64/32/16/8 on this {cores}-thread host ({cpu_model()}), OMP_PROC_BIND=close" if use_ref
-                        else f"oracle C port, {threads} threads")
-                     + f", {b['sampler_seconds']:.2f}s of {b['seconds_best_of_3']:.2f}s; SpG build + SpJoin = oracle C port ({threads} threads); "
-                       f"also timed at 1 and 16 threads (t1_* / t16_*)"}
+           "sample": f"{b['pairs']} pairs ({2 * b['pairs']} roots) of the workload, best of {b['runs']}: {sampler_name} + oracle C SpG build "
+                     f"and merge join; fastest of the 1 / 16 / probe-best team sizes"}
     return out
 
 
@@ -324,21 +329,26 @@ def literal_dropin(csr, M, k, n_cpu=32768, nthread_cpu=-1):
         t0 = time.perf_counter()
         with quiet_stdout():
             nsize, remap, enc = mod.gset_sampler(ptr_h, idx_h, idx, num_walks=M, num_steps=k - 1, **kw)
+        t1 = time.perf_counter()
         z = sps.csr_matrix((remap[1] + 1, (np.repeat(idx, nsize), remap[0])), shape=(N, N))
         assert z.has_sorted_indices
         enc = np.insert(enc, 0, np.zeros((1, k), dtype=enc.dtype), axis=0)
-        return time.perf_counter() - t0
+        t2 = time.perf_counter()
+        return t2 - t0, t1 - t0, int(remap.shape[1])
     idx = np.arange(N, dtype=np.int32)
     body(shim, idx[:4096])
-    t_gpu = min(body(shim, idx) for _ in range(2))
-    out = {"roots": N, "drop_in_seconds": t_gpu, "drop_in_roots_per_s": N / t_gpu,
+    t_gpu, t_shim, members = min(body(shim, idx) for _ in range(3))
+    out = {"roots": N, "members": members, "drop_in_seconds": t_gpu, "drop_in_roots_per_s": N / t_gpu,
+           # the two halves of the seam: inside gset_sampler (ours: upload, kernels, hand-over of 8 bytes per member) and the
+           # caller's own lines (scipy's COO -> CSR sort of X members, np.insert) that no drop-in can touch
+           "shim_seconds": t_shim, "shim_roots_per_s": N / t_shim, "caller_seconds": t_gpu - t_shim,
            "what": "random_walks.py:77-81 verbatim over `import subg_acc` of this repo: numpy in / numpy out, scipy csr_matrix, np.insert"}
     ref = oracle.ref_module()
     if ref is not None and ptr_h.dtype == np.int32:
         n = min(n_cpu, N)
-        t_cpu = min(body(ref, idx[:n], nthread=nthread_cpu) for _ in range(2))
+        t_cpu, t_cpu_call, _ = min(body(ref, idx[:n], nthread=nthread_cpu) for _ in range(2))
         out.update({"reference_roots": n, "reference_seconds": t_cpu, "reference_roots_per_s": n / t_cpu,
-                    "reference_nthread": nthread_cpu})
+                    "reference_call_roots_per_s": n / t_cpu_call, "reference_nthread": nthread_cpu})
     return out
 
 
@@ -476,7 +486,8 @@ def median(v):
 
 
 def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, with_cpu_baseline, csr_variant=True,
-             small_batches=False, two_stream_extra=True, offline=False, extra_regions=(0, 0), value_is_median=False, captured=False):
+             small_batches=False, two_stream_extra=True, offline=False, extra_regions=(0, 0), value_is_median=False, captured=False,
+             cpu_kw={}):
     """sample + SpJoin over one LP workload: W warm-up steps, K timed steps bracketed by barrier + synchronize, max over
     ranks.  Returns the JSON object (rank 0) or None.
     extra_regions = (R, Kx): after the timed region, R more regions of Kx steps each in the same loop (rank 0, 1 GPU): their
@@ -749,7 +760,7 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
         out["config"]["dedup_roots_pairs_per_s"] = dedup_loop["pairs_per_s"]
     if with_cpu_baseline and not name.startswith("twitter"):   # 12 GB CSR: no host copy
         try:
-            out["cpu_baseline"] = cpu_baseline(csr, edges[W], M, k)
+            out["cpu_baseline"] = cpu_baseline(csr, edges[W], M, k, **cpu_kw)
         except Exception as ex:  # the baseline is a report, never a reason to lose the measurement
             out["cpu_baseline"] = {"value": None, "unit": "query-pairs/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": f"failed: {type(ex).__name__}: {ex}"}
@@ -1228,6 +1239,9 @@ def flatten(out):
             put(f"{short}_cpu_t16_pairs_per_s", o["cpu_baseline"].get("t16_pairs_per_s"))
         ld = o.get("literal_dropin") or {}
         put(f"{short}_literal_dropin_roots_per_s", ld.get("drop_in_roots_per_s"))
+        put(f"{short}_dropin_shim_roots_per_s", ld.get("shim_roots_per_s"))
+        put(f"{short}_dropin_shim_ms", None if ld.get("shim_seconds") is None else 1e3 * ld["shim_seconds"])
+        put(f"{short}_dropin_caller_ms", None if ld.get("caller_seconds") is None else 1e3 * ld["caller_seconds"])
         put(f"{short}_literal_ref_roots_per_s", ld.get("reference_roots_per_s"))
     ws = (c.get("other_workloads") or {}).get("walk_sampler (collab)") or {}
     put("walk_sampler_collab_roots_per_s", ws.get("value"))
@@ -1241,8 +1255,8 @@ def flatten(out):
     put("cpu_model", cb.get("cpu_model"))
     put("cpu_t1_pairs_per_s", cb.get("t1_pairs_per_s"))
     put("cpu_t16_pairs_per_s", cb.get("t16_pairs_per_s"))
-    put("cpu_tbest_pairs_per_s", cb.get("tbest_pairs_per_s"))
-    put("cpu_tbest_nthread", cb.get("tbest_nthread"))
+    put("cpu_best_nthread", cb.get("best_nthread"))
+    put("cpu_probe_best_nthread", cb.get("probe_best_nthread"))
     ms_ = c.get("mean_stage") or {}
     for H in (96, 256):
         put(f"mean_stage_H{H}_pairs_per_s", ms_.get(f"H{H}_fused_pairs_per_s"))
@@ -1295,6 +1309,87 @@ def flatten(out):
     put("join_kernel_ms", sm.get("sjoin_fill"))
 
 
+# ---- the driver's line ------------------------------------------------------------------------------------------------------
+# The driver parses the LAST stdout line; round 4's 31 KB line (every block nested + ~170 promoted scalars) did not make it into
+# BENCH_r04.json.  So: ONE compact line (< 6 KB, guarded by tests/test_bench_line_cpu.py) with the contract's keys, <= 40 scalars
+# of `config`, the `roofline` and `cpu_baseline` blocks without prose -- and the full record (every nested block and every
+# promoted scalar, as before) in bench_detail.json next to this script (and under gpurun_out/ when that directory exists).
+LINE_LIMIT = 6000
+TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data")
+CONFIG_KEYS = ("workload", "pairs_per_step_per_gpu", "roots_per_step_per_gpu", "pairs_per_step_all_gpus", "ranks_seen",
+               "distinct_devices", "dist_backend", "rccl_version", "rng", "num_walks", "num_steps_cli", "parallelism",
+               "per_rank_ms_min", "per_rank_ms_max", "headline_median_of_3_x100", "join_frac",
+               # BASELINE.json's other configurations (medians of 3 x 100 steps) and the bit-exact rand_r stream on the headline one
+               "rand_r_pairs_per_s", "rand_r_frac", "cit2m4_pairs_per_s", "cit2m4_frac", "cit2m4_join_frac",
+               "collab_pairs_per_s", "collab_frac", "collab_join_frac", "ppa_pairs_per_s", "ppa_frac", "ppa_join_frac",
+               "twitter_pairs_per_s", "twitter_frac", "twitter_join_frac", "cit2ppr_pairs_per_s", "cit2ppr_frac",
+               "cit2ppr_frac_whole_join_call", "collab_cpu_pairs_per_s",
+               # seam A alone: random_walks.py:77-81 verbatim over the drop-in module, all N collab roots (shim = inside gset_sampler)
+               "collab_literal_dropin_roots_per_s", "collab_dropin_shim_roots_per_s", "collab_literal_ref_roots_per_s",
+               "detail")
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "launches_timed",
+                 "algorithmic_bytes_per_launch", "join_kernel_ms", "join_algorithmic_bytes_per_launch", "join_frac", "join_traffic",
+                 "line_roof_lines_per_s", "line_roof_frac", "l2_miss_lines_per_launch")
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "cpu_model", "host_threads", "t1_pairs_per_s", "t16_pairs_per_s",
+            "best_nthread", "sampler_roots_per_s", "join_pairs_per_s", "cpu_seconds")
+
+
+def _short(v, digits=6):
+    """floats to 6 significant digits (the line is a record, not a checkpoint), long strings cut"""
+    if isinstance(v, float):
+        return float(f"{v:.{digits}g}")
+    if isinstance(v, str) and len(v) > 200:
+        return v[:197] + "..."
+    return v
+
+
+def compact_line(out):
+    """the one line the driver parses: contract keys + a bounded pick of `config` scalars + roofline + cpu_baseline"""
+    line = {k_: _short(out.get(k_)) for k_ in TOP_KEYS}
+    c = out.get("config") or {}
+    line["config"] = {k_: _short(c[k_]) for k_ in CONFIG_KEYS if c.get(k_) is not None and not isinstance(c[k_], (dict, list))}
+    assert len(line["config"]) <= 40, len(line["config"])
+    r = out.get("roofline") or {}
+    line["roofline"] = {k_: _short(r.get(k_)) for k_ in ROOFLINE_KEYS if k_ in r}
+    if out.get("cpu_baseline") is not None:
+        line["cpu_baseline"] = {k_: _short(out["cpu_baseline"].get(k_)) for k_ in CPU_KEYS if k_ in out["cpu_baseline"]}
+    text = json.dumps(line)
+    if len(text) > LINE_LIMIT:         # cannot happen with the key lists above; if it ever does, keep the contract and say so
+        line["config"] = {k_: line["config"][k_] for k_ in CONFIG_KEYS[:12] if k_ in line["config"]}
+        line["config"]["truncated"] = True
+        text = json.dumps(line)
+    assert len(text) <= LINE_LIMIT, len(text)
+    return text
+
+
+def emit(out):
+    """full record -> bench_detail.json (+ gpurun_out/), compact record -> the last line of stdout"""
+    flatten(out)
+    paths = [os.path.join(ROOT, "bench_detail.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        paths.append(os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    written = None
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                json.dump(out, f)
+            written = written or os.path.relpath(p, ROOT)
+        except OSError:
+            pass
+    out["config"]["detail"] = written
+    print(compact_line(out), flush=True)
+
+
+def note(msg):
+    """progress to stderr: short, so that the driver's tail still ends in the JSON line"""
+    if os.environ.get("SUBGACC_BENCH_QUIET", "0") != "1":
+        print(f"[bench {time.perf_counter() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def summary(o):
     """what an `other_workloads` entry keeps of a full line"""
     keep = {k_: o[k_] for k_ in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype")}
@@ -1319,6 +1414,9 @@ def main():
     ap.add_argument("--rng", default="philox", choices=["philox", "rand_r"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="skip the short passes over BASELINE.json's other configs")
+    ap.add_argument("--full", action="store_true",
+                    help="also run the side studies (two-stream and root-dedup loops, packed-CSR variant, B=1,024 sweeps, the reference's "
+                         "offline flow, hgather, mean stage, walk_sampler): minutes, all of it into bench_detail.json")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only; invalidates the number)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --pairs per step PER GPU (the driver's scaling runs); strong: --pairs per step in all, split over "
@@ -1376,12 +1474,14 @@ def main():
     else:
         out = bench_lp(args, args.workload, args.rng, B, K, W, sp, sampler_mod, dev, rank, world, dist,
                        with_cpu_baseline=(world == 1 and not args.no_cpu_baseline),
-                       small_batches=(world == 1 and not args.no_others),
-                       two_stream_extra=not args.no_others,      # --no-others: the profiled command, single-stream steps only
-                       csr_variant=not args.no_others,           # ... and no pass with the packed-CSR (table rows) variant
-                       offline=(rank == 0 and world == 1 and not args.no_others and args.scale == 1.0),
+                       small_batches=(world == 1 and args.full),
+                       two_stream_extra=args.full,               # (the default run and --no-others: single-stream steps only)
+                       csr_variant=args.full,                    # ... and no pass with the packed-CSR (table rows) variant
+                       offline=(rank == 0 and world == 1 and args.full and args.scale == 1.0),
                        # the driver's K steps are the headline region; three regions of 100 steps follow, outside its clock
                        extra_regions=((3, 100) if (world == 1 and not args.no_others) else (0, 0)))
+    if rank == 0 and out is not None:
+        note(f"{args.workload}: {out['value'] / 1e6:.2f} M pairs/s in the driver's region of {K} steps")
     # BASELINE.json's other single-GPU configurations (and the reference-bit-exact rand_r stream on the headline one),
     # as short passes after the timed region: same code path, >= 5 timed steps each, their own roofline blocks
     # (configs[0], the reference's CPU-runnable collab case, rides on the collab entry as its cpu_baseline).
@@ -1404,10 +1504,13 @@ def main():
                 else:
                     o = bench_lp(args, wl, rng_o, B, Ko, Wo, sp, sampler_mod, dev, 0, 1, None,
                                  with_cpu_baseline=(wl == "collab" and not args.no_cpu_baseline), csr_variant=False,
-                                 extra_regions=(2, Ko), value_is_median=True,
+                                 two_stream_extra=args.full, extra_regions=(2, Ko), value_is_median=True,
+                                 # configs[0] (the reference's CPU-runnable case): 16 threads and the probe's pick only, ~1.5 s each
+                                 cpu_kw=({} if args.full else {"target_s": 1.5, "teams": (-1, 16, 8), "with_t1": False}),
                                  # a 2-hop step is ~0.4 ms of kernels: replayed as one HIP graph, or the host is what gets measured
                                  captured=(WORKLOADS[wl][2] <= 3))
                 others[key] = summary(o)
+                note(f"{wl} ({rng_o}): {o['value'] / 1e6:.1f} M pairs/s")
                 if wl == "collab" and not args.no_cpu_baseline:
                     from surel_plus_amd.graphs import preset_graph
                     try:
@@ -1416,15 +1519,15 @@ def main():
                         others[key]["literal_dropin"] = {"failed": f"{type(ex).__name__}: {ex}"}
             except Exception as ex:   # an extra must never cost the headline line
                 others[key] = {"failed": f"{type(ex).__name__}: {ex}"}
-        try:
-            torch.cuda.empty_cache()
-            others["walk_sampler (collab)"] = bench_walk_sampler(sp, sampler_mod, dev, 5)
-        except Exception as ex:
-            others["walk_sampler (collab)"] = {"failed": f"{type(ex).__name__}: {ex}"}
+        if args.full:
+            try:
+                torch.cuda.empty_cache()
+                others["walk_sampler (collab)"] = bench_walk_sampler(sp, sampler_mod, dev, 5)
+            except Exception as ex:
+                others["walk_sampler (collab)"] = {"failed": f"{type(ex).__name__}: {ex}"}
         out["config"]["other_workloads"] = others
     if rank == 0:
-        flatten(out)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -366,9 +366,13 @@ class SampledSets:
                                         "(number() / c / enc_int16() / to_csr() must be asked for before the buffers are re-used)")
             cfg = ctx["cfg"]
             rng = "rand_r" if cfg.rng_mode == _lib.RNG_RAND_R else "philox"
+            # the same walks: the configuration of the first sampling (first-hop rule, root-degree cap, seed) and, under rand_r,
+            # the stream positions it entered at (they carry rng_streams / calls_before) -- not this function's defaults
+            state = (ctx["rng_pos"], ctx["rng_seed"]) if (rng == "rand_r" and ctx.get("rng_pos") is not None) else None
             self._table_form = sample_sets(ctx["csr"], ctx["roots"], num_walks=self.num_walks, num_steps=self.num_steps, seed=cfg.seed,
-                                           rng=rng, fused_rows=True, strided=True, number_rows=True, key_rows=False,
-                                           uniq_capacity=int(ctx["capacity"]), sort_roots=False)
+                                           rng=rng, first_hop_wo=bool(cfg.first_hop_wo), cap_root_degree=bool(cfg.cap_root_degree),
+                                           fused_rows=True, strided=True, number_rows=True, key_rows=False,
+                                           uniq_capacity=int(ctx["capacity"]), sort_roots=False, rng_state=state)
         return self._table_form
 
     def _number_keyrows(self):
@@ -585,8 +589,11 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
                 order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False, rng_streams=1,
                 calls_before=0, dedup=True, keep_keys=None, staging_bytes=None, uniq_capacity=UNIQ_CAPACITY,
                 uniq_small_limit=0, fused_rows=False, lazy=False, strided=False, number_rows=True, key_rows=True,
-                walk_replay=False, batched_registration=True, sort_roots=True):
+                walk_replay=False, batched_registration=True, sort_roots=True, rng_state=None):
     """Run the sampler for `query` (roots) on the GPU.  See SampledSets.
+
+    rng_state=(rng_pos, rng_seed): the rand_r stream positions of the roots, already computed (a batch that is sampled a second
+    time -- SampledSets.table_form() -- enters the stream where its first sampling did, whatever rng_streams / calls_before were).
 
     rng="rand_r" on a graph with dead ends (directed graphs: a reached node without out-edges draws nothing in the reference,
     subg_acc.c:804-808): the first attempt notices (RandRDeadEnd) and the batch is sampled again with walk_replay=True -- the
@@ -652,6 +659,8 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
         walk_pos = torch.empty(n * M, dtype=torch.int32, device=dev)
         check(L.subgacc_rng_replay(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q), n, int(rng_streams), int(calls_before),
                                    ptr(rng_pos), ptr(rng_seed), ptr(walk_pos), st))
+    elif rng_state is not None and rng == "rand_r":
+        rng_pos, rng_seed = rng_state
     else:
         rng_pos, rng_seed = _rng_positions(L, cfg, csr, q, n, rng_streams, calls_before, st)
     # key rows: strided fused rows that nobody asked to number carry LP keys instead of table slots (module header)
@@ -767,7 +776,7 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
                                        cap_root_degree, emit_walks, rng_streams, calls_before, dedup, keep_keys,
                                        staging_bytes, uniq_capacity * 4, uniq_small_limit, fused_rows, lazy, strided,
                                        number_rows, key_rows=key_rows_arg, walk_replay=walk_replay,
-                                       batched_registration=batched_registration, sort_roots=sort_roots)
+                                       batched_registration=batched_registration, sort_roots=sort_roots, rng_state=rng_state)
                 if st_host[4] > max_unique:       # more distinct rows than the direct ranking numbers: the caller
                     return None                   # (sample_spg) falls through to the packed forms
                 sets.resolve()
@@ -858,7 +867,7 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
         return sample_sets(csr, q, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order, cap_root_degree,
                            emit_walks, rng_streams, calls_before, dedup, keep_keys, staging_bytes, uniq_capacity * 4,
                            uniq_small_limit, fused_rows, lazy, strided, number_rows, key_rows=key_rows_arg, walk_replay=walk_replay,
-                           batched_registration=batched_registration, sort_roots=sort_roots)
+                           batched_registration=batched_registration, sort_roots=sort_roots, rng_state=rng_state)
     sets.resolve()
     sets.ukeys = sets.ukeys.clone()
     return sets

@@ -51,17 +51,38 @@ def gset_sampler(indptr, indices, query, num_walks=100, num_steps=3, bucket=-1, 
     if not torch.is_tensor(query):
         query = _checked_query(query, csr.num_nodes)
     sets = sample_sets(csr, query, num_walks=num_walks, num_steps=num_steps, bucket=bucket, seed=seed, rng=rng)
-    nsize = sets.nsize.cpu().numpy()
+    # the hand-over (subg_acc.c:1017-1024): ids and SFptr go straight into the two rows of ONE pinned [2, X] host array, each by
+    # its own asynchronous copy; nsize and enc ride behind them on the same stream -- one wait for all four
     sf = sets.get_sf()
-    remap = torch.stack([sets.ids, sf]).cpu().numpy()
     enc_dev = sets.enc_int16()
-    enc = enc_dev.cpu().numpy()
+    raw_dev = enc_dev[sf.long()] if debug > 0 else None
+    remap, (nsize, enc, raw) = _rows_to_host([sets.ids, sf], [sets.nsize, enc_dev, raw_dev])
     if _lib.VERBOSE:
         print(f"#SubGAcc: #total {sets.X}; #enc_unique {sets.c}; compression ratio {sets.X / max(sets.c, 1):.2f}")
     if debug > 0:
-        raw = enc_dev[sf.long()].cpu().numpy()
         return [nsize, remap, enc, raw]
     return [nsize, remap, enc]
+
+
+def _rows_to_host(rows, others=()):
+    """device rows (1-D, same dtype and length) -> one NumPy [len(rows), X] array over pinned memory, each row copied by its own
+    async D2H (no stacked device copy, no pageable staging); `others`: more device tensors (or None) brought along the same way.
+    The arrays keep their pinned blocks alive; torch's host allocator takes the blocks back when they are dropped."""
+    host = None
+    if rows:
+        host = torch.empty((len(rows), rows[0].numel()), dtype=rows[0].dtype, pin_memory=True)
+        for i, r in enumerate(rows):
+            host[i].copy_(r, non_blocking=True)
+    extra = []
+    for t in others:
+        if t is None:
+            extra.append(None)
+            continue
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        h.copy_(t, non_blocking=True)
+        extra.append(h)
+    torch.cuda.current_stream().synchronize()
+    return (None if host is None else host.numpy()), [None if h is None else h.numpy() for h in extra]
 
 
 def walk_sampler(ptr, neighs, query, num_walks=100, num_steps=3, nthread=-1, seed=111413, replacement=False,
@@ -75,15 +96,14 @@ def walk_sampler(ptr, neighs, query, num_walks=100, num_steps=3, nthread=-1, see
     sets = sample_sets(csr, query, num_walks=num_walks, num_steps=num_steps, seed=seed, rng=rng,
                        first_hop_wo=bool(replacement), order=_lib.ORDER_STEP_MAJOR, cap_root_degree=False,
                        emit_walks=True, rng_streams=max(int(nthread), 1), dedup=False)
-    walks = sets.walks.cpu().numpy()
-    off = sets.row_off.cpu().numpy()
-    ids = sets.ids.cpu().numpy()
-    counts = sets.counts_int32().cpu().numpy()
+    _, (walks, off, ids, counts) = _rows_to_host([], [sets.walks, sets.row_off, sets.ids, sets.counts_int32()])
     n = len(off) - 1
+    # rpe_encoder's per-root (ids, counts) pairs (subg_acc.c:371-380) as views of the two packed arrays, cut in one C loop
     obj = np.empty((n, 2), dtype=object)
-    for i in range(n):
-        obj[i, 0] = ids[off[i]:off[i + 1]]
-        obj[i, 1] = counts[off[i]:off[i + 1]]
+    if n:
+        lo, hi = off[:-1].astype(object), off[1:].astype(object)
+        obj[:, 0] = np.frompyfunc(lambda a, b: ids[a:b], 2, 1)(lo, hi)
+        obj[:, 1] = np.frompyfunc(lambda a, b: counts[a:b], 2, 1)(lo, hi)
     return [walks, obj]
 
 
