@@ -23,6 +23,10 @@
 #define SG_HOOK_FLUSH_SLOT(s2, real) (real)
 #define SJ_HOOK_SEARCH_RANGE(lo, hi)
 #define SJ_HOOK_ROW_LOAD(ids, val, row, r, mul)
+#define SJ_HOOK_PAIR_ENTRY()
+#define SJ_HOOK_FIRST_TRIP(id, k, t)
+#define SJ_HOOK_PAIR_ROWS_READY()
+#define SJ_HOOK_SPAN_STORES(nbody) (nbody)
 #endif
 
 namespace subgacc {

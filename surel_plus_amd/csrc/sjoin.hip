@@ -258,11 +258,19 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
                 }
             } else if (KEYS) {
                 // any other width: every lane unpacks its own row (no shuffles, no per-element index arithmetic) into the
-                // wave's LDS staging area, and the span leaves as consecutive 8-byte words (k2 = 2k floats per row)
-                // (KV = 3: the 2-hop configurations, k known at compile time -- the loops unroll and the shifts are immediates)
+                // wave's LDS staging area, and the span leaves as whole, ALIGNED 16-byte words.  A row is 8*kc bytes, so a span
+                // begins on a 16-byte boundary of the output or 8 bytes past one (kc * row0 odd; any 4-byte offset if the caller's
+                // buffer is a view that starts there); the rows are staged at the same offset modulo 16, so that word f of the
+                // aligned body is one ds_read_b128 + one global_store_dwordx4 for lane f, with a head and / or tail of up to three
+                // floats from one lane each (k = 3: 96 words per full span instead of 192 8-byte ones; k = 5: 160 instead of 320)
+                // (KV = 3 / 5: the 2- and 4-hop configurations, k known at compile time -- the loops unroll, the shifts are immediates)
                 const int kc = KV > 0 ? KV : k;
+                const int w = 2 * kc;                                   // floats per output row
+                float *dst = a.out_xz + row0 * w;
+                const int mis = (int)(((uintptr_t)dst >> 2) & 3);       // floats between the 16-byte boundary in front and the span
+                const int head = (4 - mis) & 3;                         // floats of the span in front of its first aligned word
                 if (live) {
-                    float *mine = stage + lane * 2 * kc;
+                    float *mine = stage + mis + lane * w;
 #pragma unroll
                     for (int c = 0; c < (KV > 0 ? KV : 16); ++c) {
                         if (c >= kc) break;
@@ -278,16 +286,26 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                float2 *dst2 = reinterpret_cast<float2 *>(a.out_xz + row0 * 2 * kc);
-                const float2 *src2 = reinterpret_cast<const float2 *>(stage);
+                const int total = nrows * w;                            // floats of the span
+                const int nbody = SJ_HOOK_SPAN_STORES(total > head ? (total - head) >> 2 : 0);       // aligned 16-byte words
+                const int ntail = total > head ? (total - head) & 3 : 0;
+                const float *src = stage + mis;                         // float i of the span
+                const float4 *src4 = reinterpret_cast<const float4 *>(src + head);   // stage, or stage + 4: 16-byte aligned
+                float4 *dst4 = reinterpret_cast<float4 *>(dst + head);
+                {
+                    const int i = kWave - 1 - lane;                     // the last lanes have the fewest body words
+                    if (i < head && i < total) __builtin_nontemporal_store(src[i], dst + i);
+                    const int t2 = kWave - 4 - lane, at = head + 4 * nbody;
+                    if (t2 >= 0 && t2 < ntail) __builtin_nontemporal_store(src[at + t2], dst + at + t2);
+                }
                 if (KV > 0) {
 #pragma unroll
-                    for (int q = 0; q < KV; ++q) {
+                    for (int q = 0; q < (KV + 1) / 2; ++q) {            // 64 rows x 2*KV floats = 32*KV words
                         const int f = lane + q * kWave;
-                        if (f < nrows * KV) stream_store(dst2 + f, src2[f]);
+                        if (f < nbody) stream_store(dst4 + f, src4[f]);
                     }
                 } else
-                    for (int f = lane; f < nrows * k; f += kWave) stream_store(dst2 + f, src2[f]);
+                    for (int f = lane; f < nbody; f += kWave) stream_store(dst4 + f, src4[f]);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the next span of this wave re-uses the area
                 __builtin_amdgcn_wave_barrier();
             } else {
@@ -368,10 +386,13 @@ __global__ __launch_bounds__(NT) void sjoin_pair_kernel(const JoinArgs a, int64_
     // a key can hold, not just per count <= num_walks: a caller-supplied key with a field in (M, 2^SHIFT) -- not a key of this
     // num_walks -- then reads its own quotient instead of whatever lies behind the table
     float *lut = (float *)(idsB + a.max_len);
-    float *stage = lut + (1 << a.key_shift) + (threadIdx.x / kWave) * kWave * 2 * a.k;   // KEYS: [64 rows][2k] per wave (8-byte aligned)
+    // KEYS: [4 + 64 rows x 2k] floats per wave, every area on a 16-byte boundary (emit_rows stages a span at its output's offset mod 16)
+    const size_t stage_off = ((size_t)a.max_len * (2 * sizeof(Val) + 8) + ((size_t)4 << a.key_shift) + 15) & ~(size_t)15;
+    float *stage = (float *)(lds_raw + stage_off) + (threadIdx.x / kWave) * (kWave * 2 * a.k + 4);
     if (KEYS)
         for (int c = threadIdx.x; c < (1 << a.key_shift); c += NT) lut[c] = (float)c / (float)a.key_M;
 
+    SJ_HOOK_PAIR_ENTRY();
     const int64_t wg = xcd_item(blockIdx.x, gridDim.x);
     const int64_t p = wg / a.split;
     const int part = (int)(wg % a.split);
@@ -417,6 +438,7 @@ __global__ __launch_bounds__(NT) void sjoin_pair_kernel(const JoinArgs a, int64_
         valB = valA;
     }
     __syncthreads();
+    SJ_HOOK_PAIR_ROWS_READY();
     const int64_t oA = a.seg[j], oB = a.seg[j2];
     const int k = a.k, k2 = 2 * k;
     const uint32_t magic = k2 > 0 ? ((1u << 20) + (uint32_t)k2 - 1u) / (uint32_t)k2 : 0u;
@@ -427,6 +449,325 @@ __global__ __launch_bounds__(NT) void sjoin_pair_kernel(const JoinArgs a, int64_
         else
             emit_rows<F64, KV, Val, KEYS, K64>(a, lane, idsB, valB, nb, idsA, valA, na, (int64_t)(c - chunksA) * kWave, oB, j2, k, k2,
                                                magic, lut, stage);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Key rows (the payload of a member is its LP key, 32 or 64 bits): the join of the on-demand step and of a keyed store.
+// Same work split as sjoin_pair_kernel -- one workgroup per mirrored pair, both rows staged in LDS, every wave emits whole
+// 64-row spans -- rebuilt around what the timing builds of round 5 showed (tools/join_bench.py, profiles/r18_join_*.log): on
+// the 2-hop batches the kernel was neither store- nor read-bound; it spent its time (1) in the dependent chain own[] -> row
+// length -> rows before the first useful instruction of every workgroup, behind ~1,000 scalar instructions of 64-bit
+// divisions, and (2) in an emit loop made of LDS round trips with bank conflicts: a divergent binary search per output row in
+// BOTH directions and a table look-up per unpacked field.  Here:
+//   * 32-bit index arithmetic, no division on the common paths (one mirrored block, one workgroup per pair);
+//   * strided rows: the first NT members of both rows are requested BEFORE the rows' lengths are known (the row slots exist
+//     whatever the length): one level less in the dependent chain;
+//   * a match is symmetric, so only the SHORTER row S is searched in the longer one T: a hit hands the searcher's key to the
+//     member it found (pk[j], one LDS write), and T's spans are emitted afterwards without any search.  Only T is staged in LDS
+//     (12 bytes per member instead of 16 for two rows: more pairs resident per CU); S's members are each looked at by the one
+//     lane that loaded them and never leave its registers;
+//   * the search is a halving lower bound with a wave-uniform trip count (3 vector instructions + 1 LDS read per level, no
+//     exec-mask loop);
+//   * count / num_walks is computed, not looked up: q0 = c * (1/M), r = fma(-M, q0, c), q = fma(r, 1/M, q0) IS the correctly
+//     rounded quotient for every count a key of num_walks < 4,096 can hold (all 11,184,810 cases checked on the host in
+//     tests/test_host_logic_cpu.py, every count of a sweep of num_walks on the device in tests/test_gpu_round5.py); larger
+//     num_walks divide (main.py:174's IEEE division either way);
+//   * partner absent == key 0, whose unpacked row IS the zero row (flag 0, every count 0): no special case;
+//   * every width goes through the per-wave staging area and leaves as aligned 16-byte words.
+struct KeyQuot {
+    float fm, rcp;
+    bool divide;
+};
+__device__ __forceinline__ float lp_quotient(uint32_t c, const KeyQuot &q) {
+    const float a = (float)c;
+    if (q.divide) return a / q.fm;
+    const float q0 = a * q.rcp;
+    return __fmaf_rn(__fmaf_rn(-q.fm, q0, a), q.rcp, q0);
+}
+template <bool K64>
+__device__ __forceinline__ float key_field(typename std::conditional<K64, unsigned long long, uint32_t>::type key, int c, int m, int shift,
+                                           const KeyQuot &q) {
+    if (c == 0) return (float)(uint32_t)((key >> (m * shift)) & 1u);
+    return lp_quotient((uint32_t)(key >> ((m - c) * shift)) & ((1u << shift) - 1u), q);
+}
+
+// one 64-row span of the output: the lane's row (own key ka, partner key kb; 0 = absent) unpacked into the wave's staging area at
+// the span's offset modulo 16 bytes, then out as aligned 16-byte words (a head / tail of up to three floats from one lane each)
+template <int KV, bool K64, typename Key>
+__device__ __forceinline__ void emit_key_span(const JoinArgs &a, int lane, bool live, Key ka, Key kb, int nrows, int64_t row0, int64_t segj,
+                                              int kc, const KeyQuot &q, float *stage) {
+    const int w = 2 * kc, m = kc - 1, shift = a.key_shift;
+    float *dst = a.out_xz + row0 * w;
+    const int mis = (int)(((uintptr_t)dst >> 2) & 3);       // floats between the 16-byte boundary in front and the span
+    const int head = (4 - mis) & 3;                         // floats of the span in front of its first aligned word
+    if (live) {
+        float *mine = stage + mis + lane * w;
+        if (KV > 0) {
+            float f[2 * (KV > 0 ? KV : 1)];
+#pragma unroll
+            for (int c = 0; c < KV; ++c) {
+                f[c] = key_field<K64>(ka, c, m, shift, q);
+                f[KV + c] = key_field<K64>(kb, c, m, shift, q);
+            }
+#pragma unroll
+            for (int c = 0; c < 2 * KV; ++c) mine[c] = f[c];
+        } else
+            for (int c = 0; c < kc; ++c) {
+                mine[c] = key_field<K64>(ka, c, m, shift, q);
+                mine[kc + c] = key_field<K64>(kb, c, m, shift, q);
+            }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int total = nrows * w;                            // floats of the span
+    const int nbody = SJ_HOOK_SPAN_STORES(total > head ? (total - head) >> 2 : 0);       // aligned 16-byte words
+    const int ntail = total > head ? (total - head) & 3 : 0;
+    const float *src = stage + mis;                         // float i of the span
+    const float4 *src4 = reinterpret_cast<const float4 *>(src + head);   // stage, or stage + 4: 16-byte aligned
+    float4 *dst4 = reinterpret_cast<float4 *>(dst + head);
+    if (mis | ntail) {                                      // (never for rows of 16 or 32 bytes in an aligned buffer)
+        const int i = kWave - 1 - lane;                     // the last lanes have the fewest body words
+        if (i < head && i < total) __builtin_nontemporal_store(src[i], dst + i);
+        const int t2 = kWave - 4 - lane, at = head + 4 * nbody;
+        if (t2 >= 0 && t2 < ntail) __builtin_nontemporal_store(src[at + t2], dst + at + t2);
+    }
+    if (KV > 0) {
+#pragma unroll
+        for (int qd = 0; qd < (KV + 1) / 2; ++qd) {         // 64 rows x 2*KV floats = 32*KV words
+            const int f = lane + qd * kWave;
+            if (f < nbody) stream_store(dst4 + f, src4[f]);
+        }
+    } else
+        for (int f = lane; f < nbody; f += kWave) stream_store(dst4 + f, src4[f]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the next span of this wave re-uses the area
+    __builtin_amdgcn_wave_barrier();
+    if (a.out_segid && live) __builtin_nontemporal_store(segj, a.out_segid + row0 + lane);
+}
+
+template <int KV, int NT, bool K64>
+__global__ __launch_bounds__(NT) void sjoin_keypair_kernel(const JoinArgs a, uint32_t pb, uint32_t pairs) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    using Key = typename std::conditional<K64, unsigned long long, uint32_t>::type;
+    constexpr int NW = NT / kWave;
+    const int ML = a.max_len;
+    // only T, the LONGER row of the pair, is staged: S's members are looked at by exactly one lane each and stay in registers
+    Key *valT = (Key *)lds_raw;                       // [max_len] keys of T
+    Key *pk = valT + ML;                              // [max_len] partner keys of T's members (0 = absent)
+    int32_t *idsT = (int32_t *)(pk + ML);             // [max_len]
+    const int kc = KV > 0 ? KV : a.k, w = 2 * kc;     // floats per output row
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);      // (scalar: everything a span derives from it stays in SGPRs)
+    // [4 + 64 rows x 2k] floats per wave, every area on a 16-byte boundary (a span is staged at its output's offset mod 16)
+    const size_t stage_off = ((size_t)ML * (2 * sizeof(Key) + 4) + 15) & ~(size_t)15;
+    float *stage = (float *)(lds_raw + stage_off) + wave * (kWave * w + 4);
+
+    SJ_HOOK_PAIR_ENTRY();
+    const uint32_t wg = (uint32_t)(blockIdx.x & (kXcds - 1)) * (gridDim.x / kXcds) + (blockIdx.x / kXcds);    // xcd_item, 32 bits
+    uint32_t p = wg, part = 0;
+    if (a.split > 1) {
+        p = wg / (uint32_t)a.split;
+        part = wg - p * (uint32_t)a.split;
+    }
+    if (p >= pairs) return;
+    uint32_t blk = 0, off = p;
+    if (pb != pairs) {                 // several mirrored blocks (nb batches in one launch)
+        blk = p / pb;
+        off = p - blk * pb;
+    }
+    const int64_t j = (int64_t)blk * 2 * pb + off, j2 = j + pb;
+    const int64_t ra = a.own[j];
+    int64_t rb;
+    if (a.partner) {
+        rb = a.partner[j];
+        if (a.own[j2] != rb || a.partner[j2] != ra) {   // not a mirrored pair: the caller broke the precondition
+            if (tid == 0) atomicOr(&a.flags[3], 4);
+            return;
+        }
+    } else
+        rb = a.own[j2];
+    const int64_t oA = a.seg[j], oB = a.seg[j2];
+    const bool okA = (uint64_t)ra < (uint64_t)a.n_rows, okB = (uint64_t)rb < (uint64_t)a.n_rows;   // else: an empty row, never dereferenced
+    const bool same = ra == rb;
+    const Key *keys = (const Key *)a.data;
+    int64_t ab = 0, bb = 0;
+    int na = 0, nb = 0;
+    int32_t idA0 = 0, idB0 = 0;
+    Key kA0 = 0, kB0 = 0;
+    if (a.row_len) {       // strided rows: ask for the first NT members of both rows now, for their lengths next
+        ab = ra * a.row_stride, bb = rb * a.row_stride;
+        const bool in = tid < a.row_stride;
+        if (okA && in) {
+            SJ_HOOK_FIRST_TRIP(idA0, kA0, tid) {
+                idA0 = stream_load(&a.indices[ab + tid]);
+                kA0 = stream_load(&keys[ab + tid]);
+            }
+        }
+        if (okB && !same && in) {
+            SJ_HOOK_FIRST_TRIP(idB0, kB0, tid) {
+                idB0 = stream_load(&a.indices[bb + tid]);
+                kB0 = stream_load(&keys[bb + tid]);
+            }
+        }
+        na = okA ? a.row_len[ra] : 0;
+        nb = okB ? a.row_len[rb] : 0;
+    } else {
+        int64_t na64 = 0, nb64 = 0;
+        if (okA) {
+            ab = a.indptr[ra];
+            na64 = a.indptr[ra + 1] - ab;
+        }
+        if (okB) {
+            bb = a.indptr[rb];
+            nb64 = a.indptr[rb + 1] - bb;
+        }
+        na = na64 > ML ? ML + 1 : (int)na64, nb = nb64 > ML ? ML + 1 : (int)nb64;
+        if (tid < na && na <= ML) {
+            SJ_HOOK_FIRST_TRIP(idA0, kA0, tid) {
+                idA0 = stream_load(&a.indices[ab + tid]);
+                kA0 = stream_load(&keys[ab + tid]);
+            }
+        }
+        if (!same && tid < nb && nb <= ML) {
+            SJ_HOOK_FIRST_TRIP(idB0, kB0, tid) {
+                idB0 = stream_load(&a.indices[bb + tid]);
+                kB0 = stream_load(&keys[bb + tid]);
+            }
+        }
+    }
+    KeyQuot q;
+    q.fm = (float)a.key_M, q.rcp = 1.0f / q.fm, q.divide = a.key_M >= 4096;
+    if (na > ML || nb > ML) {
+        if (tid == 0) atomicOr(&a.flags[3], 1);
+        return;
+    }
+    if (same) idB0 = idA0, kB0 = kA0;      // (u,u): the second row is the first
+    // roles: S = the shorter row, searched member by member in T = the longer one
+    const bool swap = na > nb;
+    const int ns = swap ? nb : na, nt = swap ? na : nb;
+    const int64_t sb = swap ? bb : ab, tb = swap ? ab : bb;           // where the rows begin in indices / keys
+    const int64_t oS = swap ? oB : oA, oT = swap ? oA : oB, jS = swap ? j2 : j, jT = swap ? j : j2;
+    // Span c of S = members [64c, 64c + 64) = trip c / NW of wave c % NW: the members a lane needs are the ones it loads itself.
+    // Up to kRegTrips trips of S live in registers (rows of up to kRegTrips * NT members: every shape the walk kernels emit);
+    // longer rows take the rest span by span (below).  Trips 1.. of S and of T are asked for together: one round trip.
+    constexpr int kRegTrips = 4;
+    int32_t sid[kRegTrips];
+    Key skey[kRegTrips], sgot[kRegTrips];
+    sid[0] = swap ? idB0 : idA0, skey[0] = swap ? kB0 : kA0;
+    {
+        int32_t ti[kRegTrips - 1];
+        Key tk[kRegTrips - 1];
+#pragma unroll
+        for (int u = 1; u < kRegTrips; ++u) {
+            const int r = tid + u * NT;
+            sid[u] = 0, skey[u] = 0, ti[u - 1] = 0, tk[u - 1] = 0;
+            if (r < ns) {
+                SJ_HOOK_FIRST_TRIP(sid[u], skey[u], r) {
+                    sid[u] = stream_load(&a.indices[sb + r]);
+                    skey[u] = stream_load(&keys[sb + r]);
+                }
+            }
+            if (r < nt) {
+                SJ_HOOK_FIRST_TRIP(ti[u - 1], tk[u - 1], r) {
+                    ti[u - 1] = stream_load(&a.indices[tb + r]);
+                    tk[u - 1] = stream_load(&keys[tb + r]);
+                }
+            }
+        }
+        if (tid < nt) {
+            idsT[tid] = swap ? idA0 : idB0;
+            valT[tid] = swap ? kA0 : kB0;
+            pk[tid] = 0;
+        }
+#pragma unroll
+        for (int u = 1; u < kRegTrips; ++u) {
+            const int r = tid + u * NT;
+            if (r < nt) {
+                idsT[r] = ti[u - 1];
+                valT[r] = tk[u - 1];
+                pk[r] = 0;
+            }
+        }
+    }
+    for (int r = tid + kRegTrips * NT; r < nt; r += NT) {
+        SJ_HOOK_ROW_LOAD(idsT, valT, tb, r, 3);
+        idsT[r] = stream_load(&a.indices[tb + r]);
+        valT[r] = stream_load(&keys[tb + r]);
+        pk[r] = 0;
+    }
+    __syncthreads();
+    SJ_HOOK_PAIR_ROWS_READY();
+
+    // ---- search: every member of S in T (sorted-set intersection: the last member of T that is <= id, by halving; n is
+    //      wave-uniform, the trips of a lane are independent chains that share every LDS round trip).  A hit hands the member's
+    //      key to the member it found.  With `split` workgroups per pair every one of them searches all of S: its LDS needs every hit.
+    const int chunksS = (ns + kWave - 1) / kWave, chunksT = (nt + kWave - 1) / kWave;
+    const bool whole = a.split == 1;
+    {
+        int b[kRegTrips];
+#pragma unroll
+        for (int u = 0; u < kRegTrips; ++u) b[u] = 0;
+        int n = nt;
+        SJ_HOOK_SEARCH_RANGE(b[0], n);
+        const int trips = (chunksS - wave + NW - 1) / NW;       // spans of S this wave holds (<= kRegTrips of them in registers)
+        while (n > 1) {
+            const int h = n >> 1;
+#pragma unroll
+            for (int u = 0; u < kRegTrips; ++u)
+                if (u < trips) b[u] = idsT[b[u] + h] <= sid[u] ? b[u] + h : b[u];
+            n -= h;
+        }
+#pragma unroll
+        for (int u = 0; u < kRegTrips; ++u) {
+            sgot[u] = 0;
+            if (u < trips) {
+                const int32_t f = idsT[b[u]];          // (T without members: slot 0 of its LDS array, never used)
+                const Key g = valT[b[u]];
+                const bool hit = (wave + u * NW) * kWave + lane < ns && n == 1 && f == sid[u];
+                if (hit) pk[b[u]] = skey[u], sgot[u] = g;
+            }
+        }
+    }
+    // rows longer than the register trips hold: their later spans one by one, searched and emitted on the spot
+    for (int c = wave + kRegTrips * NW; c < chunksS; c += NW) {
+        const int t0 = c * kWave;
+        const bool live = t0 + lane < ns;
+        int32_t id = 0;
+        Key key = 0;
+        if (live) {
+            id = stream_load(&a.indices[sb + t0 + lane]);
+            key = stream_load(&keys[sb + t0 + lane]);
+        }
+        int bx = 0, n = nt;
+        SJ_HOOK_SEARCH_RANGE(bx, n);
+        while (n > 1) {
+            const int h = n >> 1;
+            bx = idsT[bx + h] <= id ? bx + h : bx;
+            n -= h;
+        }
+        const int32_t f = idsT[bx];
+        const Key g = valT[bx];
+        const bool hit = live && n == 1 && f == id;
+        if (hit) pk[bx] = key;
+        if (whole || (uint32_t)(c / NW) % (uint32_t)a.split == part)
+            emit_key_span<KV, K64, Key>(a, lane, live, key, hit ? g : (Key)0, ns - t0 < kWave ? ns - t0 : kWave, oS + t0, jS, kc, q, stage);
+    }
+    __syncthreads();
+    // ---- emit: S's spans out of the registers, then T's (every member's partner key is in pk), dealt so that the waves with
+    //      fewer spans of S take more of T
+#pragma unroll
+    for (int u = 0; u < kRegTrips; ++u) {
+        const int c = wave + u * NW, t0 = c * kWave;
+        if (c < chunksS && (whole || (uint32_t)u % (uint32_t)a.split == part))
+            emit_key_span<KV, K64, Key>(a, lane, t0 + lane < ns, skey[u], sgot[u], ns - t0 < kWave ? ns - t0 : kWave, oS + t0, jS, kc, q, stage);
+    }
+    const int rot = (NW - chunksS % NW) % NW;       // T's span c goes to wave (c + chunksS) % NW: the round robin simply goes on
+    for (int c = (wave + rot) % NW + (int)part * NW; c < chunksT; c += a.split * NW) {
+        const int t0 = c * kWave;
+        const bool live = t0 + lane < nt;
+        const int i = live ? t0 + lane : t0;
+        emit_key_span<KV, K64, Key>(a, lane, live, valT[i], pk[i], nt - t0 < kWave ? nt - t0 : kWave, oT + t0, jT, kc, q, stage);
     }
 }
 
@@ -831,6 +1172,9 @@ extern "C" int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t n_rows, i
 }
 
 // key payload (strided rows of a transient batch, or a packed store whose payload was re-keyed): shared launcher
+// LDS of the per-wave staging areas of emit_rows' KEYS path: [4 + 64 x 2k] floats per wave + the round-up to a 16-byte boundary
+static inline size_t key_stage_bytes(int waves, int k) { return 16 + (size_t)waves * (kWave * 2 * k + 4) * 4; }
+
 static int launch_key_join(JoinArgs &a, int32_t num_walks, int32_t num_steps, int64_t S, int64_t pair_block, void *stream,
                            const char *who, bool wide = false) {
     const int shift = subgacc_key_shift(num_walks, num_steps);
@@ -841,53 +1185,35 @@ static int launch_key_join(JoinArgs &a, int32_t num_walks, int32_t num_steps, in
     a.out_idx = nullptr;
     a.slot_id = nullptr, a.val_add = 0;
     a.key_M = num_walks, a.key_m = num_steps, a.key_shift = shift;
-    if (wide) {      // 64-bit keys: 24 bytes of LDS per member of the two rows, every lane unpacks its own row
-        const size_t lds = (size_t)a.max_len * 24 + ((size_t)4 << shift) + (size_t)(256 / kWave) * kWave * 2 * a.k * 4;
-        SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "%s: rows of %d members do not fit LDS", who, (int)a.max_len);
-        a.split = pair_split(S / 2);
-        const int64_t grid = xcd_grid(S / 2 * a.split);
-        SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "%s: too many segments in one call", who);
-        hipStream_t s = (hipStream_t)stream;
-        if (a.k == 5 && a.max_len > 512 && a.split == 1) {     // 4-hop rows (up to 801 members): 256 lanes per pair, as for the 3-hop rows
-            if (lds > 64 * 1024)
-                SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 5, true, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((sjoin_pair_kernel<false, 5, true, 256, true>), dim3((unsigned)grid), dim3(256), lds, s, a, pair_block);
-        } else {
-            if (lds > 64 * 1024)
-                SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 0, true, kPairEmit, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((sjoin_pair_kernel<false, 0, true, kPairEmit, true>), dim3((unsigned)grid), dim3(kPairEmit), lds, s, a, pair_block);
-        }
-        SG_LAUNCH_CHECK();
-        return SUBGACC_OK;
-    }
-    const size_t lds = (size_t)a.max_len * 16 + ((size_t)4 << shift) +
-                       (a.k == 4 ? 0 : (size_t)(kPairEmit / kWave) * kWave * 2 * a.k * 4);   // staging: only the generic width uses it
+    // LDS: the longer row of a pair (id + key + partner key per member), one staging area per wave
+    const int nt = (a.max_len > 512 && pair_split(S / 2) == 1 && (a.k == 4 || (wide && a.k == 5))) ? 256 : kPairEmit;
+    // (rows of 3- and 4-hop sets -- up to 601 / 801 members -- take 256 lanes per pair: the two rows arrive in half the trips and eight
+    //  wavefronts emit the ~12-25 spans: cit2 join 0.437 -> 0.429 ms; 2-hop rows, ~120 members, lose 9 % with 256 lanes and keep 128:
+    //  profiles/r12_ab_pair_threads.log)
+    const size_t lds = (size_t)a.max_len * (wide ? 20 : 12) + key_stage_bytes(nt / kWave, a.k);
     SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "%s: rows of %d members do not fit LDS", who, (int)a.max_len);
     a.split = pair_split(S / 2);
     const int64_t grid = xcd_grid(S / 2 * a.split);
-    SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "%s: too many segments in one call", who);
+    SG_REQUIRE(grid < (1ll << 31) && S / 2 < (1ll << 31), SUBGACC_ERR_BADARG, "%s: too many segments in one call", who);
     hipStream_t s = (hipStream_t)stream;
-    const bool vec4 = a.k == 4 && ((uintptr_t)a.out_xz % 16 == 0);
-    if (vec4 && a.max_len > 512 && a.split == 1) {
-        // rows of 3-hop sets (up to 601 members, ~380 on the cit2-like batch): 256 lanes per pair -- the two rows arrive in half
-        // the trips and eight wavefronts emit the ~12 spans (join kernel 0.437 -> 0.429 ms; 2-hop rows, ~120 members, lose 9 %
-        // with 256 lanes and keep 128: profiles/r12_ab_pair_threads.log)
-        if (lds > 64 * 1024)
-            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 4, true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((sjoin_pair_kernel<false, 4, true, 256>), dim3((unsigned)grid), dim3(256), lds, s, a, pair_block);
-    } else if (vec4) {
-        if (lds > 64 * 1024)
-            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((sjoin_pair_kernel<false, 4, true>), dim3((unsigned)grid), dim3(kPairEmit), lds, s, a, pair_block);
-    } else if (a.k == 3) {      // 2 hops (the collab-like configurations)
-        if (lds > 64 * 1024)
-            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((sjoin_pair_kernel<false, 3, true>), dim3((unsigned)grid), dim3(kPairEmit), lds, s, a, pair_block);
-    } else {
-        if (lds > 64 * 1024)
-            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((sjoin_pair_kernel<false, 0, true>), dim3((unsigned)grid), dim3(kPairEmit), lds, s, a, pair_block);
-    }
+    const uint32_t pairs = (uint32_t)(S / 2), pb = (uint32_t)pair_block;
+#define SG_KEY_LAUNCH(KVV, NTT, W)                                                                                             \
+    do {                                                                                                                        \
+        if (lds > 64 * 1024)                                                                                                    \
+            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_keypair_kernel<KVV, NTT, W>,                                   \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
+        hipLaunchKernelGGL((sjoin_keypair_kernel<KVV, NTT, W>), dim3((unsigned)grid), dim3(NTT), lds, s, a, pb, pairs);         \
+    } while (0)
+    if (wide) {
+        if (a.k == 5 && nt == 256) SG_KEY_LAUNCH(5, 256, true);
+        else if (a.k == 5) SG_KEY_LAUNCH(5, kPairEmit, true);
+        else SG_KEY_LAUNCH(0, kPairEmit, true);
+    } else if (a.k == 4 && nt == 256) SG_KEY_LAUNCH(4, 256, false);
+    else if (a.k == 4) SG_KEY_LAUNCH(4, kPairEmit, false);      // 3 hops
+    else if (a.k == 3) SG_KEY_LAUNCH(3, kPairEmit, false);      // 2 hops (the collab-like configurations)
+    else if (a.k == 5) SG_KEY_LAUNCH(5, kPairEmit, false);      // 4 hops with 32-bit keys (M <= 127: the reference's own citation2 setting)
+    else SG_KEY_LAUNCH(0, kPairEmit, false);
+#undef SG_KEY_LAUNCH
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }

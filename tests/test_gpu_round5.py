@@ -43,3 +43,30 @@ def test_key_rows_numbered_after_the_fact_describe_the_batch_that_was_joined(sp,
     skip = int(o_nsize[: prefix.size].sum())
     rows = np.split(o_remap[0][skip:], np.cumsum(o_nsize[prefix.size:])[:-1])
     assert np.array_equal(a.indices.cpu().numpy(), np.concatenate([np.sort(r) for r in rows]))
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 5, 7, 10, 100, 127, 128, 200, 255, 256, 300, 1000, 4095, 4096, 5000])
+def test_keyed_join_divides_every_count_like_main_py(sp, M):
+    """the key join unpacks count / num_walks itself (csrc/sjoin.hip:lp_quotient, an fma-refined reciprocal below 4,096 walks, a
+    division beyond): every value a key field of this num_walks can hold, in both fields and both slots, against numpy's float32
+    division (main.py:174: `float32(enc) / num_walks`)"""
+    from surel_plus_amd._lib import check, lib
+    m = 2
+    shift = check(lib().subgacc_key_shift(M, m))
+    assert m * shift + 1 <= 31
+    vals = np.arange(1 << shift, dtype=np.int64)
+    c1, c2 = vals, (vals * 7 + 3) & ((1 << shift) - 1)
+    keys = ((c1 << shift) | c2) | (np.int64(1) << (m * shift)) * (vals & 1)          # (every other member carries the root flag)
+    per = min(256, vals.size)
+    n_rows = vals.size // per
+    indptr = torch.arange(0, vals.size + 1, per, dtype=torch.int64, device="cuda")
+    ids = torch.arange(per, dtype=torch.int32, device="cuda").repeat(n_rows)
+    z = sp.SpG(indptr, ids, torch.from_numpy(keys.astype(np.int32)).cuda(), max_len=per, shape=(n_rows, per), max_data=0)
+    z.keyrows, z.key_M, z.key_m = True, M, m
+    rows = torch.arange(n_rows, device="cuda")
+    xz, ind = sp.gather(torch.stack([rows, rows]), z, "cuda", ptr=True, encode=z.slot_table())
+    got = xz.cpu().numpy()
+    assert got.shape == (2 * vals.size, 2, m + 1)
+    want = np.stack([(vals & 1).astype(np.float32), c1.astype(np.float32) / np.float32(M), c2.astype(np.float32) / np.float32(M)], axis=1)
+    for half in (got[: vals.size], got[vals.size:]):              # (u, u): own row and partner row are the same member
+        assert np.array_equal(half[:, 0, :], want) and np.array_equal(half[:, 1, :], want)

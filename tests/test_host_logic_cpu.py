@@ -173,3 +173,25 @@ def test_batch_views_cut_a_many_batch_join_into_reference_shaped_pieces():
     with pytest.raises(ValueError):
         BatchViews(xz, seg, 5)                                      # 24 segments are not a whole number of batches of 5
     assert BatchViews(xz[:0], torch.zeros(1, dtype=torch.int64), 2 * B) == []
+
+
+def test_the_join_kernels_quotient_formula_is_the_ieee_division():
+    """csrc/sjoin.hip:lp_quotient computes count / num_walks as q0 = c * (1/M), r = fma(-M, q0, c), q = fma(r, 1/M, q0) for
+    num_walks < 4,096 (and divides beyond).  main.py:174 divides (`float32(enc) / M`): the formula must give the correctly rounded
+    quotient for EVERY count a key field of that num_walks can hold (c < 2^bits(M)), not just for most.  Exact emulation: the fma's
+    exact arguments fit the 64-bit significand of x87 long double (c - M*q0: < 2^36 in units of ulp(q0); q0 + r*(1/M): < 2^60)."""
+    if np.finfo(np.longdouble).nmant < 63:
+        pytest.skip("needs the 64-bit significand of x87 long double")
+    cases = 0
+    for M in range(1, 4096):
+        c = np.arange(0, 1 << int(M).bit_length(), dtype=np.int64)
+        a, fm = c.astype(np.float32), np.float32(M)
+        y = np.float32(1.0) / fm
+        q0 = a * y
+        r_exact = a.astype(np.longdouble) - np.longdouble(fm) * q0.astype(np.longdouble)
+        r = r_exact.astype(np.float32)
+        assert np.array_equal(r.astype(np.longdouble), r_exact)            # fma(-M, q0, c) is exact: nothing is rounded away
+        q = (q0.astype(np.longdouble) + r.astype(np.longdouble) * y.astype(np.longdouble)).astype(np.float32)
+        assert np.array_equal(q, a / fm), M
+        cases += c.size
+    assert cases == 11184810

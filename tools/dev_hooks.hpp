@@ -10,7 +10,7 @@
 //   SG_EXPERIMENT (walk_rows.hip) 9 the last hop's read hits L2 (no missed line) | 10 every later hop's does
 //   SG_STOP_AFTER = k         every workgroup of walk_sets_kernel / walk_rows_kernel ends at stamp k (tools/walk_insts.sh)
 //   SJ_EXPERIMENT (sjoin.hip) 1 no search | 2 no output stores | 3 stores without the feature-table read | 4 no row loads
-//                             8 plain (cached) stores
+//                             8 plain (cached) stores | 5 chain only | 6 entry only | 7 staged spans not stored
 #pragma once
 #define SG_DEV_HOOKS 1
 #ifndef SG_EXPERIMENT
@@ -128,9 +128,28 @@
 #define SJ_HOOK_ROW_LOAD(ids, val, row, r, mul)          \
     {                                                    \
         ids[r] = (int32_t)((row) & 1023) + (mul) * (r);  \
-        val[r] = (Val)((r) & 127);                       \
+        val[r] = (decltype(val[0] + 0))((r) & 127);         \
         continue;                                        \
     }
+#define SJ_HOOK_FIRST_TRIP(id, k, t) id = (t) * 3; k = (t) & 127; if (false)
 #else
 #define SJ_HOOK_ROW_LOAD(ids, val, row, r, mul)
+#define SJ_HOOK_FIRST_TRIP(id, k, t)
+#endif
+// sjoin_pair_kernel: 5 = every workgroup ends once its two rows stand in LDS (the dependent chain own -> row length -> rows alone),
+// 6 = ends at entry (what starting the workgroups costs), 7 = the staged spans are unpacked and staged but not stored
+#if SJ_EXPERIMENT == 6
+#define SJ_HOOK_PAIR_ENTRY() if (a.S >= 0) return
+#else
+#define SJ_HOOK_PAIR_ENTRY()
+#endif
+#if SJ_EXPERIMENT == 5
+#define SJ_HOOK_PAIR_ROWS_READY() if (a.S >= 0) return
+#else
+#define SJ_HOOK_PAIR_ROWS_READY()
+#endif
+#if SJ_EXPERIMENT == 7
+#define SJ_HOOK_SPAN_STORES(nbody) ((nbody) == -12345 ? 1 : 0)
+#else
+#define SJ_HOOK_SPAN_STORES(nbody) (nbody)
 #endif

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Dev-only: the join kernel of the on-demand step ALONE, on the real rows of one batch, across library builds.
+
+    python tools/join_bench.py [--wl=collab,twitter,cit2,cit2m4,ppa] [--libs=-,tools/build/libsubgacc_x.so,...] [--n=50]
+
+One process per (workload, library): builds the preset graph, runs one buffered step (so that the step buffers hold the walk
+kernel's rows and the segment pointers), then times `n` launches of subgacc_sjoin_fill_keyrows(64) over those buffers with HIP
+events on the launch stream; prints ms, algorithmic bytes and the fraction of the 8 TB/s peak.  `-` = the shipped
+library.  Variant libraries are built HERE into tools/build/ (they travel to the GPU box): tools/join_bench.py --build "-DX=1" name."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("SUBGACC_QUIET", "1")
+CSRC = os.path.join(ROOT, "surel_plus_amd", "csrc")
+FLAGS = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -ffp-contract=off".split()
+
+
+def build(flags, name, files=("sjoin.hip",)):
+    out = os.path.join(ROOT, "tools", "build", f"libsubgacc_{name}.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    objs = [os.path.join(CSRC, "build", f) for f in os.listdir(os.path.join(CSRC, "build")) if f.endswith(".o") and f[:-2] + ".hip" not in files]
+    hooks = ["-include", os.path.join(ROOT, "tools", "dev_hooks.hpp")] if "EXPERIMENT" in flags else []
+    for f in files:
+        o = f"/tmp/jb_{name}_{f[:-4]}.o"
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + hooks + flags.split() + ["-c", os.path.join(CSRC, f), "-o", o])
+        objs.append(o)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
+    print("built", out)
+
+
+def one(wl, n):
+    import torch
+    import bench
+    import surel_plus_amd as sp
+    from surel_plus_amd._lib import check, lib, ptr, stream_ptr
+    from surel_plus_amd.graphs import preset_graph, query_pairs
+    from surel_plus_amd.spjoin import _arange_segments
+    preset, M, k, _, pos = bench.WORKLOADS[wl]
+    dev = torch.device("cuda", 0)
+    csr = preset_graph(preset, device=dev)
+    B = 65536
+    bufs = sp.StepBuffers(csr, B, M, k - 1)
+    e = query_pairs(csr, B, seed=1, device=dev, pos_frac=pos)
+    xz, ind, sets = sp.sample_and_gather(csr, e, num_walks=M, num_steps=k - 1, seed=1, rng="philox", buffers=bufs, lazy=True)
+    sets.prefetch(extra=ind[-1:]).resolve()
+    rows = int(sets.extra[0])
+    L, st = lib(), stream_ptr()
+    own, partner = _arange_segments(B, dev, B)
+    flags = bufs.status.view(torch.int32)[:4]
+    fill = L.subgacc_sjoin_fill_keyrows64 if bufs.key64 else L.subgacc_sjoin_fill_keyrows
+    out = bufs.out.view(-1)
+
+    def launch():
+        check(fill(ptr(bufs.nsize), 2 * B, bufs.stride, ptr(bufs.ids), ptr(bufs.slot), ptr(own), ptr(partner), 2 * B, ptr(bufs.seg),
+                   M, k - 1, ptr(out), B, ptr(flags), st))
+    for _ in range(5):
+        launch()
+    torch.cuda.synchronize()
+    best = []
+    for rep in range(3):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            launch()
+        b.record()
+        b.synchronize()
+        best.append(a.elapsed_time(b) / n)
+    ms = sorted(best)[1]
+    abytes = B * 64 + rows * (8 + 8 * k)
+    print(f"{wl:8s} lib={os.environ.get('SUBGACC_LIB', '-'):40s} rows/pair {rows / B:6.1f}  join {ms:.4f} ms (min {min(best):.4f})  "
+          f"{abytes / ms / 1e9:.2f} TB/s  frac {abytes / (ms * 1e-3) / 8e12:.3f}", flush=True)
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--build":
+        return build(sys.argv[2], sys.argv[3], tuple(sys.argv[4].split(",")) if len(sys.argv) > 4 else ("sjoin.hip",))
+    if len(sys.argv) > 1 and sys.argv[1] == "--one":
+        return one(sys.argv[2], int(sys.argv[3]))
+    opts = dict(a[2:].split("=", 1) for a in sys.argv[1:] if a.startswith("--") and "=" in a)
+    for wl in opts.get("wl", "collab,twitter").split(","):
+        for libp in opts.get("libs", "-").split(","):
+            env = dict(os.environ)
+            env.pop("SUBGACC_LIB", None)
+            if libp != "-":
+                env["SUBGACC_LIB"] = os.path.join(ROOT, libp)
+            subprocess.call([sys.executable, os.path.abspath(__file__), "--one", wl, opts.get("n", "50")], env=env)
+
+
+if __name__ == "__main__":
+    main()
