@@ -129,6 +129,10 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void stream_store(float4 *p, const float4 &t) {
+#ifdef SJ_DEV_PLAIN_STORES      // dev builds: ordinary (cached) stores for the wide words, tools/join_bench.py
+    *p = t;
+    return;
+#endif
     v4f v;
     v.x = t.x, v.y = t.y, v.z = t.z, v.w = t.w;
     __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(p));
@@ -771,6 +775,191 @@ __global__ __launch_bounds__(NT) void sjoin_keypair_kernel(const JoinArgs a, uin
     }
 }
 
+// (Round 5 also measured Q consecutive pairs per workgroup, software-pipelined -- the pairs' row numbers, offsets and lengths read
+// once per workgroup, pair q+1's first members on their way into registers while pair q is searched and emitted, two LDS buffers
+// in turn: 3-17 % SLOWER than one workgroup per pair on every workload at Q = 4, 8, 16 and with 128 or 256 lanes,
+// profiles/r18_join_pipe.log.  The hardware's own interleaving of ~16 resident workgroups per CU already hides the start-up chain;
+// fewer, longer-lived workgroups only add barriers.  The code is not kept.)
+
+// ---------------------------------------------------------------------------------------------------------
+// Float payload (the PPR encoder's store, train.py:39-43): the same pair join as sjoin_keypair_kernel -- the longer row T staged in
+// LDS with a slot per member for its partner's value, the shorter row S in the registers of the lanes that loaded it, one halving
+// search of S in T, a hit hands S's value over -- with 8-byte payloads and a two-float output row that needs no staging:
+// xz[row] = (float(own), float((partner or 0.0) + 1.0 - 1.0)), the SciPy expression of train.py:33 evaluated in double.
+template <int NT>
+__global__ __launch_bounds__(NT) void sjoin_f64pair_kernel(const JoinArgs a, uint32_t pb, uint32_t pairs) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    constexpr int NW = NT / kWave;
+    const int ML = a.max_len;
+    double *valT = (double *)lds_raw;                 // [max_len] values of T
+    double *pv = valT + ML;                           // [max_len] partner values of T's members (0.0 = absent)
+    int32_t *idsT = (int32_t *)(pv + ML);             // [max_len]
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+
+    SJ_HOOK_PAIR_ENTRY();
+    const uint32_t wg = (uint32_t)(blockIdx.x & (kXcds - 1)) * (gridDim.x / kXcds) + (blockIdx.x / kXcds);    // xcd_item, 32 bits
+    uint32_t p = wg, part = 0;
+    if (a.split > 1) {
+        p = wg / (uint32_t)a.split;
+        part = wg - p * (uint32_t)a.split;
+    }
+    if (p >= pairs) return;
+    uint32_t blk = 0, off = p;
+    if (pb != pairs) {                 // several mirrored blocks (nb batches in one launch)
+        blk = p / pb;
+        off = p - blk * pb;
+    }
+    const int64_t j = (int64_t)blk * 2 * pb + off, j2 = j + pb;
+    const int64_t ra = a.own[j];
+    int64_t rb;
+    if (a.partner) {
+        rb = a.partner[j];
+        if (a.own[j2] != rb || a.partner[j2] != ra) {   // not a mirrored pair: the caller broke the precondition
+            if (tid == 0) atomicOr(&a.flags[3], 4);
+            return;
+        }
+    } else
+        rb = a.own[j2];
+    const int64_t oA = a.seg[j], oB = a.seg[j2];
+    const bool okA = (uint64_t)ra < (uint64_t)a.n_rows, okB = (uint64_t)rb < (uint64_t)a.n_rows;   // else: an empty row, never dereferenced
+    const double *vals = (const double *)a.data;
+    int64_t ab = 0, bb = 0, na64 = 0, nb64 = 0;
+    if (okA) {
+        ab = a.indptr[ra];
+        na64 = a.indptr[ra + 1] - ab;
+    }
+    if (okB) {
+        bb = a.indptr[rb];
+        nb64 = a.indptr[rb + 1] - bb;
+    }
+    if (na64 > ML || nb64 > ML) {
+        if (tid == 0) atomicOr(&a.flags[3], 1);
+        return;
+    }
+    const int na = (int)na64, nb = (int)nb64;
+    // roles: S = the shorter row, searched member by member in T = the longer one ((u,u): S and T are the same row)
+    const bool swap = na > nb;
+    const int ns = swap ? nb : na, nt = swap ? na : nb;
+    const int64_t sb = swap ? bb : ab, tb = swap ? ab : bb;
+    const int64_t oS = swap ? oB : oA, oT = swap ? oA : oB, jS = swap ? j2 : j, jT = swap ? j : j2;
+    constexpr int kRegTrips = 4;       // trips of S in registers (rows of up to 4 * NT members; longer ones span by span below)
+    int32_t sid[kRegTrips];
+    double sval[kRegTrips], sgot[kRegTrips];
+    {
+        int32_t ti[kRegTrips];
+        double tv[kRegTrips];
+#pragma unroll
+        for (int u = 0; u < kRegTrips; ++u) {      // every trip of both rows asked for together: one round trip
+            const int r = tid + u * NT;
+            sid[u] = 0, sval[u] = 0.0, ti[u] = 0, tv[u] = 0.0;
+            if (r < ns) {
+                SJ_HOOK_FIRST_TRIP(sid[u], sval[u], r) {
+                    sid[u] = stream_load(&a.indices[sb + r]);
+                    sval[u] = stream_load(&vals[sb + r]);
+                }
+            }
+            if (r < nt) {
+                SJ_HOOK_FIRST_TRIP(ti[u], tv[u], r) {
+                    ti[u] = stream_load(&a.indices[tb + r]);
+                    tv[u] = stream_load(&vals[tb + r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kRegTrips; ++u) {
+            const int r = tid + u * NT;
+            if (r < nt) {
+                idsT[r] = ti[u];
+                valT[r] = tv[u];
+                pv[r] = 0.0;
+            }
+        }
+    }
+    for (int r = tid + kRegTrips * NT; r < nt; r += NT) {
+        idsT[r] = stream_load(&a.indices[tb + r]);
+        valT[r] = stream_load(&vals[tb + r]);
+        pv[r] = 0.0;
+    }
+    __syncthreads();
+    SJ_HOOK_PAIR_ROWS_READY();
+    const int chunksS = (ns + kWave - 1) / kWave, chunksT = (nt + kWave - 1) / kWave;
+    const bool whole = a.split == 1;
+    float2 *xz = reinterpret_cast<float2 *>(a.out_xz);
+    {
+        int b[kRegTrips];
+#pragma unroll
+        for (int u = 0; u < kRegTrips; ++u) b[u] = 0;
+        int n = nt;
+        SJ_HOOK_SEARCH_RANGE(b[0], n);
+        const int trips = (chunksS - wave + NW - 1) / NW;
+        while (n > 1) {
+            const int h = n >> 1;
+#pragma unroll
+            for (int u = 0; u < kRegTrips; ++u)
+                if (u < trips) b[u] = idsT[b[u] + h] <= sid[u] ? b[u] + h : b[u];
+            n -= h;
+        }
+#pragma unroll
+        for (int u = 0; u < kRegTrips; ++u) {
+            sgot[u] = 0.0;
+            if (u < trips) {
+                const int32_t f = idsT[b[u]];
+                const double g = valT[b[u]];
+                const bool hit = (wave + u * NW) * kWave + lane < ns && n == 1 && f == sid[u];
+                if (hit) pv[b[u]] = sval[u], sgot[u] = g;
+            }
+        }
+    }
+    for (int c = wave + kRegTrips * NW; c < chunksS; c += NW) {      // rows longer than the register trips hold
+        const int t0 = c * kWave;
+        const bool live = t0 + lane < ns;
+        int32_t id = 0;
+        double v = 0.0;
+        if (live) id = stream_load(&a.indices[sb + t0 + lane]), v = stream_load(&vals[sb + t0 + lane]);
+        int bx = 0, n = nt;
+        SJ_HOOK_SEARCH_RANGE(bx, n);
+        while (n > 1) {
+            const int h = n >> 1;
+            bx = idsT[bx + h] <= id ? bx + h : bx;
+            n -= h;
+        }
+        const int32_t f = idsT[bx];
+        const double g = valT[bx];
+        const bool hit = live && n == 1 && f == id;
+        if (hit) pv[bx] = v;
+        if (live && (whole || (uint32_t)(c / NW) % (uint32_t)a.split == part)) {
+            // the scipy expression computes (partner value or 0) + 1.0 - 1.0 in double, then casts (train.py:33,39-43)
+            float2 o;
+            o.x = (float)v, o.y = (float)(((hit ? g : 0.0) + 1.0) - 1.0);
+            stream_store(xz + oS + t0 + lane, o);
+            if (a.out_segid) __builtin_nontemporal_store(jS, a.out_segid + oS + t0 + lane);
+        }
+    }
+    // S's spans leave right away (nobody waits for them); T's after the barrier that completes pv
+#pragma unroll
+    for (int u = 0; u < kRegTrips; ++u) {
+        const int64_t t = (wave + u * NW) * kWave + lane;
+        if (t < ns && (whole || (uint32_t)u % (uint32_t)a.split == part)) {
+            float2 o;
+            o.x = (float)sval[u], o.y = (float)((sgot[u] + 1.0) - 1.0);
+            stream_store(xz + oS + t, o);
+            if (a.out_segid) __builtin_nontemporal_store(jS, a.out_segid + oS + t);
+        }
+    }
+    __syncthreads();
+    const int rot = (NW - chunksS % NW) % NW;       // T's span c goes to wave (c + chunksS) % NW: the round robin simply goes on
+    for (int c = (wave + rot) % NW + (int)part * NW; c < chunksT; c += a.split * NW) {
+        const int t = c * kWave + lane;
+        if (t < nt) {
+            float2 o;
+            o.x = (float)valT[t], o.y = (float)((pv[t] + 1.0) - 1.0);
+            stream_store(xz + oT + t, o);
+            if (a.out_segid) __builtin_nontemporal_store(jT, a.out_segid + oT + t);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Count form of the join ("next" row f.1 of SURVEY.md section 8: SpJoin fused with the first model stage).
 // The reference's Net.forward (model.py:78-83) embeds both feature slots of every output row with the same MLP
@@ -1086,16 +1275,22 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, int64_t n_rows, con
                            pair_block);                                                                           \
     } while (0)
     if (paired) {
-        if (f64 && a.max_len <= 2 * kWave) {
-            // short float rows (the top-100 PPR store): ONE wave per pair -- twice the pairs in flight per CU for a kernel whose
-            // workgroups live on a chain of dependent loads, not on bandwidth (cit2-PPR join 0.154 -> 0.139 ms; integer rows
-            // with their 6-10 KB of LDS per pair are slower this way: collab 0.175 -> 0.20 ms)
-            // (round 3 tried persistent waves with a four-stage software pipeline over their pairs -- row numbers, row offsets, rows,
-            // search + store of four consecutive pairs in flight per wave: 91 us against this kernel's 77.  The kernel is not
-            // latency-bound: it moves ~300 MB of whole lines per launch -- rows of ~90 members begin and end inside lines -- at
-            // 3.9 TB/s of mixed reads and writes)
-            hipLaunchKernelGGL((sjoin_pair_kernel<true, 0, false, kWave>), dim3((unsigned)grid), dim3(kWave), lds, s, a, pair_block);
-        } else if (f64) SG_PAIR_LAUNCH(true, 0);
+        if (f64) {
+            // float rows: T + its partner slots in LDS (20 bytes per member).  Short rows (the top-100 PPR store): ONE wave per pair
+            // -- twice the pairs in flight per CU (cit2-PPR join 0.154 -> 0.139 ms in round 2; integer rows were slower that way)
+            // (round 3 tried persistent waves with a four-stage software pipeline over their pairs: 91 us against 77; round 5 the
+            //  same for key rows, profiles/r18_join_pipe.log: the hardware's interleaving of resident workgroups wins both times)
+            const size_t flds = (size_t)a.max_len * 20 + 16;
+            SG_REQUIRE(S / 2 < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_fill: too many segments in one call");
+            const uint32_t pairs = (uint32_t)(S / 2), pb32 = (uint32_t)pair_block;
+            if (a.max_len <= 2 * kWave) {
+                hipLaunchKernelGGL((sjoin_f64pair_kernel<kWave>), dim3((unsigned)grid), dim3(kWave), flds, s, a, pb32, pairs);
+            } else {
+                if (flds > 64 * 1024)
+                    SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_f64pair_kernel<kPairEmit>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+                hipLaunchKernelGGL((sjoin_f64pair_kernel<kPairEmit>), dim3((unsigned)grid), dim3(kPairEmit), flds, s, a, pb32, pairs);
+            }
+        }
         else if (vec4) SG_PAIR_LAUNCH(false, 4);      // (256 lanes per pair, as the key form takes for long rows below, cost THIS form
                                                       //  5 %: its emit gathers feature rows from the Z_SF table)
         else SG_PAIR_LAUNCH(false, 0);

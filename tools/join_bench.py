@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Dev-only: the join kernel of the on-demand step ALONE, on the real rows of one batch, across library builds.
 
-    python tools/join_bench.py [--wl=collab,twitter,cit2,cit2m4,ppa] [--libs=-,tools/build/libsubgacc_x.so,...] [--n=50]
+    python tools/join_bench.py [--wl=collab,twitter,cit2,cit2m4,ppa] [--libs=-,tools/build/libsubgacc_x.so,...] [--n=50] [--reps=2]
 
 One process per (workload, library): builds the preset graph, runs one buffered step (so that the step buffers hold the walk
 kernel's rows and the segment pointers), then times `n` launches of subgacc_sjoin_fill_keyrows(64) over those buffers with HIP
@@ -81,12 +81,13 @@ def main():
         return one(sys.argv[2], int(sys.argv[3]))
     opts = dict(a[2:].split("=", 1) for a in sys.argv[1:] if a.startswith("--") and "=" in a)
     for wl in opts.get("wl", "collab,twitter").split(","):
-        for libp in opts.get("libs", "-").split(","):
-            env = dict(os.environ)
-            env.pop("SUBGACC_LIB", None)
-            if libp != "-":
-                env["SUBGACC_LIB"] = os.path.join(ROOT, libp)
-            subprocess.call([sys.executable, os.path.abspath(__file__), "--one", wl, opts.get("n", "50")], env=env)
+        for rep in range(int(opts.get("reps", "1"))):       # (processes of one build differ by a few per cent: alternate, repeat)
+            for libp in opts.get("libs", "-").split(","):
+                env = dict(os.environ)
+                env.pop("SUBGACC_LIB", None)
+                if libp != "-":
+                    env["SUBGACC_LIB"] = os.path.join(ROOT, libp)
+                subprocess.call([sys.executable, os.path.abspath(__file__), "--one", wl, opts.get("n", "50")], env=env)
 
 
 if __name__ == "__main__":
