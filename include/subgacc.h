@@ -479,7 +479,9 @@ int subgacc_keyrows_translate(int32_t *data_inout, int64_t n, const int64_t *n_d
 /* ABI 4: subgacc_walk_spg over ALL n rows but in the order of a work list (worklist[0 .. *n_work) names every row once:
  * subgacc_worklist_by_root) -- either RNG mode: row i keeps its place in the batch AND in the rand_r stream (rng_pos[i] /
  * rng_seed[i] from subgacc_rng_positions over the n roots in batch order; NULL for Philox), only the order in which the kernel
- * takes the rows changes.  Shapes as for subgacc_walk_spg_sparse; tags of the table of distinct rows start at 0. */
+ * takes the rows changes.  Tags of the table of distinct rows start at 0.  Shapes: any that subgacc_walk_spg takes with a
+ * table of distinct rows -- where the fused-row kernel declines (a truncating bucket, M > 256, ...) the general kernel walks
+ * the rows in batch order, which gives the same rows; key rows (uniq_table = NULL) need the fused-row kernel's shapes. */
 int subgacc_walk_spg_list(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,
                           const int32_t *query, int64_t n, const uint32_t *rng_pos, const uint32_t *rng_seed,
                           const int32_t *worklist, const int64_t *n_work, void *uniq_table, int64_t uniq_capacity,

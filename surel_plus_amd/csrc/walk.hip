@@ -759,7 +759,7 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
                        int32_t *set_ids, uint64_t *set_keys, int32_t *set_slot, void *uniq_table, int64_t uniq_capacity,
                        int64_t root_base, int32_t *nsize, int32_t *walks, int32_t *flags, void *stream,
                        bool holes = false, const int32_t *worklist = nullptr, const int64_t *n_work = nullptr,
-                       bool tags_only = false, int64_t work_cap = 0) {
+                       bool tags_only = false, int64_t work_cap = 0, bool order_only_list = false) {
     const bool spg = set_slot != nullptr;
     SG_REQUIRE(cfg && indptr && set_ids && (set_keys || spg) && nsize && flags, SUBGACC_ERR_BADARG,
                "walk: null argument");
@@ -841,6 +841,10 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
     SG_REQUIRE(!tags_only, SUBGACC_ERR_BADARG,
                "walk_tags: only the fused-row kernel registers tags alone (2..4 hops, M <= 256, a 512- or 1,024-slot table, no "
                "bucket); M = %d, m = %d", M, m);
+    if (holes && order_only_list) {      // a list that names EVERY row only says in which order to take them (subgacc_walk_spg_list): the
+        holes = false;                   // general kernel, which reads no list, takes the rows in batch order -- the same rows
+        a.worklist = nullptr, a.n_work = nullptr;
+    }
     SG_REQUIRE(!holes, SUBGACC_ERR_BADARG,
                "walk_spg_sparse: rows without a root are passed over by the fused-row kernel only (2..4 hops, M <= 256, a 512- or "
                "1,024-slot table, no bucket); M = %d, m = %d", M, m);
@@ -915,8 +919,11 @@ extern "C" int subgacc_walk_spg_list(const subgacc_walk_cfg *cfg, const void *in
     SG_REQUIRE(row_slot && worklist && n_work, SUBGACC_ERR_BADARG, "walk_spg_list: null row_slot / work list / length");
     SG_REQUIRE(cfg && !cfg->emit_walks && cfg->order == SUBGACC_ORDER_WALK_MAJOR, SUBGACC_ERR_BADARG,
                "walk_spg_list: set_sampler order only, no raw walks");
+    // (the list of this entry point is an ORDER over all n rows, not a selection: when the fused-row kernel declines the shape --
+    //  a dev build without it, a predicate of the caller that drifted from launch_walk_rows' -- the general kernel takes the rows
+    //  in batch order instead of refusing the call)
     return launch_walk(cfg, indptr, indices, num_nodes, query, n, rng_pos, rng_seed, row_ids, nullptr, row_slot, uniq_table,
-                       uniq_capacity, 0, nsize, nullptr, flags, stream, true, worklist, n_work);
+                       uniq_capacity, 0, nsize, nullptr, flags, stream, true, worklist, n_work, false, 0, true);
 }
 
 extern "C" int subgacc_walk_keyrows64(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,

@@ -166,12 +166,50 @@ def shard_pairs(edge, rank, world):
     return edge[:, lo:hi], (lo, hi)
 
 
-def replicate_rows(nsize, ids, data, group=None):
+def replicate_rows(nsize, ids, data, group=None, alloc=torch.empty):
     """The one-off exchange that makes a row-sharded SpG resident on every GPU: every rank holds the rows
     of its contiguous root range (nsize [n_r], ids / data [X_r], rank order = row order); returns the full
-    (row_off int64 [n+1], ids, data) on every rank.  Three all-gathers (RCCL ring over xGMI on GPUs; sized by the
-    store, e.g. 8 B per member), not part of the steady state."""
-    ns = torch.cat(all_gather_varlen(nsize, group))
-    row_off = torch.zeros(ns.numel() + 1, dtype=torch.int64, device=ns.device)
-    torch.cumsum(ns, 0, out=row_off[1:])
-    return row_off, torch.cat(all_gather_varlen(ids, group)), torch.cat(all_gather_varlen(data, group))
+    (row_off int64 [n+1], ids, data) on every rank.  Not part of the steady state.
+
+    Memory: the full arrays are allocated ONCE (through `alloc`, so that a test can count) and every rank's slice travels
+    straight into its place -- one small all_gather of the (n_r, X_r) pairs, then per rank one broadcast of each array into the
+    slice [off_r, off_r + X_r) of the output (RCCL over xGMI on GPUs).  Peak transient = the store itself (+ this rank's own
+    slices, which the caller holds anyway): no padded per-rank buffers, no list of `world` copies, no concatenation -- the
+    twitter-scale store SURVEY 8(e) sizes at 35-50 GB stays at 35-50 GB per GPU while it is being replicated.
+    gloo has no collectives for device tensors (the 1-GPU rehearsal, several ranks on cuda:0): staged through the host there,
+    one slice at a time."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = nsize.device
+    staged = nsize.is_cuda and dist.get_backend(group) == "gloo"
+    mine = torch.tensor([nsize.numel(), ids.numel()], dtype=torch.int64, device="cpu" if staged else dev)
+    sizes = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(sizes, mine, group=group)
+    sizes = torch.stack(sizes).cpu().tolist()             # [[n_r, X_r]] in rank order
+    n_tot, x_tot = sum(s_[0] for s_ in sizes), sum(s_[1] for s_ in sizes)
+    if data.numel() != ids.numel():
+        raise ValueError("replicate_rows: ids and data of a rank must have the same length")
+    out_ns = alloc(n_tot, dtype=nsize.dtype, device=dev)
+    out_ids = alloc(x_tot, dtype=ids.dtype, device=dev)
+    out_data = alloc(x_tot, dtype=data.dtype, device=dev)
+    row_off = alloc(n_tot + 1, dtype=torch.int64, device=dev)
+    n_off = x_off = 0
+    for r, (n_r, x_r) in enumerate(sizes):
+        src = dist.get_global_rank(group, r) if group is not None else r
+        for full, local, off, cnt in ((out_ns, nsize, n_off, n_r), (out_ids, ids, x_off, x_r), (out_data, data, x_off, x_r)):
+            if cnt == 0:
+                continue
+            piece = full[off: off + cnt]                   # a view: the broadcast writes the output in place
+            if r == rank:
+                piece.copy_(local)
+            if staged:                                     # (rehearsal only: one slice at a time through the host)
+                host = piece.cpu() if r == rank else torch.empty(cnt, dtype=full.dtype)
+                dist.broadcast(host, src=src, group=group)
+                if r != rank:
+                    piece.copy_(host)
+            else:
+                dist.broadcast(piece, src=src, group=group)
+        n_off, x_off = n_off + n_r, x_off + x_r
+    row_off[0] = 0
+    torch.cumsum(out_ns, 0, out=row_off[1:])
+    return row_off, out_ids, out_data

@@ -57,7 +57,24 @@ def _spg_worker(rank, world, port, out_dir):
     M, m = int(g["M"]), int(g["m"])
     sets, gkeys, _ = shard.sample_sets_sharded(oracle_sampler(g, M, m, 9), g["query"], rank, world)
     _, ids, data = oracle.spg_build(sets.nsize.numpy(), np.stack([sets.ids.numpy(), sets.sf.numpy().astype(np.int32)]))
-    row_off, ids, data = shard.replicate_rows(sets.nsize, torch.from_numpy(ids), torch.from_numpy(data))
+    # a counting allocator + no concatenation allowed: the replication must not hold more than the store it returns
+    # (padded per-rank buffers + a list of `world` copies + torch.cat were >= 3x the store)
+    allocated = []
+
+    def counting_alloc(*shape, **kw):
+        t = torch.empty(*shape, **kw)
+        allocated.append(t.numel() * t.element_size())
+        return t
+
+    def no_cat(*a, **k):
+        raise AssertionError("replicate_rows must not concatenate per-rank copies")
+    real_cat, shard.torch.cat = shard.torch.cat, no_cat
+    try:
+        row_off, ids, data = shard.replicate_rows(sets.nsize, torch.from_numpy(ids), torch.from_numpy(data), alloc=counting_alloc)
+    finally:
+        shard.torch.cat = real_cat
+    store = sum(t.numel() * t.element_size() for t in (row_off, ids, data)) + (row_off.numel() - 1) * sets.nsize.element_size()
+    assert sum(allocated) == store, (sum(allocated), store)          # exactly the returned arrays (+ the gathered nsize): 1x
     np.savez(os.path.join(out_dir, f"spg{rank}.npz"), row_off=row_off.numpy(), ids=ids.numpy(), data=data.numpy())
     dist.barrier()
     dist.destroy_process_group()
