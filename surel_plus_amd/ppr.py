@@ -16,7 +16,7 @@ from .spg import SpG
 
 _MODES = {"row": 0, "sym": 1, "col": 2}
 SLAB_BUDGET = 8 << 30        # bytes of HBM given to the per-wavefront tables of one launch
-MAX_WAVES = int(__import__('os').environ.get('SUBGACC_PPR_WAVES', '4096'))   # resident single-wave workgroups; the kernel saturates the memory system from ~4096 on (SUBGACC_PPR_WAVES: dev override)
+MAX_WAVES = 4096             # resident single-wave workgroups; the kernel saturates the memory system from ~4096 on (a module constant: set ppr.MAX_WAVES to experiment)
 PILOT_ROOTS = 2048           # roots sampled to size the per-wavefront tables
 LAST_STATS = None            # counters of the last ppr_topk call (dev / profiling)
 

@@ -234,6 +234,7 @@ class SampledSets:
     keyrows: bool = False        # strided rows whose payload (`slot`) is the member's LP key: no table, no numbering
     key64: bool = False          # ... a 64-bit key (`slot` is int64: 4-hop walks with M >= 128), else 32 bits
     _table_form: object = None   # key64: the same batch sampled again with the table form, once number() / to_csr() needed it
+    _fresh: object = None        # sets of a buffered step: () -> do the step buffers still hold THIS batch? (spjoin._buffered_step)
     _keyctx: dict = None         # keyrows: what number() needs to register the rows' keys (csr, roots, cfg, rng positions, capacity, fresh())
     _ktable: torch.Tensor = None  # keyrows: the table of distinct LP rows once number() has built it (capacity _kcap)
     _kcap: int = 0
@@ -320,7 +321,8 @@ class SampledSets:
         self.resolve()
         if self.strided and self._members is None:
             # (root dedup: counted from the buffers' sizes on first use -- which by then may belong to a later batch)
-            if self._keyctx is not None and not self._keyctx["fresh"]():
+            fresh = self._fresh if self._fresh is not None else (self._keyctx["fresh"] if self._keyctx is not None else None)
+            if fresh is not None and not fresh():
                 raise _lib.SubgAccError("the member count of this batch was not asked for before its step buffers took a later "
                                         "batch (X / nnz must be read before the buffers are re-used or the captured step replayed)")
             self._members = int(self.nsize.sum().item())

@@ -375,9 +375,15 @@ def gather_many(edges, x, device=None, ptr=True, encode=None, out=None, lazy=Fal
     segment ids 0..2B-1 (ptr=False).  One small host read when the call is made (the total number of rows, to size xz) and one when
     the first batch is taken (BatchViews); lazy=True (needs out= for the worst case -- nb*2B * SpG.max_len * 2k float32 -- and
     ptr=True) makes the call itself free of host reads: the next group can be queued before this one is consumed.
-    `edges` may also be a list of [2, B_i] arrays: runs of equal B are fused, the rest (an epoch's short last batch) joined singly."""
+    `edges` may also be a list of [2, B_i] arrays: runs of equal B are fused, the rest (an epoch's short last batch) joined singly
+    -- eagerly: out= / lazy=True with a list raise ValueError."""
     spg = _as_spg(x)
     if isinstance(edges, (list, tuple)):
+        if out is not None or lazy:
+            # (a list is cut into runs of equal batch size, each its own join with its own row count: one caller's buffer cannot
+            #  be handed out before those counts are read, which is exactly the host read lazy=True promises not to make)
+            raise ValueError("gather_many: out= / lazy=True need the batches as one [nb, 2, B] array (a list of batches is joined "
+                             "run by run, eagerly); stack equal-sized batches, join a short last batch with gather()")
         res, i = [], 0
         while i < len(edges):
             j = i
@@ -658,6 +664,9 @@ def _buffered_step(csr, e, bufs, seed, out):
         sets._keyctx = {"csr": csr, "roots": bufs.roots, "cfg": cfg, "rng_pos": bufs.rng_pos if rr else None,
                         "rng_seed": bufs.rng_seed if rr else None, "capacity": bufs.capacity,
                         "fresh": lambda: getattr(bufs, "step_id", 0) == step_id}
+    # every set of a buffered step -- key rows or table form -- is a view of buffers that the NEXT step overwrites: what is computed
+    # from them on demand (the member count of a deduplicated step, X / nnz) is refused once they hold a later batch
+    sets._fresh = lambda: getattr(bufs, "step_id", 0) == step_id
     sets.status, sets._tail = bufs.status, bufs.tail[n: n + (6 if bufs.dedup else 5)]
     return xz, bufs.seg, sets
 

@@ -91,10 +91,12 @@ class CapturedStep:
         if self._dedup_bufs is not None:
             _dedup_tick(self._dedup_bufs)
         bufs = self._kw.get("buffers")
-        if bufs is not None and self.sets._keyctx is not None:
-            # the buffers take a new batch: what number() said about the previous one is void, and self.sets now stands for this one
+        if bufs is not None and (self.sets._keyctx is not None or self.sets._fresh is not None):
+            # the buffers take a new batch: what number() / X said about the previous one is void, and self.sets now stands for this one
             bufs.step_id = sid = getattr(bufs, "step_id", 0) + 1
-            self.sets._keyctx["fresh"] = lambda: getattr(bufs, "step_id", 0) == sid
+            self.sets._fresh = lambda: getattr(bufs, "step_id", 0) == sid
+            if self.sets._keyctx is not None:
+                self.sets._keyctx["fresh"] = self.sets._fresh
             self.sets.ukeys = self.sets._ktable = None
         self.graph.replay()
         if self._copy_in_graph:
@@ -226,10 +228,14 @@ class CapturedJoin:
             self._host.copy_(self._tail, non_blocking=True)
         self._event = torch.cuda.Event()
 
-    def __call__(self, edge):
-        """queue the join of `edge` [2, B] on the CURRENT stream (copy-in, replay and the completion event all go there)"""
+    def __call__(self, edge, stream=None):
+        """queue the join of `edge` [2, B]: copy-in, replay and the completion event all go to ONE stream -- `stream` if given
+        (the calling convention of CapturedStep.__call__ / CapturedStepPool.submit), else the current one"""
         if tuple(edge.shape) != (2, self.B):
             raise ValueError(f"this join was captured for [2, {self.B}] pairs")
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                return self(edge)
         if edge is not self.edge:
             self.edge.copy_(edge, non_blocking=True)
         self.graph.replay()

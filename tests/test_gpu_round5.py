@@ -70,3 +70,54 @@ def test_keyed_join_divides_every_count_like_main_py(sp, M):
     want = np.stack([(vals & 1).astype(np.float32), c1.astype(np.float32) / np.float32(M), c2.astype(np.float32) / np.float32(M)], axis=1)
     for half in (got[: vals.size], got[vals.size:]):              # (u, u): own row and partner row are the same member
         assert np.array_equal(half[:, 0, :], want) and np.array_equal(half[:, 1, :], want)
+
+
+@pytest.mark.parametrize("key_rows", [True, False])
+def test_stale_member_count_is_refused_for_table_rows_too(sp, key_rows):
+    """the freshness stamp of a buffered step's sets is not a privilege of key rows -- a root-dedup step over the
+    TABLE form of the rows (key_rows=False) counts its members lazily from the same buffers"""
+    N, M, hops, B = 4000, 200, 3, 256
+    ptr_, idx = sym_graph(N, 16000, seed=12)
+    csr = sp.DeviceCSR(ptr_, idx)
+    bufs = sp.StepBuffers(csr, B, num_walks=M, num_steps=hops, dedup_roots=True, key_rows=key_rows)
+    assert bufs.keyrows == key_rows
+    rs = np.random.default_rng(5)
+    e1 = torch.from_numpy(rs.integers(0, 50, (2, B))).cuda()
+    e2 = torch.from_numpy(rs.integers(0, N, (2, B))).cuda()
+    _, _, s1 = sp.sample_and_gather(csr, e1, num_walks=M, num_steps=hops, rng="philox", buffers=bufs, dedup_roots=True)
+    s1.resolve()
+    o = oracle.gset_sampler(ptr_, idx, np.unique(e1.cpu().numpy()), num_walks=M, num_steps=hops, rng="philox", nthreads=8)
+    assert s1.X == int(o[0].sum())
+    _, _, s2 = sp.sample_and_gather(csr, e1, num_walks=M, num_steps=hops, rng="philox", buffers=bufs, dedup_roots=True)
+    s2.resolve()
+    sp.sample_and_gather(csr, e2, num_walks=M, num_steps=hops, rng="philox", buffers=bufs, dedup_roots=True)[2].resolve()
+    with pytest.raises(sp.SubgAccError, match="later batch"):
+        s2.X
+
+
+def test_gather_many_refuses_what_it_cannot_honour_and_captured_join_takes_a_stream(sp):
+    """a LIST of batches with out= / lazy=True used to ignore both silently; CapturedJoin.__call__ lost its
+    stream= keyword (CapturedStep / CapturedStepPool.submit have it)"""
+    from test_gpu_round4 import _store
+    N = 3000
+    csr, z, enc, o_spg, _ = _store(sp, N=N, M=40)
+    table = torch.from_numpy(enc.astype(np.float32) / np.float32(40)).cuda()          # Z_SF as main.py:174 makes it
+    rs = np.random.default_rng(2)
+    batches = [torch.from_numpy(rs.integers(0, N, (2, 64))).cuda() for _ in range(3)]
+    ref = [sp.gather(b, z, "cuda", ptr=True, encode=table) for b in batches]
+    got = sp.gather_many(batches, z, "cuda", ptr=True, encode=table)
+    assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(got, ref))
+    buf = torch.empty(3 * 128 * z.max_len * 2 * table.shape[1], dtype=torch.float32, device="cuda")
+    with pytest.raises(ValueError, match="one \\[nb, 2, B\\] array"):
+        sp.gather_many(batches, z, "cuda", ptr=True, encode=table, out=buf, lazy=True)
+    with pytest.raises(ValueError):
+        sp.gather_many(batches, z, "cuda", ptr=True, encode=table, lazy=True)
+    lazy = sp.gather_many(torch.stack(batches), z, "cuda", ptr=True, encode=table, out=buf, lazy=True)      # the array form honours both
+    assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(lazy, ref))
+    cj = sp.CapturedJoin(z, 64, encode=table)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    xz, ind = cj(batches[1], stream=side).finish()
+    assert torch.equal(xz, ref[1][0]) and torch.equal(ind, ref[1][1])
+    xz, ind = cj(batches[2]).finish()                                  # and without: the current stream, as before
+    assert torch.equal(xz, ref[2][0]) and torch.equal(ind, ref[2][1])

@@ -58,8 +58,8 @@ def main():
                 p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", w, "--steps", steps, "--warmup", "2",
                                     "--no-cpu-baseline", "--no-others"] + extra, env=env, capture_output=True, text=True)
                 try:
-                    d = json.loads(p.stdout.strip().splitlines()[-1])
-                    st = {k: round(x, 4) for k, x in (d["config"].get("stage_ms") or {}).items() if x}
+                    d = json.loads(p.stdout.strip().splitlines()[-1])       # the compact line: the two kernels' HIP-event times are in `roofline`
+                    st = {"walk_sets": round(d["roofline"]["kernel_ms"], 4), "sjoin_fill": round(d["roofline"].get("join_kernel_ms") or 0.0, 4)}
                     print(f"[{name}] {w}: step {d['ms_per_step']:.4f} ms  {d['value'] / 1e6:.2f} M pairs/s  {st}", flush=True)
                 except Exception:
                     print(f"[{name}] {w}: FAILED rc={p.returncode} {p.stderr[-400:]}", flush=True)

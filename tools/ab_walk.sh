@@ -16,7 +16,7 @@ for V in "" "${VS[@]}"; do
   for W in ${WLS:-cit2 collab}; do
     for rep in 1 2; do
     echo -n "[$V] $W: "
-    python $GRAFT_REPO_ROOT/bench.py --workload $W --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('walk', round(d['config']['stage_ms']['walk_sets'],4), 'step', round(d['ms_per_step'],3))"
+    python $GRAFT_REPO_ROOT/bench.py --workload $W --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('walk', round(d['roofline']['kernel_ms'],4), 'step', round(d['ms_per_step'],3))"
     done
   done
 done

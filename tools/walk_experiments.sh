@@ -11,6 +11,6 @@ for E in ${EXPS:-0 1 2}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $(ls build/*.o | grep -v -x -F -e build/walk.o) /tmp/walk_e$E.o -o $SUBGACC_LIB
   for W in ${WLS:-collab cit2}; do
     echo -n "EXPERIMENT=$E $W: "
-    python $GRAFT_REPO_ROOT/bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['config']['stage_ms']['walk_sets'])"
+    python $GRAFT_REPO_ROOT/bench.py --workload $W --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['roofline']['kernel_ms'])"
   done
 done
