@@ -472,7 +472,7 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W, extr
                        "spg_members": z.nnz, "offline_ppr_stage_s": prep_s,
                        "join_call_ms_three_launches": call_ms,
                        "frac_of_hbm_peak_whole_join_call": (abytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if call_ms else None},
-            "roofline": {"bound": "hbm", "kernel": "sjoin_pair_kernel<f64, one wave per pair>",
+            "roofline": {"bound": "hbm", "kernel": "sjoin_f64pair_kernel<64> (one wave per pair)",
                          "achieved": abytes / (ms * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms": ms, "kernel_ms_source": ms_source,
@@ -740,7 +740,7 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
                      "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                      "kernel_ms": walk_ms, "launches_timed": launches, "algorithmic_bytes_per_launch": abytes,
-                     # the step's second kernel (sjoin_pair_kernel), same contract: algorithmic bytes / its own HIP-event time
+                     # the step's second kernel (sjoin_keypair_kernel), same contract: algorithmic bytes / its own HIP-event time
                      "join_kernel_ms": join_ms, "join_algorithmic_bytes_per_launch": join_abytes,
                      "join_achieved": (join_abytes / (join_ms * 1e-3) / 1e9) if (join_ms and join_abytes) else None,
                      "join_frac": (join_abytes / (join_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (join_ms and join_abytes) else None,
@@ -1325,7 +1325,7 @@ TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "dtype", "data")
 CONFIG_KEYS = ("workload", "pairs_per_step_per_gpu", "roots_per_step_per_gpu", "pairs_per_step_all_gpus", "ranks_seen",
                "distinct_devices", "dist_backend", "rccl_version", "rng", "num_walks", "num_steps_cli", "parallelism",
-               "per_rank_ms_min", "per_rank_ms_max", "headline_median_of_3_x100", "join_frac",
+               "per_rank_ms_min", "per_rank_ms_max", "headline_median_of_3_x100", "join_frac", "fused_spg_rows",
                # BASELINE.json's other configurations (medians of 3 x 100 steps) and the bit-exact rand_r stream on the headline one
                "rand_r_pairs_per_s", "rand_r_frac", "cit2m4_pairs_per_s", "cit2m4_frac", "cit2m4_join_frac",
                "collab_pairs_per_s", "collab_frac", "collab_join_frac", "ppa_pairs_per_s", "ppa_frac", "ppa_join_frac",

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SUBGACC_ABI_VERSION 5
+#define SUBGACC_ABI_VERSION 6
 
 typedef enum subgacc_status {
     SUBGACC_OK = 0,
@@ -396,6 +396,55 @@ int subgacc_sjoin_fill_keys(const int64_t *spg_indptr, int64_t n_rows, const int
                             const int64_t *own, const int64_t *partner, int64_t S, const int64_t *seg, int32_t num_walks,
                             int32_t num_steps, float *out_xz, int64_t *out_segid, int32_t max_len, int64_t pair_block,
                             int32_t *flags, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ABI 6 -- ONE entry point for every form of the join (train.py:13-111).  The five fills and the count / pair forms above
+ * differ in what the store looks like, what a member's payload is and which outputs are wanted; the descriptor states exactly
+ * that, field by field, and subgacc_sjoin_fill_v2 dispatches.  The older entry points stay exported and forward to it (a
+ * client built against ABI 1-5 keeps working); new clients need this one only.  Sizes / segment pointers come from
+ * subgacc_sjoin_sizes (packed rows) or subgacc_sjoin_sizes_rows (strided rows), as before.
+ *
+ *   store      row_off [n_rows+1] (packed rows, the SpG of random_walks.py:79) XOR row_len [n_rows] + row_stride (strided rows, the
+ *              form the walk kernels leave a transient batch in); ids: member ids, ascending inside a row; max_len >= the longest
+ *              row touched (packed rows; strided rows: row_stride is the bound)
+ *   payload    SUBGACC_JOIN_SFPTR  int32: SFptr+1 (packed rows) or a slot of `uniq_table` (strided rows; uniq_table = NULL: the
+ *                                  table is indexed by slot+1 itself); feature rows are gathered from table f32 [table_rows, k]
+ *              SUBGACC_JOIN_F64    double: the PPR encoder's score (train.py:39-43); xz is [R,2,1]
+ *              SUBGACC_JOIN_KEY32  int32 LP key (subg_acc.c:900-955): a feature row is the key's unpacked counts / num_walks
+ *              SUBGACC_JOIN_KEY64  uint64 LP key (strided rows of subgacc_walk_keyrows64)
+ *   segments   own / partner [S] (partner may be NULL for a mirrored list), seg [S+1], pair_block as for subgacc_sjoin_fill
+ *   form       SUBGACC_JOIN_ROWS   out_xz f32 [R,2,k] and / or out_idx i32 [R,2] (SFPTR only), out_segid i64 [R] (optional)
+ *              SUBGACC_JOIN_COUNTS out_counts f32 [S, table_rows]   (subgacc_sjoin_counts)
+ *              SUBGACC_JOIN_PAIRS  out_pairs i32 [R,2], out_mult i32 [R], out_cnt i32 [S]   (subgacc_sjoin_pairs)
+ *   struct_bytes = sizeof(subgacc_join_desc): a descriptor of another size is refused (SUBGACC_ERR_BADARG), fields a form does
+ *   not read must be zero / NULL.
+ * ------------------------------------------------------------------------------------------- */
+enum { SUBGACC_JOIN_SFPTR = 0, SUBGACC_JOIN_F64 = 1, SUBGACC_JOIN_KEY32 = 2, SUBGACC_JOIN_KEY64 = 3 };
+enum { SUBGACC_JOIN_ROWS = 0, SUBGACC_JOIN_COUNTS = 1, SUBGACC_JOIN_PAIRS = 2 };
+typedef struct subgacc_join_desc {
+    int32_t struct_bytes, form, payload_kind, max_len;
+    const int64_t *row_off;
+    const int32_t *row_len;
+    int64_t row_stride, n_rows;
+    const int32_t *ids;
+    const void *payload;
+    const void *uniq_table;
+    int64_t uniq_capacity;
+    const int64_t *own, *partner;
+    int64_t S;
+    const int64_t *seg;
+    int64_t pair_block;
+    const float *table;
+    int64_t table_rows;
+    int32_t k, num_walks, num_steps, reserved;
+    float *out_xz;
+    int32_t *out_idx;
+    int64_t *out_segid;
+    float *out_counts;
+    int32_t *out_pairs, *out_mult, *out_cnt;
+    int32_t *flags;
+} subgacc_join_desc;
+int subgacc_sjoin_fill_v2(const subgacc_join_desc *d, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Prologue of one on-demand step (sample both endpoints of B query pairs -> rows -> SpJoin; train.py:120-127 calls the

@@ -34,6 +34,7 @@ SYMBOLS = (
     "subgacc_hop_records_format", "subgacc_hop_records_build", "subgacc_sjoin_fill_keyrows", "subgacc_sjoin_fill_keys", "subgacc_step_dedup_workspace_bytes",
     "subgacc_step_prologue_dedup", "subgacc_walk_spg_sparse",
     "subgacc_keyrows_register", "subgacc_keyrows_cand_capacity", "subgacc_walk_tags", "subgacc_keyrows_compact", "subgacc_keyrows_translate", "subgacc_rng_replay", "subgacc_walk_keyrows64", "subgacc_sjoin_fill_keyrows64", "subgacc_worklist_workspace_bytes", "subgacc_worklist_by_root", "subgacc_walk_spg_list",
+    "subgacc_sjoin_fill_v2",
 )
 
 
@@ -44,6 +45,22 @@ class WalkCfg(C.Structure):
                 ("cap_root_degree", C.c_int32), ("indptr64", C.c_int32), ("emit_walks", C.c_int32),
                 ("hop_records", C.c_void_p), ("rec_id_bits", C.c_int32), ("rec_beg_bits", C.c_int32),
                 ("walk_pos", C.c_void_p)]
+
+
+class JoinDesc(C.Structure):
+    """struct subgacc_join_desc (include/subgacc.h, ABI 6): what one call of subgacc_sjoin_fill_v2 joins"""
+    _fields_ = [("struct_bytes", C.c_int32), ("form", C.c_int32), ("payload_kind", C.c_int32), ("max_len", C.c_int32),
+                ("row_off", C.c_void_p), ("row_len", C.c_void_p), ("row_stride", C.c_int64), ("n_rows", C.c_int64),
+                ("ids", C.c_void_p), ("payload", C.c_void_p), ("uniq_table", C.c_void_p), ("uniq_capacity", C.c_int64),
+                ("own", C.c_void_p), ("partner", C.c_void_p), ("S", C.c_int64), ("seg", C.c_void_p), ("pair_block", C.c_int64),
+                ("table", C.c_void_p), ("table_rows", C.c_int64), ("k", C.c_int32), ("num_walks", C.c_int32),
+                ("num_steps", C.c_int32), ("reserved", C.c_int32), ("out_xz", C.c_void_p), ("out_idx", C.c_void_p),
+                ("out_segid", C.c_void_p), ("out_counts", C.c_void_p), ("out_pairs", C.c_void_p), ("out_mult", C.c_void_p),
+                ("out_cnt", C.c_void_p), ("flags", C.c_void_p)]
+
+
+JOIN_SFPTR, JOIN_F64, JOIN_KEY32, JOIN_KEY64 = 0, 1, 2, 3      # payload_kind
+JOIN_ROWS, JOIN_COUNTS, JOIN_PAIRS = 0, 1, 2                   # form
 
 
 class SubgAccError(RuntimeError):
@@ -137,12 +154,13 @@ def lib():
     sig["subgacc_worklist_workspace_bytes"] = (sz, [i64])
     sig["subgacc_worklist_by_root"] = (C.c_int, [vp, i64, i64, vp, vp, vp, sz, vp])
     sig["subgacc_walk_spg_list"] = (C.c_int, [cfgp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp])
+    sig["subgacc_sjoin_fill_v2"] = (C.c_int, [C.POINTER(JoinDesc), vp])
     assert set(sig) == set(SYMBOLS)
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    if L.subgacc_abi_version() != 5:
+    if L.subgacc_abi_version() != 6:
         raise SubgAccError("libsubgacc_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -176,6 +194,18 @@ def require_device():
 def stream_ptr():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def join_fill(form=JOIN_ROWS, payload_kind=JOIN_SFPTR, **fields):
+    """One join through subgacc_sjoin_fill_v2 on the current stream: `fields` are the members of subgacc_join_desc by name --
+    torch tensors for the pointers (None = NULL), ints for the rest; what a form does not read stays zero."""
+    d = JoinDesc()
+    d.struct_bytes, d.form, d.payload_kind = C.sizeof(JoinDesc), int(form), int(payload_kind)
+    for name, val in fields.items():
+        if val is None:
+            continue
+        setattr(d, name, val.data_ptr() if hasattr(val, "data_ptr") else int(val))
+    return check(lib().subgacc_sjoin_fill_v2(C.byref(d), stream_ptr()))
 
 
 def ptr(t):

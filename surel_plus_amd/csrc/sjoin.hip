@@ -1221,7 +1221,7 @@ extern "C" int subgacc_sjoin_sizes_rows(const int32_t *row_len, int64_t n_rows, 
     return join_sizes(nullptr, row_len, n_rows, own, partner, S, out_seg, flags, workspace, workspace_bytes, stream);
 }
 
-extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,
+static int sjoin_fill_impl(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,
                                   const int32_t *spg_data_i32, const double *spg_data_f64, const int64_t *own, const int64_t *partner, int64_t S,
                                   const int64_t *seg, const float *table, int64_t table_rows, int32_t k,
                                   float *out_xz, int32_t *out_idx, int64_t *out_segid, int32_t max_len,
@@ -1317,7 +1317,7 @@ extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, int64_t n_rows, con
     return SUBGACC_OK;
 }
 
-extern "C" int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
+static int sjoin_fill_rows_impl(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
                                        const int32_t *row_slot, const void *uniq_table, int64_t uniq_capacity,
                                        const int64_t *own, const int64_t *partner, int64_t S, const int64_t *seg,
                                        const float *table, int64_t table_rows, int32_t k, float *out_xz,
@@ -1413,7 +1413,7 @@ static int launch_key_join(JoinArgs &a, int32_t num_walks, int32_t num_steps, in
     return SUBGACC_OK;
 }
 
-extern "C" int subgacc_sjoin_fill_keyrows(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
+static int sjoin_fill_keyrows_impl(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
                                           const int32_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
                                           const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz,
                                           int64_t pair_block, int32_t *flags, void *stream) {
@@ -1434,7 +1434,7 @@ extern "C" int subgacc_sjoin_fill_keyrows(const int32_t *row_len, int64_t n_rows
     return launch_key_join(a, num_walks, num_steps, S, pair_block, stream, "sjoin_fill_keyrows");
 }
 
-extern "C" int subgacc_sjoin_fill_keyrows64(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
+static int sjoin_fill_keyrows64_impl(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
                                             const uint64_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
                                             const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz,
                                             int64_t pair_block, int32_t *flags, void *stream) {
@@ -1455,7 +1455,7 @@ extern "C" int subgacc_sjoin_fill_keyrows64(const int32_t *row_len, int64_t n_ro
     return launch_key_join(a, num_walks, num_steps, S, pair_block, stream, "sjoin_fill_keyrows64", true);
 }
 
-extern "C" int subgacc_sjoin_fill_keys(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,
+static int sjoin_fill_keys_impl(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,
                                        const int32_t *spg_keys, const int64_t *own, const int64_t *partner, int64_t S,
                                        const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz,
                                        int64_t *out_segid, int32_t max_len, int64_t pair_block, int32_t *flags, void *stream) {
@@ -1475,7 +1475,7 @@ extern "C" int subgacc_sjoin_fill_keys(const int64_t *spg_indptr, int64_t n_rows
     return launch_key_join(a, num_walks, num_steps, S, pair_block, stream, "sjoin_fill_keys");
 }
 
-extern "C" int subgacc_sjoin_counts(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,
+static int sjoin_counts_impl(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,
                                     const int32_t *spg_data_i32, const int64_t *own, const int64_t *partner, int64_t S, int64_t table_rows,
                                     float *out_counts, int32_t max_len, int64_t pair_block, int32_t *flags,
                                     void *stream) {
@@ -1510,7 +1510,7 @@ extern "C" int subgacc_sjoin_counts(const int64_t *spg_indptr, int64_t n_rows, c
     return SUBGACC_OK;
 }
 
-extern "C" int subgacc_sjoin_pairs(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,
+static int sjoin_pairs_impl(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,
                                    const int32_t *spg_data_i32, const int64_t *own, const int64_t *partner, int64_t S,
                                    const int64_t *seg, int32_t *out_pairs, int32_t *out_mult, int32_t *out_cnt,
                                    int32_t max_len, int64_t pair_block, int32_t *flags, void *stream) {
@@ -1546,3 +1546,161 @@ extern "C" int subgacc_sjoin_pairs(const int64_t *spg_indptr, int64_t n_rows, co
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// ABI 6: ONE entry point for every form of the join.  A descriptor says what the store looks like (packed or strided rows, which
+// payload), which segments to join, what the feature rows are made from and which outputs are wanted; the seven entry points of
+// ABI 1-5 (subgacc_sjoin_fill, _fill_rows, _fill_keyrows, _fill_keyrows64, _fill_keys, _counts, _pairs) remain as forwards that fill
+// one in.  The launchers above are what it dispatches to.
+extern "C" int subgacc_sjoin_fill_v2(const subgacc_join_desc *d, void *stream) {
+    SG_REQUIRE(d, SUBGACC_ERR_BADARG, "sjoin_fill_v2: null descriptor");
+    SG_REQUIRE(d->struct_bytes == (int32_t)sizeof(subgacc_join_desc), SUBGACC_ERR_BADARG,
+               "sjoin_fill_v2: descriptor of %d bytes, this library's is %d (set struct_bytes = sizeof(subgacc_join_desc))",
+               (int)d->struct_bytes, (int)sizeof(subgacc_join_desc));
+    SG_REQUIRE((d->row_off != nullptr) != (d->row_len != nullptr), SUBGACC_ERR_BADARG,
+               "sjoin_fill_v2: exactly one of row_off (packed rows) / row_len (strided rows)");
+    const bool strided = d->row_len != nullptr;
+    if (d->form == SUBGACC_JOIN_COUNTS) {
+        SG_REQUIRE(!strided && d->payload_kind == SUBGACC_JOIN_SFPTR, SUBGACC_ERR_BADARG, "sjoin_fill_v2: the count form joins a packed SFptr store");
+        return sjoin_counts_impl(d->row_off, d->n_rows, d->ids, (const int32_t *)d->payload, d->own, d->partner, d->S, d->table_rows,
+                                 d->out_counts, d->max_len, d->pair_block, d->flags, stream);
+    }
+    if (d->form == SUBGACC_JOIN_PAIRS) {
+        SG_REQUIRE(!strided && d->payload_kind == SUBGACC_JOIN_SFPTR, SUBGACC_ERR_BADARG, "sjoin_fill_v2: the pair form joins a packed SFptr store");
+        return sjoin_pairs_impl(d->row_off, d->n_rows, d->ids, (const int32_t *)d->payload, d->own, d->partner, d->S, d->seg, d->out_pairs,
+                                d->out_mult, d->out_cnt, d->max_len, d->pair_block, d->flags, stream);
+    }
+    SG_REQUIRE(d->form == SUBGACC_JOIN_ROWS, SUBGACC_ERR_BADARG, "sjoin_fill_v2: unknown form %d", (int)d->form);
+    switch (d->payload_kind) {
+    case SUBGACC_JOIN_SFPTR:
+        if (strided)
+            return sjoin_fill_rows_impl(d->row_len, d->n_rows, d->row_stride, d->ids, (const int32_t *)d->payload, d->uniq_table,
+                                        d->uniq_capacity, d->own, d->partner, d->S, d->seg, d->table, d->table_rows, d->k, d->out_xz,
+                                        d->out_idx, d->out_segid, d->pair_block, d->flags, stream);
+        return sjoin_fill_impl(d->row_off, d->n_rows, d->ids, (const int32_t *)d->payload, nullptr, d->own, d->partner, d->S, d->seg,
+                               d->table, d->table_rows, d->k, d->out_xz, d->out_idx, d->out_segid, d->max_len, d->pair_block, d->flags,
+                               stream);
+    case SUBGACC_JOIN_F64:
+        SG_REQUIRE(!strided, SUBGACC_ERR_BADARG, "sjoin_fill_v2: a float payload lives in a packed store");
+        return sjoin_fill_impl(d->row_off, d->n_rows, d->ids, nullptr, (const double *)d->payload, d->own, d->partner, d->S, d->seg,
+                               nullptr, 0, 1, d->out_xz, nullptr, d->out_segid, d->max_len, d->pair_block, d->flags, stream);
+    case SUBGACC_JOIN_KEY32:
+        if (strided) {
+            SG_REQUIRE(!d->out_segid, SUBGACC_ERR_BADARG, "sjoin_fill_v2: strided key rows are joined with segment pointers");
+            return sjoin_fill_keyrows_impl(d->row_len, d->n_rows, d->row_stride, d->ids, (const int32_t *)d->payload, d->own, d->partner,
+                                           d->S, d->seg, d->num_walks, d->num_steps, d->out_xz, d->pair_block, d->flags, stream);
+        }
+        return sjoin_fill_keys_impl(d->row_off, d->n_rows, d->ids, (const int32_t *)d->payload, d->own, d->partner, d->S, d->seg,
+                                    d->num_walks, d->num_steps, d->out_xz, d->out_segid, d->max_len, d->pair_block, d->flags, stream);
+    case SUBGACC_JOIN_KEY64:
+        SG_REQUIRE(strided && !d->out_segid, SUBGACC_ERR_BADARG, "sjoin_fill_v2: 64-bit keys are the payload of strided rows (subgacc_walk_keyrows64)");
+        return sjoin_fill_keyrows64_impl(d->row_len, d->n_rows, d->row_stride, d->ids, (const uint64_t *)d->payload, d->own, d->partner,
+                                         d->S, d->seg, d->num_walks, d->num_steps, d->out_xz, d->pair_block, d->flags, stream);
+    default:
+        SG_REQUIRE(false, SUBGACC_ERR_BADARG, "sjoin_fill_v2: unknown payload kind %d", (int)d->payload_kind);
+    }
+    return SUBGACC_ERR_BADARG;
+}
+
+// ---- the entry points of ABI 1-5: forwards
+static subgacc_join_desc join_desc(int form, int kind) {
+    subgacc_join_desc d = {};
+    d.struct_bytes = (int32_t)sizeof(subgacc_join_desc), d.form = form, d.payload_kind = kind;
+    return d;
+}
+#define SG_DESC_SEGMENTS(d) (d).own = own, (d).partner = partner, (d).S = S, (d).pair_block = pair_block, (d).flags = flags
+
+extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices, const int32_t *spg_data_i32,
+                                  const double *spg_data_f64, const int64_t *own, const int64_t *partner, int64_t S, const int64_t *seg,
+                                  const float *table, int64_t table_rows, int32_t k, float *out_xz, int32_t *out_idx, int64_t *out_segid,
+                                  int32_t max_len, int64_t pair_block, int32_t *flags, void *stream) {
+    if ((spg_data_i32 != nullptr) == (spg_data_f64 != nullptr) || (spg_data_f64 && (out_idx || table)) || !spg_indptr)      // (their own messages)
+        return sjoin_fill_impl(spg_indptr, n_rows, spg_indices, spg_data_i32, spg_data_f64, own, partner, S, seg, table, table_rows, k,
+                               out_xz, out_idx, out_segid, max_len, pair_block, flags, stream);
+    subgacc_join_desc d = join_desc(SUBGACC_JOIN_ROWS, spg_data_f64 ? SUBGACC_JOIN_F64 : SUBGACC_JOIN_SFPTR);
+    d.row_off = spg_indptr, d.n_rows = n_rows, d.ids = spg_indices, d.max_len = max_len;
+    d.payload = spg_data_f64 ? (const void *)spg_data_f64 : (const void *)spg_data_i32;
+    SG_DESC_SEGMENTS(d), d.seg = seg, d.table = table, d.table_rows = table_rows, d.k = k;
+    d.out_xz = out_xz, d.out_idx = out_idx, d.out_segid = out_segid;
+    return subgacc_sjoin_fill_v2(&d, stream);
+}
+
+extern "C" int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
+                                       const int32_t *row_slot, const void *uniq_table, int64_t uniq_capacity, const int64_t *own,
+                                       const int64_t *partner, int64_t S, const int64_t *seg, const float *table, int64_t table_rows,
+                                       int32_t k, float *out_xz, int32_t *out_idx, int64_t *out_segid, int64_t pair_block,
+                                       int32_t *flags, void *stream) {
+    if (!row_len)
+        return sjoin_fill_rows_impl(row_len, n_rows, row_stride, row_ids, row_slot, uniq_table, uniq_capacity, own, partner, S, seg, table,
+                                    table_rows, k, out_xz, out_idx, out_segid, pair_block, flags, stream);
+    subgacc_join_desc d = join_desc(SUBGACC_JOIN_ROWS, SUBGACC_JOIN_SFPTR);
+    d.row_len = row_len, d.n_rows = n_rows, d.row_stride = row_stride, d.ids = row_ids, d.payload = row_slot;
+    d.uniq_table = uniq_table, d.uniq_capacity = uniq_capacity;
+    SG_DESC_SEGMENTS(d), d.seg = seg, d.table = table, d.table_rows = table_rows, d.k = k;
+    d.out_xz = out_xz, d.out_idx = out_idx, d.out_segid = out_segid;
+    return subgacc_sjoin_fill_v2(&d, stream);
+}
+
+extern "C" int subgacc_sjoin_fill_keyrows(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
+                                          const int32_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
+                                          const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz,
+                                          int64_t pair_block, int32_t *flags, void *stream) {
+    if (!row_len)
+        return sjoin_fill_keyrows_impl(row_len, n_rows, row_stride, row_ids, row_keys, own, partner, S, seg, num_walks, num_steps, out_xz,
+                                       pair_block, flags, stream);
+    subgacc_join_desc d = join_desc(SUBGACC_JOIN_ROWS, SUBGACC_JOIN_KEY32);
+    d.row_len = row_len, d.n_rows = n_rows, d.row_stride = row_stride, d.ids = row_ids, d.payload = row_keys;
+    SG_DESC_SEGMENTS(d), d.seg = seg, d.num_walks = num_walks, d.num_steps = num_steps, d.out_xz = out_xz;
+    return subgacc_sjoin_fill_v2(&d, stream);
+}
+
+extern "C" int subgacc_sjoin_fill_keyrows64(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
+                                            const uint64_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
+                                            const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz,
+                                            int64_t pair_block, int32_t *flags, void *stream) {
+    if (!row_len)
+        return sjoin_fill_keyrows64_impl(row_len, n_rows, row_stride, row_ids, row_keys, own, partner, S, seg, num_walks, num_steps,
+                                         out_xz, pair_block, flags, stream);
+    subgacc_join_desc d = join_desc(SUBGACC_JOIN_ROWS, SUBGACC_JOIN_KEY64);
+    d.row_len = row_len, d.n_rows = n_rows, d.row_stride = row_stride, d.ids = row_ids, d.payload = row_keys;
+    SG_DESC_SEGMENTS(d), d.seg = seg, d.num_walks = num_walks, d.num_steps = num_steps, d.out_xz = out_xz;
+    return subgacc_sjoin_fill_v2(&d, stream);
+}
+
+extern "C" int subgacc_sjoin_fill_keys(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices, const int32_t *spg_keys,
+                                       const int64_t *own, const int64_t *partner, int64_t S, const int64_t *seg, int32_t num_walks,
+                                       int32_t num_steps, float *out_xz, int64_t *out_segid, int32_t max_len, int64_t pair_block,
+                                       int32_t *flags, void *stream) {
+    if (!spg_indptr)
+        return sjoin_fill_keys_impl(spg_indptr, n_rows, spg_indices, spg_keys, own, partner, S, seg, num_walks, num_steps, out_xz, out_segid,
+                                    max_len, pair_block, flags, stream);
+    subgacc_join_desc d = join_desc(SUBGACC_JOIN_ROWS, SUBGACC_JOIN_KEY32);
+    d.row_off = spg_indptr, d.n_rows = n_rows, d.ids = spg_indices, d.payload = spg_keys, d.max_len = max_len;
+    SG_DESC_SEGMENTS(d), d.seg = seg, d.num_walks = num_walks, d.num_steps = num_steps, d.out_xz = out_xz, d.out_segid = out_segid;
+    return subgacc_sjoin_fill_v2(&d, stream);
+}
+
+extern "C" int subgacc_sjoin_counts(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices, const int32_t *spg_data_i32,
+                                    const int64_t *own, const int64_t *partner, int64_t S, int64_t table_rows, float *out_counts,
+                                    int32_t max_len, int64_t pair_block, int32_t *flags, void *stream) {
+    if (!spg_indptr)
+        return sjoin_counts_impl(spg_indptr, n_rows, spg_indices, spg_data_i32, own, partner, S, table_rows, out_counts, max_len, pair_block,
+                                 flags, stream);
+    subgacc_join_desc d = join_desc(SUBGACC_JOIN_COUNTS, SUBGACC_JOIN_SFPTR);
+    d.row_off = spg_indptr, d.n_rows = n_rows, d.ids = spg_indices, d.payload = spg_data_i32, d.max_len = max_len;
+    SG_DESC_SEGMENTS(d), d.table_rows = table_rows, d.out_counts = out_counts;
+    return subgacc_sjoin_fill_v2(&d, stream);
+}
+
+extern "C" int subgacc_sjoin_pairs(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices, const int32_t *spg_data_i32,
+                                   const int64_t *own, const int64_t *partner, int64_t S, const int64_t *seg, int32_t *out_pairs,
+                                   int32_t *out_mult, int32_t *out_cnt, int32_t max_len, int64_t pair_block, int32_t *flags, void *stream) {
+    if (!spg_indptr)
+        return sjoin_pairs_impl(spg_indptr, n_rows, spg_indices, spg_data_i32, own, partner, S, seg, out_pairs, out_mult, out_cnt, max_len,
+                                pair_block, flags, stream);
+    subgacc_join_desc d = join_desc(SUBGACC_JOIN_PAIRS, SUBGACC_JOIN_SFPTR);
+    d.row_off = spg_indptr, d.n_rows = n_rows, d.ids = spg_indices, d.payload = spg_data_i32, d.max_len = max_len;
+    SG_DESC_SEGMENTS(d), d.seg = seg, d.out_pairs = out_pairs, d.out_mult = out_mult, d.out_cnt = out_cnt;
+    return subgacc_sjoin_fill_v2(&d, stream);
+}
+#undef SG_DESC_SEGMENTS

@@ -11,6 +11,7 @@ sample -> SpG -> SpJoin step queues up asynchronously.
 """
 import ctypes
 import functools
+import types
 import os
 import threading
 from dataclasses import dataclass
@@ -611,268 +612,295 @@ def sample_sets(csr, query, num_walks=100, num_steps=3, bucket=-1, seed=111413, 
     (subgacc_walk_spg); without, the general walk kernel is followed by subgacc_finish_rows (the faster pair for short
     walks over a cache-resident graph, spg.prefers_fused).  number_rows=False (strided only): the distinct LP rows are not numbered either until somebody
     asks (SampledSets.number()); the join by table slot needs no numbering."""
-    L = lib()
-    dev = csr.device
-    q = _as_query(query, dev)
-    n = q.numel()
-    walk_replay = bool(walk_replay and rng == "rand_r")
-    records = bool(fused_rows) and bucket <= 0 and num_walks * num_steps + 1 <= FUSED_MAX_Q and 2 <= num_steps <= 4 and not walk_replay
-    cfg = make_cfg(csr, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order, cap_root_degree, emit_walks, records)
-    check(L.subgacc_key_shift(cfg.num_walks, cfg.num_steps))   # AssertionError like subg_acc.c:911-915
-    M, m = cfg.num_walks, cfg.num_steps
-    stride = bucket if bucket > 0 else M * m + 1
-    if fused_rows and (M * m + 1 > FUSED_MAX_Q or not dedup or emit_walks or not first_hop_wo
-                       or order != _lib.ORDER_WALK_MAJOR):
+    p = types.SimpleNamespace(**locals())
+    if not _plan_sets(p):              # shapes, kernel form, chunking, the rand_r stream positions, the table of distinct rows
         return None
-    st = stream_ptr()
-    status = torch.zeros(4, dtype=torch.int64, device=dev)     # [flags x4 (int32) | distinct rows | members]: one memset,
-    flags = status.view(torch.int32)[:4]                        # one read-back (unpack_status)
-    if keep_keys is None:
-        keep_keys = not dedup
-    if fused_rows:
-        keep_keys = False
-    limit = uniq_small_limit if uniq_small_limit > 0 else RANK_LIMIT
-    key_rows_arg = key_rows          # (what the caller asked for: a retry with a larger table asks for the same)
-    kform = key_rows_form(M, m) if (key_rows and strided and fused_rows and not number_rows and bucket <= 0 and not walk_replay) else 0
-    per_member = (12 if kform == 64 else 8) if fused_rows else 12
-    if staging_bytes is None:     # 288 GB of HBM: one chunk of roots wherever a third of the free memory holds its staging rows
-        staging_bytes = max(STAGING_BYTES, int(0.35 * torch.cuda.mem_get_info(dev)[0])) if n * stride * per_member > STAGING_BYTES \
-            else STAGING_BYTES
-    chunk = max(1, min(n, int(staging_bytes // (stride * per_member)), (1 << 31) - 16)) if n else 0
-    lazy = bool(lazy and dedup and n > 0 and chunk == n)
-    # strided rows come from the fused-row walk kernel, or (finish=True) from the general walk kernel + finish_rows
-    finish = bool(strided and not fused_rows and dedup and not emit_walks and order == _lib.ORDER_WALK_MAJOR
-                  and stride <= FINISH_MAX_STRIDE)
-    if strided and not ((fused_rows or finish) and n > 0 and chunk == n):
-        return None
+    res = _launch_sets(p)              # per chunk: walk -> sizes -> (finish rows | register | number) -> packed copy
+    return _finish_sets(p) if res is _PACKED else res       # packed forms: global row offsets, numbering of the distinct LP rows
 
-    walk_pos = None
-    if walk_replay and n and n * M >= REPLAY_WARN_WALKS:
+
+_PACKED = object()      # _launch_sets: the chunks were packed, _finish_sets takes over (the strided forms return their sets themselves)
+
+
+def _plan_sets(p):
+    """sample_sets, part 1: what will be launched.  Fills `p` (the call's arguments as attributes) with the kernel configuration,
+    the form of the rows (key rows / table slots / packed keys), the chunking of the roots, the rand_r stream positions and the
+    table of distinct LP rows; False when the requested form (fused / strided rows) does not apply to this shape."""
+    p.L = lib()
+    p.dev = p.csr.device
+    p.q = _as_query(p.query, p.dev)
+    p.n = p.q.numel()
+    p.walk_replay = bool(p.walk_replay and p.rng == "rand_r")
+    p.records = bool(p.fused_rows) and p.bucket <= 0 and p.num_walks * p.num_steps + 1 <= FUSED_MAX_Q and 2 <= p.num_steps <= 4 and not p.walk_replay
+    p.cfg = make_cfg(p.csr, p.num_walks, p.num_steps, p.bucket, p.seed, p.rng, p.first_hop_wo, p.order, p.cap_root_degree, p.emit_walks, p.records)
+    check(p.L.subgacc_key_shift(p.cfg.num_walks, p.cfg.num_steps))   # AssertionError like subg_acc.c:911-915
+    p.M, p.m = p.cfg.num_walks, p.cfg.num_steps
+    p.stride = p.bucket if p.bucket > 0 else p.M * p.m + 1
+    if p.fused_rows and (p.M * p.m + 1 > FUSED_MAX_Q or not p.dedup or p.emit_walks or not p.first_hop_wo
+                       or p.order != _lib.ORDER_WALK_MAJOR):
+        return False
+    p.st = stream_ptr()
+    p.status = torch.zeros(4, dtype=torch.int64, device=p.dev)     # [flags x4 (int32) | distinct rows | members]: one memset,
+    p.flags = p.status.view(torch.int32)[:4]                        # one read-back (unpack_status)
+    if p.keep_keys is None:
+        p.keep_keys = not p.dedup
+    if p.fused_rows:
+        p.keep_keys = False
+    p.limit = p.uniq_small_limit if p.uniq_small_limit > 0 else RANK_LIMIT
+    p.key_rows_arg = p.key_rows          # (what the caller asked for: a retry with a larger table asks for the same)
+    p.kform = key_rows_form(p.M, p.m) if (p.key_rows and p.strided and p.fused_rows and not p.number_rows and p.bucket <= 0 and not p.walk_replay) else 0
+    p.per_member = (12 if p.kform == 64 else 8) if p.fused_rows else 12
+    if p.staging_bytes is None:     # 288 GB of HBM: one chunk of roots wherever a third of the free memory holds its staging rows
+        p.staging_bytes = max(STAGING_BYTES, int(0.35 * torch.cuda.mem_get_info(p.dev)[0])) if p.n * p.stride * p.per_member > STAGING_BYTES \
+            else STAGING_BYTES
+    p.chunk = max(1, min(p.n, int(p.staging_bytes // (p.stride * p.per_member)), (1 << 31) - 16)) if p.n else 0
+    p.lazy = bool(p.lazy and p.dedup and p.n > 0 and p.chunk == p.n)
+    # strided rows come from the fused-row walk kernel, or (finish=True) from the general walk kernel + finish_rows
+    p.finish = bool(p.strided and not p.fused_rows and p.dedup and not p.emit_walks and p.order == _lib.ORDER_WALK_MAJOR
+                  and p.stride <= FINISH_MAX_STRIDE)
+    if p.strided and not ((p.fused_rows or p.finish) and p.n > 0 and p.chunk == p.n):
+        return False
+
+    p.walk_pos = None
+    if p.walk_replay and p.n and p.n * p.M >= REPLAY_WARN_WALKS:
         # csrc/replay.hip: ONE wavefront per rand_r stream replays its walks 64 at a time, m dependent loads per round (the stream
         # is sequential by definition, and set_sampler has a single stream): ~0.1 us per walk, i.e. tens of seconds from 10^8
         # walks on -- the price of bit-exactness with the reference on a graph it was not written for.  rng="philox" has no such cost.
         import warnings
-        warnings.warn(f"rng='rand_r' on a graph with dead ends: replaying the sequential stream of {n * M:,} walks on one "
-                      f"wavefront per stream (~{n * M * 1e-7:.0f} s); rng='philox' samples the same distribution in parallel",
-                      RuntimeWarning, stacklevel=3)
-    if walk_replay and n:      # the stream replayed: the position of every root and of every walk (subgacc_rng_replay)
-        rng_pos = torch.empty(n, dtype=torch.int32, device=dev)
-        rng_seed = torch.empty(n, dtype=torch.int32, device=dev)
-        walk_pos = torch.empty(n * M, dtype=torch.int32, device=dev)
-        check(L.subgacc_rng_replay(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q), n, int(rng_streams), int(calls_before),
-                                   ptr(rng_pos), ptr(rng_seed), ptr(walk_pos), st))
-    elif rng_state is not None and rng == "rand_r":
-        rng_pos, rng_seed = rng_state
+        warnings.warn(f"rng='rand_r' on a graph with dead ends: replaying the sequential stream of {p.n * p.M:,} p.walks on one "
+                      f"wavefront per stream (~{p.n * p.M * 1e-7:.0f} s); rng='philox' samples the same distribution in parallel",
+                      RuntimeWarning, stacklevel=4)      # (the caller of sample_sets: past _plan_sets, sample_sets and its wrapper)
+    if p.walk_replay and p.n:      # the stream replayed: the position of every root and of every walk (subgacc_rng_replay)
+        p.rng_pos = torch.empty(p.n, dtype=torch.int32, device=p.dev)
+        p.rng_seed = torch.empty(p.n, dtype=torch.int32, device=p.dev)
+        p.walk_pos = torch.empty(p.n * p.M, dtype=torch.int32, device=p.dev)
+        check(p.L.subgacc_rng_replay(p.cfg, ptr(p.csr.indptr), ptr(p.csr.indices), p.csr.num_nodes, ptr(p.q), p.n, int(p.rng_streams), int(p.calls_before),
+                                   ptr(p.rng_pos), ptr(p.rng_seed), ptr(p.walk_pos), p.st))
+    elif p.rng_state is not None and p.rng == "rand_r":
+        p.rng_pos, p.rng_seed = p.rng_state
     else:
-        rng_pos, rng_seed = _rng_positions(L, cfg, csr, q, n, rng_streams, calls_before, st)
+        p.rng_pos, p.rng_seed = _rng_positions(p.L, p.cfg, p.csr, p.q, p.n, p.rng_streams, p.calls_before, p.st)
     # key rows: strided fused rows that nobody asked to number carry LP keys instead of table slots (module header)
-    key_rows = bool(kform and n > 0 and chunk == n)
-    kform = kform if key_rows else 0
+    p.key_rows = bool(p.kform and p.n > 0 and p.chunk == p.n)
+    p.kform = p.kform if p.key_rows else 0
     # a store that is kept: key rows as well, registered by one pass over the rows (csrc/keyrows.hip, module header)
-    batched = bool(batched_registration and fused_rows and dedup and not strided and bucket <= 0 and n > 0 and key_rows_ok(M, m)
-                   and not walk_replay)
-    table = None
-    if dedup and not key_rows:
-        table = torch.empty(L.subgacc_uniq_table_bytes(uniq_capacity), dtype=torch.uint8, device=dev)
-        check(L.subgacc_uniq_reset(ptr(table), uniq_capacity, st))
+    p.batched = bool(p.batched_registration and p.fused_rows and p.dedup and not p.strided and p.bucket <= 0 and p.n > 0 and key_rows_ok(p.M, p.m)
+                   and not p.walk_replay)
+    p.table = None
+    if p.dedup and not p.key_rows:
+        p.table = torch.empty(p.L.subgacc_uniq_table_bytes(p.uniq_capacity), dtype=torch.uint8, device=p.dev)
+        check(p.L.subgacc_uniq_reset(ptr(p.table), p.uniq_capacity, p.st))
 
-    nsize = torch.empty(n, dtype=torch.int32, device=dev)
-    walks = torch.empty((n, M * (m + 1)), dtype=torch.int32, device=dev) if emit_walks else None
-    ids_parts, key_parts, slot_parts = [], [], []
-    off_chunk = None
-    if n:
-        st_ids = torch.empty(chunk * stride, dtype=torch.int32, device=dev)
-        st_aux = torch.empty(chunk * stride, dtype=torch.int32 if (fused_rows and kform != 64) else torch.int64, device=dev)
-        scan_ws = torch.empty(L.subgacc_scan_workspace_bytes(chunk), dtype=torch.uint8, device=dev)
-        off_chunk = torch.empty(chunk + 1, dtype=torch.int64, device=dev)
-    X = 0
-    for lo in range(0, n, chunk if chunk else 1):
-        cn = min(chunk, n - lo)
-        if walk_pos is not None:
-            cfg.walk_pos = walk_pos[lo * M:].data_ptr()
+    return True
+
+
+def _launch_sets(p):
+    """sample_sets, part 2: the launches, chunk by chunk -- work list (one chunk), walk kernel, row offsets, then per form: rows
+    finished in place, keys registered, distinct rows numbered, packed copy.  Strided forms end here (returns the sets, None when
+    the direct ranking cannot number them, or the retry with a larger table); packed forms return _PACKED."""
+    p.nsize = torch.empty(p.n, dtype=torch.int32, device=p.dev)
+    p.walks = torch.empty((p.n, p.M * (p.m + 1)), dtype=torch.int32, device=p.dev) if p.emit_walks else None
+    p.ids_parts, p.key_parts, p.slot_parts = [], [], []
+    p.off_chunk = None
+    if p.n:
+        p.st_ids = torch.empty(p.chunk * p.stride, dtype=torch.int32, device=p.dev)
+        p.st_aux = torch.empty(p.chunk * p.stride, dtype=torch.int32 if (p.fused_rows and p.kform != 64) else torch.int64, device=p.dev)
+        p.scan_ws = torch.empty(p.L.subgacc_scan_workspace_bytes(p.chunk), dtype=torch.uint8, device=p.dev)
+        p.off_chunk = torch.empty(p.chunk + 1, dtype=torch.int64, device=p.dev)
+    p.X = 0
+    for p.lo in range(0, p.n, p.chunk if p.chunk else 1):
+        p.cn = min(p.chunk, p.n - p.lo)
+        if p.walk_pos is not None:
+            p.cfg.walk_pos = p.walk_pos[p.lo * p.M:].data_ptr()
         # a BATCH sampled in one chunk walks its rows in ascending order of root id, like the buffered step (csrc/worklist.hip:
         # repeated and neighbouring roots share their lines in L2; the rows stay where they are).  Beyond a million roots the call
         # is the offline stage over a whole graph, whose nodes come in order already (listing them again cost it 1.5 %).
-        by_root = (fused_rows and chunk == n and SORT_ROOTS_MIN <= cn <= SORT_ROOTS_MAX and sort_roots and walk_pos is None and
-                   rows_kernel_takes(M, m, bucket))
-        if by_root:
-            wl = torch.empty(cn, dtype=torch.int32, device=dev)
-            nwl = torch.zeros(1, dtype=torch.int64, device=dev)
-            wws = torch.zeros(L.subgacc_worklist_workspace_bytes(cn), dtype=torch.uint8, device=dev)
-            nsize.zero_()           # (a row that is not listed -- a root equal to SUBGACC_NO_ROOT -- reads as an empty set)
-            check(L.subgacc_worklist_by_root(ptr(q), cn, csr.num_nodes, ptr(wl), ptr(nwl), ptr(wws), wws.numel(), st))
+        p.by_root = (p.fused_rows and p.chunk == p.n and SORT_ROOTS_MIN <= p.cn <= SORT_ROOTS_MAX and p.sort_roots and p.walk_pos is None and
+                   rows_kernel_takes(p.M, p.m, p.bucket))
+        if p.by_root:
+            p.wl = torch.empty(p.cn, dtype=torch.int32, device=p.dev)
+            p.nwl = torch.zeros(1, dtype=torch.int64, device=p.dev)
+            p.wws = torch.zeros(p.L.subgacc_worklist_workspace_bytes(p.cn), dtype=torch.uint8, device=p.dev)
+            p.nsize.zero_()           # (a row that is not listed -- a root equal to SUBGACC_NO_ROOT -- reads as an empty set)
+            check(p.L.subgacc_worklist_by_root(ptr(p.q), p.cn, p.csr.num_nodes, ptr(p.wl), ptr(p.nwl), ptr(p.wws), p.wws.numel(), p.st))
         with _timed("walk_sets"):
-            if kform == 64:       # rows of 64-bit LP keys (4 hops, M >= 128): one chunk, optionally in work-list order
-                check(L.subgacc_walk_keyrows64(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q), cn,
-                                               ptr(rng_pos) if rng_pos is not None else None,
-                                               ptr(rng_seed) if rng_seed is not None else None,
-                                               ptr(wl) if by_root else None, ptr(nwl) if by_root else None,
-                                               ptr(st_ids), ptr(st_aux), ptr(nsize), ptr(flags), st))
-            elif by_root:
-                check(L.subgacc_walk_spg_list(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q), cn,
-                                              ptr(rng_pos) if rng_pos is not None else None,
-                                              ptr(rng_seed) if rng_seed is not None else None, ptr(wl), ptr(nwl),
-                                              None if batched else ptr(table), 0 if (key_rows or batched) else uniq_capacity,
-                                              ptr(st_ids), ptr(st_aux), ptr(nsize), ptr(flags), st))
-            elif fused_rows:
-                check(L.subgacc_walk_spg(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn, lo,
-                                         ptr(rng_pos[lo:]) if rng_pos is not None else None,
-                                         ptr(rng_seed[lo:]) if rng_seed is not None else None,
-                                         None if batched else ptr(table), 0 if (key_rows or batched) else uniq_capacity,
-                                         ptr(st_ids), ptr(st_aux), ptr(nsize[lo:]), ptr(flags), st))
+            if p.kform == 64:       # rows of 64-bit LP keys (4 hops, M >= 128): one chunk, optionally in work-list order
+                check(p.L.subgacc_walk_keyrows64(p.cfg, ptr(p.csr.indptr), ptr(p.csr.indices), p.csr.num_nodes, ptr(p.q), p.cn,
+                                               ptr(p.rng_pos) if p.rng_pos is not None else None,
+                                               ptr(p.rng_seed) if p.rng_seed is not None else None,
+                                               ptr(p.wl) if p.by_root else None, ptr(p.nwl) if p.by_root else None,
+                                               ptr(p.st_ids), ptr(p.st_aux), ptr(p.nsize), ptr(p.flags), p.st))
+            elif p.by_root:
+                check(p.L.subgacc_walk_spg_list(p.cfg, ptr(p.csr.indptr), ptr(p.csr.indices), p.csr.num_nodes, ptr(p.q), p.cn,
+                                              ptr(p.rng_pos) if p.rng_pos is not None else None,
+                                              ptr(p.rng_seed) if p.rng_seed is not None else None, ptr(p.wl), ptr(p.nwl),
+                                              None if p.batched else ptr(p.table), 0 if (p.key_rows or p.batched) else p.uniq_capacity,
+                                              ptr(p.st_ids), ptr(p.st_aux), ptr(p.nsize), ptr(p.flags), p.st))
+            elif p.fused_rows:
+                check(p.L.subgacc_walk_spg(p.cfg, ptr(p.csr.indptr), ptr(p.csr.indices), p.csr.num_nodes, ptr(p.q[p.lo:]), p.cn, p.lo,
+                                         ptr(p.rng_pos[p.lo:]) if p.rng_pos is not None else None,
+                                         ptr(p.rng_seed[p.lo:]) if p.rng_seed is not None else None,
+                                         None if p.batched else ptr(p.table), 0 if (p.key_rows or p.batched) else p.uniq_capacity,
+                                         ptr(p.st_ids), ptr(p.st_aux), ptr(p.nsize[p.lo:]), ptr(p.flags), p.st))
             else:
-                check(L.subgacc_walk_sets(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn,
-                                          ptr(rng_pos[lo:]) if rng_pos is not None else None,
-                                          ptr(rng_seed[lo:]) if rng_seed is not None else None,
-                                          ptr(st_ids), ptr(st_aux), ptr(nsize[lo:]),
-                                          ptr(walks[lo:]) if walks is not None else None, ptr(flags), st))
-        if not strided:
-            check(L.subgacc_exclusive_scan_i32(ptr(nsize[lo:]), cn, ptr(off_chunk), ptr(scan_ws), scan_ws.numel(), st))
-        if finish:            # (ids in first-visit order, keys) -> (ids sorted, table slots), in place: finished rows
-            st_slot = torch.empty(chunk * stride, dtype=torch.int32, device=dev)
+                check(p.L.subgacc_walk_sets(p.cfg, ptr(p.csr.indptr), ptr(p.csr.indices), p.csr.num_nodes, ptr(p.q[p.lo:]), p.cn,
+                                          ptr(p.rng_pos[p.lo:]) if p.rng_pos is not None else None,
+                                          ptr(p.rng_seed[p.lo:]) if p.rng_seed is not None else None,
+                                          ptr(p.st_ids), ptr(p.st_aux), ptr(p.nsize[p.lo:]),
+                                          ptr(p.walks[p.lo:]) if p.walks is not None else None, ptr(p.flags), p.st))
+        if not p.strided:
+            check(p.L.subgacc_exclusive_scan_i32(ptr(p.nsize[p.lo:]), p.cn, ptr(p.off_chunk), ptr(p.scan_ws), p.scan_ws.numel(), p.st))
+        if p.finish:            # (ids in first-visit order, keys) -> (ids sorted, table slots), in place: finished rows
+            p.st_slot = torch.empty(p.chunk * p.stride, dtype=torch.int32, device=p.dev)
             with _timed("spg_build"):
-                check(L.subgacc_finish_rows(ptr(st_ids), ptr(st_aux), ptr(nsize), cn, stride, 0, ptr(table), uniq_capacity,
-                                            ptr(st_slot), ptr(flags), st))
-            st_aux = st_slot
-        numbered_early = (fused_rows or finish) and chunk == n and (number_rows or not strided)
-        count = status[2:3]
-        total = None
-        if batched:
-            ccap = L.subgacc_keyrows_cand_capacity(cn)
-            cand = torch.empty(ccap, dtype=torch.int32, device=dev)
-            ncand = torch.zeros(1, dtype=torch.int64, device=dev)
-            rp, rs = (ptr(rng_pos[lo:]), ptr(rng_seed[lo:])) if rng_pos is not None else (None, None)
-            if numbered_early:      # one chunk: register -> exact tags for the candidates -> number (below) -> copy with SFptr+1
+                check(p.L.subgacc_finish_rows(ptr(p.st_ids), ptr(p.st_aux), ptr(p.nsize), p.cn, p.stride, 0, ptr(p.table), p.uniq_capacity,
+                                            ptr(p.st_slot), ptr(p.flags), p.st))
+            p.st_aux = p.st_slot
+        p.numbered_early = (p.fused_rows or p.finish) and p.chunk == p.n and (p.number_rows or not p.strided)
+        p.count = p.status[2:3]
+        p.total = None
+        if p.batched:
+            p.ccap = p.L.subgacc_keyrows_cand_capacity(p.cn)
+            p.cand = torch.empty(p.ccap, dtype=torch.int32, device=p.dev)
+            p.ncand = torch.zeros(1, dtype=torch.int64, device=p.dev)
+            p.rp, p.rs = (ptr(p.rng_pos[p.lo:]), ptr(p.rng_seed[p.lo:])) if p.rng_pos is not None else (None, None)
+            if p.numbered_early:      # one chunk: register -> exact tags for the candidates -> number (below) -> copy with SFptr+1
                 with _timed("register_rows"):
-                    check(L.subgacc_keyrows_register(ptr(st_aux), ptr(nsize[lo:]), cn, stride, lo, ptr(table), uniq_capacity,
-                                                     ptr(cand), ccap, ptr(ncand), ptr(flags), st))
-                    if lazy:
-                        total, wcap = cn * stride, 0
+                    check(p.L.subgacc_keyrows_register(ptr(p.st_aux), ptr(p.nsize[p.lo:]), p.cn, p.stride, p.lo, ptr(p.table), p.uniq_capacity,
+                                                     ptr(p.cand), p.ccap, ptr(p.ncand), ptr(p.flags), p.st))
+                    if p.lazy:
+                        p.total, p.wcap = p.cn * p.stride, 0
                     else:           # the one host read of the chunk carries the candidate count along
-                        total, wcap = (int(v) for v in torch.cat([off_chunk[cn:cn + 1], ncand]).tolist())
-                        wcap = max(min(wcap, cn), 1)
-                    check(L.subgacc_walk_tags(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn, lo, rp, rs,
-                                              ptr(cand), ptr(ncand), wcap, ptr(table), uniq_capacity, ptr(flags), st))
-        if strided and not numbered_early:
-            ukeys, max_unique = None, uniq_capacity
-        if numbered_early:    # one chunk: the table is complete -> number it now and let the copy emit SFptr+1
-            max_unique = min(uniq_capacity, limit)
-            ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
-            nws = torch.empty(L.subgacc_uniq_number_workspace_bytes(uniq_capacity, 0), dtype=torch.uint8, device=dev)
+                        p.total, p.wcap = (int(p.v) for p.v in torch.cat([p.off_chunk[p.cn:p.cn + 1], p.ncand]).tolist())
+                        p.wcap = max(min(p.wcap, p.cn), 1)
+                    check(p.L.subgacc_walk_tags(p.cfg, ptr(p.csr.indptr), ptr(p.csr.indices), p.csr.num_nodes, ptr(p.q[p.lo:]), p.cn, p.lo, p.rp, p.rs,
+                                              ptr(p.cand), ptr(p.ncand), p.wcap, ptr(p.table), p.uniq_capacity, ptr(p.flags), p.st))
+        if p.strided and not p.numbered_early:
+            p.ukeys, p.max_unique = None, p.uniq_capacity
+        if p.numbered_early:    # one chunk: the table is complete -> number it now and let the copy emit SFptr+1
+            p.max_unique = min(p.uniq_capacity, p.limit)
+            p.ukeys = torch.empty(p.max_unique, dtype=torch.int64, device=p.dev)
+            p.nws = torch.empty(p.L.subgacc_uniq_number_workspace_bytes(p.uniq_capacity, 0), dtype=torch.uint8, device=p.dev)
             with _timed("uniq_rows"):
-                check(L.subgacc_uniq_number(ptr(table), uniq_capacity, None, 0, ptr(ukeys), max_unique, ptr(count), limit,
-                                            ptr(nws), nws.numel(), st))
-        if strided:           # rows are joined from the staging arrays themselves
-            sets = SampledSets(nsize, None, st_ids, None, None, ukeys, M, m, stride, None)
-            sets.slot, sets.table, sets.capacity, sets.strided = st_aux, table, (0 if key_rows else uniq_capacity), True
-            if key_rows:
-                sets.keyrows, sets.key64 = True, kform == 64
-                sets._keyctx = {"csr": csr, "roots": q, "cfg": cfg, "rng_pos": rng_pos, "rng_seed": rng_seed,
-                                "capacity": uniq_capacity, "fresh": lambda: True}
-            torch.sum(nsize, dim=(0,), dtype=torch.int64, out=status[3])
-            sets.status = status
-            if not lazy:      # eager: same recovery as the packed forms below
-                st_host = unpack_status(status.tolist())
-                if st_host[2]:                    # the table of distinct LP rows overflowed: walk again with a larger one
-                    return sample_sets(csr, q, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order,
-                                       cap_root_degree, emit_walks, rng_streams, calls_before, dedup, keep_keys,
-                                       staging_bytes, uniq_capacity * 4, uniq_small_limit, fused_rows, lazy, strided,
-                                       number_rows, key_rows=key_rows_arg, walk_replay=walk_replay,
-                                       batched_registration=batched_registration, sort_roots=sort_roots, rng_state=rng_state)
-                if st_host[4] > max_unique:       # more distinct rows than the direct ranking numbers: the caller
+                check(p.L.subgacc_uniq_number(ptr(p.table), p.uniq_capacity, None, 0, ptr(p.ukeys), p.max_unique, ptr(p.count), p.limit,
+                                            ptr(p.nws), p.nws.numel(), p.st))
+        if p.strided:           # rows are joined from the staging arrays themselves
+            p.sets = SampledSets(p.nsize, None, p.st_ids, None, None, p.ukeys, p.M, p.m, p.stride, None)
+            p.sets.slot, p.sets.table, p.sets.capacity, p.sets.strided = p.st_aux, p.table, (0 if p.key_rows else p.uniq_capacity), True
+            if p.key_rows:
+                p.sets.keyrows, p.sets.key64 = True, p.kform == 64
+                p.sets._keyctx = {"p.csr": p.csr, "roots": p.q, "p.cfg": p.cfg, "p.rng_pos": p.rng_pos, "p.rng_seed": p.rng_seed,
+                                "capacity": p.uniq_capacity, "fresh": lambda: True}
+            torch.sum(p.nsize, dim=(0,), dtype=torch.int64, out=p.status[3])
+            p.sets.status = p.status
+            if not p.lazy:      # eager: same recovery as the packed forms below
+                p.st_host = unpack_status(p.status.tolist())
+                if p.st_host[2]:                    # the table of distinct LP rows overflowed: walk again with a larger one
+                    return sample_sets(p.csr, p.q, p.num_walks, p.num_steps, p.bucket, p.seed, p.rng, p.first_hop_wo, p.order,
+                                       p.cap_root_degree, p.emit_walks, p.rng_streams, p.calls_before, p.dedup, p.keep_keys,
+                                       p.staging_bytes, p.uniq_capacity * 4, p.uniq_small_limit, p.fused_rows, p.lazy, p.strided,
+                                       p.number_rows, key_rows=p.key_rows_arg, walk_replay=p.walk_replay,
+                                       batched_registration=p.batched_registration, sort_roots=p.sort_roots, rng_state=p.rng_state)
+                if p.st_host[4] > p.max_unique:       # more distinct rows than the direct ranking numbers: the caller
                     return None                   # (sample_spg) falls through to the packed forms
-                sets.resolve()
-            return sets
+                p.sets.resolve()
+            return p.sets
         # packed arrays: exact size (one 8-byte host read) or, lazily, the upper bound n*stride
-        if total is None:
-            total = cn * stride if lazy else int(off_chunk[cn].item())
-        ids_c = torch.empty(total, dtype=torch.int32, device=dev)
-        keys_c = torch.empty(total, dtype=torch.int64, device=dev) if keep_keys else None
-        slot_c = torch.empty(total, dtype=torch.int32, device=dev) if dedup else None
+        if p.total is None:
+            p.total = p.cn * p.stride if p.lazy else int(p.off_chunk[p.cn].item())
+        p.ids_c = torch.empty(p.total, dtype=torch.int32, device=p.dev)
+        p.keys_c = torch.empty(p.total, dtype=torch.int64, device=p.dev) if p.keep_keys else None
+        p.slot_c = torch.empty(p.total, dtype=torch.int32, device=p.dev) if p.dedup else None
         with _timed("compact_sets"):
-            if batched:     # key rows -> packed rows: SFptr+1 looked up on the way, or (several chunks) the key kept as payload
-                check(L.subgacc_keyrows_compact(ptr(st_ids), ptr(st_aux), ptr(nsize[lo:]), ptr(off_chunk), cn, stride, lo, ptr(table),
-                                                uniq_capacity, ptr(ukeys) if numbered_early else None,
-                                                ptr(count) if numbered_early else None, max_unique if numbered_early else 0,
-                                                ptr(ids_c), ptr(slot_c), ptr(cand), ccap, ptr(ncand), ptr(flags), st))
-                if not numbered_early:    # the pass registered this chunk's keys itself: now the candidates' exact tags
-                    check(L.subgacc_walk_tags(cfg, ptr(csr.indptr), ptr(csr.indices), csr.num_nodes, ptr(q[lo:]), cn, lo, rp, rs,
-                                              ptr(cand), ptr(ncand), 0, ptr(table), uniq_capacity, ptr(flags), st))
-            elif fused_rows:
-                check(L.subgacc_compact_rows(ptr(st_ids), ptr(st_aux), ptr(nsize[lo:]), ptr(off_chunk), cn, stride,
-                                             ptr(ids_c), ptr(slot_c), ptr(table) if numbered_early else None,
-                                             uniq_capacity if numbered_early else 0, st))
+            if p.batched:     # key rows -> packed rows: SFptr+1 looked up on the way, or (several chunks) the key kept as payload
+                check(p.L.subgacc_keyrows_compact(ptr(p.st_ids), ptr(p.st_aux), ptr(p.nsize[p.lo:]), ptr(p.off_chunk), p.cn, p.stride, p.lo, ptr(p.table),
+                                                p.uniq_capacity, ptr(p.ukeys) if p.numbered_early else None,
+                                                ptr(p.count) if p.numbered_early else None, p.max_unique if p.numbered_early else 0,
+                                                ptr(p.ids_c), ptr(p.slot_c), ptr(p.cand), p.ccap, ptr(p.ncand), ptr(p.flags), p.st))
+                if not p.numbered_early:    # the pass registered this chunk's keys itself: now the candidates' exact tags
+                    check(p.L.subgacc_walk_tags(p.cfg, ptr(p.csr.indptr), ptr(p.csr.indices), p.csr.num_nodes, ptr(p.q[p.lo:]), p.cn, p.lo, p.rp, p.rs,
+                                              ptr(p.cand), ptr(p.ncand), 0, ptr(p.table), p.uniq_capacity, ptr(p.flags), p.st))
+            elif p.fused_rows:
+                check(p.L.subgacc_compact_rows(ptr(p.st_ids), ptr(p.st_aux), ptr(p.nsize[p.lo:]), ptr(p.off_chunk), p.cn, p.stride,
+                                             ptr(p.ids_c), ptr(p.slot_c), ptr(p.table) if p.numbered_early else None,
+                                             p.uniq_capacity if p.numbered_early else 0, p.st))
             else:
-                check(L.subgacc_compact_sets(ptr(st_ids), ptr(st_aux), ptr(nsize[lo:]), ptr(off_chunk), cn, stride,
-                                             ptr(ids_c), ptr(keys_c), ptr(table), uniq_capacity if dedup else 0, X,
-                                             ptr(slot_c), ptr(flags), st))
-        ids_parts.append(ids_c)
-        key_parts.append(keys_c)
-        slot_parts.append(slot_c)
-        X += total
-    ids = _cat(ids_parts, torch.int32, dev)
-    keys = _cat(key_parts, torch.int64, dev) if keep_keys else None
-    slot = _cat(slot_parts, torch.int32, dev) if dedup else None
-    del ids_parts, key_parts, slot_parts
+                check(p.L.subgacc_compact_sets(ptr(p.st_ids), ptr(p.st_aux), ptr(p.nsize[p.lo:]), ptr(p.off_chunk), p.cn, p.stride,
+                                             ptr(p.ids_c), ptr(p.keys_c), ptr(p.table), p.uniq_capacity if p.dedup else 0, p.X,
+                                             ptr(p.slot_c), ptr(p.flags), p.st))
+        p.ids_parts.append(p.ids_c)
+        p.key_parts.append(p.keys_c)
+        p.slot_parts.append(p.slot_c)
+        p.X += p.total
+    return _PACKED
 
-    if lazy:
-        row_off = off_chunk               # a single chunk: its offsets are the global ones
+
+def _finish_sets(p):
+    """sample_sets, part 3 (packed forms): the chunks joined, global row offsets, the distinct LP rows numbered by first occurrence
+    (subg_acc.c:957-1000), payloads translated to SFptr(+1), status read (eager) -- with the retry when the table overflowed."""
+    p.ids = _cat(p.ids_parts, torch.int32, p.dev)
+    p.keys = _cat(p.key_parts, torch.int64, p.dev) if p.keep_keys else None
+    p.slot = _cat(p.slot_parts, torch.int32, p.dev) if p.dedup else None
+    del p.ids_parts, p.key_parts, p.slot_parts
+
+    if p.lazy:
+        p.row_off = p.off_chunk               # a single chunk: its offsets are the global ones
     else:
-        row_off = torch.empty(n + 1, dtype=torch.int64, device=dev)
-        ws = torch.empty(L.subgacc_scan_workspace_bytes(n), dtype=torch.uint8, device=dev)
-        check(L.subgacc_exclusive_scan_i32(ptr(nsize), n, ptr(row_off), ptr(ws), ws.numel(), st))
+        p.row_off = torch.empty(p.n + 1, dtype=torch.int64, device=p.dev)
+        p.ws = torch.empty(p.L.subgacc_scan_workspace_bytes(p.n), dtype=torch.uint8, device=p.dev)
+        check(p.L.subgacc_exclusive_scan_i32(ptr(p.nsize), p.n, ptr(p.row_off), ptr(p.ws), p.ws.numel(), p.st))
 
-    sets = SampledSets(nsize, row_off, ids, keys, None, None, M, m, stride, walks)
-    if not dedup:
-        check_walk_flags(sets, flags.tolist())
-        return sets
+    p.sets = SampledSets(p.nsize, p.row_off, p.ids, p.keys, None, None, p.M, p.m, p.stride, p.walks)
+    if not p.dedup:
+        check_walk_flags(p.sets, p.flags.tolist())
+        return p.sets
 
     # number the distinct LP rows by first occurrence (subg_acc.c:957-1000)
-    x_dev = row_off[n:n + 1]
-    if n and fused_rows and chunk == n:
+    p.x_dev = p.row_off[p.n:p.n + 1]
+    if p.n and p.fused_rows and p.chunk == p.n:
         pass                          # numbered before the copy, which already wrote SFptr+1
-    elif fused_rows or lazy:          # table-only direct ranking (tags need not be element positions)
-        count = status[2:3]
-        max_unique = min(uniq_capacity, limit)
-        ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
-        ws = torch.empty(L.subgacc_uniq_number_workspace_bytes(uniq_capacity, 0), dtype=torch.uint8, device=dev)
+    elif p.fused_rows or p.lazy:          # table-only direct ranking (tags need not be element positions)
+        p.count = p.status[2:3]
+        p.max_unique = min(p.uniq_capacity, p.limit)
+        p.ukeys = torch.empty(p.max_unique, dtype=torch.int64, device=p.dev)
+        p.ws = torch.empty(p.L.subgacc_uniq_number_workspace_bytes(p.uniq_capacity, 0), dtype=torch.uint8, device=p.dev)
         with _timed("uniq_rows"):
-            check(L.subgacc_uniq_number(ptr(table), uniq_capacity, None, 0, ptr(ukeys), max_unique, ptr(count), limit,
-                                        ptr(ws), ws.numel(), st))
-            if batched:               # LP key -> SFptr+1 in place (the chunks kept the keys as payload)
-                check(L.subgacc_keyrows_translate(ptr(slot), slot.numel(), ptr(x_dev), ptr(table), uniq_capacity, ptr(ukeys),
-                                                  ptr(count), max_unique, st))
-            elif fused_rows:          # slot -> SFptr+1 in place: the rows are finished SpG rows
-                check(L.subgacc_uniq_translate(ptr(table), uniq_capacity, ptr(slot), slot.numel(), ptr(x_dev), 1, st))
+            check(p.L.subgacc_uniq_number(ptr(p.table), p.uniq_capacity, None, 0, ptr(p.ukeys), p.max_unique, ptr(p.count), p.limit,
+                                        ptr(p.ws), p.ws.numel(), p.st))
+            if p.batched:               # LP key -> SFptr+1 in place (the chunks kept the keys as payload)
+                check(p.L.subgacc_keyrows_translate(ptr(p.slot), p.slot.numel(), ptr(p.x_dev), ptr(p.table), p.uniq_capacity, ptr(p.ukeys),
+                                                  ptr(p.count), p.max_unique, p.st))
+            elif p.fused_rows:          # slot -> SFptr+1 in place: the rows are finished SpG rows
+                check(p.L.subgacc_uniq_translate(ptr(p.table), p.uniq_capacity, ptr(p.slot), p.slot.numel(), ptr(p.x_dev), 1, p.st))
     else:
-        count = status[2:3]
-        max_unique = min(max(X, 1), uniq_capacity)
-        ukeys = torch.empty(max_unique, dtype=torch.int64, device=dev)
-        ws = torch.empty(L.subgacc_uniq_number_workspace_bytes(uniq_capacity, X), dtype=torch.uint8, device=dev)
+        p.count = p.status[2:3]
+        p.max_unique = min(max(p.X, 1), p.uniq_capacity)
+        p.ukeys = torch.empty(p.max_unique, dtype=torch.int64, device=p.dev)
+        p.ws = torch.empty(p.L.subgacc_uniq_number_workspace_bytes(p.uniq_capacity, p.X), dtype=torch.uint8, device=p.dev)
         with _timed("uniq_rows"):
-            check(L.subgacc_uniq_number(ptr(table), uniq_capacity, ptr(slot), X, ptr(ukeys), max_unique, ptr(count),
-                                        uniq_small_limit, ptr(ws), ws.numel(), st))
-    sets.ukeys, sets.table, sets.capacity = ukeys, table, uniq_capacity
-    if fused_rows:
-        sets.data = slot
+            check(p.L.subgacc_uniq_number(ptr(p.table), p.uniq_capacity, ptr(p.slot), p.X, ptr(p.ukeys), p.max_unique, ptr(p.count),
+                                        p.uniq_small_limit, ptr(p.ws), p.ws.numel(), p.st))
+    p.sets.ukeys, p.sets.table, p.sets.capacity = p.ukeys, p.table, p.uniq_capacity
+    if p.fused_rows:
+        p.sets.data = p.slot
     else:
-        sets.slot = slot
-    status[3:4].copy_(x_dev)
-    sets.status = status
-    if lazy:
-        return sets
+        p.sets.slot = p.slot
+    p.status[3:4].copy_(p.x_dev)
+    p.sets.status = p.status
+    if p.lazy:
+        return p.sets
     # eager: read the status now; grow the table and walk again if it overflowed
-    st_host = unpack_status(status.tolist())
-    if fused_rows and not st_host[2] and st_host[4] > max_unique:
+    p.st_host = unpack_status(p.status.tolist())
+    if p.fused_rows and not p.st_host[2] and p.st_host[4] > p.max_unique:
         return None           # more distinct rows than the direct ranking handles: the caller takes the general path
-    if st_host[2]:
-        return sample_sets(csr, q, num_walks, num_steps, bucket, seed, rng, first_hop_wo, order, cap_root_degree,
-                           emit_walks, rng_streams, calls_before, dedup, keep_keys, staging_bytes, uniq_capacity * 4,
-                           uniq_small_limit, fused_rows, lazy, strided, number_rows, key_rows=key_rows_arg, walk_replay=walk_replay,
-                           batched_registration=batched_registration, sort_roots=sort_roots, rng_state=rng_state)
-    sets.resolve()
-    sets.ukeys = sets.ukeys.clone()
-    return sets
+    if p.st_host[2]:
+        return sample_sets(p.csr, p.q, p.num_walks, p.num_steps, p.bucket, p.seed, p.rng, p.first_hop_wo, p.order, p.cap_root_degree,
+                           p.emit_walks, p.rng_streams, p.calls_before, p.dedup, p.keep_keys, p.staging_bytes, p.uniq_capacity * 4,
+                           p.uniq_small_limit, p.fused_rows, p.lazy, p.strided, p.number_rows, key_rows=p.key_rows_arg, walk_replay=p.walk_replay,
+                           batched_registration=p.batched_registration, sort_roots=p.sort_roots, rng_state=p.rng_state)
+    p.sets.resolve()
+    p.sets.ukeys = p.sets.ukeys.clone()
+    return p.sets
 
 
 def dedup_lp_rows(sets, capacity=UNIQ_CAPACITY, small_limit=0):

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import check, lib, ptr, stream_ptr
+from ._lib import JOIN_COUNTS, JOIN_F64, JOIN_KEY32, JOIN_KEY64, JOIN_PAIRS, JOIN_ROWS, JOIN_SFPTR, check, join_fill, lib, ptr, stream_ptr
 
 NO_ROOT = -2 ** 31      # include/subgacc.h: SUBGACC_NO_ROOT
 from .sampler import _timed
@@ -102,9 +102,9 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
             res = torch.empty((R, 2, k), dtype=torch.float32, device=dev)
         segid = None if ptr_mode else torch.empty(R, dtype=torch.int64, device=dev)
         with _timed("sjoin_fill"):
-            check(L.subgacc_sjoin_fill_keys(ptr(spg.indptr), spg.n_rows, ptr(spg.indices), ptr(spg.data), ptr(own), ptr(partner), S,
-                                            ptr(seg), spg.key_M, spg.key_m, ptr(res), ptr(segid), spg.max_len, pair_block,
-                                            ptr(flags), st))
+            join_fill(JOIN_ROWS, JOIN_KEY32, row_off=spg.indptr, n_rows=spg.n_rows, ids=spg.indices, payload=spg.data, max_len=spg.max_len,
+                      own=own, partner=partner, S=S, seg=seg, pair_block=pair_block, num_walks=spg.key_M, num_steps=spg.key_m,
+                      out_xz=res, out_segid=segid, flags=flags)
         return res, (seg if ptr_mode else _with_pointers(segid, seg)), flags
     if lazy and (out is None or not ptr_mode or return_index or (encode is None and not is_f64)):
         raise ValueError("lazy=True needs out=, ptr=True and an integer SpG with its encode table (or a float-payload SpG)")
@@ -125,13 +125,13 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
         else:
             xz = torch.empty((R, 2, 1), dtype=torch.float32, device=dev)
         with _timed("sjoin_fill"):
-            check(L.subgacc_sjoin_fill(ptr(spg.indptr), spg.n_rows, ptr(spg.indices), None, ptr(spg.data), ptr(own), ptr(partner), S,
-                                       ptr(seg), None, 0, 1, ptr(xz), None, ptr(segid), spg.max_len, pair_block, ptr(flags), st))
+            join_fill(JOIN_ROWS, JOIN_F64, row_off=spg.indptr, n_rows=spg.n_rows, ids=spg.indices, payload=spg.data, max_len=spg.max_len,
+                      own=own, partner=partner, S=S, seg=seg, pair_block=pair_block, out_xz=xz, out_segid=segid, flags=flags)
         out = xz
     elif return_index:
         out = torch.empty((R, 2), dtype=torch.int32, device=dev)
-        check(L.subgacc_sjoin_fill(ptr(spg.indptr), spg.n_rows, ptr(spg.indices), ptr(spg.data), None, ptr(own), ptr(partner), S,
-                                   ptr(seg), None, 0, 0, None, ptr(out), ptr(segid), spg.max_len, pair_block, ptr(flags), st))
+        join_fill(JOIN_ROWS, JOIN_SFPTR, row_off=spg.indptr, n_rows=spg.n_rows, ids=spg.indices, payload=spg.data, max_len=spg.max_len,
+                  own=own, partner=partner, S=S, seg=seg, pair_block=pair_block, out_idx=out, out_segid=segid, flags=flags)
     else:
         if encode is None:
             raise NotImplementedError("an integer SpG needs the encode table")
@@ -152,9 +152,9 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
         else:
             out = torch.empty((R, 2, k), dtype=torch.float32, device=dev)
         with _timed("sjoin_fill"):
-            check(L.subgacc_sjoin_fill(ptr(spg.indptr), spg.n_rows, ptr(spg.indices), ptr(spg.data), None, ptr(own), ptr(partner), S,
-                                       ptr(seg), ptr(enc), enc.shape[0], k, ptr(out), None, ptr(segid), spg.max_len,
-                                       pair_block, ptr(flags), st))
+            join_fill(JOIN_ROWS, JOIN_SFPTR, row_off=spg.indptr, n_rows=spg.n_rows, ids=spg.indices, payload=spg.data, max_len=spg.max_len,
+                      own=own, partner=partner, S=S, seg=seg, pair_block=pair_block, table=enc, table_rows=enc.shape[0], k=k,
+                      out_xz=out, out_segid=segid, flags=flags)
     return out, (seg if ptr_mode else _with_pointers(segid, seg)), flags
 
 
@@ -177,9 +177,9 @@ def _sjoin_strided(spg, own, partner, seg, ws, encode, ptr_mode, return_index, p
             raise ValueError("a key-rows batch has no row numbers to return: join z.to_csr() (gather_index does)")
         spg.sets.number()               # the pairs are SFptr+1: a transient batch is numbered only now
         res = torch.empty((R, 2), dtype=torch.int32, device=dev)
-        check(L.subgacc_sjoin_fill_rows(ptr(spg.nsize), spg.n_rows, spg.stride, ptr(spg.indices), ptr(spg.slot), ptr(spg.table),
-                                        spg.capacity, ptr(own), ptr(partner), S, ptr(seg), None, 0, 0, None, ptr(res),
-                                        ptr(segid), pair_block, ptr(flags), st))
+        join_fill(JOIN_ROWS, JOIN_SFPTR, row_len=spg.nsize, n_rows=spg.n_rows, row_stride=spg.stride, ids=spg.indices, payload=spg.slot,
+                  uniq_table=spg.table, uniq_capacity=spg.capacity, own=own, partner=partner, S=S, seg=seg, pair_block=pair_block,
+                  out_idx=res, out_segid=segid, flags=flags)
         return res, (seg if ptr_mode else _with_pointers(segid, seg)), flags
     if encode is None:
         raise NotImplementedError("an integer SpG needs the encode table")
@@ -204,9 +204,9 @@ def _sjoin_strided(spg, own, partner, seg, ws, encode, ptr_mode, return_index, p
         if not ptr_mode:
             raise ValueError("a key-rows batch is joined with segment pointers (ptr=True); use z.to_csr() for segment ids")
         with _timed("sjoin_fill"):
-            fill = L.subgacc_sjoin_fill_keyrows64 if spg.sets.key64 else L.subgacc_sjoin_fill_keyrows
-            check(fill(ptr(spg.nsize), spg.n_rows, spg.stride, ptr(spg.indices), ptr(spg.slot), ptr(own),
-                       ptr(partner), S, ptr(seg), M_, m_, ptr(res), pair_block, ptr(flags), st))
+            join_fill(JOIN_ROWS, JOIN_KEY64 if spg.sets.key64 else JOIN_KEY32, row_len=spg.nsize, n_rows=spg.n_rows, row_stride=spg.stride,
+                      ids=spg.indices, payload=spg.slot, own=own, partner=partner, S=S, seg=seg, pair_block=pair_block,
+                      num_walks=M_, num_steps=m_, out_xz=res, flags=flags)
         return res, seg, flags
     by_slot = encode is spg._slot_table and encode is not None      # StridedSpG.slot_table(): indexed by slot + 1
     enc = encode if by_slot else encode.to(device=dev, dtype=torch.float32).contiguous()
@@ -227,9 +227,9 @@ def _sjoin_strided(spg, own, partner, seg, ws, encode, ptr_mode, return_index, p
     else:
         res = torch.empty((R, 2, k), dtype=torch.float32, device=dev)
     with _timed("sjoin_fill"):
-        check(L.subgacc_sjoin_fill_rows(ptr(spg.nsize), spg.n_rows, spg.stride, ptr(spg.indices), ptr(spg.slot), ptr(tab), cap,
-                                        ptr(own), ptr(partner), S, ptr(seg), ptr(enc), enc.shape[0], k,
-                                        ptr(res), None, ptr(segid), pair_block, ptr(flags), st))
+        join_fill(JOIN_ROWS, JOIN_SFPTR, row_len=spg.nsize, n_rows=spg.n_rows, row_stride=spg.stride, ids=spg.indices, payload=spg.slot,
+                  uniq_table=tab, uniq_capacity=cap, own=own, partner=partner, S=S, seg=seg, pair_block=pair_block,
+                  table=enc, table_rows=enc.shape[0], k=k, out_xz=res, out_segid=segid, flags=flags)
     return res, (seg if ptr_mode else _with_pointers(segid, seg)), flags
 
 
@@ -646,13 +646,13 @@ def _buffered_step(csr, e, bufs, seed, out):
     xz = res.view(-1)[: rows * 2 * k].view(rows, 2, k)
     with _timed("sjoin_fill"):
         if kr:
-            fill = L.subgacc_sjoin_fill_keyrows64 if bufs.key64 else L.subgacc_sjoin_fill_keyrows
-            check(fill(ptr(bufs.nsize), n, bufs.stride, ptr(bufs.ids), ptr(bufs.slot), ptr(own), ptr(partner),
-                       n, ptr(bufs.seg), M, m, ptr(xz), PB, ptr(flags), st))
+            join_fill(JOIN_ROWS, JOIN_KEY64 if bufs.key64 else JOIN_KEY32, row_len=bufs.nsize, n_rows=n, row_stride=bufs.stride, ids=bufs.ids,
+                      payload=bufs.slot, own=own, partner=partner, S=n, seg=bufs.seg, pair_block=PB, num_walks=M, num_steps=m,
+                      out_xz=xz, flags=flags)
         else:
-            check(L.subgacc_sjoin_fill_rows(ptr(bufs.nsize), n, bufs.stride, ptr(bufs.ids), ptr(bufs.slot), None, 0, ptr(own),
-                                            ptr(partner), n, ptr(bufs.seg), ptr(bufs.feat), bufs.capacity + 1, k, ptr(xz), None,
-                                            None, PB, ptr(flags), st))
+            join_fill(JOIN_ROWS, JOIN_SFPTR, row_len=bufs.nsize, n_rows=n, row_stride=bufs.stride, ids=bufs.ids, payload=bufs.slot,
+                      own=own, partner=partner, S=n, seg=bufs.seg, pair_block=PB, table=bufs.feat, table_rows=bufs.capacity + 1, k=k,
+                      out_xz=xz, flags=flags)
     sets = SampledSets(bufs.nsize, None, bufs.ids, None, None, None, M, m, bufs.stride, None)
     sets.slot, sets.table, sets.capacity, sets.strided = bufs.slot, bufs.table, (0 if kr else bufs.capacity), True
     if kr:
@@ -800,8 +800,8 @@ def gather_counts(edge, x, table_rows, device=None):
     out = torch.empty((2 * B, int(table_rows)), dtype=torch.float32, device=dev)
     flags = torch.zeros(4, dtype=torch.int32, device=dev)
     with _timed("sjoin_counts"):
-        check(lib().subgacc_sjoin_counts(ptr(spg.indptr), spg.n_rows, ptr(spg.indices), ptr(spg.data), ptr(own), ptr(partner), 2 * B,
-                                         int(table_rows), ptr(out), spg.max_len, B, ptr(flags), stream_ptr()))
+        join_fill(JOIN_COUNTS, JOIN_SFPTR, row_off=spg.indptr, n_rows=spg.n_rows, ids=spg.indices, payload=spg.data, max_len=spg.max_len,
+                  own=own, partner=partner, S=2 * B, pair_block=B, table_rows=int(table_rows), out_counts=out, flags=flags)
     sizes = spg.indptr[own + 1] - spg.indptr[own]
     _checked(out, sizes, flags)
     return out, sizes
@@ -851,8 +851,8 @@ def gather_pairs(edge, x, device=None):
     mult = torch.empty(R, dtype=torch.int32, device=dev)
     cnt = torch.zeros(S, dtype=torch.int32, device=dev)
     with _timed("sjoin_pairs"):
-        check(L.subgacc_sjoin_pairs(ptr(spg.indptr), spg.n_rows, ptr(spg.indices), ptr(spg.data), ptr(own), ptr(partner), S,
-                                    ptr(seg), ptr(pairs), ptr(mult), ptr(cnt), spg.max_len, B, ptr(flags), st))
+        join_fill(JOIN_PAIRS, JOIN_SFPTR, row_off=spg.indptr, n_rows=spg.n_rows, ids=spg.indices, payload=spg.data, max_len=spg.max_len,
+                  own=own, partner=partner, S=S, seg=seg, pair_block=B, out_pairs=pairs, out_mult=mult, out_cnt=cnt, flags=flags)
     # rows of segment j sit at [seg[j], seg[j] + cnt[j]): close the gaps (R' ~ R/10 elements from here on)
     indptr = torch.zeros(S + 1, dtype=torch.int64, device=dev)
     torch.cumsum(cnt, 0, out=indptr[1:])

@@ -41,9 +41,9 @@ int main(int argc, char **argv) {
     SYM(subgacc_walk_sets); SYM(subgacc_scan_workspace_bytes); SYM(subgacc_exclusive_scan_i32); SYM(subgacc_compact_sets);
     SYM(subgacc_uniq_table_bytes); SYM(subgacc_uniq_reset); SYM(subgacc_uniq_number_workspace_bytes);
     SYM(subgacc_uniq_number); SYM(subgacc_spg_build); SYM(subgacc_sjoin_workspace_bytes); SYM(subgacc_sjoin_sizes);
-    SYM(subgacc_sjoin_fill); SYM(subgacc_unpack_lp); SYM(subgacc_sjoin_fill_keys);
+    SYM(subgacc_sjoin_fill_v2); SYM(subgacc_unpack_lp); SYM(subgacc_sjoin_fill_keys);
     SYM(subgacc_step_prologue); SYM(subgacc_walk_keyrows64); SYM(subgacc_walk_spg); SYM(subgacc_sjoin_sizes_rows);
-    SYM(subgacc_sjoin_fill_keyrows64); SYM(subgacc_sjoin_fill_keyrows);
+
     CHECK(p_subgacc_abi_version() == SUBGACC_ABI_VERSION);
     CHECK(p_subgacc_device_count() >= 1);
     CHECK(p_subgacc_key_shift(8, 2) == 4);
@@ -96,8 +96,18 @@ int main(int argc, char **argv) {
     HIP(hipMemcpy(seg_h, seg, sizeof seg_h, hipMemcpyDeviceToHost));
     const int64_t R = seg_h[4];
     float *xz = dev(R * 2 * (m + 1) * 4, NULL);
-    CHECK(p_subgacc_sjoin_fill(row_off, n, z_idx, z_dat, NULL, own, partner, 4, seg, tab, c + 1, m + 1, xz, NULL, NULL, STRIDE, 2,
-                               flags, NULL) == 0);
+    /* ABI 6: every form of the join goes through ONE entry point; the descriptor says what the store and the outputs are */
+    {
+        subgacc_join_desc d;
+        memset(&d, 0, sizeof d);
+        d.struct_bytes = (int32_t)sizeof d, d.form = SUBGACC_JOIN_ROWS, d.payload_kind = SUBGACC_JOIN_SFPTR;
+        d.row_off = row_off, d.n_rows = n, d.ids = z_idx, d.payload = z_dat, d.max_len = STRIDE;
+        d.own = own, d.partner = partner, d.S = 4, d.seg = seg, d.pair_block = 2;
+        d.table = tab, d.table_rows = c + 1, d.k = m + 1, d.out_xz = xz, d.flags = flags;
+        CHECK(p_subgacc_sjoin_fill_v2(&d, NULL) == 0);
+        d.struct_bytes = 8;                                  /* a descriptor of another layout is refused, not misread */
+        CHECK(p_subgacc_sjoin_fill_v2(&d, NULL) == SUBGACC_ERR_BADARG);
+    }
     HIP(hipDeviceSynchronize());
 
     /* checks on the host */
@@ -132,6 +142,18 @@ int main(int argc, char **argv) {
         for (int64_t e = 0; e < X; ++e) zk_h[e] = (int32_t)(uint32_t)uk_h[zd[e] - 1];
         int32_t *z_key = dev(X * 4, zk_h);
         float *xz2 = dev(R * 2 * (m + 1) * 4, NULL), *xz2_h = malloc(R * 2 * (m + 1) * 4);
+        subgacc_join_desc d;
+        memset(&d, 0, sizeof d);
+        d.struct_bytes = (int32_t)sizeof d, d.form = SUBGACC_JOIN_ROWS, d.payload_kind = SUBGACC_JOIN_KEY32;
+        d.row_off = row_off, d.n_rows = n, d.ids = z_idx, d.payload = z_key, d.max_len = STRIDE;
+        d.own = own, d.partner = partner, d.S = 4, d.seg = seg, d.pair_block = 2;
+        d.num_walks = M, d.num_steps = m, d.out_xz = xz2, d.flags = flags;
+        CHECK(p_subgacc_sjoin_fill_v2(&d, NULL) == 0);
+        HIP(hipDeviceSynchronize());
+        HIP(hipMemcpy(xz2_h, xz2, R * 2 * (m + 1) * 4, hipMemcpyDeviceToHost));
+        CHECK(memcmp(xz_h, xz2_h, R * 2 * (m + 1) * 4) == 0);
+        /* ... and the ABI 5 symbol of the same form still answers (a forward to the entry point above) */
+        HIP(hipMemset(xz2, 0, R * 2 * (m + 1) * 4));
         CHECK(p_subgacc_sjoin_fill_keys(row_off, n, z_idx, z_key, own, partner, 4, seg, M, m, xz2, NULL, STRIDE, 2, flags, NULL) == 0);
         HIP(hipDeviceSynchronize());
         HIP(hipMemcpy(xz2_h, xz2, R * 2 * (m + 1) * 4, hipMemcpyDeviceToHost));
@@ -165,12 +187,15 @@ int main(int argc, char **argv) {
         HIP(hipMemcpy(s2, seg2, sizeof s2, hipMemcpyDeviceToHost));
         const int64_t R2 = s2[4];
         float *xzk = dev(R2 * 2 * (m4 + 1) * 4, NULL), *xzk_h = malloc(R2 * 2 * (m4 + 1) * 4);
-        if (wide)
-            CHECK(p_subgacc_sjoin_fill_keyrows64(ns2, 4, S4, rid, (const uint64_t *)rkey, own2, NULL, 4, seg2, Mw, m4, xzk, 2,
-                                                 (int32_t *)status, NULL) == 0);
-        else
-            CHECK(p_subgacc_sjoin_fill_keyrows(ns2, 4, S4, rid, (const int32_t *)rkey, own2, NULL, 4, seg2, Mw, m4, xzk, 2,
-                                               (int32_t *)status, NULL) == 0);
+        {
+            subgacc_join_desc d;
+            memset(&d, 0, sizeof d);
+            d.struct_bytes = (int32_t)sizeof d, d.form = SUBGACC_JOIN_ROWS, d.payload_kind = wide ? SUBGACC_JOIN_KEY64 : SUBGACC_JOIN_KEY32;
+            d.row_len = ns2, d.n_rows = 4, d.row_stride = S4, d.ids = rid, d.payload = rkey;
+            d.own = own2, d.S = 4, d.seg = seg2, d.pair_block = 2;             /* partner = NULL: the mirror block */
+            d.num_walks = Mw, d.num_steps = m4, d.out_xz = xzk, d.flags = (int32_t *)status;
+            CHECK(p_subgacc_sjoin_fill_v2(&d, NULL) == 0);
+        }
         HIP(hipDeviceSynchronize());
         int32_t nsh[4], st32[8], *rid_h = malloc(4 * S4 * 4);
         uint64_t *rk_h = malloc((size_t)4 * S4 * 8);

@@ -106,3 +106,14 @@ def test_minimal_record_without_optional_blocks():
     bench.flatten(out)
     line = json.loads(bench.compact_line(out))
     assert "cpu_baseline" not in line and line["config"]["ranks_seen"] == 8
+
+
+def test_traffic_json_cites_tracked_files():
+    """VERDICT r4 (weak 4): `roofline.traffic` comes from profiles/traffic.json; every entry names the counter table it was computed
+    from, and that table has to be in the tree a reader gets -- not in a git-ignored scratch directory."""
+    tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    assert tj
+    for key, entry in tj.items():
+        src = entry.get("source", "")
+        assert src.startswith("profiles/") and os.path.exists(os.path.join(ROOT, src)), (key, src)
+        assert entry.get("kernel_source_sha")

@@ -27,7 +27,7 @@ def test_header_symbols_are_exported(L):
 
 def test_abi_version_and_argument_errors(L):
     from surel_plus_amd import _lib
-    assert L.subgacc_abi_version() == 5           # 5: 64-bit key rows (4-hop walks); 2: row / node counts in the join and rng_positions entry points (bounds); 3: hop records in the walk cfg; 4: batched registration of key rows
+    assert L.subgacc_abi_version() == 6           # 6: subgacc_sjoin_fill_v2 (one descriptor for every form of the join); 5: 64-bit key rows (4-hop walks); 2: row / node counts in the join and rng_positions entry points (bounds); 3: hop records in the walk cfg; 4: batched registration of key rows
     assert L.subgacc_key_shift(200, 3) == 8            # SHIFT = 32-clz(M), subg_acc.c:903
     assert L.subgacc_key_shift(100, 4) == 7
     assert L.subgacc_key_shift(200, 8) == _lib.ERR_KEYWIDTH   # 8*8+1 > 64 (subg_acc.c:905-915)

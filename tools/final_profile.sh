@@ -1,6 +1,9 @@
 #!/bin/bash
-# Dev-only: the end-of-round evidence on ONE box -- kernel-trace stats, PMC passes (separate runs, never with a trace), the full
-# bench line.   tools/final_profile.sh TAG [workloads...]     -> gpurun_out/TAG_*   (copy what is to be judged into profiles/)
+# Dev-only: the end-of-round evidence on ONE box -- kernel-trace stats, PMC passes (separate runs, never with a trace), one SQ pass
+# over the headline step, the bench line.   tools/final_profile.sh TAG [workloads...]     -> gpurun_out/TAG_*
+# gpurun brings back gpurun_out/ only: afterwards, HERE,   cp gpurun_out/TAG_*_{kernel_stats,pmc_per_launch}.csv gpurun_out/TAG_sq_cit2.csv \
+#   gpurun_out/TAG_traffic.json profiles/  &&  cp gpurun_out/TAG_traffic.json profiles/traffic.json   -- every `source` traffic.json
+# names must be a tracked file (tests/test_bench_line_cpu.py::test_traffic_json_cites_tracked_files)
 set -x
 TAG=${1:-rXX}; shift
 WLS=${@:-cit2 cit2m4 collab ppa twitter cit2loc cit2ppr}
@@ -11,7 +14,8 @@ for W in $WLS; do
   cd $R
   cp $(find gpurun_out/${TAG}_stats_$W -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_${W}_kernel_stats.csv
   if [ $W = cit2ppr ]; then export SUBGACC_PPR_EAGER=1; fi
-  bash tools/pmc_collect.sh gpurun_out/${TAG}_pmc_$W ${TAG}_$W --workload $W > gpurun_out/${TAG}_${W}_pmc_per_launch.csv 2>&1
+  bash tools/pmc_collect.sh gpurun_out/${TAG}_pmc_$W ${TAG}_$W --workload $W > gpurun_out/${TAG}_${W}_pmc.log 2>&1
+  cp gpurun_out/${TAG}_pmc_$W/${TAG}_${W}_pmc_per_launch.csv gpurun_out/      # (pmc_traffic.py wrote it there and under profiles/)
   unset SUBGACC_PPR_EAGER
 done
 cd /tmp && export TMPDIR=/tmp
@@ -19,5 +23,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_sta
 cd $R
 cp $(find gpurun_out/${TAG}_stats_offline -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_offline_cit2_kernel_stats.csv
 cp profiles/traffic.json gpurun_out/${TAG}_traffic.json
+# where the waves of the headline step's kernels spend their cycles (the 3-hop walk kernel's instruction / LDS floor, the join)
+bash tools/pmc_sq.sh gpurun_out/${TAG}_sq_cit2_passes --workload cit2 > gpurun_out/${TAG}_sq_cit2.csv 2> gpurun_out/${TAG}_sq_cit2.err
 ( time python bench.py --steps 20 --warmup 5 ) > gpurun_out/${TAG}_bench_cit2.json 2> gpurun_out/${TAG}_bench_cit2.err
 tail -c 1500 gpurun_out/${TAG}_bench_cit2.json; tail -5 gpurun_out/${TAG}_bench_cit2.err

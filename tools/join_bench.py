@@ -50,7 +50,7 @@ def one(wl, n):
     L, st = lib(), stream_ptr()
     own, partner = _arange_segments(B, dev, B)
     flags = bufs.status.view(torch.int32)[:4]
-    fill = L.subgacc_sjoin_fill_keyrows64 if bufs.key64 else L.subgacc_sjoin_fill_keyrows
+    fill = L.subgacc_sjoin_fill_keyrows64 if bufs.key64 else L.subgacc_sjoin_fill_keyrows      # (the ABI 5 forwards: old builds have them too)
     out = bufs.out.view(-1)
 
     def launch():

@@ -2,7 +2,11 @@
 tallies a 128-byte line request at 64 bytes -- MI355X_MICROARCH.md, HBM section; confirmed for random 4-byte reads by
 tools/line_probe.hip: one request per missed 128-byte line) and the matching entry of profiles/traffic.json.
 
-    python tools/pmc_traffic.py OUTDIR TAG [bench args that were used]"""
+    python tools/pmc_traffic.py OUTDIR TAG [bench args that were used]
+
+The per-kernel table is WRITTEN to profiles/TAG_pmc_per_launch.csv (and printed, and copied into OUTDIR so that gpurun brings
+it back) BEFORE profiles/traffic.json is stamped with it: an entry's `source` always names a file that exists under profiles/
+(tests/test_bench_line_cpu.py checks the tracked tree the same way)."""
 import collections
 import csv
 import glob
@@ -19,8 +23,9 @@ for f in glob.glob(os.path.join(out, "*", "*", "*counter_collection.csv")):
         k = r["Kernel_Name"]
         if "subgacc" in k or "compact_rows" in k:
             acc[k.split("(")[0].replace("void subgacc::", "").replace("subgacc::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
-print("kernel,launches,FETCH_SIZE,WRITE_SIZE,TCC_REQ_sum,TCC_HIT_sum,TCC_MISS_sum,hbm_bytes_per_launch=(2*FETCH_SIZE+WRITE_SIZE)*1024")
+table = ["kernel,launches,FETCH_SIZE,WRITE_SIZE,TCC_REQ_sum,TCC_HIT_sum,TCC_MISS_sum,hbm_bytes_per_launch=(2*FETCH_SIZE+WRITE_SIZE)*1024"]
 rows = []
+JOIN_KERNELS = ("sjoin_pair_kernel", "sjoin_keypair_kernel", "sjoin_f64pair_kernel")      # the fill kernel of a step, whichever form
 for k, c in acc.items():
     m = {n: sum(v) / len(v) for n, v in c.items()}
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
@@ -29,12 +34,19 @@ walk = None
 join_k = None
 for _, k, n, m in sorted(rows)[:12]:
     hbm = (2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024
-    print(f"\"{k}\",{n},{m['FETCH_SIZE']:.0f},{m['WRITE_SIZE']:.0f},{m.get('TCC_REQ_sum', 0):.0f},{m.get('TCC_HIT_sum', 0):.0f},{m.get('TCC_MISS_sum', 0):.0f},{hbm:.0f}")
+    table.append(f"\"{k}\",{n},{m['FETCH_SIZE']:.0f},{m['WRITE_SIZE']:.0f},{m.get('TCC_REQ_sum', 0):.0f},{m.get('TCC_HIT_sum', 0):.0f},{m.get('TCC_MISS_sum', 0):.0f},{hbm:.0f}")
     if (k.startswith("walk_sets_kernel") or k.startswith("walk_rows_kernel") or k.startswith("walk_pipe_kernel")) and \
             (walk is None or n > walk[4]):      # the walk kernel of the timed steps: the one with the most launches
         walk = (k, hbm, m.get("TCC_MISS_sum", 0), m.get("TCC_REQ_sum", 0), n)
-    if k.startswith("sjoin_pair_kernel") and (join_k is None or n > join_k[3]):       # the join of the timed steps
+    if k.startswith(JOIN_KERNELS) and (join_k is None or n > join_k[3]):       # the join of the timed steps
         join_k = (k, hbm, m.get("TCC_MISS_sum", 0), n)
+csv_name = f"{tag}_pmc_per_launch.csv"
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+for dest in (os.path.join(ROOT, "profiles", csv_name), os.path.join(out, csv_name)):
+    with open(dest, "w") as fh:
+        fh.write("\n".join(table) + "\n")
+print("\n".join(table))
+assert os.path.exists(os.path.join(ROOT, "profiles", csv_name))        # what the entries below cite
 # the bench line of one of the passes tells the configuration (workload, B, M, k, layout, rng)
 line = None
 for f in glob.glob(os.path.join(out, "*.json")):
@@ -43,7 +55,7 @@ for f in glob.glob(os.path.join(out, "*.json")):
             line = json.loads(ln)
 if line and "PPR" in line.get("metric", ""):      # the float join: its fill kernel's traffic, keyed like bench_ppr looks it up
     import bench
-    join = [(k, m) for _, k, n, m in sorted(rows) if k.startswith("sjoin_pair_kernel")]
+    join = [(k, m) for _, k, n, m in sorted(rows) if k.startswith(JOIN_KERNELS)]
     if join:
         k, m = join[0]
         B = line["config"]["pairs_per_step_per_gpu"]
