@@ -667,7 +667,7 @@ def _plan_sets(p):
         # is sequential by definition, and set_sampler has a single stream): ~0.1 us per walk, i.e. tens of seconds from 10^8
         # walks on -- the price of bit-exactness with the reference on a graph it was not written for.  rng="philox" has no such cost.
         import warnings
-        warnings.warn(f"rng='rand_r' on a graph with dead ends: replaying the sequential stream of {p.n * p.M:,} p.walks on one "
+        warnings.warn(f"rng='rand_r' on a graph with dead ends: replaying the sequential stream of {p.n * p.M:,} walks on one "
                       f"wavefront per stream (~{p.n * p.M * 1e-7:.0f} s); rng='philox' samples the same distribution in parallel",
                       RuntimeWarning, stacklevel=4)      # (the caller of sample_sets: past _plan_sets, sample_sets and its wrapper)
     if p.walk_replay and p.n:      # the stream replayed: the position of every root and of every walk (subgacc_rng_replay)
@@ -789,7 +789,7 @@ def _launch_sets(p):
             p.sets.slot, p.sets.table, p.sets.capacity, p.sets.strided = p.st_aux, p.table, (0 if p.key_rows else p.uniq_capacity), True
             if p.key_rows:
                 p.sets.keyrows, p.sets.key64 = True, p.kform == 64
-                p.sets._keyctx = {"p.csr": p.csr, "roots": p.q, "p.cfg": p.cfg, "p.rng_pos": p.rng_pos, "p.rng_seed": p.rng_seed,
+                p.sets._keyctx = {"csr": p.csr, "roots": p.q, "cfg": p.cfg, "rng_pos": p.rng_pos, "rng_seed": p.rng_seed,
                                 "capacity": p.uniq_capacity, "fresh": lambda: True}
             torch.sum(p.nsize, dim=(0,), dtype=torch.int64, out=p.status[3])
             p.sets.status = p.status
