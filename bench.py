@@ -431,10 +431,13 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W, extr
         torch.cuda.synchronize()
         region_values.append(B * K / (time.perf_counter() - t1))
     sampler_mod.KERNEL_TIMER = None
+    elapsed_local = elapsed
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    rank_records = gather_rank_records(dist, world, rank, dev, elapsed_local, timer.mean_ms("join")[0],
+                                       os.environ.get("SUBGACC_DIST_BACKEND", "nccl") if dist is not None else None)
     if rank != 0:
         return None
     if extra_regions:
@@ -466,7 +469,14 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W, extr
     return {"metric": "query-pairs/sec (SpJoin, PPR payload)", "value": world * B * K / elapsed, "unit": "query-pairs/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": desc, "pairs_per_step_per_gpu": B, "xz_rows_last_step": rows_out,
+            "config": {"workload": desc, "pairs_per_step_per_gpu": B, "pairs_per_step_all_gpus": world * B, "xz_rows_last_step": rows_out,
+                       # one record per rank (all-gathered), as for the LP workloads: which devices really took part
+                       "ranks_seen": len(rank_records), "distinct_devices": len({r["device"] for r in rank_records}),
+                       "per_rank_ms_min": min(r["elapsed_ms"] for r in rank_records) / max(K, 1),
+                       "per_rank_ms_max": max(r["elapsed_ms"] for r in rank_records) / max(K, 1),
+                       "dist_backend": (os.environ.get("SUBGACC_DIST_BACKEND", "nccl") if dist is not None else "none"),
+                       "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if dist is not None else None,
+                       "rank_records": rank_records, "rng": "none (join only)", "parallelism": f"query-shard x{world}",
                        "region_pairs_per_s": [round(v) for v in region_values], "pairs_per_s_min": min(region_values),
                        "pairs_per_s_median": median(region_values), "pairs_per_s_max": max(region_values),
                        "spg_members": z.nnz, "offline_ppr_stage_s": prep_s,

@@ -173,26 +173,11 @@ __device__ __forceinline__ void join_row(const JoinArgs &a, int64_t r, int64_t &
 // Emit up to 64 consecutive output rows of one segment (one per lane): look the lane's member up in the
 // partner row (binary search over sorted ids held in LDS) and write the feature pairs of the whole 64-row span
 // with consecutive lanes on consecutive words.  KV = 4: k == 4, rows move as float4; KV = 0: any k <= 16.
-// element c of the feature row of LP key `key` (uniq.hip:unpack_lp_kernel restated): column 0 = 1 on the root's own row,
-// column j = count of step j / num_walks, from the per-workgroup table lut[c] = float(c) / float(num_walks)
-__device__ __forceinline__ float key_feature(uint32_t key, int c, int m, int shift, const float *lut) {
-    if (key == 0xFFFFFFFFu) return 0.0f;
-    if (c == 0) return ((key >> (m * shift)) & 1u) ? 1.0f : 0.0f;
-    return lut[(key >> ((m - c) * shift)) & ((1u << shift) - 1u)];
-}
-
-// the same for a 64-bit key (4-hop walks with M >= 128: 4 x 8 + 1 = 33 bits); ~0 = partner absent
-__device__ __forceinline__ float key_feature64(unsigned long long key, int c, int m, int shift, const float *lut) {
-    if (key == ~0ull) return 0.0f;
-    if (c == 0) return ((key >> (m * shift)) & 1ull) ? 1.0f : 0.0f;
-    return lut[(uint32_t)(key >> ((m - c) * shift)) & ((1u << shift) - 1u)];
-}
-
-template <bool F64, int KV, typename Val, bool KEYS = false, bool K64 = false>
+// (the one-segment kernel's emit: lists that are NOT mirrored pairs -- the pair kernels below have their own)
+template <bool F64, int KV, typename Val>
 __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int32_t *own_ids, const Val *own_val,
                                           int64_t na, const int32_t *pids, const Val *pval, int nb, int64_t t0,
-                                          int64_t o, int64_t segj, int k, int k2, uint32_t magic, const float *lut = nullptr,
-                                          float *stage = nullptr) {
+                                          int64_t o, int64_t segj, int k, int k2, uint32_t magic) {
     const int64_t t = t0 + lane;
     const bool live = t < na;
     int32_t id = 0;
@@ -220,105 +205,38 @@ __device__ __forceinline__ void emit_rows(const JoinArgs &a, int lane, const int
             stream_store(reinterpret_cast<float2 *>(a.out_xz) + row0 + lane, v);
         }
     } else {
-        using PT = typename std::conditional<K64, unsigned long long, int32_t>::type;
-        PT pa = (PT)va, pb = hit ? (PT)pval[lo] : (PT)(KEYS ? -1 : 0);
-        if (!K64 && a.out_idx && live) {
+        int32_t pa = (int32_t)va, pb = hit ? (int32_t)pval[lo] : 0;
+        if (a.out_idx && live) {
             int2 v;
-            v.x = (int32_t)pa;
-            v.y = (int32_t)pb;
+            v.x = pa;
+            v.y = pb;
             stream_store(reinterpret_cast<int2 *>(a.out_idx) + row0 + lane, v);
         }
         if (a.out_xz) {
-            if (!KEYS && live && ((uint64_t)pa >= (uint64_t)a.table_rows || (uint64_t)pb >= (uint64_t)a.table_rows)) {
+            if (live && ((uint64_t)pa >= (uint64_t)a.table_rows || (uint64_t)pb >= (uint64_t)a.table_rows)) {
                 atomicOr(&a.flags[3], 2);  // SFptr outside the table: never read out of bounds
                 pa = pb = 0;
             }
             const int nrows = (int)((na - t0) < kWave ? (na - t0) : kWave);
             // the 64 rows of this trip are one contiguous span of the output: fetch each row's (pa, pb) from its
             // owner lane by a wave shuffle so that stores are fully coalesced
-            if (KV == 4 && !K64) {
+            if (KV == 4) {
                 const float4 *tab4 = reinterpret_cast<const float4 *>(a.table);
                 float4 *dst4 = reinterpret_cast<float4 *>(a.out_xz) + row0 * 2;
 #pragma unroll
                 for (int rnd = 0; rnd < 2; ++rnd) {
                     const int f = rnd * kWave + lane;   // float4 index inside the span
                     const int r = f >> 1;
-                    const int spa = __shfl((int)pa, r, kWave), spb = __shfl((int)pb, r, kWave);
-#ifdef SJ_HOOK_STORE4        // (tools/dev_hooks.hpp: timing variants of this store; never defined in the product build)
-                    SJ_HOOK_STORE4(r, nrows, spa, spb, dst4, tab4, f);
-#else
-                    if (KEYS) {      // k == 4 <=> 3 hops: the row is (root flag, c1, c2, c3) / M
-                        const uint32_t key = (uint32_t)((f & 1) ? spb : spa);
-                        const uint32_t fm = (1u << a.key_shift) - 1u;
-                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (key != 0xFFFFFFFFu)
-                            v = make_float4(((key >> (3 * a.key_shift)) & 1u) ? 1.0f : 0.0f, lut[(key >> (2 * a.key_shift)) & fm],
-                                            lut[(key >> a.key_shift) & fm], lut[key & fm]);
-                        if (r < nrows) stream_store(dst4 + f, v);
-                    } else if (r < nrows) {
-                        stream_store(dst4 + f, tab4[(f & 1) ? spb : spa]);
-                    }
-#endif
+                    const int spa = __shfl(pa, r, kWave), spb = __shfl(pb, r, kWave);
+                    if (r < nrows) stream_store(dst4 + f, tab4[(f & 1) ? spb : spa]);
                 }
-            } else if (KEYS) {
-                // any other width: every lane unpacks its own row (no shuffles, no per-element index arithmetic) into the
-                // wave's LDS staging area, and the span leaves as whole, ALIGNED 16-byte words.  A row is 8*kc bytes, so a span
-                // begins on a 16-byte boundary of the output or 8 bytes past one (kc * row0 odd; any 4-byte offset if the caller's
-                // buffer is a view that starts there); the rows are staged at the same offset modulo 16, so that word f of the
-                // aligned body is one ds_read_b128 + one global_store_dwordx4 for lane f, with a head and / or tail of up to three
-                // floats from one lane each (k = 3: 96 words per full span instead of 192 8-byte ones; k = 5: 160 instead of 320)
-                // (KV = 3 / 5: the 2- and 4-hop configurations, k known at compile time -- the loops unroll, the shifts are immediates)
-                const int kc = KV > 0 ? KV : k;
-                const int w = 2 * kc;                                   // floats per output row
-                float *dst = a.out_xz + row0 * w;
-                const int mis = (int)(((uintptr_t)dst >> 2) & 3);       // floats between the 16-byte boundary in front and the span
-                const int head = (4 - mis) & 3;                         // floats of the span in front of its first aligned word
-                if (live) {
-                    float *mine = stage + mis + lane * w;
-#pragma unroll
-                    for (int c = 0; c < (KV > 0 ? KV : 16); ++c) {
-                        if (c >= kc) break;
-                        if (K64) {
-                            mine[c] = key_feature64((unsigned long long)pa, c, kc - 1, a.key_shift, lut);
-                            mine[kc + c] = key_feature64((unsigned long long)pb, c, kc - 1, a.key_shift, lut);
-                        } else {
-                            mine[c] = key_feature((uint32_t)pa, c, kc - 1, a.key_shift, lut);
-                            mine[kc + c] = key_feature((uint32_t)pb, c, kc - 1, a.key_shift, lut);
-                        }
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int total = nrows * w;                            // floats of the span
-                const int nbody = SJ_HOOK_SPAN_STORES(total > head ? (total - head) >> 2 : 0);       // aligned 16-byte words
-                const int ntail = total > head ? (total - head) & 3 : 0;
-                const float *src = stage + mis;                         // float i of the span
-                const float4 *src4 = reinterpret_cast<const float4 *>(src + head);   // stage, or stage + 4: 16-byte aligned
-                float4 *dst4 = reinterpret_cast<float4 *>(dst + head);
-                {
-                    const int i = kWave - 1 - lane;                     // the last lanes have the fewest body words
-                    if (i < head && i < total) __builtin_nontemporal_store(src[i], dst + i);
-                    const int t2 = kWave - 4 - lane, at = head + 4 * nbody;
-                    if (t2 >= 0 && t2 < ntail) __builtin_nontemporal_store(src[at + t2], dst + at + t2);
-                }
-                if (KV > 0) {
-#pragma unroll
-                    for (int q = 0; q < (KV + 1) / 2; ++q) {            // 64 rows x 2*KV floats = 32*KV words
-                        const int f = lane + q * kWave;
-                        if (f < nbody) stream_store(dst4 + f, src4[f]);
-                    }
-                } else
-                    for (int f = lane; f < nbody; f += kWave) stream_store(dst4 + f, src4[f]);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the next span of this wave re-uses the area
-                __builtin_amdgcn_wave_barrier();
             } else {
                 float *dst = a.out_xz + row0 * k2;
                 const int total = nrows * k2;
                 for (int f = lane; f < kWave * k2; f += kWave) {
                     const int r = (int)(((uint32_t)f * magic) >> 20);
                     const int c = f - r * k2;
-                    const int spa = __shfl((int)pa, r, kWave), spb = __shfl((int)pb, r, kWave);
+                    const int spa = __shfl(pa, r, kWave), spb = __shfl(pb, r, kWave);
                     if (f < total)
                         __builtin_nontemporal_store(a.table[(int64_t)(c < k ? spa : spb) * k + (c < k ? c : c - k)], dst + f);
                 }
@@ -369,93 +287,15 @@ __global__ __launch_bounds__(kJoinThreads) void sjoin_fill_kernel(const JoinArgs
 }
 
 // paired: the segment list consists of blocks of `pb` segments where block 2t+1 mirrors block 2t (own and
-// partner swapped) -- gather's [u.. | v..] and hgather's [U|w ; W|u ; V|w ; W|v].  One 256-lane workgroup takes
-// the segment (A,B) and its mirror (B,A): both SpG rows are read from HBM once into LDS and both output
-// blocks are produced from there (the generic kernel reads every row twice).
+// partner swapped) -- gather's [u.. | v..] and hgather's [U|w ; W|u ; V|w ; W|v].  One workgroup takes the segment (A,B) and
+// its mirror (B,A): both SpG rows are read from HBM once and both output blocks are produced from there (the generic kernel
+// above reads every row twice).  sjoin_keypair_kernel (LP keys, and -- TAB -- SFptr / table slots with the Z_SF table) and
+// sjoin_f64pair_kernel (the PPR payload) below; rounds 1-4's sjoin_pair_kernel staged BOTH rows and searched in BOTH directions.
 constexpr int kPairThreads = 256;
 #ifndef SJ_PAIR_THREADS      // lanes of sjoin_pair_kernel's workgroups (tools/ab.py --files=sjoin.hip)
 #define SJ_PAIR_THREADS 128   // 128 lanes per pair: twice the pairs with their row loads in flight per CU (-4..6 % against 256, r02s)
 #endif
 constexpr int kPairEmit = SJ_PAIR_THREADS;
-template <bool F64, int KV, bool KEYS = false, int NT = kPairEmit, bool K64 = false>
-__global__ __launch_bounds__(NT) void sjoin_pair_kernel(const JoinArgs a, int64_t pb) {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    static_assert(!K64 || (KEYS && !F64), "64-bit payloads are LP keys");
-    using Val = typename std::conditional<F64, double, typename std::conditional<K64, unsigned long long, int32_t>::type>::type;
-    Val *valA = (Val *)lds_raw;                       // [max_len]
-    Val *valB = valA + a.max_len;                     // [max_len]
-    int32_t *idsA = (int32_t *)(valB + a.max_len);    // [max_len]
-    int32_t *idsB = idsA + a.max_len;                 // [max_len]
-    // KEYS: [1 << key_shift] count -> count / num_walks (IEEE division, main.py:174).  One entry per value the SHIFT-bit field of
-    // a key can hold, not just per count <= num_walks: a caller-supplied key with a field in (M, 2^SHIFT) -- not a key of this
-    // num_walks -- then reads its own quotient instead of whatever lies behind the table
-    float *lut = (float *)(idsB + a.max_len);
-    // KEYS: [4 + 64 rows x 2k] floats per wave, every area on a 16-byte boundary (emit_rows stages a span at its output's offset mod 16)
-    const size_t stage_off = ((size_t)a.max_len * (2 * sizeof(Val) + 8) + ((size_t)4 << a.key_shift) + 15) & ~(size_t)15;
-    float *stage = (float *)(lds_raw + stage_off) + (threadIdx.x / kWave) * (kWave * 2 * a.k + 4);
-    if (KEYS)
-        for (int c = threadIdx.x; c < (1 << a.key_shift); c += NT) lut[c] = (float)c / (float)a.key_M;
-
-    SJ_HOOK_PAIR_ENTRY();
-    const int64_t wg = xcd_item(blockIdx.x, gridDim.x);
-    const int64_t p = wg / a.split;
-    const int part = (int)(wg % a.split);
-    if (p >= a.S / 2) return;
-    const int64_t j = (p / pb) * 2 * pb + (p % pb), j2 = j + pb;
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    const int64_t ra = a.own[j], rb = join_partner(a, j);
-    if (a.own[j2] != rb || join_partner(a, j2) != ra) {   // not a mirrored pair: the caller broke the precondition
-        if (tid == 0) atomicOr(&a.flags[3], 4);
-        return;
-    }
-    int64_t ab, na64, bb, nb64;
-    join_row(a, ra, ab, na64);
-    join_row(a, rb, bb, nb64);
-    if (na64 > a.max_len || nb64 > a.max_len) {
-        if (tid == 0) atomicOr(&a.flags[3], 1);
-        return;
-    }
-    const int na = (int)na64, nb = (int)nb64;
-    const Val *data = (const Val *)a.data;
-    const bool xl = !F64 && a.slot_id != nullptr;    // strided rows carry table slots: SFptr+1 on the way into LDS
-    for (int r = tid; r < na; r += NT) {
-        SJ_HOOK_ROW_LOAD(idsA, valA, ra, r, 3);
-        idsA[r] = stream_load(&a.indices[ab + r]);
-        Val v = stream_load(&data[ab + r]);
-        if (KEYS) {}
-        else if (xl) v = (Val)(a.slot_id[(int32_t)v] + 1);
-        else if (!F64) v = (Val)((int32_t)v + a.val_add);
-        valA[r] = v;
-    }
-    if (ra != rb) {
-        for (int r = tid; r < nb; r += NT) {
-            SJ_HOOK_ROW_LOAD(idsB, valB, rb, r, 2);
-            idsB[r] = stream_load(&a.indices[bb + r]);
-            Val v = stream_load(&data[bb + r]);
-            if (KEYS) {}
-            else if (xl) v = (Val)(a.slot_id[(int32_t)v] + 1);
-            else if (!F64) v = (Val)((int32_t)v + a.val_add);
-            valB[r] = v;
-        }
-    } else {   // (u,u): the second row is the first
-        idsB = idsA;
-        valB = valA;
-    }
-    __syncthreads();
-    SJ_HOOK_PAIR_ROWS_READY();
-    const int64_t oA = a.seg[j], oB = a.seg[j2];
-    const int k = a.k, k2 = 2 * k;
-    const uint32_t magic = k2 > 0 ? ((1u << 20) + (uint32_t)k2 - 1u) / (uint32_t)k2 : 0u;
-    const int chunksA = (na + kWave - 1) / kWave, chunksB = (nb + kWave - 1) / kWave;
-    for (int c = wave + part * (NT / kWave); c < chunksA + chunksB; c += a.split * (NT / kWave)) {   // every wave takes whole 64-row spans
-        if (c < chunksA)
-            emit_rows<F64, KV, Val, KEYS, K64>(a, lane, idsA, valA, na, idsB, valB, nb, (int64_t)c * kWave, oA, j, k, k2, magic, lut, stage);
-        else
-            emit_rows<F64, KV, Val, KEYS, K64>(a, lane, idsB, valB, nb, idsA, valA, na, (int64_t)(c - chunksA) * kWave, oB, j2, k, k2,
-                                               magic, lut, stage);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Key rows (the payload of a member is its LP key, 32 or 64 bits): the join of the on-demand step and of a keyed store.
 // Same work split as sjoin_pair_kernel -- one workgroup per mirrored pair, both rows staged in LDS, every wave emits whole
@@ -498,16 +338,50 @@ __device__ __forceinline__ float key_field(typename std::conditional<K64, unsign
 
 // one 64-row span of the output: the lane's row (own key ka, partner key kb; 0 = absent) unpacked into the wave's staging area at
 // the span's offset modulo 16 bytes, then out as aligned 16-byte words (a head / tail of up to three floats from one lane each)
-template <int KV, bool K64, typename Key>
+// TAB: the payload is not a key but SFptr+1 (0 = absent = the table's zero row): the two feature rows are read from the Z_SF table
+// (a few KB..MB, L2-resident; KV = 4: one 16-byte read each), the index pair itself leaves through out_idx when asked for
+template <int KV, bool K64, bool TAB, typename Key>
 __device__ __forceinline__ void emit_key_span(const JoinArgs &a, int lane, bool live, Key ka, Key kb, int nrows, int64_t row0, int64_t segj,
                                               int kc, const KeyQuot &q, float *stage) {
     const int w = 2 * kc, m = kc - 1, shift = a.key_shift;
+    if (TAB) {
+        if (a.out_idx && live) {
+            int2 v;
+            v.x = (int32_t)ka, v.y = (int32_t)kb;
+            stream_store(reinterpret_cast<int2 *>(a.out_idx) + row0 + lane, v);
+        }
+        if (!a.out_xz) {      // index pairs only: no table is consulted
+            if (a.out_segid && live) __builtin_nontemporal_store(segj, a.out_segid + row0 + lane);
+            return;
+        }
+        if (live && ((uint64_t)ka >= (uint64_t)a.table_rows || (uint64_t)kb >= (uint64_t)a.table_rows)) {
+            atomicOr(&a.flags[3], 2);  // SFptr outside the table: never read out of bounds
+            ka = kb = 0;
+        }
+    }
     float *dst = a.out_xz + row0 * w;
     const int mis = (int)(((uintptr_t)dst >> 2) & 3);       // floats between the 16-byte boundary in front and the span
     const int head = (4 - mis) & 3;                         // floats of the span in front of its first aligned word
     if (live) {
         float *mine = stage + mis + lane * w;
-        if (KV > 0) {
+        if (TAB && KV == 4) {
+            const float4 fa = reinterpret_cast<const float4 *>(a.table)[(uint32_t)ka], fb = reinterpret_cast<const float4 *>(a.table)[(uint32_t)kb];
+            mine[0] = fa.x, mine[1] = fa.y, mine[2] = fa.z, mine[3] = fa.w;
+            mine[4] = fb.x, mine[5] = fb.y, mine[6] = fb.z, mine[7] = fb.w;
+        } else if (TAB && KV > 0) {      // a compile-time width: all 2*KV reads leave together, then the writes
+            const float *ta = a.table + (int64_t)(uint32_t)ka * KV, *tb = a.table + (int64_t)(uint32_t)kb * KV;
+            float f[2 * (KV > 0 ? KV : 1)];
+#pragma unroll
+            for (int c = 0; c < KV; ++c) f[c] = ta[c], f[KV + c] = tb[c];
+#pragma unroll
+            for (int c = 0; c < 2 * KV; ++c) mine[c] = f[c];
+        } else if (TAB) {
+            const float *ta = a.table + (int64_t)(uint32_t)ka * kc, *tb = a.table + (int64_t)(uint32_t)kb * kc;
+            for (int c = 0; c < kc; ++c) {
+                mine[c] = ta[c];
+                mine[kc + c] = tb[c];
+            }
+        } else if (KV > 0) {
             float f[2 * (KV > 0 ? KV : 1)];
 #pragma unroll
             for (int c = 0; c < KV; ++c) {
@@ -550,11 +424,19 @@ __device__ __forceinline__ void emit_key_span(const JoinArgs &a, int lane, bool 
     if (a.out_segid && live) __builtin_nontemporal_store(segj, a.out_segid + row0 + lane);
 }
 
-template <int KV, int NT, bool K64>
+template <int KV, int NT, bool K64, bool TAB = false>
 __global__ __launch_bounds__(NT) void sjoin_keypair_kernel(const JoinArgs a, uint32_t pb, uint32_t pairs) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
+    static_assert(!(K64 && TAB), "a table row number is 32 bits");
     using Key = typename std::conditional<K64, unsigned long long, uint32_t>::type;
     constexpr int NW = NT / kWave;
+    // TAB: what a member carries becomes SFptr+1 on its way in -- a slot of the numbered table of distinct rows through its id plane
+    // (strided rows of the table form), or the payload + val_add (0: packed rows hold SFptr+1; 1: the table is indexed by slot + 1)
+    const bool xl = TAB && a.slot_id != nullptr;
+    auto sfptr = [&](Key v) -> Key {
+        if (!TAB) return v;
+        return xl ? (Key)(a.slot_id[(int32_t)v] + 1) : (Key)((int32_t)v + a.val_add);
+    };
     const int ML = a.max_len;
     // only T, the LONGER row of the pair, is staged: S's members are looked at by exactly one lane each and stay in registers
     Key *valT = (Key *)lds_raw;                       // [max_len] keys of T
@@ -646,6 +528,10 @@ __global__ __launch_bounds__(NT) void sjoin_keypair_kernel(const JoinArgs a, uin
         if (tid == 0) atomicOr(&a.flags[3], 1);
         return;
     }
+    if (TAB) {      // (only now: a first trip asked for before the lengths were known may hold anything past the row's end)
+        kA0 = tid < na ? sfptr(kA0) : (Key)0;
+        kB0 = (!same && tid < nb) ? sfptr(kB0) : (Key)0;
+    }
     if (same) idB0 = idA0, kB0 = kA0;      // (u,u): the second row is the first
     // roles: S = the shorter row, searched member by member in T = the longer one
     const bool swap = na > nb;
@@ -669,13 +555,13 @@ __global__ __launch_bounds__(NT) void sjoin_keypair_kernel(const JoinArgs a, uin
             if (r < ns) {
                 SJ_HOOK_FIRST_TRIP(sid[u], skey[u], r) {
                     sid[u] = stream_load(&a.indices[sb + r]);
-                    skey[u] = stream_load(&keys[sb + r]);
+                    skey[u] = sfptr(stream_load(&keys[sb + r]));
                 }
             }
             if (r < nt) {
                 SJ_HOOK_FIRST_TRIP(ti[u - 1], tk[u - 1], r) {
                     ti[u - 1] = stream_load(&a.indices[tb + r]);
-                    tk[u - 1] = stream_load(&keys[tb + r]);
+                    tk[u - 1] = sfptr(stream_load(&keys[tb + r]));
                 }
             }
         }
@@ -697,7 +583,7 @@ __global__ __launch_bounds__(NT) void sjoin_keypair_kernel(const JoinArgs a, uin
     for (int r = tid + kRegTrips * NT; r < nt; r += NT) {
         SJ_HOOK_ROW_LOAD(idsT, valT, tb, r, 3);
         idsT[r] = stream_load(&a.indices[tb + r]);
-        valT[r] = stream_load(&keys[tb + r]);
+        valT[r] = sfptr(stream_load(&keys[tb + r]));
         pk[r] = 0;
     }
     __syncthreads();
@@ -741,7 +627,7 @@ __global__ __launch_bounds__(NT) void sjoin_keypair_kernel(const JoinArgs a, uin
         Key key = 0;
         if (live) {
             id = stream_load(&a.indices[sb + t0 + lane]);
-            key = stream_load(&keys[sb + t0 + lane]);
+            key = sfptr(stream_load(&keys[sb + t0 + lane]));
         }
         int bx = 0, n = nt;
         SJ_HOOK_SEARCH_RANGE(bx, n);
@@ -755,7 +641,7 @@ __global__ __launch_bounds__(NT) void sjoin_keypair_kernel(const JoinArgs a, uin
         const bool hit = live && n == 1 && f == id;
         if (hit) pk[bx] = key;
         if (whole || (uint32_t)(c / NW) % (uint32_t)a.split == part)
-            emit_key_span<KV, K64, Key>(a, lane, live, key, hit ? g : (Key)0, ns - t0 < kWave ? ns - t0 : kWave, oS + t0, jS, kc, q, stage);
+            emit_key_span<KV, K64, TAB, Key>(a, lane, live, key, hit ? g : (Key)0, ns - t0 < kWave ? ns - t0 : kWave, oS + t0, jS, kc, q, stage);
     }
     __syncthreads();
     // ---- emit: S's spans out of the registers, then T's (every member's partner key is in pk), dealt so that the waves with
@@ -764,14 +650,14 @@ __global__ __launch_bounds__(NT) void sjoin_keypair_kernel(const JoinArgs a, uin
     for (int u = 0; u < kRegTrips; ++u) {
         const int c = wave + u * NW, t0 = c * kWave;
         if (c < chunksS && (whole || (uint32_t)u % (uint32_t)a.split == part))
-            emit_key_span<KV, K64, Key>(a, lane, t0 + lane < ns, skey[u], sgot[u], ns - t0 < kWave ? ns - t0 : kWave, oS + t0, jS, kc, q, stage);
+            emit_key_span<KV, K64, TAB, Key>(a, lane, t0 + lane < ns, skey[u], sgot[u], ns - t0 < kWave ? ns - t0 : kWave, oS + t0, jS, kc, q, stage);
     }
     const int rot = (NW - chunksS % NW) % NW;       // T's span c goes to wave (c + chunksS) % NW: the round robin simply goes on
     for (int c = (wave + rot) % NW + (int)part * NW; c < chunksT; c += a.split * NW) {
         const int t0 = c * kWave;
         const bool live = t0 + lane < nt;
         const int i = live ? t0 + lane : t0;
-        emit_key_span<KV, K64, Key>(a, lane, live, valT[i], pk[i], nt - t0 < kWave ? nt - t0 : kWave, oT + t0, jT, kc, q, stage);
+        emit_key_span<KV, K64, TAB, Key>(a, lane, live, valT[i], pk[i], nt - t0 < kWave ? nt - t0 : kWave, oT + t0, jT, kc, q, stage);
     }
 }
 
@@ -1221,6 +1107,37 @@ extern "C" int subgacc_sjoin_sizes_rows(const int32_t *row_len, int64_t n_rows, 
     return join_sizes(nullptr, row_len, n_rows, own, partner, S, out_seg, flags, workspace, workspace_bytes, stream);
 }
 
+// LDS of the per-wave staging areas of emit_key_span: [4 + 64 x 2k] floats per wave + the round-up to a 16-byte boundary
+static inline size_t key_stage_bytes(int waves, int k) { return 16 + (size_t)waves * (kWave * 2 * k + 4) * 4; }
+
+// Table payload (SFptr+1, or slots of the table of distinct rows) over a mirrored list: the pair kernel of the key rows with the
+// feature rows read from the Z_SF table instead of unpacked (round 5: the resident-store join of the reference's own flow,
+// gather(edge, z, encode=Z_SF), takes the same plan -- one search per pair, only the longer row in LDS).  vec4: k == 4, 16-byte rows.
+static int launch_table_pairs(JoinArgs &a, int64_t S, int64_t pair_block, bool vec4, void *stream, const char *who) {
+    const int k = a.out_xz ? a.k : 1;
+    const size_t lds = (size_t)a.max_len * 12 + key_stage_bytes(kPairEmit / kWave, k);
+    SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "%s: rows of %d members do not fit LDS", who, (int)a.max_len);
+    a.split = pair_split(S / 2);
+    const int64_t grid = xcd_grid(S / 2 * a.split);
+    SG_REQUIRE(grid < (1ll << 31) && S / 2 < (1ll << 31), SUBGACC_ERR_BADARG, "%s: too many segments in one call", who);
+    const uint32_t pairs = (uint32_t)(S / 2), pb = (uint32_t)pair_block;
+    hipStream_t s = (hipStream_t)stream;
+#define SG_TAB_LAUNCH(KVV)                                                                                                     \
+    do {                                                                                                                        \
+        if (lds > 64 * 1024)                                                                                                    \
+            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_keypair_kernel<KVV, kPairEmit, false, true>,                   \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
+        hipLaunchKernelGGL((sjoin_keypair_kernel<KVV, kPairEmit, false, true>), dim3((unsigned)grid), dim3(kPairEmit), lds, s, a, pb, pairs); \
+    } while (0)
+    if (vec4) SG_TAB_LAUNCH(4);
+    else if (a.out_xz && a.k == 3) SG_TAB_LAUNCH(3);      // the 2-hop configurations (collab-like)
+    else if (a.out_xz && a.k == 5) SG_TAB_LAUNCH(5);      // 4 hops
+    else SG_TAB_LAUNCH(0);
+#undef SG_TAB_LAUNCH
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}
+
 static int sjoin_fill_impl(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,
                                   const int32_t *spg_data_i32, const double *spg_data_f64, const int64_t *own, const int64_t *partner, int64_t S,
                                   const int64_t *seg, const float *table, int64_t table_rows, int32_t k,
@@ -1266,14 +1183,6 @@ static int sjoin_fill_impl(const int64_t *spg_indptr, int64_t n_rows, const int3
     SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_fill: too many segments in one call");
     hipStream_t s = (hipStream_t)stream;
     const bool vec4 = !f64 && out_xz && k == 4 && ((uintptr_t)table % 16 == 0) && ((uintptr_t)out_xz % 16 == 0);
-#define SG_PAIR_LAUNCH(F, KVV)                                                                                   \
-    do {                                                                                                          \
-        if (lds > 64 * 1024)                                                                                      \
-            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<F, KVV>,                             \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
-        hipLaunchKernelGGL((sjoin_pair_kernel<F, KVV>), dim3((unsigned)grid), dim3(kPairEmit), lds, s, a,         \
-                           pair_block);                                                                           \
-    } while (0)
     if (paired) {
         if (f64) {
             // float rows: T + its partner slots in LDS (20 bytes per member).  Short rows (the top-100 PPR store): ONE wave per pair
@@ -1291,13 +1200,11 @@ static int sjoin_fill_impl(const int64_t *spg_indptr, int64_t n_rows, const int3
                 hipLaunchKernelGGL((sjoin_f64pair_kernel<kPairEmit>), dim3((unsigned)grid), dim3(kPairEmit), flds, s, a, pb32, pairs);
             }
         }
-        else if (vec4) SG_PAIR_LAUNCH(false, 4);      // (256 lanes per pair, as the key form takes for long rows below, cost THIS form
-                                                      //  5 %: its emit gathers feature rows from the Z_SF table)
-        else SG_PAIR_LAUNCH(false, 0);
+        else
+            return launch_table_pairs(a, S, pair_block, vec4, stream, "sjoin_fill");
         SG_LAUNCH_CHECK();
         return SUBGACC_OK;
     }
-#undef SG_PAIR_LAUNCH
 #define SG_JOIN_LAUNCH(F, KVV)                                                                                   \
     do {                                                                                                          \
         if (lds > 64 * 1024)                                                                                      \
@@ -1345,31 +1252,11 @@ static int sjoin_fill_rows_impl(const int32_t *row_len, int64_t n_rows, int64_t 
     a.slot_id = uniq_table ? (const int32_t *)((const char *)uniq_table + (size_t)uniq_capacity * 16) : nullptr;
     a.val_add = uniq_table ? 0 : 1;
     a.key_M = a.key_m = a.key_shift = 0;
-    const size_t lds = (size_t)a.max_len * 16;
-    SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "sjoin_fill_rows: rows of %lld members do not fit LDS",
-               (long long)row_stride);
-    a.split = pair_split(S / 2);
-    const int64_t grid = xcd_grid(S / 2 * a.split);
-    SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_fill_rows: too many segments in one call");
-    hipStream_t s = (hipStream_t)stream;
     const bool vec4 = out_xz && k == 4 && ((uintptr_t)table % 16 == 0) && ((uintptr_t)out_xz % 16 == 0);
-    if (vec4) {
-        if (lds > 64 * 1024)
-            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((sjoin_pair_kernel<false, 4>), dim3((unsigned)grid), dim3(kPairEmit), lds, s, a, pair_block);
-    } else {
-        if (lds > 64 * 1024)
-            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pair_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((sjoin_pair_kernel<false, 0>), dim3((unsigned)grid), dim3(kPairEmit), lds, s, a, pair_block);
-    }
-    SG_LAUNCH_CHECK();
-    return SUBGACC_OK;
+    return launch_table_pairs(a, S, pair_block, vec4, stream, "sjoin_fill_rows");
 }
 
 // key payload (strided rows of a transient batch, or a packed store whose payload was re-keyed): shared launcher
-// LDS of the per-wave staging areas of emit_rows' KEYS path: [4 + 64 x 2k] floats per wave + the round-up to a 16-byte boundary
-static inline size_t key_stage_bytes(int waves, int k) { return 16 + (size_t)waves * (kWave * 2 * k + 4) * 4; }
-
 static int launch_key_join(JoinArgs &a, int32_t num_walks, int32_t num_steps, int64_t S, int64_t pair_block, void *stream,
                            const char *who, bool wide = false) {
     const int shift = subgacc_key_shift(num_walks, num_steps);

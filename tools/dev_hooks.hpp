@@ -9,8 +9,8 @@
 //                             7 per-phase cycle shares (tools/walk_phases.py) | 8 no registration in the HBM table
 //   SG_EXPERIMENT (walk_rows.hip) 9 the last hop's read hits L2 (no missed line) | 10 every later hop's does
 //   SG_STOP_AFTER = k         every workgroup of walk_sets_kernel / walk_rows_kernel ends at stamp k (tools/walk_insts.sh)
-//   SJ_EXPERIMENT (sjoin.hip) 1 no search | 2 no output stores | 3 stores without the feature-table read | 4 no row loads
-//                             8 plain (cached) stores | 5 chain only | 6 entry only | 7 staged spans not stored
+//   SJ_EXPERIMENT (sjoin.hip) 1 no search | 4 no row loads | 5 ends when the rows stand in LDS | 6 ends at entry
+//                             7 spans unpacked and staged but not stored      (rounds 1-4 also had 2 / 3 / 8: store variants of the old kernel)
 #pragma once
 #define SG_DEV_HOOKS 1
 #ifndef SG_EXPERIMENT
@@ -116,13 +116,6 @@
 #define SJ_HOOK_SEARCH_RANGE(lo, hi) hi = 0
 #else
 #define SJ_HOOK_SEARCH_RANGE(lo, hi)
-#endif
-#if SJ_EXPERIMENT == 2
-#define SJ_HOOK_STORE4(r, nrows, spa, spb, dst4, tab4, f) if ((r) < (nrows) && (spa) == -12345) (dst4)[f] = (tab4)[((f) & 1) ? (spb) : (spa)]
-#elif SJ_EXPERIMENT == 3
-#define SJ_HOOK_STORE4(r, nrows, spa, spb, dst4, tab4, f) if ((r) < (nrows)) (dst4)[f] = make_float4((float)(spa), (float)(spb), 0.f, 0.f)
-#elif SJ_EXPERIMENT == 8
-#define SJ_HOOK_STORE4(r, nrows, spa, spb, dst4, tab4, f) if ((r) < (nrows)) (dst4)[f] = (tab4)[((f) & 1) ? (spb) : (spa)]
 #endif
 #if SJ_EXPERIMENT == 4
 #define SJ_HOOK_ROW_LOAD(ids, val, row, r, mul)          \

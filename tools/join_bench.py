@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Dev-only: the join kernel of the on-demand step ALONE, on the real rows of one batch, across library builds.
 
-    python tools/join_bench.py [--wl=collab,twitter,cit2,cit2m4,ppa] [--libs=-,tools/build/libsubgacc_x.so,...] [--n=50] [--reps=2]
+    python tools/join_bench.py [--wl=collab,twitter,cit2,cit2m4,ppa] [--libs=-,tools/build/libsubgacc_x.so,...] [--n=50] [--reps=2] [--store=1]
+(--store=1: the resident-store joins of the reference's flow -- table and keyed -- instead of the on-demand step's)
 
 One process per (workload, library): builds the preset graph, runs one buffered step (so that the step buffers hold the walk
 kernel's rows and the segment pointers), then times `n` launches of subgacc_sjoin_fill_keyrows(64) over those buffers with HIP
@@ -74,7 +75,43 @@ def one(wl, n):
           f"{abytes / ms / 1e9:.2f} TB/s  frac {abytes / (ms * 1e-3) / 8e12:.3f}", flush=True)
 
 
+def one_store(wl, n):
+    """the reference's own flow: subg_matrix over all N nodes once, then gather(edge, z, encode=Z_SF) per batch -- the fill kernel of
+    the TABLE join (payload SFptr+1, features from the Z_SF table) and of the keyed store, HIP events around the fill launch"""
+    import numpy as np
+    import torch
+    import bench
+    import surel_plus_amd as sp
+    from surel_plus_amd import sampler as sampler_mod
+    from surel_plus_amd.graphs import preset_graph, query_pairs
+    preset, M, k, _, pos = bench.WORKLOADS[wl]
+    dev = torch.device("cuda", 0)
+    csr = preset_graph(preset, device=dev)
+    z, enc = sp.subg_matrix(csr, np.arange(csr.num_nodes), num_walks=M, num_steps=k, rng="philox", seed=3)
+    table = torch.from_numpy(enc.astype(np.float32) / np.float32(M)).to(dev)
+    zk = z.keyed(enc, M)
+    B = 65536
+    e = query_pairs(csr, B, seed=1, device=dev, pos_frac=pos)
+    buf = torch.empty(2 * B * z.max_len * 2 * k, dtype=torch.float32, device=dev)
+    for name, store, encode in (("table", z, table), ("keyed", zk, zk.slot_table())):
+        timer = bench.KernelTimer()
+        sampler_mod.KERNEL_TIMER = timer
+        rows = None
+        for it in range(n + 5):
+            timer.enabled = it >= 5
+            xz, ind = sp.gather(e, store, dev, ptr=True, encode=encode, out=buf, lazy=True)
+        torch.cuda.synchronize()
+        rows = int(ind[-1].item())
+        ms = timer.mean_ms("sjoin_fill")[0]
+        abytes = B * 64 + rows * (8 + 8 * k)
+        print(f"{wl:8s} {name:6s} store lib={os.environ.get('SUBGACC_LIB', '-'):40s} rows/pair {rows / B:6.1f}  fill {ms:.4f} ms  "
+              f"{abytes / ms / 1e9:.2f} TB/s  frac {abytes / (ms * 1e-3) / 8e12:.3f}", flush=True)
+    sampler_mod.KERNEL_TIMER = None
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--one-store":
+        return one_store(sys.argv[2], int(sys.argv[3]))
     if len(sys.argv) > 1 and sys.argv[1] == "--build":
         return build(sys.argv[2], sys.argv[3], tuple(sys.argv[4].split(",")) if len(sys.argv) > 4 else ("sjoin.hip",))
     if len(sys.argv) > 1 and sys.argv[1] == "--one":
@@ -87,7 +124,7 @@ def main():
                 env.pop("SUBGACC_LIB", None)
                 if libp != "-":
                     env["SUBGACC_LIB"] = os.path.join(ROOT, libp)
-                subprocess.call([sys.executable, os.path.abspath(__file__), "--one", wl, opts.get("n", "50")], env=env)
+                subprocess.call([sys.executable, os.path.abspath(__file__), "--one-store" if "store" in opts else "--one", wl, opts.get("n", "50")], env=env)
 
 
 if __name__ == "__main__":
