@@ -368,6 +368,9 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W, extr
         torch.cuda.synchronize()
         prep_s = time.perf_counter() - t_prep
         del csr
+    import gc
+    gc.collect()          # (the previous pass's garbage: collected here, not by a pause inside this pass's regions -- see bench_lp)
+    torch.cuda.synchronize()
     gens = [torch.Generator(device=dev).manual_seed(1000 * rank + s) for s in range(min(K + W, 103))]
     all_edges = [torch.randint(0, N, (2, B), device=dev, generator=g) for g in gens]
 
@@ -510,6 +513,12 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
     global STRIDED, DEDUP
     from surel_plus_amd.graphs import preset_graph, query_pairs
     preset, M, k, desc, pos_frac = WORKLOADS[name]
+    # what the previous pass left behind (hundreds of HIP events, step buffers, its graph) is collected NOW, not by a collector
+    # pause somewhere inside this pass's timed region (r19b: the first pass after the headline lost ~35 ms that way, all of it
+    # between an event and the launch it brackets -- its walk kernel "took" 1.5x its time)
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
     if name.startswith("twitter"):      # 12 GB of CSR (+ transients of its generation) + ~8 GB of step buffers per rank: look before building
         free, total = torch.cuda.mem_get_info(dev)     # (the 47 GB of hop records are the library's call: DeviceCSR.hop_records
         need = int(24e9 * args.scale) + int(8e9)       #  builds them only within a quarter of the free memory)
@@ -582,10 +591,15 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
     torch.cuda.synchronize()
     # a pass that follows seconds of host-only work (the CPU baseline) finds the GPU clocked down: its first region read 36 % low and
     # the HIP events of its first launches doubled the kernel's mean.  Part of set-up, outside every clock: steps until wake_s is over
-    t_wake = time.perf_counter()
-    while time.perf_counter() - t_wake < wake_s:
-        run_steps(range(W, W + 10))
+    # (the clocks come back over a second or more: steps in chunks of 20 until three chunks in a row agree within 2 %, 3 s at most)
+    t_wake, chunks = time.perf_counter(), []
+    while wake_s > 0 and time.perf_counter() - t_wake < 3.0:
+        t_c = time.perf_counter()
+        run_steps(range(W, W + 20))
         torch.cuda.synchronize()
+        chunks.append(time.perf_counter() - t_c)
+        if time.perf_counter() - t_wake >= wake_s and len(chunks) >= 3 and max(chunks[-3:]) <= 1.02 * min(chunks[-3:]):
+            break
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -1409,7 +1423,7 @@ _T0 = time.perf_counter()
 def summary(o):
     """what an `other_workloads` entry keeps of a full line"""
     keep = {k_: o[k_] for k_ in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype")}
-    keep["config"] = {k_: o["config"].get(k_) for k_ in ("workload", "pairs_per_step_per_gpu", "rng", "set_members_last_step",
+    keep["config"] = {k_: o["config"].get(k_) for k_ in ("workload", "pairs_per_step_per_gpu", "rng", "set_members_last_step", "device_allocs_in_timed_region", "host_step_ms_min_median_max",
                                                          "distinct_lp_rows_last_step", "xz_rows_last_step", "graph_nnz", "spg_layout", "stage_ms", "two_stream_loop", "dedup_roots_loop", "spg_members",
                                                          "timed_loop", "region_pairs_per_s", "pairs_per_s_min", "pairs_per_s_median", "pairs_per_s_max",
                                                          "offline_ppr_stage_s", "join_call_ms_three_launches",
@@ -1512,7 +1526,13 @@ def main():
                 others[key] = {"skipped": f"time budget of {budget_s:.0f} s for the whole run reached"}
                 continue
             try:
-                torch.cuda.empty_cache()
+                # Blocks of the earlier passes are handed back to the driver only where the next pass needs the room (twitter: 12 GB of
+                # CSR + 47 GB of hop records).  The driver wipes freed VRAM in the background: right after torch.cuda.empty_cache()
+                # released ~10 GB, the first 100-step region of whatever pass came next ran 25-30 % slow with its walk kernel at 1.5x
+                # its time, whichever workload that was (r19b logs) -- so: no release where none is needed, and a pause after one
+                if wl.startswith("twitter"):
+                    torch.cuda.empty_cache()
+                    time.sleep(1.0)
                 # every pass: three regions of 100 steps (>= 40 ms each; the join-only PPR pass 300), the MEDIAN is its value
                 Ko, Wo = 100, 3
                 if WORKLOADS[wl][0] is None:
@@ -1526,7 +1546,8 @@ def main():
                                  # a 2-hop step is ~0.4 ms of kernels: replayed as one HIP graph, or the host is what gets measured
                                  captured=(WORKLOADS[wl][2] <= 3))
                 others[key] = summary(o)
-                note(f"{wl} ({rng_o}): {o['value'] / 1e6:.1f} M pairs/s")
+                note(f"{wl} ({rng_o}): {o['value'] / 1e6:.1f} M pairs/s  regions {[round(v / 1e6, 1) for v in o['config'].get('region_pairs_per_s', [])]}"
+                     f"  walk {o['roofline'].get('kernel_ms') or 0:.3f} ms")
                 if wl == "collab" and not args.no_cpu_baseline:
                     from surel_plus_amd.graphs import preset_graph
                     try:

@@ -26,4 +26,5 @@ cp profiles/traffic.json gpurun_out/${TAG}_traffic.json
 # where the waves of the headline step's kernels spend their cycles (the 3-hop walk kernel's instruction / LDS floor, the join)
 bash tools/pmc_sq.sh gpurun_out/${TAG}_sq_cit2_passes --workload cit2 > gpurun_out/${TAG}_sq_cit2.csv 2> gpurun_out/${TAG}_sq_cit2.err
 ( time python bench.py --steps 20 --warmup 5 ) > gpurun_out/${TAG}_bench_cit2.json 2> gpurun_out/${TAG}_bench_cit2.err
+cp bench_detail.json gpurun_out/${TAG}_bench_cit2_detail.json
 tail -c 1500 gpurun_out/${TAG}_bench_cit2.json; tail -5 gpurun_out/${TAG}_bench_cit2.err
