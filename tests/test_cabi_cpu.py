@@ -58,3 +58,29 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "oracle/" not in txt, f
+
+
+def test_join_descriptor_layout_matches_the_header(tmp_path, L):
+    """struct subgacc_join_desc (ABI 6) as gcc lays it out from include/subgacc.h == the ctypes mirror, field by field: a binding
+    that disagrees about one offset would hand the kernels a wrong pointer.  And the entry point refuses a descriptor of another
+    size or with neither / both row layouts before anything is launched (no GPU needed for that)."""
+    import ctypes as C
+    import subprocess
+    from surel_plus_amd import _lib
+    names = [f[0] for f in _lib.JoinDesc._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "subgacc.h"\nint main(void) {\n'
+                   '  printf("%zu\\n", sizeof(subgacc_join_desc));\n' +
+                   "".join(f'  printf("%zu\\n", offsetof(subgacc_join_desc, {n}));\n' for n in names) + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", str(src), "-I" + os.path.join(ROOT, "include"), "-o", str(exe)])
+    out = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert out[0] == C.sizeof(_lib.JoinDesc)
+    assert out[1:] == [getattr(_lib.JoinDesc, n).offset for n in names]
+    d = _lib.JoinDesc()
+    d.struct_bytes = 8
+    assert L.subgacc_sjoin_fill_v2(C.byref(d), None) == _lib.ERR_BADARG
+    assert b"descriptor" in L.subgacc_last_error()
+    d.struct_bytes = C.sizeof(_lib.JoinDesc)
+    assert L.subgacc_sjoin_fill_v2(C.byref(d), None) == _lib.ERR_BADARG          # neither row_off nor row_len
+    assert L.subgacc_sjoin_fill_v2(None, None) == _lib.ERR_BADARG

@@ -121,3 +121,53 @@ def test_gather_many_refuses_what_it_cannot_honour_and_captured_join_takes_a_str
     assert torch.equal(xz, ref[1][0]) and torch.equal(ind, ref[1][1])
     xz, ind = cj(batches[2]).finish()                                  # and without: the current stream, as before
     assert torch.equal(xz, ref[2][0]) and torch.equal(ind, ref[2][1])
+
+
+@pytest.mark.parametrize("payload", ["table3", "table4", "table7", "keyed", "float"])
+@pytest.mark.parametrize("B", [37, 3000])          # 37 pairs: two workgroups per pair (split), 3,000: one
+def test_pair_join_at_every_span_and_trip_boundary(sp, payload, B):
+    """sjoin_keypair_kernel / sjoin_f64pair_kernel hold the shorter row S of a pair in registers (four trips of NT members), stage
+    the longer row T, search once, then emit 64-row spans: rows of 0 / 1 / 63 / 64 / 65 / 127 / 128 / 129 / 255 / 256 / 257 / 511 /
+    512 / 513 / 600 / 1,030 / 1,500 / 3,000 members -- every span and trip boundary, rows beyond the register trips (the
+    span-by-span path), empty rows, (u,u) pairs, short-with-long and long-with-short pairs -- against the oracle, for every payload
+    form of the resident store, with segment pointers and with segment ids."""
+    lens = np.array([0, 1, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 600, 1030, 1500, 3000])
+    rs = np.random.default_rng(7)
+    n_rows, n_cols = 400, 6000
+    row_len = rs.choice(lens, n_rows)
+    row_len[: lens.size] = lens
+    indptr = np.zeros(n_rows + 1, np.int64)
+    np.cumsum(row_len, out=indptr[1:])
+    ids = np.concatenate([np.sort(rs.choice(n_cols, L, replace=False)) for L in row_len]).astype(np.int32)
+    X = int(indptr[-1])
+    e = rs.integers(0, n_rows, (2, B))
+    e[:, : lens.size] = np.stack([np.arange(lens.size), np.arange(lens.size)[::-1]])        # every length against every other
+    e[1, lens.size: lens.size + 6] = e[0, lens.size: lens.size + 6]                         # (u,u)
+    M = 200
+    if payload == "float":
+        data = rs.random(X) * 3.0
+        z = sp.SpG(torch.from_numpy(indptr).cuda(), torch.from_numpy(ids).cuda(), torch.from_numpy(data).cuda())
+        enc_dev, enc_host = None, None
+    else:
+        k = {"table3": 3, "table4": 4, "table7": 7, "keyed": 4}[payload]
+        c = 500
+        counts = rs.integers(0, M + 1, (c + 1, k)).astype(np.int64)
+        counts[0] = 0
+        counts[:, 0] = (rs.integers(0, 2, c + 1) * M)
+        counts[0, 0] = 0
+        counts[1:, 1] = np.maximum(counts[1:, 1], 1)                                         # a real LP row is never all zero
+        data = rs.integers(1, c + 1, X).astype(np.int32)
+        z = sp.SpG(torch.from_numpy(indptr).cuda(), torch.from_numpy(ids).cuda(), torch.from_numpy(data).cuda())
+        enc_host = counts.astype(np.float32) / np.float32(M)
+        if payload == "keyed":
+            z = z.keyed(counts.astype(np.int16), M)
+            enc_dev = z.slot_table()
+        else:
+            enc_dev = torch.from_numpy(enc_host).cuda()
+    spg_host = (indptr, ids, data)
+    edge = torch.from_numpy(e).cuda()
+    for ptr in (True, False):
+        xz, ind = sp.gather(edge, z, "cuda", ptr=ptr, encode=enc_dev)
+        oxz, oind = oracle.gather(e, spg_host, ptr=ptr, encode=enc_host)
+        assert np.array_equal(ind.cpu().numpy(), oind)
+        assert np.array_equal(xz.cpu().numpy(), oxz)
