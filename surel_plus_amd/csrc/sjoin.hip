@@ -3,11 +3,19 @@
 // Replaces the SciPy sparse arithmetic of train.py:13-45 (gather), :48-72 (hgather), :75-111
 // (bgather/pgather): `x[edge[0]]`, `xr.multiply(lmask) + lmask`, `.data - 1`, `np.stack`, `encode[...]`.
 // Those five temporaries and the host->device upload of the index array collapse into one kernel over a
-// device-resident SpG:  one wave64 workgroup per output segment (own row, partner row); the partner row's
-// sorted ids and payload are staged in LDS with coalesced loads, every lane takes one member of the own
-// row, finds it in the partner row by binary search in LDS (sorted-set intersection), and writes the
-// feature pair straight from the Z_SF table (L2-resident, a few KB..MB) -- the [R,2] index array of the
-// reference never exists in memory unless asked for.
+// device-resident SpG.  A join is a list of segments (own row, partner row); every member of the own row leaves as one output
+// row (value of the member, value of the same node in the partner row or "absent").  Kernels:
+//   sjoin_seg_reduce / sjoin_seg_scan   segment pointers = exclusive scan of the own rows' lengths (train.py:20-22)
+//   sjoin_keypair_kernel                mirrored lists (gather / hgather / nb batches at once): one workgroup per PAIR of rows, the
+//                                       longer row staged in LDS, the shorter one in registers, ONE sorted-set search per pair;
+//                                       payload = LP key (32 / 64 bits: the feature row is unpacked, count / num_walks by an
+//                                       fma-refined reciprocal) or -- TAB -- SFptr+1 / table slot with the Z_SF table
+//   sjoin_f64pair_kernel                the same plan for the PPR encoder's float payload (train.py:39-43)
+//   sjoin_fill_kernel                   any other list: one wave per segment, the partner row in LDS (or searched in place when it
+//                                       does not fit)
+//   sjoin_counts_kernel / sjoin_pairs_kernel   the count and pair forms of the join
+// One entry point, subgacc_sjoin_fill_v2(descriptor) (ABI 6); the entry points of ABI 1-5 forward to it (end of file).
+// The [R,2] index array of the reference never exists in memory unless asked for (out_idx).
 #include <cstdlib>
 #include "common.hpp"
 #include "blockscan.hpp"
