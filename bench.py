@@ -114,13 +114,20 @@ def line_probe_lib():
 
 
 def kernel_source_sha():
-    """identifies the kernels a PMC traffic figure belongs to (the GPU box has no .git): sha256 over csrc + the header"""
+    """identifies the kernels a PMC traffic figure belongs to (the GPU box has no .git): sha256 over the CODE of csrc + the header
+    -- comments and white space are taken out first, so that a reworded comment does not orphan a measurement"""
     import glob
     import hashlib
+    import re
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "surel_plus_amd", "csrc", "*.h*")) + [os.path.join(ROOT, "include", "subgacc.h")]):
-        h.update(open(f, "rb").read())
+        text = open(f, "r", errors="replace").read()
+        text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)          # block comments
+        text = re.sub(r"//[^\n]*", " ", text)                       # line comments (no string literal of these sources holds "//")
+        h.update(os.path.basename(f).encode() + b"\0" + " ".join(text.split()).encode())
     return h.hexdigest()[:16]
+
+
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # SUBGACC_FUSED: 1 = the walk kernel also emits finished SpG rows (walk_spg), 0 = general pipeline, unset = the
 # library's choice (fused for walks of >= 3 hops)

@@ -226,7 +226,7 @@ int subgacc_spg_build(const int64_t *row_off, int64_t n, const int32_t *ids, con
  * per member w of row own[j] in ascending id order with the pair
  *     ( value_own(w), value_partner(w) or 0 ).
  * gather(edge[2,B]):  own = [u..,v..], partner = [v..,u..];  hgather: [u,w,v,w] / [w,u,w,v].
- * ABI 4: with a mirrored list (pair_block > 0, see subgacc_sjoin_fill) `partner` may be NULL in every fill entry point: the
+ * ABI 4: with a mirrored list (pair_block > 0, see subgacc_join_desc) `partner` may be NULL in every fill entry point: the
  * partner of segment j is then the own row of j's mirror (own[j + pair_block] in an even block, own[j - pair_block] in an odd
  * one) -- gather() passes its [2,B] endpoint tensor as `own` as it stands and builds no second list.
  * ------------------------------------------------------------------------------------------- */
@@ -237,53 +237,88 @@ int subgacc_spg_build(const int64_t *row_off, int64_t n, const int32_t *ids, con
 size_t subgacc_sjoin_workspace_bytes(int64_t S);
 int subgacc_sjoin_sizes(const int64_t *spg_indptr, int64_t n_rows, const int64_t *own, const int64_t *partner, int64_t S,
                         int64_t *out_seg, int32_t *flags, void *workspace, size_t workspace_bytes, void *stream);
-/* Fill R = out_seg[S] rows.
- *   spg_data_i32 (payload = SFptr+1) xor spg_data_f64 (PPR payload, train.py:39-43)
- *   table f32 [table_rows, k] (Z_SF with the zero row) or NULL
- *   out_xz   f32  [R,2,k] = table[pair] (int payload)  |  [R,2,1] = float(pair) (f64 payload)
- *   out_idx  i32  [R,2]  the raw index pairs (optional, int payload only)
- *   out_segid i64 [R]    segment id of every row (`ptr=False`, train.py:25-30) (optional)
- * max_len >= longest SpG row touched (a longer partner row sets flags[3] |= 1 and its segment is skipped); rows that
- *   do not fit LDS (max_len above ~10k int / ~6.8k float entries) take a kernel that searches them in place.
- * pair_block = 0: segments are independent.  pair_block = P > 0: the list is made of blocks of P segments
- *   and block 2t+1 mirrors block 2t (own/partner swapped) -- gather passes P = B, hgather P = B; the mirrored
- *   segments are then produced together and every SpG row is read once (flags[3] |= 4 if the list is not
- *   mirrored like that). */
+int subgacc_sjoin_sizes_rows(const int32_t *row_len, int64_t n_rows, const int64_t *own, const int64_t *partner, int64_t S,
+                             int64_t *out_seg, int32_t *flags, void *workspace, size_t workspace_bytes, void *stream);   /* strided rows */
+
+/* ABI 6 -- ONE entry point fills the R = out_seg[S] rows of every form of the join: the descriptor states what the store looks
+ * like, what a member's payload is, which segments to join and which outputs are wanted; subgacc_sjoin_fill_v2 dispatches.
+ *
+ *   store      row_off [n_rows+1] (packed rows: the SpG of random_walks.py:79) XOR row_len [n_rows] + row_stride (strided rows: the
+ *              form subgacc_walk_spg leaves a transient batch in -- row r = [r*row_stride, +row_len[r]) -- joined where they lie, no
+ *              packed copy); ids: member ids, ascending inside a row; max_len >= the longest row touched (packed rows; a longer row
+ *              sets flags[3] |= 1 and its segment is skipped; strided rows: row_stride is the bound).  Mirrored lists of rows that
+ *              do not fit LDS (~13k members) and lists that are not mirrored take a one-segment-per-wave kernel; rows beyond that
+ *              (~20k int / ~13k float members) are searched in place.
+ *   payload    SUBGACC_JOIN_SFPTR  int32: SFptr+1 (packed rows) or a slot of `uniq_table` (strided rows: slots become SFptr+1 through
+ *                                  the numbered table's id plane on their way in; uniq_table = NULL: `table` is indexed by slot+1
+ *                                  itself, subgacc_unpack_lp(zero_row = 1)); feature rows are gathered from table f32 [table_rows, k]
+ *                                  (Z_SF with the zero row; an SFptr outside it is never read: flags[3] |= 2)
+ *              SUBGACC_JOIN_F64    double: the PPR encoder's score (train.py:39-43); xz is [R,2,1] = (float(own), float((partner or
+ *                                  0.0) + 1.0 - 1.0)), the SciPy expression of train.py:33 in double
+ *              SUBGACC_JOIN_KEY32  int32 LP key (key = sum_j count_j << ((num_steps - j) * SHIFT), bit num_steps*SHIFT set on a root's
+ *                                  own row, subg_acc.c:900-955): a feature row is the key's unpacked counts / num_walks -- what
+ *                                  subgacc_unpack_lp writes into the feature table, computed on the fly (main.py:174's IEEE division);
+ *                                  partner absent = the zero row.  Needs num_steps*SHIFT+1 <= 31.  Packed rows: a store re-keyed once
+ *                                  (SpG.keyed); strided rows: what subgacc_walk_spg(uniq_table = NULL) writes
+ *              SUBGACC_JOIN_KEY64  uint64 LP key: the strided rows of subgacc_walk_keyrows64 (4 hops, 32..63 bits)
+ *   segments   own / partner [S], seg [S+1] from subgacc_sjoin_sizes(_rows); pair_block = 0: independent segments (SFPTR / F64, packed
+ *              rows); pair_block = P > 0: blocks of P segments, block 2t+1 mirrors block 2t (own / partner swapped) -- gather passes
+ *              P = B, hgather P = B, nb batches at once P = B -- the two rows of a pair are read once and both blocks produced from
+ *              there (flags[3] |= 4 if the list is not mirrored like that); `partner` may then be NULL.  Strided rows, keys, the count
+ *              and the pair form: mirrored lists only
+ *   form       SUBGACC_JOIN_ROWS   out_xz f32 [R,2,k] and / or out_idx i32 [R,2] (the raw index pairs, SFPTR only), out_segid i64 [R]
+ *                                  (segment id of every row, `ptr=False`, train.py:25-30; optional; not with strided rows)
+ *              SUBGACC_JOIN_COUNTS out_counts f32 [S, table_rows]: how often LP row p (SFptr+1, 0 = partner absent) occurs in either
+ *                                  feature slot of segment j, so that segment_sum_j(MLP(xz).sum(-2)) == out_counts[j] @ MLP(Z_SF)
+ *                                  (model.py:78-83); 16*max_len + 8*table_rows bytes of LDS <= 160 KiB (SUBGACC_ERR_LDS)
+ *              SUBGACC_JOIN_PAIRS  for aggregations that are not linear in the rows (the attention gate, model.py:59-62): segment j as
+ *                                  its DISTINCT index pairs with multiplicities, in a reproducible order, at rows [seg[j], seg[j] +
+ *                                  out_cnt[j]) of out_pairs i32 [R,2], out_mult i32 [R]; out_cnt i32 [S]; max_len <= 1024
+ *   struct_bytes = sizeof(subgacc_join_desc): a descriptor of another size is refused (SUBGACC_ERR_BADARG); fields a form does not
+ *   read must be zero / NULL. */
+enum { SUBGACC_JOIN_SFPTR = 0, SUBGACC_JOIN_F64 = 1, SUBGACC_JOIN_KEY32 = 2, SUBGACC_JOIN_KEY64 = 3 };
+enum { SUBGACC_JOIN_ROWS = 0, SUBGACC_JOIN_COUNTS = 1, SUBGACC_JOIN_PAIRS = 2 };
+typedef struct subgacc_join_desc {
+    int32_t struct_bytes, form, payload_kind, max_len;
+    const int64_t *row_off;
+    const int32_t *row_len;
+    int64_t row_stride, n_rows;
+    const int32_t *ids;
+    const void *payload;
+    const void *uniq_table;
+    int64_t uniq_capacity;
+    const int64_t *own, *partner;
+    int64_t S;
+    const int64_t *seg;
+    int64_t pair_block;
+    const float *table;
+    int64_t table_rows;
+    int32_t k, num_walks, num_steps, reserved;
+    float *out_xz;
+    int32_t *out_idx;
+    int64_t *out_segid;
+    float *out_counts;
+    int32_t *out_pairs, *out_mult, *out_cnt;
+    int32_t *flags;
+} subgacc_join_desc;
+int subgacc_sjoin_fill_v2(const subgacc_join_desc *d, void *stream);
+
+/* The entry points of ABI 1-5 for the same joins: forwards that fill in a descriptor (a client built against them keeps working;
+ * new clients need subgacc_sjoin_fill_v2 only).  In the order: packed SFPTR / F64 rows; strided SFPTR rows; the count form; the
+ * pair form (key payloads: further down, with the walk entry points that write them). */
 int subgacc_sjoin_fill(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices, const int32_t *spg_data_i32,
                        const double *spg_data_f64, const int64_t *own, const int64_t *partner, int64_t S,
                        const int64_t *seg, const float *table, int64_t table_rows, int32_t k, float *out_xz,
                        int32_t *out_idx, int64_t *out_segid, int32_t max_len, int64_t pair_block, int32_t *flags,
                        void *stream);
-
-/* The same join over STRIDED rows -- the form subgacc_walk_spg leaves its output in: row r = row_ids / row_slot
- * [r*row_stride, +row_len[r]), sorted by node id, payload = slot in `uniq_table` (numbered by subgacc_uniq_number).
- * A transient batch is joined straight from there: no packed CSR copy (subgacc_compact_rows) is made, slots become
- * SFptr+1 on their way into LDS.  uniq_table = NULL: `table` is indexed by slot+1 itself (subgacc_unpack_lp over the
- * table's key plane, zero_row = 1) and no numbering is consulted.  Mirrored segment lists only (pair_block > 0). */
-int subgacc_sjoin_sizes_rows(const int32_t *row_len, int64_t n_rows, const int64_t *own, const int64_t *partner, int64_t S,
-                             int64_t *out_seg, int32_t *flags, void *workspace, size_t workspace_bytes, void *stream);
 int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids, const int32_t *row_slot,
                             const void *uniq_table, int64_t uniq_capacity, const int64_t *own, const int64_t *partner,
                             int64_t S, const int64_t *seg, const float *table, int64_t table_rows, int32_t k,
                             float *out_xz, int32_t *out_idx, int64_t *out_segid, int64_t pair_block, int32_t *flags,
                             void *stream);
-
-/* Count form of the join (SpJoin fused with the first model stage, model.py:78-83).
- * out_counts f32 [S, table_rows]: out_counts[j][p] = number of times LP row p (SFptr+1, 0 = partner absent) occurs
- * in either feature slot of segment j, so that  segment_sum_j(MLP(xz).sum(-2)) == out_counts[j] @ MLP(Z_SF).
- * The segment list must be mirrored blocks (pair_block as for subgacc_sjoin_fill, > 0).  LDS bound:
- * 16*max_len + 8*table_rows bytes <= 160 KiB (SUBGACC_ERR_LDS otherwise: use subgacc_sjoin_fill). */
 int subgacc_sjoin_counts(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices, const int32_t *spg_data_i32,
                          const int64_t *own, const int64_t *partner, int64_t S, int64_t table_rows, float *out_counts,
                          int32_t max_len, int64_t pair_block, int32_t *flags, void *stream);
-
-/* Pair form of the join, for aggregations that are not linear in the rows (the attention gate, model.py:59-62): the
- * first model stage maps an output row to e[pa] + e[pb] (e = pe_embedding of the Z_SF table), a function of the index
- * pair (pa, pb) alone, and a segment of hundreds of rows holds a few dozen distinct pairs.  Segment j leaves as its
- * DISTINCT pairs with multiplicities, in a reproducible order, at rows [seg[j], seg[j] + out_cnt[j]) of
- *   out_pairs i32 [R,2] (pa, pb: SFptr+1 of the member in the own row, in the partner row or 0), out_mult i32 [R],
- * with seg / R from subgacc_sjoin_sizes (the rows beyond out_cnt[j] of a segment stay unwritten).  Mirrored segment
- * lists only (pair_block > 0); max_len <= 1024 (SUBGACC_ERR_LDS otherwise). */
 int subgacc_sjoin_pairs(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices, const int32_t *spg_data_i32,
                         const int64_t *own, const int64_t *partner, int64_t S, const int64_t *seg, int32_t *out_pairs,
                         int32_t *out_mult, int32_t *out_cnt, int32_t max_len, int64_t pair_block, int32_t *flags,
@@ -360,91 +395,38 @@ int subgacc_walk_join(const int32_t *walks, int64_t n, int32_t stride, const int
 /* ---------------------------------------------------------------------------------------------
  * Key rows: a batch that is sampled, joined and dropped needs neither the table of distinct LP rows nor their numbering.
  * subgacc_walk_spg with uniq_table = NULL writes the member's 32-bit LP key itself as the row's payload (needs
- * num_steps*SHIFT+1 <= 31, 2 to 4 hops, set_sampler order, no bucket, M <= 256: SUBGACC_ERR_BADARG otherwise), and
- * subgacc_sjoin_fill_keyrows joins such rows: a feature row is the key's unpacked counts / num_walks -- what
- * subgacc_unpack_lp writes into the feature table, computed on the fly (the partner's row is zero when it is absent).
- * Same (xz, seg) as the table path; sizes by subgacc_sjoin_sizes_rows; mirrored segment lists only.
- * ------------------------------------------------------------------------------------------- */
-int subgacc_sjoin_fill_keyrows(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
-                               const int32_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
-                               const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz, int64_t pair_block,
-                               int32_t *flags, void *stream);
-/* ABI 5 -- key rows for the 4-hop configurations.  The paper's sampler figure is citation2 with m = 4, M = 200 (Fig. 6a): its LP
+ * num_steps*SHIFT+1 <= 31, 2 to 4 hops, set_sampler order, no bucket, M <= 256: SUBGACC_ERR_BADARG otherwise); such rows are
+ * joined with payload SUBGACC_JOIN_KEY32 (subgacc_join_desc): same (xz, seg) as the table path, sizes by subgacc_sjoin_sizes_rows.
+ *
+ * ABI 5 -- key rows for the 4-hop configurations.  The paper's sampler figure is citation2 with m = 4, M = 200 (Fig. 6a): its LP
  * key -- the reference's 64-bit `bithash`, subg_acc.c:900-955 -- takes 4 x 8 + 1 = 33 bits.  subgacc_walk_spg(uniq_table = NULL)
  * serves 2 to 4 hops while num_steps*SHIFT+1 <= 31 (4 hops: M <= 127, e.g. the reference's own citation2 setting M = 100,
  * README.md:82-96); beyond that, subgacc_walk_keyrows64 writes the same rows with the whole 64-bit key as payload:
  *   row_ids [n*stride] int32 (sorted by node id), row_keys [n*stride] uint64, nsize [n]; stride = M*m+1.
  * Shapes: 4 hops, 32 <= num_steps*SHIFT+1 <= 63, a 1,024-slot table (M*4+1 <= 818), set_sampler order, no bucket.  worklist /
  * n_work: optional (both or neither), as for subgacc_walk_spg_list / _sparse (rows that are not listed are left alone: zero nsize
- * first); rng_pos / rng_seed as for subgacc_walk_spg.  subgacc_sjoin_fill_keyrows64 joins such rows (mirrored lists, sizes by
- * subgacc_sjoin_sizes_rows): bit for bit the xz of the table path. */
+ * first); rng_pos / rng_seed as for subgacc_walk_spg.  Joined with payload SUBGACC_JOIN_KEY64: bit for bit the xz of the table path.
+ * ------------------------------------------------------------------------------------------- */
 int subgacc_walk_keyrows64(const subgacc_walk_cfg *cfg, const void *indptr, const int32_t *indices, int64_t num_nodes,
                            const int32_t *query, int64_t n, const uint32_t *rng_pos, const uint32_t *rng_seed,
                            const int32_t *worklist, const int64_t *n_work, int32_t *row_ids, uint64_t *row_keys,
                            int32_t *nsize, int32_t *flags, void *stream);
+/* The key joins of ABI 3-5: forwards to subgacc_sjoin_fill_v2 -- strided rows of 32-bit keys, of 64-bit keys, and a PACKED store
+ * whose payload was re-keyed once (for the reference's flow -- subg_matrix over all nodes once, main.py:172-178, then one join per
+ * training batch, train.py:120-127 -- that takes the gather from the Z_SF table out of every output row: xz is bit-identical to the
+ * SFPTR join with table = float32(enc) / num_walks, main.py:174). */
+int subgacc_sjoin_fill_keyrows(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
+                               const int32_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
+                               const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz, int64_t pair_block,
+                               int32_t *flags, void *stream);
 int subgacc_sjoin_fill_keyrows64(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
                                  const uint64_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
                                  const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz, int64_t pair_block,
                                  int32_t *flags, void *stream);
-/* The same join over a PACKED store (spg_indptr form, sizes by subgacc_sjoin_sizes) whose payload was re-keyed once: spg_keys[i]
- * = the LP key of member i's row of `enc` (key = sum_j count_j << ((num_steps - j) * SHIFT), bit num_steps*SHIFT set on a
- * root's own row, subg_acc.c:900-955) instead of SFptr+1.  For the reference's flow -- subg_matrix over all nodes once
- * (main.py:172-178), then one join per training batch (train.py:120-127) -- this takes the 16-byte gather from the Z_SF table
- * out of every output row: xz is bit-identical to subgacc_sjoin_fill with table = float32(enc) / num_walks (main.py:174).
- * out_segid (optional): int64 [R] segment id of every output row (hgather's second result, train.py:66-68). */
 int subgacc_sjoin_fill_keys(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices, const int32_t *spg_keys,
                             const int64_t *own, const int64_t *partner, int64_t S, const int64_t *seg, int32_t num_walks,
                             int32_t num_steps, float *out_xz, int64_t *out_segid, int32_t max_len, int64_t pair_block,
                             int32_t *flags, void *stream);
-
-/* ---------------------------------------------------------------------------------------------
- * ABI 6 -- ONE entry point for every form of the join (train.py:13-111).  The five fills and the count / pair forms above
- * differ in what the store looks like, what a member's payload is and which outputs are wanted; the descriptor states exactly
- * that, field by field, and subgacc_sjoin_fill_v2 dispatches.  The older entry points stay exported and forward to it (a
- * client built against ABI 1-5 keeps working); new clients need this one only.  Sizes / segment pointers come from
- * subgacc_sjoin_sizes (packed rows) or subgacc_sjoin_sizes_rows (strided rows), as before.
- *
- *   store      row_off [n_rows+1] (packed rows, the SpG of random_walks.py:79) XOR row_len [n_rows] + row_stride (strided rows, the
- *              form the walk kernels leave a transient batch in); ids: member ids, ascending inside a row; max_len >= the longest
- *              row touched (packed rows; strided rows: row_stride is the bound)
- *   payload    SUBGACC_JOIN_SFPTR  int32: SFptr+1 (packed rows) or a slot of `uniq_table` (strided rows; uniq_table = NULL: the
- *                                  table is indexed by slot+1 itself); feature rows are gathered from table f32 [table_rows, k]
- *              SUBGACC_JOIN_F64    double: the PPR encoder's score (train.py:39-43); xz is [R,2,1]
- *              SUBGACC_JOIN_KEY32  int32 LP key (subg_acc.c:900-955): a feature row is the key's unpacked counts / num_walks
- *              SUBGACC_JOIN_KEY64  uint64 LP key (strided rows of subgacc_walk_keyrows64)
- *   segments   own / partner [S] (partner may be NULL for a mirrored list), seg [S+1], pair_block as for subgacc_sjoin_fill
- *   form       SUBGACC_JOIN_ROWS   out_xz f32 [R,2,k] and / or out_idx i32 [R,2] (SFPTR only), out_segid i64 [R] (optional)
- *              SUBGACC_JOIN_COUNTS out_counts f32 [S, table_rows]   (subgacc_sjoin_counts)
- *              SUBGACC_JOIN_PAIRS  out_pairs i32 [R,2], out_mult i32 [R], out_cnt i32 [S]   (subgacc_sjoin_pairs)
- *   struct_bytes = sizeof(subgacc_join_desc): a descriptor of another size is refused (SUBGACC_ERR_BADARG), fields a form does
- *   not read must be zero / NULL.
- * ------------------------------------------------------------------------------------------- */
-enum { SUBGACC_JOIN_SFPTR = 0, SUBGACC_JOIN_F64 = 1, SUBGACC_JOIN_KEY32 = 2, SUBGACC_JOIN_KEY64 = 3 };
-enum { SUBGACC_JOIN_ROWS = 0, SUBGACC_JOIN_COUNTS = 1, SUBGACC_JOIN_PAIRS = 2 };
-typedef struct subgacc_join_desc {
-    int32_t struct_bytes, form, payload_kind, max_len;
-    const int64_t *row_off;
-    const int32_t *row_len;
-    int64_t row_stride, n_rows;
-    const int32_t *ids;
-    const void *payload;
-    const void *uniq_table;
-    int64_t uniq_capacity;
-    const int64_t *own, *partner;
-    int64_t S;
-    const int64_t *seg;
-    int64_t pair_block;
-    const float *table;
-    int64_t table_rows;
-    int32_t k, num_walks, num_steps, reserved;
-    float *out_xz;
-    int32_t *out_idx;
-    int64_t *out_segid;
-    float *out_counts;
-    int32_t *out_pairs, *out_mult, *out_cnt;
-    int32_t *flags;
-} subgacc_join_desc;
-int subgacc_sjoin_fill_v2(const subgacc_join_desc *d, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Prologue of one on-demand step (sample both endpoints of B query pairs -> rows -> SpJoin; train.py:120-127 calls the
