@@ -274,9 +274,6 @@ int subgacc_sjoin_sizes_rows(const int32_t *row_len, int64_t n_rows, const int64
  *              SUBGACC_JOIN_PAIRS  for aggregations that are not linear in the rows (the attention gate, model.py:59-62): segment j as
  *                                  its DISTINCT index pairs with multiplicities, in a reproducible order, at rows [seg[j], seg[j] +
  *                                  out_cnt[j]) of out_pairs i32 [R,2], out_mult i32 [R]; out_cnt i32 [S]; max_len <= 1024
- *   lanes_per_pair  0 = the library's choice; 128 | 256 = lanes of a workgroup of the key joins over a mirrored list -- worth saying where
- *              the row bound cannot tell: the sets of 2-hop walks share one 401-slot stride, ~240 output rows per pair on a co-author
- *              graph (128 lanes are 30 % faster) and ~570 on a follower graph (256 are 6 % faster); 256 pays from ~450 rows per pair on
  *   struct_bytes = sizeof(subgacc_join_desc): a descriptor of another size is refused (SUBGACC_ERR_BADARG); fields a form does not
  *   read must be zero / NULL. */
 enum { SUBGACC_JOIN_SFPTR = 0, SUBGACC_JOIN_F64 = 1, SUBGACC_JOIN_KEY32 = 2, SUBGACC_JOIN_KEY64 = 3 };
@@ -296,7 +293,7 @@ typedef struct subgacc_join_desc {
     int64_t pair_block;
     const float *table;
     int64_t table_rows;
-    int32_t k, num_walks, num_steps, lanes_per_pair;
+    int32_t k, num_walks, num_steps, reserved;
     float *out_xz;
     int32_t *out_idx;
     int64_t *out_segid;

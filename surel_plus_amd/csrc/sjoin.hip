@@ -1266,7 +1266,7 @@ static int sjoin_fill_rows_impl(const int32_t *row_len, int64_t n_rows, int64_t 
 
 // key payload (strided rows of a transient batch, or a packed store whose payload was re-keyed): shared launcher
 static int launch_key_join(JoinArgs &a, int32_t num_walks, int32_t num_steps, int64_t S, int64_t pair_block, void *stream,
-                           const char *who, bool wide = false, int32_t lanes = 0) {
+                           const char *who, bool wide = false) {
     const int shift = subgacc_key_shift(num_walks, num_steps);
     if (shift < 0) return shift;
     SG_REQUIRE(num_steps * shift + 1 <= (wide ? 63 : 31) && num_steps + 1 <= 16, SUBGACC_ERR_KEYWIDTH,
@@ -1276,13 +1276,10 @@ static int launch_key_join(JoinArgs &a, int32_t num_walks, int32_t num_steps, in
     a.slot_id = nullptr, a.val_add = 0;
     a.key_M = num_walks, a.key_m = num_steps, a.key_shift = shift;
     // LDS: the longer row of a pair (id + key + partner key per member), one staging area per wave
-    // Lanes per pair.  Rows of 3- and 4-hop sets -- up to 601 / 801 members -- take 256: the two rows arrive in half the trips and
-    // eight wavefronts emit the ~12-25 spans (cit2 join 0.437 -> 0.429 ms).  2-hop rows (a 401-slot stride) depend on the GRAPH: ~120
-    // members per set on the collab-like one lose 30 % with 256 lanes, ~285 on the twitter-like one gain 6 % (profiles/r18_join_nt.log)
-    // -- the row stride cannot tell them apart, so the caller may say what it knows (subgacc_join_desc.lanes_per_pair: 256 from
-    // ~450 output rows per pair on; the Python mirror measures a pilot batch / divides the store's members by its rows)
-    const bool many = lanes == 256 || (lanes == 0 && a.max_len > 512 && (a.k == 4 || (wide && a.k == 5)));
-    const int nt = (many && pair_split(S / 2) == 1 && (wide ? a.k == 5 : (a.k >= 3 && a.k <= 5))) ? 256 : kPairEmit;
+    const int nt = (a.max_len > 512 && pair_split(S / 2) == 1 && (a.k == 4 || (wide && a.k == 5))) ? 256 : kPairEmit;
+    // (rows of 3- and 4-hop sets -- up to 601 / 801 members -- take 256 lanes per pair: the two rows arrive in half the trips and eight
+    //  wavefronts emit the ~12-25 spans: cit2 join 0.437 -> 0.429 ms; 2-hop rows, ~120 members, lose 9 % with 256 lanes and keep 128:
+    //  profiles/r12_ab_pair_threads.log)
     const size_t lds = (size_t)a.max_len * (wide ? 20 : 12) + key_stage_bytes(nt / kWave, a.k);
     SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "%s: rows of %d members do not fit LDS", who, (int)a.max_len);
     a.split = pair_split(S / 2);
@@ -1303,9 +1300,7 @@ static int launch_key_join(JoinArgs &a, int32_t num_walks, int32_t num_steps, in
         else SG_KEY_LAUNCH(0, kPairEmit, true);
     } else if (a.k == 4 && nt == 256) SG_KEY_LAUNCH(4, 256, false);
     else if (a.k == 4) SG_KEY_LAUNCH(4, kPairEmit, false);      // 3 hops
-    else if (a.k == 3 && nt == 256) SG_KEY_LAUNCH(3, 256, false);
     else if (a.k == 3) SG_KEY_LAUNCH(3, kPairEmit, false);      // 2 hops (the collab-like configurations)
-    else if (a.k == 5 && nt == 256) SG_KEY_LAUNCH(5, 256, false);
     else if (a.k == 5) SG_KEY_LAUNCH(5, kPairEmit, false);      // 4 hops with 32-bit keys (M <= 127: the reference's own citation2 setting)
     else SG_KEY_LAUNCH(0, kPairEmit, false);
 #undef SG_KEY_LAUNCH
@@ -1316,7 +1311,7 @@ static int launch_key_join(JoinArgs &a, int32_t num_walks, int32_t num_steps, in
 static int sjoin_fill_keyrows_impl(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
                                           const int32_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
                                           const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz,
-                                          int64_t pair_block, int32_t *flags, void *stream, int32_t lanes = 0) {
+                                          int64_t pair_block, int32_t *flags, void *stream) {
     SG_REQUIRE(S >= 0 && flags && n_rows >= 0 && row_stride > 0 && row_stride < (1ll << 31), SUBGACC_ERR_BADARG,
                "sjoin_fill_keyrows: bad arguments");
     if (S == 0) return subgacc_key_shift(num_walks, num_steps) < 0 ? subgacc_key_shift(num_walks, num_steps) : SUBGACC_OK;
@@ -1331,13 +1326,13 @@ static int sjoin_fill_keyrows_impl(const int32_t *row_len, int64_t n_rows, int64
     a.max_len = (int32_t)row_stride;
     a.flags = flags;
     a.row_len = row_len, a.row_stride = row_stride;
-    return launch_key_join(a, num_walks, num_steps, S, pair_block, stream, "sjoin_fill_keyrows", false, lanes);
+    return launch_key_join(a, num_walks, num_steps, S, pair_block, stream, "sjoin_fill_keyrows");
 }
 
 static int sjoin_fill_keyrows64_impl(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
                                             const uint64_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
                                             const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz,
-                                            int64_t pair_block, int32_t *flags, void *stream, int32_t lanes = 0) {
+                                            int64_t pair_block, int32_t *flags, void *stream) {
     SG_REQUIRE(S >= 0 && flags && n_rows >= 0 && row_stride > 0 && row_stride < (1ll << 31), SUBGACC_ERR_BADARG,
                "sjoin_fill_keyrows64: bad arguments");
     if (S == 0) return subgacc_key_shift(num_walks, num_steps) < 0 ? subgacc_key_shift(num_walks, num_steps) : SUBGACC_OK;
@@ -1352,13 +1347,13 @@ static int sjoin_fill_keyrows64_impl(const int32_t *row_len, int64_t n_rows, int
     a.max_len = (int32_t)row_stride;
     a.flags = flags;
     a.row_len = row_len, a.row_stride = row_stride;
-    return launch_key_join(a, num_walks, num_steps, S, pair_block, stream, "sjoin_fill_keyrows64", true, lanes);
+    return launch_key_join(a, num_walks, num_steps, S, pair_block, stream, "sjoin_fill_keyrows64", true);
 }
 
 static int sjoin_fill_keys_impl(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,
                                        const int32_t *spg_keys, const int64_t *own, const int64_t *partner, int64_t S,
                                        const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz,
-                                       int64_t *out_segid, int32_t max_len, int64_t pair_block, int32_t *flags, void *stream, int32_t lanes = 0) {
+                                       int64_t *out_segid, int32_t max_len, int64_t pair_block, int32_t *flags, void *stream) {
     SG_REQUIRE(S >= 0 && flags && n_rows >= 0 && max_len >= 0, SUBGACC_ERR_BADARG, "sjoin_fill_keys: bad arguments");
     if (S == 0) return subgacc_key_shift(num_walks, num_steps) < 0 ? subgacc_key_shift(num_walks, num_steps) : SUBGACC_OK;
     SG_REQUIRE(spg_indptr && spg_indices && spg_keys && own && (partner || pair_block > 0) && seg && out_xz, SUBGACC_ERR_BADARG,
@@ -1372,7 +1367,7 @@ static int sjoin_fill_keys_impl(const int64_t *spg_indptr, int64_t n_rows, const
     a.max_len = max_len > 0 ? max_len : 1;
     a.flags = flags;
     a.row_len = nullptr, a.row_stride = 0;
-    return launch_key_join(a, num_walks, num_steps, S, pair_block, stream, "sjoin_fill_keys", false, lanes);
+    return launch_key_join(a, num_walks, num_steps, S, pair_block, stream, "sjoin_fill_keys");
 }
 
 static int sjoin_counts_impl(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,
@@ -1457,8 +1452,6 @@ extern "C" int subgacc_sjoin_fill_v2(const subgacc_join_desc *d, void *stream) {
     SG_REQUIRE(d->struct_bytes == (int32_t)sizeof(subgacc_join_desc), SUBGACC_ERR_BADARG,
                "sjoin_fill_v2: descriptor of %d bytes, this library's is %d (set struct_bytes = sizeof(subgacc_join_desc))",
                (int)d->struct_bytes, (int)sizeof(subgacc_join_desc));
-    SG_REQUIRE(d->lanes_per_pair == 0 || d->lanes_per_pair == 128 || d->lanes_per_pair == 256, SUBGACC_ERR_BADARG,
-               "sjoin_fill_v2: lanes_per_pair is 0 (the library's choice), 128 or 256");
     SG_REQUIRE((d->row_off != nullptr) != (d->row_len != nullptr), SUBGACC_ERR_BADARG,
                "sjoin_fill_v2: exactly one of row_off (packed rows) / row_len (strided rows)");
     const bool strided = d->row_len != nullptr;
@@ -1490,15 +1483,14 @@ extern "C" int subgacc_sjoin_fill_v2(const subgacc_join_desc *d, void *stream) {
         if (strided) {
             SG_REQUIRE(!d->out_segid, SUBGACC_ERR_BADARG, "sjoin_fill_v2: strided key rows are joined with segment pointers");
             return sjoin_fill_keyrows_impl(d->row_len, d->n_rows, d->row_stride, d->ids, (const int32_t *)d->payload, d->own, d->partner,
-                                           d->S, d->seg, d->num_walks, d->num_steps, d->out_xz, d->pair_block, d->flags, stream, d->lanes_per_pair);
+                                           d->S, d->seg, d->num_walks, d->num_steps, d->out_xz, d->pair_block, d->flags, stream);
         }
         return sjoin_fill_keys_impl(d->row_off, d->n_rows, d->ids, (const int32_t *)d->payload, d->own, d->partner, d->S, d->seg,
-                                    d->num_walks, d->num_steps, d->out_xz, d->out_segid, d->max_len, d->pair_block, d->flags, stream,
-                                    d->lanes_per_pair);
+                                    d->num_walks, d->num_steps, d->out_xz, d->out_segid, d->max_len, d->pair_block, d->flags, stream);
     case SUBGACC_JOIN_KEY64:
         SG_REQUIRE(strided && !d->out_segid, SUBGACC_ERR_BADARG, "sjoin_fill_v2: 64-bit keys are the payload of strided rows (subgacc_walk_keyrows64)");
         return sjoin_fill_keyrows64_impl(d->row_len, d->n_rows, d->row_stride, d->ids, (const uint64_t *)d->payload, d->own, d->partner,
-                                         d->S, d->seg, d->num_walks, d->num_steps, d->out_xz, d->pair_block, d->flags, stream, d->lanes_per_pair);
+                                         d->S, d->seg, d->num_walks, d->num_steps, d->out_xz, d->pair_block, d->flags, stream);
     default:
         SG_REQUIRE(false, SUBGACC_ERR_BADARG, "sjoin_fill_v2: unknown payload kind %d", (int)d->payload_kind);
     }

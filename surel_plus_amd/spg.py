@@ -124,7 +124,6 @@ class SpG:
         keys[:nnz] = torch.index_select(keytab, 0, self.data[:nnz])
         z = SpG(self.indptr, self.indices, keys, max_len=self.max_len, shape=self.shape, max_data=0)
         z.keyrows, z.key_M, z.key_m = True, int(num_walks), m
-        z.mean_len = nnz / max(self.n_rows, 1)      # members per row: what the key join picks its lanes per pair by (spjoin.sjoin)
         return z
 
     def slot_table(self):

@@ -104,8 +104,7 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
         with _timed("sjoin_fill"):
             join_fill(JOIN_ROWS, JOIN_KEY32, row_off=spg.indptr, n_rows=spg.n_rows, ids=spg.indices, payload=spg.data, max_len=spg.max_len,
                       own=own, partner=partner, S=S, seg=seg, pair_block=pair_block, num_walks=spg.key_M, num_steps=spg.key_m,
-                      out_xz=res, out_segid=segid, flags=flags,
-                      lanes_per_pair=256 if 2.0 * getattr(spg, "mean_len", 0.0) >= LANES_256_FROM_ROWS else 0)
+                      out_xz=res, out_segid=segid, flags=flags)
         return res, (seg if ptr_mode else _with_pointers(segid, seg)), flags
     if lazy and (out is None or not ptr_mode or return_index or (encode is None and not is_f64)):
         raise ValueError("lazy=True needs out=, ptr=True and an integer SpG with its encode table (or a float-payload SpG)")
@@ -541,48 +540,10 @@ class StepBuffers:
             self.dedup_steps = 0
         self.ws = torch.empty(max(L.subgacc_sjoin_workspace_bytes(n), 8), dtype=torch.uint8, device=dev)
         self.feat = None if self.keyrows else torch.empty((self.capacity + 1, self.k), dtype=torch.float32, device=dev)
-        # lanes per pair of the key join (subgacc_join_desc.lanes_per_pair): where the row stride cannot tell -- 2-hop sets share one
-        # 401-slot stride and hold ~120 members on a co-author graph, ~285 on a follower graph -- a pilot batch on THIS graph does
-        self.lanes_per_pair = pilot_lanes_per_pair(csr, self.M, self.m) if (self.keyrows and self.stride <= 512) else 0
         need = n * self.stride * 2 * self.k
         if out is not None and (out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev or out.numel() < need):
             raise ValueError("StepBuffers: out= must hold 2B * (M*m+1) * 2 * (m+1) float32 on the graph's device")
         self.out = out if out is not None else torch.empty(need, dtype=torch.float32, device=dev)
-
-
-PILOT_ROOTS = 2048
-LANES_256_FROM_ROWS = 450          # output rows per pair from which 256 lanes per pair beat 128 (profiles/r18_join_nt.log)
-
-
-def pilot_lanes_per_pair(csr, num_walks, num_steps):
-    """0 (the library's default, 128 lanes) or 256: measured once per (graph, M, m) on a pilot batch of PILOT_ROOTS roots drawn like
-    the endpoints of query pairs are (half of them ends of random edges, i.e. degree-biased, half uniform nodes) -- the mean set
-    size times two is what a pair emits.  One small launch and one read at set-up; remembered on the DeviceCSR."""
-    from .sampler import sample_sets
-    memo = getattr(csr, "_lanes_hint", None)
-    if memo is None:
-        memo = {}
-        try:
-            csr._lanes_hint = memo
-        except AttributeError:
-            pass
-    key = (int(num_walks), int(num_steps))
-    if key not in memo:
-        lanes = 0
-        if csr.num_nodes > 0:
-            g = torch.Generator(device=csr.device).manual_seed(20261004)
-            half = PILOT_ROOTS // 2
-            roots = torch.randint(0, csr.num_nodes, (PILOT_ROOTS,), device=csr.device, generator=g)
-            if csr.nnz > 0:
-                at = torch.randint(0, csr.nnz, (half,), device=csr.device, generator=g)
-                roots[:half] = csr.indices[at].to(roots.dtype)
-            sets = sample_sets(csr, roots.to(torch.int32), num_walks=num_walks, num_steps=num_steps, rng="philox", seed=0,
-                               fused_rows=True, strided=True, number_rows=False)
-            if sets is not None:
-                rows_per_pair = 2.0 * float(sets.nsize.float().mean().item())
-                lanes = 256 if rows_per_pair >= LANES_256_FROM_ROWS else 0
-        memo[key] = lanes
-    return memo[key]
 
 
 def _dedup_tick(bufs):
@@ -687,7 +648,7 @@ def _buffered_step(csr, e, bufs, seed, out):
         if kr:
             join_fill(JOIN_ROWS, JOIN_KEY64 if bufs.key64 else JOIN_KEY32, row_len=bufs.nsize, n_rows=n, row_stride=bufs.stride, ids=bufs.ids,
                       payload=bufs.slot, own=own, partner=partner, S=n, seg=bufs.seg, pair_block=PB, num_walks=M, num_steps=m,
-                      out_xz=xz, flags=flags, lanes_per_pair=bufs.lanes_per_pair)
+                      out_xz=xz, flags=flags)
         else:
             join_fill(JOIN_ROWS, JOIN_SFPTR, row_len=bufs.nsize, n_rows=n, row_stride=bufs.stride, ids=bufs.ids, payload=bufs.slot,
                       own=own, partner=partner, S=n, seg=bufs.seg, pair_block=PB, table=bufs.feat, table_rows=bufs.capacity + 1, k=k,

@@ -171,34 +171,3 @@ def test_pair_join_at_every_span_and_trip_boundary(sp, payload, B):
         oxz, oind = oracle.gather(e, spg_host, ptr=ptr, encode=enc_host)
         assert np.array_equal(ind.cpu().numpy(), oind)
         assert np.array_equal(xz.cpu().numpy(), oxz)
-
-
-@pytest.mark.parametrize("M,hops", [(200, 2), (200, 3), (100, 4), (200, 4)])
-def test_lanes_per_pair_is_a_schedule_not_a_result(sp, M, hops):
-    """subgacc_join_desc.lanes_per_pair (0 = the library's choice, 128, 256 lanes per pair of the key joins; StepBuffers sets it from a
-    pilot batch, a keyed store from its members per row): the same (xz, indptr) bit for bit, and equal to the oracle's; any other
-    value is refused"""
-    from surel_plus_amd import _lib
-    from surel_plus_amd.graphs import query_pairs
-    ptr_, idx = sym_graph(9000, 90000, seed=23, hubs=2)
-    csr = sp.DeviceCSR(ptr_, idx)
-    B = 3000                                            # > 2,048 pairs: one workgroup per pair, so the lane count is honoured
-    e = query_pairs(csr, B, seed=5)
-    bufs = sp.StepBuffers(csr, B, num_walks=M, num_steps=hops)
-    assert bufs.keyrows and bufs.lanes_per_pair in (0, 256)
-    got = {}
-    for lanes in (0, 128, 256):
-        bufs.lanes_per_pair = lanes
-        xz, ind, sets = sp.sample_and_gather(csr, e, num_walks=M, num_steps=hops, seed=11, rng="philox", buffers=bufs)
-        sets.prefetch(extra=ind[-1:]).resolve()
-        got[lanes] = (xz[: int(sets.extra[0])].clone(), ind.clone())
-    assert torch.equal(got[0][0], got[128][0]) and torch.equal(got[0][0], got[256][0])
-    assert torch.equal(got[0][1], got[128][1]) and torch.equal(got[0][1], got[256][1])
-    roots = e.reshape(-1).cpu().numpy()
-    (oi, ox, od), oenc = _oracle_spg(ptr_, idx, roots, M, hops, 11, "philox", -1)
-    table = oracle.enc_table(oenc).astype(np.float32) / np.float32(M)
-    oxz, oind = oracle.gather(np.arange(2 * B, dtype=np.int64).reshape(2, B), (oi, ox, od), ptr=True, encode=table)
-    assert np.array_equal(got[256][0].cpu().numpy(), oxz) and np.array_equal(got[256][1].cpu().numpy(), oind)
-    bufs.lanes_per_pair = 64
-    with pytest.raises(TypeError, match="lanes_per_pair"):
-        sp.sample_and_gather(csr, e, num_walks=M, num_steps=hops, seed=11, rng="philox", buffers=bufs)

@@ -51,14 +51,12 @@ def one(wl, n):
     L, st = lib(), stream_ptr()
     own, partner = _arange_segments(B, dev, B)
     flags = bufs.status.view(torch.int32)[:4]
-    from surel_plus_amd._lib import JOIN_KEY32, JOIN_KEY64, JOIN_ROWS, join_fill
+    fill = L.subgacc_sjoin_fill_keyrows64 if bufs.key64 else L.subgacc_sjoin_fill_keyrows      # (the ABI 5 forwards: old builds have them too)
     out = bufs.out.view(-1)
-    lanes = int(os.environ.get("JB_LANES", "-1"))          # -1: what StepBuffers' pilot batch chose; 0 / 128 / 256: forced
 
     def launch():
-        join_fill(JOIN_ROWS, JOIN_KEY64 if bufs.key64 else JOIN_KEY32, row_len=bufs.nsize, n_rows=2 * B, row_stride=bufs.stride, ids=bufs.ids,
-                  payload=bufs.slot, own=own, partner=partner, S=2 * B, seg=bufs.seg, pair_block=B, num_walks=M, num_steps=k - 1,
-                  out_xz=out, flags=flags, lanes_per_pair=bufs.lanes_per_pair if lanes < 0 else lanes)
+        check(fill(ptr(bufs.nsize), 2 * B, bufs.stride, ptr(bufs.ids), ptr(bufs.slot), ptr(own), ptr(partner), 2 * B, ptr(bufs.seg),
+                   M, k - 1, ptr(out), B, ptr(flags), st))
     for _ in range(5):
         launch()
     torch.cuda.synchronize()
@@ -73,7 +71,7 @@ def one(wl, n):
         best.append(a.elapsed_time(b) / n)
     ms = sorted(best)[1]
     abytes = B * 64 + rows * (8 + 8 * k)
-    print(f"{wl:8s} lanes={'pilot:' + str(bufs.lanes_per_pair) if lanes < 0 else lanes} lib={os.environ.get('SUBGACC_LIB', '-'):40s} rows/pair {rows / B:6.1f}  join {ms:.4f} ms (min {min(best):.4f})  "
+    print(f"{wl:8s} lib={os.environ.get('SUBGACC_LIB', '-'):40s} rows/pair {rows / B:6.1f}  join {ms:.4f} ms (min {min(best):.4f})  "
           f"{abytes / ms / 1e9:.2f} TB/s  frac {abytes / (ms * 1e-3) / 8e12:.3f}", flush=True)
 
 
