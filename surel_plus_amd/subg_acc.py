@@ -81,7 +81,9 @@ def _rows_to_host(rows, others=()):
         h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
         h.copy_(t, non_blocking=True)
         extra.append(h)
-    torch.cuda.current_stream().synchronize()
+    devs = {t.device for t in list(rows) + [t for t in others if t is not None] if t.is_cuda}
+    for dev in devs:           # (every copy went to the current stream of ITS tensor's device, which need not be the current device)
+        torch.cuda.current_stream(dev).synchronize()
     return (None if host is None else host.numpy()), [None if h is None else h.numpy() for h in extra]
 
 
