@@ -387,25 +387,27 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W, extr
     edges = _Cyclic()
     timer = KernelTimer()
     sampler_mod.KERNEL_TIMER = timer         # spjoin brackets the fill kernel ("sjoin_fill"); "join" below = the whole call
-    # a serving loop's form of the join: the three launches of one gather (segment reduce, segment scan, fill) captured as ONE HIP
-    # graph per buffer set (stepgraph.CapturedJoin, two in turn), sizes and status left on the device until the step is resolved --
-    # launched eagerly the step is host-bound (0.17 ms of Python and launches for ~0.09 ms of kernels)
+    # a serving loop's form of the join: stepgraph.CapturedJoin (two in turn) -- buffers and descriptor built once, a step is ONE call
+    # into the library (the size pass as a single launch, the fill behind it), the row count and the status word arrive in pinned
+    # host memory by themselves; gather(lazy=True), launch by launch, is host-bound (0.17 ms of Python for ~0.09 ms of kernels)
     eager = os.environ.get("SUBGACC_PPR_EAGER", "0") == "1"
     bufs = [torch.empty(2 * B * z.max_len * 2, dtype=torch.float32, device=dev) for _ in (0, 1)] if eager else None
-    caps = None if eager else [sp.CapturedJoin(z, B) for _ in (0, 1)]
+    # ... two of them in turn, each on its own stream (CapturedJoinPool): the size pass and the first waves of a batch's fill run
+    # under the last waves of the batch before it
+    pool = None if eager else sp.CapturedJoinPool(z, B, lanes=2)
 
     def step(s):
-        with timer("join"):
-            if eager:
+        if eager:
+            with timer("join"):
                 return sp.gather(edges[s], z, dev, ptr=True, encode=None, out=bufs[s & 1], lazy=True)
-            return caps[s & 1](edges[s])
+        return pool.submit(edges[s], sync=False)          # (the batches were made before the region and synchronised)
 
     def resolve(q):
         if eager:
             import surel_plus_amd.spjoin as sj
             sj.lazy_join_status(q[1])
             return int(q[1][-1].item())
-        return int(q.finish()[0].shape[0])
+        return int(pool.finish(q)[0].shape[0])
     for s in range(W):
         resolve(step(s))
     torch.cuda.synchronize()
@@ -440,6 +442,13 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W, extr
         resolve(pending)
         torch.cuda.synchronize()
         region_values.append(B * K / (time.perf_counter() - t1))
+    if not eager:      # one call at a time, alone on the GPU, between HIP events: what a whole join call takes (size pass + fill)
+        timer.enabled = True
+        for s in range(W, W + 10):
+            with timer("join"):
+                pool.steps[0](edges[s])
+            pool.steps[0].finish()
+        timer.enabled = False
     sampler_mod.KERNEL_TIMER = None
     elapsed_local = elapsed
     if dist is not None:
@@ -452,7 +461,7 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W, extr
         return None
     if extra_regions:
         elapsed = world * B * K / median(region_values)
-    call_ms, launches = timer.mean_ms("join")       # HIP events around the whole join: the replayed graph's three kernels back to back
+    call_ms, launches = timer.mean_ms("join")       # HIP events around a whole join call alone on the GPU: the size pass and the fill
     ms, _ = timer.mean_ms("sjoin_fill")             # the fill kernel alone (eager mode only: events do not time inside a replayed graph)
     if ms is None:                                  # ... so a few eager joins after the timed region time it, for the record
         ebuf = torch.empty(2 * B * z.max_len * 2, dtype=torch.float32, device=dev)
@@ -465,10 +474,27 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W, extr
         timer.enabled = False
         sampler_mod.KERNEL_TIMER = None
         fill_ms, _ = timer.mean_ms("sjoin_fill")
-        ms, ms_source = fill_ms, ("HIP events around the fill kernel of eager launches of the same joins right after the timed region (events "
-                                  "cannot bracket a kernel inside a replayed graph; join_graph_ms is the whole graph in the timed region)")
+        ms, ms_source = fill_ms, ("HIP events around the fill kernel of gather(lazy=True) launches of the same joins right after the timed region "
+                                  "(the timed region's call holds the size pass and the fill: join_graph_ms is that whole call)")
     else:
         fill_ms, ms_source = ms, "HIP events around the fill kernel in the timed region"
+    # an event pair around ONE launch of a ~60 us kernel reads 4-6 us more than the kernel runs (rocprofv3's kernel trace of the
+    # same launches is the arbiter: profiles/rNN_cit2ppr_kernel_stats.csv): the same fill ten times back to back between one pair
+    from surel_plus_amd import _lib as lib_
+    xz_e, ind_e = sp.gather(edges[W], z, dev, ptr=True, encode=None, out=torch.empty(2 * B * z.max_len * 2, dtype=torch.float32, device=dev), lazy=True)
+    own_e = edges[W].contiguous().view(-1)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    b2b = []
+    for _ in range(3):
+        ev0.record()
+        for _ in range(10):
+            lib_.join_fill(lib_.JOIN_ROWS, lib_.JOIN_F64, row_off=z.indptr, n_rows=z.n_rows, ids=z.indices, payload=z.data, max_len=z.max_len,
+                           own=own_e, S=own_e.numel(), seg=ind_e, pair_block=B, out_xz=xz_e, flags=ind_e.join_flags)
+        ev1.record()
+        torch.cuda.synchronize()
+        b2b.append(ev0.elapsed_time(ev1) / 10)
+    b2b_ms = median(b2b)
+    steady_ms = world * B / median(region_values) * 1e3          # the loop's period per call (per rank)
     abytes = B * 64 + rows_out * (12 + 8)      # 64 + (|S_u|+|S_v|) * (12 read: id + f64 payload, 8 written: f32 [.,2,1])
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -490,12 +516,15 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W, extr
                        "region_pairs_per_s": [round(v) for v in region_values], "pairs_per_s_min": min(region_values),
                        "pairs_per_s_median": median(region_values), "pairs_per_s_max": max(region_values),
                        "spg_members": z.nnz, "offline_ppr_stage_s": prep_s,
-                       "join_call_ms_three_launches": call_ms,
-                       "frac_of_hbm_peak_whole_join_call": (abytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if call_ms else None},
+                       "join_call_ms": call_ms,          # (two launches: the single-pass size kernel, the fill; + the event pair)
+                       # ... and what a call costs in the loop (two joins in turn on two streams): the period of the timed regions
+                       "join_call_ms_steady": steady_ms,
+                       "frac_of_hbm_peak_whole_join_call": (abytes / ((steady_ms or call_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS) if (steady_ms or call_ms) else None},
             "roofline": {"bound": "hbm", "kernel": "sjoin_f64pair_kernel<64> (one wave per pair)",
                          "achieved": abytes / (ms * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel_ms": ms, "kernel_ms_source": ms_source,
+                         "kernel_ms_x10_back_to_back": b2b_ms, "frac_x10_back_to_back": abytes / (b2b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "join_graph_ms": call_ms, "frac_whole_join": (abytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if call_ms else None,
                          "launches_timed": launches, "algorithmic_bytes_per_launch": abytes}}
 
@@ -881,8 +910,10 @@ def flatten(out):
         put(f"{short}_traffic_bytes", r.get("traffic"))
         put(f"{short}_join_ms", ((o.get("config") or {}).get("stage_ms") or {}).get("sjoin_fill"))
         put(f"{short}_dedup_pairs_per_s", ((o.get("config") or {}).get("dedup_roots_loop") or {}).get("pairs_per_s"))
-        put(f"{short}_join_call_ms", (o.get("config") or {}).get("join_call_ms_three_launches"))
+        put(f"{short}_join_call_ms", (o.get("config") or {}).get("join_call_ms"))
+        put(f"{short}_join_call_ms_steady", (o.get("config") or {}).get("join_call_ms_steady"))
         put(f"{short}_frac_whole_join_call", (o.get("config") or {}).get("frac_of_hbm_peak_whole_join_call"))
+        put(f"{short}_frac_x10_back_to_back", r.get("frac_x10_back_to_back"))
         if "cpu_baseline" in o:
             put(f"{short}_cpu_pairs_per_s", o["cpu_baseline"].get("value"))
             put(f"{short}_cpu_cores", o["cpu_baseline"].get("cores"))
@@ -1047,7 +1078,7 @@ def summary(o):
     keep["config"] = {k_: o["config"].get(k_) for k_ in ("workload", "pairs_per_step_per_gpu", "rng", "set_members_last_step", "device_allocs_in_timed_region", "host_step_ms_min_median_max",
                                                          "distinct_lp_rows_last_step", "xz_rows_last_step", "graph_nnz", "spg_layout", "stage_ms", "two_stream_loop", "dedup_roots_loop", "spg_members",
                                                          "timed_loop", "region_pairs_per_s", "pairs_per_s_min", "pairs_per_s_median", "pairs_per_s_max",
-                                                         "offline_ppr_stage_s", "join_call_ms_three_launches",
+                                                         "offline_ppr_stage_s", "join_call_ms", "join_call_ms_steady",
                                                          "frac_of_hbm_peak_whole_join_call") if k_ in o["config"]}
     keep["roofline"] = o["roofline"]
     if "cpu_baseline" in o:

@@ -274,10 +274,21 @@ int subgacc_sjoin_sizes_rows(const int32_t *row_len, int64_t n_rows, const int64
  *              SUBGACC_JOIN_PAIRS  for aggregations that are not linear in the rows (the attention gate, model.py:59-62): segment j as
  *                                  its DISTINCT index pairs with multiplicities, in a reproducible order, at rows [seg[j], seg[j] +
  *                                  out_cnt[j]) of out_pairs i32 [R,2], out_mult i32 [R]; out_cnt i32 [S]; max_len <= 1024
+ *   options    SUBGACC_JOIN_OPT_SIZES (row form): the WHOLE join of a batch in this one call -- the size pass runs first, as ONE
+ *              launch, and the fill behind it.  seg = NULL; out_seg [S+1] is written (what subgacc_sjoin_sizes writes) and read by
+ *              the fill; the outputs must hold the worst case (S * max_len rows, R is not known to the host beforehand); the size
+ *              pass ORs its status into flags[3] (16: a row number outside the store; 32: size_state was not clean -- the segment pointers
+ *              mean nothing, the fill of this call, and of every later one that finds the bit set, writes no row: zero the state
+ *              and flags and call again); host_tail (optional; int64[2] of pinned, device-visible host memory) receives [R, the status of THIS
+ *              size pass] when it ends (R = -1 with bit 32), so that a serving loop needs neither a memset in front of the join
+ *              nor a copy behind it.  size_state: subgacc_sjoin_workspace_bytes(S) bytes of device memory the caller zeroes ONCE, when allocating
+ *              it: every call leaves it zeroed again (a single-pass scan keeps its ticket and one word per tile there); one
+ *              state serves one join at a time (calls on one stream; one state per stream otherwise).
  *   struct_bytes = sizeof(subgacc_join_desc): a descriptor of another size is refused (SUBGACC_ERR_BADARG); fields a form does not
  *   read must be zero / NULL. */
 enum { SUBGACC_JOIN_SFPTR = 0, SUBGACC_JOIN_F64 = 1, SUBGACC_JOIN_KEY32 = 2, SUBGACC_JOIN_KEY64 = 3 };
 enum { SUBGACC_JOIN_ROWS = 0, SUBGACC_JOIN_COUNTS = 1, SUBGACC_JOIN_PAIRS = 2 };
+enum { SUBGACC_JOIN_OPT_SIZES = 1 };
 typedef struct subgacc_join_desc {
     int32_t struct_bytes, form, payload_kind, max_len;
     const int64_t *row_off;
@@ -293,13 +304,17 @@ typedef struct subgacc_join_desc {
     int64_t pair_block;
     const float *table;
     int64_t table_rows;
-    int32_t k, num_walks, num_steps, reserved;
+    int32_t k, num_walks, num_steps, options;
     float *out_xz;
     int32_t *out_idx;
     int64_t *out_segid;
     float *out_counts;
     int32_t *out_pairs, *out_mult, *out_cnt;
     int32_t *flags;
+    int64_t *out_seg;           /* options & SUBGACC_JOIN_OPT_SIZES */
+    void *size_state;
+    int64_t size_state_bytes;
+    int64_t *host_tail;
 } subgacc_join_desc;
 int subgacc_sjoin_fill_v2(const subgacc_join_desc *d, void *stream);
 

@@ -13,4 +13,4 @@ from .spjoin import (attn_stage, bgather, gather, gather_counts, gather_index, g
                      mean_stage, pgather, sample_and_gather, sample_and_gather_many, sjoin, split_batches, StepBuffers)
 from .subg_acc import batch_sampler, gset_sampler, walk_join, walk_sampler  # noqa: F401
 from .ppr import topk_ppr_matrix  # noqa: F401
-from .stepgraph import CapturedJoin, CapturedStep, CapturedStepPool  # noqa: F401
+from .stepgraph import CapturedJoin, CapturedJoinPool, CapturedStep, CapturedStepPool  # noqa: F401

@@ -54,13 +54,15 @@ class JoinDesc(C.Structure):
                 ("ids", C.c_void_p), ("payload", C.c_void_p), ("uniq_table", C.c_void_p), ("uniq_capacity", C.c_int64),
                 ("own", C.c_void_p), ("partner", C.c_void_p), ("S", C.c_int64), ("seg", C.c_void_p), ("pair_block", C.c_int64),
                 ("table", C.c_void_p), ("table_rows", C.c_int64), ("k", C.c_int32), ("num_walks", C.c_int32),
-                ("num_steps", C.c_int32), ("reserved", C.c_int32), ("out_xz", C.c_void_p), ("out_idx", C.c_void_p),
+                ("num_steps", C.c_int32), ("options", C.c_int32), ("out_xz", C.c_void_p), ("out_idx", C.c_void_p),
                 ("out_segid", C.c_void_p), ("out_counts", C.c_void_p), ("out_pairs", C.c_void_p), ("out_mult", C.c_void_p),
-                ("out_cnt", C.c_void_p), ("flags", C.c_void_p)]
+                ("out_cnt", C.c_void_p), ("flags", C.c_void_p), ("out_seg", C.c_void_p), ("size_state", C.c_void_p),
+                ("size_state_bytes", C.c_int64), ("host_tail", C.c_void_p)]
 
 
 JOIN_SFPTR, JOIN_F64, JOIN_KEY32, JOIN_KEY64 = 0, 1, 2, 3      # payload_kind
 JOIN_ROWS, JOIN_COUNTS, JOIN_PAIRS = 0, 1, 2                   # form
+JOIN_OPT_SIZES = 1                                             # options: size pass + fill in one call
 
 
 class SubgAccError(RuntimeError):

@@ -92,6 +92,139 @@ __global__ __launch_bounds__(kScanThreads) void sjoin_seg_scan_kernel(const SegL
     }
 }
 
+// ---- the size pass as ONE launch (subgacc_join_desc::options & SUBGACC_JOIN_OPT_SIZES): a single-pass scan with decoupled
+// look-back.  The join of a resident store is short work (65,536 pairs of the top-100 PPR store: 64 us of fill): the 16-byte memset
+// of the status words, the two size kernels above and the 24-byte read-back -- four more launches of ~4.5 us each, the floor of any
+// launch here -- were a quarter of the call.  This kernel is all four: it scans, ORs its status into flags[3] like any other entry
+// point (the status of THIS call, which a caller that never zeroes flags wants, is what host_tail gets) and leaves [R, status] in
+// pinned host memory.  What it needs in exchange is state that survives between launches -- a ticket, a count of
+// finished tiles, one word per tile -- all zero when a launch starts; the LAST tile to finish (every other tile is past its
+// look-back by then) zeroes it again, so the caller zeroes it once, when it allocates it.  Tiles take their number from the ticket
+// (a tile only ever waits for tiles that run already); a wait is bounded (kSpinLimit polls, never reached with clean state): a dirty
+// state -- a launch that was torn down half way -- ends in status bit 32 instead of a hang, and is clean again afterwards.
+struct SizeState {
+    unsigned long long ticket, done, status, total, pad[4];      // 64 bytes; one word per tile follows
+};
+constexpr unsigned long long kTileAgg = 1ull << 62, kTilePrefix = 2ull << 62, kTileValue = (1ull << 62) - 1;
+constexpr int kSpinLimit = 1 << 20;
+#ifndef SJ_ONEPASS_ITEMS      // segments per lane: 131,072 segments take 11.8 / 10.5 / 12.4 / 18.4 us with 2 / 4 / 8 / 16 (profiles/r24_onepass_items.log)
+#define SJ_ONEPASS_ITEMS 4
+#endif
+constexpr int kOnePassItems = SJ_ONEPASS_ITEMS;
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, kWave);
+    return v;
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(kScanThreads) void sjoin_sizes_onepass_kernel(const SegLen L, int64_t *__restrict__ out,
+                                                                           unsigned long long *__restrict__ state,
+                                                                           int64_t *__restrict__ host_tail, const int nb) {
+    constexpr int kTile = kScanThreads * ITEMS;
+    SizeState *hd = (SizeState *)state;
+    unsigned long long *tile = state + sizeof(SizeState) / 8;
+    __shared__ long long s_word[2];
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid / kWave;
+    if (tid == 0) s_word[0] = (long long)atomicAdd(&hd->ticket, 1ull);
+    __syncthreads();
+    const long long t = s_word[0];
+    if (t < nb) {
+        const int64_t base = t * kTile + (int64_t)tid * ITEMS;
+        int64_t v[ITEMS], s = 0;
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            const int64_t j = base + k;
+            v[k] = 0;
+            if (j < L.S) {
+                const int64_t a = L.own[j];
+                const bool oob = (uint64_t)a >= (uint64_t)L.n_rows;
+                bad |= oob || (L.partner && (uint64_t)L.partner[j] >= (uint64_t)L.n_rows);
+                if (!oob) v[k] = L.row_len ? (int64_t)L.row_len[a] : L.indptr[a + 1] - L.indptr[a];
+            }
+            s += v[k];
+        }
+        if (bad) atomicOr(&hd->status, 16ull);
+        int64_t tot;
+        int64_t run = block_exclusive_scan(s, &tot);
+        if (wid == 0) {
+            unsigned long long front = 0;
+            bool gave_up = false;
+            if (t == 0) {
+                if (lane == 0) __hip_atomic_store(&tile[0], kTilePrefix | (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                if (lane == 0) __hip_atomic_store(&tile[t], kTileAgg | (unsigned long long)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int spins = 0;
+                for (long long top = t - 1; top >= 0 && !gave_up; top -= kWave) {
+                    const long long idx = top - lane;
+                    unsigned long long x = kTilePrefix;          // in front of tile 0: the prefix 0
+                    if (idx >= 0) x = __hip_atomic_load(&tile[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while (__ballot((x >> 62) == 0) != 0ull) {
+                        if (++spins > kSpinLimit) {
+                            gave_up = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                        if ((x >> 62) == 0) x = __hip_atomic_load(&tile[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (gave_up) break;
+                    const unsigned long long pre = __ballot((x >> 62) == 2);
+                    if (pre != 0ull) {         // the nearest tile that knows its whole prefix ends the walk
+                        const int first = __ffsll((long long)pre) - 1;
+                        front += wave_sum_u64(lane <= first ? (x & kTileValue) : 0ull);
+                        break;
+                    }
+                    front += wave_sum_u64(x & kTileValue);
+                }
+                if (lane == 0) {
+                    if (gave_up) atomicOr(&hd->status, 32ull);
+                    __hip_atomic_store(&tile[t], kTilePrefix | ((front + (unsigned long long)tot) & kTileValue), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (lane == 0) s_word[1] = (long long)front;
+        }
+        __syncthreads();
+        run += s_word[1];
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            if (base + k < L.S) out[base + k] = run;
+            run += v[k];
+            if (base + k == L.S - 1) {     // the grand total lands in out[S] -- and in the state, where the finishing tile finds it
+                out[L.S] = run;
+                atomicExch(&hd->total, (unsigned long long)run);
+            }
+        }
+        if (L.S == 0 && tid == 0) out[0] = 0;
+    } else if (tid == 0) {
+        atomicOr(&hd->status, 32ull);      // a ticket beyond the tiles: the state was not zero when this launch began
+    }
+    // (no fence anywhere: everything one tile learns from another travels through device-scope atomics, which meet at the memory
+    // side; the segment pointers themselves are read by the NEXT kernel only)
+    __syncthreads();
+    if (tid == 0) s_word[0] = atomicAdd(&hd->done, 1ull) == (unsigned long long)gridDim.x - 1;
+    __syncthreads();
+    if (s_word[0]) {       // every other tile is past its look-back and its status: report, and leave the state as it was found
+        if (tid == 0) {
+            const unsigned long long st = atomicExch(&hd->status, 0ull);
+            const long long total = (long long)atomicExch(&hd->total, 0ull);
+            if (L.flags && st) atomicOr(&L.flags[3], (int)st);
+            if (host_tail) {
+                host_tail[0] = (st & 32) ? -1 : total;
+                host_tail[1] = (int64_t)st;
+            }
+            atomicExch(&hd->ticket, 0ull);
+            atomicExch(&hd->done, 0ull);
+        }
+        for (int i = tid; i < nb; i += kScanThreads) __hip_atomic_store(&tile[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// what subgacc_sjoin_fill_v2 sets around the fill of an OPT_SIZES call (JoinArgs::sized_here)
+static thread_local bool t_sized_here = false;
+
 struct JoinArgs {
     const int64_t *indptr;
     const int32_t *indices;
@@ -115,6 +248,8 @@ struct JoinArgs {
     int32_t key_M, key_m, key_shift;
     const int32_t *slot_id;   // slot -> SFptr (id plane of the numbered table of distinct LP rows); NULL with
     int32_t val_add;          // val_add = 1: the feature table is indexed by slot + 1 itself (row 0 = absent)
+    bool sized_here = t_sized_here;   // the segment pointers come from the size pass of this very call: flags[3] & 32 (its state was not
+                              // clean, the pointers mean nothing) ends every workgroup before it derives an address from them
     int64_t pb = 0;           // pair_block of a mirrored list: with partner == NULL the partner of segment j is the own row of its mirror
     int32_t split = 1;        // sjoin_pair_kernel: workgroups per pair (small batches: every one stages both rows and emits
                               // its share of the 64-row spans, so that a batch of ~1,000 pairs still fills the chip)
@@ -146,6 +281,9 @@ __device__ __forceinline__ void stream_store(float4 *p, const float4 &t) {
     __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(p));
 }
 __device__ __forceinline__ void stream_store(float2 *p, const float2 &t) {
+#ifdef SJ_DEV_SKIP_F64_STORES   // dev builds: what the float join costs without its stores (tools/ppr_join_probe.py)
+    if (t.x != -12345.f) return;
+#endif
     v2f v;
     v.x = t.x, v.y = t.y;
     __builtin_nontemporal_store(v, reinterpret_cast<v2f *>(p));
@@ -266,6 +404,7 @@ __global__ __launch_bounds__(kJoinThreads) void sjoin_fill_kernel(const JoinArgs
 
     const int64_t j = xcd_item(blockIdx.x, gridDim.x);
     if (j >= a.S) return;
+    if (a.sized_here && (a.flags[3] & 32)) return;
     const int lane = threadIdx.x;
     const int64_t ra = a.own[j], rb = join_partner(a, j);
     int64_t ab, na, bb, nb64;
@@ -458,6 +597,7 @@ __global__ __launch_bounds__(NT) void sjoin_keypair_kernel(const JoinArgs a, uin
     float *stage = (float *)(lds_raw + stage_off) + wave * (kWave * w + 4);
 
     SJ_HOOK_PAIR_ENTRY();
+    if (a.sized_here && (a.flags[3] & 32)) return;
     const uint32_t wg = (uint32_t)(blockIdx.x & (kXcds - 1)) * (gridDim.x / kXcds) + (blockIdx.x / kXcds);    // xcd_item, 32 bits
     uint32_t p = wg, part = 0;
     if (a.split > 1) {
@@ -680,6 +820,11 @@ __global__ __launch_bounds__(NT) void sjoin_keypair_kernel(const JoinArgs a, uin
 // LDS with a slot per member for its partner's value, the shorter row S in the registers of the lanes that loaded it, one halving
 // search of S in T, a hit hands S's value over -- with 8-byte payloads and a two-float output row that needs no staging:
 // xz[row] = (float(own), float((partner or 0.0) + 1.0 - 1.0)), the SciPy expression of train.py:33 evaluated in double.
+// (Measured and not kept, round 5: 2 / 4 / 8 one-wave pairs per workgroup, every wave on its own pair and its own slice of LDS, no
+// barrier between them -- 65,536 one-wave workgroups take 17 us to start when they do nothing else: 66.6 / 66.8-68 / 67.8 us against
+// 65.8-66.1, profiles/r24_ppr_pairs_per_wg.log.  Starting the workgroups is hidden behind the ones that run; timing builds
+// (profiles/r24_ppr_join_experiments.log: 67 us; 38 without the row loads, 52 without the stores, 37 without both, 55 without the
+// search) and the counters (HBM traffic 1.31x the algorithmic bytes = 4.9 TB/s of what a copy reaches here) say the rest.)
 template <int NT>
 __global__ __launch_bounds__(NT) void sjoin_f64pair_kernel(const JoinArgs a, uint32_t pb, uint32_t pairs) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -692,6 +837,7 @@ __global__ __launch_bounds__(NT) void sjoin_f64pair_kernel(const JoinArgs a, uin
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
 
     SJ_HOOK_PAIR_ENTRY();
+    if (a.sized_here && (a.flags[3] & 32)) return;
     const uint32_t wg = (uint32_t)(blockIdx.x & (kXcds - 1)) * (gridDim.x / kXcds) + (blockIdx.x / kXcds);    // xcd_item, 32 bits
     uint32_t p = wg, part = 0;
     if (a.split > 1) {
@@ -705,6 +851,7 @@ __global__ __launch_bounds__(NT) void sjoin_f64pair_kernel(const JoinArgs a, uin
         off = p - blk * pb;
     }
     const int64_t j = (int64_t)blk * 2 * pb + off, j2 = j + pb;
+    const double *vals = (const double *)a.data;
     const int64_t ra = a.own[j];
     int64_t rb;
     if (a.partner) {
@@ -717,7 +864,6 @@ __global__ __launch_bounds__(NT) void sjoin_f64pair_kernel(const JoinArgs a, uin
         rb = a.own[j2];
     const int64_t oA = a.seg[j], oB = a.seg[j2];
     const bool okA = (uint64_t)ra < (uint64_t)a.n_rows, okB = (uint64_t)rb < (uint64_t)a.n_rows;   // else: an empty row, never dereferenced
-    const double *vals = (const double *)a.data;
     int64_t ab = 0, bb = 0, na64 = 0, nb64 = 0;
     if (okA) {
         ab = a.indptr[ra];
@@ -1070,9 +1216,12 @@ __global__ __launch_bounds__(kPairThreads) void sjoin_pairs_kernel(const JoinArg
 
 using namespace subgacc;
 
+static size_t onepass_state_bytes(int64_t S);
 extern "C" size_t subgacc_sjoin_workspace_bytes(int64_t S) {
     if (S < 0) S = 0;
-    return align_up((size_t)S * 8, 256) + scan_workspace_bytes(S);
+    const size_t two_step = align_up((size_t)S * 8, 256) + scan_workspace_bytes(S);
+    const size_t one_call = onepass_state_bytes(S);       // SUBGACC_JOIN_OPT_SIZES: the single-pass scan's state
+    return two_step > one_call ? two_step : one_call;
 }
 
 static int join_sizes(const int64_t *spg_indptr, const int32_t *row_len, int64_t n_rows, const int64_t *own,
@@ -1097,6 +1246,27 @@ static int join_sizes(const int64_t *spg_indptr, const int32_t *row_len, int64_t
         hipLaunchKernelGGL(sjoin_seg_scan_kernel<kSegItems>, dim3((unsigned)nb), dim3(kScanThreads), 0, s, L, (const int64_t *)partial,
                            out_seg);
     }
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}
+
+// the size pass of subgacc_sjoin_fill_v2(options & SUBGACC_JOIN_OPT_SIZES): one launch, see sjoin_sizes_onepass_kernel
+static size_t onepass_state_bytes(int64_t S) {      // the header and one word per tile
+    return align_up(sizeof(SizeState) + (size_t)ceil_div(S > 0 ? S : 1, (int64_t)kScanThreads * kOnePassItems) * 8, 256);
+}
+
+
+static int join_sizes_onepass(const subgacc_join_desc *d, hipStream_t s) {
+    SG_REQUIRE(d->S >= 0 && d->n_rows >= 0 && d->out_seg && !d->seg, SUBGACC_ERR_BADARG,
+               "sjoin_fill_v2: OPT_SIZES writes out_seg [S+1] and reads no seg");
+    SG_REQUIRE(d->own || d->S == 0, SUBGACC_ERR_BADARG, "sjoin_fill_v2: null segment list");
+    const int64_t nb = d->S > 0 ? ceil_div(d->S, (int64_t)kScanThreads * kOnePassItems) : 1;
+    SG_REQUIRE(nb < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_fill_v2: too many segments");
+    SG_REQUIRE(d->size_state && (size_t)d->size_state_bytes >= onepass_state_bytes(d->S), SUBGACC_ERR_WORKSPACE,
+               "sjoin_fill_v2: size_state too small (subgacc_sjoin_workspace_bytes(S) bytes, zeroed once)");
+    SegLen L{d->row_off, d->row_len, d->n_rows, d->own, d->partner, d->flags, d->S};
+    hipLaunchKernelGGL(sjoin_sizes_onepass_kernel<kOnePassItems>, dim3((unsigned)nb), dim3(kScanThreads), 0, s, L, d->out_seg,
+                       (unsigned long long *)d->size_state, d->host_tail, (int)nb);
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }
@@ -1455,6 +1625,18 @@ extern "C" int subgacc_sjoin_fill_v2(const subgacc_join_desc *d, void *stream) {
     SG_REQUIRE((d->row_off != nullptr) != (d->row_len != nullptr), SUBGACC_ERR_BADARG,
                "sjoin_fill_v2: exactly one of row_off (packed rows) / row_len (strided rows)");
     const bool strided = d->row_len != nullptr;
+    const int64_t *seg = d->seg;
+    SG_REQUIRE((d->options & ~SUBGACC_JOIN_OPT_SIZES) == 0, SUBGACC_ERR_BADARG, "sjoin_fill_v2: unknown option bits %d", (int)d->options);
+    if (d->options & SUBGACC_JOIN_OPT_SIZES) {       // the whole join of a batch in one call: size pass, then the fill behind it
+        SG_REQUIRE(d->form == SUBGACC_JOIN_ROWS, SUBGACC_ERR_BADARG, "sjoin_fill_v2: OPT_SIZES goes with the row form");
+        const int rc = join_sizes_onepass(d, (hipStream_t)stream);
+        if (rc != SUBGACC_OK) return rc;
+        seg = d->out_seg;
+        t_sized_here = true;
+    }
+    struct Reset {
+        ~Reset() { t_sized_here = false; }
+    } reset_sized_here;
     if (d->form == SUBGACC_JOIN_COUNTS) {
         SG_REQUIRE(!strided && d->payload_kind == SUBGACC_JOIN_SFPTR, SUBGACC_ERR_BADARG, "sjoin_fill_v2: the count form joins a packed SFptr store");
         return sjoin_counts_impl(d->row_off, d->n_rows, d->ids, (const int32_t *)d->payload, d->own, d->partner, d->S, d->table_rows,
@@ -1462,7 +1644,7 @@ extern "C" int subgacc_sjoin_fill_v2(const subgacc_join_desc *d, void *stream) {
     }
     if (d->form == SUBGACC_JOIN_PAIRS) {
         SG_REQUIRE(!strided && d->payload_kind == SUBGACC_JOIN_SFPTR, SUBGACC_ERR_BADARG, "sjoin_fill_v2: the pair form joins a packed SFptr store");
-        return sjoin_pairs_impl(d->row_off, d->n_rows, d->ids, (const int32_t *)d->payload, d->own, d->partner, d->S, d->seg, d->out_pairs,
+        return sjoin_pairs_impl(d->row_off, d->n_rows, d->ids, (const int32_t *)d->payload, d->own, d->partner, d->S, seg, d->out_pairs,
                                 d->out_mult, d->out_cnt, d->max_len, d->pair_block, d->flags, stream);
     }
     SG_REQUIRE(d->form == SUBGACC_JOIN_ROWS, SUBGACC_ERR_BADARG, "sjoin_fill_v2: unknown form %d", (int)d->form);
@@ -1470,27 +1652,27 @@ extern "C" int subgacc_sjoin_fill_v2(const subgacc_join_desc *d, void *stream) {
     case SUBGACC_JOIN_SFPTR:
         if (strided)
             return sjoin_fill_rows_impl(d->row_len, d->n_rows, d->row_stride, d->ids, (const int32_t *)d->payload, d->uniq_table,
-                                        d->uniq_capacity, d->own, d->partner, d->S, d->seg, d->table, d->table_rows, d->k, d->out_xz,
+                                        d->uniq_capacity, d->own, d->partner, d->S, seg, d->table, d->table_rows, d->k, d->out_xz,
                                         d->out_idx, d->out_segid, d->pair_block, d->flags, stream);
-        return sjoin_fill_impl(d->row_off, d->n_rows, d->ids, (const int32_t *)d->payload, nullptr, d->own, d->partner, d->S, d->seg,
+        return sjoin_fill_impl(d->row_off, d->n_rows, d->ids, (const int32_t *)d->payload, nullptr, d->own, d->partner, d->S, seg,
                                d->table, d->table_rows, d->k, d->out_xz, d->out_idx, d->out_segid, d->max_len, d->pair_block, d->flags,
                                stream);
     case SUBGACC_JOIN_F64:
         SG_REQUIRE(!strided, SUBGACC_ERR_BADARG, "sjoin_fill_v2: a float payload lives in a packed store");
-        return sjoin_fill_impl(d->row_off, d->n_rows, d->ids, nullptr, (const double *)d->payload, d->own, d->partner, d->S, d->seg,
+        return sjoin_fill_impl(d->row_off, d->n_rows, d->ids, nullptr, (const double *)d->payload, d->own, d->partner, d->S, seg,
                                nullptr, 0, 1, d->out_xz, nullptr, d->out_segid, d->max_len, d->pair_block, d->flags, stream);
     case SUBGACC_JOIN_KEY32:
         if (strided) {
             SG_REQUIRE(!d->out_segid, SUBGACC_ERR_BADARG, "sjoin_fill_v2: strided key rows are joined with segment pointers");
             return sjoin_fill_keyrows_impl(d->row_len, d->n_rows, d->row_stride, d->ids, (const int32_t *)d->payload, d->own, d->partner,
-                                           d->S, d->seg, d->num_walks, d->num_steps, d->out_xz, d->pair_block, d->flags, stream);
+                                           d->S, seg, d->num_walks, d->num_steps, d->out_xz, d->pair_block, d->flags, stream);
         }
-        return sjoin_fill_keys_impl(d->row_off, d->n_rows, d->ids, (const int32_t *)d->payload, d->own, d->partner, d->S, d->seg,
+        return sjoin_fill_keys_impl(d->row_off, d->n_rows, d->ids, (const int32_t *)d->payload, d->own, d->partner, d->S, seg,
                                     d->num_walks, d->num_steps, d->out_xz, d->out_segid, d->max_len, d->pair_block, d->flags, stream);
     case SUBGACC_JOIN_KEY64:
         SG_REQUIRE(strided && !d->out_segid, SUBGACC_ERR_BADARG, "sjoin_fill_v2: 64-bit keys are the payload of strided rows (subgacc_walk_keyrows64)");
         return sjoin_fill_keyrows64_impl(d->row_len, d->n_rows, d->row_stride, d->ids, (const uint64_t *)d->payload, d->own, d->partner,
-                                         d->S, d->seg, d->num_walks, d->num_steps, d->out_xz, d->pair_block, d->flags, stream);
+                                         d->S, seg, d->num_walks, d->num_steps, d->out_xz, d->pair_block, d->flags, stream);
     default:
         SG_REQUIRE(false, SUBGACC_ERR_BADARG, "sjoin_fill_v2: unknown payload kind %d", (int)d->payload_kind);
     }

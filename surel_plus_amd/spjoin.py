@@ -74,11 +74,10 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
             raise ValueError("partner=None needs a mirrored segment list (pair_block > 0)")
     else:
         partner = partner.contiguous()
-    seg = torch.empty(S + 1, dtype=torch.int64, device=dev)
+    seg, flags = _seg_and_flags(S, dev)
     ws = torch.empty(L.subgacc_sjoin_workspace_bytes(S), dtype=torch.uint8, device=dev)
     if isinstance(spg, StridedSpG):
-        return _sjoin_strided(spg, own, partner, seg, ws, encode, ptr_mode, return_index, pair_block, out, lazy)
-    flags = torch.zeros(4, dtype=torch.int32, device=dev)
+        return _sjoin_strided(spg, own, partner, seg, flags, ws, encode, ptr_mode, return_index, pair_block, out, lazy)
     check(L.subgacc_sjoin_sizes(ptr(spg.indptr), spg.n_rows, ptr(own), ptr(partner), S, ptr(seg), ptr(flags), ptr(ws),
                                 ws.numel(), st))
     is_f64 = spg.data.dtype == torch.float64
@@ -158,14 +157,13 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
     return out, (seg if ptr_mode else _with_pointers(segid, seg)), flags
 
 
-def _sjoin_strided(spg, own, partner, seg, ws, encode, ptr_mode, return_index, pair_block, out, lazy):
+def _sjoin_strided(spg, own, partner, seg, flags, ws, encode, ptr_mode, return_index, pair_block, out, lazy):
     """sjoin over a StridedSpG (rows where the fused walk kernel left them): mirrored lists, segment pointers."""
     L, dev, st, S = lib(), spg.device, stream_ptr(), own.numel()
     if pair_block <= 0:
         raise ValueError("a StridedSpG is joined by gather / hgather (mirrored segment lists); use .to_csr() for the other forms")
     if lazy and not ptr_mode:
         raise ValueError("lazy=True needs ptr=True")
-    flags = torch.zeros(4, dtype=torch.int32, device=dev)
     check(L.subgacc_sjoin_sizes_rows(ptr(spg.nsize), spg.n_rows, ptr(own), ptr(partner), S, ptr(seg), ptr(flags), ptr(ws),
                                      ws.numel(), st))
     R = None if lazy else _size_and_row_check(seg, S, flags, spg.n_rows)
@@ -239,11 +237,29 @@ def _with_pointers(segid, seg):
     return segid
 
 
+def _seg_and_flags(S, dev):
+    """Segment pointers int64[S+1] and the join's int32[4] status words as ONE allocation: what the host reads of a join --
+    the output size seg[S] and the status word flags[3] -- is then one contiguous 24-byte copy (`seg.join_tail`), with no
+    cast / concatenate kernels in front of it (they were two of the seven nodes of a captured join)."""
+    buf = torch.empty(S + 3, dtype=torch.int64, device=dev)
+    flags = buf[S + 1:].view(torch.int32)
+    flags.zero_()
+    seg = buf[:S + 1]
+    seg.join_tail = buf[S:]         # [R | flags[0], flags[1] | flags[2], flags[3]]
+    return seg, flags
+
+
+def tail_words(tail):
+    """(R, status word) of a join_tail read back as three int64"""
+    R, _, w = tail
+    return int(R), (int(w) >> 32) & 0xFFFFFFFF
+
+
 def _size_and_row_check(seg, S, flags, n_rows):
     """The join's one host read: the output size R = seg[S] and, in the same copy, the status word of the size pass --
     a row number outside the store is an IndexError here as it is in the reference (scipy's x[edge[0]], train.py:15);
     the kernels never dereference such a row (it reads as empty), so nothing out of bounds has happened by now."""
-    R, status = torch.cat([seg[S:S + 1], flags[3:4].long()]).tolist()
+    R, status = tail_words(seg.join_tail.tolist())
     if status & 16:
         raise IndexError(f"row index out of range for an SpG with {n_rows} rows")
     return int(R)
@@ -841,9 +857,8 @@ def gather_pairs(edge, x, device=None):
     own = torch.cat([e[0], e[1]]).contiguous()
     partner = torch.cat([e[1], e[0]]).contiguous()
     S = 2 * B
-    seg = torch.empty(S + 1, dtype=torch.int64, device=dev)
+    seg, flags = _seg_and_flags(S, dev)
     ws = torch.empty(L.subgacc_sjoin_workspace_bytes(S), dtype=torch.uint8, device=dev)
-    flags = torch.zeros(4, dtype=torch.int32, device=dev)
     check(L.subgacc_sjoin_sizes(ptr(spg.indptr), spg.n_rows, ptr(own), ptr(partner), S, ptr(seg), ptr(flags), ptr(ws),
                                 ws.numel(), st))
     R = _size_and_row_check(seg, S, flags, spg.n_rows)

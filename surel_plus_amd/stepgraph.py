@@ -11,6 +11,7 @@ Philox streams are keyed by (seed, root id, walk, step) and the seed is baked in
 is the same in every replay -- the semantics of the reference's offline stage, where every node's set is sampled once
 and joined in every epoch (main.py:172-178).
 """
+import ctypes as _ctypes
 import os
 
 import torch
@@ -155,11 +156,14 @@ class CapturedStepPool:
     (xz, indptr) are views of the lane's static buffers: valid until that lane is submitted again, `lanes` submits later."""
 
     def __init__(self, csr, pairs, lanes=4, **kw):
-        self.steps = [CapturedStep(csr, pairs, **kw) for _ in range(int(lanes))]
-        self.streams = [torch.cuda.Stream(device=csr.device) for _ in self.steps]
+        self._lanes([CapturedStep(csr, pairs, **kw) for _ in range(int(lanes))], csr.device)
+
+    def _lanes(self, steps, device):
+        self.steps, self.device = steps, device
+        self.streams = [torch.cuda.Stream(device=device) for _ in self.steps]
         self._busy = [False] * len(self.steps)
         self._next = 0
-        self._caller = torch.cuda.current_stream(csr.device)     # looked up once: torch's stream bookkeeping costs ~6 us a call
+        self._caller = torch.cuda.current_stream(device)     # looked up once: torch's stream bookkeeping costs ~6 us a call
 
     def submit(self, edge, stream=None, sync=True):
         """stream: the stream `edge` was produced on -- MANDATORY when the caller's current stream is not the one this pool was
@@ -173,7 +177,7 @@ class CapturedStepPool:
         self._next = (i + 1) % len(self.steps)
         st = self.streams[i]
         caller = self._caller if stream is None else stream
-        if _DEBUG and torch.cuda.current_stream(self.steps[i].csr.device) != caller:
+        if _DEBUG and torch.cuda.current_stream(self.device) != caller:
             raise RuntimeError("CapturedStepPool.submit: the current stream is not the pool's creation stream -- pass stream=")
         if sync:
             st.wait_stream(caller)                     # `edge` may have been produced on the caller's stream just now
@@ -191,61 +195,129 @@ class CapturedStepPool:
 
 
 class CapturedJoin:
-    """gather(edge, z, encode) over a RESIDENT store for a fixed number of pairs, captured as ONE HIP graph: the reference's
-    online loop joins one batch after the other from the store it sampled once (train.py:120-127), and for short rows -- the
-    top-100 PPR store: 65,536 pairs are ~90 us of kernels -- the three launches of a join and the few allocations between them
-    cost the host more than the GPU needs (0.17 ms per step eagerly).  Same results as gather() (the graph holds exactly its
-    launches: segment reduce, segment scan, fill); sizes and the join's status word reach the host in one small copy.
+    """gather(edge, z, encode) over a RESIDENT store for a fixed number of pairs, with everything a call needs built once: the
+    reference's online loop joins one batch after the other from the store it sampled once (train.py:120-127), and for short rows
+    -- the top-100 PPR store: 65,536 pairs are 64 us of fill -- what surrounds the fill decides the rate.  One call is ONE entry
+    into the library (subgacc_sjoin_fill_v2 with SUBGACC_JOIN_OPT_SIZES: the size pass as a single launch, the fill behind it) on a
+    descriptor and buffers made here; the row count and the status word arrive in pinned host memory by themselves -- no memset,
+    no read-back copy, no allocation, ~10 us of host time.  Same results as gather().
 
         cj = CapturedJoin(z, 65536)                    # float payload; or CapturedJoin(z, B, encode=table) / (zk, B, encode=zk.slot_table())
-        cj(edge); xz, indptr = cj.finish()             # views of the object's static buffers, valid until the next call"""
+        cj(edge); xz, indptr = cj.finish()             # views of the object's static buffers, valid until the next call
 
-    def __init__(self, z, pairs, encode=None, warmup=2):
-        from .spjoin import gather
+    graph=True replays the same launches as ONE HIP graph (rounds 3-4's form; the name is from there): less host time still for
+    batches of ~1,024 pairs, but every replay costs the GPU ~20 us between graphs (`profiles/r24_join_call_probe.log`)."""
+
+    def __init__(self, z, pairs, encode=None, warmup=2, graph=False):
+        import ctypes as C
+        from .spg import KEY_ROWS_ENCODE
         self.z, self.B, self.encode = z, int(pairs), encode
         dev = z.device
+        B, S = self.B, 2 * self.B
+        d = _lib.JoinDesc()
+        d.struct_bytes, d.form, d.options = C.sizeof(_lib.JoinDesc), _lib.JOIN_ROWS, _lib.JOIN_OPT_SIZES
         if getattr(z, "keyrows", False):
-            k = z.key_m + 1
+            if encode is not KEY_ROWS_ENCODE:
+                raise ValueError("a keyed() store is joined with encode=zk.slot_table()")
+            k, d.payload_kind, d.num_walks, d.num_steps = z.key_m + 1, _lib.JOIN_KEY32, z.key_M, z.key_m
         elif z.data.dtype == torch.float64:
-            k = 1
+            if encode is not None:
+                raise TypeError("a float-payload SpG is joined without an encode table (train.py:39-43)")
+            k, d.payload_kind = 1, _lib.JOIN_F64
         else:
-            k = int(encode.shape[1])
-        self.edge = torch.zeros((2, self.B), dtype=torch.int64, device=dev)
-        self.out = torch.empty(2 * self.B * z.max_len * 2 * k, dtype=torch.float32, device=dev)
-        run = lambda: gather(self.edge, z, dev, ptr=True, encode=encode, out=self.out, lazy=True)     # noqa: E731
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(max(int(warmup), 1)):
-                run()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        self._host = torch.empty(2, dtype=torch.int64, pin_memory=True)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.xz, self.ind = run()
-            self._tail = torch.cat([self.ind[-1:], self.ind.join_flags[3:4].to(torch.int64)])
-            self._host.copy_(self._tail, non_blocking=True)
+            if encode is None:
+                raise NotImplementedError("an integer SpG needs the encode table")
+            self._table = encode.to(device=dev, dtype=torch.float32).contiguous()
+            if self._table.shape[0] <= z.max_data:
+                raise IndexError(f"index {z.max_data} is out of bounds for the encode table with {self._table.shape[0]} rows")
+            k, d.payload_kind = int(self._table.shape[1]), _lib.JOIN_SFPTR
+            d.table, d.table_rows, d.k = self._table.data_ptr(), self._table.shape[0], k
+        self.edge = torch.zeros((2, B), dtype=torch.int64, device=dev)
+        self.out = torch.empty(S * z.max_len * 2 * k, dtype=torch.float32, device=dev)
+        self.ind = torch.zeros(S + 1, dtype=torch.int64, device=dev)
+        self.flags = torch.zeros(4, dtype=torch.int32, device=dev)
+        self._state = torch.zeros(_lib.lib().subgacc_sjoin_workspace_bytes(S), dtype=torch.uint8, device=dev)     # zeroed ONCE
+        self._host = torch.zeros(2, dtype=torch.int64, pin_memory=True)
+        d.row_off, d.n_rows, d.ids, d.payload, d.max_len = z.indptr.data_ptr(), z.n_rows, z.indices.data_ptr(), z.data.data_ptr(), z.max_len
+        d.own, d.S, d.pair_block = self.edge.data_ptr(), S, B
+        d.out_xz, d.flags, d.out_seg = self.out.data_ptr(), self.flags.data_ptr(), self.ind.data_ptr()
+        d.size_state, d.size_state_bytes, d.host_tail = self._state.data_ptr(), self._state.numel(), self._host.data_ptr()
+        self._d, self._ref = d, C.byref(d)
+        self._fill = _lib.lib().subgacc_sjoin_fill_v2
+        self._own = None
+        self.xz = self.out.view(S * z.max_len, 2, k)
         self._event = torch.cuda.Event()
+        self.graph = None
+        if graph:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(max(int(warmup), 1)):
+                    self._launch()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._launch()            # (the capturing stream is the current one)
+
+    def _launch(self, stream=None):
+        st = stream if stream is not None else torch.cuda.current_stream(self.edge.device)
+        _lib.check(self._fill(self._ref, _ctypes.c_void_p(st.cuda_stream)))
+        return st
 
     def __call__(self, edge, stream=None):
-        """queue the join of `edge` [2, B]: copy-in, replay and the completion event all go to ONE stream -- `stream` if given
-        (the calling convention of CapturedStep.__call__ / CapturedStepPool.submit), else the current one"""
+        """queue the join of `edge` [2, B] on `stream` if given (the calling convention of CapturedStep.__call__ /
+        CapturedStepPool.submit), else on the current one; a contiguous int64 device tensor is joined where it lies (and kept
+        alive until the next call), anything else goes through the object's static buffer"""
         if tuple(edge.shape) != (2, self.B):
-            raise ValueError(f"this join was captured for [2, {self.B}] pairs")
-        if stream is not None:
+            raise ValueError(f"this join was made for [2, {self.B}] pairs")
+        if self.graph is None and torch.is_tensor(edge) and edge.dtype == torch.int64 and edge.device == self.edge.device and edge.is_contiguous():
+            self._own = edge
+            self._d.own = edge.data_ptr()
+            self._event.record(self._launch(stream))
+            return self
+        if stream is not None and torch.cuda.current_stream(self.edge.device) != stream:
             with torch.cuda.stream(stream):
-                return self(edge)
+                return self(edge, stream)
         if edge is not self.edge:
-            self.edge.copy_(edge, non_blocking=True)
-        self.graph.replay()
-        self._event.record()
+            self.edge.copy_(torch.as_tensor(edge), non_blocking=True)
+        self._own, self._d.own = None, self.edge.data_ptr()
+        if self.graph is not None:
+            self.graph.replay()
+            self._event.record()
+        else:
+            self._event.record(self._launch(stream))
         return self
 
     def finish(self):
         """wait for the queued join, raise on its errors -> (xz float32 [R,2,k] view of the static buffer, indptr)"""
         self._event.synchronize()
         rows, word = self._host.tolist()
+        if _DEBUG:
+            word |= int(self.flags[3].item())
+        if word & 32:
+            self._state.zero_()
+            self.flags.zero_()          # (bit 32 in the device flags keeps every fill from running)
+            raise _lib.SubgAccError("the join's size state was not clean (an aborted launch?): zeroed, call again")
         if word & 16:
             raise IndexError(f"row index out of range for an SpG with {self.z.n_rows} rows")
+        if word & 1:
+            raise _lib.SubgAccError("SpG row longer than SpG.max_len")
+        if word & 2:
+            raise IndexError("SFptr outside the encode table")
         return self.xz[:rows], self.ind
+
+
+class CapturedJoinPool(CapturedStepPool):
+    """`lanes` CapturedJoins over one resident store, each on its own HIP stream, taken in turn -- the serving loop for joins of
+    short rows: the size pass and the first waves of one batch's fill run under the last waves of the batch before it (the top-100
+    PPR store, 65,536 pairs: 1.02 G pairs/s with two lanes against 0.83 G one call after the other on one stream,
+    `profiles/r24_join_call_probe.log`).  submit() / finish() as CapturedStepPool's:
+
+        pool = CapturedJoinPool(z, 65536)              # or (z, B, encode=table) / (zk, B, encode=zk.slot_table())
+        t = pool.submit(edge)                          # queues the batch on the next lane (which must be free); nothing waits
+        xz, indptr = pool.finish(t)                    # views of the lane's buffers: valid until that lane is submitted again"""
+
+    def __init__(self, z, pairs, lanes=2, encode=None, **kw):
+        self._lanes([CapturedJoin(z, pairs, encode=encode, **kw) for _ in range(int(lanes))], z.device)
+

@@ -105,8 +105,31 @@ int main(int argc, char **argv) {
         d.own = own, d.partner = partner, d.S = 4, d.seg = seg, d.pair_block = 2;
         d.table = tab, d.table_rows = c + 1, d.k = m + 1, d.out_xz = xz, d.flags = flags;
         CHECK(p_subgacc_sjoin_fill_v2(&d, NULL) == 0);
+        /* the same join as ONE call (a serving loop's form): the size pass runs first, as a single launch, then the fill; the row
+         * count and the status word arrive in pinned host memory by themselves.  size_state: zeroed once (dev() does), left clean */
+        int64_t *seg1 = dev(5 * 8, NULL), *tail = NULL, seg1_h[5];
+        float *xz1 = dev(4 * STRIDE * 2 * (m + 1) * 4, NULL), *a_h = malloc(R * 2 * (m + 1) * 4), *b_h = malloc(R * 2 * (m + 1) * 4);
+        void *state = dev(jwb, NULL);
+        HIP(hipHostMalloc((void **)&tail, 16, 0));
+        tail[0] = tail[1] = -7;
+        d.seg = NULL, d.options = SUBGACC_JOIN_OPT_SIZES, d.out_seg = seg1, d.size_state = state, d.size_state_bytes = (int64_t)jwb;
+        d.host_tail = tail, d.out_xz = xz1;
+        for (int rep = 0; rep < 2; ++rep) {
+            CHECK(p_subgacc_sjoin_fill_v2(&d, NULL) == 0);
+            HIP(hipDeviceSynchronize());
+            CHECK(tail[0] == R && tail[1] == 0);
+            HIP(hipMemcpy(seg1_h, seg1, sizeof seg1_h, hipMemcpyDeviceToHost));
+            CHECK(memcmp(seg1_h, seg_h, sizeof seg_h) == 0);
+            HIP(hipMemcpy(a_h, xz, R * 2 * (m + 1) * 4, hipMemcpyDeviceToHost));
+            HIP(hipMemcpy(b_h, xz1, R * 2 * (m + 1) * 4, hipMemcpyDeviceToHost));
+            CHECK(memcmp(a_h, b_h, R * 2 * (m + 1) * 4) == 0);
+            tail[0] = -7;
+        }
+        d.size_state_bytes = 8;                              /* a state too small is refused */
+        CHECK(p_subgacc_sjoin_fill_v2(&d, NULL) == SUBGACC_ERR_WORKSPACE);
         d.struct_bytes = 8;                                  /* a descriptor of another layout is refused, not misread */
         CHECK(p_subgacc_sjoin_fill_v2(&d, NULL) == SUBGACC_ERR_BADARG);
+        free(a_h), free(b_h);
     }
     HIP(hipDeviceSynchronize());
 

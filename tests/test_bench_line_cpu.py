@@ -16,7 +16,7 @@ def fat_record(bench):
     wl = {"metric": "query-pairs/sec (sample+SpJoin)", "value": 1.23456789e8, "unit": "query-pairs/s", "steps": 100, "warmup": 3,
           "ms_per_step": 1.123456789, "dtype": "int32",
           "config": {"workload": "w" * 300, "pairs_per_s_min": 1.0, "pairs_per_s_max": 2.0, "stage_ms": {"sjoin_fill": 0.4},
-                     "dedup_roots_loop": {"pairs_per_s": 3.0}, "join_call_ms_three_launches": 0.1,
+                     "dedup_roots_loop": {"pairs_per_s": 3.0}, "join_call_ms": 0.1,
                      "frac_of_hbm_peak_whole_join_call": 0.4321, "region_pairs_per_s": list(range(50))},
           "roofline": {"frac": 0.2, "join_frac": 0.55, "kernel_ms": 0.6, "traffic": 4.5e9,
                        "random_line_roof": {"frac": 1.0, "source": "s" * 400}},

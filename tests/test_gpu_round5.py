@@ -171,3 +171,99 @@ def test_pair_join_at_every_span_and_trip_boundary(sp, payload, B):
         oxz, oind = oracle.gather(e, spg_host, ptr=ptr, encode=enc_host)
         assert np.array_equal(ind.cpu().numpy(), oind)
         assert np.array_equal(xz.cpu().numpy(), oxz)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_one_call_join_sizes_in_one_launch(sp, graph):
+    """subgacc_sjoin_fill_v2 with SUBGACC_JOIN_OPT_SIZES (CapturedJoin's call): the size pass as ONE launch -- a single-pass scan
+    whose state cleans itself -- then the fill.  Segment pointers and rows equal gather()'s for 1 tile (2,048 segments), 2 tiles,
+    a full look-back window and beyond it (70,000 pairs = 69 tiles), call after call on the same state; a row outside the store
+    raises IndexError at finish(); a state that is not clean ends in an error (never a hang) and works again afterwards."""
+    from surel_plus_amd.graphs import ppr_like_spg
+    N = 5000
+    zf = ppr_like_spg(N, 40, seed=5)
+    rs = np.random.default_rng(11)
+    for B in (1, 1024, 1025, 70000):
+        cj = sp.CapturedJoin(zf, B, graph=graph)
+        for rep in range(3):
+            e = torch.from_numpy(rs.integers(0, N, (2, B))).cuda()
+            xz, ind = cj(e).finish()
+            wxz, wind = sp.gather(e, zf, "cuda", ptr=True, encode=None)
+            assert torch.equal(ind, wind) and torch.equal(xz, wxz), (B, rep)
+            assert int(cj._state.view(torch.int64)[: 8 + -(-2 * B // 1024)].abs().sum().item()) == 0   # header + one word per tile: left clean
+    e[0, B // 2] = N                                        # a row outside the store: flagged by the size pass, never dereferenced
+    with pytest.raises(IndexError):
+        cj(e).finish()
+    e[0, B // 2] = 0
+    cj._state.view(torch.int64)[0] = 5                      # a ticket left behind by a launch that never finished
+    with pytest.raises(sp.SubgAccError, match="not clean"):
+        cj(e).finish()
+    xz, ind = cj(e).finish()
+    wxz, wind = sp.gather(e, zf, "cuda", ptr=True, encode=None)
+    assert torch.equal(ind, wind) and torch.equal(xz, wxz)
+
+
+def test_one_call_join_over_strided_key_rows_matches_the_two_step_form(sp):
+    """OPT_SIZES over the strided key rows of a transient batch (row_len + row_stride: the on-demand step's store), through the
+    descriptor itself: out_seg, the rows and host_tail equal subgacc_sjoin_sizes_rows + the plain fill; flags[3] is ORed into"""
+    from surel_plus_amd import _lib
+    from surel_plus_amd.graphs import query_pairs
+    from surel_plus_amd.spg import sample_spg
+    from surel_plus_amd.spjoin import _arange_segments, sjoin
+    from test_gpu_parity import sym_graph
+    ptr_, idx = sym_graph(4000, 30000, seed=2, hubs=2)
+    csr = sp.DeviceCSR(ptr_, idx)
+    B = 3000
+    e = query_pairs(csr, B, seed=4)
+    z, sets = sample_spg(csr, e.reshape(-1).to(torch.int32), num_walks=100, num_steps=3, seed=9, rng="philox", strided=True, fused=True,
+                         number_rows=False)
+    assert sets.keyrows and getattr(z, "keyrows", False)
+    own, partner = _arange_segments(B, "cuda")
+    xz, ind, _ = sjoin(z, own, partner, z.slot_table(), pair_block=B)
+    S = 2 * B
+    out = torch.empty_like(xz)
+    seg = torch.zeros(S + 1, dtype=torch.int64, device="cuda")
+    state = torch.zeros(_lib.lib().subgacc_sjoin_workspace_bytes(S), dtype=torch.uint8, device="cuda")
+    host = torch.full((2,), -7, dtype=torch.int64).pin_memory()
+    flags = torch.tensor([7, 7, 7, 64], dtype=torch.int32, device="cuda")
+    for _ in range(2):
+        _lib.join_fill(_lib.JOIN_ROWS, _lib.JOIN_KEY64 if z.sets.key64 else _lib.JOIN_KEY32, options=_lib.JOIN_OPT_SIZES, row_len=z.nsize,
+                       n_rows=z.n_rows, row_stride=z.stride, ids=z.indices, payload=z.slot, own=own, partner=partner, S=S, pair_block=B,
+                       num_walks=100, num_steps=3, out_xz=out, flags=flags, out_seg=seg, size_state=state, size_state_bytes=state.numel(),
+                       host_tail=host)
+        torch.cuda.synchronize()
+        assert torch.equal(seg, ind) and torch.equal(out, xz)
+        assert host.tolist() == [xz.shape[0], 0] and flags.tolist() == [7, 7, 7, 64]
+        out.zero_(), seg.zero_()
+    # what the descriptor refuses: a seg next to OPT_SIZES, no state, a state too small, another form
+    kw = dict(row_len=z.nsize, n_rows=z.n_rows, row_stride=z.stride, ids=z.indices, payload=z.slot, own=own, S=S, pair_block=B, num_walks=100,
+              num_steps=3, out_xz=out, flags=flags, options=_lib.JOIN_OPT_SIZES)
+    for bad in (dict(out_seg=seg, seg=seg, size_state=state, size_state_bytes=state.numel()), dict(out_seg=seg),
+                dict(out_seg=seg, size_state=state, size_state_bytes=64), dict(size_state=state, size_state_bytes=state.numel())):
+        with pytest.raises((TypeError, MemoryError, sp.SubgAccError)):      # (the mirror raises the reference's exception types)
+            _lib.join_fill(_lib.JOIN_ROWS, _lib.JOIN_KEY32, **kw, **bad)
+
+
+def test_join_pool_lanes_on_their_own_streams_equal_gather(sp):
+    """CapturedJoinPool: CapturedJoins taken in turn, each on its own stream (the serving loop of short-row joins) -- every batch's
+    (xz, indptr) equals gather()'s, whatever is still in flight on the other lanes; a lane that is busy refuses"""
+    from surel_plus_amd.graphs import ppr_like_spg
+    N, B = 4000, 3000
+    zf = ppr_like_spg(N, 60, seed=8)
+    rs = np.random.default_rng(5)
+    batches = [torch.from_numpy(rs.integers(0, N, (2, B))).cuda() for _ in range(7)]
+    want = [sp.gather(b, zf, "cuda", ptr=True, encode=None) for b in batches]
+    torch.cuda.synchronize()
+    pool = sp.CapturedJoinPool(zf, B, lanes=3)
+    pend = []
+    for i, b in enumerate(batches):
+        if len(pend) == 3:
+            j, t = pend.pop(0)
+            xz, ind = pool.finish(t)
+            assert torch.equal(ind, want[j][1]) and torch.equal(xz, want[j][0]), j
+        pend.append((i, pool.submit(b)))
+    with pytest.raises(RuntimeError, match="in flight"):
+        pool.submit(batches[0])
+    for j, t in pend:
+        xz, ind = pool.finish(t)
+        assert torch.equal(ind, want[j][1]) and torch.equal(xz, want[j][0]), j
