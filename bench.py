@@ -954,6 +954,7 @@ def flatten(out):
     jb = f.get("J_b1024_keyed") or {}
     put("offline_J_b1024_eager_pairs_per_s", (jb.get("eager") or {}).get("pairs_per_s"))
     put("offline_J_b1024_graph_pairs_per_s", (jb.get("graph") or {}).get("pairs_per_s"))
+    put("offline_J_b1024_pool4_pairs_per_s", (jb.get("pool_4lanes") or {}).get("pairs_per_s"))
     put("offline_J_b1024_many64_pairs_per_s", (jb.get("many_64") or {}).get("pairs_per_s"))
     if "failed" in jb:
         put("offline_J_b1024_failed", str(jb["failed"])[:200])

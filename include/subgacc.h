@@ -167,6 +167,10 @@ size_t subgacc_scan_workspace_bytes(int64_t n);
 int subgacc_exclusive_scan_i32(const int32_t *in, int64_t n, int64_t *out, void *workspace, size_t workspace_bytes,
                                void *stream);
 
+/* n <= 4,096 words of device memory (sizes, status words) to pinned, device-visible host memory by a one-wave kernel -- the read-back
+ * of a lazily resolved step without a copy engine in the stream (the reference returns its sizes by value, subg_acc.c:1017-1024). */
+int subgacc_publish_words(const int64_t *src, int64_t n, int64_t *host_dst, void *stream);
+
 /* Left-compact the strided per-root sets (subg_acc.c:870-871): row i goes to [row_off[i], +nsize[i]).
  * out_keys may be NULL when uniq_table is given.  With uniq_table (see below; `uniq_capacity` slots) the pass
  * also inserts every member's key with position tag_base + row_off[i] + r (subg_acc.c:957-978) and writes the

@@ -34,7 +34,7 @@ SYMBOLS = (
     "subgacc_hop_records_format", "subgacc_hop_records_build", "subgacc_sjoin_fill_keyrows", "subgacc_sjoin_fill_keys", "subgacc_step_dedup_workspace_bytes",
     "subgacc_step_prologue_dedup", "subgacc_walk_spg_sparse",
     "subgacc_keyrows_register", "subgacc_keyrows_cand_capacity", "subgacc_walk_tags", "subgacc_keyrows_compact", "subgacc_keyrows_translate", "subgacc_rng_replay", "subgacc_walk_keyrows64", "subgacc_sjoin_fill_keyrows64", "subgacc_worklist_workspace_bytes", "subgacc_worklist_by_root", "subgacc_walk_spg_list",
-    "subgacc_sjoin_fill_v2",
+    "subgacc_sjoin_fill_v2", "subgacc_publish_words",
 )
 
 
@@ -157,6 +157,7 @@ def lib():
     sig["subgacc_worklist_by_root"] = (C.c_int, [vp, i64, i64, vp, vp, vp, sz, vp])
     sig["subgacc_walk_spg_list"] = (C.c_int, [cfgp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp])
     sig["subgacc_sjoin_fill_v2"] = (C.c_int, [C.POINTER(JoinDesc), vp])
+    sig["subgacc_publish_words"] = (C.c_int, [vp, i64, vp, vp])
     assert set(sig) == set(SYMBOLS)
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -208,6 +209,18 @@ def join_fill(form=JOIN_ROWS, payload_kind=JOIN_SFPTR, **fields):
             continue
         setattr(d, name, val.data_ptr() if hasattr(val, "data_ptr") else int(val))
     return check(lib().subgacc_sjoin_fill_v2(C.byref(d), stream_ptr()))
+
+
+def publish(src, host):
+    """queue `host[:] = src` (a few int64 words: sizes, status) on the current stream WITHOUT a copy engine: see subgacc_publish_words.
+    SUBGACC_READBACK=copy takes torch's asynchronous copy instead (A/B)."""
+    if _READBACK_COPY or src.numel() > 4096 or not src.is_contiguous() or src.dtype != host.dtype or src.element_size() != 8:
+        host.copy_(src, non_blocking=True)
+    else:
+        check(lib().subgacc_publish_words(C.c_void_p(src.data_ptr()), src.numel(), C.c_void_p(host.data_ptr()), stream_ptr()))
+
+
+_READBACK_COPY = os.environ.get("SUBGACC_READBACK", "kernel") == "copy"
 
 
 def ptr(t):

@@ -101,3 +101,18 @@ extern "C" int subgacc_exclusive_scan_i32(const int32_t *in, int64_t n, int64_t 
     SG_REQUIRE(n >= 0 && out && (in || n == 0), SUBGACC_ERR_BADARG, "exclusive_scan_i32: bad arguments");
     return subgacc::exclusive_scan_i32(in, n, out, workspace, workspace_bytes, (hipStream_t)stream);
 }
+
+// A few words of status and sizes to pinned host memory by a KERNEL: a step's read-back as hipMemcpyAsync costs the GPU ~10 us of
+// idling behind its 4 us blit (the kernel trace of the headline step, profiles/r24_gaps_cit2.txt); one wave storing to
+// device-visible host memory does not.
+__global__ void publish_words_kernel(const int64_t *__restrict__ src, int n, int64_t *__restrict__ host_dst) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) host_dst[i] = src[i];
+}
+
+extern "C" int subgacc_publish_words(const int64_t *src, int64_t n, int64_t *host_dst, void *stream) {
+    SG_REQUIRE(n >= 0 && n <= 4096 && (n == 0 || (src && host_dst)), SUBGACC_ERR_BADARG, "publish_words: bad arguments");
+    if (n == 0) return SUBGACC_OK;
+    hipLaunchKernelGGL(publish_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, src, (int)n, host_dst);
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}

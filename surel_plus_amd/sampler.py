@@ -261,7 +261,7 @@ class SampledSets:
                 parts.append(self._join_flags[3:4].to(torch.int64))
             src = parts[0] if len(parts) == 1 else torch.cat(parts)
         host = torch.empty(src.numel(), dtype=torch.int64, pin_memory=True)
-        host.copy_(src, non_blocking=True)
+        _lib.publish(src, host)
         ev = torch.cuda.Event()
         ev.record()
         self._pending = (host, ev, src)          # src stays alive until the copy has run

@@ -326,7 +326,7 @@ class BatchViews:
             # for exactly this copy, not for whatever the stream holds by then (the next group of batches, queued in between)
             src = self._words()
             host = torch.empty(src.numel(), dtype=torch.int64, pin_memory=True)
-            host.copy_(src, non_blocking=True)
+            _lib.publish(src, host)
             ev = torch.cuda.Event()
             ev.record()
             self._pending = (host, ev, src)

@@ -69,7 +69,7 @@ class CapturedStep:
         with torch.cuda.graph(self.graph):
             self.xz, self.ind, self.sets = self._queue()
             if self.sets._tail is not None and self.sets._tail.numel() == self._host.numel():
-                self._host.copy_(self.sets._tail, non_blocking=True)
+                _lib.publish(self.sets._tail, self._host)
                 self._copy_in_graph = True
         self.status, self._rows = self.sets.status, self.ind[-1:]
         self._tail = self.sets._tail          # StepBuffers: [rows, status x4] contiguous -> one copy
@@ -103,7 +103,7 @@ class CapturedStep:
         if self._copy_in_graph:
             pass
         elif self._tail is not None:
-            self._host.copy_(self._tail, non_blocking=True)
+            _lib.publish(self._tail, self._host)
         else:
             self._host[:-1].copy_(self.status, non_blocking=True)
             self._host[-1:].copy_(self._rows, non_blocking=True)

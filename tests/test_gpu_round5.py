@@ -267,3 +267,16 @@ def test_join_pool_lanes_on_their_own_streams_equal_gather(sp):
     for j, t in pend:
         xz, ind = pool.finish(t)
         assert torch.equal(ind, want[j][1]) and torch.equal(xz, want[j][0]), j
+
+
+def test_publish_words_reaches_pinned_memory(sp):
+    """subgacc_publish_words: a step's sizes and status words to pinned host memory by a one-wave kernel (no copy engine in the stream)"""
+    from surel_plus_amd import _lib
+    for n in (1, 5, 64, 1000, 4096):
+        src = torch.arange(n, dtype=torch.int64, device="cuda") * 3 - 7
+        host = torch.full((n,), -1, dtype=torch.int64).pin_memory()
+        _lib.publish(src, host)
+        torch.cuda.synchronize()
+        assert torch.equal(host, src.cpu())
+    with pytest.raises((TypeError, sp.SubgAccError)):
+        _lib.check(_lib.lib().subgacc_publish_words(_lib.ptr(src), 5000, host.data_ptr(), _lib.stream_ptr()))

@@ -215,8 +215,20 @@ def offline_flow(sp, csr, M, k, B, K, cpu):
                     pend.pop(0).finish()
             for q in pend:
                 q.finish()
-        b1024["graph"] = rate(graph, 2 * len(es) * Bs)
+        b1024["graph"] = rate(graph, 2 * len(es) * Bs)          # (key kept from rounds 3-4: a CapturedJoin is ONE library call now, no graph)
         del cjs
+        pool = sp.CapturedJoinPool(zk, Bs, lanes=4, encode=zk.slot_table())
+
+        def lanes():      # the same on four streams (CapturedJoinPool), the batches known to be complete
+            pend = []
+            for e in es * 2:
+                pend.append(pool.submit(e, sync=False))
+                if len(pend) == 4:
+                    pool.finish(pend.pop(0))
+            for t in pend:
+                pool.finish(t)
+        b1024["pool_4lanes"] = rate(lanes, 2 * len(es) * Bs)
+        del pool
 
         sbuf2 = torch.empty_like(sbuf)
 
