@@ -535,7 +535,7 @@ def median(v):
 
 
 def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, with_cpu_baseline, csr_variant=True,
-             small_batches=False, two_stream_extra=True, offline=False, extra_regions=(0, 0), value_is_median=False, captured=False,
+             small_batches=False, two_stream_extra=True, dedup_extra=None, offline=False, extra_regions=(0, 0), value_is_median=False, captured=False,
              cpu_kw={}, wake_s=0.0):
     """sample + SpJoin over one LP workload: W warm-up steps, K timed steps bracketed by barrier + synchronize, max over
     ranks.  Returns the JSON object (rank 0) or None.
@@ -704,16 +704,17 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
             st_.wait_stream(torch.cuda.current_stream(dev))
         run_steps(range(4))
         torch.cuda.synchronize()
+        K2 = max(K, 100)
         t1 = time.perf_counter()
-        run_steps(range(W, W + K))
+        run_steps(range(W, W + K2))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
-        two_streams = {"pairs_per_s": B * K / dt, "ms_per_step": dt / max(K, 1) * 1e3, "steps": K}
+        two_streams = {"pairs_per_s": B * K2 / dt, "ms_per_step": dt / K2 * 1e3, "steps": K2}
         STREAMS, last = None, keep_last
     # ... and, outside the clock as well: the same steps with every DISTINCT endpoint of a batch sampled once (Philox keys a walk by
     # its root's id, so (xz, indptr) are the same -- tested); what a serving loop may do, not what the timed region does
     dedup_loop = None
-    if rank == 0 and world == 1 and last is not None and two_stream_extra and BUFFERED and not DEDUP and rng == "philox":
+    if rank == 0 and world == 1 and last is not None and (two_stream_extra if dedup_extra is None else dedup_extra) and BUFFERED and not DEDUP and rng == "philox":
         keep_last, DEDUP = last, True
         timer.enabled = False
         try:
@@ -932,6 +933,8 @@ def flatten(out):
     put("hgather_b2048_triplets_per_s", hg.get("value"))
     put("hgather_b2048_ms_per_step", hg.get("ms_per_step"))
     put("hgather_b2048_frac", (hg.get("roofline") or {}).get("frac"))
+    put("hgather_b2048_one_call_triplets_per_s", hg.get("one_call_triplets_per_s") if not isinstance(hg.get("one_call_triplets_per_s"), str) else None)
+    put("hgather_b2048_pool4_triplets_per_s", hg.get("pool4_triplets_per_s"))
     put("hgather_b2048_many32_triplets_per_s", hg.get("many32_triplets_per_s"))
     cb = out.get("cpu_baseline") or {}
     put("cpu_model", cb.get("cpu_model"))
@@ -1007,7 +1010,7 @@ CONFIG_KEYS = ("workload", "pairs_per_step_per_gpu", "roots_per_step_per_gpu", "
                "rand_r_pairs_per_s", "rand_r_frac", "cit2m4_pairs_per_s", "cit2m4_frac", "cit2m4_join_frac",
                "collab_pairs_per_s", "collab_frac", "collab_join_frac", "ppa_pairs_per_s", "ppa_frac", "ppa_join_frac",
                "twitter_pairs_per_s", "twitter_frac", "twitter_join_frac", "cit2ppr_pairs_per_s", "cit2ppr_frac",
-               "cit2ppr_frac_whole_join_call", "collab_cpu_pairs_per_s",
+               "cit2ppr_frac_whole_join_call", "two_stream_pairs_per_s", "collab_cpu_pairs_per_s",
                # seam A alone: random_walks.py:77-81 verbatim over the drop-in module, all N collab roots (shim = inside gset_sampler)
                "collab_literal_dropin_roots_per_s", "collab_dropin_shim_roots_per_s", "collab_literal_ref_roots_per_s",
                "detail")
@@ -1158,7 +1161,9 @@ def main():
         out = bench_lp(args, args.workload, args.rng, B, K, W, sp, sampler_mod, dev, rank, world, dist,
                        with_cpu_baseline=(world == 1 and not args.no_cpu_baseline),
                        small_batches=(world == 1 and args.full),
-                       two_stream_extra=args.full,               # (the default run and --no-others: single-stream steps only)
+                       # outside the clock, K more steps with two step buffers in turn on two streams (what a serving loop gains by it);
+                       # the pass with every distinct endpoint sampled once: --full only
+                       two_stream_extra=True, dedup_extra=args.full,
                        csr_variant=args.full,                    # ... and no pass with the packed-CSR (table rows) variant
                        offline=(rank == 0 and world == 1 and args.full and args.scale == 1.0),
                        # the driver's K steps are the headline region; three regions of 100 steps follow, outside its clock

@@ -205,15 +205,20 @@ class CapturedJoin:
         cj = CapturedJoin(z, 65536)                    # float payload; or CapturedJoin(z, B, encode=table) / (zk, B, encode=zk.slot_table())
         cj(edge); xz, indptr = cj.finish()             # views of the object's static buffers, valid until the next call
 
+    triplets=True: the same for hgather(hedge [3, B], z, encode) (train.py:48-72, main_horder.py's batches of 2,048 triplets): four
+    blocks [U|w ; W|u ; V|w ; W|v], finish() -> (xz, segment ids) as hgather returns them; one small kernel lays the four blocks out.
+
     graph=True replays the same launches as ONE HIP graph (rounds 3-4's form; the name is from there): less host time still for
     batches of ~1,024 pairs, but every replay costs the GPU ~20 us between graphs (`profiles/r24_join_call_probe.log`)."""
 
-    def __init__(self, z, pairs, encode=None, warmup=2, graph=False):
+    def __init__(self, z, pairs, encode=None, warmup=2, graph=False, triplets=False):
         import ctypes as C
         from .spg import KEY_ROWS_ENCODE
-        self.z, self.B, self.encode = z, int(pairs), encode
+        self.z, self.B, self.encode, self.triplets = z, int(pairs), encode, bool(triplets)
         dev = z.device
-        B, S = self.B, 2 * self.B
+        B, S = self.B, (4 if triplets else 2) * self.B
+        if triplets and encode is None:
+            raise NotImplementedError          # (train.py:69-70)
         d = _lib.JoinDesc()
         d.struct_bytes, d.form, d.options = C.sizeof(_lib.JoinDesc), _lib.JOIN_ROWS, _lib.JOIN_OPT_SIZES
         if getattr(z, "keyrows", False):
@@ -232,7 +237,7 @@ class CapturedJoin:
                 raise IndexError(f"index {z.max_data} is out of bounds for the encode table with {self._table.shape[0]} rows")
             k, d.payload_kind = int(self._table.shape[1]), _lib.JOIN_SFPTR
             d.table, d.table_rows, d.k = self._table.data_ptr(), self._table.shape[0], k
-        self.edge = torch.zeros((2, B), dtype=torch.int64, device=dev)
+        self.edge = torch.zeros((3 if triplets else 2, B), dtype=torch.int64, device=dev)
         self.out = torch.empty(S * z.max_len * 2 * k, dtype=torch.float32, device=dev)
         self.ind = torch.zeros(S + 1, dtype=torch.int64, device=dev)
         self.flags = torch.zeros(4, dtype=torch.int32, device=dev)
@@ -240,6 +245,12 @@ class CapturedJoin:
         self._host = torch.zeros(2, dtype=torch.int64, pin_memory=True)
         d.row_off, d.n_rows, d.ids, d.payload, d.max_len = z.indptr.data_ptr(), z.n_rows, z.indices.data_ptr(), z.data.data_ptr(), z.max_len
         d.own, d.S, d.pair_block = self.edge.data_ptr(), S, B
+        self.segid = None
+        if triplets:       # own = [u | w | v | w] (hedge rows 0, 2, 1, 2), the mirrored partner blocks are derived by the kernels
+            self._blocks = torch.empty((4, B), dtype=torch.int64, device=dev)
+            self._sel = torch.tensor([0, 2, 1, 2], dtype=torch.int64, device=dev)
+            self.segid = torch.empty(S * z.max_len, dtype=torch.int64, device=dev)
+            d.own, d.out_segid = self._blocks.data_ptr(), self.segid.data_ptr()
         d.out_xz, d.flags, d.out_seg = self.out.data_ptr(), self.flags.data_ptr(), self.ind.data_ptr()
         d.size_state, d.size_state_bytes, d.host_tail = self._state.data_ptr(), self._state.numel(), self._host.data_ptr()
         self._d, self._ref = d, C.byref(d)
@@ -265,12 +276,27 @@ class CapturedJoin:
         _lib.check(self._fill(self._ref, _ctypes.c_void_p(st.cuda_stream)))
         return st
 
+    def _call_triplets(self, hedge, stream):
+        if stream is not None and torch.cuda.current_stream(self.edge.device) != stream:
+            with torch.cuda.stream(stream):
+                return self._call_triplets(hedge, stream)
+        if not (torch.is_tensor(hedge) and hedge.dtype == torch.int64 and hedge.device == self.edge.device):
+            self.edge.copy_(torch.as_tensor(hedge), non_blocking=True)
+            hedge = self.edge
+        torch.index_select(hedge, 0, self._sel, out=self._blocks)
+        if self.graph is not None:
+            raise ValueError("triplets=True is the one-call form (graph=False)")
+        self._event.record(self._launch(stream))
+        return self
+
     def __call__(self, edge, stream=None):
         """queue the join of `edge` [2, B] on `stream` if given (the calling convention of CapturedStep.__call__ /
         CapturedStepPool.submit), else on the current one; a contiguous int64 device tensor is joined where it lies (and kept
         alive until the next call), anything else goes through the object's static buffer"""
-        if tuple(edge.shape) != (2, self.B):
-            raise ValueError(f"this join was made for [2, {self.B}] pairs")
+        if tuple(edge.shape) != tuple(self.edge.shape):
+            raise ValueError(f"this join was made for {list(self.edge.shape)} endpoints")
+        if self.triplets:
+            return self._call_triplets(edge, stream)
         if self.graph is None and torch.is_tensor(edge) and edge.dtype == torch.int64 and edge.device == self.edge.device and edge.is_contiguous():
             self._own = edge
             self._d.own = edge.data_ptr()
@@ -305,7 +331,7 @@ class CapturedJoin:
             raise _lib.SubgAccError("SpG row longer than SpG.max_len")
         if word & 2:
             raise IndexError("SFptr outside the encode table")
-        return self.xz[:rows], self.ind
+        return self.xz[:rows], (self.segid[:rows] if self.triplets else self.ind)
 
 
 class CapturedJoinPool(CapturedStepPool):

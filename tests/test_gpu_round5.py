@@ -280,3 +280,32 @@ def test_publish_words_reaches_pinned_memory(sp):
         assert torch.equal(host, src.cpu())
     with pytest.raises((TypeError, sp.SubgAccError)):
         _lib.check(_lib.lib().subgacc_publish_words(_lib.ptr(src), 5000, host.data_ptr(), _lib.stream_ptr()))
+
+
+def test_one_call_hgather_equals_hgather(sp):
+    """CapturedJoin(triplets=True) / CapturedJoinPool(..., triplets=True): hgather(hedge [3, B]) from a resident store as one library call
+    per batch -- (xz, segment ids) bit for bit what hgather() returns (train.py:48-72), table store and keyed store"""
+    from test_gpu_round4 import _store
+    N = 3000
+    csr, z, enc, o_spg, _ = _store(sp, N=N, M=40)
+    table = torch.from_numpy(enc.astype(np.float32) / np.float32(40)).cuda()
+    zk = z.keyed(enc, 40)
+    rs = np.random.default_rng(3)
+    B = 700
+    hs = [torch.from_numpy(rs.integers(0, N, (3, B))).cuda() for _ in range(4)]
+    hs[1][2, 5] = hs[1][0, 5]                                   # w == u
+    for store, encode in ((z, table), (zk, zk.slot_table())):
+        want = [sp.hgather(h, store, "cuda", encode=encode) for h in hs]
+        cj = sp.CapturedJoin(store, B, encode=encode, triplets=True)
+        for h, (wxz, wids) in zip(hs, want):
+            xz, ids = cj(h).finish()
+            assert torch.equal(ids, wids) and torch.equal(xz, wxz)
+        xz, ids = cj(hs[0].cpu().numpy()).finish()                 # host input goes through the static buffer
+        assert torch.equal(ids, want[0][1]) and torch.equal(xz, want[0][0])
+        pool = sp.CapturedJoinPool(store, B, lanes=2, encode=encode, triplets=True)
+        tickets = [pool.submit(hs[0]), pool.submit(hs[1])]
+        for t, (wxz, wids) in zip(tickets, want[:2]):
+            xz, ids = pool.finish(t)
+            assert torch.equal(ids, wids) and torch.equal(xz, wxz)
+    with pytest.raises(NotImplementedError):
+        sp.CapturedJoin(z, B, triplets=True)

@@ -299,8 +299,42 @@ def bench_hgather(sp, z, table, k, K):
         many = median(rs)
     except Exception as ex:
         many = f"{type(ex).__name__}: {ex}"
+    # ... and one batch per call with everything built once (CapturedJoin(triplets=True): one small kernel lays the four blocks out,
+    # ONE library call sizes and fills), alone and four lanes on their own streams; 3 repeats of 64 batches, median
+    one_call = pool4 = None
+    try:
+        cj = sp.CapturedJoin(z, B, encode=table, triplets=True)
+        pool = sp.CapturedJoinPool(z, B, lanes=4, encode=table, triplets=True)
+
+        def loop_one():
+            for i in range(64):
+                cj(hedges[i % len(hedges)]).finish()
+
+        def loop_pool():
+            pend = []
+            for i in range(64):
+                pend.append(pool.submit(hedges[i % len(hedges)], sync=False))
+                if len(pend) == 4:
+                    pool.finish(pend.pop(0))
+            for t in pend:
+                pool.finish(t)
+        res = []
+        for fn in (loop_one, loop_pool):
+            fn()
+            rs = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                rs.append(64 * B / (time.perf_counter() - t1))
+            res.append(median(rs))
+        one_call, pool4 = res
+        del cj, pool
+    except Exception as ex:
+        one_call = f"{type(ex).__name__}: {ex}"
     return {"metric": "triplets/sec (hgather from the resident store)", "value": B * K / wall, "unit": "triplets/s", "steps": K,
-            "many32_triplets_per_s": many,
+            "many32_triplets_per_s": many, "one_call_triplets_per_s": one_call, "pool4_triplets_per_s": pool4,
             "ms_per_step": wall / K * 1e3, "triplets_per_step": B, "xz_rows_last_step": rows,
             "roofline": {"bound": "hbm", "kernel": "sjoin_pair_kernel (4 blocks per triplet) + sizes + scan", "achieved": abytes / (ms * 1e-3) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,

@@ -80,6 +80,26 @@ for c in range(cases):
         xz, ind = sp.gather(edge, zs, "cuda", ptr=True, encode=tab)
         if not (np.array_equal(ind.cpu().numpy(), wind) and np.array_equal(xz.cpu().numpy(), wxz)):
             fails.append("gather")
+        # the resident store's join as ONE library call per batch (CapturedJoin: single-launch size pass + fill), pairs and triplets,
+        # twice on the same state; a packed store built from the oracle's rows
+        try:
+            zr = sp.spg.SpG(torch.from_numpy(oi.astype(np.int64)).cuda(), torch.from_numpy(ox.astype(np.int32)).cuda(),
+                        torch.from_numpy(od.astype(np.int32)).cuda())
+            tabr = torch.from_numpy(enc).cuda()
+            cj = sp.CapturedJoin(zr, 64, encode=tabr)
+            for _ in (0, 1):
+                cx, ci = cj(torch.from_numpy(edge).cuda()).finish()
+                if not (np.array_equal(ci.cpu().numpy(), wind) and np.array_equal(cx.cpu().numpy(), wxz)):
+                    fails.append("CapturedJoin")
+            hedge = rng0.integers(0, nq, (3, 40))
+            hx, hi = oracle.hgather(hedge, (oi, ox, od), enc)
+            ch = sp.CapturedJoin(zr, 40, encode=tabr, triplets=True)
+            gx, gi = ch(torch.from_numpy(hedge).cuda()).finish()
+            if not (np.array_equal(gi.cpu().numpy(), hi) and np.array_equal(gx.cpu().numpy(), hx)):
+                fails.append("CapturedJoin(triplets)")
+            cov["one_call_join"] = cov.get("one_call_join", 0) + 1
+        except Exception as ex:
+            fails.append(f"CapturedJoin raised {type(ex).__name__}: {ex}")
         # the same batch as rows of LP keys (no table, no numbering) where the shape has that form
         zk, sk = sp.sample_spg(csr, q, num_walks=M, num_steps=m, seed=seed, rng=rng, bucket=bucket, strided=True, number_rows=False)
         if isinstance(zk, sp.StridedSpG) and zk.keyrows:
