@@ -274,7 +274,7 @@ int subgacc_sjoin_sizes_rows(const int32_t *row_len, int64_t n_rows, const int64
  *                                  (segment id of every row, `ptr=False`, train.py:25-30; optional; not with strided rows)
  *              SUBGACC_JOIN_COUNTS out_counts f32 [S, table_rows]: how often LP row p (SFptr+1, 0 = partner absent) occurs in either
  *                                  feature slot of segment j, so that segment_sum_j(MLP(xz).sum(-2)) == out_counts[j] @ MLP(Z_SF)
- *                                  (model.py:78-83); 16*max_len + 8*table_rows bytes of LDS <= 160 KiB (SUBGACC_ERR_LDS)
+ *                                  (model.py:78-83); 8*max_len + 8*table_rows + 16 bytes of LDS <= 160 KiB (SUBGACC_ERR_LDS)
  *              SUBGACC_JOIN_PAIRS  for aggregations that are not linear in the rows (the attention gate, model.py:59-62): segment j as
  *                                  its DISTINCT index pairs with multiplicities, in a reproducible order, at rows [seg[j], seg[j] +
  *                                  out_cnt[j]) of out_pairs i32 [R,2], out_mult i32 [R]; out_cnt i32 [S]; max_len <= 1024

@@ -103,7 +103,7 @@ extern "C" int subgacc_exclusive_scan_i32(const int32_t *in, int64_t n, int64_t 
 }
 
 // A few words of status and sizes to pinned host memory by a KERNEL: a step's read-back as hipMemcpyAsync costs the GPU ~10 us of
-// idling behind its 4 us blit (the kernel trace of the headline step, profiles/r24_gaps_cit2.txt); one wave storing to
+// idling behind its 4 us blit (the kernel trace of the headline step, profiles/r24_graph_gaps_cit2.txt); one wave storing to
 // device-visible host memory does not.
 __global__ void publish_words_kernel(const int64_t *__restrict__ src, int n, int64_t *__restrict__ host_dst) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) host_dst[i] = src[i];

@@ -1009,13 +1009,16 @@ __global__ __launch_bounds__(NT) void sjoin_f64pair_kernel(const JoinArgs a, uin
 // behind it) collapse into one [S, c+1] x [c+1, H] GEMM.  Slot value 0 (partner absent) is counted too: the MLP
 // of the zero row is not zero.  Mirrored segments are produced together, as in sjoin_pair_kernel.
 __global__ __launch_bounds__(kPairThreads) void sjoin_counts_kernel(const JoinArgs a, int64_t pb, float *__restrict__ out_counts) {
+    // The plan of sjoin_keypair_kernel: only the longer row T of the pair is staged; the shorter row S is searched in it member by
+    // member (one direction: a match is symmetric), and a hit counts for both blocks.  Per block: every own value once, every
+    // partner value of a hit once, and "partner absent" (row 0) for the members without one -- n - hits, added when the row is
+    // written, not one LDS atomic per member on one address.
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    int32_t *valA = (int32_t *)lds_raw;               // [max_len]
-    int32_t *valB = valA + a.max_len;                 // [max_len]
-    int32_t *idsA = valB + a.max_len;                 // [max_len]
-    int32_t *idsB = idsA + a.max_len;                 // [max_len]
-    int32_t *histA = idsB + a.max_len;                // [table_rows]
-    int32_t *histB = histA + a.table_rows;            // [table_rows]
+    int32_t *valT = (int32_t *)lds_raw;               // [max_len]
+    int32_t *idsT = valT + a.max_len;                 // [max_len]
+    int32_t *histS = idsT + a.max_len;                // [table_rows]
+    int32_t *histT = histS + a.table_rows;            // [table_rows]
+    int32_t *nhit = histT + a.table_rows;             // [1]
 
     const int64_t p = xcd_item(blockIdx.x, gridDim.x);
     if (p >= a.S / 2) return;
@@ -1033,46 +1036,70 @@ __global__ __launch_bounds__(kPairThreads) void sjoin_counts_kernel(const JoinAr
         if (tid == 0) atomicOr(&a.flags[3], 1);
         return;
     }
-    const int na = (int)na64, nb = (int)nb64;
+    const bool swap = na64 > nb64;
+    const int ns = (int)(swap ? nb64 : na64), nt = (int)(swap ? na64 : nb64);
+    const int64_t sb = swap ? bb : ab, tb = swap ? ab : bb, jS = swap ? j2 : j, jT = swap ? j : j2;
     const int32_t *data = (const int32_t *)a.data;
     const int rows = (int)a.table_rows;
-    for (int x = tid; x < 2 * rows; x += kPairThreads) histA[x] = 0;   // histA and histB are contiguous
-    for (int r = tid; r < na; r += kPairThreads) {
-        idsA[r] = a.indices[ab + r];
-        valA[r] = data[ab + r];
+    // S's first members are asked for before anything else: they are on their way while T is staged and the histograms are cleared
+    constexpr int kTrips = 2;
+    int32_t sid[kTrips], sval[kTrips];
+#pragma unroll
+    for (int u = 0; u < kTrips; ++u) {
+        const int r = tid + u * kPairThreads;
+        sid[u] = 0, sval[u] = 0;
+        if (r < ns) sid[u] = stream_load(&a.indices[sb + r]), sval[u] = stream_load(&data[sb + r]);
     }
-    for (int r = tid; r < nb; r += kPairThreads) {
-        idsB[r] = a.indices[bb + r];
-        valB[r] = data[bb + r];
+    for (int x = tid; x < 2 * rows + 1; x += kPairThreads) histS[x] = 0;   // histS, histT and nhit are contiguous
+    for (int r = tid; r < nt; r += kPairThreads) {
+        idsT[r] = stream_load(&a.indices[tb + r]);
+        valT[r] = stream_load(&data[tb + r]);
     }
     __syncthreads();
-    for (int t = tid; t < na + nb; t += kPairThreads) {
-        const bool dirB = t >= na;
-        const int r = dirB ? t - na : t;
-        const int32_t *oid = dirB ? idsB : idsA, *oval = dirB ? valB : valA;
-        const int32_t *pid = dirB ? idsA : idsB, *pval = dirB ? valA : valB;
-        const int pn = dirB ? na : nb;
-        int32_t *hist = dirB ? histB : histA;
-        const int32_t id = oid[r];
-        int lo = 0, hi = pn;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (pid[mid] < id) lo = mid + 1;
-            else hi = mid;
+    for (int r = tid; r < nt; r += kPairThreads) {      // T's own values
+        const int32_t v = valT[r];
+        if ((uint32_t)v >= (uint32_t)rows) atomicOr(&a.flags[3], 2);  // SFptr outside the table: never counted out of bounds
+        else atomicAdd(&histT[v], 1);
+    }
+    int hits = 0;
+    for (int r0 = 0; r0 < ns; r0 += kPairThreads) {     // S: own value, and -- on a hit -- one partner value for each block
+        const int r = r0 + tid, u = r0 / kPairThreads;
+        if (r >= ns) break;
+        int32_t id, v;
+        if (u < kTrips) {
+            id = u == 0 ? sid[0] : sid[1];
+            v = u == 0 ? sval[0] : sval[1];
+        } else {
+            id = stream_load(&a.indices[sb + r]);
+            v = stream_load(&data[sb + r]);
         }
-        int32_t pa = oval[r], pbv = (lo < pn && pid[lo] == id) ? pval[lo] : 0;
-        if ((uint32_t)pa >= (uint32_t)rows || (uint32_t)pbv >= (uint32_t)rows) {
+        int b = 0, n = nt;
+        while (n > 1) {
+            const int h = n >> 1;
+            b = idsT[b + h] <= id ? b + h : b;
+            n -= h;
+        }
+        const bool hit = n == 1 && idsT[b] == id;
+        const int32_t pvT = hit ? valT[b] : 0;
+        if ((uint32_t)v >= (uint32_t)rows || (uint32_t)pvT >= (uint32_t)rows) {
             atomicOr(&a.flags[3], 2);
             continue;
         }
-        atomicAdd(&hist[pa], 1);
-        atomicAdd(&hist[pbv], 1);
+        atomicAdd(&histS[v], 1);
+        if (hit) {
+            atomicAdd(&histS[pvT], 1);
+            atomicAdd(&histT[v], 1);
+            ++hits;
+        }
     }
+    if (hits) atomicAdd(nhit, hits);
     __syncthreads();
-    float *outA = out_counts + j * (int64_t)rows, *outB = out_counts + j2 * (int64_t)rows;
+    const int h = *nhit;
+    float *outS = out_counts + jS * (int64_t)rows, *outT = out_counts + jT * (int64_t)rows;
     for (int x = tid; x < rows; x += kPairThreads) {
-        outA[x] = (float)histA[x];
-        outB[x] = (float)histB[x];
+        const int absent_s = x == 0 ? ns - h : 0, absent_t = x == 0 ? nt - h : 0;      // row 0 = partner absent (counted: MLP(0) != 0)
+        outS[x] = (float)(histS[x] + absent_s);
+        outT[x] = (float)(histT[x] + absent_t);
     }
 }
 
@@ -1560,7 +1587,7 @@ static int sjoin_counts_impl(const int64_t *spg_indptr, int64_t n_rows, const in
     a.flags = flags;
     a.row_len = nullptr, a.row_stride = 0, a.slot_id = nullptr, a.val_add = 0;
     a.key_M = a.key_m = a.key_shift = 0;
-    const size_t lds = (size_t)a.max_len * 16 + (size_t)table_rows * 8;
+    const size_t lds = (size_t)a.max_len * 8 + (size_t)table_rows * 8 + 16;
     SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS,
                "sjoin_counts: %lld distinct LP rows and rows of %d members need %zu B of LDS; use sjoin_fill",
                (long long)table_rows, max_len, lds);

@@ -84,3 +84,21 @@ def test_join_descriptor_layout_matches_the_header(tmp_path, L):
     d.struct_bytes = C.sizeof(_lib.JoinDesc)
     assert L.subgacc_sjoin_fill_v2(C.byref(d), None) == _lib.ERR_BADARG          # neither row_off nor row_len
     assert L.subgacc_sjoin_fill_v2(None, None) == _lib.ERR_BADARG
+    # SUBGACC_JOIN_OPT_SIZES (the whole join in one call): what it refuses before it launches anything
+    buf = (C.c_int64 * 64)()
+    here = C.addressof(buf)
+    d.row_off, d.n_rows, d.S, d.pair_block = here, 4, 4, 2
+    d.options = 2                                                               # an option bit this library does not know
+    assert L.subgacc_sjoin_fill_v2(C.byref(d), None) == _lib.ERR_BADARG and b"option" in L.subgacc_last_error()
+    d.options = _lib.JOIN_OPT_SIZES
+    d.form = _lib.JOIN_COUNTS
+    assert L.subgacc_sjoin_fill_v2(C.byref(d), None) == _lib.ERR_BADARG          # the row form only
+    d.form = _lib.JOIN_ROWS
+    assert L.subgacc_sjoin_fill_v2(C.byref(d), None) == _lib.ERR_BADARG          # no out_seg
+    d.out_seg, d.seg = here, here
+    assert L.subgacc_sjoin_fill_v2(C.byref(d), None) == _lib.ERR_BADARG          # seg next to out_seg
+    d.seg, d.own = None, here
+    assert L.subgacc_sjoin_fill_v2(C.byref(d), None) == _lib.ERR_WORKSPACE       # no state
+    d.size_state, d.size_state_bytes = here, 8
+    assert L.subgacc_sjoin_fill_v2(C.byref(d), None) == _lib.ERR_WORKSPACE       # a state too small
+    assert L.subgacc_sjoin_workspace_bytes(4) >= 64 + 8 and L.subgacc_sjoin_workspace_bytes(1 << 22) >= 64 + 8 * (1 << 12)

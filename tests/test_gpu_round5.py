@@ -171,6 +171,14 @@ def test_pair_join_at_every_span_and_trip_boundary(sp, payload, B):
         oxz, oind = oracle.gather(e, spg_host, ptr=ptr, encode=enc_host)
         assert np.array_equal(ind.cpu().numpy(), oind)
         assert np.array_equal(xz.cpu().numpy(), oxz)
+    if payload == "table3":        # the count form over the same pairs (sjoin_counts_kernel: the same one-directional plan, rows of up
+        # to two register trips and beyond): C[j, p] = occurrences of LP row p in either slot of segment j, from the oracle's pairs
+        own, partner = oracle.pair_segments(e)
+        seg, pairs = oracle.sjoin(indptr, ids, data, own, partner)
+        want = np.zeros((2 * B, c + 1), np.float32)
+        np.add.at(want, (np.repeat(np.arange(2 * B), np.diff(seg))[:, None].repeat(2, 1), pairs), 1.0)
+        C, sizes = sp.gather_counts(edge, z, c + 1)
+        assert np.array_equal(sizes.cpu().numpy(), np.diff(seg)) and np.array_equal(C.cpu().numpy(), want)
 
 
 @pytest.mark.parametrize("graph", [False, True])
