@@ -219,6 +219,8 @@ class CapturedJoin:
         B, S = self.B, (4 if triplets else 2) * self.B
         if triplets and encode is None:
             raise NotImplementedError          # (train.py:69-70)
+        if triplets and graph:
+            raise ValueError("triplets=True is the one-call form (graph=False)")
         d = _lib.JoinDesc()
         d.struct_bytes, d.form, d.options = C.sizeof(_lib.JoinDesc), _lib.JOIN_ROWS, _lib.JOIN_OPT_SIZES
         if getattr(z, "keyrows", False):
@@ -284,8 +286,6 @@ class CapturedJoin:
             self.edge.copy_(torch.as_tensor(hedge), non_blocking=True)
             hedge = self.edge
         torch.index_select(hedge, 0, self._sel, out=self._blocks)
-        if self.graph is not None:
-            raise ValueError("triplets=True is the one-call form (graph=False)")
         self._event.record(self._launch(stream))
         return self
 
