@@ -79,6 +79,10 @@ typedef struct subgacc_walk_cfg {
      * uint32 [n * num_walks] for the n roots of the call, from subgacc_rng_replay; NULL = positions follow from the
      * degrees (subgacc_rng_positions), the symmetrised graphs of the reference's loader. */
     const uint32_t *walk_pos;
+    /* ABI 6: words between the rows of two consecutive roots in the strided outputs (set_ids / set_keys / row_ids / row_slot); 0 =
+     * the row capacity itself (bucket, or M*m+1).  A multiple of 32 puts every row on a 128-byte line: the join reads and the walk
+     * kernels write whole lines.  Whoever reads the rows afterwards takes the same number as its `stride` / `row_stride`. */
+    int32_t row_pitch;
 } subgacc_walk_cfg;
 
 /* Hop records: rec[e] = [indices[e] : id_bits | indptr[indices[e]] : beg_bits | degree(indices[e]) : rest], one uint64 per
@@ -281,10 +285,10 @@ int subgacc_sjoin_sizes_rows(const int32_t *row_len, int64_t n_rows, const int64
  *   options    SUBGACC_JOIN_OPT_SIZES (row form): the WHOLE join of a batch in this one call -- the size pass runs first, as ONE
  *              launch, and the fill behind it.  seg = NULL; out_seg [S+1] is written (what subgacc_sjoin_sizes writes) and read by
  *              the fill; the outputs must hold the worst case (S * max_len rows, R is not known to the host beforehand); the size
- *              pass ORs its status into flags[3] (16: a row number outside the store; 32: size_state was not clean -- the segment pointers
+ *              pass ORs its status into flags[3] (16: a row number outside the store; 64: size_state was not clean -- the segment pointers
  *              mean nothing, the fill of this call, and of every later one that finds the bit set, writes no row: zero the state
  *              and flags and call again); host_tail (optional; int64[2] of pinned, device-visible host memory) receives [R, the status of THIS
- *              size pass] when it ends (R = -1 with bit 32), so that a serving loop needs neither a memset in front of the join
+ *              size pass] when it ends (R = -1 with bit 64), so that a serving loop needs neither a memset in front of the join
  *              nor a copy behind it.  size_state: subgacc_sjoin_workspace_bytes(S) bytes of device memory the caller zeroes ONCE, when allocating
  *              it: every call leaves it zeroed again (a single-pass scan keeps its ticket and one word per tile there); one
  *              state serves one join at a time (calls on one stream; one state per stream otherwise).

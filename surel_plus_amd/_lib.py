@@ -44,7 +44,7 @@ class WalkCfg(C.Structure):
                 ("seed", C.c_uint32), ("first_hop_wo", C.c_int32), ("order", C.c_int32),
                 ("cap_root_degree", C.c_int32), ("indptr64", C.c_int32), ("emit_walks", C.c_int32),
                 ("hop_records", C.c_void_p), ("rec_id_bits", C.c_int32), ("rec_beg_bits", C.c_int32),
-                ("walk_pos", C.c_void_p)]
+                ("walk_pos", C.c_void_p), ("row_pitch", C.c_int32)]
 
 
 class JoinDesc(C.Structure):

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kScanThreads) void sjoin_seg_scan_kernel(const SegL
 // finished tiles, one word per tile -- all zero when a launch starts; the LAST tile to finish (every other tile is past its
 // look-back by then) zeroes it again, so the caller zeroes it once, when it allocates it.  Tiles take their number from the ticket
 // (a tile only ever waits for tiles that run already); a wait is bounded (kSpinLimit polls, never reached with clean state): a dirty
-// state -- a launch that was torn down half way -- ends in status bit 32 instead of a hang, and is clean again afterwards.
+// state -- a launch that was torn down half way -- ends in status bit 64 instead of a hang, and is clean again afterwards.
 struct SizeState {
     unsigned long long ticket, done, status, total, pad[4];      // 64 bytes; one word per tile follows
 };
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kScanThreads) void sjoin_sizes_onepass_kernel(const
                     front += wave_sum_u64(x & kTileValue);
                 }
                 if (lane == 0) {
-                    if (gave_up) atomicOr(&hd->status, 32ull);
+                    if (gave_up) atomicOr(&hd->status, 64ull);
                     __hip_atomic_store(&tile[t], kTilePrefix | ((front + (unsigned long long)tot) & kTileValue), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kScanThreads) void sjoin_sizes_onepass_kernel(const
         }
         if (L.S == 0 && tid == 0) out[0] = 0;
     } else if (tid == 0) {
-        atomicOr(&hd->status, 32ull);      // a ticket beyond the tiles: the state was not zero when this launch began
+        atomicOr(&hd->status, 64ull);      // a ticket beyond the tiles: the state was not zero when this launch began
     }
     // (no fence anywhere: everything one tile learns from another travels through device-scope atomics, which meet at the memory
     // side; the segment pointers themselves are read by the NEXT kernel only)
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(kScanThreads) void sjoin_sizes_onepass_kernel(const
             const long long total = (long long)atomicExch(&hd->total, 0ull);
             if (L.flags && st) atomicOr(&L.flags[3], (int)st);
             if (host_tail) {
-                host_tail[0] = (st & 32) ? -1 : total;
+                host_tail[0] = (st & 64) ? -1 : total;
                 host_tail[1] = (int64_t)st;
             }
             atomicExch(&hd->ticket, 0ull);
@@ -248,7 +248,7 @@ struct JoinArgs {
     int32_t key_M, key_m, key_shift;
     const int32_t *slot_id;   // slot -> SFptr (id plane of the numbered table of distinct LP rows); NULL with
     int32_t val_add;          // val_add = 1: the feature table is indexed by slot + 1 itself (row 0 = absent)
-    bool sized_here = t_sized_here;   // the segment pointers come from the size pass of this very call: flags[3] & 32 (its state was not
+    bool sized_here = t_sized_here;   // the segment pointers come from the size pass of this very call: flags[3] & 64 (its state was not
                               // clean, the pointers mean nothing) ends every workgroup before it derives an address from them
     int64_t pb = 0;           // pair_block of a mirrored list: with partner == NULL the partner of segment j is the own row of its mirror
     int32_t split = 1;        // sjoin_pair_kernel: workgroups per pair (small batches: every one stages both rows and emits
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kJoinThreads) void sjoin_fill_kernel(const JoinArgs
 
     const int64_t j = xcd_item(blockIdx.x, gridDim.x);
     if (j >= a.S) return;
-    if (a.sized_here && (a.flags[3] & 32)) return;
+    if (a.sized_here && (a.flags[3] & 64)) return;
     const int lane = threadIdx.x;
     const int64_t ra = a.own[j], rb = join_partner(a, j);
     int64_t ab, na, bb, nb64;
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(NT) void sjoin_keypair_kernel(const JoinArgs a, uin
     float *stage = (float *)(lds_raw + stage_off) + wave * (kWave * w + 4);
 
     SJ_HOOK_PAIR_ENTRY();
-    if (a.sized_here && (a.flags[3] & 32)) return;
+    if (a.sized_here && (a.flags[3] & 64)) return;
     const uint32_t wg = (uint32_t)(blockIdx.x & (kXcds - 1)) * (gridDim.x / kXcds) + (blockIdx.x / kXcds);    // xcd_item, 32 bits
     uint32_t p = wg, part = 0;
     if (a.split > 1) {
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(NT) void sjoin_f64pair_kernel(const JoinArgs a, uin
     const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
 
     SJ_HOOK_PAIR_ENTRY();
-    if (a.sized_here && (a.flags[3] & 32)) return;
+    if (a.sized_here && (a.flags[3] & 64)) return;
     const uint32_t wg = (uint32_t)(blockIdx.x & (kXcds - 1)) * (gridDim.x / kXcds) + (blockIdx.x / kXcds);    // xcd_item, 32 bits
     uint32_t p = wg, part = 0;
     if (a.split > 1) {

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_n
         }
     }
     if (a.cap_root && rdeg64 > kNeighCap) rdeg64 = kNeighCap;
-    const int64_t obase = i * (int64_t)a.stride;
+    const int64_t obase = i * (int64_t)a.pitch;
     const unsigned long long lead = 1ull << (m * a.shift);
 
     if (rdeg64 == 0) {  // isolated root: one member, every count = M (subg_acc.c:753-761); id = the root
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_n
             unsigned long long k = lead;
             for (int s = 0; s < m; ++s) k |= (unsigned long long)M << (s * a.shift);
             a.set_ids[obase] = root;
-            if (SPG) a.set_slot[obase] = uniq_global_insert(a.table, k, (unsigned long long)((a.root_base + i) * a.stride), a.flags);
+            if (SPG) a.set_slot[obase] = uniq_global_insert(a.table, k, (unsigned long long)((a.root_base + i) * a.pitch), a.flags);
             else a.set_keys[obase] = k;
             a.nsize[i] = 1;
         }
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_n
     //     with tag = (global root index)*stride + first-visit order, which orders first occurrences exactly like the
     //     reference's sequential pass (subg_acc.c:957-978); (2) bucket-sort the members by node id in the LDS the
     //     walk tables occupied (random_walks.py:79-80) and write them to their sorted position.
-    const unsigned long long tag0 = (unsigned long long)((a.root_base + i) * (int64_t)a.stride);
+    const unsigned long long tag0 = (unsigned long long)((a.root_base + i) * (int64_t)a.pitch);
     int32_t idv[kSpgPerLane], slv[kSpgPerLane];
     bool ok[kSpgPerLane];
     int mycount = 0;
@@ -797,6 +797,10 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
     a.walks = cfg->emit_walks ? walks : nullptr;
     a.flags = flags;
     a.M = M, a.m = m, a.stride = stride, a.shift = shift;
+    // rows may lie further apart than they are long (row_pitch: every row on a 128-byte line); tags count in the same unit
+    SG_REQUIRE(cfg->row_pitch == 0 || cfg->row_pitch >= stride, SUBGACC_ERR_BADARG, "walk: row_pitch %d < the row capacity %d",
+               cfg->row_pitch, stride);
+    a.pitch = cfg->row_pitch > 0 ? cfg->row_pitch : stride;
     a.T = table_size_for(Q);
     a.tshift = 32 - (31 - __builtin_clz((unsigned)a.T));
     a.nwords = (Q + 31) / 32;

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 8 : SG_PIPE_MINW) __attribute__((am
             load_root();
             if (shufB) draws_to_lds();           // sarr belongs to B alone
         }
-        const int64_t obase = i * (int64_t)a.stride;
+        const int64_t obase = i * (int64_t)a.pitch;
 
         // ---- P1: visits of A -> tables (the root is member 0, q = 0)
         if (!isolated) {

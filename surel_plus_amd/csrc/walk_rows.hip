@@ -154,9 +154,9 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (KR ? 5 : (NT == 128 ? 7 :
         }
     }
     if (a.cap_root && rdeg64 > kNeighCap) rdeg64 = kNeighCap;
-    const int64_t obase = i * (int64_t)a.stride;
+    const int64_t obase = i * (int64_t)a.pitch;
     const CntT lead = (CntT)1 << (MH * a.shift);
-    const unsigned long long tag0 = (unsigned long long)((a.root_base + i) * (int64_t)a.stride);
+    const unsigned long long tag0 = (unsigned long long)((a.root_base + i) * (int64_t)a.pitch);
 
     if (rdeg64 == 0) {  // isolated root: one member, every count = M (subg_acc.c:753-761); id = the root
         if (tid == 0) {

@@ -481,7 +481,7 @@ class SampledSets:
 
 
 def make_cfg(csr, num_walks, num_steps, bucket=-1, seed=111413, rng="rand_r", first_hop_wo=True,
-             order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False, records=True):
+             order=_lib.ORDER_WALK_MAJOR, cap_root_degree=True, emit_walks=False, records=True, row_pitch=0):
     """records=True: hand the graph's hop records (DeviceCSR.hop_records(), built on first use) to the kernel -- only the
     fused-row kernel reads them, so the callers that launch something else pass False and nothing is built for them"""
     rng_mode = {"rand_r": _lib.RNG_RAND_R, "philox": _lib.RNG_PHILOX}[rng]
@@ -491,7 +491,7 @@ def make_cfg(csr, num_walks, num_steps, bucket=-1, seed=111413, rng="rand_r", fi
     return WalkCfg(int(num_walks), int(num_steps), int(bucket), rng_mode, int(seed) & 0xFFFFFFFF,
                    1 if first_hop_wo else 0, int(order), 1 if cap_root_degree else 0,
                    1 if csr.indptr64 else 0, 1 if emit_walks else 0,
-                   recs[0].data_ptr() if recs else None, recs[1] if recs else 0, recs[2] if recs else 0)
+                   recs[0].data_ptr() if recs else None, recs[1] if recs else 0, recs[2] if recs else 0, None, int(row_pitch))
 
 
 def _as_query(query, device):

@@ -490,6 +490,9 @@ def pgather(edge, M, device=None, encode=None, gather_func=None, ptr=True, njobs
     return gather(edge, M, device, ptr=ptr, encode=encode)
 
 
+ALIGN_ROWS = os.environ.get("SUBGACC_ALIGN_ROWS", "1") == "1"      # 0: rows M*m+1 words apart, as rounds 1-5 had them (A/B)
+
+
 class StepBuffers:
     """Everything one on-demand step (sample_and_gather) touches, allocated once for a fixed (B, M, m): the int32 roots, the
     strided rows and their sizes, the table of distinct LP rows and the feature table indexed by its slots, the segment
@@ -517,9 +520,12 @@ class StepBuffers:
             raise ValueError(f"StepBuffers: pairs = {self.B} is not a whole number of batches of {batch}")
         if self.batch != self.B and dedup_roots:
             raise ValueError("StepBuffers: root dedup works on one batch (batch=None)")
-        n, self.stride, self.k = 2 * self.B, self.M * self.m + 1, self.m + 1
-        if self.stride > FUSED_MAX_Q or self.m < 1:
-            raise ValueError(f"StepBuffers: num_walks*num_steps+1 = {self.stride} exceeds what the fused-row walk kernel holds")
+        n, self.Q, self.k = 2 * self.B, self.M * self.m + 1, self.m + 1
+        if self.Q > FUSED_MAX_Q or self.m < 1:
+            raise ValueError(f"StepBuffers: num_walks*num_steps+1 = {self.Q} exceeds what the fused-row walk kernel holds")
+        # the rows of two roots lie `stride` words apart: M*m+1 rounded up to whole 128-byte lines (subgacc_walk_cfg::row_pitch) --
+        # the join reads, and the walk kernel writes, whole lines (the join alone: 3-5 % on every workload, profiles/r28_join_pitch.log)
+        self.stride = (self.Q + 31) // 32 * 32 if ALIGN_ROWS else self.Q
         self.capacity = int(uniq_capacity)
         self.roots = torch.empty(n, dtype=torch.int32, device=dev)
         self.nsize = torch.empty(n, dtype=torch.int32, device=dev)
@@ -556,7 +562,7 @@ class StepBuffers:
             self.dedup_steps = 0
         self.ws = torch.empty(max(L.subgacc_sjoin_workspace_bytes(n), 8), dtype=torch.uint8, device=dev)
         self.feat = None if self.keyrows else torch.empty((self.capacity + 1, self.k), dtype=torch.float32, device=dev)
-        need = n * self.stride * 2 * self.k
+        need = n * self.Q * 2 * self.k
         if out is not None and (out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev or out.numel() < need):
             raise ValueError("StepBuffers: out= must hold 2B * (M*m+1) * 2 * (m+1) float32 on the graph's device")
         self.out = out if out is not None else torch.empty(need, dtype=torch.float32, device=dev)
@@ -593,7 +599,8 @@ def _buffered_step(csr, e, bufs, seed, out):
                          f"these StepBuffers were made for [{B // PB}, 2, {PB}] pairs")
     e = e.contiguous()
     flags = bufs.status.view(torch.int32)[:4]
-    cfg = make_cfg(csr, M, m, -1, seed, bufs.rng, records=(2 <= m <= 4))     # (only the fused-row kernel of 2..4 hops reads hop records)
+    cfg = make_cfg(csr, M, m, -1, seed, bufs.rng, records=(2 <= m <= 4),     # (only the fused-row kernel of 2..4 hops reads hop records)
+                   row_pitch=bufs.stride if bufs.stride != bufs.Q else 0)
     rr = bufs.rng == "rand_r"
     rp, rs = (ptr(bufs.rng_pos), ptr(bufs.rng_seed)) if rr else (None, None)
     check(L.subgacc_key_shift(cfg.num_walks, cfg.num_steps))
@@ -656,7 +663,7 @@ def _buffered_step(csr, e, bufs, seed, out):
         keys = bufs.table[: bufs.capacity * 8].view(torch.int64)
         check(L.subgacc_unpack_lp(ptr(keys), bufs.capacity, None, M, m, None, None, ptr(bufs.feat), 1, st))
     res = out if out is not None else bufs.out
-    if res.dtype != torch.float32 or not res.is_contiguous() or res.device != dev or res.numel() < n * bufs.stride * 2 * k:
+    if res.dtype != torch.float32 or not res.is_contiguous() or res.device != dev or res.numel() < n * bufs.Q * 2 * k:
         raise ValueError("out= must hold 2B * (M*m+1) * 2 * (m+1) float32 on the graph's device")
     rows = res.numel() // (2 * k)
     xz = res.view(-1)[: rows * 2 * k].view(rows, 2, k)

@@ -321,9 +321,9 @@ class CapturedJoin:
         rows, word = self._host.tolist()
         if _DEBUG:
             word |= int(self.flags[3].item())
-        if word & 32:
+        if word & 64:
             self._state.zero_()
-            self.flags.zero_()          # (bit 32 in the device flags keeps every fill from running)
+            self.flags.zero_()          # (bit 64 in the device flags keeps every fill from running)
             raise _lib.SubgAccError("the join's size state was not clean (an aborted launch?): zeroed, call again")
         if word & 16:
             raise IndexError(f"row index out of range for an SpG with {self.z.n_rows} rows")

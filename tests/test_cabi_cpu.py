@@ -77,6 +77,14 @@ def test_join_descriptor_layout_matches_the_header(tmp_path, L):
     out = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     assert out[0] == C.sizeof(_lib.JoinDesc)
     assert out[1:] == [getattr(_lib.JoinDesc, n).offset for n in names]
+    # ... and struct subgacc_walk_cfg (row_pitch joined it this round)
+    wnames = [f[0] for f in _lib.WalkCfg._fields_]
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "subgacc.h"\nint main(void) {\n'
+                   '  printf("%zu\\n", sizeof(subgacc_walk_cfg));\n' +
+                   "".join(f'  printf("%zu\\n", offsetof(subgacc_walk_cfg, {n}));\n' for n in wnames) + "  return 0;\n}\n")
+    subprocess.check_call(["gcc", "-std=c11", str(src), "-I" + os.path.join(ROOT, "include"), "-o", str(exe)])
+    wout = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert wout[0] == C.sizeof(_lib.WalkCfg) and wout[1:] == [getattr(_lib.WalkCfg, n).offset for n in wnames]
     d = _lib.JoinDesc()
     d.struct_bytes = 8
     assert L.subgacc_sjoin_fill_v2(C.byref(d), None) == _lib.ERR_BADARG

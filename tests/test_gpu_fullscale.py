@@ -208,7 +208,7 @@ def test_cit2_scale_four_hop_batch_with_64_bit_key_rows(sp):
     o_nsize, o_remap, o_enc = oracle.gset_sampler(csr.indptr.cpu().numpy(), csr.indices.cpu().numpy(), roots, num_walks=M, num_steps=m,
                                                   seed=5, rng="philox", nthreads=8)
     oi, ox, od = oracle.spg_build(o_nsize, o_remap)
-    stride = M * m + 1
+    stride = bufs.stride                   # (rows lie on whole 128-byte lines: M*m+1 rounded up, StepBuffers)
     for j, i in enumerate(pick.tolist()):
         n_i = int(bufs.nsize[i])
         assert n_i == int(o_nsize[j])

@@ -233,7 +233,7 @@ def test_one_call_join_over_strided_key_rows_matches_the_two_step_form(sp):
     seg = torch.zeros(S + 1, dtype=torch.int64, device="cuda")
     state = torch.zeros(_lib.lib().subgacc_sjoin_workspace_bytes(S), dtype=torch.uint8, device="cuda")
     host = torch.full((2,), -7, dtype=torch.int64).pin_memory()
-    flags = torch.tensor([7, 7, 7, 64], dtype=torch.int32, device="cuda")
+    flags = torch.tensor([7, 7, 7, 128], dtype=torch.int32, device="cuda")
     for _ in range(2):
         _lib.join_fill(_lib.JOIN_ROWS, _lib.JOIN_KEY64 if z.sets.key64 else _lib.JOIN_KEY32, options=_lib.JOIN_OPT_SIZES, row_len=z.nsize,
                        n_rows=z.n_rows, row_stride=z.stride, ids=z.indices, payload=z.slot, own=own, partner=partner, S=S, pair_block=B,
@@ -241,7 +241,7 @@ def test_one_call_join_over_strided_key_rows_matches_the_two_step_form(sp):
                        host_tail=host)
         torch.cuda.synchronize()
         assert torch.equal(seg, ind) and torch.equal(out, xz)
-        assert host.tolist() == [xz.shape[0], 0] and flags.tolist() == [7, 7, 7, 64]
+        assert host.tolist() == [xz.shape[0], 0] and flags.tolist() == [7, 7, 7, 128]
         out.zero_(), seg.zero_()
     # what the descriptor refuses: a seg next to OPT_SIZES, no state, a state too small, another form
     kw = dict(row_len=z.nsize, n_rows=z.n_rows, row_stride=z.stride, ids=z.indices, payload=z.slot, own=own, S=S, pair_block=B, num_walks=100,

@@ -53,9 +53,20 @@ def one(wl, n):
     flags = bufs.status.view(torch.int32)[:4]
     fill = L.subgacc_sjoin_fill_keyrows64 if bufs.key64 else L.subgacc_sjoin_fill_keyrows      # (the ABI 5 forwards: old builds have them too)
     out = bufs.out.view(-1)
+    # JB_PITCH=n (experiment): the same rows laid out again n words apart (n a multiple of 32: every row begins on a 128-byte line)
+    stride, ids, slot = bufs.stride, bufs.ids, bufs.slot
+    pitch = int(os.environ.get("JB_PITCH", "0"))
+    if pitch:
+        assert pitch >= stride
+        ids2 = torch.zeros(2 * B * pitch, dtype=ids.dtype, device=dev)
+        slot2 = torch.zeros(2 * B * pitch, dtype=slot.dtype, device=dev)
+        ids2.view(2 * B, pitch)[:, :stride] = ids[: 2 * B * stride].view(2 * B, stride)
+        slot2.view(2 * B, pitch)[:, :stride] = slot[: 2 * B * stride].view(2 * B, stride)
+        stride, ids, slot = pitch, ids2, slot2
+        wl = f"{wl}@{pitch}"
 
     def launch():
-        check(fill(ptr(bufs.nsize), 2 * B, bufs.stride, ptr(bufs.ids), ptr(bufs.slot), ptr(own), ptr(partner), 2 * B, ptr(bufs.seg),
+        check(fill(ptr(bufs.nsize), 2 * B, stride, ptr(ids), ptr(slot), ptr(own), ptr(partner), 2 * B, ptr(bufs.seg),
                    M, k - 1, ptr(out), B, ptr(flags), st))
     for _ in range(5):
         launch()
