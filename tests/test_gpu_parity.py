@@ -1587,7 +1587,8 @@ def test_shfl_fallback_of_the_wave_reductions_gives_the_same_rows():
 
 
 def test_captured_join_over_a_resident_store_equals_gather(sp):
-    """stepgraph.CapturedJoin: the three launches of a join from a resident store as one HIP graph, replayed batch after batch --
+    """stepgraph.CapturedJoin: the join of a resident store with everything built once, ONE library call per batch (and graph=True:
+    the same launches replayed as a HIP graph), batch after batch --
     float payload (the PPR store), the Z_SF-table store and the keyed store; same (xz, indptr) as gather(), IndexError for a
     row outside the store at finish()."""
     from surel_plus_amd.graphs import ppr_like_spg, query_pairs
@@ -1599,12 +1600,13 @@ def test_captured_join_over_a_resident_store_equals_gather(sp):
     zf = ppr_like_spg(6000, 100, seed=3)
     B = 500
     for store, encode in ((zf, None), (z, table), (zk, zk.slot_table())):
-        cj = sp.CapturedJoin(store, B, encode=encode)
-        for s_ in (1, 2, 3):
-            e = query_pairs(csr, B, seed=s_)
-            xz, ind = cj(e).finish()
-            wxz, wind = sp.gather(e, store, "cuda", ptr=True, encode=encode)
-            assert torch.equal(ind, wind) and torch.equal(xz, wxz)
+        for graph in (False, True):
+            cj = sp.CapturedJoin(store, B, encode=encode, graph=graph)
+            for s_ in (1, 2, 3):
+                e = query_pairs(csr, B, seed=s_)
+                xz, ind = cj(e).finish()
+                wxz, wind = sp.gather(e, store, "cuda", ptr=True, encode=encode)
+                assert torch.equal(ind, wind) and torch.equal(xz, wxz)
     bad = query_pairs(csr, B, seed=9)
     bad[1, 7] = 6000
     with pytest.raises(IndexError):

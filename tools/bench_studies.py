@@ -181,7 +181,7 @@ def offline_flow(sp, csr, M, k, B, K, cpu):
         t_key = time.perf_counter() - t2
     JK = join_rate(zk, zk.slot_table())
     # the reference's own loop AT the reference's batch size (main.py:32: 1,024 pairs; train.py:120-127), from the keyed store:
-    # one eager gather per batch, the same as ONE HIP graph per batch (CapturedJoin), and 64 batches per launch sequence
+    # one eager gather per batch, one library call per batch (CapturedJoin; four lanes of them: CapturedJoinPool), and 64 batches per launch sequence
     # (gather_many: the permutation of an epoch is known when it starts) -- 3 repeats each, the median is reported
     b1024 = {}
     try:
