@@ -191,7 +191,7 @@ def test_one_call_join_sizes_in_one_launch(sp, graph):
     N = 5000
     zf = ppr_like_spg(N, 40, seed=5)
     rs = np.random.default_rng(11)
-    for B in (1, 1024, 1025, 70000):
+    for B in (0, 1, 1024, 1025, 70000):
         cj = sp.CapturedJoin(zf, B, graph=graph)
         for rep in range(3):
             e = torch.from_numpy(rs.integers(0, N, (2, B))).cuda()
