@@ -935,6 +935,9 @@ def flatten(out):
     put("hgather_b2048_frac", (hg.get("roofline") or {}).get("frac"))
     put("hgather_b2048_one_call_triplets_per_s", hg.get("one_call_triplets_per_s") if not isinstance(hg.get("one_call_triplets_per_s"), str) else None)
     put("hgather_b2048_pool4_triplets_per_s", hg.get("pool4_triplets_per_s"))
+    if hg.get("pool4_triplets_per_s") and (hg.get("roofline") or {}).get("algorithmic_bytes_per_launch"):
+        # ... as a fraction of the HBM peak: the algorithmic bytes of one batch x batches per second (four lanes in flight)
+        put("hgather_b2048_pool4_frac", hg["roofline"]["algorithmic_bytes_per_launch"] * hg["pool4_triplets_per_s"] / hg["triplets_per_step"] / 1e9 / HBM_PEAK_GBS)
     put("hgather_b2048_many32_triplets_per_s", hg.get("many32_triplets_per_s"))
     cb = out.get("cpu_baseline") or {}
     put("cpu_model", cb.get("cpu_model"))
