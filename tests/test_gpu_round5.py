@@ -317,3 +317,19 @@ def test_one_call_hgather_equals_hgather(sp):
             assert torch.equal(ids, wids) and torch.equal(xz, wxz)
     with pytest.raises(NotImplementedError):
         sp.CapturedJoin(z, B, triplets=True)
+
+
+def test_one_call_join_size_pass_beyond_the_resident_grid(sp):
+    """the single-pass scan of SUBGACC_JOIN_OPT_SIZES with more tiles than the chip holds at once (3,000,000 segments = 2,930
+    tiles of 256 lanes; ~2,048 are resident): tiles take their numbers from a ticket, so a tile only ever waits for tiles that
+    run already -- the segment pointers equal a cumulative sum, the rows equal gather()'s, twice on the same state"""
+    from surel_plus_amd.graphs import ppr_like_spg
+    N, B = 4000, 1_500_000
+    zf = ppr_like_spg(N, 12, seed=6)
+    e = torch.randint(0, N, (2, B), device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+    cj = sp.CapturedJoin(zf, B)
+    wxz, wind = sp.gather(e, zf, "cuda", ptr=True, encode=None)
+    for _ in (0, 1):
+        xz, ind = cj(e).finish()
+        assert torch.equal(ind, wind) and torch.equal(xz, wxz)
+    assert int(cj._state.view(torch.int64)[: 8 + 2930].abs().sum().item()) == 0
