@@ -7,7 +7,8 @@
 One process per (workload, library): builds the preset graph, runs one buffered step (so that the step buffers hold the walk
 kernel's rows and the segment pointers), then times `n` launches of subgacc_sjoin_fill_keyrows(64) over those buffers with HIP
 events on the launch stream; prints ms, algorithmic bytes and the fraction of the 8 TB/s peak.  `-` = the shipped
-library.  Variant libraries are built HERE into tools/build/ (they travel to the GPU box): tools/join_bench.py --build "-DX=1" name."""
+library.  JB_PITCH=n: the same rows laid out again n words apart first (how the 128-byte-aligned pitch was measured before it became
+subgacc_walk_cfg::row_pitch; StepBuffers have it now).  Variant libraries are built HERE into tools/build/ (they travel to the GPU box): tools/join_bench.py --build "-DX=1" name."""
 import os
 import subprocess
 import sys
