@@ -1166,7 +1166,9 @@ def main():
                        small_batches=(world == 1 and args.full),
                        # outside the clock, K more steps with two step buffers in turn on two streams (what a serving loop gains by it);
                        # the pass with every distinct endpoint sampled once: --full only
-                       two_stream_extra=True, dedup_extra=args.full,
+                       # (not with --no-others: that is the command the profiles are taken with, and kernels that overlap on two
+                       #  streams would spoil its per-kernel averages)
+                       two_stream_extra=not args.no_others, dedup_extra=args.full,
                        csr_variant=args.full,                    # ... and no pass with the packed-CSR (table rows) variant
                        offline=(rank == 0 and world == 1 and args.full and args.scale == 1.0),
                        # the driver's K steps are the headline region; three regions of 100 steps follow, outside its clock

@@ -105,12 +105,10 @@ __global__ __launch_bounds__(kWlThreads) void worklist_place_kernel(const int32_
         const int64_t i = base + (int64_t)k * kWlThreads + threadIdx.x;
         if (rt[k] != SUBGACC_NO_ROOT) worklist[off[wl_bucket(rt[k], shift)] + pl[k]] = (int32_t)i;
     }
-    // the last block to get here zeroes the totals for the next call (every block has read them: the scan above)
+    // the last block to get here zeroes the totals for the next call (every block has READ them by then -- the scan above needed
+    // their values -- and that is all the order this needs: no fence, which on this chip is an L2 write-back per block)
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        last = atomicAdd(done, 1) == (int32_t)gridDim.x - 1;
-    }
+    if (threadIdx.x == 0) last = atomicAdd(done, 1) == (int32_t)gridDim.x - 1;
     __syncthreads();
     if (last) {
         for (int b = threadIdx.x; b < kWlBuckets; b += kWlThreads) totals[b] = 0;
