@@ -216,7 +216,8 @@ def hot_path_step(sp, csr, edge, M, k, seed, rng, slot=0):
         if bufs is None:
             try:
                 bufs = _STEP_BUFS[key] = sp.StepBuffers(csr, B, M, k - 1, uniq_capacity=UNIQ_CAPACITY, out=buf, dedup_roots=DEDUP, rng=rng,
-                                                        sort_roots=os.environ.get("SUBGACC_SORT_ROOTS", "1") == "1")
+                                                        sort_roots=os.environ.get("SUBGACC_SORT_ROOTS", "1") == "1",
+                                                        align_rows=os.environ.get("SUBGACC_ALIGN_ROWS", "1") == "1")     # (bench-only switches)
             except ValueError:
                 bufs = _STEP_BUFS[key] = False
     xz, ind, sets = sp.sample_and_gather(csr, edge, num_walks=M, num_steps=k - 1, seed=seed, rng=rng, out=buf if LAZY else None,

@@ -213,14 +213,14 @@ def join_fill(form=JOIN_ROWS, payload_kind=JOIN_SFPTR, **fields):
 
 def publish(src, host):
     """queue `host[:] = src` (a few int64 words: sizes, status) on the current stream WITHOUT a copy engine: see subgacc_publish_words.
-    SUBGACC_READBACK=copy takes torch's asynchronous copy instead (A/B)."""
+    (`_lib._READBACK_COPY = True` takes torch's asynchronous copy instead: the A/B switch)"""
     if _READBACK_COPY or src.numel() > 4096 or not src.is_contiguous() or src.dtype != host.dtype or src.element_size() != 8:
         host.copy_(src, non_blocking=True)
     else:
         check(lib().subgacc_publish_words(C.c_void_p(src.data_ptr()), src.numel(), C.c_void_p(host.data_ptr()), stream_ptr()))
 
 
-_READBACK_COPY = os.environ.get("SUBGACC_READBACK", "kernel") == "copy"
+_READBACK_COPY = False      # True: torch's asynchronous copy instead (how the A/B of profiles/r25_readback_ab.log was run)
 
 
 def ptr(t):

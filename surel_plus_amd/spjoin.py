@@ -490,9 +490,6 @@ def pgather(edge, M, device=None, encode=None, gather_func=None, ptr=True, njobs
     return gather(edge, M, device, ptr=ptr, encode=encode)
 
 
-ALIGN_ROWS = os.environ.get("SUBGACC_ALIGN_ROWS", "1") == "1"      # 0: rows M*m+1 words apart, as rounds 1-5 had them (A/B)
-
-
 class StepBuffers:
     """Everything one on-demand step (sample_and_gather) touches, allocated once for a fixed (B, M, m): the int32 roots, the
     strided rows and their sizes, the table of distinct LP rows and the feature table indexed by its slots, the segment
@@ -508,7 +505,7 @@ class StepBuffers:
     The hash is stamped with a per-step generation kept on the device: a captured step replays correctly."""
 
     def __init__(self, csr, pairs, num_walks=200, num_steps=3, uniq_capacity=1 << 17, out=None, dedup_roots=False, rng="philox",
-                 key_rows=True, sort_roots=True, batch=None):
+                 key_rows=True, sort_roots=True, batch=None, align_rows=True):
         from .sampler import FUSED_MAX_Q
         L, dev = lib(), csr.device
         self.B, self.M, self.m = int(pairs), int(num_walks), int(num_steps)
@@ -525,7 +522,8 @@ class StepBuffers:
             raise ValueError(f"StepBuffers: num_walks*num_steps+1 = {self.Q} exceeds what the fused-row walk kernel holds")
         # the rows of two roots lie `stride` words apart: M*m+1 rounded up to whole 128-byte lines (subgacc_walk_cfg::row_pitch) --
         # the join reads, and the walk kernel writes, whole lines (the join alone: 3-5 % on every workload, profiles/r28_join_pitch.log)
-        self.stride = (self.Q + 31) // 32 * 32 if ALIGN_ROWS else self.Q
+        # (align_rows=False: rows M*m+1 words apart, the layout of rounds 1-4)
+        self.stride = (self.Q + 31) // 32 * 32 if align_rows else self.Q
         self.capacity = int(uniq_capacity)
         self.roots = torch.empty(n, dtype=torch.int32, device=dev)
         self.nsize = torch.empty(n, dtype=torch.int32, device=dev)
