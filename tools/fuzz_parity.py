@@ -125,6 +125,13 @@ for c in range(cases):
                 R = int(bi[-1].item())
                 if not (np.array_equal(bi.cpu().numpy(), wind) and np.array_equal(bx[:R].cpu().numpy(), wxz)):
                     fails.append(f"buffered step (dedup_roots={dd})")
+                # ... and the numbering of the step's distinct LP rows on demand, from the rows as they stand in the buffers (whole
+                # 128-byte lines apart: row_pitch) -- the oracle's enc of the same endpoints, first-occurrence order
+                if not dd:
+                    ob = oracle.gset_sampler(ptr_, idx, np.asarray(q)[edge].reshape(-1), num_walks=M, num_steps=m, seed=seed, rng="philox")
+                    if not np.array_equal(bs.enc_int16().cpu().numpy(), ob[2]):
+                        fails.append("buffered step: enc on demand")
+                    cov["buffered_enc"] = cov.get("buffered_enc", 0) + 1
         T = int(rng0.choice([1, 3]))
         rep = bool(rng0.integers(0, 2))
         w1, o1 = sp.walk_sampler(ptr_, idx, q, num_walks=M, num_steps=m, nthread=T, seed=seed, replacement=rep, rng=rng)
