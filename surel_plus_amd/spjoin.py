@@ -285,7 +285,7 @@ def lazy_join_status(ind):
 def _checked(out, ind, flags, lazy=False):
     if lazy:
         ind.join_flags = flags       # see lazy_join_status()
-    if _DEBUG_FLAGS:
+    if _DEBUG_FLAGS and not torch.cuda.is_current_stream_capturing():      # (a capture cannot read back: the replay's finish() does)
         f = int(flags[3].item())
         if f & 16:
             raise IndexError("row index out of range for the SpG")

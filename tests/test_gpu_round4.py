@@ -3,6 +3,8 @@
     sequence == nb calls of the reference-shaped entry points (train.py:120-127 at main.py:32's batch size), and == the oracle;
   * the sorted work list is only taken where walk_rows_kernel runs (ADVICE r3: bucket > 0 with >= 16,384 roots);
   * rand_r dead ends are remembered on the DeviceCSR; stale member counts are refused."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -265,9 +267,13 @@ def test_gather_many_lazy_reads_nothing_until_a_batch_is_taken(sp):
     assert len(lazy[1:3]) == 2 and torch.equal(lazy[-1][0], eager[nb - 1][0])
     bad = edges.clone()
     bad[2, 0, 5] = N + 3
-    q = sp.gather_many(bad, zk, "cuda", encode=zk.slot_table(), out=out, lazy=True)
-    with pytest.raises(IndexError):
-        q[0]
+    if os.environ.get("SUBGACC_DEBUG", "0") == "1":                 # (debug mode reads the status word after every join: it raises at the call)
+        with pytest.raises(IndexError):
+            sp.gather_many(bad, zk, "cuda", encode=zk.slot_table(), out=out, lazy=True)
+    else:
+        q = sp.gather_many(bad, zk, "cuda", encode=zk.slot_table(), out=out, lazy=True)
+        with pytest.raises(IndexError):
+            q[0]
     with pytest.raises(ValueError):
         sp.gather_many(edges, zk, "cuda", ptr=False, encode=zk.slot_table(), out=out, lazy=True)
     with pytest.raises(ValueError):
