@@ -38,9 +38,9 @@
         if (SG_STOP_AFTER == (k)) {      \
             if (threadIdx.x == 0 && !a.tags_only) {   /* a well-formed one-member row, so that the rest of the step stays in bounds (subgacc_walk_tags passes no rows at all) */ \
                 a.nsize[i] = 1;          \
-                a.set_ids[i * (int64_t)a.stride] = root; \
-                if (SPG) a.set_slot[i * (int64_t)a.stride] = 0; \
-                else a.set_keys[i * (int64_t)a.stride] = 1ull << (a.m * a.shift); \
+                a.set_ids[i * (int64_t)a.pitch] = root; \
+                if (SPG) a.set_slot[i * (int64_t)a.pitch] = 0; \
+                else a.set_keys[i * (int64_t)a.pitch] = 1ull << (a.m * a.shift); \
             }                            \
             return;                      \
         }                                \
@@ -56,8 +56,8 @@
         if (SG_STOP_AFTER == (k)) {                                                                          \
             if (threadIdx.x == 0 && !a.tags_only) {   /* (subgacc_walk_tags: there are no rows to write) */   \
                 a.nsize[i] = 1;                                                                              \
-                a.set_ids[i * (int64_t)a.stride] = root;                                                     \
-                a.set_slot[i * (int64_t)a.stride] = 0;                                                       \
+                a.set_ids[i * (int64_t)a.pitch] = root;                                                     \
+                a.set_slot[i * (int64_t)a.pitch] = 0;                                                       \
             }                                                                                                \
             return;                                                                                          \
         }                                                                                                    \
