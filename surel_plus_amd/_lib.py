@@ -220,6 +220,18 @@ def publish(src, host):
         check(lib().subgacc_publish_words(C.c_void_p(src.data_ptr()), src.numel(), C.c_void_p(host.data_ptr()), stream_ptr()))
 
 
+_KEPT = []
+
+
+def keep_until(event, obj):
+    """`obj` (the pinned buffer a publish() kernel writes) stays alive until `event` -- recorded behind that kernel -- has passed,
+    even if its owner is dropped first: torch's host allocator knows nothing of a kernel that writes pinned memory and would hand
+    the block to somebody else.  (Finished entries leave when the next one arrives.)"""
+    while _KEPT and _KEPT[0][0].query():
+        _KEPT.pop(0)
+    _KEPT.append((event, obj))
+
+
 _READBACK_COPY = False      # True: torch's asynchronous copy instead (how the A/B of profiles/r25_readback_ab.log was run)
 
 

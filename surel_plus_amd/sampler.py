@@ -264,6 +264,7 @@ class SampledSets:
         _lib.publish(src, host)
         ev = torch.cuda.Event()
         ev.record()
+        _lib.keep_until(ev, host)
         self._pending = (host, ev, src)          # src stays alive until the copy has run
         return self
 

@@ -329,6 +329,7 @@ class BatchViews:
             _lib.publish(src, host)
             ev = torch.cuda.Event()
             ev.record()
+            _lib.keep_until(ev, host)
             self._pending = (host, ev, src)
 
     def _words(self):
