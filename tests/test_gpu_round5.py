@@ -333,3 +333,33 @@ def test_one_call_join_size_pass_beyond_the_resident_grid(sp):
         xz, ind = cj(e).finish()
         assert torch.equal(ind, wind) and torch.equal(xz, wxz)
     assert int(cj._state.view(torch.int64)[: 8 + 2930].abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("name", ["sjoin_int.npz", "sjoin_float.npz", "sjoin_int_emptyrows.npz"])
+def test_one_call_join_matches_reference_golden(sp, name):
+    """the reference's own outputs (train.gather run in the build container, tests/golden/): CapturedJoin / CapturedJoinPool -- one
+    library call per batch -- give the same (xz, indptr), bit for bit, as the fixtures hold for ptr=True"""
+    from test_gpu_parity import _load, _spg_from_golden
+    g = _load(name)
+    z = _spg_from_golden(sp, g)
+    enc = torch.from_numpy(g["encode"]).cuda() if g["encode"].size else None
+    edge = np.asarray(g["edge"])
+    cj = sp.CapturedJoin(z, edge.shape[1], encode=enc)
+    for e in (edge, torch.from_numpy(edge).cuda()):                # NumPy endpoints (as the fixtures have them) and a device tensor
+        xz, ind = cj(e).finish()
+        assert xz.dtype == torch.float32 and ind.dtype == torch.int64
+        assert np.array_equal(xz.cpu().numpy(), g["xz_ptr1"]) and np.array_equal(ind.cpu().numpy(), g["ind_ptr1"])
+    pool = sp.CapturedJoinPool(z, edge.shape[1], lanes=2, encode=enc)
+    xz, ind = pool.finish(pool.submit(torch.from_numpy(edge).cuda()))
+    assert np.array_equal(xz.cpu().numpy(), g["xz_ptr1"]) and np.array_equal(ind.cpu().numpy(), g["ind_ptr1"])
+
+
+def test_one_call_hgather_matches_reference_golden(sp):
+    """train.hgather's own output (tests/golden/hjoin_int.npz) through CapturedJoin(triplets=True)"""
+    from test_gpu_parity import _load, _spg_from_golden
+    g = _load("hjoin_int.npz")
+    z = _spg_from_golden(sp, g)
+    hedge = np.asarray(g["hedge"])
+    cj = sp.CapturedJoin(z, hedge.shape[1], encode=torch.from_numpy(g["encode"]).cuda(), triplets=True)
+    xz, ids = cj(torch.from_numpy(hedge).cuda()).finish()
+    assert np.array_equal(xz.cpu().numpy(), g["xz"]) and np.array_equal(ids.cpu().numpy(), g["ind"])
