@@ -368,22 +368,36 @@ def literal_dropin(csr, M, k, n_cpu=32768, nthread_cpu=-1):
     return out
 
 
-def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W, extra_regions=0):
-    """SpJoin over a resident float-payload SpG (the citation2 PPR configuration): one step = B pairs -> xz [R,2,1]."""
+_PPR_STORE = {}
+
+
+def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W, extra_regions=0, layout="aligned"):
+    """SpJoin over a resident float-payload SpG (the citation2 PPR configuration): one step = B pairs -> xz [R,2,1].
+    layout: "aligned" (round 6, the serving layout: SpG.aligned() -- rows on whole 128-byte lines at a fixed pitch, their lengths in
+    their first slots, no row pointers) or "packed" (the CSR the offline stage leaves, as rounds 1-5 joined it)."""
     from surel_plus_amd.graphs import ppr_like_spg, preset_graph
-    if os.environ.get("SUBGACC_PPR_SYNTH", "0") == "1":      # stand-in payload: exactly 100 random ids per row
+    key = (os.environ.get("SUBGACC_PPR_SYNTH", "0"), args.scale, str(dev))
+    if key in _PPR_STORE:                                    # (the store of the pass before: the offline stage is not what is timed)
+        zp, prep_s = _PPR_STORE[key]
+        N = zp.n_rows
+    elif os.environ.get("SUBGACC_PPR_SYNTH", "0") == "1":    # stand-in payload: exactly 100 random ids per row
         N = max(int(2_927_963 * args.scale), 1000)
-        z, prep_s = ppr_like_spg(N, 100, seed=3, device=dev), None
+        zp, prep_s = ppr_like_spg(N, 100, seed=3, device=dev), None
     else:                                                    # the real offline stage (main.py:181-183), not timed
         from surel_plus_amd.ppr import topk_ppr_matrix
         csr = preset_graph("cit2", device=dev, scale=args.scale)
         N = csr.num_nodes
         torch.cuda.synchronize()
         t_prep = time.perf_counter()
-        z = topk_ppr_matrix(csr, 0.1, 1e-4, torch.arange(N, dtype=torch.int32, device=dev), 100, normalization="sym", encode=True)
+        zp = topk_ppr_matrix(csr, 0.1, 1e-4, torch.arange(N, dtype=torch.int32, device=dev), 100, normalization="sym", encode=True)
         torch.cuda.synchronize()
         prep_s = time.perf_counter() - t_prep
         del csr
+    _PPR_STORE.clear()
+    _PPR_STORE[key] = (zp, prep_s)
+    members = zp.nnz
+    z = zp.aligned() if layout == "aligned" else zp
+    store_bytes = z.nbytes if layout == "aligned" else (zp.indptr.numel() * 8 + members * 12)
     import gc
     gc.collect()          # (the previous pass's garbage: collected here, not by a pause inside this pass's regions -- see bench_lp)
     torch.cuda.synchronize()
@@ -466,6 +480,7 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W, extr
         elapsed = float(t.item())
     rank_records = gather_rank_records(dist, world, rank, dev, elapsed_local, timer.mean_ms("join")[0],
                                        os.environ.get("SUBGACC_DIST_BACKEND", "nccl") if dist is not None else None)
+    require_distinct_devices(rank_records, world, os.environ.get("SUBGACC_DIST_BACKEND", "nccl") if dist is not None else None)
     if rank != 0:
         return None
     if extra_regions:
@@ -497,8 +512,9 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W, extr
     for _ in range(3):
         ev0.record()
         for _ in range(10):
-            lib_.join_fill(lib_.JOIN_ROWS, lib_.JOIN_F64, row_off=z.indptr, n_rows=z.n_rows, ids=z.indices, payload=z.data, max_len=z.max_len,
-                           own=own_e, S=own_e.numel(), seg=ind_e, pair_block=B, out_xz=xz_e, flags=ind_e.join_flags)
+            lib_.join_fill(lib_.JOIN_ROWS, lib_.JOIN_F64, n_rows=z.n_rows, payload=z.data, own=own_e, S=own_e.numel(), seg=ind_e, pair_block=B,
+                           out_xz=xz_e, flags=ind_e.join_flags,
+                           **(dict(row_stride=z.pitch, ids=z.ids) if layout == "aligned" else dict(row_off=z.indptr, ids=z.indices, max_len=z.max_len)))
         ev1.record()
         torch.cuda.synchronize()
         b2b.append(ev0.elapsed_time(ev1) / 10)
@@ -508,7 +524,7 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W, extr
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
-        tj = json.load(open(tpath)).get(f"cit2ppr:{B}:join", {})
+        tj = json.load(open(tpath)).get(f"cit2ppr:{B}:join" + (":aligned" if layout == "aligned" else ""), {})
         if tj.get("kernel_source_sha") == kernel_source_sha():
             traffic = tj.get("join_hbm_bytes_per_launch")
     return {"metric": "query-pairs/sec (SpJoin, PPR payload)", "value": world * B * K / elapsed, "unit": "query-pairs/s",
@@ -524,7 +540,8 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W, extr
                        "rank_records": rank_records, "rng": "none (join only)", "parallelism": f"query-shard x{world}",
                        "region_pairs_per_s": [round(v) for v in region_values], "pairs_per_s_min": min(region_values),
                        "pairs_per_s_median": median(region_values), "pairs_per_s_max": max(region_values),
-                       "spg_members": z.nnz, "offline_ppr_stage_s": prep_s,
+                       "spg_members": members, "offline_ppr_stage_s": prep_s, "store_layout": layout, "store_bytes": store_bytes,
+                       "store_bytes_packed": zp.indptr.numel() * 8 + members * 12,
                        "join_call_ms": call_ms,          # (two launches: the single-pass size kernel, the fill; + the event pair)
                        # ... and what a call costs in the loop (two joins in turn on two streams): the period of the timed regions
                        "join_call_ms_steady": steady_ms,
@@ -545,7 +562,7 @@ def median(v):
 
 def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, with_cpu_baseline, csr_variant=True,
              small_batches=False, two_stream_extra=True, dedup_extra=None, offline=False, extra_regions=(0, 0), value_is_median=False, captured=False,
-             cpu_kw={}, wake_s=0.0):
+             cpu_kw={}, wake_s=0.0, host_fed=False, ref_flow=False):
     """sample + SpJoin over one LP workload: W warm-up steps, K timed steps bracketed by barrier + synchronize, max over
     ranks.  Returns the JSON object (rank 0) or None.
     extra_regions = (R, Kx): after the timed region, R more regions of Kx steps each in the same loop (rank 0, 1 GPU): their
@@ -690,6 +707,7 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
         timer.enabled = False
     rank_records = gather_rank_records(dist, world, rank, dev, elapsed_local, timer.mean_ms("walk_sets")[0],
                                        os.environ.get("SUBGACC_DIST_BACKEND", "nccl") if dist is not None else None)
+    require_distinct_devices(rank_records, world, os.environ.get("SUBGACC_DIST_BACKEND", "nccl") if dist is not None else None)
 
     # what the JSON line says about the last timed step, taken NOW: the extra passes below re-use the step buffers
     last_members = last_rows = last_distinct = last_abytes = None
@@ -697,6 +715,16 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
         last_members, last_rows = int(last[1].X), int(last[2].shape[0])
         last_distinct = int(last[1].c)
         last_abytes = algorithmic_walk_bytes(csr, last[0].reshape(-1), last[1], M, k - 1)   # the last timed launch
+    host_fed_rate = None
+    if host_fed and rank == 0 and world == 1 and not captured and STREAMS is None:
+        # the same loop fed from the host (train.py:123), outside the driver's clock: 100 steps, [2,B] int64 from pinned memory per step
+        # (after the last timed step's sizes were taken, above: the loop re-uses the step buffers)
+        timer.enabled = False
+        keep_last = last
+        pinned = [e.cpu().pin_memory() for e in edges[:min(len(edges), 16)]]
+        host_fed_rate = host_fed_loop(lambda e, s: hot_path_step(sp, csr, e, M, k, seed=s, rng=rng, slot=s & 1), finish_step, pinned, B, dev,
+                                      max(extra_regions[1], 100))
+        last = keep_last
     # for the record, outside the clock: the same steps with a packed CSR SpG built for every batch (rank 0, 1 GPU)
     csr_ms = None
     if csr_variant and rank == 0 and world == 1 and last is not None and last[1].strided:
@@ -836,6 +864,9 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
         out["config"]["batch_size_and_hip_graph"] = bench_studies().batch_size_and_graph(sp, csr, M, k, rng, K)
     if two_stream_extra and two_streams:
         out["config"]["two_stream_pairs_per_s"] = two_streams["pairs_per_s"]
+    if host_fed_rate:
+        out["config"]["host_fed_pairs_per_s"] = host_fed_rate
+        out["config"]["host_fed_over_resident"] = host_fed_rate / median(region_values[1:] or region_values)
     if dedup_loop and "pairs_per_s" in dedup_loop:
         out["config"]["dedup_roots_pairs_per_s"] = dedup_loop["pairs_per_s"]
     if with_cpu_baseline and not name.startswith("twitter"):   # 12 GB CSR: no host copy
@@ -844,6 +875,12 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
         except Exception as ex:  # the baseline is a report, never a reason to lose the measurement
             out["cpu_baseline"] = {"value": None, "unit": "query-pairs/s", "cores": os.cpu_count(), "kind": "port",
                                    "sample": f"failed: {type(ex).__name__}: {ex}"}
+    if ref_flow and not offline:     # SURVEY 8(d)'s S / J / Q on the reference's own flow: part of the default run since round 6 (~1.5 s)
+        try:
+            flow = reference_flow(sp, csr, M, k, B)[0]
+            out["config"]["offline_flow"] = flow
+        except Exception as ex:     # an extra must never cost the headline line
+            out["config"]["offline_flow"] = {"failed": f"{type(ex).__name__}: {ex}"}
     if offline:      # the reference's own flow + the rest of the surface, outside the clock (rank 0, 1 GPU, the headline workload)
         try:
             torch.cuda.empty_cache()
@@ -861,6 +898,122 @@ def bench_lp(args, name, rng, B, K, W, sp, sampler_mod, dev, rank, world, dist, 
         except Exception as ex:     # an extra must never cost the headline line
             out["config"]["offline_flow"] = {"failed": f"{type(ex).__name__}: {ex}"}
     return out
+
+
+def reference_flow(sp, csr, M, k, B, reps=3):
+    """SURVEY 8(d)'s S / J / Q on the reference's OWN flow, outside the driver's clock (rank 0, 1 GPU, the headline graph):
+    main.py:172-178 samples every node once -- subg_matrix over all N: walk -> register -> number -> packed SpG resident in HBM
+    with its enc table (S, roots/s) --, train.py:120-127 then joins every batch from that resident store (J, pairs/s: gather(edge, z,
+    encode=Z_SF), B pairs per call; J_keyed: the store re-keyed once, SpG.keyed).  Q_formula = 1 / (2/S + 1/J), the survey's
+    on-demand figure made of the two; Q_amortised = 1e8 pairs / (N/S + 1e8/J), the reference-style number.
+    -> (dict, z, sets, enc, table, zk)"""
+    from surel_plus_amd.graphs import query_pairs
+    from surel_plus_amd.spg import sample_spg
+    dev, N = csr.device, csr.num_nodes
+    idx = torch.arange(N, dtype=torch.int32, device=dev)
+    z = sets = None
+    times = []
+    for _ in range(reps):       # the previous store goes back to the allocator first: steady state, no fresh GB-sized hipMalloc
+        del z, sets
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        z, sets = sample_spg(csr, idx, num_walks=M, num_steps=k - 1, seed=111413, rng="philox", fused=True)
+        enc = sets.enc_int16()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    t_off = min(times[1:])
+    table = sets.feature_table()
+    edges = [query_pairs(csr, B, seed=9000 + s_, device=dev) for s_ in range(7)]
+    cap = 2 * B * z.max_len * 2 * k
+    buf = _XZ_BUF.get((dev, cap, 0))
+    if buf is None:
+        buf = torch.empty(cap, dtype=torch.float32, device=dev)
+
+    def join_rate(store, tab):
+        for e in edges[:2]:
+            sp.gather(e, store, dev, ptr=True, encode=tab, out=buf, lazy=True)
+        rs = []
+        for _ in range(3):          # three loops of 50 joins (>= 20 ms each); the median is reported
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for j in range(50):
+                sp.gather(edges[2 + j % 5], store, dev, ptr=True, encode=tab, out=buf, lazy=True)
+            torch.cuda.synchronize()
+            rs.append(50 * B / (time.perf_counter() - t1))
+        return median(rs)
+    J = join_rate(z, table)
+    encz = torch.cat([torch.zeros((1, enc.shape[1]), dtype=enc.dtype, device=dev), enc])
+    zk = None
+    for _ in range(2):          # (steady-state allocator again: the second re-keying is the one that counts)
+        del zk
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        zk = z.keyed(encz, M)
+        torch.cuda.synchronize()
+        t_key = time.perf_counter() - t2
+    JK = join_rate(zk, zk.slot_table())
+    # ... and the keyed store laid out for serving (SpG.aligned(): rows on whole lines at a fixed pitch, no row pointers; round 6)
+    JKA = aligned_ms = aligned_bytes = None
+    try:
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        za = zk.aligned()
+        torch.cuda.synchronize()
+        aligned_ms, aligned_bytes = (time.perf_counter() - t3) * 1e3, za.nbytes
+        JKA = join_rate(za, za.slot_table())
+        del za
+    except Exception as ex:      # (an extra: never a reason to lose S / J / Q)
+        aligned_ms = f"{type(ex).__name__}: {ex}"
+    S = N / t_off
+    flow = {"all_N_sample_to_resident_spg_ms": t_off * 1e3, "S_roots_per_s": S, "set_members": z.nnz,
+            "distinct_lp_rows": int(enc.shape[0]), "J_pairs_per_s_table_store": J, "J_pairs_per_s_keyed_store": JK,
+            "rekey_once_ms": t_key * 1e3, "pairs_per_batch": B,
+            "J_pairs_per_s_keyed_aligned_store": JKA, "aligned_once_ms": aligned_ms, "aligned_store_bytes": aligned_bytes,
+            "packed_store_bytes": (N + 1) * 8 + z.nnz * 8,
+            "Q_formula_pairs_per_s": 1.0 / (2.0 / S + 1.0 / J), "Q_formula_keyed_pairs_per_s": 1.0 / (2.0 / S + 1.0 / JK),
+            "Q_amortised_at_1e8_pairs_table": 1e8 / (t_off + 1e8 / J), "Q_amortised_at_1e8_pairs_keyed": 1e8 / (t_off + t_key + 1e8 / JK),
+            "reference": "main.py:172-178 (subg_matrix over all N once) + train.py:120-127 (one join per batch from the resident store)"}
+    return flow, z, sets, enc, table, zk
+
+
+def host_fed_loop(run_step, finish, host_edges, B, dev, steps):
+    """The timed loop's shape with the [2,B] query batch coming from the HOST every step, as the reference feeds edges[:, perm]
+    (train.py:123): the batches lie in pinned host memory; the upload of step s+1 is queued on a copy stream while step s's kernels
+    run (two device slots in turn: the copy into a slot waits for the step that last read it), the step waits for its own upload only.
+    -> pairs/s (outside the driver's clock; SURVEY 7: "nothing on the steady-state path touches the host except the [2,B] query upload")"""
+    cur = torch.cuda.current_stream(dev)
+    copy_stream = torch.cuda.Stream(device=dev)
+    slots = [torch.empty_like(host_edges[0], device=dev) for _ in range(2)]
+    uploaded = [torch.cuda.Event() for _ in range(2)]
+    consumed = [torch.cuda.Event() for _ in range(2)]
+    for ev in consumed:
+        ev.record(cur)
+
+    def upload(s):
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(consumed[s & 1])
+            slots[s & 1].copy_(host_edges[s % len(host_edges)], non_blocking=True)
+            uploaded[s & 1].record(copy_stream)
+
+    def loop(n):
+        pending = None
+        upload(0)
+        for s in range(n):
+            if s + 1 < n:
+                upload(s + 1)
+            cur.wait_event(uploaded[s & 1])
+            queued = run_step(slots[s & 1], s)
+            consumed[s & 1].record(cur)
+            if pending is not None:
+                finish(*pending)
+            pending = queued
+        finish(*pending)
+    loop(6)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    loop(steps)
+    torch.cuda.synchronize()
+    return B * steps / (time.perf_counter() - t1)
 
 
 def bench_studies():
@@ -892,6 +1045,22 @@ def gather_rank_records(dist, world, rank, dev, elapsed_local, kernel_ms, backen
     return recs
 
 
+def require_distinct_devices(rank_records, world, backend):
+    """The first multi-GPU run must not be able to lie: under RCCL ("nccl": one rank per GPU is the whole point) every rank has to
+    report a device of its own.  Ranks that share one -- a launcher that did not set LOCAL_RANK, HIP_VISIBLE_DEVICES pinning every rank
+    to device 0 -- would still print a line, with a `value` N times too good to be true for N GPUs' worth of hardware: every rank
+    (they all hold the all-gathered records) ends with exit code 3 instead.  The gloo rehearsal on ONE GPU (SUBGACC_DIST_BACKEND=gloo
+    SUBGACC_SHARE_GPU=1) is the stated exception."""
+    if world <= 1 or backend != "nccl":
+        return
+    devs = [r["device"] for r in rank_records]
+    if len(rank_records) != world or len(set(devs)) != world:
+        dup = sorted({d for d in devs if devs.count(d) > 1})
+        print(f"bench.py: {world} ranks over nccl but {len(set(devs))} distinct device(s) in {len(rank_records)} rank record(s); shared: "
+              f"{dup[:2]} -- one rank per GPU is required (LOCAL_RANK / visible devices?)", file=sys.stderr, flush=True)
+        sys.exit(3)
+
+
 def flatten(out):
     """The driver keeps the SCALAR keys of `config` (names cut at 40 characters) and drops everything nested: every number
     DESIGN.md quotes is therefore promoted to a scalar key here; the nested blocks stay for whoever reads the full line."""
@@ -908,7 +1077,7 @@ def flatten(out):
         put("headline_min_of_3_x100", min(rv[1:]))
         put("headline_max_of_3_x100", max(rv[1:]))
     for name, short in (("cit2 (rng=rand_r: the reference's own stream, bit-exact mode)", "rand_r"), ("cit2m4", "cit2m4"), ("collab", "collab"),
-                        ("ppa", "ppa"), ("twitter", "twitter"), ("cit2ppr", "cit2ppr")):
+                        ("ppa", "ppa"), ("twitter", "twitter"), ("cit2ppr", "cit2ppr"), ("cit2ppr_packed", "pprpk"), ("cit2loc", "cit2loc")):
         o = (c.get("other_workloads") or {}).get(name) or {}
         put(f"{short}_pairs_per_s", o.get("value"))             # the MEDIAN of three regions of >= 100 steps
         put(f"{short}_pairs_per_s_min", (o.get("config") or {}).get("pairs_per_s_min"))
@@ -977,12 +1146,17 @@ def flatten(out):
     put("offline_J_b1024_many64_pairs_per_s", (jb.get("many_64") or {}).get("pairs_per_s"))
     if "failed" in jb:
         put("offline_J_b1024_failed", str(jb["failed"])[:200])
+    put("S_offline_roots_per_s", f.get("S_roots_per_s"))              # SURVEY 8(d)'s triple under the names the round-5 review asked for
+    put("J_resident_pairs_per_s", f.get("J_pairs_per_s_table_store"))
+    put("Q_formula_pairs_per_s", f.get("Q_formula_pairs_per_s"))
+    put("Q_amortised_1e8_pairs_per_s", f.get("Q_amortised_at_1e8_pairs_table"))
     put("offline_all_N_ms", f.get("all_N_sample_to_resident_spg_ms"))
     put("offline_all_N_4hop_ms", f.get("all_N_4hop_sample_to_resident_spg_ms"))
     put("offline_4hop_roots_per_s", f.get("all_N_4hop_roots_per_s"))
     put("offline_S_roots_per_s", f.get("S_roots_per_s"))
     put("offline_J_table_pairs_per_s", f.get("J_pairs_per_s_table_store"))
     put("offline_J_keyed_pairs_per_s", f.get("J_pairs_per_s_keyed_store"))
+    put("offline_J_keyed_aligned_pairs_per_s", f.get("J_pairs_per_s_keyed_aligned_store"))
     put("offline_Q_1e8_table_pairs_per_s", f.get("Q_amortised_at_1e8_pairs_table"))
     put("offline_Q_1e8_keyed_pairs_per_s", f.get("Q_amortised_at_1e8_pairs_keyed"))
     fc = f.get("cpu_baseline") or {}
@@ -1019,17 +1193,24 @@ def flatten(out):
 LINE_LIMIT = 6000
 TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
             "dtype", "data")
-CONFIG_KEYS = ("workload", "pairs_per_step_per_gpu", "roots_per_step_per_gpu", "pairs_per_step_all_gpus", "ranks_seen",
-               "distinct_devices", "dist_backend", "rccl_version", "rng", "num_walks", "num_steps_cli", "parallelism",
-               "per_rank_ms_min", "per_rank_ms_max", "headline_median_of_3_x100", "join_frac", "fused_spg_rows",
-               # BASELINE.json's other configurations (medians of 3 x 100 steps) and the bit-exact rand_r stream on the headline one
-               "rand_r_pairs_per_s", "rand_r_frac", "cit2m4_pairs_per_s", "cit2m4_frac", "cit2m4_join_frac",
-               "collab_pairs_per_s", "collab_frac", "collab_join_frac", "ppa_pairs_per_s", "ppa_frac", "ppa_join_frac",
-               "twitter_pairs_per_s", "twitter_frac", "twitter_join_frac", "cit2ppr_pairs_per_s", "cit2ppr_frac",
-               "cit2ppr_frac_whole_join_call", "two_stream_pairs_per_s", "collab_cpu_pairs_per_s",
+CONFIG_KEYS = ("workload", "pairs_per_step_per_gpu", "ranks_seen", "distinct_devices", "rng",
+               # the driver keeps the FIRST 24 keys of `config` (BENCH_r05: three BASELINE configurations fell off the end).  So, in this order:
+               # BASELINE.json's configs[0..4] -- collab on the CPU (the compiled reference), collab / ppa / cit2-PPR / twitter on the GPU, each
+               # with its walk and join fractions of the HBM peak (medians of 3 x 100 steps) --, then SURVEY 8(d)'s S / J / Q on the
+               # reference's own flow, the host-fed loop, the graph with id locality.  tests/test_bench_line_cpu.py asserts the POSITIONS.
+               "collab_cpu_pairs_per_s", "collab_pairs_per_s", "collab_frac", "collab_join_frac",
+               "ppa_pairs_per_s", "ppa_frac", "ppa_join_frac",
+               "cit2ppr_pairs_per_s", "cit2ppr_frac", "cit2ppr_frac_whole_join_call",
+               "twitter_pairs_per_s", "twitter_frac", "twitter_join_frac",
+               "S_offline_roots_per_s", "J_resident_pairs_per_s", "Q_formula_pairs_per_s", "Q_amortised_1e8_pairs_per_s",
+               "host_fed_pairs_per_s", "cit2loc_pairs_per_s",
+               # ---- beyond the driver's 24: the line still carries them (and bench_detail.json everything)
+               "cit2loc_frac", "pprpk_pairs_per_s", "pprpk_frac", "offline_J_keyed_aligned_pairs_per_s", "cit2m4_pairs_per_s", "cit2m4_frac", "cit2m4_join_frac", "headline_median_of_3_x100",
+               "rand_r_pairs_per_s", "rand_r_frac", "two_stream_pairs_per_s", "rccl_version",
                # seam A alone: random_walks.py:77-81 verbatim over the drop-in module, all N collab roots (shim = inside gset_sampler)
                "collab_literal_dropin_roots_per_s", "collab_dropin_shim_roots_per_s", "collab_literal_ref_roots_per_s",
                "detail")
+DRIVER_KEEPS = 24       # config keys the driver's record keeps
 ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "launches_timed",
                  "algorithmic_bytes_per_launch", "join_kernel_ms", "join_algorithmic_bytes_per_launch", "join_frac", "join_traffic",
                  "line_roof_lines_per_s", "line_roof_frac", "l2_miss_lines_per_launch")
@@ -1058,7 +1239,7 @@ def compact_line(out):
         line["cpu_baseline"] = {k_: _short(out["cpu_baseline"].get(k_)) for k_ in CPU_KEYS if k_ in out["cpu_baseline"]}
     text = json.dumps(line)
     if len(text) > LINE_LIMIT:         # cannot happen with the key lists above; if it ever does, keep the contract and say so
-        line["config"] = {k_: line["config"][k_] for k_ in CONFIG_KEYS[:12] if k_ in line["config"]}
+        line["config"] = {k_: line["config"][k_] for k_ in CONFIG_KEYS[:DRIVER_KEEPS] if k_ in line["config"]}
         line["config"]["truncated"] = True
         text = json.dumps(line)
     assert len(text) <= LINE_LIMIT, len(text)
@@ -1095,7 +1276,7 @@ _T0 = time.perf_counter()
 def summary(o):
     """what an `other_workloads` entry keeps of a full line"""
     keep = {k_: o[k_] for k_ in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype")}
-    keep["config"] = {k_: o["config"].get(k_) for k_ in ("workload", "pairs_per_step_per_gpu", "rng", "set_members_last_step", "device_allocs_in_timed_region", "host_step_ms_min_median_max",
+    keep["config"] = {k_: o["config"].get(k_) for k_ in ("workload", "pairs_per_step_per_gpu", "rng", "store_layout", "store_bytes", "store_bytes_packed", "set_members_last_step", "device_allocs_in_timed_region", "host_step_ms_min_median_max",
                                                          "distinct_lp_rows_last_step", "xz_rows_last_step", "graph_nnz", "spg_layout", "stage_ms", "two_stream_loop", "dedup_roots_loop", "spg_members",
                                                          "timed_loop", "region_pairs_per_s", "pairs_per_s_min", "pairs_per_s_median", "pairs_per_s_max",
                                                          "offline_ppr_stage_s", "join_call_ms", "join_call_ms_steady",
@@ -1172,7 +1353,8 @@ def main():
                      f"value = pairs / max-over-ranks time honest)")
     t_start = time.perf_counter()
     if WORKLOADS[args.workload][0] is None:
-        out = bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, WORKLOADS[args.workload][3], B, K, W)
+        out = bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, WORKLOADS[args.workload][3], B, K, W,
+                        layout=os.environ.get("SUBGACC_PPR_LAYOUT", "aligned"))
     else:
         out = bench_lp(args, args.workload, args.rng, B, K, W, sp, sampler_mod, dev, rank, world, dist,
                        with_cpu_baseline=(world == 1 and not args.no_cpu_baseline),
@@ -1184,6 +1366,8 @@ def main():
                        two_stream_extra=not args.no_others, dedup_extra=args.full,
                        csr_variant=args.full,                    # ... and no pass with the packed-CSR (table rows) variant
                        offline=(rank == 0 and world == 1 and args.full and args.scale == 1.0),
+                       ref_flow=(rank == 0 and world == 1 and not args.no_others and args.scale == 1.0 and not args.workload.startswith("twitter")),
+                       host_fed=not args.no_others,
                        # the driver's K steps are the headline region; three regions of 100 steps follow, outside its clock
                        extra_regions=((3, 100) if (world == 1 and not args.no_others) else (0, 0)))
     if rank == 0 and out is not None:
@@ -1197,7 +1381,8 @@ def main():
         for key, (wl, rng_o) in {"cit2 (rng=rand_r: the reference's own stream, bit-exact mode)": ("cit2", "rand_r"),
                                  "cit2m4": ("cit2m4", "philox"),
                                  "collab": ("collab", "philox"), "ppa": ("ppa", "philox"),
-                                 "cit2ppr": ("cit2ppr", "philox"), "twitter": ("twitter", "philox")}.items():
+                                 "cit2ppr": ("cit2ppr", "philox"), "cit2ppr_packed": ("cit2ppr", "packed"),
+                                 "cit2loc": ("cit2loc", "philox"), "twitter": ("twitter", "philox")}.items():
             if time.perf_counter() - t_start > budget_s:
                 others[key] = {"skipped": f"time budget of {budget_s:.0f} s for the whole run reached"}
                 continue
@@ -1211,8 +1396,9 @@ def main():
                     time.sleep(1.0)
                 # every pass: three regions of 100 steps (>= 40 ms each; the join-only PPR pass 300), the MEDIAN is its value
                 Ko, Wo = 100, 3
-                if WORKLOADS[wl][0] is None:
-                    o = bench_ppr(args, sp, sampler_mod, dev, 0, 1, None, WORKLOADS[wl][3], B, 300, Wo, extra_regions=2)
+                if WORKLOADS[wl][0] is None:     # the PPR store: the serving layout (rows on whole lines), then the packed CSR as rounds 1-5 joined it
+                    o = bench_ppr(args, sp, sampler_mod, dev, 0, 1, None, WORKLOADS[wl][3], B, 300, Wo, extra_regions=2,
+                                  layout="packed" if rng_o == "packed" else "aligned")
                 else:
                     o = bench_lp(args, wl, rng_o, B, Ko, Wo, sp, sampler_mod, dev, 0, 1, None,
                                  with_cpu_baseline=(wl == "collab" and not args.no_cpu_baseline), csr_variant=False,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SUBGACC_ABI_VERSION 6
+#define SUBGACC_ABI_VERSION 7
 
 typedef enum subgacc_status {
     SUBGACC_OK = 0,
@@ -250,13 +250,21 @@ int subgacc_sjoin_sizes_rows(const int32_t *row_len, int64_t n_rows, const int64
 
 /* ABI 6 -- ONE entry point fills the R = out_seg[S] rows of every form of the join: the descriptor states what the store looks
  * like, what a member's payload is, which segments to join and which outputs are wanted; subgacc_sjoin_fill_v2 dispatches.
+ * (ABI 7: it is the ONLY fill entry point -- the seven per-form entry points of ABI 1-5, forwards since ABI 6, are gone.)
  *
- *   store      row_off [n_rows+1] (packed rows: the SpG of random_walks.py:79) XOR row_len [n_rows] + row_stride (strided rows: the
- *              form subgacc_walk_spg leaves a transient batch in -- row r = [r*row_stride, +row_len[r]) -- joined where they lie, no
- *              packed copy); ids: member ids, ascending inside a row; max_len >= the longest row touched (packed rows; a longer row
- *              sets flags[3] |= 1 and its segment is skipped; strided rows: row_stride is the bound).  Mirrored lists of rows that
- *              do not fit LDS (~13k members) and lists that are not mirrored take a one-segment-per-wave kernel; rows beyond that
- *              (~20k int / ~13k float members) are searched in place.
+ *   store      exactly one of three row layouts.  PACKED rows: row_off [n_rows+1] (the SpG of random_walks.py:79).  STRIDED rows:
+ *              row_len [n_rows] + row_stride (the form subgacc_walk_spg leaves a transient batch in -- row r = [r*row_stride,
+ *              +row_len[r]) -- joined where they lie, no packed copy).  HEADED rows (ABI 7; row_off = row_len = NULL, row_stride > 1):
+ *              a RESIDENT store on whole 128-byte lines (subgacc_rows_to_headed writes it; row_stride a multiple of 32) -- slot 0 of
+ *              row r's ids, ids[r*row_stride], holds the row's LENGTH, its members follow at ids[r*row_stride + 1 + t], member t's
+ *              payload is payload[r*row_stride + t]: a row needs no row pointer (its place is r*row_stride, its length arrives
+ *              with its first members), begins on a line and ends inside its own last one -- what a packed store reads beyond
+ *              the algorithmic bytes (rows that begin and end inside lines, a line per row pointer) is gone, for row_stride /
+ *              (mean length) of its size.  ids: member ids, ascending inside a row; max_len >= the longest row touched (packed
+ *              rows; a longer row sets flags[3] |= 1 and its segment is skipped; strided rows: row_stride is the bound, headed
+ *              rows: row_stride - 1).  Mirrored lists of rows that do not fit LDS (~13k members) and lists that are not mirrored
+ *              take a one-segment-per-wave kernel (packed rows only); rows beyond that (~20k int / ~13k float members) are
+ *              searched in place.
  *   payload    SUBGACC_JOIN_SFPTR  int32: SFptr+1 (packed rows) or a slot of `uniq_table` (strided rows: slots become SFptr+1 through
  *                                  the numbered table's id plane on their way in; uniq_table = NULL: `table` is indexed by slot+1
  *                                  itself, subgacc_unpack_lp(zero_row = 1)); feature rows are gathered from table f32 [table_rows, k]
@@ -268,7 +276,7 @@ int subgacc_sjoin_sizes_rows(const int32_t *row_len, int64_t n_rows, const int64
  *                                  subgacc_unpack_lp writes into the feature table, computed on the fly (main.py:174's IEEE division);
  *                                  partner absent = the zero row.  Needs num_steps*SHIFT+1 <= 31.  Packed rows: a store re-keyed once
  *                                  (SpG.keyed); strided rows: what subgacc_walk_spg(uniq_table = NULL) writes
- *              SUBGACC_JOIN_KEY64  uint64 LP key: the strided rows of subgacc_walk_keyrows64 (4 hops, 32..63 bits)
+ *              SUBGACC_JOIN_KEY64  uint64 LP key: the strided rows of subgacc_walk_keyrows64 (4 hops, 32..63 bits); strided / headed rows
  *   segments   own / partner [S], seg [S+1] from subgacc_sjoin_sizes(_rows); pair_block = 0: independent segments (SFPTR / F64, packed
  *              rows); pair_block = P > 0: blocks of P segments, block 2t+1 mirrors block 2t (own / partner swapped) -- gather passes
  *              P = B, hgather P = B, nb batches at once P = B -- the two rows of a pair are read once and both blocks produced from
@@ -292,6 +300,9 @@ int subgacc_sjoin_sizes_rows(const int32_t *row_len, int64_t n_rows, const int64
  *              nor a copy behind it.  size_state: subgacc_sjoin_workspace_bytes(S) bytes of device memory the caller zeroes ONCE, when allocating
  *              it: every call leaves it zeroed again (a single-pass scan keeps its ticket and one word per tile there); one
  *              state serves one join at a time (calls on one stream; one state per stream otherwise).
+ *              With NO output (out_xz = out_idx = NULL) the call is the size pass alone: out_seg and host_tail are written and
+ *              nothing else -- the "count" half of a two-call pattern (then: allocate R rows, call again with seg = that out_seg
+ *              and without the option) for callers that do not hold a worst-case buffer.
  *   struct_bytes = sizeof(subgacc_join_desc): a descriptor of another size is refused (SUBGACC_ERR_BADARG); fields a form does not
  *   read must be zero / NULL. */
 enum { SUBGACC_JOIN_SFPTR = 0, SUBGACC_JOIN_F64 = 1, SUBGACC_JOIN_KEY32 = 2, SUBGACC_JOIN_KEY64 = 3 };
@@ -326,26 +337,13 @@ typedef struct subgacc_join_desc {
 } subgacc_join_desc;
 int subgacc_sjoin_fill_v2(const subgacc_join_desc *d, void *stream);
 
-/* The entry points of ABI 1-5 for the same joins: forwards that fill in a descriptor (a client built against them keeps working;
- * new clients need subgacc_sjoin_fill_v2 only).  In the order: packed SFPTR / F64 rows; strided SFPTR rows; the count form; the
- * pair form (key payloads: further down, with the walk entry points that write them). */
-int subgacc_sjoin_fill(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices, const int32_t *spg_data_i32,
-                       const double *spg_data_f64, const int64_t *own, const int64_t *partner, int64_t S,
-                       const int64_t *seg, const float *table, int64_t table_rows, int32_t k, float *out_xz,
-                       int32_t *out_idx, int64_t *out_segid, int32_t max_len, int64_t pair_block, int32_t *flags,
-                       void *stream);
-int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids, const int32_t *row_slot,
-                            const void *uniq_table, int64_t uniq_capacity, const int64_t *own, const int64_t *partner,
-                            int64_t S, const int64_t *seg, const float *table, int64_t table_rows, int32_t k,
-                            float *out_xz, int32_t *out_idx, int64_t *out_segid, int64_t pair_block, int32_t *flags,
-                            void *stream);
-int subgacc_sjoin_counts(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices, const int32_t *spg_data_i32,
-                         const int64_t *own, const int64_t *partner, int64_t S, int64_t table_rows, float *out_counts,
-                         int32_t max_len, int64_t pair_block, int32_t *flags, void *stream);
-int subgacc_sjoin_pairs(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices, const int32_t *spg_data_i32,
-                        const int64_t *own, const int64_t *partner, int64_t S, const int64_t *seg, int32_t *out_pairs,
-                        int32_t *out_mult, int32_t *out_cnt, int32_t max_len, int64_t pair_block, int32_t *flags,
-                        void *stream);
+
+/* Packed rows -> headed rows (ABI 7): the resident store of a serving loop laid out on whole lines.  row_off [n+1], ids, payload
+ * (payload_bytes = 4: SFptr+1 / 32-bit keys, 8: PPR scores / 64-bit keys) as SpG holds them; out_ids [n*row_stride] int32 and
+ * out_payload [n*row_stride] of the same element size, row_stride >= (longest row) + 1 (a longer row is cut and flags[3] |= 1), a
+ * multiple of 32 for rows on whole 128-byte lines.  Slots behind a row's members are left as they are. */
+int subgacc_rows_to_headed(const int64_t *row_off, int64_t n_rows, const int32_t *ids, const void *payload, int32_t payload_bytes,
+                           int64_t row_stride, int32_t *out_ids, void *out_payload, int32_t *flags, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Top-K approximate-PPR node sets -- replaces sampler/pprgo.py:9-38 (_calc_ppr_node, the
@@ -420,6 +418,9 @@ int subgacc_walk_join(const int32_t *walks, int64_t n, int32_t stride, const int
  * subgacc_walk_spg with uniq_table = NULL writes the member's 32-bit LP key itself as the row's payload (needs
  * num_steps*SHIFT+1 <= 31, 2 to 4 hops, set_sampler order, no bucket, M <= 256: SUBGACC_ERR_BADARG otherwise); such rows are
  * joined with payload SUBGACC_JOIN_KEY32 (subgacc_join_desc): same (xz, seg) as the table path, sizes by subgacc_sjoin_sizes_rows.
+ * A PACKED store whose payload was re-keyed once (SpG.keyed) is joined the same way: for the reference's flow -- subg_matrix over all
+ * nodes once, main.py:172-178, then one join per training batch, train.py:120-127 -- that takes the gather from the Z_SF table out of
+ * every output row; xz is bit-identical to the SFPTR join with table = float32(enc) / num_walks, main.py:174.
  *
  * ABI 5 -- key rows for the 4-hop configurations.  The paper's sampler figure is citation2 with m = 4, M = 200 (Fig. 6a): its LP
  * key -- the reference's 64-bit `bithash`, subg_acc.c:900-955 -- takes 4 x 8 + 1 = 33 bits.  subgacc_walk_spg(uniq_table = NULL)
@@ -434,23 +435,6 @@ int subgacc_walk_keyrows64(const subgacc_walk_cfg *cfg, const void *indptr, cons
                            const int32_t *query, int64_t n, const uint32_t *rng_pos, const uint32_t *rng_seed,
                            const int32_t *worklist, const int64_t *n_work, int32_t *row_ids, uint64_t *row_keys,
                            int32_t *nsize, int32_t *flags, void *stream);
-/* The key joins of ABI 3-5: forwards to subgacc_sjoin_fill_v2 -- strided rows of 32-bit keys, of 64-bit keys, and a PACKED store
- * whose payload was re-keyed once (for the reference's flow -- subg_matrix over all nodes once, main.py:172-178, then one join per
- * training batch, train.py:120-127 -- that takes the gather from the Z_SF table out of every output row: xz is bit-identical to the
- * SFPTR join with table = float32(enc) / num_walks, main.py:174). */
-int subgacc_sjoin_fill_keyrows(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
-                               const int32_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
-                               const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz, int64_t pair_block,
-                               int32_t *flags, void *stream);
-int subgacc_sjoin_fill_keyrows64(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
-                                 const uint64_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
-                                 const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz, int64_t pair_block,
-                                 int32_t *flags, void *stream);
-int subgacc_sjoin_fill_keys(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices, const int32_t *spg_keys,
-                            const int64_t *own, const int64_t *partner, int64_t S, const int64_t *seg, int32_t num_walks,
-                            int32_t num_steps, float *out_xz, int64_t *out_segid, int32_t max_len, int64_t pair_block,
-                            int32_t *flags, void *stream);
-
 /* ---------------------------------------------------------------------------------------------
  * Prologue of one on-demand step (sample both endpoints of B query pairs -> rows -> SpJoin; train.py:120-127 calls the
  * join once per batch of main.py:32's 1,024 pairs) in ONE launch: subgacc_uniq_reset of the table of distinct LP rows,

@@ -8,7 +8,7 @@ Host mirror of the reference's interfaces over a C-ABI HIP library (include/subg
 """
 from ._lib import SubgAccError, build  # noqa: F401
 from .sampler import DeviceCSR, SampledSets, sample_sets  # noqa: F401
-from .spg import SpG, StridedSpG, np_sampling, rw_matrix, sample_spg, subg_matrix  # noqa: F401
+from .spg import HeadedSpG, SpG, StridedSpG, np_sampling, rw_matrix, sample_spg, subg_matrix  # noqa: F401
 from .spjoin import (attn_stage, bgather, gather, gather_counts, gather_index, gather_many, gather_pairs, hgather, hgather_many, lstm_stage,  # noqa: F401
                      mean_stage, pgather, sample_and_gather, sample_and_gather_many, sjoin, split_batches, StepBuffers)
 from .subg_acc import batch_sampler, gset_sampler, walk_join, walk_sampler  # noqa: F401

@@ -7,6 +7,7 @@ same condition (subg_acc/subg_acc.c:658, :688-721, :905-915).
 import ctypes as C
 import os
 import subprocess
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SUBGACC_LIB (dev-only): load an experiment build from elsewhere (tools/ab_*.sh) -- the shipped library is never overwritten
@@ -26,15 +27,15 @@ SYMBOLS = (
     "subgacc_uniq_table_bytes", "subgacc_uniq_reset", "subgacc_uniq_insert",
     "subgacc_uniq_number_workspace_bytes", "subgacc_uniq_number", "subgacc_uniq_translate", "subgacc_unpack_lp",
     "subgacc_spg_build",
-    "subgacc_sjoin_workspace_bytes", "subgacc_sjoin_sizes", "subgacc_sjoin_fill", "subgacc_sjoin_counts",
+    "subgacc_sjoin_workspace_bytes", "subgacc_sjoin_sizes",
     "subgacc_ppr_slab_bytes", "subgacc_ppr_slab_reset", "subgacc_ppr_topk", "subgacc_ppr_normalize", "subgacc_ppr_encode",
-    "subgacc_walk_join", "subgacc_sjoin_sizes_rows", "subgacc_sjoin_fill_rows",
-    "subgacc_encode_sizes", "subgacc_encode_fill", "subgacc_sjoin_pairs", "subgacc_finish_rows",
+    "subgacc_walk_join", "subgacc_sjoin_sizes_rows",
+    "subgacc_encode_sizes", "subgacc_encode_fill", "subgacc_finish_rows",
     "subgacc_batch_sampler_workspace_bytes", "subgacc_batch_sampler", "subgacc_step_prologue",
-    "subgacc_hop_records_format", "subgacc_hop_records_build", "subgacc_sjoin_fill_keyrows", "subgacc_sjoin_fill_keys", "subgacc_step_dedup_workspace_bytes",
+    "subgacc_hop_records_format", "subgacc_hop_records_build", "subgacc_step_dedup_workspace_bytes",
     "subgacc_step_prologue_dedup", "subgacc_walk_spg_sparse",
-    "subgacc_keyrows_register", "subgacc_keyrows_cand_capacity", "subgacc_walk_tags", "subgacc_keyrows_compact", "subgacc_keyrows_translate", "subgacc_rng_replay", "subgacc_walk_keyrows64", "subgacc_sjoin_fill_keyrows64", "subgacc_worklist_workspace_bytes", "subgacc_worklist_by_root", "subgacc_walk_spg_list",
-    "subgacc_sjoin_fill_v2", "subgacc_publish_words",
+    "subgacc_keyrows_register", "subgacc_keyrows_cand_capacity", "subgacc_walk_tags", "subgacc_keyrows_compact", "subgacc_keyrows_translate", "subgacc_rng_replay", "subgacc_walk_keyrows64", "subgacc_worklist_workspace_bytes", "subgacc_worklist_by_root", "subgacc_walk_spg_list",
+    "subgacc_sjoin_fill_v2", "subgacc_publish_words", "subgacc_rows_to_headed",
 )
 
 
@@ -119,9 +120,7 @@ def lib():
         "subgacc_spg_build": (C.c_int, [vp, i64, vp, vp, vp, i64, i32, vp, vp, vp, vp]),
         "subgacc_sjoin_workspace_bytes": (sz, [i64]),
         "subgacc_sjoin_sizes": (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, sz, vp]),
-        "subgacc_sjoin_fill": (C.c_int, [vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, i32, i64, vp, vp]),
     }
-    sig["subgacc_sjoin_counts"] = (C.c_int, [vp, i64, vp, vp, vp, vp, i64, i64, vp, i32, i64, vp, vp])
     f32 = C.c_float
     sig["subgacc_ppr_slab_bytes"] = (sz, [i32, i32])
     sig["subgacc_ppr_slab_reset"] = (C.c_int, [vp, i32, i32, vp])
@@ -131,8 +130,6 @@ def lib():
     sig["subgacc_walk_join"] = (C.c_int, [vp, i64, i32, vp, vp, vp, i32, vp, i64, vp, vp])
     sig["subgacc_hop_records_format"] = (C.c_int, [i64, i64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)])
     sig["subgacc_hop_records_build"] = (C.c_int, [vp, i32, vp, i64, i64, i32, i32, vp, vp])
-    sig["subgacc_sjoin_fill_keyrows"] = (C.c_int, [vp, i64, i64, vp, vp, vp, vp, i64, vp, i32, i32, vp, i64, vp, vp])
-    sig["subgacc_sjoin_fill_keys"] = (C.c_int, [vp, i64, vp, vp, vp, vp, i64, vp, i32, i32, vp, vp, i32, i64, vp, vp])
     sig["subgacc_step_dedup_workspace_bytes"] = (C.c_size_t, [i64])
     sig["subgacc_step_prologue_dedup"] = (C.c_int, [vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, C.c_size_t, vp, vp])
     sig["subgacc_walk_spg_sparse"] = (C.c_int, [cfgp, vp, vp, i64, vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, vp])
@@ -140,10 +137,8 @@ def lib():
     sig["subgacc_batch_sampler_workspace_bytes"] = (sz, [i64])
     sig["subgacc_batch_sampler"] = (C.c_int, [vp, i32, vp, i64, vp, i64, i32, i32, i32, C.c_uint32, vp, i64, vp, vp, sz, vp, vp])
     sig["subgacc_sjoin_sizes_rows"] = (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, sz, vp])
-    sig["subgacc_sjoin_fill_rows"] = (C.c_int, [vp, i64, i64, vp, vp, vp, i64, vp, vp, i64, vp, vp, i64, i32, vp, vp, vp, i64, vp, vp])
     sig["subgacc_encode_sizes"] = (C.c_int, [vp, vp, i64, vp, i32, vp, i32, vp, vp, vp])
     sig["subgacc_encode_fill"] = (C.c_int, [vp, vp, vp, i64, i32, vp, i32, vp, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp])
-    sig["subgacc_sjoin_pairs"] = (C.c_int, [vp, i64, vp, vp, vp, vp, i64, vp, vp, vp, vp, i32, i64, vp, vp])
     sig["subgacc_finish_rows"] = (C.c_int, [vp, vp, vp, i64, i32, i64, vp, i64, vp, vp, vp])
     sig["subgacc_keyrows_register"] = (C.c_int, [vp, vp, i64, i32, i64, vp, i64, vp, i64, vp, vp, vp])
     sig["subgacc_keyrows_cand_capacity"] = (i64, [i64])
@@ -151,19 +146,19 @@ def lib():
     sig["subgacc_keyrows_compact"] = (C.c_int, [vp, vp, vp, vp, i64, i32, i64, vp, i64, vp, vp, i64, vp, vp, vp, i64, vp, vp, vp])
     sig["subgacc_keyrows_translate"] = (C.c_int, [vp, i64, vp, vp, i64, vp, vp, i64, vp])
     sig["subgacc_walk_keyrows64"] = (C.c_int, [cfgp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp])
-    sig["subgacc_sjoin_fill_keyrows64"] = (C.c_int, [vp, i64, i64, vp, vp, vp, vp, i64, vp, i32, i32, vp, i64, vp, vp])
     sig["subgacc_rng_replay"] = (C.c_int, [cfgp, vp, vp, i64, vp, i64, i32, u64, vp, vp, vp, vp])
     sig["subgacc_worklist_workspace_bytes"] = (sz, [i64])
     sig["subgacc_worklist_by_root"] = (C.c_int, [vp, i64, i64, vp, vp, vp, sz, vp])
     sig["subgacc_walk_spg_list"] = (C.c_int, [cfgp, vp, vp, i64, vp, i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp])
     sig["subgacc_sjoin_fill_v2"] = (C.c_int, [C.POINTER(JoinDesc), vp])
     sig["subgacc_publish_words"] = (C.c_int, [vp, i64, vp, vp])
+    sig["subgacc_rows_to_headed"] = (C.c_int, [vp, i64, vp, vp, i32, i64, vp, vp, vp, vp])
     assert set(sig) == set(SYMBOLS)
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
-    if L.subgacc_abi_version() != 6:
+    if L.subgacc_abi_version() != 7:
         raise SubgAccError("libsubgacc_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -221,15 +216,20 @@ def publish(src, host):
 
 
 _KEPT = []
+_KEPT_LOCK = threading.Lock()
 
 
 def keep_until(event, obj):
     """`obj` (the pinned buffer a publish() kernel writes) stays alive until `event` -- recorded behind that kernel -- has passed,
     even if its owner is dropped first: torch's host allocator knows nothing of a kernel that writes pinned memory and would hand
-    the block to somebody else.  (Finished entries leave when the next one arrives.)"""
-    while _KEPT and _KEPT[0][0].query():
-        _KEPT.pop(0)
-    _KEPT.append((event, obj))
+    the block to somebody else.  (Finished entries leave when the next one arrives.)
+    Called from every thread that queues steps (the reference's loader runs four, train.py:88-111): look-then-pop on the shared list
+    is one critical section -- without the lock a second thread could pop the entry BEHIND the finished one the first had seen,
+    i.e. drop a block a kernel is still going to write.  Entries are queued by different streams, so a finished one may stand behind
+    an unfinished one: every finished entry leaves, wherever it stands."""
+    with _KEPT_LOCK:
+        _KEPT[:] = [(ev, o) for ev, o in _KEPT if not ev.query()]
+        _KEPT.append((event, obj))
 
 
 _READBACK_COPY = False      # True: torch's asynchronous copy instead (how the A/B of profiles/r25_readback_ab.log was run)

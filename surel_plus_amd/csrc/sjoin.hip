@@ -36,12 +36,17 @@ struct SegLen {
     const int64_t *own, *partner;
     int32_t *flags;
     int64_t S;
+    const int32_t *row_head = nullptr;      // headed rows (ABI 7): the length of row r is row_head[r * row_stride]
+    int64_t row_stride = 0;
+    __device__ __forceinline__ int64_t len(int64_t a) const {
+        return row_len ? (int64_t)row_len[a] : (row_head ? (int64_t)row_head[a * row_stride] : indptr[a + 1] - indptr[a]);
+    }
     __device__ __forceinline__ int64_t operator()(int64_t j, bool flag_it) const {
         if (j >= S) return 0;
         const int64_t a = own[j];
         const bool bad = (uint64_t)a >= (uint64_t)n_rows;
         if (flag_it && (bad || (partner && (uint64_t)partner[j] >= (uint64_t)n_rows)) && flags) atomicOr(&flags[3], 16);
-        return bad ? 0 : (row_len ? (int64_t)row_len[a] : indptr[a + 1] - indptr[a]);
+        return bad ? 0 : len(a);
     }
 };
 #ifndef SJ_SEG_ITEMS      // segments per lane of the two size kernels: 2 (131,072 segments = 256 workgroups; 8 per lane left 3/4 of the CUs idle: 17.8 -> 12 us)
@@ -101,7 +106,9 @@ __global__ __launch_bounds__(kScanThreads) void sjoin_seg_scan_kernel(const SegL
 // finished tiles, one word per tile -- all zero when a launch starts; the LAST tile to finish (every other tile is past its
 // look-back by then) zeroes it again, so the caller zeroes it once, when it allocates it.  Tiles take their number from the ticket
 // (a tile only ever waits for tiles that run already); a wait is bounded (kSpinLimit polls, never reached with clean state): a dirty
-// state -- a launch that was torn down half way -- ends in status bit 64 instead of a hang, and is clean again afterwards.
+// state -- a launch that was torn down half way -- ends in status bit 64 instead of a hang (a ticket beyond the tiles, a look-back
+// that gives up).  That is a best-effort detector, not a recovery: with `done` or the tile words dirty the tile that believes it
+// is the last may not be, so after bit 64 the CALLER zeroes the state (CapturedJoin.finish() does) before the next call.
 struct SizeState {
     unsigned long long ticket, done, status, total, pad[4];      // 64 bytes; one word per tile follows
 };
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(kScanThreads) void sjoin_sizes_onepass_kernel(const
                 const int64_t a = L.own[j];
                 const bool oob = (uint64_t)a >= (uint64_t)L.n_rows;
                 bad |= oob || (L.partner && (uint64_t)L.partner[j] >= (uint64_t)L.n_rows);
-                if (!oob) v[k] = L.row_len ? (int64_t)L.row_len[a] : L.indptr[a + 1] - L.indptr[a];
+                if (!oob) v[k] = L.len(a);
             }
             s += v[k];
         }
@@ -201,12 +208,21 @@ __global__ __launch_bounds__(kScanThreads) void sjoin_sizes_onepass_kernel(const
     } else if (tid == 0) {
         atomicOr(&hd->status, 64ull);      // a ticket beyond the tiles: the state was not zero when this launch began
     }
-    // (no fence anywhere: everything one tile learns from another travels through device-scope atomics, which meet at the memory
-    // side; the segment pointers themselves are read by the NEXT kernel only)
+    // Ordering.  Everything one tile learns from another travels through agent-scope atomics on the state's words (the segment
+    // pointers themselves are read by the NEXT kernel only) -- but the state must also be left CLEAN, and that needs an order between
+    // different addresses: every store / OR / exchange this tile made on tile[t], status and total has to be performed before the
+    // finishing tile zeroes those words.  A workgroup barrier alone does not give that (outside tgsplit mode it does not wait for a
+    // lane's global atomics in flight: a late OR could land behind the finishing tile's exchange and leak into the next call -- round
+    // 5 relied on it).  So: every wave drains its own memory operations (s_waitcnt vmcnt(0): gfx9 counts stores and atomics without
+    // return there too), the barrier collects the waves, and only then thread 0 adds to `done` -- with release / acquire semantics at
+    // agent scope, so that the tile which reads gridDim.x - 1 there also has the formal edge: its reads and its zeroing stores come
+    // after everything every other tile did before ITS increment.
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (tid == 0) s_word[0] = atomicAdd(&hd->done, 1ull) == (unsigned long long)gridDim.x - 1;
+    if (tid == 0)
+        s_word[0] = __hip_atomic_fetch_add(&hd->done, 1ull, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)gridDim.x - 1;
     __syncthreads();
-    if (s_word[0]) {       // every other tile is past its look-back and its status: report, and leave the state as it was found
+    if (s_word[0]) {       // every other tile is past its look-back, its status and its total: report, and leave the state as it was found
         if (tid == 0) {
             const unsigned long long st = atomicExch(&hd->status, 0ull);
             const long long total = (long long)atomicExch(&hd->total, 0ull);
@@ -221,9 +237,6 @@ __global__ __launch_bounds__(kScanThreads) void sjoin_sizes_onepass_kernel(const
         for (int i = tid; i < nb; i += kScanThreads) __hip_atomic_store(&tile[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-
-// what subgacc_sjoin_fill_v2 sets around the fill of an OPT_SIZES call (JoinArgs::sized_here)
-static thread_local bool t_sized_here = false;
 
 struct JoinArgs {
     const int64_t *indptr;
@@ -243,12 +256,15 @@ struct JoinArgs {
     // strided rows (subgacc_sjoin_*_rows): row r = [r*row_stride, +row_len[r]) of indices / data, data = table slots
     const int32_t *row_len;
     int64_t row_stride;
+    // headed rows (ABI 7: a resident store on whole 128-byte lines): row r = members [r*row_stride, +row_head[r*row_stride]) of
+    // indices / data, where `indices` points ONE WORD behind row_head -- slot 0 of a row's ids holds its length, its members follow
+    const int32_t *row_head = nullptr;
     // key rows (subgacc_sjoin_fill_keyrows): the rows' payload is the member's 32-bit LP key; a feature row is its unpacked
     // counts / num_walks (lut[c] = float(c) / float(M), built per workgroup), 0xFFFFFFFF = partner absent -> the zero row
     int32_t key_M, key_m, key_shift;
     const int32_t *slot_id;   // slot -> SFptr (id plane of the numbered table of distinct LP rows); NULL with
     int32_t val_add;          // val_add = 1: the feature table is indexed by slot + 1 itself (row 0 = absent)
-    bool sized_here = t_sized_here;   // the segment pointers come from the size pass of this very call: flags[3] & 64 (its state was not
+    bool sized_here = false;  // the segment pointers come from the size pass of this very call: flags[3] & 64 (its state was not
                               // clean, the pointers mean nothing) ends every workgroup before it derives an address from them
     int64_t pb = 0;           // pair_block of a mirrored list: with partner == NULL the partner of segment j is the own row of its mirror
     int32_t split = 1;        // sjoin_pair_kernel: workgroups per pair (small batches: every one stages both rows and emits
@@ -307,9 +323,9 @@ __device__ __forceinline__ void join_row(const JoinArgs &a, int64_t r, int64_t &
         beg = 0, len = 0;
         return;
     }
-    if (a.row_len) {
+    if (a.row_stride) {
         beg = r * a.row_stride;
-        len = a.row_len[r];
+        len = a.row_len ? a.row_len[r] : a.row_head[beg];
     } else {
         beg = a.indptr[r];
         len = a.indptr[r + 1] - beg;
@@ -629,9 +645,9 @@ __global__ __launch_bounds__(NT) void sjoin_keypair_kernel(const JoinArgs a, uin
     int na = 0, nb = 0;
     int32_t idA0 = 0, idB0 = 0;
     Key kA0 = 0, kB0 = 0;
-    if (a.row_len) {       // strided rows: ask for the first NT members of both rows now, for their lengths next
+    if (a.row_stride) {    // strided / headed rows: ask for the first NT members of both rows now, for their lengths next
         ab = ra * a.row_stride, bb = rb * a.row_stride;
-        const bool in = tid < a.row_stride;
+        const bool in = tid < ML;
         if (okA && in) {
             SJ_HOOK_FIRST_TRIP(idA0, kA0, tid) {
                 idA0 = stream_load(&a.indices[ab + tid]);
@@ -644,8 +660,8 @@ __global__ __launch_bounds__(NT) void sjoin_keypair_kernel(const JoinArgs a, uin
                 kB0 = stream_load(&keys[bb + tid]);
             }
         }
-        na = okA ? a.row_len[ra] : 0;
-        nb = okB ? a.row_len[rb] : 0;
+        na = okA ? (a.row_len ? a.row_len[ra] : a.row_head[ab]) : 0;       // (headed: the word in front of the members asked for above)
+        nb = okB ? (a.row_len ? a.row_len[rb] : a.row_head[bb]) : 0;
     } else {
         int64_t na64 = 0, nb64 = 0;
         if (okA) {
@@ -865,13 +881,19 @@ __global__ __launch_bounds__(NT) void sjoin_f64pair_kernel(const JoinArgs a, uin
     const int64_t oA = a.seg[j], oB = a.seg[j2];
     const bool okA = (uint64_t)ra < (uint64_t)a.n_rows, okB = (uint64_t)rb < (uint64_t)a.n_rows;   // else: an empty row, never dereferenced
     int64_t ab = 0, bb = 0, na64 = 0, nb64 = 0;
-    if (okA) {
-        ab = a.indptr[ra];
-        na64 = a.indptr[ra + 1] - ab;
-    }
-    if (okB) {
-        bb = a.indptr[rb];
-        nb64 = a.indptr[rb + 1] - bb;
+    if (a.row_stride) {        // strided / headed rows: no row pointer to wait for, the length is a row's own first word
+        ab = ra * a.row_stride, bb = rb * a.row_stride;
+        if (okA) na64 = a.row_len ? a.row_len[ra] : a.row_head[ab];
+        if (okB) nb64 = a.row_len ? a.row_len[rb] : a.row_head[bb];
+    } else {
+        if (okA) {
+            ab = a.indptr[ra];
+            na64 = a.indptr[ra + 1] - ab;
+        }
+        if (okB) {
+            bb = a.indptr[rb];
+            nb64 = a.indptr[rb + 1] - bb;
+        }
     }
     if (na64 > ML || nb64 > ML) {
         if (tid == 0) atomicOr(&a.flags[3], 1);
@@ -1292,6 +1314,7 @@ static int join_sizes_onepass(const subgacc_join_desc *d, hipStream_t s) {
     SG_REQUIRE(d->size_state && (size_t)d->size_state_bytes >= onepass_state_bytes(d->S), SUBGACC_ERR_WORKSPACE,
                "sjoin_fill_v2: size_state too small (subgacc_sjoin_workspace_bytes(S) bytes, zeroed once)");
     SegLen L{d->row_off, d->row_len, d->n_rows, d->own, d->partner, d->flags, d->S};
+    if (!d->row_off && !d->row_len) L.row_head = d->ids, L.row_stride = d->row_stride;      // headed rows
     hipLaunchKernelGGL(sjoin_sizes_onepass_kernel<kOnePassItems>, dim3((unsigned)nb), dim3(kScanThreads), 0, s, L, d->out_seg,
                        (unsigned long long *)d->size_state, d->host_tail, (int)nb);
     SG_LAUNCH_CHECK();
@@ -1343,124 +1366,10 @@ static int launch_table_pairs(JoinArgs &a, int64_t S, int64_t pair_block, bool v
     return SUBGACC_OK;
 }
 
-static int sjoin_fill_impl(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,
-                                  const int32_t *spg_data_i32, const double *spg_data_f64, const int64_t *own, const int64_t *partner, int64_t S,
-                                  const int64_t *seg, const float *table, int64_t table_rows, int32_t k,
-                                  float *out_xz, int32_t *out_idx, int64_t *out_segid, int32_t max_len,
-                                  int64_t pair_block, int32_t *flags, void *stream) {
-    SG_REQUIRE(S >= 0 && max_len >= 0 && flags && n_rows >= 0, SUBGACC_ERR_BADARG, "sjoin_fill: bad arguments");
-    if (S == 0) return SUBGACC_OK;
-    SG_REQUIRE(spg_indptr && spg_indices && own && (partner || pair_block > 0) && seg, SUBGACC_ERR_BADARG, "sjoin_fill: null argument");
-    SG_REQUIRE((spg_data_i32 != nullptr) != (spg_data_f64 != nullptr), SUBGACC_ERR_BADARG,
-               "sjoin_fill: exactly one of spg_data_i32 / spg_data_f64");
-    const bool f64 = spg_data_f64 != nullptr;
-    if (f64) {
-        SG_REQUIRE(out_xz && !out_idx && !table, SUBGACC_ERR_BADARG,
-                   "sjoin_fill: float payload writes out_xz [R,2,1] only (train.py:39-43)");
-    } else {
-        SG_REQUIRE(out_xz || out_idx, SUBGACC_ERR_BADARG, "sjoin_fill: no output requested");
-        SG_REQUIRE(!out_xz || (table && table_rows > 0 && k > 0), SUBGACC_ERR_BADARG,
-                   "sjoin_fill: out_xz needs the feature table");
-    }
-    JoinArgs a;
-    a.indptr = spg_indptr, a.indices = spg_indices;
-    a.data = f64 ? (const void *)spg_data_f64 : (const void *)spg_data_i32;
-    a.pb = pair_block; a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
-    a.table = table, a.table_rows = table_rows, a.k = k;
-    a.out_xz = out_xz, a.out_idx = out_idx, a.out_segid = out_segid;
-    a.max_len = max_len > 0 ? max_len : 1;
-    a.flags = flags;
-    a.row_len = nullptr, a.row_stride = 0, a.slot_id = nullptr, a.val_add = 0;
-    a.key_M = a.key_m = a.key_shift = 0;
-    SG_REQUIRE(pair_block >= 0 && (pair_block == 0 || S % (2 * pair_block) == 0), SUBGACC_ERR_BADARG,
-               "sjoin_fill: S = %lld is not a multiple of 2*pair_block", (long long)S);
-    bool paired = pair_block > 0;
-    size_t lds = (size_t)a.max_len * (f64 ? 12 : 8) * (paired ? 2 : 1);
-    if (paired && lds > (size_t)kLdsBytes) {     // two rows do not fit LDS: one might (the mirrored list is a list all the same)
-        paired = false;
-        lds /= 2;
-    }
-    const bool staged = lds <= (size_t)kLdsBytes;   // else: rows longer than LDS, searched in place (sjoin_fill_kernel<.., false>)
-    if (!staged) lds = 0;
-    SG_REQUIRE(k <= 16, SUBGACC_ERR_BADARG, "sjoin_fill: feature width k = %d > 16 is not supported", k);
-    if (paired) a.split = pair_split(S / 2);
-    const int64_t grid = xcd_grid(paired ? S / 2 * a.split : S);
-    SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_fill: too many segments in one call");
-    hipStream_t s = (hipStream_t)stream;
-    const bool vec4 = !f64 && out_xz && k == 4 && ((uintptr_t)table % 16 == 0) && ((uintptr_t)out_xz % 16 == 0);
-    if (paired) {
-        if (f64) {
-            // float rows: T + its partner slots in LDS (20 bytes per member).  Short rows (the top-100 PPR store): ONE wave per pair
-            // -- twice the pairs in flight per CU (cit2-PPR join 0.154 -> 0.139 ms in round 2; integer rows were slower that way)
-            // (round 3 tried persistent waves with a four-stage software pipeline over their pairs: 91 us against 77; round 5 the
-            //  same for key rows, profiles/r18_join_pipe.log: the hardware's interleaving of resident workgroups wins both times)
-            const size_t flds = (size_t)a.max_len * 20 + 16;
-            SG_REQUIRE(S / 2 < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_fill: too many segments in one call");
-            const uint32_t pairs = (uint32_t)(S / 2), pb32 = (uint32_t)pair_block;
-            if (a.max_len <= 2 * kWave) {
-                hipLaunchKernelGGL((sjoin_f64pair_kernel<kWave>), dim3((unsigned)grid), dim3(kWave), flds, s, a, pb32, pairs);
-            } else {
-                if (flds > 64 * 1024)
-                    SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_f64pair_kernel<kPairEmit>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
-                hipLaunchKernelGGL((sjoin_f64pair_kernel<kPairEmit>), dim3((unsigned)grid), dim3(kPairEmit), flds, s, a, pb32, pairs);
-            }
-        }
-        else
-            return launch_table_pairs(a, S, pair_block, vec4, stream, "sjoin_fill");
-        SG_LAUNCH_CHECK();
-        return SUBGACC_OK;
-    }
-#define SG_JOIN_LAUNCH(F, KVV)                                                                                   \
-    do {                                                                                                          \
-        if (lds > 64 * 1024)                                                                                      \
-            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_fill_kernel<F, KVV>,                             \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
-        hipLaunchKernelGGL((sjoin_fill_kernel<F, KVV>), dim3((unsigned)grid), dim3(kJoinThreads), lds, s, a);     \
-    } while (0)
-    if (!staged) {
-        if (f64) hipLaunchKernelGGL((sjoin_fill_kernel<true, 0, false>), dim3((unsigned)grid), dim3(kJoinThreads), 0, s, a);
-        else if (vec4) hipLaunchKernelGGL((sjoin_fill_kernel<false, 4, false>), dim3((unsigned)grid), dim3(kJoinThreads), 0, s, a);
-        else hipLaunchKernelGGL((sjoin_fill_kernel<false, 0, false>), dim3((unsigned)grid), dim3(kJoinThreads), 0, s, a);
-    } else if (f64) SG_JOIN_LAUNCH(true, 0);
-    else if (vec4) SG_JOIN_LAUNCH(false, 4);
-    else SG_JOIN_LAUNCH(false, 0);
-#undef SG_JOIN_LAUNCH
-    SG_LAUNCH_CHECK();
-    return SUBGACC_OK;
-}
-
-static int sjoin_fill_rows_impl(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
-                                       const int32_t *row_slot, const void *uniq_table, int64_t uniq_capacity,
-                                       const int64_t *own, const int64_t *partner, int64_t S, const int64_t *seg,
-                                       const float *table, int64_t table_rows, int32_t k, float *out_xz,
-                                       int32_t *out_idx, int64_t *out_segid, int64_t pair_block, int32_t *flags,
-                                       void *stream) {
-    SG_REQUIRE(S >= 0 && flags && n_rows >= 0 && row_stride > 0 && row_stride < (1ll << 31), SUBGACC_ERR_BADARG,
-               "sjoin_fill_rows: bad arguments");
-    if (S == 0) return SUBGACC_OK;
-    SG_REQUIRE(row_len && row_ids && row_slot && (!uniq_table || uniq_capacity > 0) && own && (partner || pair_block > 0) && seg,
-               SUBGACC_ERR_BADARG, "sjoin_fill_rows: null argument");
-    SG_REQUIRE(out_xz || out_idx, SUBGACC_ERR_BADARG, "sjoin_fill_rows: no output requested");
-    SG_REQUIRE(!out_xz || (table && table_rows > 0 && k > 0 && k <= 16), SUBGACC_ERR_BADARG,
-               "sjoin_fill_rows: out_xz needs the feature table, k <= 16");
-    SG_REQUIRE(pair_block > 0 && S % (2 * pair_block) == 0, SUBGACC_ERR_BADARG,
-               "sjoin_fill_rows: the segment list must be mirrored blocks (pair_block > 0, S a multiple of 2*pair_block)");
-    JoinArgs a;
-    a.indptr = nullptr, a.indices = row_ids, a.data = row_slot;
-    a.pb = pair_block; a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
-    a.table = table, a.table_rows = table_rows, a.k = k;
-    a.out_xz = out_xz, a.out_idx = out_idx, a.out_segid = out_segid;
-    a.max_len = (int32_t)row_stride;
-    a.flags = flags;
-    a.row_len = row_len, a.row_stride = row_stride;
-    // numbered table given: slot -> SFptr+1 through its id plane (uniq_table.hpp); else the table is indexed by slot+1
-    a.slot_id = uniq_table ? (const int32_t *)((const char *)uniq_table + (size_t)uniq_capacity * 16) : nullptr;
-    a.val_add = uniq_table ? 0 : 1;
-    a.key_M = a.key_m = a.key_shift = 0;
-    const bool vec4 = out_xz && k == 4 && ((uintptr_t)table % 16 == 0) && ((uintptr_t)out_xz % 16 == 0);
-    return launch_table_pairs(a, S, pair_block, vec4, stream, "sjoin_fill_rows");
-}
-
+// ---------------------------------------------------------------------------------------------------------
+// ONE entry point for every form of the join (ABI 6; since ABI 7 the only one -- the seven per-form entry points of ABI 1-5 are gone).
+// A descriptor says what the store looks like (packed, strided or headed rows; which payload), which segments to join, what the
+// feature rows are made from and which outputs are wanted.  The kernels' arguments are built from it ONCE, here.
 // key payload (strided rows of a transient batch, or a packed store whose payload was re-keyed): shared launcher
 static int launch_key_join(JoinArgs &a, int32_t num_walks, int32_t num_steps, int64_t S, int64_t pair_block, void *stream,
                            const char *who, bool wide = false) {
@@ -1505,306 +1414,191 @@ static int launch_key_join(JoinArgs &a, int32_t num_walks, int32_t num_steps, in
     return SUBGACC_OK;
 }
 
-static int sjoin_fill_keyrows_impl(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
-                                          const int32_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
-                                          const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz,
-                                          int64_t pair_block, int32_t *flags, void *stream) {
-    SG_REQUIRE(S >= 0 && flags && n_rows >= 0 && row_stride > 0 && row_stride < (1ll << 31), SUBGACC_ERR_BADARG,
-               "sjoin_fill_keyrows: bad arguments");
-    if (S == 0) return subgacc_key_shift(num_walks, num_steps) < 0 ? subgacc_key_shift(num_walks, num_steps) : SUBGACC_OK;
-    SG_REQUIRE(row_len && row_ids && row_keys && own && (partner || pair_block > 0) && seg && out_xz, SUBGACC_ERR_BADARG,
-               "sjoin_fill_keyrows: null argument");
-    SG_REQUIRE(pair_block > 0 && S % (2 * pair_block) == 0, SUBGACC_ERR_BADARG,
-               "sjoin_fill_keyrows: the segment list must be mirrored blocks (pair_block > 0, S a multiple of 2*pair_block)");
-    JoinArgs a;
-    a.indptr = nullptr, a.indices = row_ids, a.data = row_keys;
-    a.pb = pair_block; a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
-    a.out_xz = out_xz, a.out_segid = nullptr;
-    a.max_len = (int32_t)row_stride;
-    a.flags = flags;
-    a.row_len = row_len, a.row_stride = row_stride;
-    return launch_key_join(a, num_walks, num_steps, S, pair_block, stream, "sjoin_fill_keyrows");
-}
 
-static int sjoin_fill_keyrows64_impl(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
-                                            const uint64_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
-                                            const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz,
-                                            int64_t pair_block, int32_t *flags, void *stream) {
-    SG_REQUIRE(S >= 0 && flags && n_rows >= 0 && row_stride > 0 && row_stride < (1ll << 31), SUBGACC_ERR_BADARG,
-               "sjoin_fill_keyrows64: bad arguments");
-    if (S == 0) return subgacc_key_shift(num_walks, num_steps) < 0 ? subgacc_key_shift(num_walks, num_steps) : SUBGACC_OK;
-    SG_REQUIRE(row_len && row_ids && row_keys && own && (partner || pair_block > 0) && seg && out_xz, SUBGACC_ERR_BADARG,
-               "sjoin_fill_keyrows64: null argument");
-    SG_REQUIRE(pair_block > 0 && S % (2 * pair_block) == 0, SUBGACC_ERR_BADARG,
-               "sjoin_fill_keyrows64: the segment list must be mirrored blocks (pair_block > 0, S a multiple of 2*pair_block)");
-    JoinArgs a;
-    a.indptr = nullptr, a.indices = row_ids, a.data = row_keys;
-    a.pb = pair_block; a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
-    a.out_xz = out_xz, a.out_segid = nullptr;
-    a.max_len = (int32_t)row_stride;
-    a.flags = flags;
-    a.row_len = row_len, a.row_stride = row_stride;
-    return launch_key_join(a, num_walks, num_steps, S, pair_block, stream, "sjoin_fill_keyrows64", true);
-}
-
-static int sjoin_fill_keys_impl(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,
-                                       const int32_t *spg_keys, const int64_t *own, const int64_t *partner, int64_t S,
-                                       const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz,
-                                       int64_t *out_segid, int32_t max_len, int64_t pair_block, int32_t *flags, void *stream) {
-    SG_REQUIRE(S >= 0 && flags && n_rows >= 0 && max_len >= 0, SUBGACC_ERR_BADARG, "sjoin_fill_keys: bad arguments");
-    if (S == 0) return subgacc_key_shift(num_walks, num_steps) < 0 ? subgacc_key_shift(num_walks, num_steps) : SUBGACC_OK;
-    SG_REQUIRE(spg_indptr && spg_indices && spg_keys && own && (partner || pair_block > 0) && seg && out_xz, SUBGACC_ERR_BADARG,
-               "sjoin_fill_keys: null argument");
-    SG_REQUIRE(pair_block > 0 && S % (2 * pair_block) == 0, SUBGACC_ERR_BADARG,
-               "sjoin_fill_keys: the segment list must be mirrored blocks (pair_block > 0, S a multiple of 2*pair_block)");
-    JoinArgs a;
-    a.indptr = spg_indptr, a.indices = spg_indices, a.data = spg_keys;
-    a.pb = pair_block; a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
-    a.out_xz = out_xz, a.out_segid = out_segid;
-    a.max_len = max_len > 0 ? max_len : 1;
-    a.flags = flags;
-    a.row_len = nullptr, a.row_stride = 0;
-    return launch_key_join(a, num_walks, num_steps, S, pair_block, stream, "sjoin_fill_keys");
-}
-
-static int sjoin_counts_impl(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,
-                                    const int32_t *spg_data_i32, const int64_t *own, const int64_t *partner, int64_t S, int64_t table_rows,
-                                    float *out_counts, int32_t max_len, int64_t pair_block, int32_t *flags,
-                                    void *stream) {
-    SG_REQUIRE(S >= 0 && max_len >= 0 && flags && table_rows > 0 && n_rows >= 0, SUBGACC_ERR_BADARG,
-               "sjoin_counts: bad arguments");
-    if (S == 0) return SUBGACC_OK;
-    SG_REQUIRE(spg_indptr && spg_indices && spg_data_i32 && own && (partner || pair_block > 0) && out_counts, SUBGACC_ERR_BADARG,
-               "sjoin_counts: null argument");
-    SG_REQUIRE(pair_block > 0 && S % (2 * pair_block) == 0, SUBGACC_ERR_BADARG,
-               "sjoin_counts: the segment list must be mirrored blocks (pair_block > 0, S a multiple of 2*pair_block)");
-    JoinArgs a;
-    a.indptr = spg_indptr, a.indices = spg_indices, a.data = spg_data_i32;
-    a.pb = pair_block; a.own = own, a.partner = partner, a.seg = nullptr, a.S = S, a.n_rows = n_rows;
-    a.table = nullptr, a.table_rows = table_rows, a.k = 0;
-    a.out_xz = nullptr, a.out_idx = nullptr, a.out_segid = nullptr;
-    a.max_len = max_len > 0 ? max_len : 1;
-    a.flags = flags;
-    a.row_len = nullptr, a.row_stride = 0, a.slot_id = nullptr, a.val_add = 0;
-    a.key_M = a.key_m = a.key_shift = 0;
-    const size_t lds = (size_t)a.max_len * 8 + (size_t)table_rows * 8 + 16;
-    SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS,
-               "sjoin_counts: %lld distinct LP rows and rows of %d members need %zu B of LDS; use sjoin_fill",
-               (long long)table_rows, max_len, lds);
-    if (lds > 64 * 1024)
-        SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_counts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)lds));
-    const int64_t grid = xcd_grid(S / 2);
-    SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_counts: too many segments in one call");
-    hipLaunchKernelGGL(sjoin_counts_kernel, dim3((unsigned)grid), dim3(kPairThreads), lds, (hipStream_t)stream, a,
-                       pair_block, out_counts);
+// mirrored lists of a float payload (train.py:39-43)
+static int launch_f64_pairs(JoinArgs &a, int64_t S, int64_t pair_block, void *stream) {
+    // float rows: T + its partner slots in LDS (20 bytes per member).  Short rows (the top-100 PPR store): ONE wave per pair
+    // -- twice the pairs in flight per CU (cit2-PPR join 0.154 -> 0.139 ms in round 2; integer rows were slower that way)
+    // (round 3 tried persistent waves with a four-stage software pipeline over their pairs: 91 us against 77; round 5 the
+    //  same for key rows, profiles/r18_join_pipe.log: the hardware's interleaving of resident workgroups wins both times)
+    const size_t flds = (size_t)a.max_len * 20 + 16;
+    SG_REQUIRE(flds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "sjoin_fill: float rows of %d members do not fit LDS", (int)a.max_len);
+    a.split = pair_split(S / 2);
+    const int64_t grid = xcd_grid(S / 2 * a.split);
+    SG_REQUIRE(grid < (1ll << 31) && S / 2 < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_fill: too many segments in one call");
+    const uint32_t pairs = (uint32_t)(S / 2), pb32 = (uint32_t)pair_block;
+    hipStream_t s = (hipStream_t)stream;
+    if (a.max_len <= 2 * kWave) {
+        hipLaunchKernelGGL((sjoin_f64pair_kernel<kWave>), dim3((unsigned)grid), dim3(kWave), flds, s, a, pb32, pairs);
+    } else {
+        if (flds > 64 * 1024)
+            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_f64pair_kernel<kPairEmit>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+        hipLaunchKernelGGL((sjoin_f64pair_kernel<kPairEmit>), dim3((unsigned)grid), dim3(kPairEmit), flds, s, a, pb32, pairs);
+    }
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }
 
-static int sjoin_pairs_impl(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices,
-                                   const int32_t *spg_data_i32, const int64_t *own, const int64_t *partner, int64_t S,
-                                   const int64_t *seg, int32_t *out_pairs, int32_t *out_mult, int32_t *out_cnt,
-                                   int32_t max_len, int64_t pair_block, int32_t *flags, void *stream) {
-    SG_REQUIRE(S >= 0 && max_len >= 0 && flags && n_rows >= 0, SUBGACC_ERR_BADARG, "sjoin_pairs: bad arguments");
-    if (S == 0) return SUBGACC_OK;
-    SG_REQUIRE(spg_indptr && spg_indices && spg_data_i32 && own && (partner || pair_block > 0) && seg && out_pairs && out_mult && out_cnt,
-               SUBGACC_ERR_BADARG, "sjoin_pairs: null argument");
-    SG_REQUIRE(pair_block > 0 && S % (2 * pair_block) == 0, SUBGACC_ERR_BADARG,
-               "sjoin_pairs: the segment list must be mirrored blocks (pair_block > 0, S a multiple of 2*pair_block)");
-    JoinArgs a;
-    a.indptr = spg_indptr, a.indices = spg_indices, a.data = spg_data_i32;
-    a.pb = pair_block; a.own = own, a.partner = partner, a.seg = seg, a.S = S, a.n_rows = n_rows;
-    a.table = nullptr, a.table_rows = 0, a.k = 0;
-    a.out_xz = nullptr, a.out_idx = nullptr, a.out_segid = nullptr;
-    a.max_len = max_len > 0 ? max_len : 1;
-    a.flags = flags;
-    a.row_len = nullptr, a.row_stride = 0, a.slot_id = nullptr, a.val_add = 0;
-    a.key_M = a.key_m = a.key_shift = 0;
+// any list that is not made of mirrored pairs (or whose two rows do not fit LDS together): one wave per segment
+static int launch_segments(JoinArgs &a, bool f64, bool vec4, void *stream) {
+    size_t lds = (size_t)a.max_len * (f64 ? 12 : 8);
+    const bool staged = lds <= (size_t)kLdsBytes;   // else: rows longer than LDS, searched in place (sjoin_fill_kernel<.., false>)
+    if (!staged) lds = 0;
+    const int64_t grid = xcd_grid(a.S);
+    SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_fill: too many segments in one call");
+    hipStream_t s = (hipStream_t)stream;
+#define SG_JOIN_LAUNCH(F, KVV)                                                                                   \
+    do {                                                                                                          \
+        if (lds > 64 * 1024)                                                                                      \
+            SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_fill_kernel<F, KVV>,                             \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));              \
+        hipLaunchKernelGGL((sjoin_fill_kernel<F, KVV>), dim3((unsigned)grid), dim3(kJoinThreads), lds, s, a);     \
+    } while (0)
+    if (!staged) {
+        if (f64) hipLaunchKernelGGL((sjoin_fill_kernel<true, 0, false>), dim3((unsigned)grid), dim3(kJoinThreads), 0, s, a);
+        else if (vec4) hipLaunchKernelGGL((sjoin_fill_kernel<false, 4, false>), dim3((unsigned)grid), dim3(kJoinThreads), 0, s, a);
+        else hipLaunchKernelGGL((sjoin_fill_kernel<false, 0, false>), dim3((unsigned)grid), dim3(kJoinThreads), 0, s, a);
+    } else if (f64) SG_JOIN_LAUNCH(true, 0);
+    else if (vec4) SG_JOIN_LAUNCH(false, 4);
+    else SG_JOIN_LAUNCH(false, 0);
+#undef SG_JOIN_LAUNCH
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}
+
+static int launch_counts(JoinArgs &a, int64_t pair_block, float *out_counts, void *stream) {
+    const size_t lds = (size_t)a.max_len * 8 + (size_t)a.table_rows * 8 + 16;
+    SG_REQUIRE(lds <= (size_t)kLdsBytes, SUBGACC_ERR_LDS,
+               "sjoin_counts: %lld distinct LP rows and rows of %d members need %zu B of LDS; use the row form",
+               (long long)a.table_rows, (int)a.max_len, lds);
+    if (lds > 64 * 1024)
+        SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_counts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t grid = xcd_grid(a.S / 2);
+    SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_counts: too many segments in one call");
+    hipLaunchKernelGGL(sjoin_counts_kernel, dim3((unsigned)grid), dim3(kPairThreads), lds, (hipStream_t)stream, a, pair_block, out_counts);
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}
+
+static int launch_pair_form(JoinArgs &a, int64_t pair_block, int32_t *out_pairs, int32_t *out_mult, int32_t *out_cnt, void *stream) {
     SG_REQUIRE(2 * (int64_t)a.max_len <= 8 * kPairThreads, SUBGACC_ERR_LDS,
-               "sjoin_pairs: rows of %d members are too long for the pair form (<= %d); use sjoin_fill", max_len,
-               4 * kPairThreads);
+               "sjoin_pairs: rows of %d members are too long for the pair form (<= %d); use the row form", (int)a.max_len, 4 * kPairThreads);
     int ts_log2 = 6;                                           // distinct pairs of one block <= its row length
     while ((1 << ts_log2) < a.max_len + a.max_len / 4 + 1) ++ts_log2;
     const size_t lds = (size_t)2 * (1u << ts_log2) * 12 + (size_t)a.max_len * 16;
     SG_REQUIRE(lds + 64 <= (size_t)kLdsBytes, SUBGACC_ERR_LDS, "sjoin_pairs: %zu B of LDS needed", lds);
     if (lds > 64 * 1024)
-        SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)lds));
-    const int64_t grid = xcd_grid(S / 2);
+        SG_CHECK_HIP(hipFuncSetAttribute((const void *)sjoin_pairs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t grid = xcd_grid(a.S / 2);
     SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "sjoin_pairs: too many segments in one call");
-    hipLaunchKernelGGL(sjoin_pairs_kernel, dim3((unsigned)grid), dim3(kPairThreads), lds, (hipStream_t)stream, a,
-                       pair_block, ts_log2, out_pairs, out_mult, out_cnt);
+    hipLaunchKernelGGL(sjoin_pairs_kernel, dim3((unsigned)grid), dim3(kPairThreads), lds, (hipStream_t)stream, a, pair_block, ts_log2,
+                       out_pairs, out_mult, out_cnt);
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// ABI 6: ONE entry point for every form of the join.  A descriptor says what the store looks like (packed or strided rows, which
-// payload), which segments to join, what the feature rows are made from and which outputs are wanted; the seven entry points of
-// ABI 1-5 (subgacc_sjoin_fill, _fill_rows, _fill_keyrows, _fill_keyrows64, _fill_keys, _counts, _pairs) remain as forwards that fill
-// one in.  The launchers above are what it dispatches to.
 extern "C" int subgacc_sjoin_fill_v2(const subgacc_join_desc *d, void *stream) {
     SG_REQUIRE(d, SUBGACC_ERR_BADARG, "sjoin_fill_v2: null descriptor");
     SG_REQUIRE(d->struct_bytes == (int32_t)sizeof(subgacc_join_desc), SUBGACC_ERR_BADARG,
                "sjoin_fill_v2: descriptor of %d bytes, this library's is %d (set struct_bytes = sizeof(subgacc_join_desc))",
                (int)d->struct_bytes, (int)sizeof(subgacc_join_desc));
-    SG_REQUIRE((d->row_off != nullptr) != (d->row_len != nullptr), SUBGACC_ERR_BADARG,
-               "sjoin_fill_v2: exactly one of row_off (packed rows) / row_len (strided rows)");
-    const bool strided = d->row_len != nullptr;
-    const int64_t *seg = d->seg;
+    // the store's layout: packed rows (row_off), strided rows (row_len + row_stride), headed rows (neither; row_stride)
+    const bool packed = d->row_off != nullptr, strided = d->row_len != nullptr;
+    const bool headed = !packed && !strided && d->row_stride > 0;
+    SG_REQUIRE((int)packed + (int)strided + (int)headed == 1, SUBGACC_ERR_BADARG,
+               "sjoin_fill_v2: exactly one of row_off (packed rows) / row_len (strided rows) / neither, with row_stride (headed rows)");
+    SG_REQUIRE(packed || (d->row_stride > (headed ? 1 : 0) && d->row_stride < (1ll << 31)), SUBGACC_ERR_BADARG,
+               "sjoin_fill_v2: row_stride = %lld", (long long)d->row_stride);
     SG_REQUIRE((d->options & ~SUBGACC_JOIN_OPT_SIZES) == 0, SUBGACC_ERR_BADARG, "sjoin_fill_v2: unknown option bits %d", (int)d->options);
-    if (d->options & SUBGACC_JOIN_OPT_SIZES) {       // the whole join of a batch in one call: size pass, then the fill behind it
-        SG_REQUIRE(d->form == SUBGACC_JOIN_ROWS, SUBGACC_ERR_BADARG, "sjoin_fill_v2: OPT_SIZES goes with the row form");
-        const int rc = join_sizes_onepass(d, (hipStream_t)stream);
-        if (rc != SUBGACC_OK) return rc;
-        seg = d->out_seg;
-        t_sized_here = true;
+    SG_REQUIRE(d->form >= SUBGACC_JOIN_ROWS && d->form <= SUBGACC_JOIN_PAIRS, SUBGACC_ERR_BADARG, "sjoin_fill_v2: unknown form %d", (int)d->form);
+    SG_REQUIRE(d->payload_kind >= SUBGACC_JOIN_SFPTR && d->payload_kind <= SUBGACC_JOIN_KEY64, SUBGACC_ERR_BADARG,
+               "sjoin_fill_v2: unknown payload kind %d", (int)d->payload_kind);
+    const int kind = d->payload_kind;
+    const bool f64 = kind == SUBGACC_JOIN_F64, keyed = kind == SUBGACC_JOIN_KEY32 || kind == SUBGACC_JOIN_KEY64;
+    const bool sized = (d->options & SUBGACC_JOIN_OPT_SIZES) != 0;
+    const bool sizes_only = sized && !d->out_xz && !d->out_idx;      // the "count" half of a two-call pattern: out_seg and host_tail only
+    const int64_t *seg = sized ? d->out_seg : d->seg;
+    const int64_t S = d->S, pb = d->pair_block;
+    // ---- what the kernels would not survive is refused here, before anything is launched (with OPT_SIZES: before the size pass has
+    //      written out_seg / host_tail)
+    SG_REQUIRE(S >= 0 && d->n_rows >= 0 && d->max_len >= 0, SUBGACC_ERR_BADARG, "sjoin_fill_v2: bad arguments");
+    SG_REQUIRE(!sized || d->form == SUBGACC_JOIN_ROWS, SUBGACC_ERR_BADARG, "sjoin_fill_v2: OPT_SIZES goes with the row form");
+    if (!sizes_only) {
+        SG_REQUIRE(d->flags, SUBGACC_ERR_BADARG, "sjoin_fill_v2: null argument (flags)");
+        SG_REQUIRE(!(kind == SUBGACC_JOIN_KEY64 && packed) && !(keyed && strided && d->out_segid), SUBGACC_ERR_BADARG,
+                   "sjoin_fill_v2: this payload kind does not go with this row layout (64-bit keys: strided or headed rows; keys "
+                   "of strided rows -- a transient batch -- are joined with segment pointers)");
+        SG_REQUIRE(d->form == SUBGACC_JOIN_ROWS || kind == SUBGACC_JOIN_SFPTR, SUBGACC_ERR_BADARG,
+                   "sjoin_fill_v2: the count and pair forms join an SFptr store");
+        if (S > 0 || sized) {
+            SG_REQUIRE(d->ids && d->payload, SUBGACC_ERR_BADARG, "sjoin_fill_v2: null argument (ids / payload)");
+            if (d->form == SUBGACC_JOIN_ROWS) SG_REQUIRE(d->out_xz || d->out_idx, SUBGACC_ERR_BADARG, "sjoin_fill_v2: no output requested");
+        }
     }
-    struct Reset {
-        ~Reset() { t_sized_here = false; }
-    } reset_sized_here;
+    if (sized) {       // the whole join of a batch in one call: size pass, then the fill behind it
+        const int rc = join_sizes_onepass(d, (hipStream_t)stream);
+        if (rc != SUBGACC_OK || sizes_only) return rc;
+    }
+    if (keyed) {       // (also for S == 0: a caller learns about a key width that does not fit from its first, empty, call)
+        const int shift = subgacc_key_shift(d->num_walks, d->num_steps);
+        if (shift < 0) return shift;
+    }
+    if (S == 0) return SUBGACC_OK;
+    SG_REQUIRE(d->own && (d->partner || pb > 0), SUBGACC_ERR_BADARG, "sjoin_fill_v2: null argument (segments)");
+    SG_REQUIRE(pb >= 0 && (pb == 0 || S % (2 * pb) == 0), SUBGACC_ERR_BADARG,
+               "sjoin_fill_v2: S = %lld is not a multiple of 2*pair_block", (long long)S);
+    const bool mirrored = pb > 0;
+    SG_REQUIRE(d->form == SUBGACC_JOIN_COUNTS || seg, SUBGACC_ERR_BADARG, "sjoin_fill_v2: null argument (seg)");
+
+    JoinArgs a;
+    a.sized_here = sized;
+    a.indptr = d->row_off, a.indices = headed ? d->ids + 1 : d->ids, a.data = d->payload;
+    a.row_len = d->row_len, a.row_stride = packed ? 0 : d->row_stride, a.row_head = headed ? d->ids : nullptr;
+    a.pb = pb, a.own = d->own, a.partner = d->partner, a.seg = seg, a.S = S, a.n_rows = d->n_rows;
+    a.table = d->table, a.table_rows = d->table_rows, a.k = d->k;
+    a.out_xz = d->out_xz, a.out_idx = d->out_idx, a.out_segid = d->out_segid;
+    // the longest row: the caller's bound for packed rows, what a row's slot holds otherwise
+    a.max_len = packed ? (d->max_len > 0 ? d->max_len : 1) : (int32_t)(headed ? d->row_stride - 1 : d->row_stride);
+    a.flags = d->flags;
+    a.slot_id = nullptr, a.val_add = 0;
+    a.key_M = a.key_m = a.key_shift = 0;
+
     if (d->form == SUBGACC_JOIN_COUNTS) {
-        SG_REQUIRE(!strided && d->payload_kind == SUBGACC_JOIN_SFPTR, SUBGACC_ERR_BADARG, "sjoin_fill_v2: the count form joins a packed SFptr store");
-        return sjoin_counts_impl(d->row_off, d->n_rows, d->ids, (const int32_t *)d->payload, d->own, d->partner, d->S, d->table_rows,
-                                 d->out_counts, d->max_len, d->pair_block, d->flags, stream);
+        SG_REQUIRE(mirrored && d->out_counts && d->table_rows > 0, SUBGACC_ERR_BADARG,
+                   "sjoin_counts: mirrored blocks (pair_block > 0), out_counts and table_rows > 0");
+        a.seg = nullptr, a.table = nullptr, a.k = 0, a.out_xz = nullptr, a.out_idx = nullptr, a.out_segid = nullptr;
+        return launch_counts(a, pb, d->out_counts, stream);
     }
     if (d->form == SUBGACC_JOIN_PAIRS) {
-        SG_REQUIRE(!strided && d->payload_kind == SUBGACC_JOIN_SFPTR, SUBGACC_ERR_BADARG, "sjoin_fill_v2: the pair form joins a packed SFptr store");
-        return sjoin_pairs_impl(d->row_off, d->n_rows, d->ids, (const int32_t *)d->payload, d->own, d->partner, d->S, seg, d->out_pairs,
-                                d->out_mult, d->out_cnt, d->max_len, d->pair_block, d->flags, stream);
+        SG_REQUIRE(mirrored && d->out_pairs && d->out_mult && d->out_cnt, SUBGACC_ERR_BADARG,
+                   "sjoin_pairs: mirrored blocks (pair_block > 0), out_pairs, out_mult and out_cnt");
+        a.table = nullptr, a.table_rows = 0, a.k = 0, a.out_xz = nullptr, a.out_idx = nullptr, a.out_segid = nullptr;
+        return launch_pair_form(a, pb, d->out_pairs, d->out_mult, d->out_cnt, stream);
     }
-    SG_REQUIRE(d->form == SUBGACC_JOIN_ROWS, SUBGACC_ERR_BADARG, "sjoin_fill_v2: unknown form %d", (int)d->form);
-    switch (d->payload_kind) {
-    case SUBGACC_JOIN_SFPTR:
-        if (strided)
-            return sjoin_fill_rows_impl(d->row_len, d->n_rows, d->row_stride, d->ids, (const int32_t *)d->payload, d->uniq_table,
-                                        d->uniq_capacity, d->own, d->partner, d->S, seg, d->table, d->table_rows, d->k, d->out_xz,
-                                        d->out_idx, d->out_segid, d->pair_block, d->flags, stream);
-        return sjoin_fill_impl(d->row_off, d->n_rows, d->ids, (const int32_t *)d->payload, nullptr, d->own, d->partner, d->S, seg,
-                               d->table, d->table_rows, d->k, d->out_xz, d->out_idx, d->out_segid, d->max_len, d->pair_block, d->flags,
-                               stream);
-    case SUBGACC_JOIN_F64:
-        SG_REQUIRE(!strided, SUBGACC_ERR_BADARG, "sjoin_fill_v2: a float payload lives in a packed store");
-        return sjoin_fill_impl(d->row_off, d->n_rows, d->ids, nullptr, (const double *)d->payload, d->own, d->partner, d->S, seg,
-                               nullptr, 0, 1, d->out_xz, nullptr, d->out_segid, d->max_len, d->pair_block, d->flags, stream);
-    case SUBGACC_JOIN_KEY32:
-        if (strided) {
-            SG_REQUIRE(!d->out_segid, SUBGACC_ERR_BADARG, "sjoin_fill_v2: strided key rows are joined with segment pointers");
-            return sjoin_fill_keyrows_impl(d->row_len, d->n_rows, d->row_stride, d->ids, (const int32_t *)d->payload, d->own, d->partner,
-                                           d->S, seg, d->num_walks, d->num_steps, d->out_xz, d->pair_block, d->flags, stream);
-        }
-        return sjoin_fill_keys_impl(d->row_off, d->n_rows, d->ids, (const int32_t *)d->payload, d->own, d->partner, d->S, seg,
-                                    d->num_walks, d->num_steps, d->out_xz, d->out_segid, d->max_len, d->pair_block, d->flags, stream);
-    case SUBGACC_JOIN_KEY64:
-        SG_REQUIRE(strided && !d->out_segid, SUBGACC_ERR_BADARG, "sjoin_fill_v2: 64-bit keys are the payload of strided rows (subgacc_walk_keyrows64)");
-        return sjoin_fill_keyrows64_impl(d->row_len, d->n_rows, d->row_stride, d->ids, (const uint64_t *)d->payload, d->own, d->partner,
-                                         d->S, seg, d->num_walks, d->num_steps, d->out_xz, d->pair_block, d->flags, stream);
-    default:
-        SG_REQUIRE(false, SUBGACC_ERR_BADARG, "sjoin_fill_v2: unknown payload kind %d", (int)d->payload_kind);
+    if (keyed) {
+        SG_REQUIRE(mirrored && d->out_xz, SUBGACC_ERR_BADARG,
+                   "sjoin_fill_v2: key rows are joined as mirrored blocks (pair_block > 0, S a multiple of 2*pair_block) into out_xz");
+        return launch_key_join(a, d->num_walks, d->num_steps, S, pb, stream, "sjoin_fill_v2", kind == SUBGACC_JOIN_KEY64);
     }
-    return SUBGACC_ERR_BADARG;
+    if (f64) {
+        SG_REQUIRE(d->out_xz && !d->out_idx && !d->table, SUBGACC_ERR_BADARG,
+                   "sjoin_fill_v2: float payload writes out_xz [R,2,1] only (train.py:39-43)");
+        a.k = 1, a.table = nullptr, a.table_rows = 0;
+        if (mirrored && (size_t)a.max_len * 20 + 16 <= (size_t)kLdsBytes) return launch_f64_pairs(a, S, pb, stream);
+        SG_REQUIRE(packed, SUBGACC_ERR_BADARG, "sjoin_fill_v2: strided / headed float rows are joined as mirrored blocks (pair_block > 0)");
+        return launch_segments(a, true, false, stream);
+    }
+    // SFptr+1 (packed / headed rows of a numbered store) or table slots (strided rows of a transient batch) with the Z_SF table
+    SG_REQUIRE(!d->out_xz || (d->table && d->table_rows > 0 && d->k > 0 && d->k <= 16), SUBGACC_ERR_BADARG,
+               "sjoin_fill_v2: out_xz needs the feature table, k <= 16");
+    if (strided) {
+        // numbered table given: slot -> SFptr+1 through its id plane (uniq_table.hpp); else the table is indexed by slot+1
+        SG_REQUIRE(!d->uniq_table || d->uniq_capacity > 0, SUBGACC_ERR_BADARG, "sjoin_fill_v2: uniq_capacity");
+        a.slot_id = d->uniq_table ? (const int32_t *)((const char *)d->uniq_table + (size_t)d->uniq_capacity * 16) : nullptr;
+        a.val_add = d->uniq_table ? 0 : 1;
+    }
+    const bool vec4 = d->out_xz && d->k == 4 && ((uintptr_t)d->table % 16 == 0) && ((uintptr_t)d->out_xz % 16 == 0);
+    if (mirrored && (size_t)a.max_len * 16 <= (size_t)kLdsBytes) return launch_table_pairs(a, S, pb, vec4, stream, "sjoin_fill_v2");
+    SG_REQUIRE(packed, SUBGACC_ERR_BADARG, "sjoin_fill_v2: strided / headed rows are joined as mirrored blocks (pair_block > 0)");
+    return launch_segments(a, false, vec4, stream);
 }
-
-// ---- the entry points of ABI 1-5: forwards
-static subgacc_join_desc join_desc(int form, int kind) {
-    subgacc_join_desc d = {};
-    d.struct_bytes = (int32_t)sizeof(subgacc_join_desc), d.form = form, d.payload_kind = kind;
-    return d;
-}
-#define SG_DESC_SEGMENTS(d) (d).own = own, (d).partner = partner, (d).S = S, (d).pair_block = pair_block, (d).flags = flags
-
-extern "C" int subgacc_sjoin_fill(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices, const int32_t *spg_data_i32,
-                                  const double *spg_data_f64, const int64_t *own, const int64_t *partner, int64_t S, const int64_t *seg,
-                                  const float *table, int64_t table_rows, int32_t k, float *out_xz, int32_t *out_idx, int64_t *out_segid,
-                                  int32_t max_len, int64_t pair_block, int32_t *flags, void *stream) {
-    if ((spg_data_i32 != nullptr) == (spg_data_f64 != nullptr) || (spg_data_f64 && (out_idx || table)) || !spg_indptr)      // (their own messages)
-        return sjoin_fill_impl(spg_indptr, n_rows, spg_indices, spg_data_i32, spg_data_f64, own, partner, S, seg, table, table_rows, k,
-                               out_xz, out_idx, out_segid, max_len, pair_block, flags, stream);
-    subgacc_join_desc d = join_desc(SUBGACC_JOIN_ROWS, spg_data_f64 ? SUBGACC_JOIN_F64 : SUBGACC_JOIN_SFPTR);
-    d.row_off = spg_indptr, d.n_rows = n_rows, d.ids = spg_indices, d.max_len = max_len;
-    d.payload = spg_data_f64 ? (const void *)spg_data_f64 : (const void *)spg_data_i32;
-    SG_DESC_SEGMENTS(d), d.seg = seg, d.table = table, d.table_rows = table_rows, d.k = k;
-    d.out_xz = out_xz, d.out_idx = out_idx, d.out_segid = out_segid;
-    return subgacc_sjoin_fill_v2(&d, stream);
-}
-
-extern "C" int subgacc_sjoin_fill_rows(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
-                                       const int32_t *row_slot, const void *uniq_table, int64_t uniq_capacity, const int64_t *own,
-                                       const int64_t *partner, int64_t S, const int64_t *seg, const float *table, int64_t table_rows,
-                                       int32_t k, float *out_xz, int32_t *out_idx, int64_t *out_segid, int64_t pair_block,
-                                       int32_t *flags, void *stream) {
-    if (!row_len)
-        return sjoin_fill_rows_impl(row_len, n_rows, row_stride, row_ids, row_slot, uniq_table, uniq_capacity, own, partner, S, seg, table,
-                                    table_rows, k, out_xz, out_idx, out_segid, pair_block, flags, stream);
-    subgacc_join_desc d = join_desc(SUBGACC_JOIN_ROWS, SUBGACC_JOIN_SFPTR);
-    d.row_len = row_len, d.n_rows = n_rows, d.row_stride = row_stride, d.ids = row_ids, d.payload = row_slot;
-    d.uniq_table = uniq_table, d.uniq_capacity = uniq_capacity;
-    SG_DESC_SEGMENTS(d), d.seg = seg, d.table = table, d.table_rows = table_rows, d.k = k;
-    d.out_xz = out_xz, d.out_idx = out_idx, d.out_segid = out_segid;
-    return subgacc_sjoin_fill_v2(&d, stream);
-}
-
-extern "C" int subgacc_sjoin_fill_keyrows(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
-                                          const int32_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
-                                          const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz,
-                                          int64_t pair_block, int32_t *flags, void *stream) {
-    if (!row_len)
-        return sjoin_fill_keyrows_impl(row_len, n_rows, row_stride, row_ids, row_keys, own, partner, S, seg, num_walks, num_steps, out_xz,
-                                       pair_block, flags, stream);
-    subgacc_join_desc d = join_desc(SUBGACC_JOIN_ROWS, SUBGACC_JOIN_KEY32);
-    d.row_len = row_len, d.n_rows = n_rows, d.row_stride = row_stride, d.ids = row_ids, d.payload = row_keys;
-    SG_DESC_SEGMENTS(d), d.seg = seg, d.num_walks = num_walks, d.num_steps = num_steps, d.out_xz = out_xz;
-    return subgacc_sjoin_fill_v2(&d, stream);
-}
-
-extern "C" int subgacc_sjoin_fill_keyrows64(const int32_t *row_len, int64_t n_rows, int64_t row_stride, const int32_t *row_ids,
-                                            const uint64_t *row_keys, const int64_t *own, const int64_t *partner, int64_t S,
-                                            const int64_t *seg, int32_t num_walks, int32_t num_steps, float *out_xz,
-                                            int64_t pair_block, int32_t *flags, void *stream) {
-    if (!row_len)
-        return sjoin_fill_keyrows64_impl(row_len, n_rows, row_stride, row_ids, row_keys, own, partner, S, seg, num_walks, num_steps,
-                                         out_xz, pair_block, flags, stream);
-    subgacc_join_desc d = join_desc(SUBGACC_JOIN_ROWS, SUBGACC_JOIN_KEY64);
-    d.row_len = row_len, d.n_rows = n_rows, d.row_stride = row_stride, d.ids = row_ids, d.payload = row_keys;
-    SG_DESC_SEGMENTS(d), d.seg = seg, d.num_walks = num_walks, d.num_steps = num_steps, d.out_xz = out_xz;
-    return subgacc_sjoin_fill_v2(&d, stream);
-}
-
-extern "C" int subgacc_sjoin_fill_keys(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices, const int32_t *spg_keys,
-                                       const int64_t *own, const int64_t *partner, int64_t S, const int64_t *seg, int32_t num_walks,
-                                       int32_t num_steps, float *out_xz, int64_t *out_segid, int32_t max_len, int64_t pair_block,
-                                       int32_t *flags, void *stream) {
-    if (!spg_indptr)
-        return sjoin_fill_keys_impl(spg_indptr, n_rows, spg_indices, spg_keys, own, partner, S, seg, num_walks, num_steps, out_xz, out_segid,
-                                    max_len, pair_block, flags, stream);
-    subgacc_join_desc d = join_desc(SUBGACC_JOIN_ROWS, SUBGACC_JOIN_KEY32);
-    d.row_off = spg_indptr, d.n_rows = n_rows, d.ids = spg_indices, d.payload = spg_keys, d.max_len = max_len;
-    SG_DESC_SEGMENTS(d), d.seg = seg, d.num_walks = num_walks, d.num_steps = num_steps, d.out_xz = out_xz, d.out_segid = out_segid;
-    return subgacc_sjoin_fill_v2(&d, stream);
-}
-
-extern "C" int subgacc_sjoin_counts(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices, const int32_t *spg_data_i32,
-                                    const int64_t *own, const int64_t *partner, int64_t S, int64_t table_rows, float *out_counts,
-                                    int32_t max_len, int64_t pair_block, int32_t *flags, void *stream) {
-    if (!spg_indptr)
-        return sjoin_counts_impl(spg_indptr, n_rows, spg_indices, spg_data_i32, own, partner, S, table_rows, out_counts, max_len, pair_block,
-                                 flags, stream);
-    subgacc_join_desc d = join_desc(SUBGACC_JOIN_COUNTS, SUBGACC_JOIN_SFPTR);
-    d.row_off = spg_indptr, d.n_rows = n_rows, d.ids = spg_indices, d.payload = spg_data_i32, d.max_len = max_len;
-    SG_DESC_SEGMENTS(d), d.table_rows = table_rows, d.out_counts = out_counts;
-    return subgacc_sjoin_fill_v2(&d, stream);
-}
-
-extern "C" int subgacc_sjoin_pairs(const int64_t *spg_indptr, int64_t n_rows, const int32_t *spg_indices, const int32_t *spg_data_i32,
-                                   const int64_t *own, const int64_t *partner, int64_t S, const int64_t *seg, int32_t *out_pairs,
-                                   int32_t *out_mult, int32_t *out_cnt, int32_t max_len, int64_t pair_block, int32_t *flags, void *stream) {
-    if (!spg_indptr)
-        return sjoin_pairs_impl(spg_indptr, n_rows, spg_indices, spg_data_i32, own, partner, S, seg, out_pairs, out_mult, out_cnt, max_len,
-                                pair_block, flags, stream);
-    subgacc_join_desc d = join_desc(SUBGACC_JOIN_PAIRS, SUBGACC_JOIN_SFPTR);
-    d.row_off = spg_indptr, d.n_rows = n_rows, d.ids = spg_indices, d.payload = spg_data_i32, d.max_len = max_len;
-    SG_DESC_SEGMENTS(d), d.seg = seg, d.out_pairs = out_pairs, d.out_mult = out_mult, d.out_cnt = out_cnt;
-    return subgacc_sjoin_fill_v2(&d, stream);
-}
-#undef SG_DESC_SEGMENTS

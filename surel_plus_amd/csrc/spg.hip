@@ -464,3 +464,50 @@ extern "C" int subgacc_finish_rows(int32_t *row_ids, const uint64_t *row_keys, c
     SG_LAUNCH_CHECK();
     return SUBGACC_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Packed rows -> headed rows (ABI 7): the resident store of a serving loop on whole 128-byte lines (include/subgacc.h: the HEADED
+// layout of subgacc_join_desc).  One wavefront per row, four rows per workgroup: the row's length goes into slot 0 of its ids, its
+// members behind it, payloads at the same pitch -- a streaming copy (reads and writes of consecutive lanes on consecutive words).
+namespace subgacc {
+template <typename P>
+__global__ __launch_bounds__(256) void rows_to_headed_kernel(const int64_t *__restrict__ row_off, int64_t n, const int32_t *__restrict__ ids,
+                                                             const P *__restrict__ payload, int64_t stride, int32_t *__restrict__ out_ids,
+                                                             P *__restrict__ out_payload, int32_t *__restrict__ flags) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t r = xcd_item(blockIdx.x, gridDim.x) * 4 + threadIdx.x / kWave;
+    if (r >= n) return;
+    const int64_t beg = row_off[r];
+    int64_t len = row_off[r + 1] - beg;
+    if (len > stride - 1) {        // does not fit its slot: cut (never out of bounds), and said
+        len = stride - 1;
+        if (lane == 0 && flags) atomicOr(&flags[3], 1);
+    }
+    int32_t *oi = out_ids + r * stride;
+    P *op = out_payload + r * stride;
+    if (lane == 0) oi[0] = (int32_t)len;
+    for (int64_t t = lane; t < len; t += kWave) {
+        oi[1 + t] = __builtin_nontemporal_load(&ids[beg + t]);
+        op[t] = __builtin_nontemporal_load(&payload[beg + t]);
+    }
+}
+}  // namespace subgacc
+
+extern "C" int subgacc_rows_to_headed(const int64_t *row_off, int64_t n_rows, const int32_t *ids, const void *payload, int32_t payload_bytes,
+                                      int64_t row_stride, int32_t *out_ids, void *out_payload, int32_t *flags, void *stream) {
+    using namespace subgacc;
+    SG_REQUIRE(n_rows >= 0 && row_stride > 1 && row_stride < (1ll << 31) && (payload_bytes == 4 || payload_bytes == 8), SUBGACC_ERR_BADARG,
+               "rows_to_headed: bad arguments (row_stride > 1, payload_bytes 4 or 8)");
+    if (n_rows == 0) return SUBGACC_OK;
+    SG_REQUIRE(row_off && ids && payload && out_ids && out_payload, SUBGACC_ERR_BADARG, "rows_to_headed: null argument");
+    const int64_t grid = xcd_grid((n_rows + 3) / 4);
+    SG_REQUIRE(grid < (1ll << 31), SUBGACC_ERR_BADARG, "rows_to_headed: too many rows in one call");
+    if (payload_bytes == 4)
+        hipLaunchKernelGGL(rows_to_headed_kernel<int32_t>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, row_off, n_rows, ids,
+                           (const int32_t *)payload, row_stride, out_ids, (int32_t *)out_payload, flags);
+    else
+        hipLaunchKernelGGL(rows_to_headed_kernel<unsigned long long>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, row_off, n_rows,
+                           ids, (const unsigned long long *)payload, row_stride, out_ids, (unsigned long long *)out_payload, flags);
+    SG_LAUNCH_CHECK();
+    return SUBGACC_OK;
+}

@@ -37,6 +37,14 @@ namespace subgacc {
 #define SG_ROW_STORE(p, v) (*(p) = (v))
 #endif
 
+// Scalar registers: gfx950 holds 800 per SIMD -- up to 100 per wave leave all 8 wave slots usable; the 80 of rounds 2-5 dated from a
+// 10-wave device and made the allocator park uniform values in vector lanes (v_writelane / v_readlane) for nothing.
+#ifndef SG_ROWS_SGPR
+#define SG_ROWS_SGPR 102
+#endif
+#ifndef SG_ROWS_KR_WAVES1
+#define SG_ROWS_KR_WAVES1 7
+#endif
 #ifndef SG_LAST_HOP_ID     // 1: with hop records, the last hop reads the bare id from `indices` (A/B: tools/ab.py)
 #define SG_LAST_HOP_ID 1
 #endif
@@ -52,10 +60,15 @@ namespace subgacc {
 // dropped needs neither the table of distinct LP rows nor their numbering -- the join turns a key into its feature row
 // arithmetically -- so the whole fold / registration / flush stage (a quarter of the kernel's vector instructions, its
 // global atomics) and the first-visit bookkeeping (minq: one LDS atomic per visit, 4 bytes of LDS per slot) fall away.
-template <bool IDX64, int RNG, int MH, int SPL, int NT, int REC = 0, bool K32 = false, bool KR = false>
+// EPLP (key rows): members per lane the epilogue's sort provides registers for, ns <= EPLP * NT (0: SPL, or 7 for one wave x 8 slots:
+// a 512-slot table holds 408) -- every reference shape has M * m + 1 <= 640, five members per lane of 128: 69 VGPRs instead of 80 + scratch.
+template <bool IDX64, int RNG, int MH, int SPL, int NT, int REC = 0, bool K32 = false, bool KR = false, int EPLP = 0>
 // (waves per SIMD asked of the register allocator: the table form with 32-bit counts holds 12 bytes of LDS per slot + the fold table,
 //  ~15 KB per workgroup of two waves = 5 waves per SIMD whatever the registers; 64-bit counts on 128 lanes, 10.5 KB: 7; the rest 8)
-__global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (KR ? 5 : (NT == 128 ? 7 : 8))) __attribute__((amdgpu_num_sgpr(80))) void walk_rows_kernel(const WalkArgs a) {
+//  key rows with 32-bit counts: 6 asked for; with five members per lane in the sort (EPLP = 5) the kernel lands on 72 VGPRs = SEVEN waves
+//  per SIMD without a spill -- on a graph with id locality the kernel is bound by its instructions and LDS round trips, not by missed
+//  lines, and the seventh wave is worth 6 %: cit2loc 0.627 -> 0.588 ms, profiles/r42_sort_ab.log; one wave per root: SG_ROWS_KR_WAVES1)
+__global__ __launch_bounds__(NT, K32 ? (KR ? (NT == 64 ? SG_ROWS_KR_WAVES1 : 6) : 5) : (KR ? 5 : (NT == 128 ? 7 : 8))) __attribute__((amdgpu_num_sgpr(SG_ROWS_SGPR))) void walk_rows_kernel(const WalkArgs a) {
     static_assert(!KR || SPL % 4 == 0, "key rows: 4-slot chunks");
     constexpr bool KR64 = KR && !K32;      // rows of 64-bit LP keys
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -503,30 +516,43 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (KR ? 5 : (NT == 128 ? 7 :
         if (tid == 0) a.nsize[i] = ns;
         const int32_t mn = NT > kWave ? min(min(red[0], red[1]), min(red[2], red[3])) : (int32_t)min(umn, 0x7FFFFFFFu);
         const int32_t mx = NT > kWave ? max(max(red[4], red[5]), max(red[6], red[7])) : vmax;
-        // The sort: a two-level distribution sort in LDS.  Level 1 is a histogram over B buckets of equal id WIDTH (the top bits of
-        // id - min); level 2 gives bucket b as many sub-buckets as it has members -- sub-bucket = offset inside b's window scaled by
-        // b's count -- so that idx2 = start1[b] + sub is a monotone map of the ids onto [0, ns) that follows the set's own
-        // distribution (a piecewise-linear equalisation).  With ids spread evenly over their range (a structureless graph) level 1
-        // alone had ~3 members per bucket; on a graph with id locality most of a set lies in one community = ONE bucket of 200+
-        // members, and ranking inside it by counting was quadratic (cit2-like graph with communities: 3.4x the vector instructions,
-        // the kernel 2x slower -- profiles/r05u_sq_locality.csv).  Sub-buckets hold ~1 member either way; the ranking by counting
-        // that remains runs over those.
+        // The sort: a distribution sort in LDS of up to three levels.
+        //   Level 1: B <= NT buckets of equal id WIDTH (the top bits of id - min), one counter per lane: count with a returning LDS
+        //     atomic (the return is the member's arrival order), scan into offsets.  Ids spread evenly over their range (a
+        //     structureless graph) lie ~3 to a bucket and the sort is done.
+        //   Level 2, where a bucket is still crowded (workgroup-uniform: > kFineAbove members): bucket b is cut into as many
+        //     sub-buckets of equal width as it has members -- idx = start[b] + floor(offset in b's window * count_b / width), exact
+        //     (umulhi) -- a monotone map of the ids onto [0, ns) that follows the set's own distribution (a piecewise-linear
+        //     equalisation); 16-bit counters, two per word, scanned in place.  A graph with id locality puts most of a set into ONE
+        //     community of consecutive ids = one bucket (32,768 ids wide on a 2.9 M-node graph).
+        //   Level 3, where a sub-bucket is STILL crowded: level 2 cuts a bucket that holds a community of 2,048 ids into sub-buckets
+        //     ~130 ids wide, ~16 members each, and the ranking by counting below was an LDS latency loop of up to 30 trips (cit2loc:
+        //     0.2 of the kernel's 0.68 ms -- profiles/r40_loc_phase_ms.log).  The same cut once more, of every level-2 sub-bucket by
+        //     ITS count, with the position inside the sub-bucket's id window as a float: any monotone map of the ids of one sub-bucket
+        //     onto [0, count) will do -- rounding only moves the balance, and float multiply / subtract / truncate are monotone.
+        //     (Measured instead and not kept: a level 1 of 1,024 buckets in 16-bit counters, which makes level 3 rare -- its wider
+        //     zeroing and scan cost every set more than level 3 costs the crowded ones: cit2loc 0.617 against 0.588 ms, twitter and
+        //     collab +3-4 %, profiles/r43_sort_ab.log.)
+        // What is left in a (sub-)bucket is ranked by counting.
         unsigned long long *A = (unsigned long long *)lds_raw;            // [ns <= stride] over the counts and the ids
         // 64-bit keys do not fit beside the id in a sort element: they stay where they were packed (KK[p], never moved) and the
         // element carries p -- (id << 32 | p) sorts like (id << 32 | key), ids being distinct
         unsigned long long *KK = A + a.stride;                            // [ns] (KR64 only)
-        int32_t *start = (int32_t *)(lds_raw + (KR64 ? 16 : 8) * (size_t)a.stride);       // [B+1] level-1 counts, then offsets
-        uint32_t *cnt2 = (uint32_t *)(start + NT + 1);                      // [(ns+2)/2 + 1] level-2 counts, two 16-bit counters per word
+        constexpr int CW = 4;                          // counter words per lane in the scan of levels 2 and 3
+        constexpr int kFineAbove = 12;                 // a finer level from this many members in one (sub-)bucket on
+        int32_t *start = (int32_t *)(lds_raw + (KR64 ? 16 : 8) * (size_t)a.stride);      // [B+1] level-1 counts, then offsets
+        uint32_t *cnt2 = (uint32_t *)(start + NT + 1);                                   // [(ns+2)/2 + 1] counters of levels 2 and 3, then offsets (+ the total)
         int logb = 0;
         while ((1 << logb) < ns && (2 << logb) <= T / 4 && (2 << logb) <= NT) ++logb;
         const int B = 1 << logb;
+        const int W2 = (ns + 2) / 2;                   // words of the counters 0 .. ns of levels 2 and 3 (<= CW * NT: checked at launch)
         const uint32_t range = (uint32_t)(mx - mn) + 1u;
         const int Ls = (range <= 1u) ? 0 : (32 - __builtin_clz(range - 1u));
         const int bshift = Ls > logb ? Ls - logb : 0;
-        constexpr int kFineAbove = 12;                 // level 2 from this many members in one level-1 bucket on
-        constexpr int CW = 4;                          // level-2 words per lane in the scan: (stride + 2) / 2 + 1 <= CW * NT (checked at launch)
-        const int W2 = (ns + 2) / 2 + 1;               // words that hold counters 0 .. ns (counter ns stays 0: its offset is the total)
         if (tid < B) start[tid] = 0;
+#pragma unroll
+        for (int c = 0; c < CW; ++c)
+            if (c * NT + tid < W2) cnt2[c * NT + tid] = 0u;
         {
             int p = wbase + incl - cnt;
 #pragma unroll
@@ -543,23 +569,63 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (KR ? 5 : (NT == 128 ? 7 :
         }
         __syncthreads();
         SG_HOOK_RSTAMP(11);
-        unsigned long long el[SPL];
-        uint32_t bk[SPL];
-        int32_t pos[SPL];                           // arrival order inside the sub-bucket, then the final position
+        // one more member of (sub-)bucket idx: -> how many came before it
+        auto count16 = [](uint32_t *cw, uint32_t idx) -> int32_t {
+            const uint32_t sh = (idx & 1u) * 16u;
+            return (int32_t)((atomicAdd(&cw[idx >> 1], 1u << sh) >> sh) & 0xFFFFu);
+        };
+        // exclusive scan of 2 * nw 16-bit counters in place (offsets <= ns < 2^16), CW consecutive words per lane; word nw receives
+        // the total in both halves (the end of the last bucket); -> the largest count
+        auto scan16 = [&](uint32_t *cw, int nw) -> int32_t {
+            uint32_t w[CW];
+            int32_t s2 = 0, mc = 0;
 #pragma unroll
-        for (int e = 0; e < SPL; ++e) {
+            for (int c = 0; c < CW; ++c) {
+                const int x = tid * CW + c;
+                w[c] = x < nw ? cw[x] : 0u;
+                s2 += (int32_t)((w[c] & 0xFFFFu) + (w[c] >> 16));
+                mc = max(mc, max((int32_t)(w[c] & 0xFFFFu), (int32_t)(w[c] >> 16)));
+            }
+            const int32_t inc = wave_scan_add_i32_incl(s2);
+            mc = wave_red_max_i32(mc);
+            int32_t run = inc - s2;
+            if (NT > kWave) {
+                if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc, red[4 + tid / kWave] = mc;
+                __syncthreads();
+                for (int w2 = 0; w2 < tid / kWave; ++w2) run += red[12 + w2];
+                mc = red[4];
+                for (int w2 = 1; w2 < NT / kWave; ++w2) mc = max(mc, red[4 + w2]);
+            }
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                const int x = tid * CW + c;
+                const uint32_t lo16 = (uint32_t)run;
+                run += (int32_t)(w[c] & 0xFFFFu);
+                const uint32_t hi16 = (uint32_t)run;
+                run += (int32_t)(w[c] >> 16);
+                if (x < nw) cw[x] = lo16 | (hi16 << 16);
+                if (x == nw - 1) cw[nw] = (uint32_t)run * 0x10001u;
+            }
+            return mc;
+        };
+        constexpr int EPL = EPLP ? EPLP : (NT == 64 && SPL == 8 ? 7 : SPL);      // members per lane: ns <= EPL * NT (checked at launch)
+        unsigned long long el[EPL];
+        int32_t pos[EPL];                           // arrival order inside the (sub-)bucket, then the final position
+        // (the member's level-1 bucket, (id - mn) >> bshift, is worked out again wherever it is needed: two instructions against a
+        //  register per member held across every phase of the sort)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
             if (e * NT >= ns) break;
             const int x = e * NT + tid;
             if (x < ns) {
                 el[e] = A[x];
-                bk[e] = ((uint32_t)(el[e] >> 32) - (uint32_t)mn) >> bshift;
-                pos[e] = atomicAdd(&start[bk[e]], 1);
+                pos[e] = atomicAdd(&start[((uint32_t)(el[e] >> 32) - (uint32_t)mn) >> bshift], 1);
             }
         }
         __syncthreads();
         SG_HOOK_RSTAMP(12);
         int32_t maxc;
-        {
+        {   // level 1: exclusive scan over the B <= NT buckets, one bucket per lane
             const int32_t c = tid < B ? start[tid] : 0;
             const int32_t inc = wave_scan_add_i32_incl(c);
             const int32_t mc = wave_red_max_i32(c);
@@ -578,97 +644,86 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (KR ? 5 : (NT == 128 ? 7 :
         }
         __syncthreads();
         SG_HOOK_RSTAMP(13);
-        int blo[SPL], bhi[SPL];
-        // level 2 only where level 1 left a crowded bucket (workgroup-uniform): evenly spread ids -- every set of a structureless
-        // graph -- keep the short path (collab: the kernel is bound by vector instructions, level 2 for every set cost it 8 %)
-        if (maxc <= kFineAbove) {
+        const uint16_t *off2 = (const uint16_t *)cnt2;
+        uint32_t bb[EPL];          // the member's (sub-)bucket: first position | end << 16 (positions <= ns < 2^16)
 #pragma unroll
-            for (int e = 0; e < SPL; ++e) {
+        for (int e = 0; e < EPL; ++e) {
+            if (e * NT >= ns) break;
+            if (e * NT + tid < ns) {
+                const uint32_t b1 = ((uint32_t)(el[e] >> 32) - (uint32_t)mn) >> bshift;
+                bb[e] = (uint32_t)start[b1] | ((uint32_t)start[b1 + 1] << 16);
+            }
+        }
+        // levels 2 and 3: one loop body (a second copy of it cost 6 VGPRs and 40 bytes of scratch); the counters are the same words
+#pragma unroll 1
+        for (int lvl = 0; lvl < 2 && maxc > kFineAbove; ++lvl) {
+            if (lvl) {
+                __syncthreads();        // every lane has read its offsets of the level before
+#pragma unroll
+                for (int c = 0; c < CW; ++c)
+                    if (c * NT + tid < W2) cnt2[c * NT + tid] = 0u;
+                __syncthreads();
+            }
+            uint32_t idx2[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
                 if (e * NT >= ns) break;
                 if (e * NT + tid < ns) {
-                    blo[e] = start[bk[e]];
-                    bhi[e] = start[bk[e] + 1];
+                    const uint32_t ido = (uint32_t)(el[e] >> 32) - (uint32_t)mn, b1 = ido >> bshift;
+                    const uint32_t lo1 = (uint32_t)start[b1], kb = (uint32_t)start[b1 + 1] - lo1;
+                    const uint32_t off = ido - (b1 << bshift);                                             // < 2^bshift
+                    uint32_t sub = bshift ? __umulhi(off << (32 - bshift), kb) : 0u;                       // floor(off * kb / 2^bshift) < kb
+                    if (lvl) {
+                        // off * kb / 2^bshift - sub: where inside its level-2 sub-bucket's id window the member lies, [0, 1)
+                        const float fr = (float)off * __builtin_ldexpf((float)kb, -bshift) - (float)sub;
+                        const int k2 = (int)(bb[e] >> 16) - (int)(bb[e] & 0xFFFFu);
+                        sub = (uint32_t)min(max((int)(fr * (float)k2), 0), k2 - 1);
+                        idx2[e] = (bb[e] & 0xFFFFu) + sub;
+                    } else {
+                        idx2[e] = lo1 + sub;
+                    }
+                    pos[e] = count16(cnt2, idx2[e]);
                 }
             }
-        } else {
+            __syncthreads();
+            maxc = scan16(cnt2, W2);
+            __syncthreads();
 #pragma unroll
-        for (int c = 0; c < CW; ++c)
-            if (c * NT + tid < W2) cnt2[c * NT + tid] = 0u;
-        __syncthreads();
-        uint32_t idx2[SPL];
+            for (int e = 0; e < EPL; ++e) {
+                if (e * NT >= ns) break;
+                if (e * NT + tid < ns) bb[e] = (uint32_t)off2[idx2[e]] | ((uint32_t)off2[idx2[e] + 1] << 16);
+            }
+        }
 #pragma unroll
-        for (int e = 0; e < SPL; ++e) {
+        for (int e = 0; e < EPL; ++e) {
             if (e * NT >= ns) break;
-            if (e * NT + tid < ns) {
-                const uint32_t lo1 = (uint32_t)start[bk[e]], kb = (uint32_t)start[bk[e] + 1] - lo1;
-                const uint32_t off = ((uint32_t)(el[e] >> 32) - (uint32_t)mn) - (bk[e] << bshift);      // < 2^bshift
-                const uint32_t sub = bshift ? __umulhi(off << (32 - bshift), kb) : 0u;                 // floor(off * kb / 2^bshift) < kb
-                idx2[e] = lo1 + sub;
-                const uint32_t sh = (idx2[e] & 1u) * 16u;
-                pos[e] = (int32_t)((atomicAdd(&cnt2[idx2[e] >> 1], 1u << sh) >> sh) & 0xFFFFu);
-            }
-        }
-        __syncthreads();
-        {   // exclusive scan of the ns + 1 level-2 counters, in place (offsets <= ns < 2^16): CW consecutive words per lane
-            uint32_t w[CW];
-            int32_t s2 = 0;
-#pragma unroll
-            for (int c = 0; c < CW; ++c) {
-                const int x = tid * CW + c;
-                w[c] = x < W2 ? cnt2[x] : 0u;
-                s2 += (int32_t)((w[c] & 0xFFFFu) + (w[c] >> 16));
-            }
-            const int32_t inc = wave_scan_add_i32_incl(s2);
-            int32_t run = inc - s2;
-            if (NT > kWave) {
-                if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc;
-                __syncthreads();
-                for (int w2 = 0; w2 < tid / kWave; ++w2) run += red[12 + w2];
-            }
-#pragma unroll
-            for (int c = 0; c < CW; ++c) {
-                const int x = tid * CW + c;
-                const uint32_t lo16 = (uint32_t)run;
-                run += (int32_t)(w[c] & 0xFFFFu);
-                const uint32_t hi16 = (uint32_t)run;
-                run += (int32_t)(w[c] >> 16);
-                if (x < W2) cnt2[x] = lo16 | (hi16 << 16);
-            }
-        }
-        __syncthreads();
-        const uint16_t *off2 = (const uint16_t *)cnt2;
-#pragma unroll
-        for (int e = 0; e < SPL; ++e) {
-            if (e * NT >= ns) break;
-            if (e * NT + tid < ns) {
-                blo[e] = off2[idx2[e]];
-                bhi[e] = off2[idx2[e] + 1];
-            }
-        }
-        }
-#pragma unroll
-        for (int e = 0; e < SPL; ++e) {
-            if (e * NT >= ns) break;
-            if (e * NT + tid < ns) A[blo[e] + pos[e]] = el[e];         // every packed element was read before the barriers above
+            if (e * NT + tid < ns) A[(bb[e] & 0xFFFFu) + (uint32_t)pos[e]] = el[e];         // every packed element was read before the barriers above
         }
         __syncthreads();
         SG_HOOK_RSTAMP(14);
         const uint32_t *Ahi = (const uint32_t *)A;
 #pragma unroll
-        for (int e = 0; e < SPL; ++e) {
+        for (int e = 0; e < EPL; ++e) {
             if (e * NT >= ns) break;
             if (e * NT + tid < ns) {
                 const uint32_t me = (uint32_t)(el[e] >> 32);
                 int rank = 0;       // ids are distinct within a set: the high word of A decides
+                const int lo = (int)(bb[e] & 0xFFFFu), hi = (int)(bb[e] >> 16);
+                int t2 = lo;
+#pragma unroll 1         // (four members per trip: the loop is LDS latency, not issue)
+                for (; t2 + 3 < hi; t2 += 4) {
+                    const uint32_t a0 = Ahi[2 * t2 + 1], a1 = Ahi[2 * t2 + 3], a2 = Ahi[2 * t2 + 5], a3 = Ahi[2 * t2 + 7];
+                    rank += (a0 < me ? 1 : 0) + (a1 < me ? 1 : 0) + (a2 < me ? 1 : 0) + (a3 < me ? 1 : 0);
+                }
 #pragma unroll 1
-                for (int t2 = blo[e]; t2 < bhi[e]; ++t2) rank += (Ahi[2 * t2 + 1] < me) ? 1 : 0;
-                pos[e] = blo[e] + rank;
+                for (; t2 < hi; ++t2) rank += (Ahi[2 * t2 + 1] < me) ? 1 : 0;
+                pos[e] = lo + rank;
             }
         }
         __syncthreads();        // every rank is known: the bucket-grouped array can become the sorted one, in place
         SG_HOOK_RSTAMP(15);
 #pragma unroll
-        for (int e = 0; e < SPL; ++e) {
+        for (int e = 0; e < EPL; ++e) {
             if (e * NT >= ns) break;
             if (e * NT + tid < ns) A[pos[e]] = el[e];
         }
@@ -959,13 +1014,18 @@ int launch_walk_rows(const WalkArgs &a, bool indptr64, int rng_mode, size_t lds,
         // walk tables, the keys leave through set_keys.  1,024-slot table, 128 lanes x 2 walks x 8 slots, ~15 KB of LDS per root.
         if (a.m != 4 || a.m * a.shift + 1 > 63 || a.T != 1024 || !a.set_keys || ((int64_t)a.stride + 2) / 2 + 1 > 4 * 128) return 0;
         const size_t lds64 = kr_red_offset(1024, a.M, a.stride, 128, true) + 64 + 16;
-#define SG_KR64W(I64, RNGM)                                                                                           \
+#define SG_KR64W_E(I64, RNGM, EP)                                                                                     \
     do {                                                                                                             \
         if (rec)                                                                                                     \
-            hipLaunchKernelGGL((walk_rows_kernel<I64, RNGM, 4, 8, 128, I64 ? 16 : 8, false, true>), dim3((unsigned)grid), dim3(128), lds64, s, a); \
+            hipLaunchKernelGGL((walk_rows_kernel<I64, RNGM, 4, 8, 128, I64 ? 16 : 8, false, true, EP>), dim3((unsigned)grid), dim3(128), lds64, s, a); \
         else                                                                                                         \
-            hipLaunchKernelGGL((walk_rows_kernel<I64, RNGM, 4, 8, 128, 0, false, true>), dim3((unsigned)grid), dim3(128), lds64, s, a); \
+            hipLaunchKernelGGL((walk_rows_kernel<I64, RNGM, 4, 8, 128, 0, false, true, EP>), dim3((unsigned)grid), dim3(128), lds64, s, a); \
         return 1;                                                                                                    \
+    } while (0)
+#define SG_KR64W(I64, RNGM)                                  \
+    do {                                                     \
+        if (a.stride <= 7 * 128) SG_KR64W_E(I64, RNGM, 7);   \
+        SG_KR64W_E(I64, RNGM, 0);                            \
     } while (0)
         if (indptr64) {
             if (rr) SG_KR64W(true, SUBGACC_RNG_RAND_R);
@@ -974,6 +1034,7 @@ int launch_walk_rows(const WalkArgs &a, bool indptr64, int rng_mode, size_t lds,
         if (rr) SG_KR64W(false, SUBGACC_RNG_RAND_R);
         SG_KR64W(false, SUBGACC_RNG_PHILOX);
 #undef SG_KR64W
+#undef SG_KR64W_E
     }
     if (a.keyrows) {      // rows that carry the LP key itself: 32-bit counts, 128 lanes, 2 to 4 hops -- or not at all
         // (the epilogue's sort lives over the dead walk tables AND the Fisher-Yates draws behind them: packed members 8*stride,
@@ -982,13 +1043,19 @@ int launch_walk_rows(const WalkArgs &a, bool indptr64, int rng_mode, size_t lds,
         // (the reduction words sit behind the walk tables and behind the epilogue's sort, whichever reaches further: kr_red_offset)
         const bool one_wave = (nt64 || (!indptr64 && !nt128)) && a.m == 2 && a.T == 512;
         const size_t ldsk = kr_red_offset(a.T, a.M, a.stride, one_wave ? 64 : 128, false) + 64 + 16;
-#define SG_KR(I64, RNGM, MHH, SPLL)                                                                                  \
+#define SG_KR_E(I64, RNGM, MHH, SPLL, EP)                                                                            \
     do {                                                                                                             \
         if (rec)                                                                                                     \
-            hipLaunchKernelGGL((walk_rows_kernel<I64, RNGM, MHH, SPLL, 128, I64 ? 16 : 8, true, true>), dim3((unsigned)grid), dim3(128), ldsk, s, a); \
+            hipLaunchKernelGGL((walk_rows_kernel<I64, RNGM, MHH, SPLL, 128, I64 ? 16 : 8, true, true, EP>), dim3((unsigned)grid), dim3(128), ldsk, s, a); \
         else                                                                                                         \
-            hipLaunchKernelGGL((walk_rows_kernel<I64, RNGM, MHH, SPLL, 128, 0, true, true>), dim3((unsigned)grid), dim3(128), ldsk, s, a); \
+            hipLaunchKernelGGL((walk_rows_kernel<I64, RNGM, MHH, SPLL, 128, 0, true, true, EP>), dim3((unsigned)grid), dim3(128), ldsk, s, a); \
         return 1;                                                                                                    \
+    } while (0)
+#define SG_KR(I64, RNGM, MHH, SPLL) SG_KR_E(I64, RNGM, MHH, SPLL, 0)
+#define SG_KR8(I64, RNGM, MHH)                                           \
+    do {                                                                 \
+        if (a.stride <= 5 * 128) SG_KR_E(I64, RNGM, MHH, 8, 5);          \
+        SG_KR_E(I64, RNGM, MHH, 8, 0);                                   \
     } while (0)
 #define SG_KR64(I64, RNGM, MHH, SPLL)                                                                                \
     do {                                                                                                             \
@@ -1001,9 +1068,9 @@ int launch_walk_rows(const WalkArgs &a, bool indptr64, int rng_mode, size_t lds,
 #define SG_KR_MH(I64, RNGM)                                  \
     do {                                                     \
         if (a.T == 1024) {                                   \
-            if (a.m == 2) SG_KR(I64, RNGM, 2, 8);            \
-            if (a.m == 3) SG_KR(I64, RNGM, 3, 8);            \
-            SG_KR(I64, RNGM, 4, 8);                          \
+            if (a.m == 2) SG_KR8(I64, RNGM, 2);              \
+            if (a.m == 3) SG_KR8(I64, RNGM, 3);              \
+            SG_KR8(I64, RNGM, 4);                            \
         }                                                    \
         if ((nt64 || (!I64 && !nt128)) && a.m == 2) SG_KR64(I64, RNGM, 2, 8); \
         if (a.m == 2) SG_KR(I64, RNGM, 2, 4);                \
@@ -1019,6 +1086,8 @@ int launch_walk_rows(const WalkArgs &a, bool indptr64, int rng_mode, size_t lds,
 #undef SG_KR_MH
 #undef SG_KR64
 #undef SG_KR
+#undef SG_KR8
+#undef SG_KR_E
     }
     // 1,024-slot table with counts that fit 32 bits: 128 lanes x 8 slots, 12 bytes of LDS per slot -> 11 roots per CU
     // (dev builds: -DSG_DEV_ROWS_NT=256 keeps the 256-lane form).  int32 row offsets + 8-byte records / plain CSR only.

@@ -132,6 +132,16 @@ class SpG:
             raise ValueError("slot_table() belongs to a keyed() store; a plain SpG is joined with its Z_SF table")
         return KEY_ROWS_ENCODE
 
+    def aligned(self, pitch=None):
+        """The same store laid out for a SERVING loop (round 6): every row on whole 128-byte lines at a fixed pitch -- row r's ids
+        begin at r*pitch with the row's LENGTH in their first slot, its payload at the same pitch (include/subgacc.h: headed rows).
+        A join then needs no row pointer (a packed store reads a 128-byte line for 16 bytes of them, per row), and no row begins or
+        ends inside a line it shares with its neighbours.  -> HeadedSpG: gather / hgather / CapturedJoin(Pool) take it like the
+        store it was made from (same encode argument, bit-identical results); the count / pair / index forms and to_scipy() stay
+        with the packed store.  pitch: words between two rows, default the longest row + 1 rounded up to a multiple of 32; the store
+        grows by pitch / (mean row length) -- HBM is what an MI355X has plenty of (288 GB), lines per second it has not."""
+        return HeadedSpG.from_spg(self, pitch)
+
     def to_scipy(self):
         import scipy.sparse as sp
         nnz = self.nnz
@@ -140,6 +150,68 @@ class SpG:
 
 
 KEY_ROWS_ENCODE = "key rows"      # StridedSpG.slot_table() of a key-rows batch: the join needs no table
+
+
+class HeadedSpG:
+    """A resident store in the HEADED row layout of include/subgacc.h (ABI 7): `ids` int32 [n_rows * pitch] -- ids[r*pitch] = the
+    length of row r, its members (ascending node ids) behind it --, `data` [n_rows * pitch] with member t's payload at r*pitch + t
+    (int32 SFptr+1, int32 LP keys of a keyed() store, float64 PPR scores).  Made by SpG.aligned(); joined by gather / hgather /
+    gather_many / CapturedJoin / CapturedJoinPool exactly like the SpG it came from."""
+
+    def __init__(self, ids, data, pitch, n_rows, max_len, shape, max_data=None):
+        assert ids.dtype == torch.int32 and data.dtype in (torch.int32, torch.float64) and pitch > 1
+        self.ids, self.data, self.pitch, self.n_rows = ids, data, int(pitch), int(n_rows)
+        self.max_len = int(max_len)              # the longest row (<= pitch - 1): sizes the worst-case output of a one-call join
+        self.max_data, self.shape, self.device = max_data, shape, ids.device
+        self.keyrows, self.key_M, self.key_m = False, 0, 0
+
+    @classmethod
+    def from_spg(cls, z, pitch=None):
+        if not isinstance(z, SpG):
+            raise TypeError("aligned() lays a packed SpG out again")
+        need = int(z.max_len) + 1
+        pitch = -(-need // 32) * 32 if pitch is None else int(pitch)
+        if pitch < need:
+            raise ValueError(f"pitch {pitch} < longest row + 1 = {need}")
+        dev = z.device
+        ids = torch.empty(max(z.n_rows, 1) * pitch, dtype=torch.int32, device=dev)
+        data = torch.empty(max(z.n_rows, 1) * pitch, dtype=z.data.dtype, device=dev)
+        flags = torch.zeros(4, dtype=torch.int32, device=dev)
+        check(lib().subgacc_rows_to_headed(ptr(z.indptr), z.n_rows, ptr(z.indices), ptr(z.data), z.data.element_size(), pitch, ptr(ids),
+                                           ptr(data), ptr(flags), stream_ptr()))
+        if int(flags[3].item()) & 1:
+            raise _lib.SubgAccError("aligned(): a row is longer than SpG.max_len says")
+        h = cls(ids, data, pitch, z.n_rows, z.max_len, z.shape, max_data=z.max_data)
+        if z.keyrows:
+            h.keyrows, h.key_M, h.key_m = True, z.key_M, z.key_m
+        return h
+
+    @property
+    def nbytes(self):
+        return self.ids.numel() * 4 + self.data.numel() * self.data.element_size()
+
+    def slot_table(self):
+        if not self.keyrows:
+            raise ValueError("slot_table() belongs to a keyed() store; a plain SpG is joined with its Z_SF table")
+        return KEY_ROWS_ENCODE
+
+    def row_lengths(self):
+        """int32 [n_rows]: what the rows' first slots hold"""
+        return self.ids.view(-1, self.pitch)[: self.n_rows, 0].contiguous()
+
+    def to_spg(self):
+        """back to packed rows (tests; the layout is for serving)"""
+        lens = self.row_lengths().long()
+        indptr = torch.zeros(self.n_rows + 1, dtype=torch.int64, device=self.device)
+        torch.cumsum(lens, 0, out=indptr[1:])
+        col = torch.arange(self.pitch - 1, device=self.device)[None, :]
+        keep = col < lens[:, None]
+        idx = self.ids.view(-1, self.pitch)[: self.n_rows, 1:][keep]
+        dat = self.data.view(-1, self.pitch)[: self.n_rows, : self.pitch - 1][keep]
+        z = SpG(indptr, idx.contiguous(), dat.contiguous(), max_len=self.max_len, shape=self.shape, max_data=self.max_data)
+        if self.keyrows:
+            z.keyrows, z.key_M, z.key_m = True, self.key_M, self.key_m
+        return z
 
 
 class StridedSpG:

@@ -17,13 +17,13 @@ from ._lib import JOIN_COUNTS, JOIN_F64, JOIN_KEY32, JOIN_KEY64, JOIN_PAIRS, JOI
 
 NO_ROOT = -2 ** 31      # include/subgacc.h: SUBGACC_NO_ROOT
 from .sampler import _timed
-from .spg import SpG, StridedSpG
+from .spg import HeadedSpG, SpG, StridedSpG
 
 _scipy_cache = weakref.WeakKeyDictionary()
 
 
 def _as_spg(x):
-    if isinstance(x, (SpG, StridedSpG)):
+    if isinstance(x, (SpG, StridedSpG, HeadedSpG)):
         return x
     try:
         hit = _scipy_cache.get(x)
@@ -78,6 +78,8 @@ def sjoin(spg, own, partner, encode=None, ptr_mode=True, return_index=False, pai
     ws = torch.empty(L.subgacc_sjoin_workspace_bytes(S), dtype=torch.uint8, device=dev)
     if isinstance(spg, StridedSpG):
         return _sjoin_strided(spg, own, partner, seg, flags, ws, encode, ptr_mode, return_index, pair_block, out, lazy)
+    if isinstance(spg, HeadedSpG):
+        return _sjoin_headed(spg, own, partner, seg, flags, encode, ptr_mode, return_index, pair_block, out, lazy)
     check(L.subgacc_sjoin_sizes(ptr(spg.indptr), spg.n_rows, ptr(own), ptr(partner), S, ptr(seg), ptr(flags), ptr(ws),
                                 ws.numel(), st))
     is_f64 = spg.data.dtype == torch.float64
@@ -228,6 +230,70 @@ def _sjoin_strided(spg, own, partner, seg, flags, ws, encode, ptr_mode, return_i
         join_fill(JOIN_ROWS, JOIN_SFPTR, row_len=spg.nsize, n_rows=spg.n_rows, row_stride=spg.stride, ids=spg.indices, payload=spg.slot,
                   uniq_table=tab, uniq_capacity=cap, own=own, partner=partner, S=S, seg=seg, pair_block=pair_block,
                   table=enc, table_rows=enc.shape[0], k=k, out_xz=res, out_segid=segid, flags=flags)
+    return res, (seg if ptr_mode else _with_pointers(segid, seg)), flags
+
+
+def _sjoin_headed(spg, own, partner, seg, flags, encode, ptr_mode, return_index, pair_block, out, lazy):
+    """sjoin over a HeadedSpG (a resident store on whole lines, include/subgacc.h: headed rows): mirrored lists.  The size pass is
+    the library's one-launch form (SUBGACC_JOIN_OPT_SIZES): lazily it and the fill are ONE call into a worst-case `out`; eagerly it
+    runs alone first (no output: the "count" call), the host reads [R, status] from pinned memory, and the fill follows into R rows."""
+    from .spg import KEY_ROWS_ENCODE
+    dev, S = spg.device, own.numel()
+    if pair_block <= 0 and S > 0:
+        raise ValueError("a HeadedSpG is joined by gather / hgather (mirrored segment lists); keep the packed store for the other forms")
+    if return_index:
+        raise ValueError("index pairs come from the packed store (gather_index)")
+    kw = dict(row_stride=spg.pitch, n_rows=spg.n_rows, ids=spg.ids, payload=spg.data, own=own, partner=partner, S=S, pair_block=pair_block,
+              flags=flags)
+    if spg.keyrows:
+        if encode is not KEY_ROWS_ENCODE:
+            raise ValueError("a keyed() store is joined by gather / hgather(…, encode=zk.slot_table())")
+        kind, k = JOIN_KEY32, spg.key_m + 1
+        kw.update(num_walks=spg.key_M, num_steps=spg.key_m)
+    elif spg.data.dtype == torch.float64:
+        if encode is not None:
+            raise TypeError("a float-payload SpG is joined without an encode table (train.py:39-43)")
+        kind, k = JOIN_F64, 1
+    else:
+        if encode is None:
+            raise NotImplementedError("an integer SpG needs the encode table")
+        enc = encode.to(device=dev, dtype=torch.float32).contiguous()
+        if enc.shape[0] <= spg.max_data:
+            raise IndexError(f"index {spg.max_data} is out of bounds for the encode table with {enc.shape[0]} rows")
+        kind, k = JOIN_SFPTR, int(enc.shape[1])
+        kw.update(table=enc, table_rows=enc.shape[0], k=k)
+    if lazy and (out is None or not ptr_mode):
+        raise ValueError("lazy=True needs out= and ptr=True")
+    state = torch.zeros(lib().subgacc_sjoin_workspace_bytes(S), dtype=torch.uint8, device=dev)
+    host = torch.empty(2, dtype=torch.int64, pin_memory=True)
+    sized = dict(options=_lib.JOIN_OPT_SIZES, out_seg=seg, size_state=state, size_state_bytes=state.numel(), host_tail=host)
+    if lazy:
+        if out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev or out.numel() < S * spg.max_len * 2 * k:
+            raise ValueError("lazy out= must hold S * SpG.max_len * 2 * k float32 on the SpG's device")
+        rows = out.numel() // (2 * k)
+        res = out.view(-1)[: rows * 2 * k].view(rows, 2, k)
+        with _timed("sjoin_fill"):
+            join_fill(JOIN_ROWS, kind, out_xz=res, **kw, **sized)
+        ev = torch.cuda.Event()
+        ev.record()
+        _lib.keep_until(ev, (host, state))          # the kernels write both after this function has returned
+        return res, seg, flags
+    join_fill(JOIN_ROWS, kind, **kw, **sized)        # no output: the size pass alone
+    torch.cuda.current_stream(dev).synchronize()
+    R, status = (int(v) for v in host.tolist())
+    if status & 64:
+        raise _lib.SubgAccError("the join's size state was not clean")
+    if status & 16:
+        raise IndexError(f"row index out of range for an SpG with {spg.n_rows} rows")
+    if out is not None:
+        if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() < R * 2 * k or out.device != dev:
+            raise ValueError("out= must be a contiguous float32 buffer on the SpG's device with >= R*2*k elements")
+        res = out.view(-1)[: R * 2 * k].view(R, 2, k)
+    else:
+        res = torch.empty((R, 2, k), dtype=torch.float32, device=dev)
+    segid = None if ptr_mode else torch.empty(R, dtype=torch.int64, device=dev)
+    with _timed("sjoin_fill"):
+        join_fill(JOIN_ROWS, kind, seg=seg, out_xz=res, out_segid=segid, **kw)
     return res, (seg if ptr_mode else _with_pointers(segid, seg)), flags
 
 

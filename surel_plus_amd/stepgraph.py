@@ -245,7 +245,10 @@ class CapturedJoin:
         self.flags = torch.zeros(4, dtype=torch.int32, device=dev)
         self._state = torch.zeros(_lib.lib().subgacc_sjoin_workspace_bytes(S), dtype=torch.uint8, device=dev)     # zeroed ONCE
         self._host = torch.zeros(2, dtype=torch.int64, pin_memory=True)
-        d.row_off, d.n_rows, d.ids, d.payload, d.max_len = z.indptr.data_ptr(), z.n_rows, z.indices.data_ptr(), z.data.data_ptr(), z.max_len
+        if hasattr(z, "pitch"):       # HeadedSpG (SpG.aligned()): rows on whole lines, their lengths in their first slots, no row pointers
+            d.row_stride, d.n_rows, d.ids, d.payload = z.pitch, z.n_rows, z.ids.data_ptr(), z.data.data_ptr()
+        else:
+            d.row_off, d.n_rows, d.ids, d.payload, d.max_len = z.indptr.data_ptr(), z.n_rows, z.indices.data_ptr(), z.data.data_ptr(), z.max_len
         d.own, d.S, d.pair_block = self.edge.data_ptr(), S, B
         self.segid = None
         if triplets:       # own = [u | w | v | w] (hedge rows 0, 2, 1, 2), the mirrored partner blocks are derived by the kernels
@@ -319,12 +322,20 @@ class CapturedJoin:
         """wait for the queued join, raise on its errors -> (xz float32 [R,2,k] view of the static buffer, indptr)"""
         self._event.synchronize()
         rows, word = self._host.tolist()
+        # `word` is the SIZE pass's status (bits 16 and 64: every row index is looked at there).  What a fill could add -- a row longer
+        # than max_len (1), an SFptr outside the encode table (2) -- is ruled out when this object is built (max_len and max_data are
+        # the store's own; the table is checked against them), so the fills' word, flags[3], is read back with SUBGACC_DEBUG=1 only;
+        # it is zeroed after a report either way, so that one bad batch does not fail every batch after it.
         if _DEBUG:
             word |= int(self.flags[3].item())
         if word & 64:
+            # the one-pass scan's state was not zero when the launch began (an aborted launch before it): nothing it wrote means
+            # anything, and it may not have left the state clean either -- zeroed here, on the host's side, before the next call
             self._state.zero_()
             self.flags.zero_()          # (bit 64 in the device flags keeps every fill from running)
             raise _lib.SubgAccError("the join's size state was not clean (an aborted launch?): zeroed, call again")
+        if word & (16 | 1 | 2):
+            self.flags.zero_()
         if word & 16:
             raise IndexError(f"row index out of range for an SpG with {self.z.n_rows} rows")
         if word & 1:

@@ -41,7 +41,7 @@ int main(int argc, char **argv) {
     SYM(subgacc_walk_sets); SYM(subgacc_scan_workspace_bytes); SYM(subgacc_exclusive_scan_i32); SYM(subgacc_compact_sets);
     SYM(subgacc_uniq_table_bytes); SYM(subgacc_uniq_reset); SYM(subgacc_uniq_number_workspace_bytes);
     SYM(subgacc_uniq_number); SYM(subgacc_spg_build); SYM(subgacc_sjoin_workspace_bytes); SYM(subgacc_sjoin_sizes);
-    SYM(subgacc_sjoin_fill_v2); SYM(subgacc_unpack_lp); SYM(subgacc_sjoin_fill_keys);
+    SYM(subgacc_sjoin_fill_v2); SYM(subgacc_unpack_lp); SYM(subgacc_rows_to_headed);
     SYM(subgacc_step_prologue); SYM(subgacc_walk_keyrows64); SYM(subgacc_walk_spg); SYM(subgacc_sjoin_sizes_rows);
 
     CHECK(p_subgacc_abi_version() == SUBGACC_ABI_VERSION);
@@ -175,12 +175,38 @@ int main(int argc, char **argv) {
         HIP(hipDeviceSynchronize());
         HIP(hipMemcpy(xz2_h, xz2, R * 2 * (m + 1) * 4, hipMemcpyDeviceToHost));
         CHECK(memcmp(xz_h, xz2_h, R * 2 * (m + 1) * 4) == 0);
-        /* ... and the ABI 5 symbol of the same form still answers (a forward to the entry point above) */
-        HIP(hipMemset(xz2, 0, R * 2 * (m + 1) * 4));
-        CHECK(p_subgacc_sjoin_fill_keys(row_off, n, z_idx, z_key, own, partner, 4, seg, M, m, xz2, NULL, STRIDE, 2, flags, NULL) == 0);
-        HIP(hipDeviceSynchronize());
-        HIP(hipMemcpy(xz2_h, xz2, R * 2 * (m + 1) * 4, hipMemcpyDeviceToHost));
-        CHECK(memcmp(xz_h, xz2_h, R * 2 * (m + 1) * 4) == 0);
+        /* ABI 7: the same store laid out on whole 128-byte lines -- HEADED rows: a row's length in slot 0 of its ids, no row pointers --
+         * and joined in ONE call (SUBGACC_JOIN_OPT_SIZES: size pass + fill; [R, status] land in pinned host memory): what a C serving
+         * loop over a resident store does per batch */
+        {
+            enum { PITCH = 32 };                                                    /* >= STRIDE + 1, a multiple of 32 words */
+            int32_t *h_ids = dev(n * PITCH * 4, NULL), *h_key = dev(n * PITCH * 4, NULL);
+            CHECK(p_subgacc_rows_to_headed(row_off, n, z_idx, z_key, 4, PITCH, h_ids, h_key, flags, NULL) == 0);
+            const size_t sbytes = p_subgacc_sjoin_workspace_bytes(4);
+            void *state = dev(sbytes, NULL);                                        /* zeroed ONCE */
+            int64_t *seg3 = dev(5 * 8, NULL), *tail = NULL, seg3_h[5];
+            HIP(hipHostMalloc((void **)&tail, 16, 0));
+            const size_t cap = (size_t)4 * (PITCH - 1) * 2 * (m + 1) * 4;            /* the worst case: R is not known beforehand */
+            float *xz3 = dev(cap, NULL);
+            subgacc_join_desc h;
+            memset(&h, 0, sizeof h);
+            h.struct_bytes = (int32_t)sizeof h, h.form = SUBGACC_JOIN_ROWS, h.payload_kind = SUBGACC_JOIN_KEY32;
+            h.row_stride = PITCH, h.n_rows = n, h.ids = h_ids, h.payload = h_key;
+            h.own = own, h.partner = partner, h.S = 4, h.pair_block = 2, h.num_walks = M, h.num_steps = m;
+            h.options = SUBGACC_JOIN_OPT_SIZES, h.out_seg = seg3, h.size_state = state, h.size_state_bytes = (int64_t)sbytes, h.host_tail = tail;
+            h.flags = flags;
+            for (int rep = 0; rep < 2; ++rep) {                                     /* (the state cleans itself: call after call) */
+                tail[0] = tail[1] = -7;
+                h.out_xz = rep ? xz3 : NULL;                                        /* first the size pass alone, then the whole join */
+                CHECK(p_subgacc_sjoin_fill_v2(&h, NULL) == 0);
+                HIP(hipDeviceSynchronize());
+                CHECK(tail[0] == R && tail[1] == 0);
+            }
+            HIP(hipMemcpy(seg3_h, seg3, sizeof seg3_h, hipMemcpyDeviceToHost));
+            CHECK(memcmp(seg3_h, seg_h, sizeof seg3_h) == 0);
+            HIP(hipMemcpy(xz2_h, xz3, R * 2 * (m + 1) * 4, hipMemcpyDeviceToHost));
+            CHECK(memcmp(xz_h, xz2_h, R * 2 * (m + 1) * 4) == 0);
+        }
         HIP(hipMemcpy(fl, flags, 16, hipMemcpyDeviceToHost));
         CHECK(fl[3] == 0);
     }

@@ -24,7 +24,7 @@ def fat_record(bench):
           "literal_dropin": {"drop_in_roots_per_s": 5.2e5, "shim_roots_per_s": 6e6, "shim_seconds": 0.04, "caller_seconds": 0.4,
                              "reference_roots_per_s": 1.8e5}}
     others = {name: json.loads(json.dumps(wl)) for name in
-              ("cit2 (rng=rand_r: the reference's own stream, bit-exact mode)", "cit2m4", "collab", "ppa", "twitter", "cit2ppr")}
+              ("cit2 (rng=rand_r: the reference's own stream, bit-exact mode)", "cit2m4", "collab", "ppa", "twitter", "cit2ppr", "cit2loc")}
     others["walk_sampler (collab)"] = {"value": 2.2e8, "roofline": {"frac": 0.1}}
     return {
         "metric": "query-pairs/sec (sample+SpJoin)", "value": 58934567.123456, "unit": "query-pairs/s", "n_gpus": 8, "steps": 20,
@@ -37,7 +37,9 @@ def fat_record(bench):
                    "rank_records": [{"rank": r, "device": "AMD Instinct MI355X|" + "u" * 64, "elapsed_ms": 22.0, "walk_kernel_ms": 0.66,
                                      "host": "h" * 40, "pid": 12345} for r in range(8)],
                    "region_pairs_per_s": [58e6, 59e6, 59.1e6, 59.2e6], "stage_ms": {"walk_sets": 0.66, "sjoin_fill": 0.42},
-                   "other_workloads": others, "offline_flow": {"S_roots_per_s": 1.6e8, "junk": ["j" * 100] * 50},
+                   "other_workloads": others, "host_fed_pairs_per_s": 5.9e7,
+                   "offline_flow": {"S_roots_per_s": 1.6e8, "J_pairs_per_s_table_store": 1.45e8, "Q_formula_pairs_per_s": 5.2e7,
+                                    "Q_amortised_at_1e8_pairs_table": 1.41e8, "junk": ["j" * 100] * 50},
                    "hgather": {"value": 2.7e7, "roofline": {"frac": 0.21}}, "mean_stage": {"H96_fused_pairs_per_s": 7.2e7},
                    "batch_size_and_hip_graph": {"B=1024 eager": {"pairs_per_s": 1.5e7}}},
         "roofline": {"bound": "hbm", "kernel": "walk_rows_kernel<false,1,3,8,128,8,true,true>", "achieved": 1601.23456, "peak": 8000.0,
@@ -73,6 +75,18 @@ def test_compact_line_is_small_and_complete():
                 "cit2ppr_pairs_per_s", "collab_frac", "collab_join_frac", "twitter_join_frac", "cit2m4_join_frac",
                 "cit2ppr_frac_whole_join_call", "collab_dropin_shim_roots_per_s", "headline_median_of_3_x100", "detail"):
         assert key in cfg, key
+    # the driver's record keeps the FIRST 24 keys of `config` (BENCH_r05 lost ppa / twitter / cit2-PPR off the end): every BASELINE.json
+    # configuration, SURVEY 8(d)'s S / J / Q and the host-fed loop must sit in front of that cut -- position, not just presence
+    head = list(cfg)[:bench.DRIVER_KEEPS]
+    assert bench.DRIVER_KEEPS == 24
+    for key in ("workload", "pairs_per_step_per_gpu", "ranks_seen", "distinct_devices",
+                "collab_cpu_pairs_per_s",                                                    # configs[0]
+                "collab_pairs_per_s", "collab_frac", "collab_join_frac",                     # configs[1]
+                "ppa_pairs_per_s", "ppa_frac", "ppa_join_frac",                              # configs[2]
+                "cit2ppr_pairs_per_s", "cit2ppr_frac", "cit2ppr_frac_whole_join_call",       # configs[3]
+                "twitter_pairs_per_s", "twitter_frac", "twitter_join_frac",                  # configs[4]
+                "S_offline_roots_per_s", "J_resident_pairs_per_s", "Q_formula_pairs_per_s", "host_fed_pairs_per_s"):
+        assert key in head, (key, head)
     rl = line["roofline"]
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(rl)
     assert rl["frac"] == pytest.approx(rl["achieved"] / rl["peak"], rel=1e-4)

@@ -27,7 +27,7 @@ def test_header_symbols_are_exported(L):
 
 def test_abi_version_and_argument_errors(L):
     from surel_plus_amd import _lib
-    assert L.subgacc_abi_version() == 6           # 6: subgacc_sjoin_fill_v2 (one descriptor for every form of the join); 5: 64-bit key rows (4-hop walks); 2: row / node counts in the join and rng_positions entry points (bounds); 3: hop records in the walk cfg; 4: batched registration of key rows
+    assert L.subgacc_abi_version() == 7           # 7: headed rows, the per-form join entry points of ABI 1-5 gone; 6: subgacc_sjoin_fill_v2 (one descriptor for every form of the join); 5: 64-bit key rows (4-hop walks); 2: row / node counts in the join and rng_positions entry points (bounds); 3: hop records in the walk cfg; 4: batched registration of key rows
     assert L.subgacc_key_shift(200, 3) == 8            # SHIFT = 32-clz(M), subg_acc.c:903
     assert L.subgacc_key_shift(100, 4) == 7
     assert L.subgacc_key_shift(200, 8) == _lib.ERR_KEYWIDTH   # 8*8+1 > 64 (subg_acc.c:905-915)
@@ -106,7 +106,25 @@ def test_join_descriptor_layout_matches_the_header(tmp_path, L):
     d.out_seg, d.seg = here, here
     assert L.subgacc_sjoin_fill_v2(C.byref(d), None) == _lib.ERR_BADARG          # seg next to out_seg
     d.seg, d.own = None, here
+    assert L.subgacc_sjoin_fill_v2(C.byref(d), None) == _lib.ERR_WORKSPACE       # (no output: the size pass alone) no state
+    # (round 6: with an output, what the FILL would refuse is refused before the size pass has written out_seg / host_tail)
+    d.out_xz = here
+    assert L.subgacc_sjoin_fill_v2(C.byref(d), None) == _lib.ERR_BADARG and b"null argument" in L.subgacc_last_error()
+    d.ids = d.payload = d.flags = here
+    d.payload_kind = 9
+    assert L.subgacc_sjoin_fill_v2(C.byref(d), None) == _lib.ERR_BADARG and b"payload kind" in L.subgacc_last_error()
+    d.payload_kind = _lib.JOIN_KEY64                                            # 64-bit keys are the payload of STRIDED / HEADED rows
+    assert L.subgacc_sjoin_fill_v2(C.byref(d), None) == _lib.ERR_BADARG and b"row layout" in L.subgacc_last_error()
+    d.payload_kind = _lib.JOIN_SFPTR
     assert L.subgacc_sjoin_fill_v2(C.byref(d), None) == _lib.ERR_WORKSPACE       # no state
+    # ABI 7, headed rows: neither row_off nor row_len, a row_stride -- and not two layouts at once
+    d.row_len, d.row_stride = here, 32
+    assert L.subgacc_sjoin_fill_v2(C.byref(d), None) == _lib.ERR_BADARG and b"exactly one" in L.subgacc_last_error()
+    d.row_off = d.row_len = None
+    assert L.subgacc_sjoin_fill_v2(C.byref(d), None) == _lib.ERR_WORKSPACE       # headed rows: accepted up to the missing state
+    d.row_stride = 1
+    assert L.subgacc_sjoin_fill_v2(C.byref(d), None) == _lib.ERR_BADARG          # a headed row needs a slot behind its length
+    d.row_off, d.row_stride = here, 0
     d.size_state, d.size_state_bytes = here, 8
     assert L.subgacc_sjoin_fill_v2(C.byref(d), None) == _lib.ERR_WORKSPACE       # a state too small
     assert L.subgacc_sjoin_workspace_bytes(4) >= 64 + 8 and L.subgacc_sjoin_workspace_bytes(1 << 22) >= 64 + 8 * (1 << 12)

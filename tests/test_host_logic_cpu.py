@@ -195,3 +195,64 @@ def test_the_join_kernels_quotient_formula_is_the_ieee_division():
         assert np.array_equal(q, a / fm), M
         cases += c.size
     assert cases == 11184810
+
+
+def test_keep_until_never_drops_an_unfinished_entry_under_four_threads():
+    """VERDICT r5 #8a / SURVEY 8(b) ("safe to call from the 4 pgather-style Python threads"): _lib.keep_until holds the pinned block a
+    publish kernel is still going to write until its event has passed.  Four threads queue 4,000 entries each while their events
+    finish in any order; an entry may only leave the list once ITS event reports finished (round 5's look-then-pop could pop the
+    unfinished entry behind a finished one when two threads interleaved)."""
+    import random
+    import threading
+
+    from surel_plus_amd import _lib
+
+    class FakeEvent:
+        def __init__(self):
+            self.done = False
+
+        def query(self):
+            return self.done
+
+    dropped_early = []
+
+    class Block:
+        def __init__(self, ev):
+            self.ev = ev
+
+        def __del__(self):
+            if not self.ev.done:
+                dropped_early.append(1)
+
+    saved = list(_lib._KEPT)
+    _lib._KEPT.clear()
+    try:
+        def worker(seed):
+            rng = random.Random(seed)
+            mine = []
+            for _ in range(4000):
+                ev = FakeEvent()
+                _lib.keep_until(ev, Block(ev))
+                mine.append(ev)
+                if len(mine) > 3:
+                    mine.pop(rng.randrange(len(mine))).done = True       # the kernels of different streams finish in any order
+            return mine
+        left = []
+        threads = [threading.Thread(target=lambda s=s: left.extend(worker(s))) for s in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not dropped_early
+        pending = {id(ev) for ev in left}
+        assert pending <= {id(ev) for ev, _ in _lib._KEPT}                # every unfinished entry is still held
+        for ev in left:
+            ev.done = True
+        done_ev = FakeEvent()
+        done_ev.done = True
+        _lib.keep_until(done_ev, object())
+        assert len(_lib._KEPT) == 1 and not dropped_early                  # ... and leaves once its event has passed
+    finally:
+        for ev, _ in _lib._KEPT:
+            ev.done = True
+        _lib._KEPT[:] = saved

@@ -5,6 +5,7 @@ import os
 import types
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -207,3 +208,34 @@ def test_rand_r_calls_is_the_stream_position_of_the_next_root():
     assert not all(np.array_equal(x, y) for x, y in zip(a, c))
     assert shard.rand_r_calls(indptr, np.zeros(0, np.int32), M, m) == 0
     assert shard.rand_r_calls(torch.from_numpy(indptr), pa, M, m, first_hop_wo=False) == 8 * M * m
+
+
+def _device_worker(rank, world, port, same_device, backend_label, out_dir):
+    """one rank of bench.py's device check over gloo: the records are all-gathered as in a real run, the device identity is faked"""
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    bench.device_identity = lambda dev: "AMD Instinct MI355X|uuid-0|idx0" if same_device else f"AMD Instinct MI355X|uuid-{rank}|idx{rank}"
+    recs = bench.gather_rank_records(dist, world, rank, None, 0.02, 0.66, backend_label)
+    code = 0
+    try:
+        bench.require_distinct_devices(recs, world, backend_label)
+    except SystemExit as ex:
+        code = ex.code
+    with open(os.path.join(out_dir, f"code_{rank}"), "w") as f:
+        f.write(str(code))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("same_device,backend,want", [(True, "nccl", 3), (False, "nccl", 0), (True, "gloo", 0)])
+def test_bench_refuses_ranks_that_share_a_device_under_rccl(tmp_path, same_device, backend, want):
+    """the first 8-GPU run must not be able to lie.  Two ranks over gloo, the all-gathered rank records as bench.py makes
+    them with the device identity faked: a repeated device under "nccl" ends EVERY rank with exit code 3; distinct devices pass; the
+    one-GPU gloo rehearsal (SUBGACC_DIST_BACKEND=gloo SUBGACC_SHARE_GPU=1) may share its device."""
+    world, port = 2, 29640 + (os.getpid() + 7 * int(same_device) + 3 * (backend == "gloo")) % 300
+    mp.spawn(_device_worker, args=(world, port, same_device, backend, str(tmp_path)), nprocs=world, join=True)
+    assert [int(open(tmp_path / f"code_{r}").read()) for r in range(world)] == [want] * world

@@ -116,19 +116,9 @@ def offline_flow(sp, csr, M, k, B, K, cpu):
     from surel_plus_amd.graphs import query_pairs
     from surel_plus_amd.spg import sample_spg
     dev, N = csr.device, csr.num_nodes
-    out = {}
+    # S / J / Q themselves are part of the default run since round 6 (bench.reference_flow); what --full adds follows
+    base, z, sets, enc, table, zk = bench.reference_flow(sp, csr, M, k, B)
     idx = torch.arange(N, dtype=torch.int32, device=dev)
-    z = sets = None
-    times = []
-    for _ in range(3):          # the previous store goes back to the allocator first: steady state, no fresh GB-sized hipMalloc
-        del z, sets
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        z, sets = sample_spg(csr, idx, num_walks=M, num_steps=k - 1, seed=111413, rng="philox", fused=True)
-        enc = sets.enc_int16()
-        torch.cuda.synchronize()
-        times.append(time.perf_counter() - t0)
-    t_off = min(times[1:])
     # the paper's own sampler figure (Fig. 6a: citation2, m = 4, M = 200 -- 143..302 s on 16..1 CPU threads "incl. encoding + SpG
     # conversion") read with m as the hop count: all N roots, 4 hops, store resident + enc numbered
     t_m4 = None
@@ -147,39 +137,6 @@ def offline_flow(sp, csr, M, k, B, K, cpu):
     except Exception as ex:
         t_m4 = None
         m4_members = m4_rows = f"{type(ex).__name__}: {ex}"
-    table = sets.feature_table()
-    edges = [query_pairs(csr, B, seed=9000 + s_, device=dev) for s_ in range(max(K, 5) + 2)]
-    cap = 2 * B * z.max_len * 2 * k
-    buf = _XZ_BUF.get((dev, cap, 0))
-    if buf is None:
-        buf = torch.empty(cap, dtype=torch.float32, device=dev)
-
-    def join_rate(store, tab):
-        for e in edges[:2]:
-            sp.gather(e, store, dev, ptr=True, encode=tab, out=buf, lazy=True)
-        rs = []
-        for _ in range(3):          # three loops of >= 50 joins (>= 20 ms each); the median is reported
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            n_j = 0
-            while n_j < 50:
-                for e in edges[2:]:
-                    sp.gather(e, store, dev, ptr=True, encode=tab, out=buf, lazy=True)
-                    n_j += 1
-            torch.cuda.synchronize()
-            rs.append(n_j * B / (time.perf_counter() - t1))
-        return median(rs)
-    J = join_rate(z, table)
-    encz = torch.cat([torch.zeros((1, enc.shape[1]), dtype=enc.dtype, device=dev), enc])
-    zk = None
-    for _ in range(2):          # (steady-state allocator again: the second re-keying is the one that counts)
-        del zk
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        zk = z.keyed(encz, M)
-        torch.cuda.synchronize()
-        t_key = time.perf_counter() - t2
-    JK = join_rate(zk, zk.slot_table())
     # the reference's own loop AT the reference's batch size (main.py:32: 1,024 pairs; train.py:120-127), from the keyed store:
     # one eager gather per batch, one library call per batch (CapturedJoin; four lanes of them: CapturedJoinPool), and 64 batches per launch sequence
     # (gather_many: the permutation of an epoch is known when it starts) -- 3 repeats each, the median is reported
@@ -245,13 +202,9 @@ def offline_flow(sp, csr, M, k, B, K, cpu):
         del sbuf, sbuf2, stacks
     except Exception as ex:
         b1024["failed"] = f"{type(ex).__name__}: {ex}"
-    out = {"J_b1024_keyed": b1024, "all_N_4hop_sample_to_resident_spg_ms": t_m4 * 1e3 if t_m4 else None,
-           "all_N_4hop_roots_per_s": N / t_m4 if t_m4 else None, "all_N_4hop_set_members": m4_members, "all_N_4hop_distinct_lp_rows": m4_rows,
-           "all_N_sample_to_resident_spg_ms": t_off * 1e3, "S_roots_per_s": N / t_off, "set_members": z.nnz,
-           "distinct_lp_rows": int(enc.shape[0]), "J_pairs_per_s_table_store": J, "J_pairs_per_s_keyed_store": JK,
-           "rekey_once_ms": t_key * 1e3, "pairs_per_batch": B,
-           "Q_amortised_at_1e8_pairs_table": 1e8 / (t_off + 1e8 / J), "Q_amortised_at_1e8_pairs_keyed": 1e8 / (t_off + t_key + 1e8 / JK),
-           "reference": "main.py:172-178 (subg_matrix over all N once) + train.py:120-127 (one join per batch from the resident store)"}
+    out = dict(base)
+    out.update({"J_b1024_keyed": b1024, "all_N_4hop_sample_to_resident_spg_ms": t_m4 * 1e3 if t_m4 else None,
+                "all_N_4hop_roots_per_s": N / t_m4 if t_m4 else None, "all_N_4hop_set_members": m4_members, "all_N_4hop_distinct_lp_rows": m4_rows})
     if cpu and cpu.get("sampler_roots_per_s"):
         Sc, Jc = cpu["sampler_roots_per_s"], cpu["join_pairs_per_s"]
         out["cpu_baseline"] = {"S_roots_per_s": Sc, "J_pairs_per_s": Jc, "Q_amortised_at_1e8_pairs": 1e8 / (N / Sc + 1e8 / Jc),

@@ -52,7 +52,7 @@ def one(wl, n):
     L, st = lib(), stream_ptr()
     own, partner = _arange_segments(B, dev, B)
     flags = bufs.status.view(torch.int32)[:4]
-    fill = L.subgacc_sjoin_fill_keyrows64 if bufs.key64 else L.subgacc_sjoin_fill_keyrows      # (the ABI 5 forwards: old builds have them too)
+    from surel_plus_amd import _lib
     out = bufs.out.view(-1)
     # JB_PITCH=n (experiment): the same rows laid out again n words apart (n a multiple of 32: every row begins on a 128-byte line)
     stride, ids, slot = bufs.stride, bufs.ids, bufs.slot
@@ -66,9 +66,10 @@ def one(wl, n):
         stride, ids, slot = pitch, ids2, slot2
         wl = f"{wl}@{pitch}"
 
-    def launch():
-        check(fill(ptr(bufs.nsize), 2 * B, stride, ptr(ids), ptr(slot), ptr(own), ptr(partner), 2 * B, ptr(bufs.seg),
-                   M, k - 1, ptr(out), B, ptr(flags), st))
+    def launch():        # (ABI 7: through the descriptor; builds older than round 6 need the round-5 version of this script)
+        _lib.join_fill(_lib.JOIN_ROWS, _lib.JOIN_KEY64 if bufs.key64 else _lib.JOIN_KEY32, row_len=bufs.nsize, n_rows=2 * B, row_stride=stride,
+                       ids=ids, payload=slot, own=own, partner=partner, S=2 * B, seg=bufs.seg, pair_block=B, num_walks=M, num_steps=k - 1,
+                       out_xz=out, flags=flags)
     for _ in range(5):
         launch()
     torch.cuda.synchronize()
