@@ -259,6 +259,7 @@ struct JoinArgs {
     // headed rows (ABI 7: a resident store on whole 128-byte lines): row r = members [r*row_stride, +row_head[r*row_stride]) of
     // indices / data, where `indices` points ONE WORD behind row_head -- slot 0 of a row's ids holds its length, its members follow
     const int32_t *row_head = nullptr;
+    int32_t spec_len = 0;     // strided / headed float rows: members asked for before a row's length is known (sjoin_f64pair_kernel)
     // key rows (subgacc_sjoin_fill_keyrows): the rows' payload is the member's 32-bit LP key; a feature row is its unpacked
     // counts / num_walks (lut[c] = float(c) / float(M), built per workgroup), 0xFFFFFFFF = partner absent -> the zero row
     int32_t key_M, key_m, key_shift;
@@ -881,10 +882,66 @@ __global__ __launch_bounds__(NT) void sjoin_f64pair_kernel(const JoinArgs a, uin
     const int64_t oA = a.seg[j], oB = a.seg[j2];
     const bool okA = (uint64_t)ra < (uint64_t)a.n_rows, okB = (uint64_t)rb < (uint64_t)a.n_rows;   // else: an empty row, never dereferenced
     int64_t ab = 0, bb = 0, na64 = 0, nb64 = 0;
-    if (a.row_stride) {        // strided / headed rows: no row pointer to wait for, the length is a row's own first word
+    constexpr int kRegTrips = 4;       // trips of S in registers (rows of up to 4 * NT members; longer ones span by span below)
+    int32_t sid[kRegTrips];
+    double sval[kRegTrips], sgot[kRegTrips];
+    int ns, nt;
+    int64_t sb, tb, oS, oT, jS, jT;
+    if (a.row_stride) {
+        // Strided / headed rows: a row's slot exists whatever its length, so its first a.spec_len members are asked for NOW, together
+        // with its length (the word in front of them) -- own[] -> {length, members}: two dependent round trips where packed rows need
+        // three (own[] -> row pointers -> members).  This kernel is bound by exactly that chain: 8 one-wave pairs per SIMD, each
+        // waiting for its next answer (profiles/r24_ppr_join_experiments.log).  spec_len is the store's typical row length rounded to
+        // whole lines of ids (HeadedSpG: 96 for the top-100 PPR store): what lies behind it -- few rows have it -- is asked for once
+        // the length is known; a shorter row's speculative tail is read for nothing (its own slot: never out of bounds).
         ab = ra * a.row_stride, bb = rb * a.row_stride;
+        const int spec = a.spec_len < ML ? a.spec_len : ML;
+        int32_t ia[kRegTrips], ib[kRegTrips];
+        double va[kRegTrips], vb[kRegTrips];
+#pragma unroll
+        for (int u = 0; u < kRegTrips; ++u) {
+            const int r = tid + u * NT;
+            ia[u] = ib[u] = 0, va[u] = vb[u] = 0.0;
+            if (u * NT < spec && r < spec) {
+                if (okA) ia[u] = stream_load(&a.indices[ab + r]), va[u] = stream_load(&vals[ab + r]);
+                if (okB && ra != rb) ib[u] = stream_load(&a.indices[bb + r]), vb[u] = stream_load(&vals[bb + r]);
+            }
+        }
         if (okA) na64 = a.row_len ? a.row_len[ra] : a.row_head[ab];
         if (okB) nb64 = a.row_len ? a.row_len[rb] : a.row_head[bb];
+        if (na64 > ML || nb64 > ML) {
+            if (tid == 0) atomicOr(&a.flags[3], 1);
+            return;
+        }
+        const int na = (int)na64, nb = (int)nb64;
+#pragma unroll
+        for (int u = 0; u < kRegTrips; ++u) {      // what lies behind the speculative part
+            const int r = tid + u * NT;
+            if (r >= spec) {
+                if (r < na) ia[u] = stream_load(&a.indices[ab + r]), va[u] = stream_load(&vals[ab + r]);
+                if (r < nb && ra != rb) ib[u] = stream_load(&a.indices[bb + r]), vb[u] = stream_load(&vals[bb + r]);
+            }
+        }
+        if (ra == rb) {
+#pragma unroll
+            for (int u = 0; u < kRegTrips; ++u) ib[u] = ia[u], vb[u] = va[u];
+        }
+        // roles: S = the shorter row, searched member by member in T = the longer one ((u,u): S and T are the same row)
+        const bool swap = na > nb;
+        ns = swap ? nb : na, nt = swap ? na : nb;
+        sb = swap ? bb : ab, tb = swap ? ab : bb;
+        oS = swap ? oB : oA, oT = swap ? oA : oB, jS = swap ? j2 : j, jT = swap ? j : j2;
+#pragma unroll
+        for (int u = 0; u < kRegTrips; ++u) {
+            const int r = tid + u * NT;
+            sid[u] = swap ? ib[u] : ia[u], sval[u] = swap ? vb[u] : va[u];
+            if (r >= ns) sid[u] = 0, sval[u] = 0.0;          // (a speculative read behind the row's end holds anything)
+            if (r < nt) {
+                idsT[r] = swap ? ia[u] : ib[u];
+                valT[r] = swap ? va[u] : vb[u];
+                pv[r] = 0.0;
+            }
+        }
     } else {
         if (okA) {
             ab = a.indptr[ra];
@@ -894,21 +951,16 @@ __global__ __launch_bounds__(NT) void sjoin_f64pair_kernel(const JoinArgs a, uin
             bb = a.indptr[rb];
             nb64 = a.indptr[rb + 1] - bb;
         }
-    }
-    if (na64 > ML || nb64 > ML) {
-        if (tid == 0) atomicOr(&a.flags[3], 1);
-        return;
-    }
-    const int na = (int)na64, nb = (int)nb64;
-    // roles: S = the shorter row, searched member by member in T = the longer one ((u,u): S and T are the same row)
-    const bool swap = na > nb;
-    const int ns = swap ? nb : na, nt = swap ? na : nb;
-    const int64_t sb = swap ? bb : ab, tb = swap ? ab : bb;
-    const int64_t oS = swap ? oB : oA, oT = swap ? oA : oB, jS = swap ? j2 : j, jT = swap ? j : j2;
-    constexpr int kRegTrips = 4;       // trips of S in registers (rows of up to 4 * NT members; longer ones span by span below)
-    int32_t sid[kRegTrips];
-    double sval[kRegTrips], sgot[kRegTrips];
-    {
+        if (na64 > ML || nb64 > ML) {
+            if (tid == 0) atomicOr(&a.flags[3], 1);
+            return;
+        }
+        const int na = (int)na64, nb = (int)nb64;
+        // roles: S = the shorter row, searched member by member in T = the longer one ((u,u): S and T are the same row)
+        const bool swap = na > nb;
+        ns = swap ? nb : na, nt = swap ? na : nb;
+        sb = swap ? bb : ab, tb = swap ? ab : bb;
+        oS = swap ? oB : oA, oT = swap ? oA : oB, jS = swap ? j2 : j, jT = swap ? j : j2;
         int32_t ti[kRegTrips];
         double tv[kRegTrips];
 #pragma unroll
@@ -1584,6 +1636,7 @@ extern "C" int subgacc_sjoin_fill_v2(const subgacc_join_desc *d, void *stream) {
         SG_REQUIRE(d->out_xz && !d->out_idx && !d->table, SUBGACC_ERR_BADARG,
                    "sjoin_fill_v2: float payload writes out_xz [R,2,1] only (train.py:39-43)");
         a.k = 1, a.table = nullptr, a.table_rows = 0;
+        a.spec_len = packed ? 0 : (d->max_len > 0 ? d->max_len : (int32_t)(a.max_len < 128 ? a.max_len : 128));     // (headed / strided rows: max_len is the hint)
         if (mirrored && (size_t)a.max_len * 20 + 16 <= (size_t)kLdsBytes) return launch_f64_pairs(a, S, pb, stream);
         SG_REQUIRE(packed, SUBGACC_ERR_BADARG, "sjoin_fill_v2: strided / headed float rows are joined as mirrored blocks (pair_block > 0)");
         return launch_segments(a, true, false, stream);

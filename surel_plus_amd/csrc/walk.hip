@@ -111,7 +111,9 @@ __global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_n
     }
     if ((uint64_t)(int64_t)root >= (uint64_t)a.num_nodes) {   // the reference would read out of bounds here (no checks)
         if (tid == 0) {
-            atomicOr(&a.flags[3], 16);
+            // (SUBGACC_NO_ROOT marks a row that has no root -- a repeated endpoint of a batch whose first occurrence carries the set: an
+            //  empty row, not an error, in this kernel as in the fused-row one; round 5's fallback of subgacc_walk_spg_list flagged it)
+            if (root != SUBGACC_NO_ROOT) atomicOr(&a.flags[3], 16);
             a.nsize[i] = 0;
         }
         return;
@@ -433,7 +435,8 @@ __global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_n
         if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc, red[4 + tid / kWave] = mc;   // (the id range is in registers)
         __syncthreads();
         int32_t base = 0;
-        for (int w2 = 0; w2 < tid / kWave; ++w2) base += red[12 + w2];
+#pragma unroll
+        for (int w2 = 0; w2 < kWalkThreads / kWave - 1; ++w2) base += w2 < tid / kWave ? red[12 + w2] : 0;      // (spelled out: as a loop over tid / 64 the compiler vectorises it)
         maxc = max(max(red[4], red[5]), max(red[6], red[7]));
         const int32_t excl = base + inc - c;
         if (tid < B) {
@@ -496,7 +499,8 @@ __global__ __launch_bounds__(kWalkThreads, SG_WALK_MINW) __attribute__((amdgpu_n
             if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc;
             __syncthreads();
             int32_t run = inc - s2;
-            for (int w2 = 0; w2 < tid / kWave; ++w2) run += red[12 + w2];
+#pragma unroll
+            for (int w2 = 0; w2 < kWalkThreads / kWave - 1; ++w2) run += w2 < tid / kWave ? red[12 + w2] : 0;
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
                 const int x = tid * CW + c;

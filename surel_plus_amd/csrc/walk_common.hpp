@@ -152,12 +152,12 @@ static inline size_t walk_lds_bytes(int T, int nwords, int M, int Q, bool spg, b
 
 // walk_rows_kernel with key rows: where its 16 reduction words live -- behind the walk tables (counts + ids: 8 bytes per slot, 12
 // with 64-bit counts; then the Fisher-Yates draws) AND behind what the epilogue's sort lays over them (sort elements: 8 bytes per
-// member, + 8 for a 64-bit key; level-1 offsets [NT+1]; the 16-bit counters of levels 2 and 3, one per member + 1, + the total's
-// word).  The tables usually are the larger part; few walks of many hops (M = 100, m = 4: 401 members in
+// member, + 8 for a 64-bit key; level-1 offsets [NT+1] (+3: the next array begins on 16 bytes); the 16-bit counters of levels 2 and
+// 3, 4 * NT words whatever the set's size: a lane zeroes, scans and reads its four as ONE 16-byte LDS access).  The tables usually are the larger part; few walks of many hops (M = 100, m = 4: 401 members in
 // a 512-slot table, 400 bytes of draws) and the 512-slot tables with 128 lanes turn that round.
 __host__ __device__ static inline size_t kr_red_offset(int T, int M, int stride, int NT, bool wide) {
     const size_t walk = (size_t)T * (wide ? 12 : 8) + (size_t)M * 4 + 8;
-    const size_t sort = (size_t)stride * (wide ? 16 : 8) + (size_t)(NT + 1) * 4 + (size_t)((stride + 2) / 2 + 1) * 4;
+    const size_t sort = (size_t)stride * (wide ? 16 : 8) + (size_t)(NT + 4) * 4 + (size_t)(4 * NT) * 4;
     return ((walk > sort ? walk : sort) + 15) & ~(size_t)15;
 }
 

@@ -42,8 +42,14 @@ namespace subgacc {
 #ifndef SG_ROWS_SGPR
 #define SG_ROWS_SGPR 102
 #endif
-#ifndef SG_ROWS_KR_WAVES1
-#define SG_ROWS_KR_WAVES1 7
+#ifndef SG_SORT_LEVELS      // finer levels of the key rows' sort behind level 1 (dev builds: 0 / 1 for timing; the result is sorted either way)
+#define SG_SORT_LEVELS 2
+#endif
+#ifndef SG_SORT_ZERO_UPFRONT
+#define SG_SORT_ZERO_UPFRONT 0
+#endif
+#ifndef SG_SORT_RANK_UNROLL
+#define SG_SORT_RANK_UNROLL 1
 #endif
 #ifndef SG_LAST_HOP_ID     // 1: with hop records, the last hop reads the bare id from `indices` (A/B: tools/ab.py)
 #define SG_LAST_HOP_ID 1
@@ -65,10 +71,10 @@ namespace subgacc {
 template <bool IDX64, int RNG, int MH, int SPL, int NT, int REC = 0, bool K32 = false, bool KR = false, int EPLP = 0>
 // (waves per SIMD asked of the register allocator: the table form with 32-bit counts holds 12 bytes of LDS per slot + the fold table,
 //  ~15 KB per workgroup of two waves = 5 waves per SIMD whatever the registers; 64-bit counts on 128 lanes, 10.5 KB: 7; the rest 8)
-//  key rows with 32-bit counts: 6 asked for; with five members per lane in the sort (EPLP = 5) the kernel lands on 72 VGPRs = SEVEN waves
-//  per SIMD without a spill -- on a graph with id locality the kernel is bound by its instructions and LDS round trips, not by missed
-//  lines, and the seventh wave is worth 6 %: cit2loc 0.627 -> 0.588 ms, profiles/r42_sort_ab.log; one wave per root: SG_ROWS_KR_WAVES1)
-__global__ __launch_bounds__(NT, K32 ? (KR ? (NT == 64 ? SG_ROWS_KR_WAVES1 : 6) : 5) : (KR ? 5 : (NT == 128 ? 7 : 8))) __attribute__((amdgpu_num_sgpr(SG_ROWS_SGPR))) void walk_rows_kernel(const WalkArgs a) {
+//  key rows with 32-bit counts: 6 asked for -- since round 6 the kernel needs 51 VGPRs (five members per lane in the sort, their state in
+//  one word each, no loops over the wave index for the compiler to vectorise): all eight wave slots of a SIMD; how many roots a CU
+//  then holds is the launch's choice, through the LDS it asks for: SG_ROWS_KR_LDS_MIN)
+__global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (KR ? 5 : (NT == 128 ? 7 : 8))) __attribute__((amdgpu_num_sgpr(SG_ROWS_SGPR))) void walk_rows_kernel(const WalkArgs a) {
     static_assert(!KR || SPL % 4 == 0, "key rows: 4-slot chunks");
     constexpr bool KR64 = KR && !K32;      // rows of 64-bit LP keys
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -101,6 +107,9 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? (NT == 64 ? SG_ROWS_KR_WAVES1 : 6) 
         if ((int64_t)blockIdx.x >= ge) return;
         const int64_t k = xcd_item(blockIdx.x, ge);
         if (k >= ne) return;
+        // (round 6 measured a record per list entry -- row, root id, the root's row pointers in ONE 16-byte read instead of the three
+        //  dependent ones worklist[k] -> query[i] -> indptr[root]: no difference on any workload, profiles/r51_workrec_ab.log; the
+        //  hardware's other resident workgroups hide that chain)
         i = a.worklist[k];
     } else {
         i = xcd_item(blockIdx.x, gridDim.x);
@@ -541,18 +550,15 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? (NT == 64 ? SG_ROWS_KR_WAVES1 : 6) 
         constexpr int CW = 4;                          // counter words per lane in the scan of levels 2 and 3
         constexpr int kFineAbove = 12;                 // a finer level from this many members in one (sub-)bucket on
         int32_t *start = (int32_t *)(lds_raw + (KR64 ? 16 : 8) * (size_t)a.stride);      // [B+1] level-1 counts, then offsets
-        uint32_t *cnt2 = (uint32_t *)(start + NT + 1);                                   // [(ns+2)/2 + 1] counters of levels 2 and 3, then offsets (+ the total)
+        uint32_t *cnt2 = (uint32_t *)(start + NT + 4);                                   // [CW * NT] 16-bit counters of levels 2 and 3 (0 .. ns used), then offsets; 16-byte aligned
         int logb = 0;
         while ((1 << logb) < ns && (2 << logb) <= T / 4 && (2 << logb) <= NT) ++logb;
         const int B = 1 << logb;
-        const int W2 = (ns + 2) / 2;                   // words of the counters 0 .. ns of levels 2 and 3 (<= CW * NT: checked at launch)
         const uint32_t range = (uint32_t)(mx - mn) + 1u;
         const int Ls = (range <= 1u) ? 0 : (32 - __builtin_clz(range - 1u));
         const int bshift = Ls > logb ? Ls - logb : 0;
         if (tid < B) start[tid] = 0;
-#pragma unroll
-        for (int c = 0; c < CW; ++c)
-            if (c * NT + tid < W2) cnt2[c * NT + tid] = 0u;
+        if (SG_SORT_ZERO_UPFRONT) ((uint4 *)cnt2)[tid] = make_uint4(0u, 0u, 0u, 0u);
         {
             int p = wbase + incl - cnt;
 #pragma unroll
@@ -569,20 +575,17 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? (NT == 64 ? SG_ROWS_KR_WAVES1 : 6) 
         }
         __syncthreads();
         SG_HOOK_RSTAMP(11);
-        // one more member of (sub-)bucket idx: -> how many came before it
-        auto count16 = [](uint32_t *cw, uint32_t idx) -> int32_t {
-            const uint32_t sh = (idx & 1u) * 16u;
-            return (int32_t)((atomicAdd(&cw[idx >> 1], 1u << sh) >> sh) & 0xFFFFu);
-        };
-        // exclusive scan of 2 * nw 16-bit counters in place (offsets <= ns < 2^16), CW consecutive words per lane; word nw receives
-        // the total in both halves (the end of the last bucket); -> the largest count
-        auto scan16 = [&](uint32_t *cw, int nw) -> int32_t {
-            uint32_t w[CW];
+        // exclusive scan of the CW * NT words of 16-bit counters in place (offsets <= ns < 2^16), CW consecutive words per lane: one
+        // 16-byte LDS read and one write per lane; the words behind the last counter are zero; -> the largest count
+        // (a wave's base = the totals of the waves in front of it: at most NT / 64 - 1 of them, spelled out -- as a loop over
+        //  tid / 64 the compiler vectorised it into 16-byte reads with a scalar tail, ~60 instructions for one addition)
+        auto scan16 = [&](uint32_t *cw) -> int32_t {
+            static_assert(CW == 4, "one uint4 per lane");
+            const uint4 v = ((const uint4 *)cw)[tid];
+            const uint32_t w[CW] = {v.x, v.y, v.z, v.w};
             int32_t s2 = 0, mc = 0;
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
-                const int x = tid * CW + c;
-                w[c] = x < nw ? cw[x] : 0u;
                 s2 += (int32_t)((w[c] & 0xFFFFu) + (w[c] >> 16));
                 mc = max(mc, max((int32_t)(w[c] & 0xFFFFu), (int32_t)(w[c] >> 16)));
             }
@@ -592,34 +595,49 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? (NT == 64 ? SG_ROWS_KR_WAVES1 : 6) 
             if (NT > kWave) {
                 if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc, red[4 + tid / kWave] = mc;
                 __syncthreads();
-                for (int w2 = 0; w2 < tid / kWave; ++w2) run += red[12 + w2];
+#pragma unroll
+                for (int w2 = 0; w2 < NT / kWave - 1; ++w2) run += w2 < tid / kWave ? red[12 + w2] : 0;
                 mc = red[4];
+#pragma unroll
                 for (int w2 = 1; w2 < NT / kWave; ++w2) mc = max(mc, red[4 + w2]);
             }
+            uint32_t o[CW];
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
-                const int x = tid * CW + c;
                 const uint32_t lo16 = (uint32_t)run;
                 run += (int32_t)(w[c] & 0xFFFFu);
-                const uint32_t hi16 = (uint32_t)run;
+                o[c] = lo16 | ((uint32_t)run << 16);
                 run += (int32_t)(w[c] >> 16);
-                if (x < nw) cw[x] = lo16 | (hi16 << 16);
-                if (x == nw - 1) cw[nw] = (uint32_t)run * 0x10001u;
             }
+            ((uint4 *)cw)[tid] = make_uint4(o[0], o[1], o[2], o[3]);
             return mc;
         };
         constexpr int EPL = EPLP ? EPLP : (NT == 64 && SPL == 8 ? 7 : SPL);      // members per lane: ns <= EPL * NT (checked at launch)
         unsigned long long el[EPL];
-        int32_t pos[EPL];                           // arrival order inside the (sub-)bucket, then the final position
-        // (the member's level-1 bucket, (id - mn) >> bshift, is worked out again wherever it is needed: two instructions against a
-        //  register per member held across every phase of the sort)
+        // A member's state across the phases of the sort: where its (sub-)bucket begins (while counting: the bucket's number), where it
+        // ends, the member's arrival order inside it -- positions and counts are <= ns <= 1,020 (checked at launch).  PACK: ONE word per
+        // member, 10 bits each, and the member's level-1 bucket worked out again wherever it is needed -- three more registers per
+        // member were 14 more VGPRs and a wave slot per SIMD, which the graph with id locality feels.  (!PACK, the plain registers of
+        // rounds 3-5, is kept as a form for the one-wave kernel, which loses ~4 % on collab to the new epilogue as a whole
+        // (profiles/r54_collab_bisect.log, r57_collab_levels_ab.log: not to the finer levels, not to occupancy, not to the unroll) --
+        // but unpacked it needs 80 VGPRs and spills, so it is off.)
+        // What an LDS operation returns is never used in the pass that issued it outside the level loop: a lane's reads and returning
+        // atomics of a pass are all in flight together.
+        constexpr bool PACK = true;
+        uint32_t st[EPL], s_hi[PACK ? 1 : EPL], s_pos[PACK ? 1 : EPL], s_bk[PACK ? 1 : EPL];
+        auto LO = [&](int e) -> uint32_t { return PACK ? (st[e] & 0x3FFu) : st[e]; };
+        auto HI = [&](int e) -> uint32_t { return PACK ? ((st[e] >> 10) & 0x3FFu) : s_hi[e]; };
+        auto POS = [&](int e) -> uint32_t { return PACK ? (st[e] >> 20) : s_pos[e]; };
+        auto BK = [&](int e) -> uint32_t { return PACK ? (((uint32_t)(el[e] >> 32) - (uint32_t)mn) >> bshift) : s_bk[e]; };
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             if (e * NT >= ns) break;
             const int x = e * NT + tid;
             if (x < ns) {
                 el[e] = A[x];
-                pos[e] = atomicAdd(&start[((uint32_t)(el[e] >> 32) - (uint32_t)mn) >> bshift], 1);
+                const uint32_t b1 = ((uint32_t)(el[e] >> 32) - (uint32_t)mn) >> bshift;
+                if (!PACK) s_bk[e] = b1;
+                (PACK ? st[e] : s_pos[e]) = (uint32_t)atomicAdd(&start[b1], 1);     // (the arrival order, as it comes)
             }
         }
         __syncthreads();
@@ -634,8 +652,10 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? (NT == 64 ? SG_ROWS_KR_WAVES1 : 6) 
             if (NT > kWave) {
                 if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc, red[4 + tid / kWave] = mc;
                 __syncthreads();
-                for (int w2 = 0; w2 < tid / kWave; ++w2) base += red[12 + w2];
+#pragma unroll
+                for (int w2 = 0; w2 < NT / kWave - 1; ++w2) base += w2 < tid / kWave ? red[12 + w2] : 0;
                 maxc = red[4];
+#pragma unroll
                 for (int w2 = 1; w2 < NT / kWave; ++w2) maxc = max(maxc, red[4 + w2]);
             }
             const int32_t excl = base + inc - c;
@@ -645,59 +665,94 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? (NT == 64 ? SG_ROWS_KR_WAVES1 : 6) 
         __syncthreads();
         SG_HOOK_RSTAMP(13);
         const uint16_t *off2 = (const uint16_t *)cnt2;
-        uint32_t bb[EPL];          // the member's (sub-)bucket: first position | end << 16 (positions <= ns < 2^16)
+        if (PACK) {
+            uint32_t ta[EPL], tb[EPL];         // what the first pass asked the LDS for, until the second packs it
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            if (e * NT >= ns) break;
-            if (e * NT + tid < ns) {
-                const uint32_t b1 = ((uint32_t)(el[e] >> 32) - (uint32_t)mn) >> bshift;
-                bb[e] = (uint32_t)start[b1] | ((uint32_t)start[b1 + 1] << 16);
+            for (int e = 0; e < EPL; ++e) {
+                if (e * NT >= ns) break;
+                if (e * NT + tid < ns) ta[e] = (uint32_t)start[BK(e)], tb[e] = (uint32_t)start[BK(e) + 1];
+            }
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                if (e * NT >= ns) break;
+                if (e * NT + tid < ns) st[e] = (st[e] << 20) | ta[e] | (tb[e] << 10);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                if (e * NT >= ns) break;
+                if (e * NT + tid < ns) st[e] = (uint32_t)start[BK(e)], s_hi[e] = (uint32_t)start[BK(e) + 1];
             }
         }
-        // levels 2 and 3: one loop body (a second copy of it cost 6 VGPRs and 40 bytes of scratch); the counters are the same words
+        // levels 2 and 3: the counters are the same words, scanned by the same code.  A (sub-)bucket of k members is cut into FINE * k
+        // parts, FINE = as many as the counter array holds for this set: the scan covers all 2 * CW * NT counters whatever the set's
+        // size, so the finer cut is free -- and on the graph with id locality it is what makes level 3 the exception (a community of
+        // 2,048 ids in a window of 32,768 cut into 3 x 250 parts: ~5 members each instead of ~16)
+        const uint32_t FINE = (uint32_t)(2 * CW * NT - 1) / (uint32_t)(ns + 1);      // >= 1: ns <= 2 * CW * NT - 2 (checked at launch)
 #pragma unroll 1
-        for (int lvl = 0; lvl < 2 && maxc > kFineAbove; ++lvl) {
-            if (lvl) {
-                __syncthreads();        // every lane has read its offsets of the level before
-#pragma unroll
-                for (int c = 0; c < CW; ++c)
-                    if (c * NT + tid < W2) cnt2[c * NT + tid] = 0u;
+        for (int lvl = 0; lvl < SG_SORT_LEVELS && maxc > kFineAbove; ++lvl) {
+            if (lvl || !SG_SORT_ZERO_UPFRONT) {
+                if (lvl) __syncthreads();        // every lane has read its offsets of the level before
+                ((uint4 *)cnt2)[tid] = make_uint4(0u, 0u, 0u, 0u);
                 __syncthreads();
             }
-            uint32_t idx2[EPL];
+            // (two copies of the member loop, not one with `if (lvl)` inside: the compiler turned that branch into selects and every
+            //  level-2 pass paid for level 3's float arithmetic -- 150 instructions a root on the one-wave form.  In here a member's
+            //  LDS results ARE used on the spot: this loop is the cold path of the structureless workloads.)
+            // during the count, LO(e) holds the number of the member's (sub-)bucket
+            if (lvl == 0) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    if (e * NT >= ns) break;
+                    if (e * NT + tid < ns) {
+                        const uint32_t ido = (uint32_t)(el[e] >> 32) - (uint32_t)mn, b1 = ido >> bshift;       // (not BK(e): the cold path keeps no register for it)
+                        const uint32_t lo1 = (uint32_t)start[b1], kb = ((uint32_t)start[b1 + 1] - lo1) * FINE;
+                        const uint32_t off = ido - (b1 << bshift);                                             // < 2^bshift
+                        const uint32_t idx = lo1 * FINE + (bshift ? __umulhi(off << (32 - bshift), kb) : 0u);  // + floor(off * kb / 2^bshift) < kb
+                        const uint32_t sh = (idx & 1u) * 16u;
+                        const uint32_t arrived = (atomicAdd(&cnt2[idx >> 1], 1u << sh) >> sh) & 0xFFFFu;
+                        if (PACK) st[e] = idx | (arrived << 20);
+                        else st[e] = idx, s_pos[e] = arrived;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    if (e * NT >= ns) break;
+                    if (e * NT + tid < ns) {
+                        const uint32_t ido = (uint32_t)(el[e] >> 32) - (uint32_t)mn, b1 = ido >> bshift;
+                        const uint32_t lo1 = (uint32_t)start[b1], kb = ((uint32_t)start[b1 + 1] - lo1) * FINE;
+                        const uint32_t off = ido - (b1 << bshift);
+                        const uint32_t sub = bshift ? __umulhi(off << (32 - bshift), kb) : 0u;
+                        // off * kb / 2^bshift - sub: where inside its level-2 sub-bucket's id window the member lies, [0, 1)
+                        const float fr = (float)off * __builtin_ldexpf((float)kb, -bshift) - (float)sub;
+                        const uint32_t lo2 = LO(e);
+                        const int k2 = ((int)HI(e) - (int)lo2) * (int)FINE;
+                        const uint32_t idx = lo2 * FINE + (uint32_t)min(max((int)(fr * (float)k2), 0), k2 - 1);
+                        const uint32_t sh = (idx & 1u) * 16u;
+                        const uint32_t arrived = (atomicAdd(&cnt2[idx >> 1], 1u << sh) >> sh) & 0xFFFFu;
+                        if (PACK) st[e] = idx | (arrived << 20);
+                        else st[e] = idx, s_pos[e] = arrived;
+                    }
+                }
+            }
+            __syncthreads();
+            maxc = scan16(cnt2);
+            __syncthreads();
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
                 if (e * NT >= ns) break;
                 if (e * NT + tid < ns) {
-                    const uint32_t ido = (uint32_t)(el[e] >> 32) - (uint32_t)mn, b1 = ido >> bshift;
-                    const uint32_t lo1 = (uint32_t)start[b1], kb = (uint32_t)start[b1 + 1] - lo1;
-                    const uint32_t off = ido - (b1 << bshift);                                             // < 2^bshift
-                    uint32_t sub = bshift ? __umulhi(off << (32 - bshift), kb) : 0u;                       // floor(off * kb / 2^bshift) < kb
-                    if (lvl) {
-                        // off * kb / 2^bshift - sub: where inside its level-2 sub-bucket's id window the member lies, [0, 1)
-                        const float fr = (float)off * __builtin_ldexpf((float)kb, -bshift) - (float)sub;
-                        const int k2 = (int)(bb[e] >> 16) - (int)(bb[e] & 0xFFFFu);
-                        sub = (uint32_t)min(max((int)(fr * (float)k2), 0), k2 - 1);
-                        idx2[e] = (bb[e] & 0xFFFFu) + sub;
-                    } else {
-                        idx2[e] = lo1 + sub;
-                    }
-                    pos[e] = count16(cnt2, idx2[e]);
+                    const uint32_t idx = LO(e);
+                    if (PACK) st[e] = (st[e] & 0x3FF00000u) | (uint32_t)off2[idx] | ((uint32_t)off2[idx + 1] << 10);
+                    else st[e] = (uint32_t)off2[idx], s_hi[e] = (uint32_t)off2[idx + 1];
                 }
-            }
-            __syncthreads();
-            maxc = scan16(cnt2, W2);
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                if (e * NT >= ns) break;
-                if (e * NT + tid < ns) bb[e] = (uint32_t)off2[idx2[e]] | ((uint32_t)off2[idx2[e] + 1] << 16);
             }
         }
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             if (e * NT >= ns) break;
-            if (e * NT + tid < ns) A[(bb[e] & 0xFFFFu) + (uint32_t)pos[e]] = el[e];         // every packed element was read before the barriers above
+            if (e * NT + tid < ns) A[LO(e) + POS(e)] = el[e];         // every packed element was read before the barriers above
         }
         __syncthreads();
         SG_HOOK_RSTAMP(14);
@@ -708,16 +763,18 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? (NT == 64 ? SG_ROWS_KR_WAVES1 : 6) 
             if (e * NT + tid < ns) {
                 const uint32_t me = (uint32_t)(el[e] >> 32);
                 int rank = 0;       // ids are distinct within a set: the high word of A decides
-                const int lo = (int)(bb[e] & 0xFFFFu), hi = (int)(bb[e] >> 16);
+                const int lo = (int)LO(e), hi = (int)HI(e);
                 int t2 = lo;
+#if SG_SORT_RANK_UNROLL
 #pragma unroll 1         // (four members per trip: the loop is LDS latency, not issue)
                 for (; t2 + 3 < hi; t2 += 4) {
                     const uint32_t a0 = Ahi[2 * t2 + 1], a1 = Ahi[2 * t2 + 3], a2 = Ahi[2 * t2 + 5], a3 = Ahi[2 * t2 + 7];
                     rank += (a0 < me ? 1 : 0) + (a1 < me ? 1 : 0) + (a2 < me ? 1 : 0) + (a3 < me ? 1 : 0);
                 }
+#endif
 #pragma unroll 1
                 for (; t2 < hi; ++t2) rank += (Ahi[2 * t2 + 1] < me) ? 1 : 0;
-                pos[e] = lo + rank;
+                st[e] = (uint32_t)(lo + rank);          // the member's final position
             }
         }
         __syncthreads();        // every rank is known: the bucket-grouped array can become the sorted one, in place
@@ -725,7 +782,7 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? (NT == 64 ? SG_ROWS_KR_WAVES1 : 6) 
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
             if (e * NT >= ns) break;
-            if (e * NT + tid < ns) A[pos[e]] = el[e];
+            if (e * NT + tid < ns) A[st[e]] = el[e];
         }
         __syncthreads();
         for (int x = tid; x < ns; x += NT) {
@@ -876,7 +933,8 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? (NT == 64 ? SG_ROWS_KR_WAVES1 : 6) 
         if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc, red[4 + tid / kWave] = mc;
         __syncthreads();
         int32_t base = 0;
-        for (int w2 = 0; w2 < tid / kWave; ++w2) base += red[12 + w2];
+#pragma unroll
+        for (int w2 = 0; w2 < NT / kWave - 1; ++w2) base += w2 < tid / kWave ? red[12 + w2] : 0;      // (spelled out: as a loop over tid / 64 the compiler vectorises it)
         maxc = red[4];
         for (int w2 = 1; w2 < NT / kWave; ++w2) maxc = max(maxc, red[4 + w2]);
         const int32_t excl = base + inc - c;
@@ -928,7 +986,8 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? (NT == 64 ? SG_ROWS_KR_WAVES1 : 6) 
             if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc;
             __syncthreads();
             int32_t run = inc - s2;
-            for (int w2 = 0; w2 < tid / kWave; ++w2) run += red[12 + w2];
+#pragma unroll
+            for (int w2 = 0; w2 < NT / kWave - 1; ++w2) run += w2 < tid / kWave ? red[12 + w2] : 0;
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
                 const int x = tid * CW + c;
@@ -1042,7 +1101,12 @@ int launch_walk_rows(const WalkArgs &a, bool indptr64, int rng_mode, size_t lds,
         if (a.m * a.shift + 1 > 31 || a.m > 4 || ((int64_t)a.stride + 2) / 2 + 1 > 4 * (a.T == 512 ? 64 : 128)) return 0;
         // (the reduction words sit behind the walk tables and behind the epilogue's sort, whichever reaches further: kr_red_offset)
         const bool one_wave = (nt64 || (!indptr64 && !nt128)) && a.m == 2 && a.T == 512;
-        const size_t ldsk = kr_red_offset(a.T, a.M, a.stride, one_wave ? 64 : 128, false) + 64 + 16;
+        // (SG_ROWS_KR_LDS_MIN, dev builds: LDS asked for per two-wave workgroup at least -- 160 KB / n roots per CU; A/B of 12 / 14 / 16 roots)
+#ifndef SG_ROWS_KR_LDS_MIN
+#define SG_ROWS_KR_LDS_MIN 0
+#endif
+        size_t ldsk = kr_red_offset(a.T, a.M, a.stride, one_wave ? 64 : 128, false) + 64 + 16;
+        if (!one_wave && ldsk < (size_t)SG_ROWS_KR_LDS_MIN) ldsk = SG_ROWS_KR_LDS_MIN;
 #define SG_KR_E(I64, RNGM, MHH, SPLL, EP)                                                                            \
     do {                                                                                                             \
         if (rec)                                                                                                     \

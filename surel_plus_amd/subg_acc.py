@@ -64,22 +64,29 @@ def gset_sampler(indptr, indices, query, num_walks=100, num_steps=3, bucket=-1, 
     return [nsize, remap, enc]
 
 
+PINNED_LIMIT = 256 << 20      # bytes: results beyond this leave through pageable memory
+
+
 def _rows_to_host(rows, others=()):
     """device rows (1-D, same dtype and length) -> one NumPy [len(rows), X] array over pinned memory, each row copied by its own
     async D2H (no stacked device copy, no pageable staging); `others`: more device tensors (or None) brought along the same way.
-    The arrays keep their pinned blocks alive; torch's host allocator takes the blocks back when they are dropped."""
+    The arrays keep their pinned blocks alive; torch's host allocator takes the blocks back when they are dropped -- but it rounds a
+    request up to a power of two and never returns a block to the OS, and these results are the caller's to keep (the offline stage
+    over all nodes hands over GBs): an array above PINNED_LIMIT is a pageable one (a slower copy, no page-locked memory left behind)."""
     host = None
     if rows:
-        host = torch.empty((len(rows), rows[0].numel()), dtype=rows[0].dtype, pin_memory=True)
+        big = len(rows) * rows[0].numel() * rows[0].element_size() > PINNED_LIMIT
+        host = torch.empty((len(rows), rows[0].numel()), dtype=rows[0].dtype, pin_memory=not big)
         for i, r in enumerate(rows):
-            host[i].copy_(r, non_blocking=True)
+            host[i].copy_(r, non_blocking=not big)
     extra = []
     for t in others:
         if t is None:
             extra.append(None)
             continue
-        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-        h.copy_(t, non_blocking=True)
+        big = t.numel() * t.element_size() > PINNED_LIMIT
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=not big)
+        h.copy_(t, non_blocking=not big)
         extra.append(h)
     devs = {t.device for t in list(rows) + [t for t in others if t is not None] if t.is_cuda}
     for dev in devs:           # (every copy went to the current stream of ITS tensor's device, which need not be the current device)

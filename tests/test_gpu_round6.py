@@ -262,3 +262,24 @@ def test_aligned_store_at_every_span_and_trip_boundary(sp, payload, max_len):
         sp.gather(e, za, "cuda", ptr=True, encode=za.slot_table() if payload == "keyed" else enc)
     with pytest.raises(IndexError):
         cj(torch.from_numpy(e).cuda()).finish()
+
+
+def test_rows_without_a_root_stay_empty_when_the_general_kernel_takes_a_work_list_call(sp):
+    """subgacc_walk_spg_list hands the launch to the general kernel when the fused-row kernel declines it (here: a
+    truncating bucket); that kernel reads no list and walks all n rows -- a row whose root is SUBGACC_NO_ROOT (what the list had left
+    out) must stay an EMPTY row there too, not be reported as a root outside the graph."""
+    from test_gpu_parity import sym_graph
+    N, M, m, bucket = 20000, 200, 2, 50
+    ptr_, idx = sym_graph(N, 60000, seed=6, hubs=2)
+    csr = sp.DeviceCSR(ptr_, idx)
+    q = np.random.default_rng(1).permutation(N)[:17000].astype(np.int32)
+    holes = np.random.default_rng(2).random(q.size) < 0.1
+    qh = q.copy()
+    qh[holes] = -2 ** 31
+    z, sets = sp.sample_spg(csr, qh, num_walks=M, num_steps=m, seed=4, rng="philox", bucket=bucket, fused=True)
+    nsize = sets.nsize.cpu().numpy()
+    assert (nsize[holes] == 0).all() and (nsize[~holes] > 0).all()
+    (oi, ox, od), oenc = _oracle_spg(ptr_, idx, q[~holes], M, m, 4, "philox", bucket)
+    keep = np.flatnonzero(~holes)
+    got_ptr = z.indptr.cpu().numpy()
+    assert np.array_equal(np.diff(got_ptr)[keep], np.diff(oi)) and np.array_equal(z.indices[: z.nnz].cpu().numpy(), ox)

@@ -16,6 +16,12 @@ for W in $WLS; do
   if [ $W = cit2ppr ]; then export SUBGACC_PPR_EAGER=1; fi
   bash tools/pmc_collect.sh gpurun_out/${TAG}_pmc_$W ${TAG}_$W --workload $W > gpurun_out/${TAG}_${W}_pmc.log 2>&1
   cp gpurun_out/${TAG}_pmc_$W/${TAG}_${W}_pmc_per_launch.csv gpurun_out/      # (pmc_traffic.py wrote it there and under profiles/)
+  if [ $W = cit2ppr ]; then      # ... and the packed store of rounds 1-5 beside the headed one
+    export SUBGACC_PPR_LAYOUT=packed
+    bash tools/pmc_collect.sh gpurun_out/${TAG}_pmc_${W}_packed ${TAG}_${W}_packed --workload $W > gpurun_out/${TAG}_${W}_packed_pmc.log 2>&1
+    cp gpurun_out/${TAG}_pmc_${W}_packed/${TAG}_${W}_packed_pmc_per_launch.csv gpurun_out/
+    unset SUBGACC_PPR_LAYOUT
+  fi
   unset SUBGACC_PPR_EAGER
 done
 cd /tmp && export TMPDIR=/tmp
@@ -25,6 +31,8 @@ cp $(find gpurun_out/${TAG}_stats_offline -name "*kernel_stats.csv" | head -1) g
 cp profiles/traffic.json gpurun_out/${TAG}_traffic.json
 # where the waves of the headline step's kernels spend their cycles (the 3-hop walk kernel's instruction / LDS floor, the join)
 bash tools/pmc_sq.sh gpurun_out/${TAG}_sq_cit2_passes --workload cit2 > gpurun_out/${TAG}_sq_cit2.csv 2> gpurun_out/${TAG}_sq_cit2.err
+bash tools/pmc_sq.sh gpurun_out/${TAG}_sq_cit2loc_passes --workload cit2loc > gpurun_out/${TAG}_sq_cit2loc.csv 2> gpurun_out/${TAG}_sq_cit2loc.err
+bash tools/pmc_sq.sh gpurun_out/${TAG}_sq_collab_passes --workload collab > gpurun_out/${TAG}_sq_collab.csv 2> gpurun_out/${TAG}_sq_collab.err
 ( time python bench.py --steps 20 --warmup 5 ) > gpurun_out/${TAG}_bench_cit2.json 2> gpurun_out/${TAG}_bench_cit2.err
 cp bench_detail.json gpurun_out/${TAG}_bench_cit2_detail.json
 tail -c 1500 gpurun_out/${TAG}_bench_cit2.json; tail -5 gpurun_out/${TAG}_bench_cit2.err

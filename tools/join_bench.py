@@ -54,6 +54,17 @@ def one(wl, n):
     flags = bufs.status.view(torch.int32)[:4]
     from surel_plus_amd import _lib
     out = bufs.out.view(-1)
+    # JB_OUT=fresh2m: the output in a buffer of its own that begins on a 2 MB boundary and was written once (round 6: does WHERE xz lies
+    # explain the run-to-run spread of the 4-hop join?); JB_OUT_SHIFT=bytes: the same, shifted by that many bytes
+    mode = os.environ.get("JB_OUT", "")
+    if mode in ("fresh2m", "fresh_empty"):      # a buffer of its own on a 2 MB boundary: written once before the clock / never written
+        big = (torch.zeros if mode == "fresh2m" else torch.empty)(out.numel() + (1 << 20), dtype=torch.float32, device=dev)
+        off = (-big.data_ptr()) % (2 << 20) + int(os.environ.get("JB_OUT_SHIFT", "0"))
+        out = big[off // 4: off // 4 + out.numel()]
+    elif mode == "pretouch":                     # the step buffers' own output, every page of it written once before the clock
+        out.zero_()
+    elif mode == "free_first":                   # the step buffers' own output, after the caching allocator gave its free blocks back
+        torch.cuda.empty_cache()
     # JB_PITCH=n (experiment): the same rows laid out again n words apart (n a multiple of 32: every row begins on a 128-byte line)
     stride, ids, slot = bufs.stride, bufs.ids, bufs.slot
     pitch = int(os.environ.get("JB_PITCH", "0"))
@@ -84,8 +95,9 @@ def one(wl, n):
         best.append(a.elapsed_time(b) / n)
     ms = sorted(best)[1]
     abytes = B * 64 + rows * (8 + 8 * k)
+    where = "  ".join(f"{nm} %2M={t.data_ptr() % (2 << 20):>8d} %1G={t.data_ptr() % (1 << 30) >> 20:>4d}M" for nm, t in (("xz", out), ("ids", ids), ("keys", slot)))
     print(f"{wl:8s} lib={os.environ.get('SUBGACC_LIB', '-'):40s} rows/pair {rows / B:6.1f}  join {ms:.4f} ms (min {min(best):.4f})  "
-          f"{abytes / ms / 1e9:.2f} TB/s  frac {abytes / (ms * 1e-3) / 8e12:.3f}", flush=True)
+          f"{abytes / ms / 1e9:.2f} TB/s  frac {abytes / (ms * 1e-3) / 8e12:.3f}   {where}", flush=True)
 
 
 def one_store(wl, n):
@@ -106,7 +118,8 @@ def one_store(wl, n):
     B = 65536
     e = query_pairs(csr, B, seed=1, device=dev, pos_frac=pos)
     buf = torch.empty(2 * B * z.max_len * 2 * k, dtype=torch.float32, device=dev)
-    for name, store, encode in (("table", z, table), ("keyed", zk, zk.slot_table())):
+    za = zk.aligned()
+    for name, store, encode in (("table", z, table), ("keyed", zk, zk.slot_table()), ("keyed-aligned", za, za.slot_table())):
         timer = bench.KernelTimer()
         sampler_mod.KERNEL_TIMER = timer
         rows = None
@@ -117,7 +130,7 @@ def one_store(wl, n):
         rows = int(ind[-1].item())
         ms = timer.mean_ms("sjoin_fill")[0]
         abytes = B * 64 + rows * (8 + 8 * k)
-        print(f"{wl:8s} {name:6s} store lib={os.environ.get('SUBGACC_LIB', '-'):40s} rows/pair {rows / B:6.1f}  fill {ms:.4f} ms  "
+        print(f"{wl:8s} {name:13s} store lib={os.environ.get('SUBGACC_LIB', '-'):40s} rows/pair {rows / B:6.1f}  fill {ms:.4f} ms  "
               f"{abytes / ms / 1e9:.2f} TB/s  frac {abytes / (ms * 1e-3) / 8e12:.3f}", flush=True)
     sampler_mod.KERNEL_TIMER = None
 

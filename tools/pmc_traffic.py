@@ -62,7 +62,8 @@ if line and "PPR" in line.get("metric", ""):      # the float join: its fill ker
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
         tj = {kk: v for kk, v in tj.items() if isinstance(v, dict) and "kernel_source_sha" in v}
-        tj[f"cit2ppr:{B}:join"] = {"join_hbm_bytes_per_launch": (2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024,
+        layout = os.environ.get("SUBGACC_PPR_LAYOUT", "aligned")       # (bench_ppr's default store layout since round 6: headed rows)
+        tj[f"cit2ppr:{B}:join" + (":aligned" if layout == "aligned" else "")] = {"join_hbm_bytes_per_launch": (2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024,
                                    "join_l2_miss_lines_per_launch": m.get("TCC_MISS_sum", 0), "kernel": k,
                                    "kernel_source_sha": bench.kernel_source_sha(), "source": f"profiles/{tag}_pmc_per_launch.csv",
                                    "how": "tools/pmc_collect.sh ... --workload cit2ppr (SUBGACC_PPR_EAGER=1: eager launches); bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024"}
@@ -76,7 +77,8 @@ if walk and line:
     for i, a in enumerate(bargs):
         if a == "--workload":
             name = bargs[i + 1]
-    key = f"{name}:{cfg['pairs_per_step_per_gpu']}:{cfg['num_walks']}:{cfg['num_steps_cli']}:{'spg' if cfg['fused_spg_rows'] else 'sets'}:{cfg['rng']}"
+    # (M and k from the workload table: the compact line no longer carries them; the step's rows are fused rows for every preset)
+    key = f"{name}:{cfg['pairs_per_step_per_gpu']}:{bench.WORKLOADS[name][1]}:{bench.WORKLOADS[name][2]}:spg:{cfg['rng']}"
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
     tj = {k: v for k, v in tj.items() if isinstance(v, dict) and "kernel_source_sha" in v}     # entries without a hash are stale
