@@ -614,167 +614,283 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (KR ? 5 : (NT == 128 ? 7 :
         };
         constexpr int EPL = EPLP ? EPLP : (NT == 64 && SPL == 8 ? 7 : SPL);      // members per lane: ns <= EPL * NT (checked at launch)
         unsigned long long el[EPL];
-        // A member's state across the phases of the sort: where its (sub-)bucket begins (while counting: the bucket's number), where it
-        // ends, the member's arrival order inside it -- positions and counts are <= ns <= 1,020 (checked at launch).  PACK: ONE word per
-        // member, 10 bits each, and the member's level-1 bucket worked out again wherever it is needed -- three more registers per
-        // member were 14 more VGPRs and a wave slot per SIMD, which the graph with id locality feels.  (!PACK, the plain registers of
-        // rounds 3-5, is kept as a form for the one-wave kernel, which loses ~4 % on collab to the new epilogue as a whole
-        // (profiles/r54_collab_bisect.log, r57_collab_levels_ab.log: not to the finer levels, not to occupancy, not to the unroll) --
-        // but unpacked it needs 80 VGPRs and spills, so it is off.)
-        // What an LDS operation returns is never used in the pass that issued it outside the level loop: a lane's reads and returning
-        // atomics of a pass are all in flight together.
-        constexpr bool PACK = true;
-        uint32_t st[EPL], s_hi[PACK ? 1 : EPL], s_pos[PACK ? 1 : EPL], s_bk[PACK ? 1 : EPL];
-        auto LO = [&](int e) -> uint32_t { return PACK ? (st[e] & 0x3FFu) : st[e]; };
-        auto HI = [&](int e) -> uint32_t { return PACK ? ((st[e] >> 10) & 0x3FFu) : s_hi[e]; };
-        auto POS = [&](int e) -> uint32_t { return PACK ? (st[e] >> 20) : s_pos[e]; };
-        auto BK = [&](int e) -> uint32_t { return PACK ? (((uint32_t)(el[e] >> 32) - (uint32_t)mn) >> bshift) : s_bk[e]; };
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            if (e * NT >= ns) break;
-            const int x = e * NT + tid;
-            if (x < ns) {
-                el[e] = A[x];
-                const uint32_t b1 = ((uint32_t)(el[e] >> 32) - (uint32_t)mn) >> bshift;
-                if (!PACK) s_bk[e] = b1;
-                (PACK ? st[e] : s_pos[e]) = (uint32_t)atomicAdd(&start[b1], 1);     // (the arrival order, as it comes)
-            }
-        }
-        __syncthreads();
-        SG_HOOK_RSTAMP(12);
-        int32_t maxc;
-        {   // level 1: exclusive scan over the B <= NT buckets, one bucket per lane
-            const int32_t c = tid < B ? start[tid] : 0;
-            const int32_t inc = wave_scan_add_i32_incl(c);
-            const int32_t mc = wave_red_max_i32(c);
-            int32_t base = 0;
-            maxc = mc;
-            if (NT > kWave) {
-                if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc, red[4 + tid / kWave] = mc;
-                __syncthreads();
-#pragma unroll
-                for (int w2 = 0; w2 < NT / kWave - 1; ++w2) base += w2 < tid / kWave ? red[12 + w2] : 0;
-                maxc = red[4];
-#pragma unroll
-                for (int w2 = 1; w2 < NT / kWave; ++w2) maxc = max(maxc, red[4 + w2]);
-            }
-            const int32_t excl = base + inc - c;
-            if (tid < B) start[tid] = excl;
-            if (tid == B - 1) start[B] = excl + c;
-        }
-        __syncthreads();
-        SG_HOOK_RSTAMP(13);
-        const uint16_t *off2 = (const uint16_t *)cnt2;
-        if (PACK) {
-            uint32_t ta[EPL], tb[EPL];         // what the first pass asked the LDS for, until the second packs it
+        uint32_t st[EPL];           // the member's state across the phases (below); at the end: its final position in the row
+        if (NT == kWave) {
+            // ONE wavefront per root (the 2-hop shapes over int32 row offsets: collab): the two-level sort of rounds 3-5 with a member's
+            // bucket, arrival order and bucket bounds in registers of their own.  The multi-level form below -- packed state, buckets
+            // recomputed, a loop over the finer levels -- costs this shape 4-5 % on the structureless collab-like graph, and none of
+            // its parts alone explains it (profiles/r54_collab_bisect.log, r57_collab_levels_ab.log, r59_collab_nt128_ab.log: not the
+            // finer levels, not occupancy, not the SGPR cap, not the unrolled ranking loop; two waves per root: +25 %); this form has
+            // the registers (66) and its sets are small (<= 408 members: level 2 leaves at most a handful per sub-bucket).
+            constexpr int CW1 = 4;
+            const int W2 = (ns + 2) / 2 + 1;               // words that hold counters 0 .. ns (counter ns stays 0: its offset is the total)
+            uint32_t bk[EPL];
+            int32_t pos[EPL];                           // arrival order inside the sub-bucket
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
                 if (e * NT >= ns) break;
-                if (e * NT + tid < ns) ta[e] = (uint32_t)start[BK(e)], tb[e] = (uint32_t)start[BK(e) + 1];
+                const int x = e * NT + tid;
+                if (x < ns) {
+                    el[e] = A[x];
+                    bk[e] = ((uint32_t)(el[e] >> 32) - (uint32_t)mn) >> bshift;
+                    pos[e] = atomicAdd(&start[bk[e]], 1);
+                }
             }
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                if (e * NT >= ns) break;
-                if (e * NT + tid < ns) st[e] = (st[e] << 20) | ta[e] | (tb[e] << 10);
+            __syncthreads();
+            SG_HOOK_RSTAMP(12);
+            int32_t maxc;
+            {
+                const int32_t c = tid < B ? start[tid] : 0;
+                const int32_t inc = wave_scan_add_i32_incl(c);
+                maxc = wave_red_max_i32(c);
+                const int32_t excl = inc - c;
+                if (tid < B) start[tid] = excl;
+                if (tid == B - 1) start[B] = excl + c;
             }
-        } else {
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) {
-                if (e * NT >= ns) break;
-                if (e * NT + tid < ns) st[e] = (uint32_t)start[BK(e)], s_hi[e] = (uint32_t)start[BK(e) + 1];
-            }
-        }
-        // levels 2 and 3: the counters are the same words, scanned by the same code.  A (sub-)bucket of k members is cut into FINE * k
-        // parts, FINE = as many as the counter array holds for this set: the scan covers all 2 * CW * NT counters whatever the set's
-        // size, so the finer cut is free -- and on the graph with id locality it is what makes level 3 the exception (a community of
-        // 2,048 ids in a window of 32,768 cut into 3 x 250 parts: ~5 members each instead of ~16)
-        const uint32_t FINE = (uint32_t)(2 * CW * NT - 1) / (uint32_t)(ns + 1);      // >= 1: ns <= 2 * CW * NT - 2 (checked at launch)
-#pragma unroll 1
-        for (int lvl = 0; lvl < SG_SORT_LEVELS && maxc > kFineAbove; ++lvl) {
-            if (lvl || !SG_SORT_ZERO_UPFRONT) {
-                if (lvl) __syncthreads();        // every lane has read its offsets of the level before
-                ((uint4 *)cnt2)[tid] = make_uint4(0u, 0u, 0u, 0u);
-                __syncthreads();
-            }
-            // (two copies of the member loop, not one with `if (lvl)` inside: the compiler turned that branch into selects and every
-            //  level-2 pass paid for level 3's float arithmetic -- 150 instructions a root on the one-wave form.  In here a member's
-            //  LDS results ARE used on the spot: this loop is the cold path of the structureless workloads.)
-            // during the count, LO(e) holds the number of the member's (sub-)bucket
-            if (lvl == 0) {
+            __syncthreads();
+            SG_HOOK_RSTAMP(13);
+            int blo[EPL], bhi[EPL];
+            if (maxc <= kFineAbove) {
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
                     if (e * NT >= ns) break;
                     if (e * NT + tid < ns) {
-                        const uint32_t ido = (uint32_t)(el[e] >> 32) - (uint32_t)mn, b1 = ido >> bshift;       // (not BK(e): the cold path keeps no register for it)
-                        const uint32_t lo1 = (uint32_t)start[b1], kb = ((uint32_t)start[b1 + 1] - lo1) * FINE;
-                        const uint32_t off = ido - (b1 << bshift);                                             // < 2^bshift
-                        const uint32_t idx = lo1 * FINE + (bshift ? __umulhi(off << (32 - bshift), kb) : 0u);  // + floor(off * kb / 2^bshift) < kb
-                        const uint32_t sh = (idx & 1u) * 16u;
-                        const uint32_t arrived = (atomicAdd(&cnt2[idx >> 1], 1u << sh) >> sh) & 0xFFFFu;
-                        if (PACK) st[e] = idx | (arrived << 20);
-                        else st[e] = idx, s_pos[e] = arrived;
+                        blo[e] = start[bk[e]];
+                        bhi[e] = start[bk[e] + 1];
                     }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CW1; ++c)
+                    if (c * NT + tid < W2) cnt2[c * NT + tid] = 0u;
+                __syncthreads();
+                uint32_t idx2[EPL];
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    if (e * NT >= ns) break;
+                    if (e * NT + tid < ns) {
+                        const uint32_t lo1 = (uint32_t)start[bk[e]], kb = (uint32_t)start[bk[e] + 1] - lo1;
+                        const uint32_t off = ((uint32_t)(el[e] >> 32) - (uint32_t)mn) - (bk[e] << bshift);      // < 2^bshift
+                        const uint32_t sub = bshift ? __umulhi(off << (32 - bshift), kb) : 0u;                 // floor(off * kb / 2^bshift) < kb
+                        idx2[e] = lo1 + sub;
+                        const uint32_t sh = (idx2[e] & 1u) * 16u;
+                        pos[e] = (int32_t)((atomicAdd(&cnt2[idx2[e] >> 1], 1u << sh) >> sh) & 0xFFFFu);
+                    }
+                }
+                __syncthreads();
+                {   // exclusive scan of the ns + 1 level-2 counters, in place (offsets <= ns < 2^16): CW1 consecutive words per lane
+                    uint32_t w[CW1];
+                    int32_t s2 = 0;
+#pragma unroll
+                    for (int c = 0; c < CW1; ++c) {
+                        const int x = tid * CW1 + c;
+                        w[c] = x < W2 ? cnt2[x] : 0u;
+                        s2 += (int32_t)((w[c] & 0xFFFFu) + (w[c] >> 16));
+                    }
+                    int32_t run = wave_scan_add_i32_incl(s2) - s2;
+#pragma unroll
+                    for (int c = 0; c < CW1; ++c) {
+                        const int x = tid * CW1 + c;
+                        const uint32_t lo16 = (uint32_t)run;
+                        run += (int32_t)(w[c] & 0xFFFFu);
+                        const uint32_t hi16 = (uint32_t)run;
+                        run += (int32_t)(w[c] >> 16);
+                        if (x < W2) cnt2[x] = lo16 | (hi16 << 16);
+                    }
+                }
+                __syncthreads();
+                const uint16_t *off2 = (const uint16_t *)cnt2;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    if (e * NT >= ns) break;
+                    if (e * NT + tid < ns) {
+                        blo[e] = off2[idx2[e]];
+                        bhi[e] = off2[idx2[e] + 1];
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                if (e * NT >= ns) break;
+                if (e * NT + tid < ns) A[blo[e] + pos[e]] = el[e];         // every packed element was read before the barriers above
+            }
+            __syncthreads();
+            SG_HOOK_RSTAMP(14);
+            const uint32_t *Ahi = (const uint32_t *)A;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                if (e * NT >= ns) break;
+                if (e * NT + tid < ns) {
+                    const uint32_t me = (uint32_t)(el[e] >> 32);
+                    int rank = 0;       // ids are distinct within a set: the high word of A decides
+#pragma unroll 1
+                    for (int t2 = blo[e]; t2 < bhi[e]; ++t2) rank += (Ahi[2 * t2 + 1] < me) ? 1 : 0;
+                    st[e] = (uint32_t)(blo[e] + rank);
+                }
+            }
+        } else {
+            // A member's state across the phases of the sort: where its (sub-)bucket begins (while counting: the bucket's number), where it
+            // ends, the member's arrival order inside it -- positions and counts are <= ns <= 1,020 (checked at launch).  PACK: ONE word per
+            // member, 10 bits each, and the member's level-1 bucket worked out again wherever it is needed -- three more registers per
+            // member were 14 more VGPRs and a wave slot per SIMD, which the graph with id locality feels.  (!PACK, the plain registers of
+            // rounds 3-5, is kept as a form for the one-wave kernel, which loses ~4 % on collab to the new epilogue as a whole
+            // (profiles/r54_collab_bisect.log, r57_collab_levels_ab.log: not to the finer levels, not to occupancy, not to the unroll) --
+            // but unpacked it needs 80 VGPRs and spills, so it is off.)
+            // What an LDS operation returns is never used in the pass that issued it outside the level loop: a lane's reads and returning
+            // atomics of a pass are all in flight together.
+            constexpr bool PACK = true;
+            uint32_t s_hi[PACK ? 1 : EPL], s_pos[PACK ? 1 : EPL], s_bk[PACK ? 1 : EPL];
+            auto LO = [&](int e) -> uint32_t { return PACK ? (st[e] & 0x3FFu) : st[e]; };
+            auto HI = [&](int e) -> uint32_t { return PACK ? ((st[e] >> 10) & 0x3FFu) : s_hi[e]; };
+            auto POS = [&](int e) -> uint32_t { return PACK ? (st[e] >> 20) : s_pos[e]; };
+            auto BK = [&](int e) -> uint32_t { return PACK ? (((uint32_t)(el[e] >> 32) - (uint32_t)mn) >> bshift) : s_bk[e]; };
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                if (e * NT >= ns) break;
+                const int x = e * NT + tid;
+                if (x < ns) {
+                    el[e] = A[x];
+                    const uint32_t b1 = ((uint32_t)(el[e] >> 32) - (uint32_t)mn) >> bshift;
+                    if (!PACK) s_bk[e] = b1;
+                    (PACK ? st[e] : s_pos[e]) = (uint32_t)atomicAdd(&start[b1], 1);     // (the arrival order, as it comes)
+                }
+            }
+            __syncthreads();
+            SG_HOOK_RSTAMP(12);
+            int32_t maxc;
+            {   // level 1: exclusive scan over the B <= NT buckets, one bucket per lane
+                const int32_t c = tid < B ? start[tid] : 0;
+                const int32_t inc = wave_scan_add_i32_incl(c);
+                const int32_t mc = wave_red_max_i32(c);
+                int32_t base = 0;
+                maxc = mc;
+                if (NT > kWave) {
+                    if ((tid & (kWave - 1)) == kWave - 1) red[12 + tid / kWave] = inc, red[4 + tid / kWave] = mc;
+                    __syncthreads();
+#pragma unroll
+                    for (int w2 = 0; w2 < NT / kWave - 1; ++w2) base += w2 < tid / kWave ? red[12 + w2] : 0;
+                    maxc = red[4];
+#pragma unroll
+                    for (int w2 = 1; w2 < NT / kWave; ++w2) maxc = max(maxc, red[4 + w2]);
+                }
+                const int32_t excl = base + inc - c;
+                if (tid < B) start[tid] = excl;
+                if (tid == B - 1) start[B] = excl + c;
+            }
+            __syncthreads();
+            SG_HOOK_RSTAMP(13);
+            const uint16_t *off2 = (const uint16_t *)cnt2;
+            if (PACK) {
+                uint32_t ta[EPL], tb[EPL];         // what the first pass asked the LDS for, until the second packs it
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    if (e * NT >= ns) break;
+                    if (e * NT + tid < ns) ta[e] = (uint32_t)start[BK(e)], tb[e] = (uint32_t)start[BK(e) + 1];
+                }
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    if (e * NT >= ns) break;
+                    if (e * NT + tid < ns) st[e] = (st[e] << 20) | ta[e] | (tb[e] << 10);
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
                     if (e * NT >= ns) break;
+                    if (e * NT + tid < ns) st[e] = (uint32_t)start[BK(e)], s_hi[e] = (uint32_t)start[BK(e) + 1];
+                }
+            }
+            // levels 2 and 3: the counters are the same words, scanned by the same code.  A (sub-)bucket of k members is cut into FINE * k
+            // parts, FINE = as many as the counter array holds for this set: the scan covers all 2 * CW * NT counters whatever the set's
+            // size, so the finer cut is free -- and on the graph with id locality it is what makes level 3 the exception (a community of
+            // 2,048 ids in a window of 32,768 cut into 3 x 250 parts: ~5 members each instead of ~16)
+            const uint32_t FINE = (uint32_t)(2 * CW * NT - 1) / (uint32_t)(ns + 1);      // >= 1: ns <= 2 * CW * NT - 2 (checked at launch)
+#pragma unroll 1
+            for (int lvl = 0; lvl < SG_SORT_LEVELS && maxc > kFineAbove; ++lvl) {
+                if (lvl || !SG_SORT_ZERO_UPFRONT) {
+                    if (lvl) __syncthreads();        // every lane has read its offsets of the level before
+                    ((uint4 *)cnt2)[tid] = make_uint4(0u, 0u, 0u, 0u);
+                    __syncthreads();
+                }
+                // (two copies of the member loop, not one with `if (lvl)` inside: the compiler turned that branch into selects and every
+                //  level-2 pass paid for level 3's float arithmetic -- 150 instructions a root on the one-wave form.  In here a member's
+                //  LDS results ARE used on the spot: this loop is the cold path of the structureless workloads.)
+                // during the count, LO(e) holds the number of the member's (sub-)bucket
+                if (lvl == 0) {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) {
+                        if (e * NT >= ns) break;
+                        if (e * NT + tid < ns) {
+                            const uint32_t ido = (uint32_t)(el[e] >> 32) - (uint32_t)mn, b1 = ido >> bshift;       // (not BK(e): the cold path keeps no register for it)
+                            const uint32_t lo1 = (uint32_t)start[b1], kb = ((uint32_t)start[b1 + 1] - lo1) * FINE;
+                            const uint32_t off = ido - (b1 << bshift);                                             // < 2^bshift
+                            const uint32_t idx = lo1 * FINE + (bshift ? __umulhi(off << (32 - bshift), kb) : 0u);  // + floor(off * kb / 2^bshift) < kb
+                            const uint32_t sh = (idx & 1u) * 16u;
+                            const uint32_t arrived = (atomicAdd(&cnt2[idx >> 1], 1u << sh) >> sh) & 0xFFFFu;
+                            if (PACK) st[e] = idx | (arrived << 20);
+                            else st[e] = idx, s_pos[e] = arrived;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) {
+                        if (e * NT >= ns) break;
+                        if (e * NT + tid < ns) {
+                            const uint32_t ido = (uint32_t)(el[e] >> 32) - (uint32_t)mn, b1 = ido >> bshift;
+                            const uint32_t lo1 = (uint32_t)start[b1], kb = ((uint32_t)start[b1 + 1] - lo1) * FINE;
+                            const uint32_t off = ido - (b1 << bshift);
+                            const uint32_t sub = bshift ? __umulhi(off << (32 - bshift), kb) : 0u;
+                            // off * kb / 2^bshift - sub: where inside its level-2 sub-bucket's id window the member lies, [0, 1)
+                            const float fr = (float)off * __builtin_ldexpf((float)kb, -bshift) - (float)sub;
+                            const uint32_t lo2 = LO(e);
+                            const int k2 = ((int)HI(e) - (int)lo2) * (int)FINE;
+                            const uint32_t idx = lo2 * FINE + (uint32_t)min(max((int)(fr * (float)k2), 0), k2 - 1);
+                            const uint32_t sh = (idx & 1u) * 16u;
+                            const uint32_t arrived = (atomicAdd(&cnt2[idx >> 1], 1u << sh) >> sh) & 0xFFFFu;
+                            if (PACK) st[e] = idx | (arrived << 20);
+                            else st[e] = idx, s_pos[e] = arrived;
+                        }
+                    }
+                }
+                __syncthreads();
+                maxc = scan16(cnt2);
+                __syncthreads();
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    if (e * NT >= ns) break;
                     if (e * NT + tid < ns) {
-                        const uint32_t ido = (uint32_t)(el[e] >> 32) - (uint32_t)mn, b1 = ido >> bshift;
-                        const uint32_t lo1 = (uint32_t)start[b1], kb = ((uint32_t)start[b1 + 1] - lo1) * FINE;
-                        const uint32_t off = ido - (b1 << bshift);
-                        const uint32_t sub = bshift ? __umulhi(off << (32 - bshift), kb) : 0u;
-                        // off * kb / 2^bshift - sub: where inside its level-2 sub-bucket's id window the member lies, [0, 1)
-                        const float fr = (float)off * __builtin_ldexpf((float)kb, -bshift) - (float)sub;
-                        const uint32_t lo2 = LO(e);
-                        const int k2 = ((int)HI(e) - (int)lo2) * (int)FINE;
-                        const uint32_t idx = lo2 * FINE + (uint32_t)min(max((int)(fr * (float)k2), 0), k2 - 1);
-                        const uint32_t sh = (idx & 1u) * 16u;
-                        const uint32_t arrived = (atomicAdd(&cnt2[idx >> 1], 1u << sh) >> sh) & 0xFFFFu;
-                        if (PACK) st[e] = idx | (arrived << 20);
-                        else st[e] = idx, s_pos[e] = arrived;
+                        const uint32_t idx = LO(e);
+                        if (PACK) st[e] = (st[e] & 0x3FF00000u) | (uint32_t)off2[idx] | ((uint32_t)off2[idx + 1] << 10);
+                        else st[e] = (uint32_t)off2[idx], s_hi[e] = (uint32_t)off2[idx + 1];
                     }
                 }
             }
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) {
+                if (e * NT >= ns) break;
+                if (e * NT + tid < ns) A[LO(e) + POS(e)] = el[e];         // every packed element was read before the barriers above
+            }
             __syncthreads();
-            maxc = scan16(cnt2);
-            __syncthreads();
+            SG_HOOK_RSTAMP(14);
+            const uint32_t *Ahi = (const uint32_t *)A;
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
                 if (e * NT >= ns) break;
                 if (e * NT + tid < ns) {
-                    const uint32_t idx = LO(e);
-                    if (PACK) st[e] = (st[e] & 0x3FF00000u) | (uint32_t)off2[idx] | ((uint32_t)off2[idx + 1] << 10);
-                    else st[e] = (uint32_t)off2[idx], s_hi[e] = (uint32_t)off2[idx + 1];
-                }
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            if (e * NT >= ns) break;
-            if (e * NT + tid < ns) A[LO(e) + POS(e)] = el[e];         // every packed element was read before the barriers above
-        }
-        __syncthreads();
-        SG_HOOK_RSTAMP(14);
-        const uint32_t *Ahi = (const uint32_t *)A;
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            if (e * NT >= ns) break;
-            if (e * NT + tid < ns) {
-                const uint32_t me = (uint32_t)(el[e] >> 32);
-                int rank = 0;       // ids are distinct within a set: the high word of A decides
-                const int lo = (int)LO(e), hi = (int)HI(e);
-                int t2 = lo;
+                    const uint32_t me = (uint32_t)(el[e] >> 32);
+                    int rank = 0;       // ids are distinct within a set: the high word of A decides
+                    const int lo = (int)LO(e), hi = (int)HI(e);
+                    int t2 = lo;
 #if SG_SORT_RANK_UNROLL
 #pragma unroll 1         // (four members per trip: the loop is LDS latency, not issue)
-                for (; t2 + 3 < hi; t2 += 4) {
-                    const uint32_t a0 = Ahi[2 * t2 + 1], a1 = Ahi[2 * t2 + 3], a2 = Ahi[2 * t2 + 5], a3 = Ahi[2 * t2 + 7];
-                    rank += (a0 < me ? 1 : 0) + (a1 < me ? 1 : 0) + (a2 < me ? 1 : 0) + (a3 < me ? 1 : 0);
-                }
+                    for (; t2 + 3 < hi; t2 += 4) {
+                        const uint32_t a0 = Ahi[2 * t2 + 1], a1 = Ahi[2 * t2 + 3], a2 = Ahi[2 * t2 + 5], a3 = Ahi[2 * t2 + 7];
+                        rank += (a0 < me ? 1 : 0) + (a1 < me ? 1 : 0) + (a2 < me ? 1 : 0) + (a3 < me ? 1 : 0);
+                    }
 #endif
 #pragma unroll 1
-                for (; t2 < hi; ++t2) rank += (Ahi[2 * t2 + 1] < me) ? 1 : 0;
-                st[e] = (uint32_t)(lo + rank);          // the member's final position
+                    for (; t2 < hi; ++t2) rank += (Ahi[2 * t2 + 1] < me) ? 1 : 0;
+                    st[e] = (uint32_t)(lo + rank);          // the member's final position
+                }
             }
         }
         __syncthreads();        // every rank is known: the bucket-grouped array can become the sorted one, in place
