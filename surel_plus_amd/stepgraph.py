@@ -5,7 +5,7 @@ a step (tens of microseconds) is smaller than the cost of launching its ~25 kern
 captured once for a fixed (B, M, m) -- the C ABI allocates nothing and never synchronises (include/subgacc.h), torch's
 allocator serves a capture from a private pool -- and replayed with new pairs copied into a static input buffer.
 Sizes and status flags stay on the device during the replay (the lazy forms of sampler / spjoin); finish() reads them
-back in one small copy.  Results are the ones the eager path gives (tests/test_gpu_parity.py).
+back in one small copy.  Results are the ones the eager path gives (tests/test_gpu_join.py).
 
 Philox streams are keyed by (seed, root id, walk, step) and the seed is baked into the captured launches: a root's set
 is the same in every replay -- the semantics of the reference's offline stage, where every node's set is sampled once

@@ -11,7 +11,7 @@ import scipy.sparse as sps
 import torch
 
 from oracle import oracle as orc
-from test_gpu_parity import sym_graph
+from gpu_helpers import sym_graph
 
 pytestmark = pytest.mark.gpu
 

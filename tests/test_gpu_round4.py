@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import oracle
-from test_gpu_parity import _oracle_spg, dir_graph, sp, sym_graph  # noqa: F401
+from gpu_helpers import _oracle_spg, dir_graph, sp, sym_graph  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 

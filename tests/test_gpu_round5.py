@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import oracle
-from test_gpu_parity import _oracle_spg, dir_graph, sp, sym_graph  # noqa: F401
+from gpu_helpers import _oracle_spg, dir_graph, sp, sym_graph  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
@@ -218,7 +218,7 @@ def test_one_call_join_over_strided_key_rows_matches_the_two_step_form(sp):
     from surel_plus_amd.graphs import query_pairs
     from surel_plus_amd.spg import sample_spg
     from surel_plus_amd.spjoin import _arange_segments, sjoin
-    from test_gpu_parity import sym_graph
+    from gpu_helpers import sym_graph
     ptr_, idx = sym_graph(4000, 30000, seed=2, hubs=2)
     csr = sp.DeviceCSR(ptr_, idx)
     B = 3000
@@ -339,7 +339,7 @@ def test_one_call_join_size_pass_beyond_the_resident_grid(sp):
 def test_one_call_join_matches_reference_golden(sp, name):
     """the reference's own outputs (train.gather run in the build container, tests/golden/): CapturedJoin / CapturedJoinPool -- one
     library call per batch -- give the same (xz, indptr), bit for bit, as the fixtures hold for ptr=True"""
-    from test_gpu_parity import _load, _spg_from_golden
+    from gpu_helpers import _load, _spg_from_golden
     g = _load(name)
     z = _spg_from_golden(sp, g)
     enc = torch.from_numpy(g["encode"]).cuda() if g["encode"].size else None
@@ -356,7 +356,7 @@ def test_one_call_join_matches_reference_golden(sp, name):
 
 def test_one_call_hgather_matches_reference_golden(sp):
     """train.hgather's own output (tests/golden/hjoin_int.npz) through CapturedJoin(triplets=True)"""
-    from test_gpu_parity import _load, _spg_from_golden
+    from gpu_helpers import _load, _spg_from_golden
     g = _load("hjoin_int.npz")
     z = _spg_from_golden(sp, g)
     hedge = np.asarray(g["hedge"])

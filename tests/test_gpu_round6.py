@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import oracle
-from test_gpu_parity import _oracle_spg, sp  # noqa: F401
+from gpu_helpers import _oracle_spg, sp  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
@@ -126,7 +126,7 @@ def test_four_threads_of_lazy_steps_on_four_streams(sp):
     import threading
 
     from surel_plus_amd.graphs import query_pairs
-    from test_gpu_parity import sym_graph
+    from gpu_helpers import sym_graph
     ptr_, idx = sym_graph(20000, 120000, seed=13, hubs=3)
     csr = sp.DeviceCSR(ptr_, idx)
     M, hops, B, STEPS = 64, 2, 256, 2000
@@ -174,7 +174,7 @@ def test_aligned_store_matches_reference_golden(sp, name):
     """the reference's own outputs (train.gather run in the build container, tests/golden/) through the store laid out again on whole
     128-byte lines -- SpG.aligned(): rows at a fixed pitch, their lengths in their first slots, no row pointers -- eagerly (size
     pass alone, then the fill), lazily (one call), as CapturedJoin / CapturedJoinPool, with segment pointers and segment ids"""
-    from test_gpu_parity import _load, _spg_from_golden
+    from gpu_helpers import _load, _spg_from_golden
     g = _load(name)
     z = _spg_from_golden(sp, g)
     za = z.aligned()
@@ -205,7 +205,7 @@ def test_aligned_store_matches_reference_golden(sp, name):
 
 def test_aligned_hgather_matches_reference_golden(sp):
     """train.hgather's own output (tests/golden/hjoin_int.npz) from the aligned store, eagerly and as CapturedJoin(triplets=True)"""
-    from test_gpu_parity import _load, _spg_from_golden
+    from gpu_helpers import _load, _spg_from_golden
     g = _load("hjoin_int.npz")
     za = _spg_from_golden(sp, g).aligned()
     hedge = np.asarray(g["hedge"])
@@ -268,7 +268,7 @@ def test_rows_without_a_root_stay_empty_when_the_general_kernel_takes_a_work_lis
     """subgacc_walk_spg_list hands the launch to the general kernel when the fused-row kernel declines it (here: a
     truncating bucket); that kernel reads no list and walks all n rows -- a row whose root is SUBGACC_NO_ROOT (what the list had left
     out) must stay an EMPTY row there too, not be reported as a root outside the graph."""
-    from test_gpu_parity import sym_graph
+    from gpu_helpers import sym_graph
     N, M, m, bucket = 20000, 200, 2, 50
     ptr_, idx = sym_graph(N, 60000, seed=6, hubs=2)
     csr = sp.DeviceCSR(ptr_, idx)

@@ -19,7 +19,7 @@ import torch.distributed as dist  # noqa: E402
 
 def problem():
     """the graph, roots and pairs of the test: rows shorter and longer than M, isolated nodes, repeated roots"""
-    from test_gpu_parity import sym_graph
+    from gpu_helpers import sym_graph
     indptr, indices = sym_graph(3000, 9000, seed=11, hubs=3)
     rng = np.random.default_rng(4)
     roots = rng.integers(0, 3000, 2001).astype(np.int32)

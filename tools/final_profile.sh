@@ -7,6 +7,7 @@
 set -x
 TAG=${1:-rXX}; shift
 WLS=${@:-cit2 cit2m4 collab ppa twitter cit2loc cit2ppr}
+[ "$WLS" = none ] && WLS=""
 R=$GRAFT_REPO_ROOT
 for W in $WLS; do
   cd /tmp && export TMPDIR=/tmp
@@ -24,6 +25,7 @@ for W in $WLS; do
   fi
   unset SUBGACC_PPR_EAGER
 done
+[ "${FP_EXTRAS:-1}" = 0 ] && exit 0      # (the evidence takes more than one 20-minute call: FP_EXTRAS=0 = the workloads' passes only)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_offline -- python3 $R/tools/offline_run.py cit2 4 > $R/gpurun_out/${TAG}_offline_cit2.log 2>&1
 cd $R
