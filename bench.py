@@ -61,7 +61,7 @@ WORKLOADS = {
     "cit2ppr": (None, 0, 1, "cit2-like PPR encoder: float64 SpG = topk_ppr_matrix(alpha=0.1, eps=1e-4, top-100, 'sym') + encoding 'PPR' "
                             "over all N=2,927,963 nodes (built on the GPU in set-up), SpJoin only (train.py:39-43)", 0.5),
 }
-# tools/line_probe.hip (profiles/r02_line_probe_pmc.csv) established that an L2 miss moves one whole 128-byte line whatever
+# line_probe.hip (tools/archive.tar.gz; profiles/r02_line_probe_pmc.csv) established that an L2 miss moves one whole 128-byte line whatever
 # the access width and that the chip sustains ~55 G random lines/s from tables up to 1 GiB (Infinity Cache or HBM alike),
 # ~48-50 G lines/s from 4-12 GiB.  This -- not bytes of useful data -- is what bounds a random walk.  The rate is measured
 # again in every run, on the table the walk kernel reads (the hop records, else the adjacency array), right after the timed
@@ -487,7 +487,28 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W, extr
         elapsed = world * B * K / median(region_values)
     call_ms, launches = timer.mean_ms("join")       # HIP events around a whole join call alone on the GPU: the size pass and the fill
     ms, _ = timer.mean_ms("sjoin_fill")             # the fill kernel alone (eager mode only: events do not time inside a replayed graph)
-    if ms is None:                                  # ... so a few eager joins after the timed region time it, for the record
+    from surel_plus_amd import _lib as lib_
+    xz_e, ind_e = sp.gather(edges[W], z, dev, ptr=True, encode=None, out=torch.empty(2 * B * z.max_len * 2, dtype=torch.float32, device=dev), lazy=True)
+    own_e = edges[W].contiguous().view(-1)
+
+    def fill_alone():       # the fill kernel of one batch, sizes known: one launch
+        lib_.join_fill(lib_.JOIN_ROWS, lib_.JOIN_F64, n_rows=z.n_rows, payload=z.data, own=own_e, S=own_e.numel(), seg=ind_e, pair_block=B,
+                       out_xz=xz_e, flags=ind_e.join_flags,
+                       **(dict(row_stride=z.pitch, ids=z.ids) if layout == "aligned" else dict(row_off=z.indptr, ids=z.indices, max_len=z.max_len)))
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if ms is None and layout == "aligned":
+        # a lazy gather from a headed store is ONE library call (size pass + fill, what join_graph_ms times): the fill alone is
+        # launched here, on the segments of one of the timed batches, one launch per event pair
+        one = []
+        for _ in range(6):
+            ev0.record()
+            fill_alone()
+            ev1.record()
+            torch.cuda.synchronize()
+            one.append(ev0.elapsed_time(ev1))
+        fill_ms = sum(one[1:]) / len(one[1:])
+        ms, ms_source = fill_ms, "HIP events around single launches of the fill kernel on one batch of the timed region, sizes known (after the region)"
+    elif ms is None:                                # ... so a few eager joins after the timed region time it, for the record
         ebuf = torch.empty(2 * B * z.max_len * 2, dtype=torch.float32, device=dev)
         timer.pairs.pop("sjoin_fill", None)
         sampler_mod.KERNEL_TIMER = timer
@@ -504,17 +525,11 @@ def bench_ppr(args, sp, sampler_mod, dev, rank, world, dist, desc, B, K, W, extr
         fill_ms, ms_source = ms, "HIP events around the fill kernel in the timed region"
     # an event pair around ONE launch of a ~60 us kernel reads 4-6 us more than the kernel runs (rocprofv3's kernel trace of the
     # same launches is the arbiter: profiles/rNN_cit2ppr_kernel_stats.csv): the same fill ten times back to back between one pair
-    from surel_plus_amd import _lib as lib_
-    xz_e, ind_e = sp.gather(edges[W], z, dev, ptr=True, encode=None, out=torch.empty(2 * B * z.max_len * 2, dtype=torch.float32, device=dev), lazy=True)
-    own_e = edges[W].contiguous().view(-1)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     b2b = []
     for _ in range(3):
         ev0.record()
         for _ in range(10):
-            lib_.join_fill(lib_.JOIN_ROWS, lib_.JOIN_F64, n_rows=z.n_rows, payload=z.data, own=own_e, S=own_e.numel(), seg=ind_e, pair_block=B,
-                           out_xz=xz_e, flags=ind_e.join_flags,
-                           **(dict(row_stride=z.pitch, ids=z.ids) if layout == "aligned" else dict(row_off=z.indptr, ids=z.indices, max_len=z.max_len)))
+            fill_alone()
         ev1.record()
         torch.cuda.synchronize()
         b2b.append(ev0.elapsed_time(ev1) / 10)
