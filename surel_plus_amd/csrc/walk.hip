@@ -813,6 +813,8 @@ static int launch_walk(const subgacc_walk_cfg *cfg, const void *indptr, const in
     a.step_major = cfg->order == SUBGACC_ORDER_STEP_MAJOR ? 1 : 0;
     a.cap_root = cfg->cap_root_degree ? 1 : 0;
     a.set_slot = set_slot;
+    // key rows leave four members per store where every row begins on a 16-byte boundary (walk_rows_kernel)
+    a.wide_rows = (a.pitch % 4 == 0 && (((uintptr_t)set_ids | (uintptr_t)set_slot) & 15u) == 0) ? 1 : 0;
     a.table = (spg && uniq_table) ? uniq_view(uniq_table, uniq_capacity) : UniqTable{nullptr, nullptr, nullptr, 0};
     a.keyrows = (spg && !uniq_table) ? 1 : 0;
     a.root_base = root_base;

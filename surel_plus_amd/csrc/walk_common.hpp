@@ -113,6 +113,7 @@ struct WalkArgs {
     int32_t *flags;
     int32_t M, m, stride, shift;
     int32_t pitch;       // words between two roots' rows in set_ids / set_slot / set_keys (>= stride; subgacc_walk_cfg::row_pitch)
+    int32_t wide_rows;   // every row begins on a 16-byte boundary in set_ids and set_slot (pitch % 4 == 0, aligned bases): 16-byte row stores
     int32_t T, tshift;   // table size (pow2) and 32-log2(T)
     int32_t nwords;      // bitmap words over q in [0, M*m]
     uint32_t seed;

@@ -42,6 +42,12 @@ namespace subgacc {
 #ifndef SG_ROWS_SGPR
 #define SG_ROWS_SGPR 102
 #endif
+#ifndef SG_SORT_AGAIN_ABOVE   // the two-wave key rows' level 3: from this many members in one level-2 part on
+#define SG_SORT_AGAIN_ABOVE 16
+#endif
+#ifndef SG_SORT_RANK_HEAD   // members of a (sub-)bucket compared without a loop when the sorted position is counted (two-wave key rows)
+#define SG_SORT_RANK_HEAD 4
+#endif
 #ifndef SG_SORT_LEVELS      // finer levels of the key rows' sort behind level 1 (dev builds: 0 / 1 for timing; the result is sorted either way)
 #define SG_SORT_LEVELS 2
 #endif
@@ -534,7 +540,8 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (KR ? 5 : (NT == 128 ? 7 :
         //     (umulhi) -- a monotone map of the ids onto [0, ns) that follows the set's own distribution (a piecewise-linear
         //     equalisation); 16-bit counters, two per word, scanned in place.  A graph with id locality puts most of a set into ONE
         //     community of consecutive ids = one bucket (32,768 ids wide on a 2.9 M-node graph).
-        //   Level 3, where a sub-bucket is STILL crowded: level 2 cuts a bucket that holds a community of 2,048 ids into sub-buckets
+        //   Level 3, where a sub-bucket is STILL crowded (> SG_SORT_AGAIN_ABOVE members; 16 measured against 12 / 24 / never:
+        //     profiles/r68_again_ab.log): level 2 cuts a bucket that holds a community of 2,048 ids into sub-buckets
         //     ~130 ids wide, ~16 members each, and the ranking by counting below was an LDS latency loop of up to 30 trips (cit2loc:
         //     0.2 of the kernel's 0.68 ms -- profiles/r40_loc_phase_ms.log).  The same cut once more, of every level-2 sub-bucket by
         //     ITS count, with the position inside the sub-bucket's id window as a float: any monotone map of the ids of one sub-bucket
@@ -780,7 +787,11 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (KR ? 5 : (NT == 128 ? 7 :
             __syncthreads();
             SG_HOOK_RSTAMP(13);
             const uint16_t *off2 = (const uint16_t *)cnt2;
-            if (PACK) {
+            // (a crowded set's first trip through the level loop works the level-1 bounds out for itself and overwrites the state:
+            //  the pass below is for the sets that skip the loop -- maxc is workgroup-uniform)
+            const bool finer = SG_SORT_LEVELS > 0 && maxc > kFineAbove;
+            if (finer) {
+            } else if (PACK) {
                 uint32_t ta[EPL], tb[EPL];         // what the first pass asked the LDS for, until the second packs it
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) {
@@ -805,7 +816,7 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (KR ? 5 : (NT == 128 ? 7 :
             // 2,048 ids in a window of 32,768 cut into 3 x 250 parts: ~5 members each instead of ~16)
             const uint32_t FINE = (uint32_t)(2 * CW * NT - 1) / (uint32_t)(ns + 1);      // >= 1: ns <= 2 * CW * NT - 2 (checked at launch)
 #pragma unroll 1
-            for (int lvl = 0; lvl < SG_SORT_LEVELS && maxc > kFineAbove; ++lvl) {
+            for (int lvl = 0; lvl < SG_SORT_LEVELS && maxc > (lvl ? SG_SORT_AGAIN_ABOVE : kFineAbove); ++lvl) {
                 if (lvl || !SG_SORT_ZERO_UPFRONT) {
                     if (lvl) __syncthreads();        // every lane has read its offsets of the level before
                     ((uint4 *)cnt2)[tid] = make_uint4(0u, 0u, 0u, 0u);
@@ -877,9 +888,16 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (KR ? 5 : (NT == 128 ? 7 :
                 if (e * NT >= ns) break;
                 if (e * NT + tid < ns) {
                     const uint32_t me = (uint32_t)(el[e] >> 32);
-                    int rank = 0;       // ids are distinct within a set: the high word of A decides
+                    // ids are distinct within a set: the high word of A decides.  The first SG_SORT_RANK_HEAD members of the (sub-)bucket without a
+                    // loop -- after the finer cuts few hold more, and a loop runs as long as the longest of a wave's 64 lanes needs, with
+                    // a branch and an exec-mask round trip per trip: 60 vector instructions a wave on the graph with id locality
+                    // (words behind the bucket's end are read and masked; behind the set's end they are still inside this workgroup's LDS)
                     const int lo = (int)LO(e), hi = (int)HI(e);
-                    int t2 = lo;
+                    const uint32_t cnt = (uint32_t)(hi - lo);        // >= 1: the member itself
+                    int rank = 0;
+#pragma unroll
+                    for (int i = 0; i < SG_SORT_RANK_HEAD; ++i) rank += (int)((Ahi[2 * (lo + i) + 1] < me) & (i == 0 || cnt > (uint32_t)i));
+                    int t2 = lo + SG_SORT_RANK_HEAD;
 #if SG_SORT_RANK_UNROLL
 #pragma unroll 1         // (four members per trip: the loop is LDS latency, not issue)
                     for (; t2 + 3 < hi; t2 += 4) {
@@ -901,7 +919,20 @@ __global__ __launch_bounds__(NT, K32 ? (KR ? 6 : 5) : (KR ? 5 : (NT == 128 ? 7 :
             if (e * NT + tid < ns) A[st[e]] = el[e];
         }
         __syncthreads();
-        for (int x = tid; x < ns; x += NT) {
+        int xs = tid;
+        if (!KR64 && a.wide_rows) {      // rows begin on 16-byte boundaries (a pitch of whole lines): four members per lane and store
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            const int n4 = ns >> 2;
+            for (int q = tid; q < n4; q += NT) {
+                const ulonglong2 v0 = ((const ulonglong2 *)A)[2 * q], v1 = ((const ulonglong2 *)A)[2 * q + 1];
+                const v4i ids4 = {(int32_t)(v0.x >> 32), (int32_t)(v0.y >> 32), (int32_t)(v1.x >> 32), (int32_t)(v1.y >> 32)};
+                const v4i sl4 = {(int32_t)(uint32_t)v0.x, (int32_t)(uint32_t)v0.y, (int32_t)(uint32_t)v1.x, (int32_t)(uint32_t)v1.y};
+                SG_ROW_STORE((v4i *)&a.set_ids[obase + 4 * q], ids4);
+                SG_ROW_STORE((v4i *)&a.set_slot[obase + 4 * q], sl4);
+            }
+            xs = (n4 << 2) + tid;       // the last ns % 4 members, one by one
+        }
+        for (int x = xs; x < ns; x += NT) {
             const unsigned long long v = A[x];
             SG_ROW_STORE(&a.set_ids[obase + x], (int32_t)(v >> 32));
             if (KR64) SG_ROW_STORE(&a.set_keys[obase + x], (uint64_t)KK[(uint32_t)v]);
