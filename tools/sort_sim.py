@@ -26,7 +26,8 @@ ids = z.indices.cpu().numpy()
 rt = roots.cpu().numpy()
 NT, FINE_TOTAL, ABOVE = 128, 1023, 12
 stat = {"sets": 0, "finer_now": 0, "again_now": 0, "finer_window": 0, "members": 0}
-maxpart_now, maxpart_win = [], []
+maxpart_now, maxpart_win, inblock = [], [], []
+FRAC = float(os.environ.get('SIM_FRAC', '0.7'))
 for r in range(R):
     s = ids[indptr[r]:indptr[r + 1]].astype(np.int64)
     ns = len(s)
@@ -52,14 +53,15 @@ for r in range(R):
         maxpart_now.append(c2.max())
         if c2.max() > 16:
             stat["again_now"] += 1
-    # a level 1 over a window around the root: the smallest radius 2^j that holds >= 70 % of the set, 96 fine buckets over
+    # a level 1 over a window around the root: the smallest radius 2^j that holds >= SIM_FRAC of the set, 96 fine buckets over
     # [root - 2^j, root + 2^j), 16 coarse buckets on either side
     d = np.abs(s - int(rt[r]))
     j = None
     for jj in range(8, 18):
-        if (d < (1 << jj)).sum() >= 0.7 * ns:
+        if (d < (1 << jj)).sum() >= FRAC * ns:
             j = jj
             break
+    inblock.append((d < 2048).sum() / ns)
     if j is None or (2 << j) >= rng_:
         cw = c1
     else:
@@ -75,7 +77,7 @@ for r in range(R):
     maxpart_win.append(cw.max())
     if cw.max() > ABOVE:
         stat["finer_window"] += 1
-print(wl, stat, "mean set", round(stat["members"] / max(1, stat["sets"]), 1))
+print(wl, "window threshold", FRAC, stat, "mean set", round(stat["members"] / max(1, stat["sets"]), 1), "share within 2,048 ids of the root: mean %.2f p10 %.2f p90 %.2f" % (np.mean(inblock), *np.percentile(inblock, [10, 90])))
 if maxpart_now:
     print("  level-2 parts now: max per set  mean %.1f  p50 %d  p90 %d  p99 %d" % (np.mean(maxpart_now), *np.percentile(maxpart_now, [50, 90, 99])))
 print("  windowed level 1: max bucket per set  mean %.1f  p50 %d  p90 %d  p99 %d; sets above 12: %d, above 16: %d" % (
