@@ -338,7 +338,9 @@ typedef struct subgacc_join_desc {
 int subgacc_sjoin_fill_v2(const subgacc_join_desc *d, void *stream);
 
 
-/* Packed rows -> headed rows (ABI 7): the resident store of a serving loop laid out on whole lines.  row_off [n+1], ids, payload
+/* Packed rows -> headed rows (ABI 7): the resident store of a serving loop laid out on whole lines -- the rows random_walks.py:79-81
+ * builds as a SciPy CSR and train.py:17-18 / :39-43 slice one by one (x[edge[0]]), in the layout the pair kernels read with one
+ * dependent trip less.  row_off [n+1], ids, payload
  * (payload_bytes = 4: SFptr+1 / 32-bit keys, 8: PPR scores / 64-bit keys) as SpG holds them; out_ids [n*row_stride] int32 and
  * out_payload [n*row_stride] of the same element size, row_stride >= (longest row) + 1 (a longer row is cut and flags[3] |= 1), a
  * multiple of 32 for rows on whole 128-byte lines.  Slots behind a row's members are left as they are. */
