@@ -283,3 +283,26 @@ def test_rows_without_a_root_stay_empty_when_the_general_kernel_takes_a_work_lis
     keep = np.flatnonzero(~holes)
     got_ptr = z.indptr.cpu().numpy()
     assert np.array_equal(np.diff(got_ptr)[keep], np.diff(oi)) and np.array_equal(z.indices[: z.nnz].cpu().numpy(), ox)
+
+
+@pytest.mark.parametrize("M,hops", [(200, 3), (37, 2), (50, 4), (203, 4)])
+def test_rows_written_four_members_per_store_equal_rows_written_one_by_one(sp, M, hops):
+    """walk_rows_kernel writes a key row four members per 16-byte store where every row begins on a 16-byte boundary (StepBuffers: a
+    pitch of whole 128-byte lines) and one member per store otherwise (align_rows=False: rows M*m+1 words apart, odd) -- same rows,
+    same join, for set sizes of every remainder modulo 4; 32-bit keys and (M = 203, 4 hops) 64-bit keys, which stay on the narrow path."""
+    from gpu_helpers import sym_graph
+    ptr_, idx = sym_graph(30_000, 150_000, seed=41, hubs=3)
+    csr = sp.DeviceCSR(ptr_, idx)
+    B = 3000
+    rng = np.random.default_rng(11)
+    edge = torch.from_numpy(rng.integers(0, 30_000, (2, B)).astype(np.int64)).cuda()
+    out = []
+    for aligned in (True, False):
+        bufs = sp.StepBuffers(csr, B, num_walks=M, num_steps=hops, rng="philox", align_rows=aligned)
+        assert (bufs.stride % 4 == 0) == aligned
+        xz, ind, sets = sp.sample_and_gather(csr, edge, num_walks=M, num_steps=hops, seed=5, rng="philox", buffers=bufs)
+        sets.resolve()
+        n = sets.nsize.cpu().numpy()
+        assert len({int(v) % 4 for v in n}) == 4           # every remainder of a row's length occurs
+        out.append((xz[: int(ind[-1])].cpu().numpy().copy(), ind.cpu().numpy().copy(), n.copy()))
+    assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][0], out[1][0])
