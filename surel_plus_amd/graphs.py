@@ -78,6 +78,14 @@ def community_graph(N, avg_deg, seed=4, exponent=2.5, block=2048, p_in=0.75, dev
     return DeviceCSR(indptr.to(torch.int32 if key.numel() < 2**31 - 1 else torch.int64), col, torch.device(device))
 
 
+def _cumsum_f64_in_order(w):
+    """cumsum of 4*10^7 doubles with ONE summation order.  The device's scan (decoupled look-back) combines its partial sums in an
+    order that varies from run to run; in floating point that moves a few last bits of the CDF, and a handful of the billion
+    edges drawn through it land on a neighbouring node: two processes built slightly different twitter-like graphs (found in round 6
+    when two builds of the library disagreed on a digest that was the GRAPH's).  Sequentially on the host: 0.2 s."""
+    return torch.cumsum(w.cpu(), 0).to(w.device)
+
+
 def directed_powerlaw_graph(N, avg_deg, seed=3, exponent=2.2, device="cuda", chunk=1 << 28, max_weight_frac=0.0005):
     """Billion-edge stand-in for twitter-follower (41.65 M nodes, ~2.9 B adjacency entries after symmetrisation):
     every node gets max(1, d_i) out-neighbours drawn from a heavy-tailed popularity distribution, generated in
@@ -93,7 +101,7 @@ def directed_powerlaw_graph(N, avg_deg, seed=3, exponent=2.2, device="cuda", chu
     indptr = torch.zeros(N + 1, dtype=torch.int64, device=device)
     indptr[1:] = torch.cumsum(deg, 0)
     nnz = int(indptr[-1].item())
-    cdf = torch.cumsum(w, 0)
+    cdf = _cumsum_f64_in_order(w)
     cdf = (cdf / cdf[-1]).to(torch.float32)
     del ranks, w, deg
     indices = torch.empty(nnz, dtype=torch.int32, device=device)
@@ -124,7 +132,7 @@ def symmetric_powerlaw_graph_big(N, avg_deg, seed=3, exponent=2.2, device="cuda"
     optr = torch.zeros(N + 1, dtype=torch.int64, device=device)
     optr[1:] = torch.cumsum(odeg, 0)
     E = int(optr[-1].item())
-    cdf = torch.cumsum(w, 0)
+    cdf = _cumsum_f64_in_order(w)
     cdf = (cdf / cdf[-1]).to(torch.float32)
     del ranks, w, odeg
     dst = torch.empty(E, dtype=torch.int32, device=device)
